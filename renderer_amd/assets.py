@@ -1,0 +1,49 @@
+"""Mesh assets shipped with the repo.
+
+The three meshes BASELINE.json's configs name (chessboard.tri, statue.ply,
+dragon_vis.ply -- the reference's own 3D-Objects/ data files) are kept
+xz-compressed under ``assets/`` so that they travel to the GPU box, and are
+unpacked on first use into a scratch directory (the loaders, like the
+reference's, read plain files; a ``<mesh>.bvh`` cache may be written beside
+them, Raytracer.cc:747-753).
+"""
+from __future__ import annotations
+
+import hashlib
+import lzma
+import os
+import tempfile
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ASSET_DIR = os.path.join(_ROOT, "assets")
+
+# sha256 of the unpacked files (== the reference's 3D-Objects/ files)
+SHA256 = {
+    "chessboard.tri": "83fc4d47e47ab93526d671eed00a4f7e6115f423a450c98b6e420205a09c5386",
+    "statue.ply": "ca4906aeaef5646f69612a41fbab21922cb7512162f571ef65e220dd27a3af9b",
+    "dragon_vis.ply": "4d70bb53c2fe06df59d8d8c8087196446919ccc3324c9f286bfcdf0f181027fb",
+}
+
+
+def cache_dir() -> str:
+    d = os.environ.get("RENDERER_AMD_CACHE") or os.path.join(
+        tempfile.gettempdir(), "renderer_amd_cache_%d" % os.getuid())
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def mesh_path(name: str) -> str:
+    """Return the path of the unpacked mesh ``name`` (unpacking it if needed)."""
+    if name not in SHA256:
+        raise KeyError("unknown mesh asset %r (have: %s)" % (name, ", ".join(SHA256)))
+    dst = os.path.join(cache_dir(), name)
+    if not os.path.exists(dst):
+        with lzma.open(os.path.join(ASSET_DIR, name + ".xz"), "rb") as f:
+            data = f.read()
+        if hashlib.sha256(data).hexdigest() != SHA256[name]:
+            raise RuntimeError("asset %s is corrupt" % name)
+        tmp = dst + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(data)
+        os.replace(tmp, dst)
+    return dst

@@ -1,0 +1,38 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle_ctypes as O
+    O.build()
+    return O
+
+
+_SCENES = {}
+
+
+@pytest.fixture(scope="session")
+def oracle_scene(oracle):
+    """Oracle scenes (with BVH) cached per session; BVH cached on disk in the scratch dir."""
+    from renderer_amd import assets
+
+    def get(name, bvh=False):
+        key = name
+        if key not in _SCENES:
+            _SCENES[key] = oracle.Scene(assets.mesh_path(name))
+        s = _SCENES[key]
+        if bvh and s.num_nodes == 0:
+            s.bvh_ensure(os.path.join(assets.cache_dir(), name + ".oracle.bvh"))
+        return s
+    return get

@@ -1,0 +1,73 @@
+"""Pin the CPU oracle against outputs of the REAL reference.
+
+The reference cannot be rebuilt here (it needs SDL 1.2 headers the image lacks and
+stand-ins are not allowed), so the pins are the frame hashes, counters, camera
+probes and .bvh statistics the survey recorded from the strict single-thread
+reference build.  If these pass, the restatement is bit-identical to the reference
+on every BASELINE.json config's first benchmark frame.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+PINS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_pins.json")))
+
+
+def test_benchmark_cameras(oracle):
+    c0, lights, n = oracle.benchmark_frame(0)
+    assert n == 1
+    p = PINS["cameras"]
+    # the survey printed 9 significant digits: enough to identify a float32 uniquely
+    assert np.array_equal(np.array(c0.eye[:], np.float32), np.array(p["f0"]["eye"], np.float32))
+    assert np.array_equal(np.array(c0.mv[:], np.float32), np.array(p["f0"]["mv"], np.float32))
+    assert np.array_equal(np.array(lights[0].pos[:], np.float32), np.array(p["light"], np.float32))
+    for k in (1, 2):
+        ck, _, _ = oracle.benchmark_frame(k)
+        assert np.array_equal(np.array(ck.eye[:], np.float32), np.array(p["f%d" % k]["eye"], np.float32))
+
+
+@pytest.mark.parametrize("mesh", list(PINS["mesh_counts"]))
+def test_mesh_counts(oracle_scene, mesh):
+    s = oracle_scene(mesh)
+    assert [s.nv, s.nt] == PINS["mesh_counts"][mesh]
+
+
+@pytest.mark.parametrize("mesh", list(PINS["bvh"]))
+def test_bvh_pins(oracle, oracle_scene, mesh, tmp_path):
+    s = oracle_scene(mesh)
+    n = s.bvh_build()          # always rebuild here: this is the SAH-builder pin
+    pin = PINS["bvh"][mesh]
+    assert n == pin["nodes"]
+    f = str(tmp_path / "x.bvh")
+    s.bvh_save(f)
+    data = open(f, "rb").read()
+    assert len(data) == 8 + 32 * n + 4 * s.nt
+    h = hashlib.sha256(data).hexdigest()
+    assert h.startswith(pin["sha_prefix"]) and h.endswith(pin["sha_suffix"])
+    nodes, tri_idx = s.bvh()
+    inner = (nodes[:, 6] & 0x80000000) == 0
+    # idxLeft == own index + 1 for every inner node
+    assert np.array_equal(nodes[inner, 6], np.nonzero(inner)[0].astype(np.uint32) + 1)
+    assert sorted(tri_idx.tolist()) == list(range(s.nt))
+
+
+@pytest.mark.parametrize("pin", PINS["frames"], ids=[p["id"] for p in PINS["frames"]])
+def test_frame_pins(oracle, oracle_scene, pin):
+    cam, lights, n = oracle.benchmark_frame(0)
+    s = oracle_scene(pin["mesh"], bvh=pin["mode"] >= 9)
+    o = oracle.default_opts(pin["w"], pin["h"], max_ray_depth=pin["depth"], threads=os.cpu_count() or 1)
+    maps = [s.shadowmap(lights[0])] if pin["mode"] in (7, 8) else None
+    img, _, st = s.render(pin["mode"], cam, lights, n, o, shadow_maps=maps)
+    rgb = oracle.rgb_bytes(img)
+    assert int((img != 0).sum()) == pin["nonblack"]
+    assert int(np.frombuffer(rgb, np.uint8).sum(dtype=np.int64)) == pin["sum"]
+    assert hashlib.sha256(rgb).hexdigest() == pin["sha256"]
+    ctr = PINS["counters"].get(pin["id"])
+    if ctr:
+        got = st.as_dict()
+        assert {k: got[k] for k in ctr} == ctr
+    if pin["id"] == "cfg2":
+        assert st.tris_drawn == PINS["counters"]["raster_cfg2"]["tris_drawn"]
