@@ -1,0 +1,155 @@
+/*
+ * mi355_render.h -- C ABI of the MI355X-native hot path of ttsiodras/renderer.
+ *
+ * The reference has no FFI; its seam is the Scene::render* family that
+ * renderer.cc:522-583 calls once per frame.  This header is what a binding for
+ * that seam binds: plain pointers and sizes, C linkage, no exceptions, no C++ or
+ * torch types.  Each entry point cites the reference interface it replaces
+ * (file:line relative to the reference tree).
+ *
+ * Conventions
+ *   - int return: 0 = OK, negative = error; text via mi355_last_error().
+ *   - One host thread per context.  Calls are synchronous unless they take a
+ *     stream: the frame is complete when mi355_render() returns, exactly like
+ *     Scene::render*() (Scene.h:76-85).
+ *   - The caller owns every host buffer; the library owns device memory until
+ *     mi355_scene_destroy().
+ *   - Colours are XRGB8888 words r<<16|g<<8|b, i.e. SDL_MapRGB() on the 32-bpp
+ *     surface the reference asks for (Screen.h:76, Screen.cc:40-43).
+ */
+#ifndef MI355_RENDER_H
+#define MI355_RENDER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_ABI_VERSION 1
+
+/* RenderMode, renderer.cc:68-79 */
+enum {
+    MI355_MODE_POINTS = 1,                /* Scene::renderPoints(asTriangles=false)  Rasterizers.cc:56-76  */
+    MI355_MODE_POINTS_FROM_TRIANGLES = 2, /* Scene::renderPoints(asTriangles=true)   Rasterizers.cc:77-109 */
+    MI355_MODE_LINES = 3,                 /* Scene::renderWireframe -- NOT on the hot path, returns error  */
+    MI355_MODE_AMBIENT = 4,               /* Scene::renderAmbient               Rasterizers.cc:360-363 */
+    MI355_MODE_GOURAUD = 5,               /* Scene::renderGouraud               Rasterizers.cc:365-368 */
+    MI355_MODE_PHONG = 6,                 /* Scene::renderPhong                 Rasterizers.cc:370-373 */
+    MI355_MODE_PHONG_SHADOWMAPS = 7,      /* Scene::renderPhongAndShadowed      Rasterizers.cc:375-378 */
+    MI355_MODE_PHONG_SOFTSHADOWMAPS = 8,  /* Scene::renderPhongAndSoftShadowed  Rasterizers.cc:380-383 */
+    MI355_MODE_RAYTRACE = 9,              /* Scene::renderRaytracer(antiAlias=false) Raytracer.cc:791-868 */
+    MI355_MODE_RAYTRACE_ANTIALIAS = 10    /* Scene::renderRaytracer(antiAlias=true)                      */
+};
+
+#define MI355_MAX_LIGHTS 4
+
+typedef struct mi355_ctx mi355_ctx;
+
+/* Camera (Camera.h:26-58): position + the world->camera rows Camera::UpdateMV builds (Camera.cc:24-42) */
+typedef struct {
+    float eye[3];
+    float mv[9]; /* _mv._row1 (up), _row2 (right), _row3 (forward) */
+} mi355_camera;
+
+/* Light (Light.h:32-66): world position + the per-frame members renderer.cc:498-507 refreshes */
+typedef struct {
+    float pos[3];
+    float in_camera_space[3]; /* Light::_inCameraSpace      (Light.cc:162-171) */
+    float camera_to_light[9]; /* Light::_cameraToLightSpace (Light.cc:194-216) */
+    float world_to_light[9];  /* Light::_worldToLightSpace  (Light.cc:173-192) */
+} mi355_light;
+
+/* What the reference fixes at compile time (Defines.h:23-38, Raytracer.cc:52-85, Rasterizers.cc:39),
+ * as run-time fields with the reference's defaults (mi355_default_opts). */
+typedef struct {
+    int32_t width, height;   /* WIDTH, HEIGHT */
+    int32_t screen_dist;     /* SCREEN_DIST = 2*HEIGHT */
+    int32_t max_ray_depth;   /* MAX_RAY_DEPTH = 3 (1..4) */
+    int32_t use_shadows;     /* USE_SHADOWS */
+    int32_t use_reflections; /* REFLECTIONS */
+    int32_t shadowmap_size;  /* SHADOWMAPSIZE = 1024 */
+    float reflect_rate;      /* REFLECTIONS_RATE 0.375 */
+    float nudge;             /* NUDGE_FACTOR 1e-5f */
+    float ambient, diffuse, specular; /* AMBIENT/DIFFUSE/SPECULAR = 96/128/192 */
+    float clip_z;            /* ClipPlaneDistance 0.2f */
+    /* Screen-band sharding for multi-GPU frames (no reference counterpart): render only rows y
+     * with (y / band_rows) % band_count == band_index.  band_count <= 1 renders every row.
+     * With compact_rows != 0 the selected rows are written densely (row r of the output is the
+     * r-th selected row), which is the layout the RCCL gather moves. */
+    int32_t band_rows, band_index, band_count, compact_rows;
+    int32_t collect_stats;   /* fill the traversal counters of mi355_stats (slower kernel variant) */
+    int32_t variant;         /* kernel variant selector for tuning; 0 = default */
+} mi355_opts;
+
+/* Counters.  Ray counts are always filled for raytrace modes; the rest only
+ * when opts.collect_stats != 0. */
+typedef struct {
+    uint64_t normal_rays, shadow_rays;
+    uint64_t node_pops, inner_box_hits, tri_tests, plane_pass, shaded_hits;
+    uint64_t tris_drawn, spans, ztests, plots;
+    float kernel_ms;         /* hipEvent time of the frame's kernels on the launch stream */
+    float reserved;
+} mi355_stats;
+
+/* Scene data, one flat array per attribute (struct-of-arrays); this is the content of
+ * Scene::_vertices / Scene::_triangles (Scene.h:35-36, Base3d.h:27-66) after Scene::load. */
+typedef struct {
+    uint32_t n_vertices, n_triangles;
+    const float *vertex_pos;       /* [3V]  Vertex::_x,_y,_z                          */
+    const float *vertex_normal;    /* [3V]  Vertex::_normal                           */
+    const uint32_t *vertex_ao;     /* [V]   Vertex::_ambientOcclusionCoeff            */
+    const int32_t *tri_index;      /* [3T]  _vertexA/B/C as indices into the vertices */
+    const float *tri_center;       /* [3T]  Triangle::_center                         */
+    const float *tri_normal;       /* [3T]  Triangle::_normal                         */
+    const float *tri_colorf;       /* [3T]  Triangle::_colorf as r,g,b                */
+    const uint32_t *tri_color32;   /* [T]   Triangle::_color                          */
+    const uint8_t *tri_two_sided;  /* [T]   Triangle::_twoSided                       */
+    const float *tri_d;            /* [4T]  _d,_d1,_d2,_d3                            */
+    const float *tri_e;            /* [9T]  _e1,_e2,_e3                               */
+} mi355_scene_desc;
+
+/* Library / device bring-up.  Fails (negative) when no HIP device is usable: there is no CPU path. */
+int mi355_abi_version(void);
+int mi355_init(int n_devices_requested, int *n_devices_out);
+const char *mi355_last_error(void);
+void mi355_default_opts(mi355_opts *o, int width, int height);
+
+/* Upload a loaded scene (replaces handing `Scene&` to render*, Scene.h:32-86). */
+mi355_ctx *mi355_scene_create(const mi355_scene_desc *desc, int device);
+void mi355_scene_destroy(mi355_ctx *);
+
+/* Hand over the flat BVH in the reference's own AoS layout -- CacheFriendlyBVHNode[n_nodes]
+ * (BVH.h:52-65, 32 B each) + triIndexList (Scene.h:44-47), i.e. the content of a `.bvh` cache file
+ * (Raytracer.cc:747-753).  Replaces Scene::UpdateBoundingVolumeHierarchy's result (Raytracer.cc:720-789). */
+int mi355_scene_set_bvh(mi355_ctx *, const void *nodes32B, uint32_t n_nodes, const int32_t *tri_idx,
+                        uint32_t n_idx);
+
+/* Light::RenderSceneIntoShadowBuffer (Light.h:61, Light.cc:218-244) for light slot `slot`;
+ * out_map (optional) receives the size*size floats of Light::_shadowBuffer. */
+int mi355_shadowmap_render(mi355_ctx *, int slot, const mi355_light *light, int size, float *out_map);
+/* Upload an externally computed Light::_shadowBuffer instead. */
+int mi355_shadowmap_set(mi355_ctx *, int slot, const float *map, int size);
+
+/* One frame = one Scene::render*(camera, canvas) call (renderer.cc:522-583).
+ * out_xrgb: host buffer, rows `pitch_bytes` apart (SDL_Surface::pixels / ::pitch, Screen.h:309-362).
+ * out_rgb_f32 (optional, raytrace modes): width*height*3 floats r,g,b BEFORE the (Uint8) truncation of
+ * Raytracer.cc:600-604 -- the buffer the 1e-4 float criterion is checked on. */
+int mi355_render(mi355_ctx *, int mode, const mi355_camera *, const mi355_light *lights, int n_lights,
+                 const mi355_opts *, uint32_t *out_xrgb, int pitch_bytes, float *out_rgb_f32,
+                 mi355_stats *stats);
+
+/* Same frame, but asynchronous and device-resident: d_out_xrgb / d_out_rgb_f32 are device pointers
+ * (e.g. a torch tensor's data_ptr()) and all work is enqueued on `hip_stream` (a hipStream_t; NULL =
+ * the default stream).  Nothing is copied to the host and the call does not synchronise; this is the
+ * entry the multi-GPU gather and the benchmark use.  Counters, if requested, are accumulated into
+ * device memory and fetched with mi355_fetch_stats() after the caller synchronises. */
+int mi355_render_device(mi355_ctx *, int mode, const mi355_camera *, const mi355_light *lights, int n_lights,
+                        const mi355_opts *, void *d_out_xrgb, int pitch_bytes, void *d_out_rgb_f32,
+                        void *hip_stream);
+int mi355_fetch_stats(mi355_ctx *, mi355_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_RENDER_H */

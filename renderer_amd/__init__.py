@@ -1,0 +1,326 @@
+"""renderer_amd -- MI355X-native hot path of ttsiodras/renderer.
+
+The product is native: HIP kernels + a C ABI (``include/mi355_render.h``,
+``lib/libmi355render.so``) and a C++ host layer with the reference's
+Scene/Camera/Light/Screen API (``csrc/host``, ``lib/libmi355host.so``).  This
+Python module is only the ctypes glue the tests, ``bench.py`` and the
+multi-GPU driver (``renderer_amd.multigpu``) use to call them; it contains no
+rendering code and no CPU fallback -- if the native libraries are missing or
+no GPU is present, rendering calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import assets  # noqa: F401
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_PKG)
+LIB_DIR = os.path.join(_PKG, "lib")
+RENDER_SO = os.path.join(LIB_DIR, "libmi355render.so")
+HOST_SO = os.path.join(LIB_DIR, "libmi355host.so")
+RENDER_CLI = os.path.join(LIB_DIR, "render_cli")
+HEADER = os.path.join(ROOT, "include", "mi355_render.h")
+
+MAX_LIGHTS = 4
+
+
+class Mi355Error(RuntimeError):
+    pass
+
+
+# ---------------------------------------------------------------- ABI structs (include/mi355_render.h)
+class Camera(C.Structure):
+    _fields_ = [("eye", C.c_float * 3), ("mv", C.c_float * 9)]
+
+
+class Light(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("in_camera_space", C.c_float * 3),
+                ("camera_to_light", C.c_float * 9), ("world_to_light", C.c_float * 9)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("screen_dist", C.c_int32),
+                ("max_ray_depth", C.c_int32), ("use_shadows", C.c_int32), ("use_reflections", C.c_int32),
+                ("shadowmap_size", C.c_int32), ("reflect_rate", C.c_float), ("nudge", C.c_float),
+                ("ambient", C.c_float), ("diffuse", C.c_float), ("specular", C.c_float),
+                ("clip_z", C.c_float), ("band_rows", C.c_int32), ("band_index", C.c_int32),
+                ("band_count", C.c_int32), ("compact_rows", C.c_int32), ("collect_stats", C.c_int32),
+                ("variant", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("normal_rays", "shadow_rays", "node_pops", "inner_box_hits", "tri_tests", "plane_pass",
+                 "shaded_hits", "tris_drawn", "spans", "ztests", "plots")] + \
+               [("kernel_ms", C.c_float), ("reserved", C.c_float)]
+
+    def as_dict(self):
+        return {n: (int(getattr(self, n)) if t is C.c_uint64 else float(getattr(self, n)))
+                for n, t in self._fields_}
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("n_vertices", C.c_uint32), ("n_triangles", C.c_uint32),
+                ("vertex_pos", C.POINTER(C.c_float)), ("vertex_normal", C.POINTER(C.c_float)),
+                ("vertex_ao", C.POINTER(C.c_uint32)), ("tri_index", C.POINTER(C.c_int32)),
+                ("tri_center", C.POINTER(C.c_float)), ("tri_normal", C.POINTER(C.c_float)),
+                ("tri_colorf", C.POINTER(C.c_float)), ("tri_color32", C.POINTER(C.c_uint32)),
+                ("tri_two_sided", C.POINTER(C.c_uint8)), ("tri_d", C.POINTER(C.c_float)),
+                ("tri_e", C.POINTER(C.c_float))]
+
+
+# ---------------------------------------------------------------- native libraries
+def build(force: bool = False) -> None:
+    """Compile the HIP C-ABI library for gfx950 and the C++ host layer (in-tree, under lib/)."""
+    args = ["-B"] if force else []
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_PKG, "csrc"), "-j4"] + args)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_PKG, "csrc", "host")] + args)
+
+
+_render = None
+_host = None
+
+
+def lib():
+    """libmi355render.so -- the C ABI.  Raises if it has not been built: there is no fallback."""
+    global _render
+    if _render is None:
+        if not os.path.exists(RENDER_SO):
+            raise Mi355Error("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(the HIP extension is required, there is no CPU path)" % RENDER_SO)
+        L = C.CDLL(RENDER_SO, mode=C.RTLD_GLOBAL)
+        L.mi355_abi_version.restype = C.c_int
+        L.mi355_init.argtypes = [C.c_int, C.POINTER(C.c_int)]
+        L.mi355_last_error.restype = C.c_char_p
+        L.mi355_default_opts.argtypes = [C.POINTER(Opts), C.c_int, C.c_int]
+        L.mi355_scene_create.restype = C.c_void_p
+        L.mi355_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int]
+        L.mi355_scene_destroy.argtypes = [C.c_void_p]
+        L.mi355_scene_set_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.mi355_shadowmap_render.argtypes = [C.c_void_p, C.c_int, C.POINTER(Light), C.c_int, C.c_void_p]
+        L.mi355_shadowmap_set.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.mi355_render.argtypes = [C.c_void_p, C.c_int, C.POINTER(Camera), C.POINTER(Light), C.c_int,
+                                   C.POINTER(Opts), C.c_void_p, C.c_int, C.c_void_p, C.POINTER(Stats)]
+        L.mi355_render_device.argtypes = [C.c_void_p, C.c_int, C.POINTER(Camera), C.POINTER(Light), C.c_int,
+                                          C.POINTER(Opts), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.mi355_fetch_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        _render = L
+    return _render
+
+
+def host():
+    """libmi355host.so -- the C++ Scene/Camera/Light layer (loaders, BVH builder, harness)."""
+    global _host
+    if _host is None:
+        lib()
+        if not os.path.exists(HOST_SO):
+            raise Mi355Error("%s is missing: run __graft_entry__.build()" % HOST_SO)
+        H = C.CDLL(HOST_SO)
+        H.mi355h_last_error.restype = C.c_char_p
+        H.mi355h_scene_load.restype = C.c_void_p
+        H.mi355h_scene_load.argtypes = [C.c_char_p]
+        H.mi355h_scene_free.argtypes = [C.c_void_p]
+        H.mi355h_scene_desc.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+        H.mi355h_set_device.argtypes = [C.c_void_p, C.c_int]
+        H.mi355h_bvh_create.argtypes = [C.c_void_p]
+        H.mi355h_bvh_update.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        H.mi355h_bvh_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        H.mi355h_opts.restype = C.POINTER(Opts)
+        H.mi355h_opts.argtypes = [C.c_void_p]
+        H.mi355h_context.restype = C.c_void_p
+        H.mi355h_context.argtypes = [C.c_void_p]
+        H.mi355h_camera_set.argtypes = [C.POINTER(Camera), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        H.mi355h_light_update.argtypes = [C.POINTER(Light), C.POINTER(Camera)]
+        H.mi355h_benchmark_frame.argtypes = [C.c_int, C.c_int, C.POINTER(Camera), C.POINTER(Light), C.POINTER(C.c_int)]
+        H.mi355h_render_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                          C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_void_p,
+                                          C.POINTER(Stats)]
+        _host = H
+    return _host
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise Mi355Error("%s failed (%d): %s" % (what, rc, lib().mi355_last_error().decode()))
+
+
+def default_opts(width: int, height: int, **kw) -> Opts:
+    o = Opts()
+    lib().mi355_default_opts(C.byref(o), width, height)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    return n.value if lib().mi355_init(0, C.byref(n)) == 0 else 0
+
+
+def benchmark_frame(k: int, second_light: bool = False):
+    """Camera and lights of frame k of the reference's `renderer -b` loop (host C++ harness)."""
+    cam = Camera()
+    lights = (Light * 2)()
+    n = C.c_int(0)
+    host().mi355h_benchmark_frame(k, int(second_light), C.byref(cam), lights, C.byref(n))
+    return cam, lights, n.value
+
+
+def camera(eye, lookat) -> Camera:
+    cam = Camera()
+    host().mi355h_camera_set(C.byref(cam), (C.c_float * 3)(*eye), (C.c_float * 3)(*lookat))
+    return cam
+
+
+def light(pos, cam: Camera) -> Light:
+    l = Light()
+    l.pos[:] = list(pos)
+    host().mi355h_light_update(C.byref(l), C.byref(cam))
+    return l
+
+
+def _np_view(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype)
+
+
+class Scene:
+    """A loaded mesh (C++ mi355::Scene) and, lazily, its device context."""
+
+    def __init__(self, path: str, device: int = 0):
+        self._h = host().mi355h_scene_load(path.encode())
+        if not self._h:
+            raise Mi355Error(host().mi355h_last_error().decode())
+        self.path = path
+        if device:
+            host().mi355h_set_device(self._h, device)
+        d = SceneDesc()
+        host().mi355h_scene_desc(self._h, C.byref(d))
+        self.desc = d
+        self.nv, self.nt = int(d.n_vertices), int(d.n_triangles)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            host().mi355h_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host data (views into the C++ Scene's arrays) ------------------------------------------
+    def arrays(self):
+        d, V, T = self.desc, self.nv, self.nt
+        return dict(
+            vertex_pos=_np_view(d.vertex_pos, 3 * V, np.float32).reshape(V, 3),
+            vertex_normal=_np_view(d.vertex_normal, 3 * V, np.float32).reshape(V, 3),
+            vertex_ao=_np_view(d.vertex_ao, V, np.uint32),
+            tri_index=_np_view(d.tri_index, 3 * T, np.int32).reshape(T, 3),
+            tri_center=_np_view(d.tri_center, 3 * T, np.float32).reshape(T, 3),
+            tri_normal=_np_view(d.tri_normal, 3 * T, np.float32).reshape(T, 3),
+            tri_colorf=_np_view(d.tri_colorf, 3 * T, np.float32).reshape(T, 3),
+            tri_color32=_np_view(d.tri_color32, T, np.uint32),
+            tri_two_sided=_np_view(d.tri_two_sided, T, np.uint8),
+            tri_d=_np_view(d.tri_d, 4 * T, np.float32).reshape(T, 4),
+            tri_e=_np_view(d.tri_e, 9 * T, np.float32).reshape(T, 9))
+
+    # -- BVH ---------------------------------------------------------------------------------------
+    def bvh_create(self) -> int:
+        if host().mi355h_bvh_create(self._h) != 0:
+            raise Mi355Error(host().mi355h_last_error().decode())
+        return self.bvh_info()[0]
+
+    def bvh_update(self, filename: str | None = None, force: bool = False) -> int:
+        """Scene::UpdateBoundingVolumeHierarchy: `<filename>.bvh` cache or build."""
+        if host().mi355h_bvh_update(self._h, (filename or self.path).encode(), int(force)) != 0:
+            raise Mi355Error(host().mi355h_last_error().decode())
+        return self.bvh_info()[0]
+
+    def bvh_info(self):
+        nn, ni, md = C.c_uint32(0), C.c_uint32(0), C.c_int(0)
+        pn, pi = C.c_void_p(0), C.c_void_p(0)
+        host().mi355h_bvh_info(self._h, C.byref(nn), C.byref(ni), C.byref(md), C.byref(pn), C.byref(pi))
+        return nn.value, ni.value, md.value, pn.value, pi.value
+
+    def bvh_arrays(self):
+        nn, ni, _, pn, pi = self.bvh_info()
+        if nn == 0:
+            return np.zeros((0, 8), np.uint32), np.zeros(0, np.int32)
+        nodes = np.ctypeslib.as_array(C.cast(pn, C.POINTER(C.c_uint32)), shape=(nn * 8,)).reshape(nn, 8)
+        idx = np.ctypeslib.as_array(C.cast(pi, C.POINTER(C.c_int32)), shape=(ni,))
+        return nodes, idx
+
+    # -- device ------------------------------------------------------------------------------------
+    def context(self):
+        ctx = host().mi355h_context(self._h)
+        if not ctx:
+            raise Mi355Error(host().mi355h_last_error().decode())
+        return ctx
+
+    def shadowmap_render(self, slot: int, l: Light, size: int = 1024, fetch: bool = False):
+        out = np.empty((size, size), np.float32) if fetch else None
+        _check(lib().mi355_shadowmap_render(self.context(), slot, C.byref(l), size,
+                                            out.ctypes.data if fetch else None), "mi355_shadowmap_render")
+        return out
+
+    def shadowmap_set(self, slot: int, m: np.ndarray):
+        m = np.ascontiguousarray(m, np.float32)
+        _check(lib().mi355_shadowmap_set(self.context(), slot, m.ctypes.data, m.shape[0]), "mi355_shadowmap_set")
+
+    def render(self, mode: int, cam: Camera, lights, n_lights: int, opts: Opts, want_f32: bool = False,
+               pitch_words: int | None = None):
+        """One frame through mi355_render().  Returns (xrgb[H,W] uint32, f32[H,W,3] or None, Stats)."""
+        W, H = opts.width, opts.height
+        rows = H
+        if opts.band_count > 1 and opts.compact_rows:
+            rows = sum(1 for y in range(H) if (y // opts.band_rows) % opts.band_count == opts.band_index)
+        pw = pitch_words or W
+        out = np.zeros((rows, pw), np.uint32)
+        outf = np.zeros((rows, W, 3), np.float32) if want_f32 else None
+        st = Stats()
+        _check(lib().mi355_render(self.context(), mode, C.byref(cam), lights, n_lights, C.byref(opts),
+                                  out.ctypes.data, pw * 4, outf.ctypes.data if want_f32 else None, C.byref(st)),
+               "mi355_render")
+        return out[:, :W], outf, st
+
+    def render_device(self, mode: int, cam: Camera, lights, n_lights: int, opts: Opts, d_out: int,
+                      pitch_bytes: int, d_outf: int = 0, stream: int = 0):
+        """Asynchronous frame into device memory (torch tensor data_ptr) on HIP stream `stream`."""
+        _check(lib().mi355_render_device(self.context(), mode, C.byref(cam), lights, n_lights, C.byref(opts),
+                                         d_out, pitch_bytes, d_outf or None, stream or None),
+               "mi355_render_device")
+
+    def fetch_stats(self) -> Stats:
+        st = Stats()
+        _check(lib().mi355_fetch_stats(self.context(), C.byref(st)), "mi355_fetch_stats")
+        return st
+
+    def render_frame_cxx(self, mode: int, width: int, height: int, eye, lookat, light_positions):
+        """One frame through the C++ Scene::render* API (mi355::Scene, what a front-end calls)."""
+        out = np.zeros((height, width), np.uint32)
+        lp = np.ascontiguousarray(np.asarray(light_positions, np.float32).reshape(-1, 3))
+        st = Stats()
+        rc = host().mi355h_render_frame(self._h, mode, width, height, (C.c_float * 3)(*eye), (C.c_float * 3)(*lookat),
+                                        lp.ctypes.data_as(C.POINTER(C.c_float)), lp.shape[0], out.ctypes.data,
+                                        C.byref(st))
+        if rc != 0:
+            raise Mi355Error(host().mi355h_last_error().decode())
+        return out, st
+
+    def opts(self) -> Opts:
+        return host().mi355h_opts(self._h).contents
+
+
+def rgb_bytes(xrgb: np.ndarray) -> bytes:
+    """Raw R,G,B bytes, row-major from the top row: the layout the reference's frame pins hash."""
+    a = np.ascontiguousarray(xrgb)
+    return np.stack([(a >> 16) & 0xff, (a >> 8) & 0xff, a & 0xff], axis=-1).astype(np.uint8).tobytes()

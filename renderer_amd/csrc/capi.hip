@@ -1,0 +1,504 @@
+// capi.hip -- implementation of include/mi355_render.h: context, HBM layouts, dispatch.
+//
+// There is no CPU rendering path in this library: every mode runs as HIP kernels and every
+// entry point fails (negative return + mi355_last_error) when no HIP device is usable.
+#include "../../include/mi355_render.h"
+#include "dev_scene.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// kernel launchers (defined next to their kernels)
+extern "C" int mi355i_raytrace_blocks_per_cu(int stats);
+extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int n_blocks,
+                                             hipStream_t);
+extern "C" hipError_t mi355i_launch_points(const DevScene *, const FrameParams *, int as_triangles, hipStream_t);
+struct RasterScratch;
+extern "C" hipError_t mi355i_launch_raster(const DevScene *, const FrameParams *, int mode, RasterScratch *,
+                                           hipStream_t);
+extern "C" hipError_t mi355i_launch_shadowmap(const DevScene *, const float *light_pos, const float *w2l, int size,
+                                              float *d_map, RasterScratch *, hipStream_t);
+extern "C" RasterScratch *mi355i_raster_scratch_create(void);
+extern "C" void mi355i_raster_scratch_destroy(RasterScratch *);
+extern "C" uint32_t mi355i_raster_overflow(RasterScratch *);
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr, code)                                                              \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) return fail(code, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t n)
+    {
+        if (n <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    template <class T> hipError_t upload(const std::vector<T> &v)
+    {
+        hipError_t e = ensure(v.size() * sizeof(T) + 16);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct V3h { float x, y, z; };
+inline V3h subh(V3h a, V3h b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3h crossh(V3h l, V3h r) { return {l.y * r.z - r.y * l.z, r.x * l.z - l.x * r.z, l.x * r.y - l.y * r.x}; }
+inline float lenh(V3h v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
+inline float disth(V3h a, V3h b) { float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z; return sqrtf(dx * dx + dy * dy + dz * dz); }
+
+} // namespace
+
+struct mi355_ctx {
+    int device = 0;
+    int n_cus = 256;
+    // host copy of the scene (needed again when the BVH arrives / changes)
+    uint32_t nV = 0, nT = 0;
+    std::vector<float> vpos, vnrm, tcenter, tnormal, tcolorf, td, te;
+    std::vector<uint32_t> vao, tcolor32;
+    std::vector<int32_t> tidx;
+    std::vector<uint8_t> ttwo;
+    bool has_bvh = false;
+    // device
+    DevBuf nodes, tri_plane, tri_edge, tri_shade, rs_tri, rs_col, rs_idx, rs_vert;
+    DevBuf ctrl;            // [0] work counter (16 B) | counters[CS_COUNT]
+    DevBuf fb, fbf;         // internal framebuffer for the host-output path
+    DevBuf smap[MI355_MAX_LIGHTS];
+    int smap_size[MI355_MAX_LIGHTS] = {0, 0, 0, 0};
+    RasterScratch *rscratch = nullptr;
+    DevScene dev{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool last_stats = false;
+};
+
+namespace {
+
+int select_device(mi355_ctx *c)
+{
+    HIP_TRY(hipSetDevice(c->device), -10);
+    return 0;
+}
+
+inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+int count_rows(const mi355_opts &o)
+{
+    if (o.band_count <= 1 || o.band_rows <= 0) return o.height;
+    int n = 0;
+    for (int y = 0; y < o.height; y++)
+        if ((y / o.band_rows) % o.band_count == o.band_index) n++;
+    return n;
+}
+
+int validate_opts(const mi355_opts &o, int mode)
+{
+    if (o.width <= 0 || o.height <= 0 || o.width > 16384 || o.height > 16384) return fail(-20, "bad frame size %dx%d", o.width, o.height);
+    if (o.screen_dist <= 0) return fail(-20, "bad screen_dist %d", o.screen_dist);
+    if (mode >= MI355_MODE_RAYTRACE && (o.max_ray_depth < 1 || o.max_ray_depth > MI_MAX_DEPTH))
+        return fail(-20, "max_ray_depth %d outside 1..%d", o.max_ray_depth, MI_MAX_DEPTH);
+    if (o.band_count > 1 && (o.band_rows <= 0 || o.band_index < 0 || o.band_index >= o.band_count))
+        return fail(-20, "bad band sharding rows=%d index=%d count=%d", o.band_rows, o.band_index, o.band_count);
+    if (o.shadowmap_size <= 0 || o.shadowmap_size > 16384) return fail(-20, "bad shadowmap_size %d", o.shadowmap_size);
+    return 0;
+}
+
+int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_light *lights, int n_lights,
+                const mi355_opts *o, void *d_out, int pitch_bytes, void *d_outf, FrameParams &P)
+{
+    memset(&P, 0, sizeof P);
+    if (n_lights < 0 || n_lights > MI355_MAX_LIGHTS) return fail(-21, "n_lights %d outside 0..%d", n_lights, MI355_MAX_LIGHTS);
+    if (pitch_bytes < o->width * 4 || (pitch_bytes & 3)) return fail(-21, "bad pitch %d for width %d", pitch_bytes, o->width);
+    memcpy(P.eye, cam->eye, sizeof P.eye);
+    memcpy(P.mv, cam->mv, sizeof P.mv);
+    P.n_lights = n_lights;
+    for (int i = 0; i < n_lights; i++) {
+        memcpy(P.light_pos[i], lights[i].pos, 12);
+        memcpy(P.light_ics[i], lights[i].in_camera_space, 12);
+        memcpy(P.light_c2l[i], lights[i].camera_to_light, 36);
+        P.shadow_map[i] = (const float *)c->smap[i].p;
+        if ((mode == MI355_MODE_PHONG_SHADOWMAPS || mode == MI355_MODE_PHONG_SOFTSHADOWMAPS) &&
+            (!c->smap[i].p || c->smap_size[i] != o->shadowmap_size))
+            return fail(-22, "light %d has no %d^2 shadow map: call mi355_shadowmap_render/_set first", i, o->shadowmap_size);
+    }
+    P.W = o->width; P.H = o->height; P.SD = o->screen_dist;
+    P.max_depth = o->max_ray_depth; P.use_shadows = o->use_shadows; P.use_refl = o->use_reflections;
+    P.aa = mode == MI355_MODE_RAYTRACE_ANTIALIAS;
+    P.sm_size = o->shadowmap_size;
+    P.refl_rate = o->reflect_rate; P.nudge = o->nudge;
+    P.ambient = o->ambient; P.diffuse = o->diffuse; P.specular = o->specular; P.clip_z = o->clip_z;
+    P.band_rows = o->band_rows; P.band_index = o->band_index; P.band_count = o->band_count;
+    P.compact = (o->band_count > 1 && o->compact_rows) ? 1 : 0;
+    P.n_rows = count_rows(*o);
+    P.out_rows = (o->band_count > 1 && !P.compact) ? o->height : P.n_rows;
+    P.out = (uint32_t *)d_out;
+    P.pitch_words = pitch_bytes / 4;
+    P.outf = (float *)d_outf;
+    P.work_counter = (uint32_t *)c->ctrl.p;
+    P.counters = (unsigned long long *)((char *)c->ctrl.p + 16);
+    // tuning knobs: variant = xmin | rmin<<8 | (chunk/64)<<16 ; 0 = defaults
+    const int v = o->variant;
+    P.xmin = (v & 0xff) ? (v & 0xff) : 12;
+    P.rmin = ((v >> 8) & 0xff) ? ((v >> 8) & 0xff) : 16;
+    P.chunk = ((v >> 16) & 0xff) ? ((v >> 16) & 0xff) * 64 : 256;
+    return 0;
+}
+
+// Thread the reference's flat BVH (pre-order CacheFriendlyBVHNode[], BVH.h:52-65) with hit/miss
+// links and build the leaf-ordered triangle streams.
+int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int32_t *triIdx, uint32_t nI)
+{
+    struct RefNode { float bottom[3], top[3]; uint32_t a, b; };
+    const RefNode *rn = (const RefNode *)nodes32B;
+    if (nN == 0) return fail(-30, "empty BVH");
+    if (nI != c->nT) return fail(-30, "triangle index list has %u entries, scene has %u triangles", nI, c->nT);
+    std::vector<uint8_t> seen(c->nT, 0);
+    for (uint32_t i = 0; i < nI; i++) {
+        if (triIdx[i] < 0 || (uint32_t)triIdx[i] >= c->nT || seen[triIdx[i]]) return fail(-30, "triangle index list is not a permutation (entry %u)", i);
+        seen[triIdx[i]] = 1;
+    }
+    auto is_leaf = [&](uint32_t i) { return (rn[i].a & 0x80000000u) != 0; };
+    auto link = [&](uint32_t i) { return i == MI_END_LINK ? MI_END_LINK : (is_leaf(i) ? (i | MI_LEAF_BIT) : i); };
+    std::vector<float4> nodes((size_t)nN * 2);
+    std::vector<uint8_t> visited(nN, 0);
+    struct Item { uint32_t node, escape; int depth; };
+    std::vector<Item> st;
+    st.push_back({0u, MI_END_LINK, 0});
+    size_t nvis = 0;
+    while (!st.empty()) {
+        Item it = st.back(); st.pop_back();
+        if (it.node >= nN || visited[it.node]) return fail(-30, "BVH is not a tree (node %u)", it.node);
+        if (it.depth >= 64) return fail(-30, "BVH deeper than 64 levels");
+        visited[it.node] = 1; nvis++;
+        const RefNode &n = rn[it.node];
+        float4 lo, hi;
+        if (!is_leaf(it.node)) {
+            if (n.a >= nN || n.b >= nN) return fail(-30, "BVH child index out of range at node %u", it.node);
+            lo = make_float4(n.bottom[0], n.bottom[1], n.bottom[2], u2f(link(n.a)));
+            hi = make_float4(n.top[0], n.top[1], n.top[2], u2f(link(it.escape)));
+            st.push_back({n.b, it.escape, it.depth + 1});
+            st.push_back({n.a, n.b, it.depth + 1});
+        } else {
+            const uint32_t cnt = n.a & 0x7fffffffu, first = n.b;
+            if ((uint64_t)first + cnt > nI) return fail(-30, "BVH leaf %u exceeds the triangle list", it.node);
+            lo = make_float4(u2f(first), u2f(cnt), 0.f, 0.f);
+            hi = make_float4(0.f, 0.f, 0.f, u2f(link(it.escape)));
+        }
+        nodes[(size_t)it.node * 2] = lo;
+        nodes[(size_t)it.node * 2 + 1] = hi;
+    }
+    if (nvis != nN) return fail(-30, "BVH has %u nodes but only %zu are reachable", nN, nvis);
+
+    const uint32_t T = c->nT;
+    std::vector<float4> plane((size_t)T * 2), edge((size_t)T * 3), shade((size_t)T * 5);
+    for (uint32_t j = 0; j < T; j++) {
+        const uint32_t t = (uint32_t)triIdx[j];
+        const float *nrm = &c->tnormal[3 * t], *cen = &c->tcenter[3 * t], *d = &c->td[4 * t], *e = &c->te[9 * t];
+        plane[(size_t)j * 2] = make_float4(nrm[0], nrm[1], nrm[2], d[0]);
+        plane[(size_t)j * 2 + 1] = make_float4(cen[0], cen[1], cen[2], u2f(c->ttwo[t] ? 1u : 0u));
+        edge[(size_t)j * 3] = make_float4(e[0], e[1], e[2], d[1]);
+        edge[(size_t)j * 3 + 1] = make_float4(e[3], e[4], e[5], d[2]);
+        edge[(size_t)j * 3 + 2] = make_float4(e[6], e[7], e[8], d[3]);
+        const int32_t *ix = &c->tidx[3 * t];
+        const V3h A = {c->vpos[3 * ix[0]], c->vpos[3 * ix[0] + 1], c->vpos[3 * ix[0] + 2]};
+        const V3h B = {c->vpos[3 * ix[1]], c->vpos[3 * ix[1] + 1], c->vpos[3 * ix[1] + 2]};
+        const V3h C = {c->vpos[3 * ix[2]], c->vpos[3 * ix[2] + 1], c->vpos[3 * ix[2] + 2]};
+        // Raytracer.cc:352-361: |AB|, |BC|, |CA| and 2*area depend only on the triangle, so they
+        // are evaluated once here with the same float operations the reference repeats per hit.
+        const float area = lenh(crossh(subh(B, A), subh(C, B)));
+        shade[(size_t)j * 5] = make_float4(disth(A, B), disth(B, C), disth(C, A), area);
+        for (int k = 0; k < 3; k++) {
+            const float *vn = &c->vnrm[3 * ix[k]];
+            shade[(size_t)j * 5 + 1 + k] = make_float4(vn[0], vn[1], vn[2], (float)c->vao[ix[k]]);
+        }
+        shade[(size_t)j * 5 + 4] = make_float4(c->tcolorf[3 * t], c->tcolorf[3 * t + 1], c->tcolorf[3 * t + 2], 0.f);
+    }
+    HIP_TRY(c->nodes.upload(nodes), -31);
+    HIP_TRY(c->tri_plane.upload(plane), -31);
+    HIP_TRY(c->tri_edge.upload(edge), -31);
+    HIP_TRY(c->tri_shade.upload(shade), -31);
+    c->dev.nodes = (const float4 *)c->nodes.p;
+    c->dev.tri_plane = (const float4 *)c->tri_plane.p;
+    c->dev.tri_edge = (const float4 *)c->tri_edge.p;
+    c->dev.tri_shade = (const float4 *)c->tri_shade.p;
+    c->dev.root_link = link(0);
+    c->dev.n_nodes = nN;
+    c->has_bvh = true;
+    return 0;
+}
+
+int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipStream_t st)
+{
+    HIP_TRY(hipMemsetAsync(c->ctrl.p, 0, 16 + sizeof(unsigned long long) * CS_COUNT, st), -40);
+    c->last_stats = stats != 0;
+    hipError_t e = hipSuccess;
+    switch (mode) {
+    case MI355_MODE_POINTS: e = mi355i_launch_points(&c->dev, &P, 0, st); break;
+    case MI355_MODE_POINTS_FROM_TRIANGLES: e = mi355i_launch_points(&c->dev, &P, 1, st); break;
+    case MI355_MODE_AMBIENT: case MI355_MODE_GOURAUD: case MI355_MODE_PHONG:
+    case MI355_MODE_PHONG_SHADOWMAPS: case MI355_MODE_PHONG_SOFTSHADOWMAPS:
+        e = mi355i_launch_raster(&c->dev, &P, mode, c->rscratch, st);
+        break;
+    case MI355_MODE_RAYTRACE: case MI355_MODE_RAYTRACE_ANTIALIAS: {
+        if (!c->has_bvh) return fail(-41, "raytrace modes need mi355_scene_set_bvh first");
+        int n_blocks = mi355i_raytrace_blocks_per_cu(stats) * c->n_cus;
+        const long long lanes_needed = ((long long)P.W * P.n_rows + 255) / 256;
+        if (n_blocks > lanes_needed) n_blocks = (int)(lanes_needed > 0 ? lanes_needed : 1);
+        e = mi355i_launch_raytrace(&c->dev, &P, stats, n_blocks, st);
+        break;
+    }
+    case MI355_MODE_LINES:
+        return fail(-42, "mode 3 (wireframe, Scene::renderWireframe) is outside the accelerated hot path");
+    default:
+        return fail(-42, "unknown render mode %d", mode);
+    }
+    if (e != hipSuccess) return fail(-43, "kernel launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int mi355_abi_version(void) { return MI355_ABI_VERSION; }
+
+const char *mi355_last_error(void) { return g_err.c_str(); }
+
+int mi355_init(int n_devices_requested, int *n_devices_out)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        if (n_devices_out) *n_devices_out = 0;
+        return fail(-1, "no HIP device available (%s); this library has no CPU path", e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+    }
+    if (n_devices_requested > 0 && n_devices_requested > n)
+        return fail(-2, "%d devices requested, %d present", n_devices_requested, n);
+    if (n_devices_out) *n_devices_out = n_devices_requested > 0 ? n_devices_requested : n;
+    return 0;
+}
+
+void mi355_default_opts(mi355_opts *o, int width, int height)
+{
+    memset(o, 0, sizeof *o);
+    o->width = width; o->height = height; o->screen_dist = 2 * height;       // Defines.h:26-28
+    o->max_ray_depth = 3; o->use_shadows = 1; o->use_reflections = 1;         // Raytracer.cc:56,63,67
+    o->shadowmap_size = 1024;                                                 // Defines.h:25
+    o->reflect_rate = 0.375f; o->nudge = 1e-5f;                               // Raytracer.cc:68,59
+    o->ambient = 96.f; o->diffuse = 128.f; o->specular = 192.f;               // Defines.h:30-32
+    o->clip_z = 0.2f;                                                         // Rasterizers.cc:39
+    o->band_rows = 15; o->band_index = 0; o->band_count = 1; o->compact_rows = 0;
+}
+
+mi355_ctx *mi355_scene_create(const mi355_scene_desc *d, int device)
+{
+    if (!d || !d->vertex_pos || !d->vertex_normal || !d->vertex_ao || !d->tri_index || !d->tri_center ||
+        !d->tri_normal || !d->tri_colorf || !d->tri_color32 || !d->tri_two_sided || !d->tri_d || !d->tri_e) {
+        fail(-3, "mi355_scene_create: null array in scene descriptor");
+        return nullptr;
+    }
+    int ndev = 0;
+    if (mi355_init(0, &ndev) != 0) return nullptr;
+    if (device < 0 || device >= ndev) { fail(-3, "device %d out of range (have %d)", device, ndev); return nullptr; }
+    for (uint32_t i = 0; i < d->n_triangles * 3u; i++)
+        if (d->tri_index[i] < 0 || (uint32_t)d->tri_index[i] >= d->n_vertices) {
+            fail(-3, "triangle %u references vertex %d of %u", i / 3, d->tri_index[i], d->n_vertices);
+            return nullptr;
+        }
+    mi355_ctx *c = new mi355_ctx;
+    c->device = device;
+    auto bail = [&](const char *what, hipError_t e) { fail(-4, "%s: %s", what, hipGetErrorString(e)); mi355_scene_destroy(c); return (mi355_ctx *)nullptr; };
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const uint32_t V = d->n_vertices, T = d->n_triangles;
+    c->nV = V; c->nT = T;
+    c->vpos.assign(d->vertex_pos, d->vertex_pos + 3 * (size_t)V);
+    c->vnrm.assign(d->vertex_normal, d->vertex_normal + 3 * (size_t)V);
+    c->vao.assign(d->vertex_ao, d->vertex_ao + V);
+    c->tidx.assign(d->tri_index, d->tri_index + 3 * (size_t)T);
+    c->tcenter.assign(d->tri_center, d->tri_center + 3 * (size_t)T);
+    c->tnormal.assign(d->tri_normal, d->tri_normal + 3 * (size_t)T);
+    c->tcolorf.assign(d->tri_colorf, d->tri_colorf + 3 * (size_t)T);
+    c->tcolor32.assign(d->tri_color32, d->tri_color32 + T);
+    c->ttwo.assign(d->tri_two_sided, d->tri_two_sided + T);
+    c->td.assign(d->tri_d, d->tri_d + 4 * (size_t)T);
+    c->te.assign(d->tri_e, d->tri_e + 9 * (size_t)T);
+    // rasterizer streams, input order
+    std::vector<float4> rs_tri((size_t)T * 2), rs_col(T), rs_vert((size_t)V * 2);
+    std::vector<uint4> rs_idx(T);
+    for (uint32_t t = 0; t < T; t++) {
+        rs_tri[(size_t)t * 2] = make_float4(c->tcenter[3 * t], c->tcenter[3 * t + 1], c->tcenter[3 * t + 2], u2f(c->ttwo[t] ? 1u : 0u));
+        rs_tri[(size_t)t * 2 + 1] = make_float4(c->tnormal[3 * t], c->tnormal[3 * t + 1], c->tnormal[3 * t + 2], u2f(c->tcolor32[t]));
+        rs_col[t] = make_float4(c->tcolorf[3 * t], c->tcolorf[3 * t + 1], c->tcolorf[3 * t + 2], 0.f);
+        rs_idx[t] = make_uint4((uint32_t)c->tidx[3 * t], (uint32_t)c->tidx[3 * t + 1], (uint32_t)c->tidx[3 * t + 2], 0u);
+    }
+    for (uint32_t v = 0; v < V; v++) {
+        rs_vert[(size_t)v * 2] = make_float4(c->vpos[3 * v], c->vpos[3 * v + 1], c->vpos[3 * v + 2], (float)c->vao[v]);
+        rs_vert[(size_t)v * 2 + 1] = make_float4(c->vnrm[3 * v], c->vnrm[3 * v + 1], c->vnrm[3 * v + 2], 0.f);
+    }
+    if ((e = c->rs_tri.upload(rs_tri)) != hipSuccess) return bail("upload", e);
+    if ((e = c->rs_col.upload(rs_col)) != hipSuccess) return bail("upload", e);
+    if ((e = c->rs_idx.upload(rs_idx)) != hipSuccess) return bail("upload", e);
+    if ((e = c->rs_vert.upload(rs_vert)) != hipSuccess) return bail("upload", e);
+    if ((e = c->ctrl.ensure(16 + sizeof(unsigned long long) * CS_COUNT)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemset(c->ctrl.p, 0, c->ctrl.bytes)) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipStreamCreate(&c->stream)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    c->rscratch = mi355i_raster_scratch_create();
+    c->dev.rs_tri = (const float4 *)c->rs_tri.p;
+    c->dev.rs_col = (const float4 *)c->rs_col.p;
+    c->dev.rs_idx = (const uint4 *)c->rs_idx.p;
+    c->dev.rs_vert = (const float4 *)c->rs_vert.p;
+    c->dev.n_tris = T; c->dev.n_verts = V;
+    return c;
+}
+
+void mi355_scene_destroy(mi355_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->nodes, &c->tri_plane, &c->tri_edge, &c->tri_shade, &c->rs_tri, &c->rs_col, &c->rs_idx,
+                      &c->rs_vert, &c->ctrl, &c->fb, &c->fbf})
+        b->release();
+    for (auto &m : c->smap) m.release();
+    if (c->rscratch) mi355i_raster_scratch_destroy(c->rscratch);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mi355_scene_set_bvh(mi355_ctx *c, const void *nodes32B, uint32_t n_nodes, const int32_t *tri_idx, uint32_t n_idx)
+{
+    if (!c || !nodes32B || !tri_idx) return fail(-3, "mi355_scene_set_bvh: null argument");
+    if (int r = select_device(c)) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream), -40);
+    return build_bvh_streams(c, nodes32B, n_nodes, tri_idx, n_idx);
+}
+
+int mi355_shadowmap_set(mi355_ctx *c, int slot, const float *map, int size)
+{
+    if (!c || !map) return fail(-3, "mi355_shadowmap_set: null argument");
+    if (slot < 0 || slot >= MI355_MAX_LIGHTS || size <= 0) return fail(-3, "bad light slot %d / size %d", slot, size);
+    if (int r = select_device(c)) return r;
+    HIP_TRY(c->smap[slot].ensure((size_t)size * size * 4), -31);
+    HIP_TRY(hipMemcpy(c->smap[slot].p, map, (size_t)size * size * 4, hipMemcpyHostToDevice), -31);
+    c->smap_size[slot] = size;
+    return 0;
+}
+
+int mi355_shadowmap_render(mi355_ctx *c, int slot, const mi355_light *light, int size, float *out_map)
+{
+    if (!c || !light) return fail(-3, "mi355_shadowmap_render: null argument");
+    if (slot < 0 || slot >= MI355_MAX_LIGHTS || size <= 0 || size > 16384) return fail(-3, "bad light slot %d / size %d", slot, size);
+    if (int r = select_device(c)) return r;
+    HIP_TRY(c->smap[slot].ensure((size_t)size * size * 4), -31);
+    hipError_t e = mi355i_launch_shadowmap(&c->dev, light->pos, light->world_to_light, size, (float *)c->smap[slot].p,
+                                           c->rscratch, c->stream);
+    if (e != hipSuccess) return fail(-43, "shadow map launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipStreamSynchronize(c->stream), -40);
+    if (uint32_t dropped = mi355i_raster_overflow(c->rscratch))
+        return fail(-44, "shadow map span buffer overflowed (%u rows dropped)", dropped);
+    c->smap_size[slot] = size;
+    if (out_map) HIP_TRY(hipMemcpy(out_map, c->smap[slot].p, (size_t)size * size * 4, hipMemcpyDeviceToHost), -31);
+    return 0;
+}
+
+int mi355_render_device(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_light *lights, int n_lights,
+                        const mi355_opts *o, void *d_out, int pitch_bytes, void *d_outf, void *hip_stream)
+{
+    if (!c || !cam || !o || !d_out || (n_lights > 0 && !lights)) return fail(-3, "mi355_render_device: null argument");
+    if (int r = validate_opts(*o, mode)) return r;
+    if (int r = select_device(c)) return r;
+    FrameParams P;
+    if (int r = fill_params(c, mode, cam, lights, n_lights, o, d_out, pitch_bytes, d_outf, P)) return r;
+    return enqueue_frame(c, mode, P, o->collect_stats, (hipStream_t)hip_stream);
+}
+
+int mi355_fetch_stats(mi355_ctx *c, mi355_stats *s)
+{
+    if (!c || !s) return fail(-3, "mi355_fetch_stats: null argument");
+    if (int r = select_device(c)) return r;
+    unsigned long long h[CS_COUNT];
+    HIP_TRY(hipMemcpy(h, (char *)c->ctrl.p + 16, sizeof h, hipMemcpyDeviceToHost), -31);
+    memset(s, 0, sizeof *s);
+    s->normal_rays = h[CS_NORMAL_RAYS]; s->shadow_rays = h[CS_SHADOW_RAYS];
+    s->node_pops = h[CS_NODE_POPS]; s->inner_box_hits = h[CS_INNER_HITS]; s->tri_tests = h[CS_TRI_TESTS];
+    s->plane_pass = h[CS_PLANE_PASS]; s->shaded_hits = h[CS_SHADED_HITS];
+    s->tris_drawn = h[CS_TRIS_DRAWN]; s->spans = h[CS_SPANS]; s->ztests = h[CS_ZTESTS]; s->plots = h[CS_PLOTS];
+    if (h[CS_OVERFLOW]) return fail(-44, "rasterizer span buffer overflowed (%llu rows dropped)", h[CS_OVERFLOW]);
+    return 0;
+}
+
+int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_light *lights, int n_lights,
+                 const mi355_opts *o, uint32_t *out_xrgb, int pitch_bytes, float *out_rgb_f32, mi355_stats *stats)
+{
+    if (!c || !cam || !o || !out_xrgb || (n_lights > 0 && !lights)) return fail(-3, "mi355_render: null argument");
+    if (int r = validate_opts(*o, mode)) return r;
+    if (int r = select_device(c)) return r;
+    const int W = o->width;
+    const int rows = (o->band_count > 1 && o->compact_rows) ? count_rows(*o) : o->height;
+    HIP_TRY(c->fb.ensure((size_t)W * o->height * 4), -31);
+    const bool wantf = out_rgb_f32 && mode >= MI355_MODE_RAYTRACE;
+    if (wantf) HIP_TRY(c->fbf.ensure((size_t)W * o->height * 12), -31);
+    if (o->band_count > 1) {    // rows of other bands are never written: define them as black
+        HIP_TRY(hipMemsetAsync(c->fb.p, 0, (size_t)W * o->height * 4, c->stream), -40);
+        if (wantf) HIP_TRY(hipMemsetAsync(c->fbf.p, 0, (size_t)W * o->height * 12, c->stream), -40);
+    }
+    FrameParams P;
+    if (int r = fill_params(c, mode, cam, lights, n_lights, o, c->fb.p, W * 4, wantf ? c->fbf.p : nullptr, P)) return r;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream), -40);
+    if (int r = enqueue_frame(c, mode, P, o->collect_stats, c->stream)) return r;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream), -40);
+    HIP_TRY(hipStreamSynchronize(c->stream), -40);
+    HIP_TRY(hipMemcpy2D(out_xrgb, (size_t)pitch_bytes, c->fb.p, (size_t)W * 4, (size_t)W * 4, (size_t)rows, hipMemcpyDeviceToHost), -31);
+    if (wantf) HIP_TRY(hipMemcpy(out_rgb_f32, c->fbf.p, (size_t)W * rows * 12, hipMemcpyDeviceToHost), -31);
+    if (stats) {
+        if (int r = mi355_fetch_stats(c, stats)) return r;
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1), -40);
+        stats->kernel_ms = ms;
+    } else {
+        mi355_stats tmp;
+        if (int r = mi355_fetch_stats(c, &tmp)) return r;    // surfaces rasterizer overflow
+    }
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,89 @@
+// dev_scene.h -- HBM layouts shared by the kernels and the C ABI.
+//
+// The reference keeps a 144-byte Triangle AoS with pointers to 28-byte Vertex
+// structs (Base3d.h:27-66) and a 32-byte CacheFriendlyBVHNode (BVH.h:52-65).
+// On the device the scene is split into per-phase streams so that each phase of
+// a ray's life touches only the bytes it needs, every record is one or more
+// aligned 16-byte vectors (one dwordx4 load per lane per vector), and the
+// triangles of a leaf are contiguous:
+//
+//   nodes     [n_nodes][2] float4   traversal  (box + skip links)          32 B
+//   tri_plane [T][2]       float4   leaf test, first half (normal,d,centre) 32 B
+//   tri_edge  [T][3]       float4   leaf test, second half (e1..e3,d1..d3)  48 B
+//   tri_shade [T][5]       float4   closest-hit shading                     80 B
+//   (all three tri_* streams are in LEAF ORDER = position in triIndexList)
+//
+//   rs_tri    [T][2]  float4 + [T] uint4   rasterizer: centre/normal/colour + vertex ids, input order
+//   rs_vert   [V][2]  float4               rasterizer: position+ao, normal
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MI_END_LINK 0x7fffffffu   // traversal finished
+#define MI_LEAF_BIT 0x80000000u   // link target is a leaf
+
+#define MI_MAX_LIGHTS 4
+#define MI_MAX_DEPTH 4
+
+// Node record (32 B):
+//   inner: lo = (bmin.xyz, link_if_hit)   hi = (bmax.xyz, link_if_miss)
+//   leaf : lo = (first, count, -, -)      hi = (-, -, -, link_next)
+// A link is a node index with MI_LEAF_BIT set when the target is a leaf, or MI_END_LINK.
+// link_if_hit is the left child, link_if_miss / link_next is the next node of the
+// reference's depth-first, left-first order (Raytracer.cc:217-230) that is not below this
+// one -- so following links visits exactly the nodes the reference pops, in the same order,
+// without a stack.
+struct DevScene {
+    const float4 *nodes;
+    const float4 *tri_plane;
+    const float4 *tri_edge;
+    const float4 *tri_shade;
+    uint32_t root_link;
+    uint32_t n_nodes;
+    uint32_t n_tris;
+    uint32_t n_verts;
+    // rasterizer streams (input order)
+    const float4 *rs_tri;     // [T][2]: (centre.xyz, twoSided), (normal.xyz, color32 bits)
+    const float4 *rs_col;     // [T]   : (colorf r,g,b, -)
+    const uint4 *rs_idx;      // [T]   : (a, b, c, -)
+    const float4 *rs_vert;    // [V][2]: (pos.xyz, ao as float), (normal.xyz, -)
+};
+
+struct FrameParams {
+    float eye[3];
+    float mv[9];
+    int32_t n_lights;
+    float light_pos[MI_MAX_LIGHTS][3];
+    float light_ics[MI_MAX_LIGHTS][3];     // _inCameraSpace
+    float light_c2l[MI_MAX_LIGHTS][9];     // _cameraToLightSpace
+    const float *shadow_map[MI_MAX_LIGHTS];
+    int32_t W, H, SD;
+    int32_t max_depth, use_shadows, use_refl, aa;
+    int32_t sm_size;
+    float refl_rate, nudge, ambient, diffuse, specular, clip_z;
+    int32_t band_rows, band_index, band_count, compact;
+    int32_t n_rows;            // number of selected rows
+    int32_t out_rows;          // rows of the output buffer (n_rows when compact or unsharded, else H)
+    uint32_t rows_cap;         // rasterizer span-record capacity (filled by the launcher)
+    uint32_t *out;             // XRGB words
+    int32_t pitch_words;
+    float *outf;               // optional r,g,b floats (raytrace)
+    unsigned long long *counters; // device counters (see CounterSlot)
+    uint32_t *work_counter;    // persistent-kernel pixel dispenser
+    int32_t xmin;              // service state transitions once this many lanes wait (or nobody traverses)
+    int32_t rmin;              // refill once this many lanes are idle (or nobody is alive)
+    int32_t chunk;             // pixel indices a wave takes from the dispenser at a time
+};
+
+enum CounterSlot {
+    CS_NORMAL_RAYS = 0, CS_SHADOW_RAYS, CS_NODE_POPS, CS_INNER_HITS, CS_TRI_TESTS, CS_PLANE_PASS,
+    CS_SHADED_HITS, CS_TRIS_DRAWN, CS_SPANS, CS_ZTESTS, CS_PLOTS, CS_OVERFLOW, CS_COUNT
+};
+
+// compact row r (0..n_rows) -> screen row y for the band sharding of mi355_opts
+__host__ __device__ inline int band_row_to_y(int r, int band_rows, int band_index, int band_count)
+{
+    if (band_count <= 1 || band_rows <= 0) return r;
+    int b = r / band_rows, w = r - b * band_rows;
+    return (b * band_count + band_index) * band_rows + w;
+}

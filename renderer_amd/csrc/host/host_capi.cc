@@ -1,0 +1,152 @@
+// host_capi.cc -- plain-C hooks into the C++ host layer, for language bindings and tests
+// (Python ctypes in renderer_amd/__init__.py).  Thin wrappers only: every function forwards to
+// the mi355::Scene / Camera / Light API of renderer_host.h and converts its std::string
+// exceptions (the reference's THROW(), Exceptions.h:28-33) into an error return.
+#include "renderer_host.h"
+
+#include <cstring>
+#include <memory>
+
+using namespace mi355;
+
+namespace {
+thread_local std::string g_herr;
+template <class F> int guarded(F &&f)
+{
+    try { f(); return 0; }
+    catch (const std::string &e) { g_herr = e; }
+    catch (const std::exception &e) { g_herr = e.what(); }
+    return -1;
+}
+struct Handle {
+    Scene scene;
+    std::vector<std::unique_ptr<Light>> lights;
+};
+} // namespace
+
+extern "C" {
+
+const char *mi355h_last_error(void) { return g_herr.c_str(); }
+
+void *mi355h_scene_load(const char *path)
+{
+    Handle *h = new Handle;
+    if (guarded([&] { h->scene.load(path); }) != 0) { delete h; return nullptr; }
+    return h;
+}
+void mi355h_scene_free(void *h) { delete (Handle *)h; }
+
+int mi355h_scene_desc(void *h, mi355_scene_desc *out) { *out = ((Handle *)h)->scene.desc(); return 0; }
+
+int mi355h_set_device(void *h, int device)
+{
+    Handle *H = (Handle *)h;
+    H->scene.invalidateDevice();
+    H->scene._device = device;
+    return 0;
+}
+
+// BVH: build (always), or the reference's cache-or-build entry point
+int mi355h_bvh_create(void *h) { return guarded([&] { ((Handle *)h)->scene.CreateBVH(); }); }
+int mi355h_bvh_update(void *h, const char *filename, int force)
+{
+    return guarded([&] { ((Handle *)h)->scene.UpdateBoundingVolumeHierarchy(filename, force != 0); });
+}
+int mi355h_bvh_info(void *h, uint32_t *n_nodes, uint32_t *n_idx, int *max_depth, const void **nodes, const int32_t **tri_idx)
+{
+    Scene &s = ((Handle *)h)->scene;
+    if (n_nodes) *n_nodes = (uint32_t)s._pCFBVH.size();
+    if (n_idx) *n_idx = (uint32_t)s._triIndexList.size();
+    if (max_depth) *max_depth = s._bvhMaxDepth;
+    if (nodes) *nodes = s._pCFBVH.data();
+    if (tri_idx) *tri_idx = s._triIndexList.data();
+    return 0;
+}
+
+mi355_opts *mi355h_opts(void *h) { return &((Handle *)h)->scene._opts; }
+mi355_ctx *mi355h_context(void *h)
+{
+    mi355_ctx *c = nullptr;
+    if (guarded([&] { c = ((Handle *)h)->scene.context(); }) != 0) return nullptr;
+    return c;
+}
+
+void mi355h_camera_set(mi355_camera *out, const float eye[3], const float lookat[3])
+{
+    Camera c(Vector3(eye[0], eye[1], eye[2]), Vector3(lookat[0], lookat[1], lookat[2]));
+    *out = c.abi();
+}
+
+// fill the derived members of a light for a camera (renderer.cc:498-507)
+void mi355h_light_update(mi355_light *l, const mi355_camera *cam)
+{
+    Light L(l->pos[0], l->pos[1], l->pos[2]);
+    Camera c(0, 0, 0, 1, 0, 0);
+    c._x = cam->eye[0]; c._y = cam->eye[1]; c._z = cam->eye[2];
+    c._mv._row1 = Vector3(cam->mv[0], cam->mv[1], cam->mv[2]);
+    c._mv._row2 = Vector3(cam->mv[3], cam->mv[4], cam->mv[5]);
+    c._mv._row3 = Vector3(cam->mv[6], cam->mv[7], cam->mv[8]);
+    L.CalculatePositionInCameraSpace(c);
+    L.CalculateXformFromCameraToLightSpace(c);
+    L.CalculateXformFromWorldToLightSpace();
+    *l = L.abi();
+}
+
+// camera + light(s) of frame k (0-based) of `renderer -b` (renderer.cc:243-341, 481-507)
+void mi355h_benchmark_frame(int k, int second_light, mi355_camera *cam, mi355_light *lights /*[2]*/, int *n_lights)
+{
+    BenchmarkOrbit orbit;
+    for (int f = 0; f <= k; f++) orbit.advance();
+    Camera sony(orbit.eye, orbit.lookat);
+    *cam = sony.abi();
+    const Vector3 lp[2] = {BenchmarkOrbit::lightPosition(), BenchmarkOrbit::secondLightPosition()};
+    *n_lights = second_light ? 2 : 1;
+    for (int i = 0; i < *n_lights; i++) {
+        memset(&lights[i], 0, sizeof(mi355_light));
+        lights[i].pos[0] = lp[i]._x; lights[i].pos[1] = lp[i]._y; lights[i].pos[2] = lp[i]._z;
+        mi355h_light_update(&lights[i], cam);
+    }
+}
+
+// One frame through the C++ Scene::render* API (what renderer.cc:522-583 does), lights given by position.
+// mode = reference RenderMode; out = width*height XRGB words.
+int mi355h_render_frame(void *h, int mode, int width, int height, const float eye[3], const float lookat[3],
+                        const float *light_pos, int n_lights, uint32_t *out, mi355_stats *stats)
+{
+    Handle *H = (Handle *)h;
+    return guarded([&] {
+        Scene &s = H->scene;
+        while ((int)H->lights.size() < n_lights) H->lights.emplace_back(new Light(0, 0, 0));
+        bool moved = (int)s._lights.size() != n_lights;
+        s._lights.clear();
+        for (int i = 0; i < n_lights; i++) {
+            Light &L = *H->lights[i];
+            if (L._x != light_pos[3 * i] || L._y != light_pos[3 * i + 1] || L._z != light_pos[3 * i + 2] || L._slot < 0) moved = true;
+            L._x = light_pos[3 * i]; L._y = light_pos[3 * i + 1]; L._z = light_pos[3 * i + 2];
+            s._lights.push_back(&L);
+        }
+        Screen canvas(s, width, height);
+        Camera sony(Vector3(eye[0], eye[1], eye[2]), Vector3(lookat[0], lookat[1], lookat[2]));
+        for (Light *L : s._lights) {
+            L->CalculatePositionInCameraSpace(sony);
+            L->CalculateXformFromCameraToLightSpace(sony);
+            if ((mode == 7 || mode == 8) && moved) L->RenderSceneIntoShadowBuffer(s);
+        }
+        switch (mode) {
+        case 1: s.renderPoints(sony, canvas, false); break;
+        case 2: s.renderPoints(sony, canvas, true); break;
+        case 4: s.renderAmbient(sony, canvas); break;
+        case 5: s.renderGouraud(sony, canvas); break;
+        case 6: s.renderPhong(sony, canvas); break;
+        case 7: s.renderPhongAndShadowed(sony, canvas); break;
+        case 8: s.renderPhongAndSoftShadowed(sony, canvas); break;
+        case 9: s.renderRaytracer(sony, canvas, false); break;
+        case 10: case 0: s.renderRaytracer(sony, canvas, true); break;
+        default: throw std::string("unsupported render mode");
+        }
+        memcpy(out, canvas._pixels.data(), (size_t)width * height * 4);
+        if (stats) *stats = s._lastStats;
+    });
+}
+
+} // extern "C"

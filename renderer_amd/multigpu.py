@@ -1,0 +1,98 @@
+"""Multi-GPU frames: interleaved screen bands + one gather per frame.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" in CPU tests).
+The scene is replicated; rank r renders the bands b with b % world == r (bands of `band_rows`
+scanlines, interleaved so the model's silhouette is spread over all GPUs) into a compact
+[rows_r, W] XRGB buffer; a single gather moves the buffers to rank 0, which de-interleaves them
+into the frame.  There is no exchange inside a frame.  Nothing here renders: the render callback
+is the C ABI's mi355_render_device (or, in CPU tests, the oracle).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+BAND_ROWS = 15      # divides 1080 and 2160 into 72 / 144 bands: even for 1, 2, 4, 8 GPUs
+
+
+def rows_of_rank(height: int, band_rows: int, world: int, rank: int) -> int:
+    return sum(1 for y in range(height) if (y // band_rows) % world == rank)
+
+
+def row_map(height: int, band_rows: int, world: int):
+    """For every screen row y: (owning rank, row inside that rank's compact buffer)."""
+    owner = np.empty(height, np.int64)
+    local = np.empty(height, np.int64)
+    fill = [0] * world
+    for y in range(height):
+        r = (y // band_rows) % world
+        owner[y], local[y] = r, fill[r]
+        fill[r] += 1
+    return owner, local
+
+
+def assemble_numpy(parts, height: int, band_rows: int) -> np.ndarray:
+    world = len(parts)
+    owner, local = row_map(height, band_rows, world)
+    out = np.empty((height, parts[0].shape[1]), parts[0].dtype)
+    for y in range(height):
+        out[y] = parts[owner[y]][local[y]]
+    return out
+
+
+class FrameGatherer:
+    """Gathers per-rank compact band buffers on rank 0 and de-interleaves them (torch tensors)."""
+
+    def __init__(self, width: int, height: int, device, band_rows: int = BAND_ROWS, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.W, self.H, self.band_rows, self.device = width, height, band_rows, device
+        self.my_rows = rows_of_rank(height, band_rows, self.world, self.rank)
+        self.max_rows = max(rows_of_rank(height, band_rows, self.world, r) for r in range(self.world))
+        owner, local = row_map(height, band_rows, self.world)
+        # frame row y lives at flat row owner*max_rows + local of the gathered [world, max_rows, W] block
+        self.src_rows = torch.as_tensor(owner * self.max_rows + local, device=device)
+        # double-buffered so frame k+1 can render while frame k is on the wire
+        self.send = [torch.zeros((self.max_rows, width), dtype=torch.int32, device=device) for _ in range(2)]
+        self.recv = [torch.zeros((self.world, self.max_rows, width), dtype=torch.int32, device=device)
+                     if self.rank == 0 else None for _ in range(2)]
+        self.pending = [None, None]
+
+    def send_buffer(self, slot: int):
+        """Wait until buffer `slot` is free again and return it (rank-local compact band buffer)."""
+        if self.pending[slot] is not None:
+            self.pending[slot].wait()
+            self.pending[slot] = None
+        return self.send[slot]
+
+    def gather(self, slot: int, async_op: bool = True):
+        """Launch the gather of buffer `slot` to rank 0 (one collective per frame)."""
+        if self.world == 1:
+            return None
+        if self.rank == 0:
+            lst = list(self.recv[slot].unbind(0))
+            w = self.dist.gather(self.send[slot], gather_list=lst, dst=0, group=self.group, async_op=async_op)
+        else:
+            w = self.dist.gather(self.send[slot], gather_list=None, dst=0, group=self.group, async_op=async_op)
+        self.pending[slot] = w if async_op else None
+        return w
+
+    def frame(self, slot: int):
+        """Rank 0: the assembled [H, W] frame of buffer `slot` (waits for its gather)."""
+        if self.pending[slot] is not None:
+            self.pending[slot].wait()
+            self.pending[slot] = None
+        if self.rank != 0:
+            return None
+        if self.world == 1:
+            return self.send[slot][: self.H]
+        flat = self.recv[slot].view(self.world * self.max_rows, self.W)
+        return flat.index_select(0, self.src_rows)
+
+    def drain(self):
+        for s in (0, 1):
+            if self.pending[s] is not None:
+                self.pending[s].wait()
+                self.pending[s] = None
