@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline benchmark on MI355X.
+
+A "step" is one frame of the hot path: `renderer -b -m 9 dragon_vis.ply` at 1920x1080 (BVH raytrace
+with shadow rays and 2 reflection bounces, BASELINE.json configs[3]), camera k of the reference's
+auto-spin orbit, scene + BVH resident in HBM, frame left in HBM.  value = Mrays/s over all GPUs
+(a ray = one BVH_IntersectTriangles call); frames/s is reported beside it, and the
+chessboard Phong rasterizer (configs[1]) is timed as a second workload at N=1.
+
+N>1: one process per GPU; every rank renders its interleaved 15-row screen bands of the SAME frame
+and a single RCCL gather per frame assembles it on rank 0 (strong scaling).
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W]
+       (N>1 is launched by torch.distributed.run, one rank per GPU)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(st, width, rows):
+    """B = 32*N_pop + 36*N_tri + 48*N_plane + 96*N_hit + 4*W*H per raytraced frame."""
+    return 32 * st["node_pops"] + 36 * st["tri_tests"] + 48 * st["plane_pass"] + 96 * st["shaded_hits"] + 4 * width * rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--mesh", default="dragon_vis.ply")
+    ap.add_argument("--mode", type=int, default=9)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary (rasterizer) workloads")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import renderer_amd as R
+    from renderer_amd import multigpu
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    W, H, K, WU = args.width, args.height, args.steps, args.warmup
+    scene = R.Scene(R.assets.mesh_path(args.mesh), device=local_rank)
+    if args.mode >= 9:
+        scene.bvh_update()                 # <mesh>.bvh cache in the scratch dir, else build (untimed, like -b)
+    cams = [R.benchmark_frame(k) for k in range(max(K, WU))]
+
+    def opts(**kw):
+        o = R.default_opts(W, H, variant=args.variant, **kw)
+        if world > 1:
+            o.band_rows, o.band_index, o.band_count, o.compact_rows = multigpu.BAND_ROWS, rank, world, 1
+        return o
+
+    gather = multigpu.FrameGatherer(W, H, dev)
+    my_rows = gather.my_rows
+    stream = torch.cuda.current_stream(dev)
+
+    if args.mode in (7, 8):
+        scene.shadowmap_render(0, cams[0][1][0])
+
+    def enqueue(k, o, slot):
+        cam, lights, n = cams[k]
+        buf = gather.send_buffer(slot)
+        scene.render_device(args.mode, cam, lights, n, o, buf.data_ptr(), W * 4, 0, stream.cuda_stream)
+        gather.gather(slot)
+
+    # ---- untimed pre-pass: per-frame ray counts and algorithmic bytes from the counting kernel variant
+    o_stats = opts(collect_stats=1)
+    rays = np.zeros(K, np.float64)
+    abytes = np.zeros(K, np.float64)
+    for k in range(K):
+        cam, lights, n = cams[k]
+        buf = gather.send_buffer(0)
+        scene.render_device(args.mode, cam, lights, n, o_stats, buf.data_ptr(), W * 4, 0, stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        st = scene.fetch_stats().as_dict()
+        rays[k] = st["normal_rays"] + st["shadow_rays"]
+        abytes[k] = algorithmic_bytes(st, W, my_rows)
+    if world > 1:
+        t = torch.tensor([rays.sum(), abytes.sum()], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        total_rays, total_abytes = float(t[0]), float(t[1])
+    else:
+        total_rays, total_abytes = float(rays.sum()), float(abytes.sum())
+
+    # ---- warmup
+    o_run = opts()
+    for k in range(WU):
+        enqueue(k % len(cams), o_run, k & 1)
+    gather.drain()
+
+    # ---- timed region: exactly K frames, barrier + synchronize on both sides, max over ranks
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for k in range(K):
+        enqueue(k, o_run, k & 1)
+    ev1.record(stream)
+    gather.drain()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)        # HIP events on the launch stream: GPU time of the K launches
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+
+    # sanity: the last assembled frame is a real picture
+    if rank == 0:
+        last = gather.frame((K - 1) & 1)
+        nonblack = int((last != 0).sum().item())
+        assert nonblack > 0, "rendered frame is empty"
+
+    result = None
+    if rank == 0:
+        ms_per_step = dt * 1e3 / K
+        kernel_ms = gpu_ms / K
+        result = {
+            "metric": "Mrays/sec",
+            "value": round(total_rays / dt / 1e6, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": WU,
+            "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic orbit: reference mesh %s (shipped asset), reference benchmark cameras f0..f%d, BVH built by the host library" % (args.mesh, K - 1),
+            "config": {"workload": "%s, BVH raytrace mode %d (primary + shadow rays + 2 reflection bounces), %dx%d, 1 light"
+                                   % (args.mesh, args.mode, W, H),
+                       "parallelism": "screen bands x%d, 1 RCCL gather/frame" % world if world > 1 else "single GPU",
+                       "rays_per_frame": round(total_rays / K, 1), "variant": args.variant},
+            "frames_per_sec": round(K / dt, 3),
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(total_abytes / K / (kernel_ms * 1e-3) / 1e9 / max(world, 1), 3),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(total_abytes / K / (kernel_ms * 1e-3) / 1e9 / max(world, 1) / HBM_PEAK_GBS, 5),
+                "traffic": None,
+                "kernel": "k_raytrace",
+                "kernel_ms": round(kernel_ms, 5),
+                "algorithmic_bytes_per_launch": round(total_abytes / K / max(world, 1), 1),
+                "note": "achieved = SURVEY 8(d) algorithmic bytes per launch / HIP-event time per launch on the "
+                        "launch stream (rank 0); the scene (~8 MB) is L2/MALL resident so real HBM traffic is far "
+                        "lower -- see profiles/",
+            },
+        }
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if world == 1 and os.path.exists(tfile):
+            try:
+                result["roofline"]["traffic"] = json.load(open(tfile)).get("k_raytrace_hbm_bytes_per_launch")
+            except Exception:
+                pass
+
+    # ---- secondary workloads (N=1 only, untimed by the driver's contract but reported)
+    if rank == 0 and world == 1 and not args.no_extra:
+        extra = {}
+        try:
+            chess = R.Scene(R.assets.mesh_path("chessboard.tri"), device=local_rank)
+            buf = torch.zeros((H, W), dtype=torch.int32, device=dev)
+            chess.shadowmap_render(0, cams[0][1][0])
+            for mode, name in ((6, "chessboard_phong_1080p"), (8, "chessboard_softshadow_1080p"), (2, "chessboard_points_1080p")):
+                o6 = R.default_opts(W, H)
+                n_f = min(K, 100)
+                for k in range(5):
+                    chess.render_device(mode, cams[k][0], cams[k][1], cams[k][2], o6, buf.data_ptr(), W * 4, 0, stream.cuda_stream)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for k in range(n_f):
+                    chess.render_device(mode, cams[k][0], cams[k][1], cams[k][2], o6, buf.data_ptr(), W * 4, 0, stream.cuda_stream)
+                torch.cuda.synchronize(dev)
+                extra[name + "_fps"] = round(n_f / (time.perf_counter() - t1), 2)
+        except Exception as e:      # secondary numbers must never break the headline line
+            extra["error"] = str(e)
+        result["other_workloads"] = extra
+
+    # ---- CPU baseline: the oracle (a port of the reference's path) on this box's host cores, bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            from oracle import oracle_ctypes as O
+            ncpu = os.cpu_count() or 1
+            osc = O.Scene(R.assets.mesh_path(args.mesh))
+            if args.mode >= 9:
+                osc.bvh_ensure(os.path.join(R.assets.cache_dir(), args.mesh + ".oracle.bvh"))
+            oo = O.default_opts(W, H, threads=ncpu)
+            maps = None
+            done_rays, done_frames, t_cpu = 0.0, 0, 0.0
+            k = 0
+            while t_cpu < args.cpu_seconds and k < K:
+                ocam, olights, on = O.benchmark_frame(k)
+                if args.mode in (7, 8) and maps is None:
+                    maps = [osc.shadowmap(olights[0])]
+                t1 = time.perf_counter()
+                _, _, st = osc.render(args.mode, ocam, olights, on, oo, shadow_maps=maps)
+                t_cpu += time.perf_counter() - t1
+                done_rays += st.normal_rays + st.shadow_rays
+                done_frames += 1
+                k += 1
+            result["cpu_baseline"] = {
+                "value": round(done_rays / t_cpu / 1e6, 3), "unit": "Mrays/s", "cores": ncpu, "kind": "port",
+                "sample": "oracle (strict-IEEE C++ port of the reference, OpenMP over pixels like Raytracer.cc:558) on "
+                          "frames f0..f%d of the same workload, %.1f s" % (done_frames - 1, t_cpu),
+                "frames_per_sec": round(done_frames / t_cpu, 3),
+            }
+        except Exception as e:
+            result["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": "failed: %s" % e}
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
