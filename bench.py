@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--mesh", default="dragon_vis.ply")
     ap.add_argument("--mode", type=int, default=9)
-    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--tune", default="{}", help="JSON dict of renderer_amd.tune() knobs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (rasterizer) workloads")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -74,7 +74,7 @@ def main():
     cams = [R.benchmark_frame(k) for k in range(max(K, WU))]
 
     def opts(**kw):
-        o = R.default_opts(W, H, variant=args.variant, **kw)
+        o = R.default_opts(W, H, tune=json.loads(args.tune), **kw)
         if world > 1:
             o.band_rows, o.band_index, o.band_count, o.compact_rows = multigpu.BAND_ROWS, rank, world, 1
         return o
@@ -165,7 +165,7 @@ def main():
             "config": {"workload": "%s, BVH raytrace mode %d (primary + shadow rays + 2 reflection bounces), %dx%d, 1 light"
                                    % (args.mesh, args.mode, W, H),
                        "parallelism": "screen bands x%d, 1 RCCL gather/frame" % world if world > 1 else "single GPU",
-                       "rays_per_frame": round(total_rays / K, 1), "variant": args.variant},
+                       "rays_per_frame": round(total_rays / K, 1), "tune": json.loads(args.tune)},
             "frames_per_sec": round(K / dt, 3),
             "roofline": {
                 "bound": "hbm",

@@ -79,7 +79,17 @@ typedef struct {
      * r-th selected row), which is the layout the RCCL gather moves. */
     int32_t band_rows, band_index, band_count, compact_rows;
     int32_t collect_stats;   /* fill the traversal counters of mi355_stats (slower kernel variant) */
-    int32_t variant;         /* kernel variant selector for tuning; 0 = default */
+    /* Kernel tuning knobs; all 0 = defaults.  They never change a pixel (tests/test_gpu_parity.py).
+     * [0] xmin   lanes waiting for a state transition before the wave services them
+     * [1] rmin   idle lanes before the wave refills from the pixel dispenser
+     * [2] chunk  pixel indices a wave takes from the dispenser at once
+     * [3] lmin   lanes gathered on leaves before the triangle tests run
+     * [4] blocks per CU (0 = occupancy query)
+     * [5] flags  1 exact box test only | 2 row-major tile order | 4 no LDS BVH-top cache |
+     *            16 scattered pixel dispensing | 32 wave-cooperative traversal of a wave's last rays
+     * [6] coop_steps  > 0: a ray longer than this many node visits is finished wave-cooperatively
+     * [7] reserved */
+    int32_t tune[8];
 } mi355_opts;
 
 /* Counters.  Ray counts are always filled for raytrace modes; the rest only

@@ -50,7 +50,7 @@ class Opts(C.Structure):
                 ("ambient", C.c_float), ("diffuse", C.c_float), ("specular", C.c_float),
                 ("clip_z", C.c_float), ("band_rows", C.c_int32), ("band_index", C.c_int32),
                 ("band_count", C.c_int32), ("compact_rows", C.c_int32), ("collect_stats", C.c_int32),
-                ("variant", C.c_int32)]
+                ("tune", C.c_int32 * 8)]
 
 
 class Stats(C.Structure):
@@ -154,8 +154,17 @@ def default_opts(width: int, height: int, **kw) -> Opts:
     o = Opts()
     lib().mi355_default_opts(C.byref(o), width, height)
     for k, v in kw.items():
-        setattr(o, k, v)
+        if k == "tune":
+            o.tune[:] = tune(**v) if isinstance(v, dict) else list(v)
+        else:
+            setattr(o, k, v)
     return o
+
+
+def tune(xmin=0, rmin=0, chunk=0, lmin=0, bpc=0, exact=0, rowmajor=0, nolds=0, coop_drain=0, scatter=0, coop_steps=0):
+    """mi355_opts::tune as a list (see include/mi355_render.h); every knob leaves the pixels unchanged."""
+    flags = (1 if exact else 0) | (2 if rowmajor else 0) | (4 if nolds else 0) | (16 if scatter else 0) | (32 if coop_drain else 0)
+    return [xmin, rmin, chunk, lmin, bpc, flags, coop_steps, 0]
 
 
 def device_count() -> int:

@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdarg>
@@ -16,9 +17,9 @@
 #include <vector>
 
 // kernel launchers (defined next to their kernels)
-extern "C" int mi355i_raytrace_blocks_per_cu(int stats);
-extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int n_blocks,
-                                             hipStream_t);
+extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int trav, int lds_bytes);
+extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int trav, int n_blocks,
+                                             int lds_bytes, hipStream_t);
 extern "C" hipError_t mi355i_launch_points(const DevScene *, const FrameParams *, int as_triangles, hipStream_t);
 struct RasterScratch;
 extern "C" hipError_t mi355i_launch_raster(const DevScene *, const FrameParams *, int mode, RasterScratch *,
@@ -90,9 +91,13 @@ struct mi355_ctx {
     std::vector<uint8_t> ttwo;
     bool has_bvh = false;
     // device
-    DevBuf nodes, tri_plane, tri_edge, tri_shade, rs_tri, rs_col, rs_idx, rs_vert;
+    DevBuf nodes, top_nodes, node_right, top_right, coop_queue, leafs, tri_edge, tri_shade, rs_tri, rs_col, rs_idx, rs_vert;
     DevBuf ctrl;            // [0] work counter (16 B) | counters[CS_COUNT]
     DevBuf fb, fbf;         // internal framebuffer for the host-output path
+    DevBuf tile_order;      // raytrace dispenser order (ensure_tile_order)
+    long long tile_key[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t coop_cap = 0;
+    bool boxes_tame = false; // every BVH box coordinate is 0 or within [1e-30, 1e17] in magnitude
     DevBuf smap[MI355_MAX_LIGHTS];
     int smap_size[MI355_MAX_LIGHTS] = {0, 0, 0, 0};
     RasterScratch *rscratch = nullptr;
@@ -134,6 +139,31 @@ int validate_opts(const mi355_opts &o, int mode)
     return 0;
 }
 
+// Dispenser order of the 8x8 pixel tiles of a raytraced frame: nearest to the screen centre first.
+// The benchmark camera (and any look-at camera) keeps the model around the centre, so the
+// expensive tiles are handed out first and the cheap background tiles fill the tail of the launch.
+int ensure_tile_order(mi355_ctx *c, const FrameParams &P)
+{
+    const long long key[6] = {P.W, P.H, P.n_rows, P.band_rows, P.band_index, P.band_count};
+    if (c->tile_order.p && !memcmp(key, c->tile_key, sizeof key)) return 0;
+    const int tiles_x = (P.W + 7) >> 3, tiles_y = (P.n_rows + 7) >> 3;
+    std::vector<std::pair<float, uint32_t>> t((size_t)tiles_x * tiles_y);
+    for (int ty = 0; ty < tiles_y; ty++) {
+        const int r = ty * 8 + 4 < P.n_rows ? ty * 8 + 4 : P.n_rows - 1;
+        const float y = (float)band_row_to_y(r, P.band_rows, P.band_index, P.band_count) - 0.5f * (float)P.H;
+        for (int tx = 0; tx < tiles_x; tx++) {
+            const float x = (float)(tx * 8 + 4) - 0.5f * (float)P.W;
+            t[(size_t)ty * tiles_x + tx] = {x * x + y * y, (uint32_t)(ty * tiles_x + tx)};
+        }
+    }
+    std::sort(t.begin(), t.end());
+    std::vector<uint32_t> order(t.size());
+    for (size_t i = 0; i < t.size(); i++) order[i] = t[i].second;
+    HIP_TRY(c->tile_order.upload(order), -31);
+    memcpy(c->tile_key, key, sizeof key);
+    return 0;
+}
+
 int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_light *lights, int n_lights,
                 const mi355_opts *o, void *d_out, int pitch_bytes, void *d_outf, FrameParams &P)
 {
@@ -167,11 +197,29 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.outf = (float *)d_outf;
     P.work_counter = (uint32_t *)c->ctrl.p;
     P.counters = (unsigned long long *)((char *)c->ctrl.p + 16);
-    // tuning knobs: variant = xmin | rmin<<8 | (chunk/64)<<16 ; 0 = defaults
-    const int v = o->variant;
-    P.xmin = (v & 0xff) ? (v & 0xff) : 12;
-    P.rmin = ((v >> 8) & 0xff) ? ((v >> 8) & 0xff) : 16;
-    P.chunk = ((v >> 16) & 0xff) ? ((v >> 16) & 0xff) * 64 : 256;
+    // tuning knobs (mi355_opts::tune, 0 = default)
+    const int32_t *t = o->tune;
+    const int flags = t[5];
+    P.xmin = t[0] > 0 ? (t[0] > 64 ? 64 : t[0]) : 12;
+    P.rmin = t[1] > 0 ? (t[1] > 64 ? 64 : t[1]) : 16;
+    P.chunk = t[2] > 0 ? t[2] : 64;
+    P.lmin = t[3] > 0 ? (t[3] > 64 ? 64 : t[3]) : 8;
+    P.blocks_per_cu = t[4] > 0 ? t[4] : 0;
+    P.trav = (flags & 1) ? 2 : 0;
+    if (!c->boxes_tame) P.trav = 2;          // box coordinates outside the filtered test's validated range
+    P.no_lds_top = (flags & 4) ? 1 : 0;
+    P.scatter = (flags & 16) ? 1 : 0;
+    P.coop_queue = (uint32_t *)c->coop_queue.p;
+    P.coop_cap = c->coop_cap;
+    // cooperative traversal: off unless asked for (flag 32 = drain mode, tune[6] > 0 = long-ray trigger)
+    P.coop_max = (flags & 32) ? 8 : 0;
+    P.coop_steps = t[6] > 0 ? t[6] : 0;
+    if (P.coop_max > 0 || P.coop_steps > 0) P.trav |= 4;
+    P.tile_order = nullptr;
+    if (mode >= MI355_MODE_RAYTRACE && !(flags & 2)) {
+        if (int r = ensure_tile_order(c, P)) return r;
+        P.tile_order = (const uint32_t *)c->tile_order.p;
+    }
     return 0;
 }
 
@@ -189,8 +237,38 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
         seen[triIdx[i]] = 1;
     }
     auto is_leaf = [&](uint32_t i) { return (rn[i].a & 0x80000000u) != 0; };
-    auto link = [&](uint32_t i) { return i == MI_END_LINK ? MI_END_LINK : (is_leaf(i) ? (i | MI_LEAF_BIT) : i); };
-    std::vector<float4> nodes((size_t)nN * 2);
+    // leaf blocks: header + one 32-byte plane record per triangle, in node order
+    std::vector<uint32_t> leaf_off(nN, 0);
+    size_t n4 = 0;
+    for (uint32_t i = 0; i < nN; i++)
+        if (is_leaf(i)) {
+            const uint32_t cnt = rn[i].a & 0x7fffffffu, first = rn[i].b;
+            if ((uint64_t)first + cnt > nI) return fail(-30, "BVH leaf %u exceeds the triangle list", i);
+            leaf_off[i] = (uint32_t)n4;
+            n4 += 1 + 2 * (size_t)cnt;
+        }
+    if (n4 + 8 >= 0x7fffffffull) return fail(-30, "BVH too large");
+    // breadth-first order of the inner nodes nearest the root: candidates for the per-workgroup LDS cache
+    std::vector<uint32_t> top_slot(nN, 0xffffffffu), top_list;
+    {
+        std::vector<uint32_t> q;
+        q.push_back(0);
+        for (size_t h = 0; h < q.size() && top_list.size() < MI_TOP_CAP; h++) {
+            const uint32_t i = q[h];
+            if (i >= nN || is_leaf(i) || top_slot[i] != 0xffffffffu) continue;
+            top_slot[i] = (uint32_t)top_list.size();
+            top_list.push_back(i);
+            if (rn[i].a < nN) q.push_back(rn[i].a);
+            if (rn[i].b < nN) q.push_back(rn[i].b);
+        }
+    }
+    auto link = [&](uint32_t i) {
+        if (i == MI_END_LINK) return MI_END_LINK;
+        if (is_leaf(i)) return leaf_off[i] | MI_LEAF_BIT;
+        return top_slot[i] != 0xffffffffu ? (top_slot[i] | MI_TOP_BIT) : i;
+    };
+    std::vector<float4> nodes((size_t)nN * 2, make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<float4> leafs(n4 + 8, make_float4(0.f, 0.f, 0.f, 0.f));     // +8: the kernel reads 4 records past a header
     std::vector<uint8_t> visited(nN, 0);
     struct Item { uint32_t node, escape; int depth; };
     std::vector<Item> st;
@@ -202,31 +280,39 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
         if (it.depth >= 64) return fail(-30, "BVH deeper than 64 levels");
         visited[it.node] = 1; nvis++;
         const RefNode &n = rn[it.node];
-        float4 lo, hi;
         if (!is_leaf(it.node)) {
             if (n.a >= nN || n.b >= nN) return fail(-30, "BVH child index out of range at node %u", it.node);
-            lo = make_float4(n.bottom[0], n.bottom[1], n.bottom[2], u2f(link(n.a)));
-            hi = make_float4(n.top[0], n.top[1], n.top[2], u2f(link(it.escape)));
+            nodes[(size_t)it.node * 2] = make_float4(n.bottom[0], n.bottom[1], n.bottom[2], u2f(link(n.a)));
+            nodes[(size_t)it.node * 2 + 1] = make_float4(n.top[0], n.top[1], n.top[2], u2f(link(it.escape)));
             st.push_back({n.b, it.escape, it.depth + 1});
             st.push_back({n.a, n.b, it.depth + 1});
         } else {
             const uint32_t cnt = n.a & 0x7fffffffu, first = n.b;
-            if ((uint64_t)first + cnt > nI) return fail(-30, "BVH leaf %u exceeds the triangle list", it.node);
-            lo = make_float4(u2f(first), u2f(cnt), 0.f, 0.f);
-            hi = make_float4(0.f, 0.f, 0.f, u2f(link(it.escape)));
+            float4 *blk = &leafs[leaf_off[it.node]];
+            blk[0] = make_float4(u2f(link(it.escape)), u2f(cnt), u2f(first), 0.f);
+            for (uint32_t k = 0; k < cnt; k++) {
+                const uint32_t t = (uint32_t)triIdx[first + k];
+                const float *nrm = &c->tnormal[3 * t], *cen = &c->tcenter[3 * t];
+                blk[1 + 2 * k] = make_float4(nrm[0], nrm[1], nrm[2], c->td[4 * t]);
+                blk[2 + 2 * k] = make_float4(cen[0], cen[1], cen[2], u2f(c->ttwo[t] ? 1u : 0u));
+            }
         }
-        nodes[(size_t)it.node * 2] = lo;
-        nodes[(size_t)it.node * 2 + 1] = hi;
     }
     if (nvis != nN) return fail(-30, "BVH has %u nodes but only %zu are reachable", nN, nvis);
+    bool tame = true;
+    for (uint32_t i = 0; i < nN && tame; i++)
+        if (!is_leaf(i))
+            for (int k = 0; k < 6; k++) {
+                const float x = fabsf(k < 3 ? rn[i].bottom[k] : rn[i].top[k - 3]);
+                if (!(x == 0.f || (x >= 1e-30f && x <= 1e17f))) { tame = false; break; }
+            }
+    c->boxes_tame = tame;
 
     const uint32_t T = c->nT;
-    std::vector<float4> plane((size_t)T * 2), edge((size_t)T * 3), shade((size_t)T * 5);
+    std::vector<float4> edge((size_t)T * 3), shade((size_t)T * 5);
     for (uint32_t j = 0; j < T; j++) {
         const uint32_t t = (uint32_t)triIdx[j];
-        const float *nrm = &c->tnormal[3 * t], *cen = &c->tcenter[3 * t], *d = &c->td[4 * t], *e = &c->te[9 * t];
-        plane[(size_t)j * 2] = make_float4(nrm[0], nrm[1], nrm[2], d[0]);
-        plane[(size_t)j * 2 + 1] = make_float4(cen[0], cen[1], cen[2], u2f(c->ttwo[t] ? 1u : 0u));
+        const float *d = &c->td[4 * t], *e = &c->te[9 * t];
         edge[(size_t)j * 3] = make_float4(e[0], e[1], e[2], d[1]);
         edge[(size_t)j * 3 + 1] = make_float4(e[3], e[4], e[5], d[2]);
         edge[(size_t)j * 3 + 2] = make_float4(e[6], e[7], e[8], d[3]);
@@ -244,12 +330,43 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
         }
         shade[(size_t)j * 5 + 4] = make_float4(c->tcolorf[3 * t], c->tcolorf[3 * t + 1], c->tcolorf[3 * t + 2], 0.f);
     }
+    std::vector<uint32_t> node_right(nN, MI_END_LINK), top_right(top_list.size() + 1, MI_END_LINK);
+    int max_depth = 0;
+    {
+        std::vector<std::pair<uint32_t, int>> dq;
+        dq.push_back({0u, 0});
+        while (!dq.empty()) {
+            auto [i, d] = dq.back(); dq.pop_back();
+            if (d > max_depth) max_depth = d;
+            if (!is_leaf(i)) { dq.push_back({rn[i].a, d + 1}); dq.push_back({rn[i].b, d + 1}); }
+        }
+    }
+    for (uint32_t i = 0; i < nN; i++)
+        if (!is_leaf(i)) {
+            node_right[i] = link(rn[i].b);
+            if (top_slot[i] != 0xffffffffu) top_right[top_slot[i]] = link(rn[i].b);
+        }
+    HIP_TRY(c->node_right.upload(node_right), -31);
+    HIP_TRY(c->top_right.upload(top_right), -31);
+    c->dev.node_right = (const uint32_t *)c->node_right.p;
+    c->dev.top_right = (const uint32_t *)c->top_right.p;
+    // cooperative-traversal LIFO: 64 newest items leave per round, so at most 64 leftovers per tree level + 128
+    c->coop_cap = 64u * (uint32_t)(max_depth + 4) + 128u;
+    HIP_TRY(c->coop_queue.ensure((size_t)c->coop_cap * 4u * 8u * (size_t)c->n_cus * 4u), -31);
+    std::vector<float4> top((size_t)top_list.size() * 2 + 2, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (size_t k = 0; k < top_list.size(); k++) {
+        top[2 * k] = nodes[(size_t)top_list[k] * 2];
+        top[2 * k + 1] = nodes[(size_t)top_list[k] * 2 + 1];
+    }
+    HIP_TRY(c->top_nodes.upload(top), -31);
+    c->dev.top_nodes = (const float4 *)c->top_nodes.p;
+    c->dev.n_top_cand = (uint32_t)top_list.size();
     HIP_TRY(c->nodes.upload(nodes), -31);
-    HIP_TRY(c->tri_plane.upload(plane), -31);
+    HIP_TRY(c->leafs.upload(leafs), -31);
     HIP_TRY(c->tri_edge.upload(edge), -31);
     HIP_TRY(c->tri_shade.upload(shade), -31);
     c->dev.nodes = (const float4 *)c->nodes.p;
-    c->dev.tri_plane = (const float4 *)c->tri_plane.p;
+    c->dev.leafs = (const float4 *)c->leafs.p;
     c->dev.tri_edge = (const float4 *)c->tri_edge.p;
     c->dev.tri_shade = (const float4 *)c->tri_shade.p;
     c->dev.root_link = link(0);
@@ -261,6 +378,8 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
 int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipStream_t st)
 {
     HIP_TRY(hipMemsetAsync(c->ctrl.p, 0, 16 + sizeof(unsigned long long) * CS_COUNT, st), -40);
+    if (stats)   // the two "min" time stamps start at all-ones
+        HIP_TRY(hipMemsetAsync((char *)c->ctrl.p + 16 + sizeof(unsigned long long) * CS_TIME0, 0xff, 2 * sizeof(unsigned long long), st), -40);
     c->last_stats = stats != 0;
     hipError_t e = hipSuccess;
     switch (mode) {
@@ -272,10 +391,22 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipSt
         break;
     case MI355_MODE_RAYTRACE: case MI355_MODE_RAYTRACE_ANTIALIAS: {
         if (!c->has_bvh) return fail(-41, "raytrace modes need mi355_scene_set_bvh first");
-        int n_blocks = mi355i_raytrace_blocks_per_cu(stats) * c->n_cus;
+        // Blocks per CU from registers alone, then give each block an equal share of the CU's 160 KB of LDS:
+        // 12 KB of per-lane colour columns + as many BFS-top node records as fit.
+        int per_cu = mi355i_raytrace_blocks_per_cu(stats, P.trav, 12288);
+        if (P.blocks_per_cu > 0 && P.blocks_per_cu < per_cu) per_cu = P.blocks_per_cu;
+        FrameParams &Pm = const_cast<FrameParams &>(P);
+        int lds_budget = (160 * 1024) / per_cu - 512;
+        if (lds_budget > 160 * 1024 - 1024) lds_budget = 160 * 1024 - 1024;
+        int n_top = (lds_budget - 12288) / 32;
+        if (n_top > (int)c->dev.n_top_cand) n_top = (int)c->dev.n_top_cand;
+        if (n_top < 0 || P.no_lds_top) n_top = 0;
+        Pm.n_top_lds = n_top;
+        const int lds_bytes = 12288 + n_top * 32;
+        int n_blocks = per_cu * c->n_cus;
         const long long lanes_needed = ((long long)P.W * P.n_rows + 255) / 256;
         if (n_blocks > lanes_needed) n_blocks = (int)(lanes_needed > 0 ? lanes_needed : 1);
-        e = mi355i_launch_raytrace(&c->dev, &P, stats, n_blocks, st);
+        e = mi355i_launch_raytrace(&c->dev, &P, stats, P.trav, n_blocks, lds_bytes, st);
         break;
     }
     case MI355_MODE_LINES:
@@ -393,8 +524,8 @@ void mi355_scene_destroy(mi355_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->nodes, &c->tri_plane, &c->tri_edge, &c->tri_shade, &c->rs_tri, &c->rs_col, &c->rs_idx,
-                      &c->rs_vert, &c->ctrl, &c->fb, &c->fbf})
+    for (DevBuf *b : {&c->nodes, &c->top_nodes, &c->node_right, &c->top_right, &c->coop_queue, &c->leafs, &c->tri_edge, &c->tri_shade, &c->rs_tri, &c->rs_col, &c->rs_idx,
+                      &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->tile_order})
         b->release();
     for (auto &m : c->smap) m.release();
     if (c->rscratch) mi355i_raster_scratch_destroy(c->rscratch);
@@ -463,6 +594,17 @@ int mi355_fetch_stats(mi355_ctx *c, mi355_stats *s)
     s->plane_pass = h[CS_PLANE_PASS]; s->shaded_hits = h[CS_SHADED_HITS];
     s->tris_drawn = h[CS_TRIS_DRAWN]; s->spans = h[CS_SPANS]; s->ztests = h[CS_ZTESTS]; s->plots = h[CS_PLOTS];
     if (h[CS_OVERFLOW]) return fail(-44, "rasterizer span buffer overflowed (%llu rows dropped)", h[CS_OVERFLOW]);
+    return 0;
+}
+
+// Not part of the public ABI: kernel phase profile of the last frame rendered with collect_stats
+// (20 words: total/refill/transition/inner/leaf cycles, iteration and lane-occupancy sums, wave count, LDS visits,
+// then 100 MHz stamps: launch start, dispenser dry, last wave end, and the largest per-wave iteration count).
+int mi355i_fetch_profile(mi355_ctx *c, unsigned long long *out16)
+{
+    if (!c || !out16) return fail(-3, "mi355i_fetch_profile: null argument");
+    if (int r = select_device(c)) return r;
+    HIP_TRY(hipMemcpy(out16, (char *)c->ctrl.p + 16 + sizeof(unsigned long long) * CS_PROF0, 20 * sizeof(unsigned long long), hipMemcpyDeviceToHost), -31);
     return 0;
 }
 

@@ -8,10 +8,10 @@
 // triangles of a leaf are contiguous:
 //
 //   nodes     [n_nodes][2] float4   traversal  (box + skip links)          32 B
-//   tri_plane [T][2]       float4   leaf test, first half (normal,d,centre) 32 B
+//   leafs     [...]        float4   per leaf: header + its triangles' plane records (normal,d,centre) 16+32n B
 //   tri_edge  [T][3]       float4   leaf test, second half (e1..e3,d1..d3)  48 B
 //   tri_shade [T][5]       float4   closest-hit shading                     80 B
-//   (all three tri_* streams are in LEAF ORDER = position in triIndexList)
+//   (leaf blocks and both tri_* streams are in LEAF ORDER = position in triIndexList)
 //
 //   rs_tri    [T][2]  float4 + [T] uint4   rasterizer: centre/normal/colour + vertex ids, input order
 //   rs_vert   [V][2]  float4               rasterizer: position+ao, normal
@@ -21,21 +21,30 @@
 
 #define MI_END_LINK 0x7fffffffu   // traversal finished
 #define MI_LEAF_BIT 0x80000000u   // link target is a leaf
+#define MI_TOP_BIT  0x40000000u   // link target is an inner node of the BFS-top set: low bits = slot in top_nodes
+#define MI_TOP_CAP  4608u         // candidates kept in top_nodes (144 KB); a launch caches a prefix of them in LDS
 
 #define MI_MAX_LIGHTS 4
 #define MI_MAX_DEPTH 4
 
 // Node record (32 B):
 //   inner: lo = (bmin.xyz, link_if_hit)   hi = (bmax.xyz, link_if_miss)
-//   leaf : lo = (first, count, -, -)      hi = (-, -, -, link_next)
-// A link is a node index with MI_LEAF_BIT set when the target is a leaf, or MI_END_LINK.
+//   (leaf nodes keep their slot in the array but are never read: a leaf is reached through a link)
+// A link is an inner node's index in `nodes`, or MI_TOP_BIT | slot for one of the MI_TOP_CAP inner nodes
+// nearest the root (kept in breadth-first order in `top_nodes`; each workgroup copies a prefix of
+// that array into LDS and serves those visits from there), or MI_LEAF_BIT | float4-offset of a
+// leaf block in `leafs`, or MI_END_LINK.  A leaf block's header carries the link to follow after the leaf.
 // link_if_hit is the left child, link_if_miss / link_next is the next node of the
 // reference's depth-first, left-first order (Raytracer.cc:217-230) that is not below this
 // one -- so following links visits exactly the nodes the reference pops, in the same order,
 // without a stack.
 struct DevScene {
     const float4 *nodes;
-    const float4 *tri_plane;
+    const float4 *top_nodes;  // the first n_top_cand inner nodes in breadth-first order, same 32-B records
+    uint32_t n_top_cand;
+    const uint32_t *node_right; // [n_nodes] link of an inner node's right child (cooperative traversal only)
+    const uint32_t *top_right;  // [n_top_cand] the same for top_nodes slots
+    const float4 *leafs;      // packed leaf blocks: [next link, count, first tri, -][plane records...]
     const float4 *tri_edge;
     const float4 *tri_shade;
     uint32_t root_link;
@@ -73,11 +82,23 @@ struct FrameParams {
     int32_t xmin;              // service state transitions once this many lanes wait (or nobody traverses)
     int32_t rmin;              // refill once this many lanes are idle (or nobody is alive)
     int32_t chunk;             // pixel indices a wave takes from the dispenser at a time
+    int32_t trav;              // bit 1: exact box test only (bit 0 unused)
+    int32_t lmin;              // leaf postponement: test leaves once this many lanes wait on one (1 = if-if)
+    int32_t n_top_lds;         // top_nodes records cached in LDS by this launch (prefix length)
+    int32_t no_lds_top;        // tuning: disable the LDS cache of the BVH top
+    int32_t scatter;           // dispenser hands out pixel slot s of every tile before slot s+1 (load balance)
+    uint32_t *coop_queue;      // per-wave LIFO regions of coop_cap links for the cooperative drain traversal
+    uint32_t coop_cap;
+    int32_t coop_max;          // switch a wave to cooperative traversal when <= this many rays remain (0 = never)
+    int32_t coop_steps;        // finish a ray cooperatively once it has made this many node visits (0 = never)
+    const uint32_t *tile_order; // dispenser index -> 8x8 tile id (heavy tiles first), or NULL = row-major
+    int32_t blocks_per_cu;     // 0 = occupancy query
 };
 
 enum CounterSlot {
     CS_NORMAL_RAYS = 0, CS_SHADOW_RAYS, CS_NODE_POPS, CS_INNER_HITS, CS_TRI_TESTS, CS_PLANE_PASS,
-    CS_SHADED_HITS, CS_TRIS_DRAWN, CS_SPANS, CS_ZTESTS, CS_PLOTS, CS_OVERFLOW, CS_COUNT
+    CS_SHADED_HITS, CS_TRIS_DRAWN, CS_SPANS, CS_ZTESTS, CS_PLOTS, CS_OVERFLOW,
+    CS_PROF0, CS_TIME0 = CS_PROF0 + 16, CS_COUNT = CS_TIME0 + 4   // phase profile + time stamps (counting builds only)
 };
 
 // compact row r (0..n_rows) -> screen row y for the band sharding of mi355_opts

@@ -1,0 +1,51 @@
+"""Worker for test_multigpu_cpu.py: world_size-N gloo run of the band-shard + gather + de-interleave path.
+
+The pixels come from the CPU oracle here (this is a CPU test of the distributed plumbing in
+renderer_amd/multigpu.py, which is backend-agnostic); on GPUs the same FrameGatherer moves buffers that
+mi355_render_device filled."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle_ctypes as O          # noqa: E402
+from renderer_amd import assets, multigpu      # noqa: E402
+
+
+def main():
+    out_path, W, H, frames = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    s = O.Scene(assets.mesh_path("dragon_vis.ply"))
+    s.bvh_ensure(os.path.join(assets.cache_dir(), "dragon_vis.ply.oracle.bvh"))
+    g = multigpu.FrameGatherer(W, H, torch.device("cpu"))
+    assert g.my_rows == multigpu.rows_of_rank(H, multigpu.BAND_ROWS, world, rank)
+    ok = True
+    for k in range(frames):
+        cam, lights, n = O.benchmark_frame(k)
+        o = O.default_opts(W, H, band_rows=multigpu.BAND_ROWS, band_index=rank, band_count=world)
+        img, _, _ = s.render(9, cam, lights, n, o)
+        ys = np.arange(H)
+        mine = (ys // multigpu.BAND_ROWS) % world == rank
+        buf = g.send_buffer(k & 1)
+        buf.zero_()
+        buf[: g.my_rows] = torch.from_numpy(img[mine].astype(np.int32))
+        g.gather(k & 1)                      # async; next frame renders meanwhile
+        if rank == 0:
+            full, _, _ = s.render(9, cam, lights, n, O.default_opts(W, H))
+            got = g.frame(k & 1).numpy().astype(np.uint32)
+            ok = ok and bool(np.array_equal(got, full)) and int((full != 0).sum()) > 0
+    g.drain()
+    dist.barrier()
+    if rank == 0:
+        open(out_path, "w").write("OK" if ok else "MISMATCH")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

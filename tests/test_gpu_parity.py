@@ -40,7 +40,7 @@ def both_frames(oracle, oracle_scene, gpu_scene, mesh, mode, W, H, frame=0, seco
     cam, lights, n = R.benchmark_frame(frame, second_light)
     ocam, olights, on = oracle.benchmark_frame(frame, second_light)
     ho = R.default_opts(W, H, **optkw)
-    oo = oracle.default_opts(W, H, threads=NCPU, **{k: v for k, v in optkw.items() if k != "collect_stats"})
+    oo = oracle.default_opts(W, H, threads=NCPU, **{k: v for k, v in optkw.items() if k not in ("collect_stats", "tune")})
     maps = None
     if mode in (7, 8):
         maps = [osc.shadowmap(olights[i]) for i in range(on)]
@@ -125,9 +125,16 @@ def test_raytrace_ragged_sizes(oracle, oracle_scene, gpu_scene, size):
     assert_same(g, o)
 
 
-@pytest.mark.parametrize("variant", [1 | (1 << 8) | (1 << 16), 32 | (48 << 8) | (8 << 16), 64 | (64 << 8) | (64 << 16)])
-def test_raytrace_tuning_knobs_do_not_change_pixels(oracle, oracle_scene, gpu_scene, variant):
-    g, o = both_frames(oracle, oracle_scene, gpu_scene, "dragon_vis.ply", 9, 640, 360, 9, variant=variant)
+@pytest.mark.parametrize("knobs", [
+    dict(xmin=1, rmin=1, chunk=64, lmin=1), dict(xmin=32, rmin=48, chunk=512, lmin=64), dict(xmin=64, rmin=64, chunk=4096),
+    dict(exact=1), dict(rowmajor=1, nolds=1), dict(coop_drain=1), dict(coop_steps=1), dict(coop_steps=16, lmin=16),
+    dict(scatter=1, coop_steps=32), dict(bpc=1, coop_steps=8, coop_drain=1), dict(bpc=2, nolds=1, exact=1, coop_steps=4)],
+    ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
+def test_raytrace_tuning_knobs_do_not_change_pixels(oracle, oracle_scene, gpu_scene, knobs):
+    """Scheduling knobs (incl. the wave-cooperative traversal and the filtered box test) are invisible in the output."""
+    g, o = both_frames(oracle, oracle_scene, gpu_scene, "dragon_vis.ply", 9, 640, 360, 9, want_f32=True, tune=knobs)
+    assert_same(g, o)
+    g, o = both_frames(oracle, oracle_scene, gpu_scene, "statue.ply", 9, 320, 180, 3, want_f32=True, tune=knobs)
     assert_same(g, o)
 
 
