@@ -219,14 +219,28 @@ def main():
             osc = O.Scene(R.assets.mesh_path(args.mesh))
             if args.mode >= 9:
                 osc.bvh_ensure(os.path.join(R.assets.cache_dir(), args.mesh + ".oracle.bvh"))
-            oo = O.default_opts(W, H, threads=ncpu)
+            # the port scales to a box-dependent thread count (OpenMP over scanlines, like the reference): probe
+            # a few counts on frame 0 and time the sample with the fastest one
             maps = None
+            ocam, olights, on = O.benchmark_frame(0)
+            if args.mode in (7, 8):
+                maps = [osc.shadowmap(olights[0])]
+            best_t, best_dt = 1, None
+            for t in sorted({1, 8, 16, 32, 64, ncpu}):
+                if t > ncpu:
+                    continue
+                ot = O.default_opts(W, H, threads=t)
+                osc.render(args.mode, ocam, olights, on, ot, shadow_maps=maps)
+                t1 = time.perf_counter()
+                osc.render(args.mode, ocam, olights, on, ot, shadow_maps=maps)
+                d = time.perf_counter() - t1
+                if best_dt is None or d < best_dt:
+                    best_t, best_dt = t, d
+            oo = O.default_opts(W, H, threads=best_t)
             done_rays, done_frames, t_cpu = 0.0, 0, 0.0
             k = 0
             while t_cpu < args.cpu_seconds and k < K:
                 ocam, olights, on = O.benchmark_frame(k)
-                if args.mode in (7, 8) and maps is None:
-                    maps = [osc.shadowmap(olights[0])]
                 t1 = time.perf_counter()
                 _, _, st = osc.render(args.mode, ocam, olights, on, oo, shadow_maps=maps)
                 t_cpu += time.perf_counter() - t1
@@ -234,9 +248,10 @@ def main():
                 done_frames += 1
                 k += 1
             result["cpu_baseline"] = {
-                "value": round(done_rays / t_cpu / 1e6, 3), "unit": "Mrays/s", "cores": ncpu, "kind": "port",
+                "value": round(done_rays / t_cpu / 1e6, 3), "unit": "Mrays/s", "cores": best_t, "kind": "port",
                 "sample": "oracle (strict-IEEE C++ port of the reference, OpenMP over pixels like Raytracer.cc:558) on "
-                          "frames f0..f%d of the same workload, %.1f s" % (done_frames - 1, t_cpu),
+                          "frames f0..f%d of the same workload, %.1f s; %d threads = fastest of a probe over {1,8,16,32,64,%d} on this %d-thread host"
+                          % (done_frames - 1, t_cpu, best_t, ncpu, ncpu),
                 "frames_per_sec": round(done_frames / t_cpu, 3),
             }
         except Exception as e:

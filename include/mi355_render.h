@@ -86,9 +86,8 @@ typedef struct {
      * [3] lmin   lanes gathered on leaves before the triangle tests run
      * [4] blocks per CU (0 = occupancy query)
      * [5] flags  1 exact box test only | 2 row-major tile order | 4 no LDS BVH-top cache |
-     *            16 scattered pixel dispensing | 32 wave-cooperative traversal of a wave's last rays
-     * [6] coop_steps  > 0: a ray longer than this many node visits is finished wave-cooperatively
-     * [7] reserved */
+     *            8 no walk splitting over idle lanes | 16 scattered pixel dispensing
+     * [6], [7] reserved */
     int32_t tune[8];
 } mi355_opts;
 

@@ -618,7 +618,7 @@ static void render_raytrace(const orc_scene &s, const orc_camera &cam, const orc
         RtCtx c; c.s = &s; c.o = &o; c.eye = eye; c.lights = lights; c.nLights = nLights;
         memset(&c.st, 0, sizeof c.st);
 #ifdef _OPENMP
-#pragma omp for schedule(dynamic, 4) collapse(1)
+#pragma omp for schedule(dynamic, 1)
 #endif
         for (int y = 0; y < H; y++) {
             if (!row_selected(o, y)) continue;

@@ -91,12 +91,13 @@ struct mi355_ctx {
     std::vector<uint8_t> ttwo;
     bool has_bvh = false;
     // device
-    DevBuf nodes, top_nodes, node_right, top_right, coop_queue, leafs, tri_edge, tri_shade, rs_tri, rs_col, rs_idx, rs_vert;
+    DevBuf nodes, top_nodes, node_right, top_right, leafs, tri_edge, tri_shade, rs_tri, rs_col, rs_idx, rs_vert;
     DevBuf ctrl;            // [0] work counter (16 B) | counters[CS_COUNT]
     DevBuf fb, fbf;         // internal framebuffer for the host-output path
     DevBuf tile_order;      // raytrace dispenser order (ensure_tile_order)
+    DevBuf wave_prof;       // per-wave phase profile of counting launches (debug)
+    int last_blocks = 0;
     long long tile_key[6] = {0, 0, 0, 0, 0, 0};
-    uint32_t coop_cap = 0;
     bool boxes_tame = false; // every BVH box coordinate is 0 or within [1e-30, 1e17] in magnitude
     DevBuf smap[MI355_MAX_LIGHTS];
     int smap_size[MI355_MAX_LIGHTS] = {0, 0, 0, 0};
@@ -200,8 +201,8 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     // tuning knobs (mi355_opts::tune, 0 = default)
     const int32_t *t = o->tune;
     const int flags = t[5];
-    P.xmin = t[0] > 0 ? (t[0] > 64 ? 64 : t[0]) : 12;
-    P.rmin = t[1] > 0 ? (t[1] > 64 ? 64 : t[1]) : 16;
+    P.xmin = t[0] > 0 ? (t[0] > 64 ? 64 : t[0]) : 24;
+    P.rmin = t[1] > 0 ? (t[1] > 64 ? 64 : t[1]) : 32;
     P.chunk = t[2] > 0 ? t[2] : 64;
     P.lmin = t[3] > 0 ? (t[3] > 64 ? 64 : t[3]) : 8;
     P.blocks_per_cu = t[4] > 0 ? t[4] : 0;
@@ -209,12 +210,11 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     if (!c->boxes_tame) P.trav = 2;          // box coordinates outside the filtered test's validated range
     P.no_lds_top = (flags & 4) ? 1 : 0;
     P.scatter = (flags & 16) ? 1 : 0;
-    P.coop_queue = (uint32_t *)c->coop_queue.p;
-    P.coop_cap = c->coop_cap;
-    // cooperative traversal: off unless asked for (flag 32 = drain mode, tune[6] > 0 = long-ray trigger)
-    P.coop_max = (flags & 32) ? 8 : 0;
-    P.coop_steps = t[6] > 0 ? t[6] : 0;
-    if (P.coop_max > 0 || P.coop_steps > 0) P.trav |= 4;
+    if (!(flags & 8)) P.trav |= 4;           // flag 8 disables walk splitting in the drain phase
+    P.wave_prof = nullptr;
+    if (o->collect_stats) {
+        if (c->wave_prof.ensure((size_t)8 * c->n_cus * 4 * 16 * 8) == hipSuccess) P.wave_prof = (unsigned long long *)c->wave_prof.p;
+    }
     P.tile_order = nullptr;
     if (mode >= MI355_MODE_RAYTRACE && !(flags & 2)) {
         if (int r = ensure_tile_order(c, P)) return r;
@@ -350,9 +350,6 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
     HIP_TRY(c->top_right.upload(top_right), -31);
     c->dev.node_right = (const uint32_t *)c->node_right.p;
     c->dev.top_right = (const uint32_t *)c->top_right.p;
-    // cooperative-traversal LIFO: 64 newest items leave per round, so at most 64 leftovers per tree level + 128
-    c->coop_cap = 64u * (uint32_t)(max_depth + 4) + 128u;
-    HIP_TRY(c->coop_queue.ensure((size_t)c->coop_cap * 4u * 8u * (size_t)c->n_cus * 4u), -31);
     std::vector<float4> top((size_t)top_list.size() * 2 + 2, make_float4(0.f, 0.f, 0.f, 0.f));
     for (size_t k = 0; k < top_list.size(); k++) {
         top[2 * k] = nodes[(size_t)top_list[k] * 2];
@@ -406,6 +403,8 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipSt
         int n_blocks = per_cu * c->n_cus;
         const long long lanes_needed = ((long long)P.W * P.n_rows + 255) / 256;
         if (n_blocks > lanes_needed) n_blocks = (int)(lanes_needed > 0 ? lanes_needed : 1);
+        c->last_blocks = n_blocks;
+        if (P.wave_prof) HIP_TRY(hipMemsetAsync(c->wave_prof.p, 0, (size_t)n_blocks * 4 * 16 * 8, st), -40);
         e = mi355i_launch_raytrace(&c->dev, &P, stats, P.trav, n_blocks, lds_bytes, st);
         break;
     }
@@ -524,8 +523,8 @@ void mi355_scene_destroy(mi355_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->nodes, &c->top_nodes, &c->node_right, &c->top_right, &c->coop_queue, &c->leafs, &c->tri_edge, &c->tri_shade, &c->rs_tri, &c->rs_col, &c->rs_idx,
-                      &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->tile_order})
+    for (DevBuf *b : {&c->nodes, &c->top_nodes, &c->node_right, &c->top_right, &c->leafs, &c->tri_edge, &c->tri_shade, &c->rs_tri, &c->rs_col, &c->rs_idx,
+                      &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->tile_order, &c->wave_prof})
         b->release();
     for (auto &m : c->smap) m.release();
     if (c->rscratch) mi355i_raster_scratch_destroy(c->rscratch);
@@ -606,6 +605,17 @@ int mi355i_fetch_profile(mi355_ctx *c, unsigned long long *out16)
     if (int r = select_device(c)) return r;
     HIP_TRY(hipMemcpy(out16, (char *)c->ctrl.p + 16 + sizeof(unsigned long long) * CS_PROF0, 20 * sizeof(unsigned long long), hipMemcpyDeviceToHost), -31);
     return 0;
+}
+
+// debug: per-wave profiles of the last counting raytrace launch; returns the number of waves written
+int mi355i_fetch_wave_profiles(mi355_ctx *c, unsigned long long *out, int max_waves)
+{
+    if (!c || !out || !c->wave_prof.p) return fail(-3, "no wave profile");
+    if (int r = select_device(c)) return r;
+    int n = c->last_blocks * 4;
+    if (n > max_waves) n = max_waves;
+    HIP_TRY(hipMemcpy(out, c->wave_prof.p, (size_t)n * 16 * 8, hipMemcpyDeviceToHost), -31);
+    return n;
 }
 
 int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_light *lights, int n_lights,

@@ -42,7 +42,7 @@ struct DevScene {
     const float4 *nodes;
     const float4 *top_nodes;  // the first n_top_cand inner nodes in breadth-first order, same 32-B records
     uint32_t n_top_cand;
-    const uint32_t *node_right; // [n_nodes] link of an inner node's right child (cooperative traversal only)
+    const uint32_t *node_right; // [n_nodes] link of an inner node's right child (kept for tools; the traversal follows hit/miss links)
     const uint32_t *top_right;  // [n_top_cand] the same for top_nodes slots
     const float4 *leafs;      // packed leaf blocks: [next link, count, first tri, -][plane records...]
     const float4 *tri_edge;
@@ -82,15 +82,12 @@ struct FrameParams {
     int32_t xmin;              // service state transitions once this many lanes wait (or nobody traverses)
     int32_t rmin;              // refill once this many lanes are idle (or nobody is alive)
     int32_t chunk;             // pixel indices a wave takes from the dispenser at a time
-    int32_t trav;              // bit 1: exact box test only (bit 0 unused)
+    int32_t trav;              // bit 1: exact box test only; bit 2: split long walks over idle lanes
     int32_t lmin;              // leaf postponement: test leaves once this many lanes wait on one (1 = if-if)
     int32_t n_top_lds;         // top_nodes records cached in LDS by this launch (prefix length)
     int32_t no_lds_top;        // tuning: disable the LDS cache of the BVH top
     int32_t scatter;           // dispenser hands out pixel slot s of every tile before slot s+1 (load balance)
-    uint32_t *coop_queue;      // per-wave LIFO regions of coop_cap links for the cooperative drain traversal
-    uint32_t coop_cap;
-    int32_t coop_max;          // switch a wave to cooperative traversal when <= this many rays remain (0 = never)
-    int32_t coop_steps;        // finish a ray cooperatively once it has made this many node visits (0 = never)
+    unsigned long long *wave_prof; // counting builds: 16 words of phase profile per wave (debug), or NULL
     const uint32_t *tile_order; // dispenser index -> 8x8 tile id (heavy tiles first), or NULL = row-major
     int32_t blocks_per_cu;     // 0 = occupancy query
 };

@@ -19,8 +19,11 @@
 //                (`start += dLR`, serial) and does a 64-bit atomicMax of (zbits << 32 | ~tri).
 //                Only z > 0 can pass the reference's test against the cleared buffer, and
 //                positive floats order like their bit patterns.
-//   k_rs_shade : 1 lane / span row.  Walks all interpolants again and shades ONLY the fragment
-//                whose key won -- the reference shades every Z-pass (~2x overdraw).
+//   k_rs_attr  : 1 lane / span row.  Walks all interpolants again and stores the fat point of the
+//                fragment whose key won into a per-pixel G-buffer (2 x float4).
+//   k_rs_shade : 1 lane / PIXEL.  Plot<> / IlluminatePixel / LightingEquation on the stored fat point,
+//                fully parallel and coalesced; only winners are shaded (the reference shades every
+//                Z-pass, ~2x overdraw).
 //
 // The shadow map is a pure max of 1/z (order independent): same setup, 32-bit atomicMax on an
 // order-preserving float key.
@@ -39,6 +42,7 @@ struct RowRec {            // 80 B
 
 struct RasterScratch {
     unsigned long long *keys = nullptr; size_t keys_words = 0;
+    float4 *gbuf = nullptr;        // [pixels][2] interpolated fat point of the winning fragment
     RowRec *rows = nullptr; uint32_t rows_cap = 0;
     uint32_t *ctl = nullptr;       // [0] rows used, [1] rows dropped because the span buffer was full
     uint32_t *smkeys = nullptr; size_t sm_words = 0;
@@ -319,49 +323,35 @@ __global__ void __launch_bounds__(128) k_rs_setup(const DevScene S, const FrameP
 
 // ---------------------------------------------------------------------------------------------
 // Span walk, shared by the depth and shade passes (Screen.h:244-290)
-template <int MODE, bool SHADE>
+template <int MODE, bool ATTR>
 __global__ void __launch_bounds__(256) k_rs_spans(const DevScene S, const FrameParams P, const RowRec *rows,
-                                                  const uint32_t *ctl, unsigned long long *keys)
+                                                  const uint32_t *ctl, unsigned long long *keys, float4 *gbuf)
 {
     constexpr int N = FatN<MODE>::N;
     constexpr int ZI = (MODE == M_AMBIENT || MODE == M_GOURAUD) ? 1 : 3;
     uint32_t n_rows = ctl[0];
     if (n_rows > P.rows_cap) n_rows = P.rows_cap;       // allocation overshoot of dropped triangles
     const int W = P.W;
-    unsigned long long ztests = 0, plots = 0;
+    unsigned long long ztests = 0;
     for (uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x; ri < n_rows; ri += gridDim.x * blockDim.x) {
         const RowRec &R = rows[ri];
         const int y = R.y;
-        const int orow = out_row(P, y);
-        if (orow < 0) continue;
-        const uint32_t tri = R.tri;
-        const unsigned long long trikey = (unsigned long long)(0xffffffffu - tri);
-        float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (SHADE && MODE >= M_PHONG) col = S.rs_col[tri];
+        if (out_row(P, y) < 0) continue;
+        const unsigned long long trikey = (unsigned long long)(0xffffffffu - R.tri);
 
-        // z-test / plot of one fragment
+        // z-test (pass 1) / capture of the winner's interpolants (pass 2) for one fragment
         auto frag = [&](int x, const float (&v)[N]) {
             const float z = v[ZI];
             if (!(z > 0.f)) return;                       // cannot beat the cleared Z-buffer (Screen.h:209)
             const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | trikey;
-            unsigned long long *kp = &keys[(size_t)y * W + x];
-            if (!SHADE) { atomicMax(kp, key); return; }
-            if (*kp != key) return;
-            plots++;
-            uint32_t out;
-            if constexpr (MODE == M_AMBIENT || MODE == M_GOURAUD) {       // Screen.cc:34-56
-                out = pack_xrgb(v[4], v[3], v[2]);
-            } else {                                                      // IlluminatePixel, Screen.cc:77-93
-                f3 point = mk3(v[1], v[2], v[3]);
-                point.x /= point.z; point.y /= point.z; point.z = 1.0f / point.z;
-                const f3 normal = norm3(mk3(v[5], v[6], v[7]));
-                float r, g, b;
-                if (MODE == M_PHONG) compute_pixel<SH_NONE>(P, point, normal, col.x, col.y, col.z, v[4], r, g, b);
-                else if (MODE == M_PHONG_SH) compute_pixel<SH_HARD>(P, point, normal, col.x, col.y, col.z, v[4], r, g, b);
-                else compute_pixel<SH_SOFT>(P, point, normal, col.x, col.y, col.z, v[4], r, g, b);
-                out = pack_xrgb(r, g, b);
-            }
-            P.out[(size_t)orow * P.pitch_words + x] = out;
+            const size_t pix = (size_t)y * W + x;
+            if (!ATTR) { atomicMax(&keys[pix], key); return; }
+            if (keys[pix] != key) return;
+            float4 g0, g1;
+            g0 = make_float4(v[0], v[1], v[2], v[3]);
+            if constexpr (N == 5) g1 = make_float4(v[4], 0.f, 0.f, 0.f);
+            else g1 = make_float4(v[4], v[5], v[6], v[7]);
+            gbuf[pix * 2] = g0; gbuf[pix * 2 + 1] = g1;
         };
 
         float start[N];
@@ -401,14 +391,50 @@ __global__ void __launch_bounds__(256) k_rs_spans(const DevScene S, const FrameP
             ztests++; frag(x1, start);
         }
     }
-    if (P.counters && (ztests | plots)) {
-        if (!SHADE) atomicAdd(&P.counters[CS_ZTESTS], ztests);
-        else atomicAdd(&P.counters[CS_PLOTS], plots);
+    if (P.counters && !ATTR) {
+        if (ztests) atomicAdd(&P.counters[CS_ZTESTS], ztests);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            atomicAdd(&P.counters[CS_SPANS], (unsigned long long)n_rows);
+            if (ctl[1]) atomicAdd(&P.counters[CS_OVERFLOW], (unsigned long long)ctl[1]);
+        }
     }
-    if (P.counters && !SHADE && blockIdx.x == 0 && threadIdx.x == 0) {
-        atomicAdd(&P.counters[CS_SPANS], (unsigned long long)n_rows);
-        if (ctl[1]) atomicAdd(&P.counters[CS_OVERFLOW], (unsigned long long)ctl[1]);
+}
+
+// Per-pixel shading of the winning fragment: Screen::Plot<> (Screen.cc:34-56) for the colour-interpolating
+// modes, IlluminatePixel + LightingEquation (Screen.cc:77-93, LightingEq.h:45-170) for the Phong modes.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_rs_shade(const DevScene S, const FrameParams P, const unsigned long long *keys,
+                                                  const float4 *gbuf)
+{
+    const int W = P.W;
+    const long n = (long)W * P.H;
+    unsigned long long plots = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const unsigned long long key = keys[i];
+        if (!key) continue;
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        const int orow = out_row(P, y);
+        if (orow < 0) continue;
+        const uint32_t tri = 0xffffffffu - (uint32_t)(key & 0xffffffffull);
+        const float4 g0 = gbuf[i * 2], g1 = gbuf[i * 2 + 1];
+        uint32_t out;
+        if constexpr (MODE == M_AMBIENT || MODE == M_GOURAUD) {
+            out = pack_xrgb(g1.x, g0.w, g0.z);              // v[4]=r, v[3]=g, v[2]=b
+        } else {
+            const float4 col = S.rs_col[tri];
+            f3 point = mk3(g0.y, g0.z, g0.w);               // x/z, y/z, 1/z
+            point.x /= point.z; point.y /= point.z; point.z = 1.0f / point.z;
+            const f3 normal = norm3(mk3(g1.y, g1.z, g1.w));
+            float r, g, b;
+            if (MODE == M_PHONG) compute_pixel<SH_NONE>(P, point, normal, col.x, col.y, col.z, g1.x, r, g, b);
+            else if (MODE == M_PHONG_SH) compute_pixel<SH_HARD>(P, point, normal, col.x, col.y, col.z, g1.x, r, g, b);
+            else compute_pixel<SH_SOFT>(P, point, normal, col.x, col.y, col.z, g1.x, r, g, b);
+            out = pack_xrgb(r, g, b);
+        }
+        P.out[(size_t)orow * P.pitch_words + x] = out;
+        plots++;
     }
+    if (P.counters && plots) atomicAdd(&P.counters[CS_PLOTS], plots);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -492,6 +518,7 @@ extern "C" void mi355i_raster_scratch_destroy(RasterScratch *s)
 {
     if (!s) return;
     if (s->keys) (void)hipFree(s->keys);
+    if (s->gbuf) (void)hipFree(s->gbuf);
     if (s->rows) (void)hipFree(s->rows);
     if (s->ctl) (void)hipFree(s->ctl);
     if (s->smkeys) (void)hipFree(s->smkeys);
@@ -503,8 +530,12 @@ static hipError_t scratch_ensure(RasterScratch *s, size_t key_words, size_t sm_w
     hipError_t e;
     if (key_words > s->keys_words) {
         if (s->keys) (void)hipFree(s->keys);
+    if (s->gbuf) (void)hipFree(s->gbuf);
         s->keys = nullptr; s->keys_words = 0;
         if ((e = hipMalloc((void **)&s->keys, key_words * 8)) != hipSuccess) return e;
+        if (s->gbuf) (void)hipFree(s->gbuf);
+        s->gbuf = nullptr;
+        if ((e = hipMalloc((void **)&s->gbuf, key_words * 32)) != hipSuccess) return e;
         s->keys_words = key_words;
     }
     if (sm_words > s->sm_words) {
@@ -541,8 +572,9 @@ static hipError_t raster_frame(const DevScene *S, const FrameParams *Pin, Raster
     const FrameParams *P = &Pv;
     const int nbT = (int)((S->n_tris + 127) / 128);
     hipLaunchKernelGGL((k_rs_setup<MODE>), dim3(nbT > 0 ? nbT : 1), dim3(128), 0, st, *S, *P, s->rows, s->rows_cap, s->ctl);
-    hipLaunchKernelGGL((k_rs_spans<MODE, false>), dim3(2048), dim3(256), 0, st, *S, *P, s->rows, s->ctl, s->keys);
-    hipLaunchKernelGGL((k_rs_spans<MODE, true>), dim3(2048), dim3(256), 0, st, *S, *P, s->rows, s->ctl, s->keys);
+    hipLaunchKernelGGL((k_rs_spans<MODE, false>), dim3(2048), dim3(256), 0, st, *S, *P, s->rows, s->ctl, s->keys, s->gbuf);
+    hipLaunchKernelGGL((k_rs_spans<MODE, true>), dim3(2048), dim3(256), 0, st, *S, *P, s->rows, s->ctl, s->keys, s->gbuf);
+    hipLaunchKernelGGL((k_rs_shade<MODE>), dim3(2048), dim3(256), 0, st, *S, *P, s->keys, s->gbuf);
     return hipGetLastError();
 }
 

@@ -44,7 +44,9 @@ struct Lane {
     f3 o, d;
     f3 inv;                // rcp(d) per component, for the filtered box test
     bool tame;             // ray_is_tame(d)
-    int steps;             // node visits of the current ray (long rays are finished cooperatively)
+    uint32_t end;          // link at which this lane's share of the walk stops (MI_END_LINK for a whole ray)
+    int owner;             // helper lanes: lane id of the ray's owner; -1 on the owner itself
+    int pending;           // owner lanes: helpers still walking parts of the current ray
     int avoid;             // leaf-order index of the triangle to skip (avoidSelf), -1 = none
     float best;            // bestTriDist
     int btri;              // closest triangle so far (leaf order), -1 = none
@@ -140,7 +142,7 @@ MI_DEV void set_ray_aux(Lane &L)
 {
     L.inv = mk3(__builtin_amdgcn_rcpf(L.d.x), __builtin_amdgcn_rcpf(L.d.y), __builtin_amdgcn_rcpf(L.d.z));
     L.tame = ray_is_tame(L.o, L.d);
-    L.steps = 0;
+    L.end = MI_END_LINK; L.owner = -1; L.pending = 0;       // a fresh ray: whole walk, no helpers
 }
 
 // Primary ray of pixel (px,py), sample index `traced` (Raytracer.cc:563-593)
@@ -236,48 +238,49 @@ MI_DEV void shade_begin(const FrameParams &P, const DevScene &S, Lane &L)
     L.li = 0;
 }
 
-// Inner-node visit (Raytracer.cc:222-230): box test, then follow the hit or the miss link.
-// The node record comes from the workgroup's LDS copy of the BVH top when the link says so (about
-// three visits in four), else from HBM/L2.  Load and compute are separate so that the caller can
-// put every lane's loads in flight before anybody waits.
-template <bool STATS>
-MI_DEV void inner_load(const DevScene &S, const float4 *lds_top, int n_top_lds, uint32_t cur, float4 &lo, float4 &hi,
-                       unsigned &n_lds)
-{
-    if (cur & MI_TOP_BIT) {
-        const uint32_t slot = cur & ~MI_TOP_BIT;
-        if ((int)slot < n_top_lds) { lo = lds_top[slot * 2]; hi = lds_top[slot * 2 + 1]; if (STATS) n_lds++; }
-        else { lo = S.top_nodes[(size_t)slot * 2]; hi = S.top_nodes[(size_t)slot * 2 + 1]; }
-    } else { lo = S.nodes[(size_t)cur * 2]; hi = S.nodes[(size_t)cur * 2 + 1]; }
-}
+// ---------------------------------------------------------------------------------------------
+// Pipelined traversal.
+//
+// A lane always holds the RECORD of the node it is about to visit (Rec: three float4):
+//     inner node : a = (bmin, hit link)   b = (bmax, miss link)            (c unused)
+//     leaf block : a = header (next link, count, first triangle)  b, c = plane record of triangle 0
+// The walk is a chain of dependent loads, and a frame lasts as long as its longest chain, so the
+// loop never waits for a successor it could have asked for earlier: the moment a record is in
+// registers its links are known, and the records of BOTH possible successors (hit target and miss
+// target; for a leaf: the next node and the leaf's second plane record) are requested before the
+// box / triangle arithmetic starts.  When the arithmetic is done the right record is already on
+// its way.  Records of the BVH top come from the workgroup's LDS copy, the rest from L2/HBM; a flat
+// pointer hides the difference.
+struct Rec { float4 a, b, c; };
 
-template <bool STATS, bool EXACT_BOX>
-MI_DEV void inner_compute(Lane &L, const float4 lo, const float4 hi, unsigned &n_pops, unsigned &n_ihits)
+// address of the record a link points to (a harmless dummy for MI_END_LINK)
+MI_DEV const float4 *rec_addr(const DevScene &S, const float4 *lds_top, int n_top_lds, uint32_t link)
 {
-    bool h;
-    if (EXACT_BOX) h = ray_box_exact(L.o, L.d, lo, hi);
-    else {
-        bool sure;
-        h = ray_box_fast(L.o, L.inv, lo, hi, sure);
-        if (__builtin_expect(!(sure && L.tame), 0)) h = ray_box_exact(L.o, L.d, lo, hi);
+    const float4 *p = S.nodes + (size_t)(link & 0x3fffffffu) * 2;
+    if (link & MI_TOP_BIT) {
+        const uint32_t slot = link & 0x3fffffffu;
+        p = ((int)slot < n_top_lds) ? (lds_top + slot * 2) : (S.top_nodes + (size_t)slot * 2);
     }
-    if (STATS) { n_pops++; if (h) n_ihits++; }
-    L.steps++;
-    L.cur = h ? __float_as_uint(lo.w) : __float_as_uint(hi.w);
+    if (link & MI_LEAF_BIT) p = S.leafs + (size_t)(link & ~MI_LEAF_BIT);
+    if (link == MI_END_LINK) p = S.nodes;
+    return p;
 }
 
-// Leaf visit: the leaf's triangles in list order (Raytracer.cc:235-298).
-// The leaf is a packed block of float4s -- [next link, count, first triangle, -] followed by the
-// 32-byte plane records of its triangles.  The header and the first two plane records are loaded
-// up front (LeafRegs, 5 independent dwordx4 loads issued together with the inner lanes' node
-// loads), both planes are tested, and the edge records of the survivors are then fetched together:
-// two memory round trips per leaf instead of one per record.
-struct LeafRegs { float4 hdr, p0, p1, q0, q1; };
-
-MI_DEV void leaf_load(const DevScene &S, uint32_t cur, LeafRegs &R)
+MI_DEV void rec_fetch(const float4 *p, bool third, Rec &r)
 {
-    const float4 *B = S.leafs + (size_t)(cur & ~MI_LEAF_BIT);
-    R.hdr = B[0]; R.p0 = B[1]; R.p1 = B[2]; R.q0 = B[3]; R.q1 = B[4];      // blocks are padded: always readable
+    r.a = p[0]; r.b = p[1];
+    if (third) r.c = p[2];
+}
+
+// Box test of an inner node's record (Raytracer.cc:222-230)
+template <bool EXACT_BOX>
+MI_DEV bool inner_test(const Lane &L, const Rec &R)
+{
+    if (EXACT_BOX) return ray_box_exact(L.o, L.d, R.a, R.b);
+    bool sure;
+    bool h = ray_box_fast(L.o, L.inv, R.a, R.b, sure);
+    if (__builtin_expect(!(sure && L.tame), 0)) h = ray_box_exact(L.o, L.d, R.a, R.b);
+    return h;
 }
 
 // plane half of the triangle test (Raytracer.cc:245-267): false = rejected, else `hit` is the plane point
@@ -313,17 +316,19 @@ MI_DEV bool tri_edge_test(Lane &L, uint32_t j, const f3 hit, const float4 e1, co
     return false;
 }
 
+// Leaf visit: the leaf's triangles in list order (Raytracer.cc:235-298).  R holds the header and the
+// plane record of triangle 0, `second` the plane record of triangle 1 (requested one iteration
+// earlier); edge records are fetched for the triangles that survive the plane test, both at once.
+// Returns true when a shadow ray was blocked.
 template <bool STATS>
-MI_DEV void leaf_compute(const DevScene &S, const FrameParams &P, Lane &L, const LeafRegs &R, unsigned &n_pops,
-                         unsigned &n_tris, unsigned &n_plane)
+MI_DEV bool leaf_visit(const DevScene &S, const FrameParams &P, Lane &L, const Rec &R, const Rec &second,
+                       unsigned &n_pops, unsigned &n_tris, unsigned &n_plane)
 {
-    const uint32_t count = __float_as_uint(R.hdr.y), first = __float_as_uint(R.hdr.z);
-    uint32_t next = __float_as_uint(R.hdr.x);
+    const uint32_t count = __float_as_uint(R.a.y), first = __float_as_uint(R.a.z);
     if (STATS) n_pops++;
-    // triangles 0 and 1: planes first, then both edge fetches in flight together
     f3 h0 = mk3(0.f, 0.f, 0.f), h1 = h0;
-    const bool t0 = count > 0 && tri_plane_test(L, P.nudge, first, R.p0, R.p1, h0);
-    const bool t1 = count > 1 && tri_plane_test(L, P.nudge, first + 1, R.q0, R.q1, h1);
+    const bool t0 = count > 0 && tri_plane_test(L, P.nudge, first, R.b, R.c, h0);
+    const bool t1 = count > 1 && tri_plane_test(L, P.nudge, first + 1, second.a, second.b, h1);
     float4 a1, a2, a3, b1, b2, b3;
     if (t0) { a1 = S.tri_edge[(size_t)first * 3]; a2 = S.tri_edge[(size_t)first * 3 + 1]; a3 = S.tri_edge[(size_t)first * 3 + 2]; }
     if (t1) { b1 = S.tri_edge[(size_t)(first + 1) * 3]; b2 = S.tri_edge[(size_t)(first + 1) * 3 + 1]; b3 = S.tri_edge[(size_t)(first + 1) * 3 + 2]; }
@@ -349,170 +354,7 @@ MI_DEV void leaf_compute(const DevScene &S, const FrameParams &P, Lane &L, const
             if (tri_edge_test(L, j, h, S.tri_edge[(size_t)j * 3], S.tri_edge[(size_t)j * 3 + 1], S.tri_edge[(size_t)j * 3 + 2])) { blocked = true; break; }
         }
     }
-    if (blocked) next = MI_END_LINK;
-    L.steps++;
-    L.cur = next;
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Wave-cooperative traversal of ONE ray (drain phase).
-//
-// Once the pixel dispenser is dry, a wave is left with a handful of rays whose remaining walks are
-// hundreds or thousands of nodes long, one dependent step at a time, while 60 lanes idle.  This
-// routine spends all 64 lanes on one such ray.  It is exact:
-//   * The nodes still to visit are the current node plus everything reachable through the chain
-//     of miss links behind it (that chain IS the reference's pending stack, Raytracer.cc:217-230).
-//     Those subtrees are independent of one another, so they can be expanded in any order.
-//   * A closest-hit ray keeps the triangle with the smallest squared distance and, among equals,
-//     the one visited first (strict `<`, Raytracer.cc:288).  Visiting order == leaf-order index j,
-//     so the answer is the lexicographic minimum of (hitZ, j) over all passing triangles -- a
-//     reduction, not a sequence.  An any-hit (shadow) ray is a plain OR.
-// Work items are links in a per-wave LIFO in global memory (L2-resident; bounded by
-// 64*(depth+2) entries because every round pops the 64 newest = deepest items).
-struct CoopRay { f3 o, d, inv, lp; float best; int avoid, mode; bool tame; };
-
-MI_DEV float wave_bcast_f(float v, int src) { return __shfl(v, src); }
-MI_DEV int wave_bcast_i(int v, int src) { return __shfl(v, src); }
-
-template <bool EXACT_BOX>
-MI_DEV void coop_traverse(const DevScene &S, const FrameParams &P, Lane &L, const int src, uint32_t *queue,
-                          const uint32_t qcap)
-{
-    const int lane = (int)(threadIdx.x & 63u);
-    CoopRay R;
-    R.o = mk3(wave_bcast_f(L.o.x, src), wave_bcast_f(L.o.y, src), wave_bcast_f(L.o.z, src));
-    R.d = mk3(wave_bcast_f(L.d.x, src), wave_bcast_f(L.d.y, src), wave_bcast_f(L.d.z, src));
-    R.inv = mk3(wave_bcast_f(L.inv.x, src), wave_bcast_f(L.inv.y, src), wave_bcast_f(L.inv.z, src));
-    R.lp = mk3(wave_bcast_f(L.lp.x, src), wave_bcast_f(L.lp.y, src), wave_bcast_f(L.lp.z, src));
-    R.best = wave_bcast_f(L.best, src);
-    R.avoid = wave_bcast_i(L.avoid, src);
-    R.mode = wave_bcast_i(L.mode, src);
-    R.tame = wave_bcast_i(L.tame ? 1 : 0, src) != 0;
-
-    // seed: the source lane walks its miss-link chain and lists the pending subtree roots
-    uint32_t qn = 0;
-    if (lane == src) {
-        uint32_t x = L.cur;
-        while (x != MI_END_LINK && qn < qcap) {
-            __hip_atomic_store(&queue[qn], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            qn++;
-            if (x & MI_LEAF_BIT) x = __float_as_uint(S.leafs[(size_t)(x & ~MI_LEAF_BIT)].x);
-            else if (x & MI_TOP_BIT) x = __float_as_uint(S.top_nodes[(size_t)(x & ~MI_TOP_BIT) * 2 + 1].w);
-            else x = __float_as_uint(S.nodes[(size_t)x * 2 + 1].w);
-        }
-    }
-    qn = (uint32_t)wave_bcast_i((int)qn, src);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    // lane-local result
-    float c_best = R.best;            // candidates must beat the ray's current best (strictly)
-    int c_j = -1;
-    f3 c_hit = mk3(0.f, 0.f, 0.f);
-    float c_k1 = 0.f, c_k2 = 0.f, c_k3 = 0.f;
-    bool c_shadow = false;
-    bool overflow = false;
-
-    while (qn) {
-        const uint32_t take = qn < 64u ? qn : 64u;
-        const uint32_t base = qn - take;
-        uint32_t item = MI_END_LINK;
-        if ((uint32_t)lane < take) item = __hip_atomic_load(&queue[base + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        qn = base;
-        uint32_t push_a = MI_END_LINK, push_b = MI_END_LINK;
-        if (item != MI_END_LINK) {
-            if (!(item & MI_LEAF_BIT)) {
-                float4 lo, hi; uint32_t right;
-                if (item & MI_TOP_BIT) {
-                    const uint32_t slot = item & ~MI_TOP_BIT;
-                    lo = S.top_nodes[(size_t)slot * 2]; hi = S.top_nodes[(size_t)slot * 2 + 1]; right = S.top_right[slot];
-                } else { lo = S.nodes[(size_t)item * 2]; hi = S.nodes[(size_t)item * 2 + 1]; right = S.node_right[item]; }
-                bool h;
-                if (EXACT_BOX) h = ray_box_exact(R.o, R.d, lo, hi);
-                else {
-                    bool sure;
-                    h = ray_box_fast(R.o, R.inv, lo, hi, sure);
-                    if (!(sure && R.tame)) h = ray_box_exact(R.o, R.d, lo, hi);
-                }
-                if (h) { push_a = __float_as_uint(lo.w); push_b = right; }
-            } else {
-                const float4 *B = S.leafs + (size_t)(item & ~MI_LEAF_BIT);
-                const float4 hdr = B[0];
-                const uint32_t count = __float_as_uint(hdr.y), first = __float_as_uint(hdr.z);
-                for (uint32_t t = 0; t < count; t++) {
-                    const uint32_t j = first + t;
-                    if ((int)j == R.avoid) continue;
-                    const float4 p0 = B[1 + 2 * t], p1 = B[2 + 2 * t];
-                    const f3 n = mk3(p0.x, p0.y, p0.z);
-                    if (__float_as_uint(p1.w) == 0u) {
-                        f3 fto = sub3(R.o, mk3(p1.x, p1.y, p1.z));
-                        if (dot3(fto, n) < 0.f) continue;
-                    }
-                    float k = dot3(n, R.d);
-                    if (k == 0.0f) continue;
-                    float sdist = (p0.w - dot3(n, R.o)) / k;
-                    if (sdist <= 0.0f) continue;
-                    if (sdist <= P.nudge) continue;
-                    f3 hit = add3(mul3(R.d, sdist), R.o);
-                    const float4 e1 = S.tri_edge[(size_t)j * 3], e2 = S.tri_edge[(size_t)j * 3 + 1], e3 = S.tri_edge[(size_t)j * 3 + 2];
-                    float kt1 = dot3(mk3(e1.x, e1.y, e1.z), hit) - e1.w; if (kt1 < 0.0f) continue;
-                    float kt2 = dot3(mk3(e2.x, e2.y, e2.z), hit) - e2.w; if (kt2 < 0.0f) continue;
-                    float kt3 = dot3(mk3(e3.x, e3.y, e3.z), hit) - e3.w; if (kt3 < 0.0f) continue;
-                    if (R.mode == MODE_SHADOW) {
-                        if (distsq3(R.lp, hit) < R.best) { c_shadow = true; break; }
-                    } else {
-                        const float hitZ = distsq3(R.o, hit);
-                        // within a lane items arrive in no particular order: keep the (hitZ, j) minimum
-                        if (hitZ < c_best || (hitZ == c_best && c_j >= 0 && (int)j < c_j)) {
-                            c_best = hitZ; c_j = (int)j; c_hit = hit; c_k1 = kt1; c_k2 = kt2; c_k3 = kt3;
-                        }
-                    }
-                }
-            }
-        }
-        if (R.mode == MODE_SHADOW && __ballot(c_shadow)) break;
-        // append the children of every box that was hit
-        const unsigned long long mP = __ballot(push_a != MI_END_LINK);
-        if (mP) {
-            const uint32_t np = (uint32_t)__popcll(mP);
-            if (qn + 2u * np > qcap) { overflow = true; break; }
-            if (push_a != MI_END_LINK) {
-                const uint32_t r = (uint32_t)__popcll(mP & ((1ull << lane) - 1ull));
-                // right child below, left child on top: roughly the reference's order, irrelevant for the result
-                __hip_atomic_store(&queue[qn + 2u * r], push_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&queue[qn + 2u * r + 1u], push_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            qn += 2u * np;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // lanes exchange items through L2: stores first
-        }
-    }
-
-    // reduce to the source lane
-    if (R.mode == MODE_SHADOW) {
-        const bool any = __ballot(c_shadow) != 0ull;
-        if (lane == src) { L.shadow_hit = any; L.cur = MI_END_LINK; }
-    } else {
-        // lexicographic (hitZ, j) minimum over the lanes that found something
-        const unsigned long long none = ~0ull;
-        unsigned long long key = c_j >= 0 ? (((unsigned long long)__float_as_uint(c_best) << 32) | (unsigned)c_j) : none;
-        unsigned long long kmin = key;
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned lo32 = (unsigned)__shfl_xor((int)(unsigned)kmin, off);
-            const unsigned hi32 = (unsigned)__shfl_xor((int)(unsigned)(kmin >> 32), off);
-            const unsigned long long other = ((unsigned long long)hi32 << 32) | lo32;
-            kmin = other < kmin ? other : kmin;
-        }
-        if (kmin != none) {
-            const int winner = __ffsll((long long)__ballot(key == kmin)) - 1;
-            const float b = wave_bcast_f(c_best, winner);
-            const int j = wave_bcast_i(c_j, winner);
-            const float hx = wave_bcast_f(c_hit.x, winner), hy = wave_bcast_f(c_hit.y, winner), hz = wave_bcast_f(c_hit.z, winner);
-            const float k1 = wave_bcast_f(c_k1, winner), k2 = wave_bcast_f(c_k2, winner), k3 = wave_bcast_f(c_k3, winner);
-            if (lane == src) { L.best = b; L.btri = j; L.hit = mk3(hx, hy, hz); L.k1 = k1; L.k2 = k2; L.k3 = k3; }
-        }
-        if (lane == src) L.cur = MI_END_LINK;
-    }
-    if (overflow && lane == src && P.counters) atomicAdd(&P.counters[CS_OVERFLOW], 1ull);
+    return blocked;
 }
 
 } // namespace
@@ -528,7 +370,13 @@ k_raytrace(const DevScene S, const FrameParams P)
     for (int i = threadIdx.x; i < P.n_top_lds * 2; i += 256) lds_dyn[(MI_MAX_DEPTH * 3 * 256) / 4 + i] = S.top_nodes[i];
     __syncthreads();
     Lane L;
+    constexpr bool SPLIT = !STATS && (TRAV & 4) != 0;   // counting builds keep the reference's visiting order
     bool alive = false;         // lane owns a pixel
+    bool helper = false;        // lane walks part of another lane's ray
+    bool need_rec = true;       // the record of L.cur has not been fetched yet
+    Rec R;                      // record of the node this lane visits next
+    uint32_t offer_link = MI_END_LINK;
+    R.a = R.b = R.c = make_float4(0.f, 0.f, 0.f, 0.f);
     bool want_pixel = true;     // lane needs a (new) pixel
     bool exhausted = false;     // dispenser ran dry (wave-uniform)
     uint32_t pool_next = 0, pool_end = 0;   // wave-local pixel pool (wave-uniform)
@@ -536,7 +384,7 @@ k_raytrace(const DevScene S, const FrameParams P)
     L.fr = L.fg = L.fb = 0.f; L.px = L.py = L.orow = 0; L.avoid = -1; L.best = 0.f;
     L.shadow_hit = false; L.li = 0; L.cr = L.cg = L.cb = 0.f; L.k1 = L.k2 = L.k3 = 0.f;
     L.o = L.d = L.hit = L.pn = L.refl = L.lp = L.inv = mk3(0.f, 0.f, 0.f);
-    L.tame = false; L.steps = 0;
+    L.tame = false; L.end = MI_END_LINK; L.owner = -1; L.pending = 0;
 
     unsigned n_normal = 0, n_shadow = 0;
     unsigned n_pops = 0, n_ihits = 0, n_tris = 0, n_plane = 0, n_shaded = 0, n_lds = 0;
@@ -547,6 +395,7 @@ k_raytrace(const DevScene S, const FrameParams P)
     const unsigned long long tick0 = tick;
     const unsigned long long rt0 = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned long long rt_dry = 0;
+    unsigned long long it_loops = 0;
 #define MI_PHASE(acc) do { if (STATS) { const unsigned long long t_ = __builtin_readcyclecounter(); acc += t_ - tick; tick = t_; } } while (0)
 
     const int tiles_x = (P.W + 7) >> 3;
@@ -565,7 +414,9 @@ k_raytrace(const DevScene S, const FrameParams P)
             const unsigned long long mW = __ballot(want_pixel);
             if (mW) {
                 const int nW = __popcll(mW);
-                if (nW >= P.rmin || !__ballot(alive)) {
+                // refill when enough lanes idle to justify a dispenser grab -- or at once if this wave still
+                // holds indices it has already taken (they are invisible to every other wave until started)
+                if (nW >= P.rmin || pool_next != pool_end || !__ballot(alive)) {
                     const int lane = (int)(threadIdx.x & 63u);
                     if (STATS) { it_refill++; ln_refill += nW; }
                     if (pool_next == pool_end && !exhausted) {
@@ -603,7 +454,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                                     L.fr = L.fg = L.fb = 0.f;
                                     L.samples_left = P.aa ? 3 : 0;
                                     primary_ray(P, L, L.samples_left);
-                                    L.cur = S.root_link;
+                                    L.cur = S.root_link; need_rec = true;
                                     n_normal++;
                                     alive = true;
                                     want_pixel = false;
@@ -616,38 +467,53 @@ k_raytrace(const DevScene S, const FrameParams P)
             }
         }
 
-        // ---------------- drain: wave-cooperative traversal of the last few rays ------------------
-        // (a) any ray that has already made P.coop_steps node visits, (b) the last few rays of a wave once
-        // the dispenser is dry
-        if (!STATS && (TRAV & 4) != 0 && (P.coop_steps > 0 || P.coop_max > 0)) {
-            const bool trav_now = alive && L.cur != MI_END_LINK;
-            unsigned long long mC = P.coop_steps > 0 ? __ballot(trav_now && L.steps >= P.coop_steps) : 0ull;
-            if (exhausted && pool_next == pool_end && P.coop_max > 0) {
-                const unsigned long long mAll = __ballot(trav_now);
-                if (__popcll(mAll) <= P.coop_max) mC = mAll;
-            }
-            if (mC) {
-                uint32_t *queue = P.coop_queue + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * P.coop_cap;
-                while (mC) {
-                    const int src = __ffsll((long long)mC) - 1;
-                    mC &= mC - 1ull;
-                    coop_traverse<(TRAV & 2) != 0>(S, P, L, src, queue, P.coop_cap);
+        // ---------------- helpers that finished their share: fold the result into the owner lane ----
+        // (SPLIT builds only.)  A helper walked a continuation of some owner's ray; its candidate
+        // competes with the owner's under the reference's rule -- smaller squared distance wins,
+        // equal distance goes to the triangle visited first = lower leaf-order index (Raytracer.cc:288).
+        const bool drain = exhausted && pool_next == pool_end;
+        if (SPLIT) {
+            unsigned long long mH = __ballot(helper && L.cur == L.end);
+            const int lane = (int)(threadIdx.x & 63u);
+            while (mH) {
+                const int h = __ffsll((long long)mH) - 1;
+                mH &= mH - 1ull;
+                const int ow = __builtin_amdgcn_readlane(L.owner, h);
+                const int h_tri = __builtin_amdgcn_readlane(L.btri, h);
+                const float h_best = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.best), h));
+                const int h_shadow = __builtin_amdgcn_readlane(L.shadow_hit ? 1 : 0, h);
+                const float hx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.hit.x), h));
+                const float hy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.hit.y), h));
+                const float hz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.hit.z), h));
+                const float hk1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.k1), h));
+                const float hk2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.k2), h));
+                const float hk3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.k3), h));
+                if (lane == ow) {
+                    L.pending--;
+                    if (L.mode == MODE_SHADOW) { if (h_shadow) L.shadow_hit = true; }
+                    else if (h_tri >= 0 && (L.btri < 0 || h_best < L.best || (h_best == L.best && h_tri < L.btri))) {
+                        L.best = h_best; L.btri = h_tri; L.hit = mk3(hx, hy, hz); L.k1 = hk1; L.k2 = hk2; L.k3 = hk3;
+                    }
                 }
+                if (lane == h) { helper = false; L.owner = -1; }
             }
         }
-
-        const unsigned long long mX = __ballot(alive && L.cur == MI_END_LINK);
-        const unsigned long long mT = __ballot(alive && L.cur != MI_END_LINK);
+        // a lane's ray is complete when its own share is walked and no helper is still out
+        const bool ray_done = alive && L.cur == L.end && L.pending == 0;
+        const bool trav_now = (alive || helper) && L.cur != L.end;
+        const unsigned long long mX = __ballot(ray_done);
+        const unsigned long long mT = __ballot(trav_now);
         if (!mX && !mT) {
             if (!__ballot(want_pixel)) break;
             continue;
         }
+        const int xmin_now = drain ? 1 : P.xmin;          // nothing left to batch with once the dispenser is dry
 
-        if (mX && (__popcll(mX) >= P.xmin || !mT)) {
+        if (mX && (__popcll(mX) >= xmin_now || !mT)) {
             // ---------------- transitions ------------------------------------------------
             MI_PHASE(pc_refill);
             if (STATS) { it_trans++; ln_trans += __popcll(mX); }
-            if (alive && L.cur == MI_END_LINK) {
+            if (ray_done) {
                 bool finish = false;     // ray tree complete -> fold
                 bool lights = false;     // continue with light loop
                 if (L.mode == MODE_CLOSEST) {
@@ -676,7 +542,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                             L.best = distsq3(L.o, L.lp);            // Raytracer.cc:209
                             L.mode = MODE_SHADOW;
                             L.shadow_hit = false;
-                            L.cur = S.root_link;
+                            L.cur = S.root_link; need_rec = true;
                             // avoid stays = the triangle just hit (set below on first entry)
                             L.avoid = L.btri;
                             n_shadow++;
@@ -694,7 +560,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                             L.o = L.hit; L.d = L.refl; L.avoid = L.btri;
                             set_ray_aux(L);
                             L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.btri = -1;
-                            L.cur = S.root_link;
+                            L.cur = S.root_link; need_rec = true;
                             n_normal++;
                         } else finish = true;
                     }
@@ -708,7 +574,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     if (L.samples_left > 0) {
                         L.samples_left--;
                         primary_ray(P, L, L.samples_left);
-                        L.cur = S.root_link;
+                        L.cur = S.root_link; need_rec = true;
                         n_normal++;
                     } else {
                         float r = L.fr, g = L.fg, b = L.fb;
@@ -723,7 +589,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         }
                         alive = false;
                         want_pixel = true;
-                        L.cur = MI_END_LINK;
+                        L.cur = MI_END_LINK; L.end = MI_END_LINK;
                     }
                 }
             }
@@ -734,34 +600,101 @@ k_raytrace(const DevScene S, const FrameParams P)
         // ---------------- traversal burst ------------------------------------------------
         // Keep traversing until enough lanes have run off the tree to make servicing them worthwhile.
         MI_PHASE(pc_refill);
+        // lanes with nothing to do and nothing to fetch: candidates to help with somebody else's ray
+        unsigned long long idle_mask = (SPLIT && drain) ? __ballot(!alive && !helper) : 0ull;
         for (;;) {
             // Every traversing lane sits on an inner node or on a leaf.  Inner lanes take one step per
             // iteration; leaf lanes are held back until P.lmin of them have gathered (or nothing else can
             // move), so the triangle-test code runs with a fuller exec mask.  lmin = 1 is plain if-if,
             // lmin = 64 is while-while.
-            const bool inner = alive && L.cur < MI_END_LINK;             // no leaf bit, not END
-            const bool leaf_any = alive && (L.cur & MI_LEAF_BIT) != 0;
+            if (STATS) it_loops++;
+            const bool trav = (alive || helper) && L.cur != L.end;
+            // a lane that has just been given a ray does not hold its first record yet
+            if (trav && need_rec) {
+                rec_fetch(rec_addr(S, lds_top, P.n_top_lds, L.cur), (L.cur & MI_LEAF_BIT) != 0, R);
+                need_rec = false;
+            }
+            const bool inner = trav && (L.cur & MI_LEAF_BIT) == 0;
+            const bool leaf_any = trav && (L.cur & MI_LEAF_BIT) != 0;
             const unsigned long long mI = __ballot(inner), mL = __ballot(leaf_any);
             const bool leaf = leaf_any && (!mI || __popcll(mL) >= P.lmin);
-            // all loads of this iteration go out before anybody waits: leaf blocks, then node records
-            LeafRegs LR;
-            float4 nlo, nhi;
-            if (leaf) leaf_load(S, L.cur, LR);
-            if (inner) inner_load<STATS>(S, lds_top, P.n_top_lds, L.cur, nlo, nhi, n_lds);
+            // ---- request the successors' records before any arithmetic -----------------------------
+            //   inner lane: slot 1 = record behind the hit link, slot 2 = record behind the miss link
+            //   leaf lane : slot 1 = record behind the leaf's next link, slot 2 = plane record of triangle 1
+            const uint32_t link1 = inner ? __float_as_uint(R.a.w) : __float_as_uint(R.a.x);
+            const uint32_t link2 = __float_as_uint(R.b.w);
+            Rec N1, N2;
+            if (inner || leaf) {
+                const float4 *p1 = rec_addr(S, lds_top, P.n_top_lds, link1);
+                const float4 *p2 = inner ? rec_addr(S, lds_top, P.n_top_lds, link2)
+                                         : (S.leafs + (size_t)(L.cur & ~MI_LEAF_BIT) + 3);
+                rec_fetch(p1, (link1 & MI_LEAF_BIT) != 0, N1);
+                rec_fetch(p2, inner && (link2 & MI_LEAF_BIT) != 0, N2);
+            }
+            bool offer = false;
             if (mI) {
                 if (STATS) { it_a++; ln_a += __popcll(mI); }
-                if (inner) inner_compute<STATS, (TRAV & 2) != 0>(L, nlo, nhi, n_pops, n_ihits);
+                if (inner) {
+                    const bool h = inner_test<(TRAV & 2) != 0>(L, R);
+                    if (STATS) { n_pops++; if (h) n_ihits++; if ((L.cur & MI_TOP_BIT) && (int)(L.cur & 0x3fffffffu) < P.n_top_lds) n_lds++; }
+                    // Box hit at node X: this lane now walks X's subtree, then everything from X's miss link
+                    // up to L.end.  That second part can be given away if it starts high in the tree.
+                    offer = SPLIT && h && link2 != L.end && (link2 & MI_TOP_BIT) != 0 && link2 != MI_END_LINK;
+                    offer_link = link2;
+                    L.cur = h ? link1 : link2;
+                    R.a = h ? N1.a : N2.a; R.b = h ? N1.b : N2.b; R.c = h ? N1.c : N2.c;
+                }
                 MI_PHASE(pc_a);
+            }
+            if (SPLIT && idle_mask) {
+                // ---- hand continuations to idle lanes (drain phase only) --------------------------------
+                unsigned long long mO = __ballot(offer);
+                const int lane = (int)(threadIdx.x & 63u);
+                while (mO && idle_mask) {
+                    const int a = __ffsll((long long)mO) - 1, t = __ffsll((long long)idle_mask) - 1;
+                    mO &= mO - 1ull;
+                    idle_mask &= idle_mask - 1ull;
+#define MI_RL_F(v) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (v)), a))
+#define MI_RL_I(v) __builtin_amdgcn_readlane((int)(v), a)
+                    const float ox = MI_RL_F(L.o.x), oy = MI_RL_F(L.o.y), oz = MI_RL_F(L.o.z);
+                    const float dx = MI_RL_F(L.d.x), dy = MI_RL_F(L.d.y), dz = MI_RL_F(L.d.z);
+                    const float ix = MI_RL_F(L.inv.x), iy = MI_RL_F(L.inv.y), iz = MI_RL_F(L.inv.z);
+                    const float lx = MI_RL_F(L.lp.x), ly = MI_RL_F(L.lp.y), lz = MI_RL_F(L.lp.z);
+                    const float a_best = MI_RL_F(L.best);
+                    const int a_avoid = MI_RL_I(L.avoid), a_mode = MI_RL_I(L.mode), a_tame = MI_RL_I(L.tame ? 1 : 0);
+                    const uint32_t a_end = (uint32_t)MI_RL_I(L.end);
+                    const uint32_t a_k = (uint32_t)MI_RL_I(offer_link);
+                    const int a_owner = MI_RL_I(L.owner);
+#undef MI_RL_F
+#undef MI_RL_I
+                    const int ow = a_owner >= 0 ? a_owner : a;
+                    if (lane == t) {
+                        L.o = mk3(ox, oy, oz); L.d = mk3(dx, dy, dz); L.inv = mk3(ix, iy, iz); L.lp = mk3(lx, ly, lz);
+                        L.best = a_best;          // a later triangle must beat what the walk before it has found
+                        L.avoid = a_avoid; L.mode = a_mode; L.tame = a_tame != 0;
+                        L.btri = -1; L.shadow_hit = false;
+                        L.cur = a_k; L.end = a_end; L.owner = ow; L.pending = 0;
+                        helper = true; need_rec = true;
+                    }
+                    if (lane == a) L.end = a_k;   // the giver stops where the helper starts
+                    if (lane == ow) L.pending++;
+                }
             }
             if (mL && (!mI || __popcll(mL) >= P.lmin)) {
                 if (STATS) { it_b++; ln_b += __popcll(mL); }
-                if (leaf) leaf_compute<STATS>(S, P, L, LR, n_pops, n_tris, n_plane);
+                if (leaf) {
+                    const bool blocked = leaf_visit<STATS>(S, P, L, R, N2, n_pops, n_tris, n_plane);
+                    L.cur = blocked ? L.end : link1;          // a blocked shadow ray stops here (Raytracer.cc:284)
+                    R = N1;
+                }
                 MI_PHASE(pc_b);
             }
-            const unsigned long long mEnd = __ballot(alive && L.cur == MI_END_LINK);
-            const unsigned long long mTr = __ballot(alive && L.cur != MI_END_LINK);
-            if (!mTr || __popcll(mEnd) >= P.xmin) break;
-            if (!STATS && (TRAV & 4) != 0 && P.coop_steps > 0 && __ballot(alive && L.cur != MI_END_LINK && L.steps >= P.coop_steps)) break;
+            const unsigned long long mTr = __ballot((alive || helper) && L.cur != L.end);
+            if (!mTr) break;
+            // owners waiting for helpers do not count; finished helpers are serviced at once in the drain
+            const unsigned long long mDone = __ballot(alive && L.cur == L.end && L.pending == 0);
+            if (__popcll(mDone) >= xmin_now) break;
+            if (SPLIT && __ballot(helper && L.cur == L.end)) break;
         }
     }
     if (STATS) pc_total = __builtin_readcyclecounter() - tick0;
@@ -795,6 +728,11 @@ k_raytrace(const DevScene S, const FrameParams P)
                 if (rt_dry) atomicMin(&P.counters[CS_TIME0 + 1], rt_dry);
                 atomicMax(&P.counters[CS_TIME0 + 2], __builtin_amdgcn_s_memrealtime());
                 atomicMax(&P.counters[CS_TIME0 + 3], it_a + it_b);   // most traversal iterations done by one wave
+                if (P.wave_prof) {
+                    unsigned long long *w = P.wave_prof + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * 16u;
+                    for (int i = 0; i < 15; i++) w[i] = prof[i];
+                    w[15] = it_loops;
+                }
             }
         }
     }
@@ -802,7 +740,7 @@ k_raytrace(const DevScene S, const FrameParams P)
 }
 
 // ---- launch helper (called from capi.hip) ------------------------------------------------
-// trav: bit 1 = always use the exact six-division box test, bit 2 = include the cooperative traversal
+// trav: bit 1 = always use the exact six-division box test, bit 2 = split long walks over idle lanes
 template <bool STATS, int TRAV> static int occ_of(int lds_bytes)
 {
     int nb = 0;

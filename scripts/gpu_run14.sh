@@ -1,0 +1,3 @@
+mkdir -p gpurun_out
+(timeout 900 python -m pytest tests -m gpu -x -q -k "reference_frame_hashes or option_matrix or tuning or antialias or small_frames or ragged or stats_variant or band" 2>&1 | tail -5) > gpurun_out/pytest14.log
+(timeout 900 python scripts/rt_sweep.py --frames 6 --grid '[{}, {"nosplit":1}, {"lmin":1}, {"lmin":4}, {"lmin":16}, {"xmin":6,"rmin":8}, {"xmin":24,"rmin":32}, {"bpc":1}, {"nolds":1}, {"chunk":128}, {"rowmajor":1}]' 2>&1 | tail -30) > gpurun_out/sweep14.log
