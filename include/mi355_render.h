@@ -83,10 +83,9 @@ typedef struct {
      * [0] xmin   lanes waiting for a state transition before the wave services them
      * [1] rmin   idle lanes before the wave refills from the pixel dispenser
      * [2] chunk  pixel indices a wave takes from the dispenser at once
-     * [3] lmin   lanes gathered on leaves before the triangle tests run
+     * [3] lmin   lanes gathered on triangle blocks before the plane tests run (1 = plain if-if)
      * [4] blocks per CU (0 = occupancy query)
-     * [5] flags  1 exact box test only | 2 row-major tile order | 4 no LDS BVH-top cache |
-     *            8 no walk splitting over idle lanes | 16 scattered pixel dispensing
+     * [5] flags  1 exact box test only | 2 row-major tile order | 16 scattered pixel dispensing
      * [6], [7] reserved */
     int32_t tune[8];
 } mi355_opts;

@@ -161,9 +161,9 @@ def default_opts(width: int, height: int, **kw) -> Opts:
     return o
 
 
-def tune(xmin=0, rmin=0, chunk=0, lmin=0, bpc=0, exact=0, rowmajor=0, nolds=0, nosplit=0, scatter=0):
+def tune(xmin=0, rmin=0, chunk=0, lmin=0, bpc=0, exact=0, rowmajor=0, scatter=0):
     """mi355_opts::tune as a list (see include/mi355_render.h); every knob leaves the pixels unchanged."""
-    flags = (1 if exact else 0) | (2 if rowmajor else 0) | (4 if nolds else 0) | (8 if nosplit else 0) | (16 if scatter else 0)
+    flags = (1 if exact else 0) | (2 if rowmajor else 0) | (16 if scatter else 0)
     return [xmin, rmin, chunk, lmin, bpc, flags, 0, 0]
 
 

@@ -17,9 +17,9 @@
 #include <vector>
 
 // kernel launchers (defined next to their kernels)
-extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int trav, int lds_bytes);
-extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int trav, int n_blocks,
-                                             int lds_bytes, hipStream_t);
+extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact);
+extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int n_blocks,
+                                             hipStream_t);
 extern "C" hipError_t mi355i_launch_points(const DevScene *, const FrameParams *, int as_triangles, hipStream_t);
 struct RasterScratch;
 extern "C" hipError_t mi355i_launch_raster(const DevScene *, const FrameParams *, int mode, RasterScratch *,
@@ -91,7 +91,7 @@ struct mi355_ctx {
     std::vector<uint8_t> ttwo;
     bool has_bvh = false;
     // device
-    DevBuf nodes, top_nodes, node_right, top_right, leafs, tri_edge, tri_shade, rs_tri, rs_col, rs_idx, rs_vert;
+    DevBuf walk, tri_edge, tri_shade, rs_tri, rs_col, rs_idx, rs_vert;
     DevBuf ctrl;            // [0] work counter (16 B) | counters[CS_COUNT]
     DevBuf fb, fbf;         // internal framebuffer for the host-output path
     DevBuf tile_order;      // raytrace dispenser order (ensure_tile_order)
@@ -204,13 +204,11 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.xmin = t[0] > 0 ? (t[0] > 64 ? 64 : t[0]) : 24;
     P.rmin = t[1] > 0 ? (t[1] > 64 ? 64 : t[1]) : 32;
     P.chunk = t[2] > 0 ? t[2] : 64;
-    P.lmin = t[3] > 0 ? (t[3] > 64 ? 64 : t[3]) : 8;
+    P.lmin = t[3] > 0 ? (t[3] > 64 ? 64 : t[3]) : 1;
     P.blocks_per_cu = t[4] > 0 ? t[4] : 0;
-    P.trav = (flags & 1) ? 2 : 0;
-    if (!c->boxes_tame) P.trav = 2;          // box coordinates outside the filtered test's validated range
-    P.no_lds_top = (flags & 4) ? 1 : 0;
+    P.exact_box = (flags & 1) ? 1 : 0;
+    if (!c->boxes_tame) P.exact_box = 1;     // box coordinates outside the filtered test's validated range
     P.scatter = (flags & 16) ? 1 : 0;
-    if (!(flags & 8)) P.trav |= 4;           // flag 8 disables walk splitting in the drain phase
     P.wave_prof = nullptr;
     if (o->collect_stats) {
         if (c->wave_prof.ensure((size_t)8 * c->n_cus * 4 * 16 * 8) == hipSuccess) P.wave_prof = (unsigned long long *)c->wave_prof.p;
@@ -237,38 +235,20 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
         seen[triIdx[i]] = 1;
     }
     auto is_leaf = [&](uint32_t i) { return (rn[i].a & 0x80000000u) != 0; };
-    // leaf blocks: header + one 32-byte plane record per triangle, in node order
-    std::vector<uint32_t> leaf_off(nN, 0);
+    // record offsets (float4 units) in pre-order: inner node 2, leaf 3 per triangle (an empty leaf keeps one dummy block)
+    std::vector<uint32_t> off(nN, 0);
     size_t n4 = 0;
-    for (uint32_t i = 0; i < nN; i++)
+    for (uint32_t i = 0; i < nN; i++) {
+        off[i] = (uint32_t)n4;
         if (is_leaf(i)) {
             const uint32_t cnt = rn[i].a & 0x7fffffffu, first = rn[i].b;
             if ((uint64_t)first + cnt > nI) return fail(-30, "BVH leaf %u exceeds the triangle list", i);
-            leaf_off[i] = (uint32_t)n4;
-            n4 += 1 + 2 * (size_t)cnt;
-        }
-    if (n4 + 8 >= 0x7fffffffull) return fail(-30, "BVH too large");
-    // breadth-first order of the inner nodes nearest the root: candidates for the per-workgroup LDS cache
-    std::vector<uint32_t> top_slot(nN, 0xffffffffu), top_list;
-    {
-        std::vector<uint32_t> q;
-        q.push_back(0);
-        for (size_t h = 0; h < q.size() && top_list.size() < MI_TOP_CAP; h++) {
-            const uint32_t i = q[h];
-            if (i >= nN || is_leaf(i) || top_slot[i] != 0xffffffffu) continue;
-            top_slot[i] = (uint32_t)top_list.size();
-            top_list.push_back(i);
-            if (rn[i].a < nN) q.push_back(rn[i].a);
-            if (rn[i].b < nN) q.push_back(rn[i].b);
-        }
+            n4 += 3 * (size_t)(cnt ? cnt : 1);
+        } else n4 += 2;
     }
-    auto link = [&](uint32_t i) {
-        if (i == MI_END_LINK) return MI_END_LINK;
-        if (is_leaf(i)) return leaf_off[i] | MI_LEAF_BIT;
-        return top_slot[i] != 0xffffffffu ? (top_slot[i] | MI_TOP_BIT) : i;
-    };
-    std::vector<float4> nodes((size_t)nN * 2, make_float4(0.f, 0.f, 0.f, 0.f));
-    std::vector<float4> leafs(n4 + 8, make_float4(0.f, 0.f, 0.f, 0.f));     // +8: the kernel reads 4 records past a header
+    if (n4 + 8 >= 0x7fffffffull) return fail(-30, "BVH too large");
+    auto link = [&](uint32_t i) { return i == MI_END_LINK ? MI_END_LINK : (is_leaf(i) ? (off[i] | MI_LEAF_BIT) : off[i]); };
+    std::vector<float4> walk(n4 + 4, make_float4(0.f, 0.f, 0.f, 0.f));       // +4: a record fetch always reads 3 float4
     std::vector<uint8_t> visited(nN, 0);
     struct Item { uint32_t node, escape; int depth; };
     std::vector<Item> st;
@@ -280,21 +260,25 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
         if (it.depth >= 64) return fail(-30, "BVH deeper than 64 levels");
         visited[it.node] = 1; nvis++;
         const RefNode &n = rn[it.node];
+        float4 *rec = &walk[off[it.node]];
         if (!is_leaf(it.node)) {
             if (n.a >= nN || n.b >= nN) return fail(-30, "BVH child index out of range at node %u", it.node);
-            nodes[(size_t)it.node * 2] = make_float4(n.bottom[0], n.bottom[1], n.bottom[2], u2f(link(n.a)));
-            nodes[(size_t)it.node * 2 + 1] = make_float4(n.top[0], n.top[1], n.top[2], u2f(link(it.escape)));
+            rec[0] = make_float4(n.bottom[0], n.bottom[1], n.bottom[2], u2f(link(n.a)));
+            rec[1] = make_float4(n.top[0], n.top[1], n.top[2], u2f(link(it.escape)));
             st.push_back({n.b, it.escape, it.depth + 1});
             st.push_back({n.a, n.b, it.depth + 1});
         } else {
             const uint32_t cnt = n.a & 0x7fffffffu, first = n.b;
-            float4 *blk = &leafs[leaf_off[it.node]];
-            blk[0] = make_float4(u2f(link(it.escape)), u2f(cnt), u2f(first), 0.f);
+            if (cnt == 0) {      // never produced by the reference builder; a block whose plane rejects every ray
+                rec[0] = make_float4(u2f(link(it.escape)), u2f(0xffffffffu), u2f(1u), 0.f);
+            }
             for (uint32_t k = 0; k < cnt; k++) {
                 const uint32_t t = (uint32_t)triIdx[first + k];
                 const float *nrm = &c->tnormal[3 * t], *cen = &c->tcenter[3 * t];
-                blk[1 + 2 * k] = make_float4(nrm[0], nrm[1], nrm[2], c->td[4 * t]);
-                blk[2 + 2 * k] = make_float4(cen[0], cen[1], cen[2], u2f(c->ttwo[t] ? 1u : 0u));
+                const uint32_t next = k + 1 < cnt ? ((off[it.node] + 3 * (k + 1)) | MI_LEAF_BIT) : link(it.escape);
+                rec[3 * k] = make_float4(u2f(next), u2f(first + k), u2f(k == 0 ? 1u : 0u), 0.f);
+                rec[3 * k + 1] = make_float4(nrm[0], nrm[1], nrm[2], c->td[4 * t]);
+                rec[3 * k + 2] = make_float4(cen[0], cen[1], cen[2], u2f(c->ttwo[t] ? 1u : 0u));
             }
         }
     }
@@ -330,40 +314,10 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
         }
         shade[(size_t)j * 5 + 4] = make_float4(c->tcolorf[3 * t], c->tcolorf[3 * t + 1], c->tcolorf[3 * t + 2], 0.f);
     }
-    std::vector<uint32_t> node_right(nN, MI_END_LINK), top_right(top_list.size() + 1, MI_END_LINK);
-    int max_depth = 0;
-    {
-        std::vector<std::pair<uint32_t, int>> dq;
-        dq.push_back({0u, 0});
-        while (!dq.empty()) {
-            auto [i, d] = dq.back(); dq.pop_back();
-            if (d > max_depth) max_depth = d;
-            if (!is_leaf(i)) { dq.push_back({rn[i].a, d + 1}); dq.push_back({rn[i].b, d + 1}); }
-        }
-    }
-    for (uint32_t i = 0; i < nN; i++)
-        if (!is_leaf(i)) {
-            node_right[i] = link(rn[i].b);
-            if (top_slot[i] != 0xffffffffu) top_right[top_slot[i]] = link(rn[i].b);
-        }
-    HIP_TRY(c->node_right.upload(node_right), -31);
-    HIP_TRY(c->top_right.upload(top_right), -31);
-    c->dev.node_right = (const uint32_t *)c->node_right.p;
-    c->dev.top_right = (const uint32_t *)c->top_right.p;
-    std::vector<float4> top((size_t)top_list.size() * 2 + 2, make_float4(0.f, 0.f, 0.f, 0.f));
-    for (size_t k = 0; k < top_list.size(); k++) {
-        top[2 * k] = nodes[(size_t)top_list[k] * 2];
-        top[2 * k + 1] = nodes[(size_t)top_list[k] * 2 + 1];
-    }
-    HIP_TRY(c->top_nodes.upload(top), -31);
-    c->dev.top_nodes = (const float4 *)c->top_nodes.p;
-    c->dev.n_top_cand = (uint32_t)top_list.size();
-    HIP_TRY(c->nodes.upload(nodes), -31);
-    HIP_TRY(c->leafs.upload(leafs), -31);
+    HIP_TRY(c->walk.upload(walk), -31);
+    c->dev.walk = (const float4 *)c->walk.p;
     HIP_TRY(c->tri_edge.upload(edge), -31);
     HIP_TRY(c->tri_shade.upload(shade), -31);
-    c->dev.nodes = (const float4 *)c->nodes.p;
-    c->dev.leafs = (const float4 *)c->leafs.p;
     c->dev.tri_edge = (const float4 *)c->tri_edge.p;
     c->dev.tri_shade = (const float4 *)c->tri_shade.p;
     c->dev.root_link = link(0);
@@ -388,24 +342,14 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipSt
         break;
     case MI355_MODE_RAYTRACE: case MI355_MODE_RAYTRACE_ANTIALIAS: {
         if (!c->has_bvh) return fail(-41, "raytrace modes need mi355_scene_set_bvh first");
-        // Blocks per CU from registers alone, then give each block an equal share of the CU's 160 KB of LDS:
-        // 12 KB of per-lane colour columns + as many BFS-top node records as fit.
-        int per_cu = mi355i_raytrace_blocks_per_cu(stats, P.trav, 12288);
+        int per_cu = mi355i_raytrace_blocks_per_cu(stats, P.exact_box);
         if (P.blocks_per_cu > 0 && P.blocks_per_cu < per_cu) per_cu = P.blocks_per_cu;
-        FrameParams &Pm = const_cast<FrameParams &>(P);
-        int lds_budget = (160 * 1024) / per_cu - 512;
-        if (lds_budget > 160 * 1024 - 1024) lds_budget = 160 * 1024 - 1024;
-        int n_top = (lds_budget - 12288) / 32;
-        if (n_top > (int)c->dev.n_top_cand) n_top = (int)c->dev.n_top_cand;
-        if (n_top < 0 || P.no_lds_top) n_top = 0;
-        Pm.n_top_lds = n_top;
-        const int lds_bytes = 12288 + n_top * 32;
         int n_blocks = per_cu * c->n_cus;
         const long long lanes_needed = ((long long)P.W * P.n_rows + 255) / 256;
         if (n_blocks > lanes_needed) n_blocks = (int)(lanes_needed > 0 ? lanes_needed : 1);
         c->last_blocks = n_blocks;
         if (P.wave_prof) HIP_TRY(hipMemsetAsync(c->wave_prof.p, 0, (size_t)n_blocks * 4 * 16 * 8, st), -40);
-        e = mi355i_launch_raytrace(&c->dev, &P, stats, P.trav, n_blocks, lds_bytes, st);
+        e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, n_blocks, st);
         break;
     }
     case MI355_MODE_LINES:
@@ -523,7 +467,7 @@ void mi355_scene_destroy(mi355_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->nodes, &c->top_nodes, &c->node_right, &c->top_right, &c->leafs, &c->tri_edge, &c->tri_shade, &c->rs_tri, &c->rs_col, &c->rs_idx,
+    for (DevBuf *b : {&c->walk, &c->tri_edge, &c->tri_shade, &c->rs_tri, &c->rs_col, &c->rs_idx,
                       &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->tile_order, &c->wave_prof})
         b->release();
     for (auto &m : c->smap) m.release();

@@ -7,11 +7,12 @@
 // aligned 16-byte vectors (one dwordx4 load per lane per vector), and the
 // triangles of a leaf are contiguous:
 //
-//   nodes     [n_nodes][2] float4   traversal  (box + skip links)          32 B
-//   leafs     [...]        float4   per leaf: header + its triangles' plane records (normal,d,centre) 16+32n B
+//   walk      [...]        float4   traversal records, one buffer so that address = base + 16*link:
+//                                  inner node 32 B (box + hit/miss links), triangle block 48 B
+//                                  (next link, triangle, flags | normal,d | centre,twoSided)
 //   tri_edge  [T][3]       float4   leaf test, second half (e1..e3,d1..d3)  48 B
 //   tri_shade [T][5]       float4   closest-hit shading                     80 B
-//   (leaf blocks and both tri_* streams are in LEAF ORDER = position in triIndexList)
+//   (triangle blocks and both tri_* streams are in LEAF ORDER = position in triIndexList)
 //
 //   rs_tri    [T][2]  float4 + [T] uint4   rasterizer: centre/normal/colour + vertex ids, input order
 //   rs_vert   [V][2]  float4               rasterizer: position+ao, normal
@@ -20,31 +21,21 @@
 #include <stdint.h>
 
 #define MI_END_LINK 0x7fffffffu   // traversal finished
-#define MI_LEAF_BIT 0x80000000u   // link target is a leaf
-#define MI_TOP_BIT  0x40000000u   // link target is an inner node of the BFS-top set: low bits = slot in top_nodes
-#define MI_TOP_CAP  4608u         // candidates kept in top_nodes (144 KB); a launch caches a prefix of them in LDS
+#define MI_LEAF_BIT 0x80000000u   // link target is a triangle block
 
 #define MI_MAX_LIGHTS 4
 #define MI_MAX_DEPTH 4
 
-// Node record (32 B):
-//   inner: lo = (bmin.xyz, link_if_hit)   hi = (bmax.xyz, link_if_miss)
-//   (leaf nodes keep their slot in the array but are never read: a leaf is reached through a link)
-// A link is an inner node's index in `nodes`, or MI_TOP_BIT | slot for one of the MI_TOP_CAP inner nodes
-// nearest the root (kept in breadth-first order in `top_nodes`; each workgroup copies a prefix of
-// that array into LDS and serves those visits from there), or MI_LEAF_BIT | float4-offset of a
-// leaf block in `leafs`, or MI_END_LINK.  A leaf block's header carries the link to follow after the leaf.
-// link_if_hit is the left child, link_if_miss / link_next is the next node of the
-// reference's depth-first, left-first order (Raytracer.cc:217-230) that is not below this
-// one -- so following links visits exactly the nodes the reference pops, in the same order,
-// without a stack.
+// Walk records (float4 units; a link is the float4 index of a record, | MI_LEAF_BIT for a triangle
+// block, or MI_END_LINK):
+//   inner node    : (bmin.xyz, link_if_hit) (bmax.xyz, link_if_miss)
+//   triangle block: (next link, triangle j, flags, -) (normal.xyz, d) (centre.xyz, twoSided)
+// link_if_hit is the left child, link_if_miss / next is the next node of the reference's depth-first,
+// left-first order (Raytracer.cc:217-230) that is not below this one -- so following links visits
+// exactly the nodes the reference pops, in the same order, without a stack.  A leaf of n triangles
+// is a chain of n triangle blocks in list order; flags bit 0 marks the first block of a leaf.
 struct DevScene {
-    const float4 *nodes;
-    const float4 *top_nodes;  // the first n_top_cand inner nodes in breadth-first order, same 32-B records
-    uint32_t n_top_cand;
-    const uint32_t *node_right; // [n_nodes] link of an inner node's right child (kept for tools; the traversal follows hit/miss links)
-    const uint32_t *top_right;  // [n_top_cand] the same for top_nodes slots
-    const float4 *leafs;      // packed leaf blocks: [next link, count, first tri, -][plane records...]
+    const float4 *walk;
     const float4 *tri_edge;
     const float4 *tri_shade;
     uint32_t root_link;
@@ -82,10 +73,8 @@ struct FrameParams {
     int32_t xmin;              // service state transitions once this many lanes wait (or nobody traverses)
     int32_t rmin;              // refill once this many lanes are idle (or nobody is alive)
     int32_t chunk;             // pixel indices a wave takes from the dispenser at a time
-    int32_t trav;              // bit 1: exact box test only; bit 2: split long walks over idle lanes
+    int32_t exact_box;         // always use the exact six-division box test
     int32_t lmin;              // leaf postponement: test leaves once this many lanes wait on one (1 = if-if)
-    int32_t n_top_lds;         // top_nodes records cached in LDS by this launch (prefix length)
-    int32_t no_lds_top;        // tuning: disable the LDS cache of the BVH top
     int32_t scatter;           // dispenser hands out pixel slot s of every tile before slot s+1 (load balance)
     unsigned long long *wave_prof; // counting builds: 16 words of phase profile per wave (debug), or NULL
     const uint32_t *tile_order; // dispenser index -> 8x8 tile id (heavy tiles first), or NULL = row-major

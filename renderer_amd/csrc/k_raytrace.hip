@@ -1,27 +1,27 @@
-// k_raytrace.hip -- BVH-traversal raytracer, one ray per lane, persistent wavefronts.
+// k_raytrace.hip -- BVH-traversal raytracer, one pixel per lane, persistent wavefronts.
 //
 // Replaces RaytraceScanline<AA>::{RaytraceHorizontalSegment, Raytrace, BVH_IntersectTriangles}
 // and RayIntersectsBox (Raytracer.cc:99-606) and the scanline loop of Scene::renderRaytracer
 // (Raytracer.cc:791-868).  One launch renders a whole frame (or this GPU's screen bands).
 //
-// MI355X design:
+// MI355X design (every choice below is backed by a measurement in profiles/):
 //  * A lane owns one PIXEL and walks its whole ray tree as a small state machine:
-//    closest-hit traversal -> shading -> one any-hit shadow traversal per light ->
-//    reflection ray ... -> fold the per-depth colours.  The reference's recursion
-//    (Raytracer.cc:315-553) becomes forward evaluation + a backward fold with the same
-//    clamping Pixel::operator+ at each level.
-//  * Wavefronts are persistent: a lane that finishes its pixel pulls the next pixel from a
-//    global dispenser (one atomic per wave per refill, ballot + mbcnt ranking), so the 64
-//    lanes stay packed with live rays although ~88 % of primary rays die at the root box.
-//  * Traversal is STACKLESS.  The reference pops an explicit stack in a fixed left-first
-//    order that does not depend on the ray, so the pre-order node array is threaded with
-//    hit/miss links at upload time; following them visits exactly the reference's node
-//    sequence.  (No LDS stack is needed; LDS stays free for occupancy.)
-//  * Traversal runs "while-while": all traversing lanes first descend through inner nodes
-//    until each sits on a leaf, then the leaves' triangles are tested together, which keeps
-//    the box-test and triangle-test instruction streams converged.
-//  * State transitions (shading etc.) are batched: lanes whose traversal ended wait until
-//    XMIN lanes need service (or nobody traverses any more).
+//    closest-hit walk -> shading -> one any-hit shadow walk per light -> reflection walk ... ->
+//    fold the per-depth colours.  The reference's recursion (Raytracer.cc:315-553) becomes
+//    forward evaluation + a backward fold with the same clamping Pixel::operator+ at each level.
+//  * Wavefronts are persistent: a lane that finishes its pixel pulls the next one from a dispenser
+//    (ballot + mbcnt ranking, one global atomic per 64 pixels), so the 64 lanes stay packed although
+//    ~88 % of primary rays die at the root box.
+//  * The walk is STACKLESS: the reference pops an explicit stack in a fixed left-first order that
+//    does not depend on the ray, so every record carries the link to follow on a hit and on a miss;
+//    following them visits exactly the reference's node sequence.
+//  * A frame lasts as long as its longest chain of dependent steps (~1000 node visits for the
+//    worst pixel), so the loop is built to never wait on memory inside a step: all records live in
+//    ONE buffer (address = base + 16*link), the records behind BOTH links of a node are requested
+//    as soon as the node's own record is in registers, a leaf is a chain of single-triangle blocks,
+//    and a triangle's edge test is deferred by one step (its edge record is requested when the plane
+//    test passes and consumed at the lane's next step -- legal because a candidate only updates the
+//    running best, never the visiting order).
 //
 // Arithmetic follows the cited reference lines operation by operation (dev_math.h).
 #include "dev_math.h"
@@ -44,15 +44,17 @@ struct Lane {
     f3 o, d;
     f3 inv;                // rcp(d) per component, for the filtered box test
     bool tame;             // ray_is_tame(d)
-    uint32_t end;          // link at which this lane's share of the walk stops (MI_END_LINK for a whole ray)
-    int owner;             // helper lanes: lane id of the ray's owner; -1 on the owner itself
-    int pending;           // owner lanes: helpers still walking parts of the current ray
     int avoid;             // leaf-order index of the triangle to skip (avoidSelf), -1 = none
     float best;            // bestTriDist
     int btri;              // closest triangle so far (leaf order), -1 = none
     f3 hit;
     float k1, k2, k3;      // kAB, kBC, kCA
     bool shadow_hit;
+    // triangle that passed the plane test at the previous step; its edge test is still to run
+    bool pend;
+    int pj;
+    f3 ph;
+    float4 pe1, pe2, pe3;
     // shading context kept across the shadow rays of one hit
     f3 pn;                 // interpolated (Phong) normal
     f3 refl;               // reflected direction
@@ -142,7 +144,7 @@ MI_DEV void set_ray_aux(Lane &L)
 {
     L.inv = mk3(__builtin_amdgcn_rcpf(L.d.x), __builtin_amdgcn_rcpf(L.d.y), __builtin_amdgcn_rcpf(L.d.z));
     L.tame = ray_is_tame(L.o, L.d);
-    L.end = MI_END_LINK; L.owner = -1; L.pending = 0;       // a fresh ray: whole walk, no helpers
+    L.pend = false;
 }
 
 // Primary ray of pixel (px,py), sample index `traced` (Raytracer.cc:563-593)
@@ -239,37 +241,18 @@ MI_DEV void shade_begin(const FrameParams &P, const DevScene &S, Lane &L)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pipelined traversal.
-//
-// A lane always holds the RECORD of the node it is about to visit (Rec: three float4):
-//     inner node : a = (bmin, hit link)   b = (bmax, miss link)            (c unused)
-//     leaf block : a = header (next link, count, first triangle)  b, c = plane record of triangle 0
-// The walk is a chain of dependent loads, and a frame lasts as long as its longest chain, so the
-// loop never waits for a successor it could have asked for earlier: the moment a record is in
-// registers its links are known, and the records of BOTH possible successors (hit target and miss
-// target; for a leaf: the next node and the leaf's second plane record) are requested before the
-// box / triangle arithmetic starts.  When the arithmetic is done the right record is already on
-// its way.  Records of the BVH top come from the workgroup's LDS copy, the rest from L2/HBM; a flat
-// pointer hides the difference.
+// Walk records (DevScene::walk, float4 units; a link = index | MI_LEAF_BIT, or MI_END_LINK):
+//     inner node    : a = (bmin, hit link)            b = (bmax, miss link)
+//     triangle block: a = (next link, j, flags, -)    b = (normal, d)    c = (centre, twoSided)
+// A leaf of n triangles is a chain of n triangle blocks in list order; flags bit 0 marks the first
+// block of a leaf (the reference's "pop" of the leaf node, for the counters).
 struct Rec { float4 a, b, c; };
 
-// address of the record a link points to (a harmless dummy for MI_END_LINK)
-MI_DEV const float4 *rec_addr(const DevScene &S, const float4 *lds_top, int n_top_lds, uint32_t link)
+MI_DEV void rec_fetch(const DevScene &S, uint32_t link, Rec &r)
 {
-    const float4 *p = S.nodes + (size_t)(link & 0x3fffffffu) * 2;
-    if (link & MI_TOP_BIT) {
-        const uint32_t slot = link & 0x3fffffffu;
-        p = ((int)slot < n_top_lds) ? (lds_top + slot * 2) : (S.top_nodes + (size_t)slot * 2);
-    }
-    if (link & MI_LEAF_BIT) p = S.leafs + (size_t)(link & ~MI_LEAF_BIT);
-    if (link == MI_END_LINK) p = S.nodes;
-    return p;
-}
-
-MI_DEV void rec_fetch(const float4 *p, bool third, Rec &r)
-{
-    r.a = p[0]; r.b = p[1];
-    if (third) r.c = p[2];
+    const uint32_t idx = link == MI_END_LINK ? 0u : (link & ~MI_LEAF_BIT);
+    const float4 *p = S.walk + (size_t)idx;
+    r.a = p[0]; r.b = p[1]; r.c = p[2];
 }
 
 // Box test of an inner node's record (Raytracer.cc:222-230)
@@ -301,93 +284,47 @@ MI_DEV bool tri_plane_test(const Lane &L, float nudge, uint32_t j, const float4 
     return true;
 }
 
-// edge half (Raytracer.cc:269-297); returns true when a shadow ray is blocked (stop traversing)
-MI_DEV bool tri_edge_test(Lane &L, uint32_t j, const f3 hit, const float4 e1, const float4 e2, const float4 e3)
+// edge half (Raytracer.cc:269-297) of the pending candidate; returns true when a shadow ray is blocked
+MI_DEV bool tri_edge_test(Lane &L)
 {
-    const float kt1 = dot3(mk3(e1.x, e1.y, e1.z), hit) - e1.w; if (kt1 < 0.0f) return false;
-    const float kt2 = dot3(mk3(e2.x, e2.y, e2.z), hit) - e2.w; if (kt2 < 0.0f) return false;
-    const float kt3 = dot3(mk3(e3.x, e3.y, e3.z), hit) - e3.w; if (kt3 < 0.0f) return false;
+    const f3 hit = L.ph;
+    const float kt1 = dot3(mk3(L.pe1.x, L.pe1.y, L.pe1.z), hit) - L.pe1.w; if (kt1 < 0.0f) return false;
+    const float kt2 = dot3(mk3(L.pe2.x, L.pe2.y, L.pe2.z), hit) - L.pe2.w; if (kt2 < 0.0f) return false;
+    const float kt3 = dot3(mk3(L.pe3.x, L.pe3.y, L.pe3.z), hit) - L.pe3.w; if (kt3 < 0.0f) return false;
     if (L.mode == MODE_SHADOW) {
         if (distsq3(L.lp, hit) < L.best) { L.shadow_hit = true; return true; }
     } else {
         const float hitZ = distsq3(L.o, hit);
-        if (hitZ < L.best) { L.best = hitZ; L.btri = (int)j; L.hit = hit; L.k1 = kt1; L.k2 = kt2; L.k3 = kt3; }
+        if (hitZ < L.best) { L.best = hitZ; L.btri = L.pj; L.hit = hit; L.k1 = kt1; L.k2 = kt2; L.k3 = kt3; }
     }
     return false;
 }
 
-// Leaf visit: the leaf's triangles in list order (Raytracer.cc:235-298).  R holds the header and the
-// plane record of triangle 0, `second` the plane record of triangle 1 (requested one iteration
-// earlier); edge records are fetched for the triangles that survive the plane test, both at once.
-// Returns true when a shadow ray was blocked.
-template <bool STATS>
-MI_DEV bool leaf_visit(const DevScene &S, const FrameParams &P, Lane &L, const Rec &R, const Rec &second,
-                       unsigned &n_pops, unsigned &n_tris, unsigned &n_plane)
-{
-    const uint32_t count = __float_as_uint(R.a.y), first = __float_as_uint(R.a.z);
-    if (STATS) n_pops++;
-    f3 h0 = mk3(0.f, 0.f, 0.f), h1 = h0;
-    const bool t0 = count > 0 && tri_plane_test(L, P.nudge, first, R.b, R.c, h0);
-    const bool t1 = count > 1 && tri_plane_test(L, P.nudge, first + 1, second.a, second.b, h1);
-    float4 a1, a2, a3, b1, b2, b3;
-    if (t0) { a1 = S.tri_edge[(size_t)first * 3]; a2 = S.tri_edge[(size_t)first * 3 + 1]; a3 = S.tri_edge[(size_t)first * 3 + 2]; }
-    if (t1) { b1 = S.tri_edge[(size_t)(first + 1) * 3]; b2 = S.tri_edge[(size_t)(first + 1) * 3 + 1]; b3 = S.tri_edge[(size_t)(first + 1) * 3 + 2]; }
-    bool blocked = false;
-    if (t0) blocked = tri_edge_test(L, first, h0, a1, a2, a3);
-    // a blocked shadow ray returns before the reference even looks at the next triangle (Raytracer.cc:284)
-    const bool run1 = t1 && !blocked;
-    if (run1) blocked = tri_edge_test(L, first + 1, h1, b1, b2, b3);
-    if (STATS) {
-        // the reference's counters, in its order: triangle 1 is only reached when triangle 0 did not end the ray
-        const bool reached1 = count > 1 && !(t0 && blocked && !run1);
-        n_tris += (count > 0 ? 1u : 0u) + (reached1 ? 1u : 0u);
-        n_plane += (t0 ? 1u : 0u) + ((t1 && reached1) ? 1u : 0u);
-    }
-    if (!blocked && count > 2) {
-        const float4 *B = S.leafs + (size_t)(L.cur & ~MI_LEAF_BIT);
-        for (uint32_t t = 2; t < count; t++) {
-            const uint32_t j = first + t;
-            if (STATS) n_tris++;
-            f3 h;
-            if (!tri_plane_test(L, P.nudge, j, B[1 + 2 * t], B[2 + 2 * t], h)) continue;
-            if (STATS) n_plane++;
-            if (tri_edge_test(L, j, h, S.tri_edge[(size_t)j * 3], S.tri_edge[(size_t)j * 3 + 1], S.tri_edge[(size_t)j * 3 + 2])) { blocked = true; break; }
-        }
-    }
-    return blocked;
-}
-
 } // namespace
 
-template <bool STATS, int TRAV>
+template <bool STATS, bool EXACT_BOX>
 __global__ void __launch_bounds__(256)
 k_raytrace(const DevScene S, const FrameParams P)
 {
-    // LDS: [0, 12 KB) per-lane colour columns; then P.n_top_lds BVH-top node records of 32 B
-    extern __shared__ float4 lds_dyn[];
-    float *lds_col = reinterpret_cast<float *>(lds_dyn);
-    const float4 *lds_top = lds_dyn + (MI_MAX_DEPTH * 3 * 256) / 4;
-    for (int i = threadIdx.x; i < P.n_top_lds * 2; i += 256) lds_dyn[(MI_MAX_DEPTH * 3 * 256) / 4 + i] = S.top_nodes[i];
-    __syncthreads();
+    // LDS: per-lane colour columns of the ray tree's depth levels
+    __shared__ float lds_col[MI_MAX_DEPTH * 3 * 256];
     Lane L;
-    constexpr bool SPLIT = !STATS && (TRAV & 4) != 0;   // counting builds keep the reference's visiting order
     bool alive = false;         // lane owns a pixel
-    bool helper = false;        // lane walks part of another lane's ray
-    bool need_rec = true;       // the record of L.cur has not been fetched yet
-    Rec R;                      // record of the node this lane visits next
-    uint32_t offer_link = MI_END_LINK;
-    R.a = R.b = R.c = make_float4(0.f, 0.f, 0.f, 0.f);
     bool want_pixel = true;     // lane needs a (new) pixel
     bool exhausted = false;     // dispenser ran dry (wave-uniform)
+    bool need_rec = true;       // the record of L.cur has not been fetched yet
+    Rec R;                      // record of the node this lane visits next
+    R.a = R.b = R.c = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t pool_next = 0, pool_end = 0;   // wave-local pixel pool (wave-uniform)
     L.cur = MI_END_LINK; L.mode = MODE_CLOSEST; L.btri = -1; L.depth = 0; L.samples_left = 0;
     L.fr = L.fg = L.fb = 0.f; L.px = L.py = L.orow = 0; L.avoid = -1; L.best = 0.f;
     L.shadow_hit = false; L.li = 0; L.cr = L.cg = L.cb = 0.f; L.k1 = L.k2 = L.k3 = 0.f;
-    L.o = L.d = L.hit = L.pn = L.refl = L.lp = L.inv = mk3(0.f, 0.f, 0.f);
-    L.tame = false; L.end = MI_END_LINK; L.owner = -1; L.pending = 0;
+    L.o = L.d = L.hit = L.pn = L.refl = L.lp = L.inv = L.ph = mk3(0.f, 0.f, 0.f);
+    L.tame = false; L.pend = false; L.pj = -1;
+    L.pe1 = L.pe2 = L.pe3 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     unsigned n_normal = 0, n_shadow = 0;
-    unsigned n_pops = 0, n_ihits = 0, n_tris = 0, n_plane = 0, n_shaded = 0, n_lds = 0;
+    unsigned n_pops = 0, n_ihits = 0, n_tris = 0, n_plane = 0, n_shaded = 0;
     // phase profile (STATS builds only; wave-uniform): cycles and lane occupancy per phase
     unsigned long long pc_refill = 0, pc_trans = 0, pc_a = 0, pc_b = 0, pc_total = 0;
     unsigned long long it_refill = 0, ln_refill = 0, it_trans = 0, ln_trans = 0, it_a = 0, ln_a = 0, it_b = 0, ln_b = 0;
@@ -402,8 +339,6 @@ k_raytrace(const DevScene S, const FrameParams P)
     const int tiles_y = (P.n_rows + 7) >> 3;
     const uint32_t n_tiles = (uint32_t)tiles_x * (uint32_t)tiles_y;
     const uint32_t total = n_tiles * 64u;
-    const f3 eye = mk3(P.eye[0], P.eye[1], P.eye[2]);
-    (void)eye;
 
     for (;;) {
         // ---------------- refill: hand new pixels to idle lanes --------------------------
@@ -438,9 +373,8 @@ k_raytrace(const DevScene S, const FrameParams P)
                             const uint32_t rank = (uint32_t)__popcll(mW & ((1ull << lane) - 1ull));
                             if (rank < avail) {
                                 const uint32_t idx = pool_next + rank;
-                                // index -> (tile, pixel in tile).  Scattered: consecutive indices walk over different
-                                // tiles (same pixel slot), so the 64 pixels a wave takes at once come from 64
-                                // neighbouring tiles and every wave gets the same mix of cheap and expensive pixels.
+                                // index -> (tile, pixel in tile); optionally scattered (pixel slot s of every tile
+                                // before slot s+1), which balances better but loses ray coherence
                                 uint32_t tslot, sub;
                                 if (P.scatter) { tslot = idx % n_tiles; sub = idx / n_tiles; }
                                 else { tslot = idx >> 6; sub = idx & 63u; }
@@ -467,46 +401,15 @@ k_raytrace(const DevScene S, const FrameParams P)
             }
         }
 
-        // ---------------- helpers that finished their share: fold the result into the owner lane ----
-        // (SPLIT builds only.)  A helper walked a continuation of some owner's ray; its candidate
-        // competes with the owner's under the reference's rule -- smaller squared distance wins,
-        // equal distance goes to the triangle visited first = lower leaf-order index (Raytracer.cc:288).
-        const bool drain = exhausted && pool_next == pool_end;
-        if (SPLIT) {
-            unsigned long long mH = __ballot(helper && L.cur == L.end);
-            const int lane = (int)(threadIdx.x & 63u);
-            while (mH) {
-                const int h = __ffsll((long long)mH) - 1;
-                mH &= mH - 1ull;
-                const int ow = __builtin_amdgcn_readlane(L.owner, h);
-                const int h_tri = __builtin_amdgcn_readlane(L.btri, h);
-                const float h_best = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.best), h));
-                const int h_shadow = __builtin_amdgcn_readlane(L.shadow_hit ? 1 : 0, h);
-                const float hx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.hit.x), h));
-                const float hy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.hit.y), h));
-                const float hz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.hit.z), h));
-                const float hk1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.k1), h));
-                const float hk2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.k2), h));
-                const float hk3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.k3), h));
-                if (lane == ow) {
-                    L.pending--;
-                    if (L.mode == MODE_SHADOW) { if (h_shadow) L.shadow_hit = true; }
-                    else if (h_tri >= 0 && (L.btri < 0 || h_best < L.best || (h_best == L.best && h_tri < L.btri))) {
-                        L.best = h_best; L.btri = h_tri; L.hit = mk3(hx, hy, hz); L.k1 = hk1; L.k2 = hk2; L.k3 = hk3;
-                    }
-                }
-                if (lane == h) { helper = false; L.owner = -1; }
-            }
-        }
-        // a lane's ray is complete when its own share is walked and no helper is still out
-        const bool ray_done = alive && L.cur == L.end && L.pending == 0;
-        const bool trav_now = (alive || helper) && L.cur != L.end;
+        // a lane's ray is complete when its walk has ended and no candidate is left to judge
+        const bool ray_done = alive && L.cur == MI_END_LINK && !L.pend;
         const unsigned long long mX = __ballot(ray_done);
-        const unsigned long long mT = __ballot(trav_now);
+        const unsigned long long mT = __ballot(alive && !ray_done);
         if (!mX && !mT) {
             if (!__ballot(want_pixel)) break;
             continue;
         }
+        const bool drain = exhausted && pool_next == pool_end;
         const int xmin_now = drain ? 1 : P.xmin;          // nothing left to batch with once the dispenser is dry
 
         if (mX && (__popcll(mX) >= xmin_now || !mT)) {
@@ -543,8 +446,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                             L.mode = MODE_SHADOW;
                             L.shadow_hit = false;
                             L.cur = S.root_link; need_rec = true;
-                            // avoid stays = the triangle just hit (set below on first entry)
-                            L.avoid = L.btri;
+                            L.avoid = L.btri;                       // avoidSelf = the triangle just hit (Raytracer.cc:335)
                             n_shadow++;
                             launched = true;
                             break;
@@ -589,7 +491,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         }
                         alive = false;
                         want_pixel = true;
-                        L.cur = MI_END_LINK; L.end = MI_END_LINK;
+                        L.cur = MI_END_LINK;
                     }
                 }
             }
@@ -598,103 +500,69 @@ k_raytrace(const DevScene S, const FrameParams P)
         }
 
         // ---------------- traversal burst ------------------------------------------------
-        // Keep traversing until enough lanes have run off the tree to make servicing them worthwhile.
+        // Keep walking until enough lanes have finished their ray to make servicing them worthwhile.
         MI_PHASE(pc_refill);
-        // lanes with nothing to do and nothing to fetch: candidates to help with somebody else's ray
-        unsigned long long idle_mask = (SPLIT && drain) ? __ballot(!alive && !helper) : 0ull;
         for (;;) {
-            // Every traversing lane sits on an inner node or on a leaf.  Inner lanes take one step per
-            // iteration; leaf lanes are held back until P.lmin of them have gathered (or nothing else can
-            // move), so the triangle-test code runs with a fuller exec mask.  lmin = 1 is plain if-if,
-            // lmin = 64 is while-while.
             if (STATS) it_loops++;
-            const bool trav = (alive || helper) && L.cur != L.end;
             // a lane that has just been given a ray does not hold its first record yet
-            if (trav && need_rec) {
-                rec_fetch(rec_addr(S, lds_top, P.n_top_lds, L.cur), (L.cur & MI_LEAF_BIT) != 0, R);
-                need_rec = false;
+            if (alive && need_rec && L.cur != MI_END_LINK) { rec_fetch(S, L.cur, R); need_rec = false; }
+            // 1. judge the triangle that passed the plane test at the previous step
+            if (__ballot(L.pend)) {
+                if (L.pend) {
+                    L.pend = false;
+                    if (tri_edge_test(L)) L.cur = MI_END_LINK;      // a blocked shadow ray stops (Raytracer.cc:284)
+                }
             }
-            const bool inner = trav && (L.cur & MI_LEAF_BIT) == 0;
-            const bool leaf_any = trav && (L.cur & MI_LEAF_BIT) != 0;
-            const unsigned long long mI = __ballot(inner), mL = __ballot(leaf_any);
-            const bool leaf = leaf_any && (!mI || __popcll(mL) >= P.lmin);
-            // ---- request the successors' records before any arithmetic -----------------------------
-            //   inner lane: slot 1 = record behind the hit link, slot 2 = record behind the miss link
-            //   leaf lane : slot 1 = record behind the leaf's next link, slot 2 = plane record of triangle 1
+            const bool walking = alive && L.cur != MI_END_LINK;
+            const bool inner = walking && (L.cur & MI_LEAF_BIT) == 0;
+            const bool tri_any = walking && (L.cur & MI_LEAF_BIT) != 0;
+            const unsigned long long mI = __ballot(inner), mL = __ballot(tri_any);
+            // triangle lanes may be held back until P.lmin of them have gathered (lmin = 1: plain if-if)
+            const bool tri = tri_any && (!mI || __popcll(mL) >= P.lmin);
+            // 2. request the successors' records before any arithmetic
+            //    inner lane: behind the hit link and behind the miss link; triangle lane: behind the next link
             const uint32_t link1 = inner ? __float_as_uint(R.a.w) : __float_as_uint(R.a.x);
             const uint32_t link2 = __float_as_uint(R.b.w);
             Rec N1, N2;
-            if (inner || leaf) {
-                const float4 *p1 = rec_addr(S, lds_top, P.n_top_lds, link1);
-                const float4 *p2 = inner ? rec_addr(S, lds_top, P.n_top_lds, link2)
-                                         : (S.leafs + (size_t)(L.cur & ~MI_LEAF_BIT) + 3);
-                rec_fetch(p1, (link1 & MI_LEAF_BIT) != 0, N1);
-                rec_fetch(p2, inner && (link2 & MI_LEAF_BIT) != 0, N2);
-            }
-            bool offer = false;
+            if (inner || tri) rec_fetch(S, link1, N1);
+            if (inner) rec_fetch(S, link2, N2);
+            // 3. inner nodes
             if (mI) {
                 if (STATS) { it_a++; ln_a += __popcll(mI); }
                 if (inner) {
-                    const bool h = inner_test<(TRAV & 2) != 0>(L, R);
-                    if (STATS) { n_pops++; if (h) n_ihits++; if ((L.cur & MI_TOP_BIT) && (int)(L.cur & 0x3fffffffu) < P.n_top_lds) n_lds++; }
-                    // Box hit at node X: this lane now walks X's subtree, then everything from X's miss link
-                    // up to L.end.  That second part can be given away if it starts high in the tree.
-                    offer = SPLIT && h && link2 != L.end && (link2 & MI_TOP_BIT) != 0 && link2 != MI_END_LINK;
-                    offer_link = link2;
+                    const bool h = inner_test<EXACT_BOX>(L, R);
+                    if (STATS) { n_pops++; if (h) n_ihits++; }
                     L.cur = h ? link1 : link2;
                     R.a = h ? N1.a : N2.a; R.b = h ? N1.b : N2.b; R.c = h ? N1.c : N2.c;
                 }
                 MI_PHASE(pc_a);
             }
-            if (SPLIT && idle_mask) {
-                // ---- hand continuations to idle lanes (drain phase only) --------------------------------
-                unsigned long long mO = __ballot(offer);
-                const int lane = (int)(threadIdx.x & 63u);
-                while (mO && idle_mask) {
-                    const int a = __ffsll((long long)mO) - 1, t = __ffsll((long long)idle_mask) - 1;
-                    mO &= mO - 1ull;
-                    idle_mask &= idle_mask - 1ull;
-#define MI_RL_F(v) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (v)), a))
-#define MI_RL_I(v) __builtin_amdgcn_readlane((int)(v), a)
-                    const float ox = MI_RL_F(L.o.x), oy = MI_RL_F(L.o.y), oz = MI_RL_F(L.o.z);
-                    const float dx = MI_RL_F(L.d.x), dy = MI_RL_F(L.d.y), dz = MI_RL_F(L.d.z);
-                    const float ix = MI_RL_F(L.inv.x), iy = MI_RL_F(L.inv.y), iz = MI_RL_F(L.inv.z);
-                    const float lx = MI_RL_F(L.lp.x), ly = MI_RL_F(L.lp.y), lz = MI_RL_F(L.lp.z);
-                    const float a_best = MI_RL_F(L.best);
-                    const int a_avoid = MI_RL_I(L.avoid), a_mode = MI_RL_I(L.mode), a_tame = MI_RL_I(L.tame ? 1 : 0);
-                    const uint32_t a_end = (uint32_t)MI_RL_I(L.end);
-                    const uint32_t a_k = (uint32_t)MI_RL_I(offer_link);
-                    const int a_owner = MI_RL_I(L.owner);
-#undef MI_RL_F
-#undef MI_RL_I
-                    const int ow = a_owner >= 0 ? a_owner : a;
-                    if (lane == t) {
-                        L.o = mk3(ox, oy, oz); L.d = mk3(dx, dy, dz); L.inv = mk3(ix, iy, iz); L.lp = mk3(lx, ly, lz);
-                        L.best = a_best;          // a later triangle must beat what the walk before it has found
-                        L.avoid = a_avoid; L.mode = a_mode; L.tame = a_tame != 0;
-                        L.btri = -1; L.shadow_hit = false;
-                        L.cur = a_k; L.end = a_end; L.owner = ow; L.pending = 0;
-                        helper = true; need_rec = true;
-                    }
-                    if (lane == a) L.end = a_k;   // the giver stops where the helper starts
-                    if (lane == ow) L.pending++;
-                }
-            }
+            // 4. triangle blocks: plane test now, edge test at this lane's next step
             if (mL && (!mI || __popcll(mL) >= P.lmin)) {
                 if (STATS) { it_b++; ln_b += __popcll(mL); }
-                if (leaf) {
-                    const bool blocked = leaf_visit<STATS>(S, P, L, R, N2, n_pops, n_tris, n_plane);
-                    L.cur = blocked ? L.end : link1;          // a blocked shadow ray stops here (Raytracer.cc:284)
+                if (tri) {
+                    const uint32_t j = __float_as_uint(R.a.y);
+                    if (STATS) { n_tris++; if (__float_as_uint(R.a.z) & 1u) n_pops++; }
+                    f3 h;
+                    if (tri_plane_test(L, P.nudge, j, R.b, R.c, h)) {
+                        if (STATS) n_plane++;
+                        L.pe1 = S.tri_edge[(size_t)j * 3]; L.pe2 = S.tri_edge[(size_t)j * 3 + 1]; L.pe3 = S.tri_edge[(size_t)j * 3 + 2];
+                        L.pj = (int)j; L.ph = h; L.pend = true;
+                    }
+                    L.cur = link1;
                     R = N1;
+                    if (STATS && L.pend) {
+                        // counting builds judge at once so that a blocked shadow ray stops exactly where the
+                        // reference does and the counters stay comparable
+                        L.pend = false;
+                        if (tri_edge_test(L)) L.cur = MI_END_LINK;
+                    }
                 }
                 MI_PHASE(pc_b);
             }
-            const unsigned long long mTr = __ballot((alive || helper) && L.cur != L.end);
-            if (!mTr) break;
-            // owners waiting for helpers do not count; finished helpers are serviced at once in the drain
-            const unsigned long long mDone = __ballot(alive && L.cur == L.end && L.pending == 0);
-            if (__popcll(mDone) >= xmin_now) break;
-            if (SPLIT && __ballot(helper && L.cur == L.end)) break;
+            const unsigned long long mDone = __ballot(alive && L.cur == MI_END_LINK && !L.pend);
+            const unsigned long long mBusy = __ballot(alive && !(L.cur == MI_END_LINK && !L.pend));
+            if (!mBusy || __popcll(mDone) >= xmin_now) break;
         }
     }
     if (STATS) pc_total = __builtin_readcyclecounter() - tick0;
@@ -715,19 +583,19 @@ k_raytrace(const DevScene S, const FrameParams P)
         if (lead) { atomicAdd(&P.counters[CS_NORMAL_RAYS], a); atomicAdd(&P.counters[CS_SHADOW_RAYS], b); }
         if (STATS) {
             const unsigned long long c = wsum(n_pops), d = wsum(n_ihits), e = wsum(n_tris), f = wsum(n_plane),
-                                     g = wsum(n_shaded), h = wsum(n_lds);
+                                     g = wsum(n_shaded);
             if (lead) {
                 atomicAdd(&P.counters[CS_NODE_POPS], c); atomicAdd(&P.counters[CS_INNER_HITS], d);
                 atomicAdd(&P.counters[CS_TRI_TESTS], e); atomicAdd(&P.counters[CS_PLANE_PASS], f);
                 atomicAdd(&P.counters[CS_SHADED_HITS], g);
                 const unsigned long long prof[15] = {pc_total, pc_refill, pc_trans, pc_a, pc_b, it_refill, ln_refill,
-                                                     it_trans, ln_trans, it_a, ln_a, it_b, ln_b, 1ull, h};
+                                                     it_trans, ln_trans, it_a, ln_a, it_b, ln_b, 1ull, 0ull};
                 for (int i = 0; i < 15; i++) atomicAdd(&P.counters[CS_PROF0 + i], prof[i]);
                 // 100 MHz real-time stamps: launch start (min), dispenser dry (min), last wave done (max)
                 atomicMin(&P.counters[CS_TIME0], rt0);
                 if (rt_dry) atomicMin(&P.counters[CS_TIME0 + 1], rt_dry);
                 atomicMax(&P.counters[CS_TIME0 + 2], __builtin_amdgcn_s_memrealtime());
-                atomicMax(&P.counters[CS_TIME0 + 3], it_a + it_b);   // most traversal iterations done by one wave
+                atomicMax(&P.counters[CS_TIME0 + 3], it_loops);      // most loop iterations done by one wave
                 if (P.wave_prof) {
                     unsigned long long *w = P.wave_prof + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * 16u;
                     for (int i = 0; i < 15; i++) w[i] = prof[i];
@@ -740,44 +608,30 @@ k_raytrace(const DevScene S, const FrameParams P)
 }
 
 // ---- launch helper (called from capi.hip) ------------------------------------------------
-// trav: bit 1 = always use the exact six-division box test, bit 2 = split long walks over idle lanes
-template <bool STATS, int TRAV> static int occ_of(int lds_bytes)
+template <bool STATS, bool EXACT> static int occ_of()
 {
     int nb = 0;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_raytrace<STATS, TRAV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_raytrace<STATS, TRAV>, 256, lds_bytes) != hipSuccess || nb < 1) nb = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_raytrace<STATS, EXACT>, 256, 0) != hipSuccess || nb < 1) nb = 2;
     return nb > 8 ? 8 : nb;
 }
 
-extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int trav, int lds_bytes)
+extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact)
 {
-    static int occ[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    if (stats) trav &= 2;                       // counting builds never use the cooperative traversal
-    int &o = occ[stats ? 1 : 0][(trav >> 1) & 3];
-    if (!o) {
-        switch (((stats ? 1 : 0) << 2) | ((trav >> 1) & 3)) {
-        case 0: o = occ_of<false, 0>(lds_bytes); break;
-        case 1: o = occ_of<false, 2>(lds_bytes); break;
-        case 2: o = occ_of<false, 4>(lds_bytes); break;
-        case 3: o = occ_of<false, 6>(lds_bytes); break;
-        case 4: o = occ_of<true, 0>(lds_bytes); break;
-        default: o = occ_of<true, 2>(lds_bytes); break;
-        }
-    }
+    static int occ[2][2] = {{0, 0}, {0, 0}};
+    int &o = occ[stats ? 1 : 0][exact ? 1 : 0];
+    if (!o) o = stats ? (exact ? occ_of<true, true>() : occ_of<true, false>()) : (exact ? occ_of<false, true>() : occ_of<false, false>());
     return o;
 }
 
-extern "C" hipError_t mi355i_launch_raytrace(const DevScene *S, const FrameParams *P, int stats, int trav, int n_blocks,
-                                             int lds_bytes, hipStream_t st)
+extern "C" hipError_t mi355i_launch_raytrace(const DevScene *S, const FrameParams *P, int stats, int exact, int n_blocks,
+                                             hipStream_t st)
 {
-    if (stats) trav &= 2;
-    switch (((stats ? 1 : 0) << 2) | ((trav >> 1) & 3)) {
-    case 0: hipLaunchKernelGGL((k_raytrace<false, 0>), dim3(n_blocks), dim3(256), lds_bytes, st, *S, *P); break;
-    case 1: hipLaunchKernelGGL((k_raytrace<false, 2>), dim3(n_blocks), dim3(256), lds_bytes, st, *S, *P); break;
-    case 2: hipLaunchKernelGGL((k_raytrace<false, 4>), dim3(n_blocks), dim3(256), lds_bytes, st, *S, *P); break;
-    case 3: hipLaunchKernelGGL((k_raytrace<false, 6>), dim3(n_blocks), dim3(256), lds_bytes, st, *S, *P); break;
-    case 4: hipLaunchKernelGGL((k_raytrace<true, 0>), dim3(n_blocks), dim3(256), lds_bytes, st, *S, *P); break;
-    default: hipLaunchKernelGGL((k_raytrace<true, 2>), dim3(n_blocks), dim3(256), lds_bytes, st, *S, *P); break;
+    if (stats) {
+        if (exact) hipLaunchKernelGGL((k_raytrace<true, true>), dim3(n_blocks), dim3(256), 0, st, *S, *P);
+        else hipLaunchKernelGGL((k_raytrace<true, false>), dim3(n_blocks), dim3(256), 0, st, *S, *P);
+    } else {
+        if (exact) hipLaunchKernelGGL((k_raytrace<false, true>), dim3(n_blocks), dim3(256), 0, st, *S, *P);
+        else hipLaunchKernelGGL((k_raytrace<false, false>), dim3(n_blocks), dim3(256), 0, st, *S, *P);
     }
     return hipGetLastError();
 }
