@@ -10,16 +10,20 @@
 // equals, the lowest triangle index.  The GPU pipeline makes that order explicit instead of
 // racing on it (the reference's OpenMP build does race):
 //
-//   k_rs_setup : 1 lane / triangle.  Cull, transform, near-reject, project, Filler, then the three
-//                edge walkers of the ScanConverter are advanced TOGETHER scanline by scanline
-//                (each edge still accumulates `vtc += d12` serially from its own start, and a
-//                row receives its endpoints in the reference's AB, AC, BC order), so every
-//                row's (left, right) span record is produced in registers and written once.
-//   k_rs_depth : 1 lane / span row.  Walks 1/z across the span exactly like the reference
+//   k_rs_tri   : 1 lane / triangle.  Cull, transform, near-reject, project, Filler; allocates the
+//                triangle's row records and work items.
+//   k_rs_rows  : 1 lane / 32 scanlines of a drawn triangle.  The three edge walkers of the
+//                ScanConverter are advanced TOGETHER scanline by scanline (each edge still
+//                accumulates `vtc += d12` serially from its own start -- a lane that begins in the
+//                middle of a triangle first replays those additions in registers -- and a row
+//                receives its endpoints in the reference's AB, AC, BC order), so every row's
+//                (left, right) span record is produced in registers and written once.
+//   k_rs_spans : 1 lane / 64 pixels of a span row (again with an in-register replay of the serial
+//                `start += dLR` chain up to its chunk).  Depth pass: walks 1/z exactly like the reference
 //                (`start += dLR`, serial) and does a 64-bit atomicMax of (zbits << 32 | ~tri).
 //                Only z > 0 can pass the reference's test against the cleared buffer, and
 //                positive floats order like their bit patterns.
-//   k_rs_attr  : 1 lane / span row.  Walks all interpolants again and stores the fat point of the
+//   (attr pass)  the same walk over all interpolants stores the fat point of the
 //                fragment whose key won into a per-pixel G-buffer (2 x float4).
 //   k_rs_shade : 1 lane / PIXEL.  Plot<> / IlluminatePixel / LightingEquation on the stored fat point,
 //                fully parallel and coalesced; only winners are shaded (the reference shades every
@@ -31,6 +35,8 @@
 #include "dev_scene.h"
 #include <cstring>
 
+#define MI_SPAN_CHUNK 32    // pixels of a span one lane walks with memory operations
+
 struct RowRec {            // 80 B
     float l[8];
     float r[8];
@@ -40,11 +46,25 @@ struct RowRec {            // 80 B
     uint32_t pad;
 };
 
+#define MI_ROW_CHUNK 4      // scanlines of a triangle one lane of k_rs_rows emits
+
+struct TriRec {            // a triangle that survived culling, ready for the edge walk (144 B)
+    float f[3][8];         // the three fat points (N <= 8 interpolants)
+    int32_t iy[3];
+    uint32_t tri;          // input-order index
+    int32_t miny;
+    uint32_t nrows, rows_base, work_base, slots_per_row;
+    uint32_t pad[3];
+};
+
 struct RasterScratch {
     unsigned long long *keys = nullptr; size_t keys_words = 0;
     float4 *gbuf = nullptr;        // [pixels][2] interpolated fat point of the winning fragment
     RowRec *rows = nullptr; uint32_t rows_cap = 0;
-    uint32_t *ctl = nullptr;       // [0] rows used, [1] rows dropped because the span buffer was full
+    uint32_t *ctl = nullptr;       // [0] rows used, [1] rows dropped because the span buffer was full, [2] span chunks
+    uint2 *work = nullptr; uint32_t work_cap = 0;   // (row, chunk) items of the span passes
+    TriRec *tris = nullptr; uint32_t tris_cap = 0;   // drawn triangles; ctl[3] = count
+    uint2 *rcwork = nullptr; uint32_t rcwork_cap = 0; // (triangle record, row chunk) items of k_rs_rows; ctl[4] = count
     uint32_t *smkeys = nullptr; size_t sm_words = 0;
 };
 
@@ -202,9 +222,38 @@ MI_DEV void edge_row(Edge<N> &E, int y, float (&l)[N], float (&r)[N], uint32_t &
     scan_add<N>(l, r, cnt, E.v);
 }
 
+// visible pixels of a row, counted exactly as Screen::RasterizeTriangle clips them (Screen.h:244-275), in chunks
+// edge_row for a walker that edge_skip() already advanced to row ystart-1: identical (the addition that produces
+// row y from row y-1 happens here for every y > y0)
+template <int N>
+MI_DEV void edge_row_at(Edge<N> &E, int y, int ystart, float (&l)[N], float (&r)[N], uint32_t &cnt)
+{
+    (void)ystart;
+    edge_row<N>(E, y, l, r, cnt);
+}
+
+template <int N>
+MI_DEV uint32_t row_chunks(float lx, float rx, uint32_t cnt, int W)
+{
+    long long npix = 1;
+    const int x1 = myfloor_i(lx);
+    if (cnt >= 2) {
+        const int x2 = myfloor_i(rx);
+        if (x1 >= W || x2 < 0) return 0;
+        long long steps = llabs((long long)x2 - (long long)x1);
+        if (steps) {
+            if (x1 < 0) steps -= -(long long)x1;
+            if (x2 >= W) steps -= ((long long)x2 - W + 1);
+            npix = steps + 1;
+        }
+    }
+    return npix > 0 ? (uint32_t)((npix + MI_SPAN_CHUNK - 1) / MI_SPAN_CHUNK) : 0u;
+}
+
 template <int N>
 MI_DEV void emit_rows(int iy0, int iy1, int iy2, const float (&A)[N], const float (&B)[N], const float (&C)[N],
-                      int order, int height, uint32_t tri, RowRec *rows, uint32_t rows_cap, uint32_t *ctl)
+                      int order, int height, uint32_t tri, RowRec *rows, uint32_t rows_cap, uint32_t *ctl,
+                      int W = 0, uint2 *work = nullptr, uint32_t work_cap = 0)
 {
     const int INT_MIN_ = (int)0x80000000;
     if (iy0 == INT_MIN_ || iy1 == INT_MIN_ || iy2 == INT_MIN_) return;    // NaN / overflowed projections
@@ -228,6 +277,19 @@ MI_DEV void emit_rows(int iy0, int iy1, int iy2, const float (&A)[N], const floa
         edge_init<N>(e1, iy1, B, iy2, C, height);
         edge_init<N>(e2, iy0, A, iy2, C, height);
     }
+    // upper bound of 64-pixel chunks any row of this triangle can need, from its projected x extent
+    uint32_t slots_per_row = 1, wbase = 0;
+    if (work) {
+        float xlo = A[0] < B[0] ? A[0] : B[0]; xlo = xlo < C[0] ? xlo : C[0];
+        float xhi = A[0] > B[0] ? A[0] : B[0]; xhi = xhi > C[0] ? xhi : C[0];
+        if (!(xlo > -1.f)) xlo = -1.f;
+        if (!(xhi < (float)W)) xhi = (float)W;
+        const float wpx = xhi - xlo;
+        slots_per_row = (wpx > 0.f ? (uint32_t)(wpx * (1.0f / MI_SPAN_CHUNK)) : 0u) + 2u;
+        const uint32_t need = slots_per_row * nrows;
+        wbase = atomicAdd(&ctl[2], need);
+        if (wbase + need > work_cap) { atomicAdd(&ctl[1], nrows); work = nullptr; }
+    }
     for (int y = miny; y <= maxy; y++) {
         float l[N], r[N];
         uint32_t cnt = 0;
@@ -240,6 +302,103 @@ MI_DEV void emit_rows(int iy0, int iy1, int iy2, const float (&A)[N], const floa
 #pragma unroll
         for (int i = 0; i < N; i++) { R.l[i] = l[i]; R.r[i] = r[i]; }
         R.tri = tri; R.y = y; R.cnt = cnt; R.pad = 0;
+        if (work) {
+            // (row, chunk) items of the span passes: this triangle owns slots_per_row slots per row, unused ones
+            // are marked invalid, so no second pass and no per-row atomic is needed
+            const uint32_t nch = row_chunks<N>(l[0], r[0], cnt, W);
+            uint2 *wr = work + wbase + (size_t)(y - miny) * slots_per_row;
+            for (uint32_t c = 0; c < slots_per_row; c++)
+                wr[c] = c < nch ? make_uint2(base + (uint32_t)(y - miny), c) : make_uint2(0xffffffffu, 0u);
+        }
+    }
+}
+
+// ---- the same work as emit_rows, split so that tall triangles are spread over several lanes -------------
+// tri_alloc: row range, row records and span-chunk slots of one triangle; one (record, row chunk) item per
+// MI_ROW_CHUNK scanlines.  rows_emit: one such item -- the three edge walkers are re-initialised and their
+// serial `vtc += d12` additions (ScanConverter.h:112-116) replayed in registers up to the chunk's first row.
+template <int N>
+MI_DEV void tri_alloc(int iy0, int iy1, int iy2, const float (&A)[N], const float (&B)[N], const float (&C)[N], int height,
+                      int W, uint32_t tri, uint32_t rows_cap, uint32_t work_cap, TriRec *tris, uint32_t tris_cap,
+                      uint2 *rcwork, uint32_t rcwork_cap, uint32_t *ctl)
+{
+    const int INT_MIN_ = (int)0x80000000;
+    if (iy0 == INT_MIN_ || iy1 == INT_MIN_ || iy2 == INT_MIN_) return;    // NaN / overflowed projections
+    int miny = min(iy0, min(iy1, iy2)), maxy = max(iy0, max(iy1, iy2));
+    if (miny < 0) miny = 0;
+    if (maxy > height - 1) maxy = height - 1;
+    if (miny > maxy) return;
+    const uint32_t nrows = (uint32_t)(maxy - miny + 1);
+    float xlo = A[0] < B[0] ? A[0] : B[0]; xlo = xlo < C[0] ? xlo : C[0];
+    float xhi = A[0] > B[0] ? A[0] : B[0]; xhi = xhi > C[0] ? xhi : C[0];
+    if (!(xlo > -1.f)) xlo = -1.f;
+    if (!(xhi < (float)W)) xhi = (float)W;
+    const float wpx = xhi - xlo;
+    const uint32_t slots_per_row = (wpx > 0.f ? (uint32_t)(wpx * (1.0f / MI_SPAN_CHUNK)) : 0u) + 2u;
+    const uint32_t nrc = (nrows + MI_ROW_CHUNK - 1) / MI_ROW_CHUNK;
+    const uint32_t rows_base = atomicAdd(&ctl[0], nrows);
+    const uint32_t work_base = atomicAdd(&ctl[2], slots_per_row * nrows);
+    const uint32_t ti = atomicAdd(&ctl[3], 1u);
+    const uint32_t rcb = atomicAdd(&ctl[4], nrc);
+    if (rows_base + nrows > rows_cap || work_base + slots_per_row * nrows > work_cap || ti >= tris_cap || rcb + nrc > rcwork_cap) {
+        atomicAdd(&ctl[1], nrows);
+        // keep the item lists consistent: the items of a dropped triangle are marked invalid
+        for (uint32_t c = 0; c < nrc && rcb + c < rcwork_cap; c++) rcwork[rcb + c] = make_uint2(0xffffffffu, 0u);
+        return;
+    }
+    TriRec &T = tris[ti];
+#pragma unroll
+    for (int i = 0; i < N; i++) { T.f[0][i] = A[i]; T.f[1][i] = B[i]; T.f[2][i] = C[i]; }
+    T.iy[0] = iy0; T.iy[1] = iy1; T.iy[2] = iy2;
+    T.tri = tri; T.miny = miny; T.nrows = nrows; T.rows_base = rows_base; T.work_base = work_base; T.slots_per_row = slots_per_row;
+    for (uint32_t c = 0; c < nrc; c++) rcwork[rcb + c] = make_uint2(ti, c);
+}
+
+template <int N>
+MI_DEV void edge_skip(Edge<N> &E, int ystart)
+{
+    // bring the walker to the state it has after emitting row ystart-1
+    if (E.horiz || E.y0 > E.y1) return;
+    int last = ystart - 1;
+    if (last > E.y1) last = E.y1;
+    for (int y = E.y0 + 1; y <= last; y++) {
+#pragma unroll
+        for (int i = 0; i < N; i++) E.v[i] += E.d[i];
+    }
+}
+
+template <int N>
+MI_DEV void rows_emit(const TriRec &T, uint32_t rc, int height, int W, RowRec *rows, uint2 *work)
+{
+    float A[N], B[N], C[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) { A[i] = T.f[0][i]; B[i] = T.f[1][i]; C[i] = T.f[2][i]; }
+    Edge<N> e0, e1, e2;                 // Screen.h:239-241: AB, AC, BC
+    edge_init<N>(e0, T.iy[0], A, T.iy[1], B, height);
+    edge_init<N>(e1, T.iy[0], A, T.iy[2], C, height);
+    edge_init<N>(e2, T.iy[1], B, T.iy[2], C, height);
+    const int ystart = T.miny + (int)(rc * MI_ROW_CHUNK);
+    int yend = ystart + MI_ROW_CHUNK - 1;
+    const int maxy = T.miny + (int)T.nrows - 1;
+    if (yend > maxy) yend = maxy;
+    edge_skip<N>(e0, ystart); edge_skip<N>(e1, ystart); edge_skip<N>(e2, ystart);
+    for (int y = ystart; y <= yend; y++) {
+        float l[N], r[N];
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) { l[i] = 0.f; r[i] = 0.f; }
+        // a walker that was skipped forward must not add again on its first row here unless that row is past its start
+        edge_row_at<N>(e0, y, ystart, l, r, cnt);
+        edge_row_at<N>(e1, y, ystart, l, r, cnt);
+        edge_row_at<N>(e2, y, ystart, l, r, cnt);
+        const uint32_t ri = T.rows_base + (uint32_t)(y - T.miny);
+        RowRec &R = rows[ri];
+#pragma unroll
+        for (int i = 0; i < N; i++) { R.l[i] = l[i]; R.r[i] = r[i]; }
+        R.tri = T.tri; R.y = y; R.cnt = cnt; R.pad = 0;
+        const uint32_t nch = row_chunks<N>(l[0], r[0], cnt, W);
+        uint2 *wr = work + T.work_base + (size_t)(y - T.miny) * T.slots_per_row;
+        for (uint32_t c = 0; c < T.slots_per_row; c++) wr[c] = c < nch ? make_uint2(ri, c) : make_uint2(0xffffffffu, 0u);
     }
 }
 
@@ -257,8 +416,9 @@ MI_DEV int out_row(const FrameParams &P, int y)
 // ---------------------------------------------------------------------------------------------
 // Triangle setup: Rasterizers.cc:253-309 + Filler<> (Fillers.h:176-300) + edge walk
 template <int MODE>
-__global__ void __launch_bounds__(128) k_rs_setup(const DevScene S, const FrameParams P, RowRec *rows,
-                                                  uint32_t rows_cap, uint32_t *ctl)
+__global__ void __launch_bounds__(128) k_rs_tri(const DevScene S, const FrameParams P, uint32_t rows_cap, uint32_t *ctl,
+                                                uint32_t work_cap, TriRec *tris, uint32_t tris_cap, uint2 *rcwork,
+                                                uint32_t rcwork_cap)
 {
     constexpr int N = FatN<MODE>::N;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -318,47 +478,72 @@ __global__ void __launch_bounds__(128) k_rs_setup(const DevScene S, const FrameP
         }
     }
     if (P.counters) atomicAdd(&P.counters[CS_TRIS_DRAWN], 1ull);
-    emit_rows<N>(iy[0], iy[1], iy[2], f[0], f[1], f[2], 0, P.H, t, rows, rows_cap, ctl);
+    tri_alloc<N>(iy[0], iy[1], iy[2], f[0], f[1], f[2], P.H, P.W, t, rows_cap, work_cap, tris, tris_cap, rcwork, rcwork_cap, ctl);
+}
+
+// Edge walk of MI_ROW_CHUNK scanlines of one drawn triangle (ScanConverter.h:27-137 + row clipping of Screen.h:244-275)
+template <int MODE>
+__global__ void __launch_bounds__(128) k_rs_rows(const FrameParams P, const TriRec *tris, const uint2 *rcwork,
+                                                 uint32_t rcwork_cap, const uint32_t *ctl, RowRec *rows, uint2 *work)
+{
+    constexpr int N = FatN<MODE>::N;
+    uint32_t n = ctl[4];
+    if (n > rcwork_cap) n = rcwork_cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint2 item = rcwork[i];
+        if (item.x == 0xffffffffu) continue;
+        rows_emit<N>(tris[item.x], item.y, P.H, P.W, rows, work);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Span walk, shared by the depth and shade passes (Screen.h:244-290)
 template <int MODE, bool ATTR>
 __global__ void __launch_bounds__(256) k_rs_spans(const DevScene S, const FrameParams P, const RowRec *rows,
-                                                  const uint32_t *ctl, unsigned long long *keys, float4 *gbuf)
+                                                  const uint32_t *ctl, const uint2 *work, uint32_t work_cap,
+                                                  unsigned long long *keys, float4 *gbuf)
 {
     constexpr int N = FatN<MODE>::N;
     constexpr int ZI = (MODE == M_AMBIENT || MODE == M_GOURAUD) ? 1 : 3;
-    uint32_t n_rows = ctl[0];
-    if (n_rows > P.rows_cap) n_rows = P.rows_cap;       // allocation overshoot of dropped triangles
+    constexpr int NW = ATTR ? N : 1;                     // the depth pass only interpolates 1/z
+    uint32_t n_work = ctl[2];
+    if (n_work > work_cap) n_work = work_cap;
     const int W = P.W;
     unsigned long long ztests = 0;
-    for (uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x; ri < n_rows; ri += gridDim.x * blockDim.x) {
-        const RowRec &R = rows[ri];
+    for (uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x; wi < n_work; wi += gridDim.x * blockDim.x) {
+        const uint2 item = work[wi];
+        if (item.x == 0xffffffffu) continue;             // unused slot of a triangle's reservation
+        const RowRec &R = rows[item.x];
         const int y = R.y;
         if (out_row(P, y) < 0) continue;
         const unsigned long long trikey = (unsigned long long)(0xffffffffu - R.tri);
+        const size_t rowbase = (size_t)y * W;
 
         // z-test (pass 1) / capture of the winner's interpolants (pass 2) for one fragment
-        auto frag = [&](int x, const float (&v)[N]) {
-            const float z = v[ZI];
+        auto frag = [&](int x, const float (&v)[NW]) {
+            const float z = ATTR ? v[ATTR ? ZI : 0] : v[0];
             if (!(z > 0.f)) return;                       // cannot beat the cleared Z-buffer (Screen.h:209)
             const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | trikey;
-            const size_t pix = (size_t)y * W + x;
-            if (!ATTR) { atomicMax(&keys[pix], key); return; }
-            if (keys[pix] != key) return;
-            float4 g0, g1;
-            g0 = make_float4(v[0], v[1], v[2], v[3]);
-            if constexpr (N == 5) g1 = make_float4(v[4], 0.f, 0.f, 0.f);
-            else g1 = make_float4(v[4], v[5], v[6], v[7]);
-            gbuf[pix * 2] = g0; gbuf[pix * 2 + 1] = g1;
+            if (!ATTR) { atomicMax(&keys[rowbase + x], key); return; }
+            if (keys[rowbase + x] != key) return;
+            if constexpr (ATTR) {
+                float4 g0 = make_float4(v[0], v[1], v[2], v[3]), g1;
+                if constexpr (N == 5) g1 = make_float4(v[4], 0.f, 0.f, 0.f);
+                else g1 = make_float4(v[4], v[5], v[6], v[7]);
+                gbuf[(rowbase + x) * 2] = g0; gbuf[(rowbase + x) * 2 + 1] = g1;
+            }
+        };
+        auto pick = [&](const float *src, float (&dst)[NW]) {
+            if constexpr (ATTR) {
+#pragma unroll
+                for (int i = 0; i < N; i++) dst[i] = src[i];
+            } else dst[0] = src[ZI];
         };
 
-        float start[N];
-#pragma unroll
-        for (int i = 0; i < N; i++) start[i] = R.l[i];
+        float start[NW];
+        pick(R.l, start);
         if (R.cnt == 1) {
-            const int x = myfloor_i(start[0]);
+            const int x = myfloor_i(R.l[0]);
             if (x >= 0 && x < W) { ztests++; frag(x, start); }
             continue;
         }
@@ -370,23 +555,35 @@ __global__ void __launch_bounds__(256) k_rs_spans(const DevScene S, const FrameP
             if (x1 >= 0 && x1 < W) { ztests++; frag(x1, start); }
             continue;
         }
-        float dLR[N];
+        float right[NW], dLR[NW];
+        pick(R.r, right);
         const float fsteps = (float)(int)steps;
 #pragma unroll
-        for (int i = 0; i < N; i++) dLR[i] = (R.r[i] - start[i]) / fsteps;
+        for (int i = 0; i < NW; i++) dLR[i] = (right[i] - start[i]) / fsteps;
         if (x1 < 0) {
             const float k = (float)-x1;
 #pragma unroll
-            for (int i = 0; i < N; i++) start[i] += dLR[i] * k;
+            for (int i = 0; i < NW; i++) start[i] += dLR[i] * k;
             steps -= (-(long long)x1);
             x1 = 0;
         }
         if (x2 >= W) steps -= ((long long)x2 - W + 1);
-        ztests++; frag(x1, start);
-        while (steps-- > 0) {
+        // this lane's chunk: replay the serial `start += dLR` chain up to its first pixel in registers
+        // (same additions in the same order as the reference's loop, Screen.h:280-287), then walk it
+        long long skip = (long long)item.y * MI_SPAN_CHUNK;
+        if (skip > steps) continue;
+        long long todo = steps - skip;                   // additions left after the chunk's first pixel
+        if (todo > MI_SPAN_CHUNK - 1) todo = MI_SPAN_CHUNK - 1;
+        x1 += (int)skip;
+        for (long long k = 0; k < skip; k++) {
+#pragma unroll
+            for (int i = 0; i < NW; i++) start[i] += dLR[i];
+        }
+        if (x1 < W) { ztests++; frag(x1, start); }
+        while (todo-- > 0) {
             x1++;
 #pragma unroll
-            for (int i = 0; i < N; i++) start[i] += dLR[i];
+            for (int i = 0; i < NW; i++) start[i] += dLR[i];
             if (x1 >= W) break;                          // unreachable for left<=right; guards the frame
             ztests++; frag(x1, start);
         }
@@ -394,6 +591,8 @@ __global__ void __launch_bounds__(256) k_rs_spans(const DevScene S, const FrameP
     if (P.counters && !ATTR) {
         if (ztests) atomicAdd(&P.counters[CS_ZTESTS], ztests);
         if (blockIdx.x == 0 && threadIdx.x == 0) {
+            uint32_t n_rows = ctl[0];
+            if (n_rows > P.rows_cap) n_rows = P.rows_cap;
             atomicAdd(&P.counters[CS_SPANS], (unsigned long long)n_rows);
             if (ctl[1]) atomicAdd(&P.counters[CS_OVERFLOW], (unsigned long long)ctl[1]);
         }
@@ -520,6 +719,9 @@ extern "C" void mi355i_raster_scratch_destroy(RasterScratch *s)
     if (s->keys) (void)hipFree(s->keys);
     if (s->gbuf) (void)hipFree(s->gbuf);
     if (s->rows) (void)hipFree(s->rows);
+    if (s->work) (void)hipFree(s->work);
+    if (s->tris) (void)hipFree(s->tris);
+    if (s->rcwork) (void)hipFree(s->rcwork);
     if (s->ctl) (void)hipFree(s->ctl);
     if (s->smkeys) (void)hipFree(s->smkeys);
     delete s;
@@ -554,12 +756,34 @@ static hipError_t scratch_ensure(RasterScratch *s, size_t key_words, size_t sm_w
     if (want > 0xfffffff0ull) want = 0xfffffff0ull;
     if ((uint32_t)want > s->rows_cap) {
         if (s->rows) (void)hipFree(s->rows);
+    if (s->work) (void)hipFree(s->work);
         s->rows = nullptr; s->rows_cap = 0;
         if ((e = hipMalloc((void **)&s->rows, (size_t)want * sizeof(RowRec))) != hipSuccess) return e;
         s->rows_cap = (uint32_t)want;
+        if (s->work) (void)hipFree(s->work);
+        s->work = nullptr; s->work_cap = 0;
+        const unsigned long long wwant = want * 4ull < 0xfffffff0ull ? want * 4ull : 0xfffffff0ull;
+        if ((e = hipMalloc((void **)&s->work, (size_t)wwant * sizeof(uint2))) != hipSuccess) return e;
+        s->work_cap = (uint32_t)wwant;
     }
     if (!s->ctl) {
         if ((e = hipMalloc((void **)&s->ctl, 64)) != hipSuccess) return e;
+    }
+    if (n_tris + 16 > s->tris_cap) {
+        if (s->tris) (void)hipFree(s->tris);
+        if (s->rcwork) (void)hipFree(s->rcwork);
+        s->tris = nullptr; s->rcwork = nullptr; s->tris_cap = s->rcwork_cap = 0;
+        if ((e = hipMalloc((void **)&s->tris, (size_t)(n_tris + 16) * sizeof(TriRec))) != hipSuccess) return e;
+        s->tris_cap = n_tris + 16;
+    }
+    {   // row-chunk items: one per MI_ROW_CHUNK rows
+        const unsigned long long rcw = (unsigned long long)s->rows_cap / MI_ROW_CHUNK + (unsigned long long)n_tris + 16ull;
+        if (rcw > s->rcwork_cap) {
+            if (s->rcwork) (void)hipFree(s->rcwork);
+            s->rcwork = nullptr; s->rcwork_cap = 0;
+            if ((e = hipMalloc((void **)&s->rcwork, (size_t)rcw * sizeof(uint2))) != hipSuccess) return e;
+            s->rcwork_cap = (uint32_t)rcw;
+        }
     }
     return hipSuccess;
 }
@@ -571,9 +795,10 @@ static hipError_t raster_frame(const DevScene *S, const FrameParams *Pin, Raster
     Pv.rows_cap = s->rows_cap;
     const FrameParams *P = &Pv;
     const int nbT = (int)((S->n_tris + 127) / 128);
-    hipLaunchKernelGGL((k_rs_setup<MODE>), dim3(nbT > 0 ? nbT : 1), dim3(128), 0, st, *S, *P, s->rows, s->rows_cap, s->ctl);
-    hipLaunchKernelGGL((k_rs_spans<MODE, false>), dim3(2048), dim3(256), 0, st, *S, *P, s->rows, s->ctl, s->keys, s->gbuf);
-    hipLaunchKernelGGL((k_rs_spans<MODE, true>), dim3(2048), dim3(256), 0, st, *S, *P, s->rows, s->ctl, s->keys, s->gbuf);
+    hipLaunchKernelGGL((k_rs_tri<MODE>), dim3(nbT > 0 ? nbT : 1), dim3(128), 0, st, *S, *P, s->rows_cap, s->ctl, s->work_cap, s->tris, s->tris_cap, s->rcwork, s->rcwork_cap);
+    hipLaunchKernelGGL((k_rs_rows<MODE>), dim3(1024), dim3(128), 0, st, *P, s->tris, s->rcwork, s->rcwork_cap, s->ctl, s->rows, s->work);
+    hipLaunchKernelGGL((k_rs_spans<MODE, false>), dim3(2048), dim3(256), 0, st, *S, *P, s->rows, s->ctl, s->work, s->work_cap, s->keys, s->gbuf);
+    hipLaunchKernelGGL((k_rs_spans<MODE, true>), dim3(2048), dim3(256), 0, st, *S, *P, s->rows, s->ctl, s->work, s->work_cap, s->keys, s->gbuf);
     hipLaunchKernelGGL((k_rs_shade<MODE>), dim3(2048), dim3(256), 0, st, *S, *P, s->keys, s->gbuf);
     return hipGetLastError();
 }

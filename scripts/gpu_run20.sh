@@ -1,0 +1,4 @@
+mkdir -p gpurun_out
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+(timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_raster -- python $R/bench.py --mesh chessboard.tri --mode 8 --steps 60 --warmup 5 --no-cpu-baseline --no-extra 2>&1 | tail -2) > $R/gpurun_out/prof_raster.log
