@@ -204,7 +204,7 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.xmin = t[0] > 0 ? (t[0] > 64 ? 64 : t[0]) : 24;
     P.rmin = t[1] > 0 ? (t[1] > 64 ? 64 : t[1]) : 32;
     P.chunk = t[2] > 0 ? t[2] : 64;
-    P.lmin = t[3] > 0 ? (t[3] > 64 ? 64 : t[3]) : 1;
+    P.lmin = 0;     // tune[3] is reserved
     P.blocks_per_cu = t[4] > 0 ? t[4] : 0;
     P.exact_box = (flags & 1) ? 1 : 0;
     if (!c->boxes_tame) P.exact_box = 1;     // box coordinates outside the filtered test's validated range
@@ -235,20 +235,39 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
         seen[triIdx[i]] = 1;
     }
     auto is_leaf = [&](uint32_t i) { return (rn[i].a & 0x80000000u) != 0; };
-    // record offsets (float4 units) in pre-order: inner node 2, leaf 3 per triangle (an empty leaf keeps one dummy block)
+    // Record offsets (float4 units): inner nodes first, two float4 each in array order (the reference's
+    // flattening is pre-order); then triangle block j at tri_base + 2*j for every position j of the
+    // triangle list; then one dummy block per empty leaf (never produced by the reference builder).
     std::vector<uint32_t> off(nN, 0);
-    size_t n4 = 0;
+    std::vector<uint8_t> owned(nI, 0);
+    size_t n_inner = 0, n_dummy = 0;
+    for (uint32_t i = 0; i < nN; i++)
+        if (!is_leaf(i)) off[i] = (uint32_t)(2 * n_inner++);
+    const size_t tri_base = 2 * n_inner;
     for (uint32_t i = 0; i < nN; i++) {
-        off[i] = (uint32_t)n4;
-        if (is_leaf(i)) {
-            const uint32_t cnt = rn[i].a & 0x7fffffffu, first = rn[i].b;
-            if ((uint64_t)first + cnt > nI) return fail(-30, "BVH leaf %u exceeds the triangle list", i);
-            n4 += 3 * (size_t)(cnt ? cnt : 1);
-        } else n4 += 2;
+        if (!is_leaf(i)) continue;
+        const uint32_t cnt = rn[i].a & 0x7fffffffu, first = rn[i].b;
+        if ((uint64_t)first + cnt > nI) return fail(-30, "BVH leaf %u exceeds the triangle list", i);
+        for (uint32_t k = 0; k < cnt; k++) {
+            if (owned[first + k]) return fail(-30, "BVH leaves overlap at triangle list entry %u", first + k);
+            owned[first + k] = 1;
+        }
+        off[i] = cnt ? (uint32_t)(tri_base + 2 * (size_t)first) : (uint32_t)(tri_base + 2 * ((size_t)nI + n_dummy++));
     }
-    if (n4 + 8 >= 0x7fffffffull) return fail(-30, "BVH too large");
-    auto link = [&](uint32_t i) { return i == MI_END_LINK ? MI_END_LINK : (is_leaf(i) ? (off[i] | MI_LEAF_BIT) : off[i]); };
-    std::vector<float4> walk(n4 + 4, make_float4(0.f, 0.f, 0.f, 0.f));       // +4: a record fetch always reads 3 float4
+    const size_t n4 = tri_base + 2 * ((size_t)nI + n_dummy);
+    if (n4 + 8 >= (size_t)MI_INDEX_MASK) return fail(-30, "BVH too large");
+    auto tri_link = [&](size_t j, bool first_of_leaf) {     // link to triangle block j (list position)
+        uint32_t l = (uint32_t)(tri_base + 2 * j) | MI_LEAF_BIT;
+        if (first_of_leaf) l |= MI_FIRST_BIT;
+        if (j < nI && c->ttwo[triIdx[j]]) l |= MI_TWOSIDED_BIT;
+        return l;
+    };
+    auto link = [&](uint32_t i) {
+        if (i == MI_END_LINK) return (uint32_t)MI_END_LINK;
+        if (!is_leaf(i)) return off[i];
+        return tri_link(((size_t)off[i] - tri_base) / 2, true);
+    };
+    std::vector<float4> walk(n4 + 2, make_float4(0.f, 0.f, 0.f, 0.f));
     std::vector<uint8_t> visited(nN, 0);
     struct Item { uint32_t node, escape; int depth; };
     std::vector<Item> st;
@@ -269,16 +288,14 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
             st.push_back({n.a, n.b, it.depth + 1});
         } else {
             const uint32_t cnt = n.a & 0x7fffffffu, first = n.b;
-            if (cnt == 0) {      // never produced by the reference builder; a block whose plane rejects every ray
-                rec[0] = make_float4(u2f(link(it.escape)), u2f(0xffffffffu), u2f(1u), 0.f);
-            }
+            // an empty leaf is a block with a zero normal: its plane rejects every ray (k == 0)
+            if (cnt == 0) rec[0] = make_float4(0.f, 0.f, 0.f, u2f(link(it.escape)));
             for (uint32_t k = 0; k < cnt; k++) {
                 const uint32_t t = (uint32_t)triIdx[first + k];
                 const float *nrm = &c->tnormal[3 * t], *cen = &c->tcenter[3 * t];
-                const uint32_t next = k + 1 < cnt ? ((off[it.node] + 3 * (k + 1)) | MI_LEAF_BIT) : link(it.escape);
-                rec[3 * k] = make_float4(u2f(next), u2f(first + k), u2f(k == 0 ? 1u : 0u), 0.f);
-                rec[3 * k + 1] = make_float4(nrm[0], nrm[1], nrm[2], c->td[4 * t]);
-                rec[3 * k + 2] = make_float4(cen[0], cen[1], cen[2], u2f(c->ttwo[t] ? 1u : 0u));
+                const uint32_t next = k + 1 < cnt ? tri_link((size_t)first + k + 1, false) : link(it.escape);
+                rec[2 * k] = make_float4(nrm[0], nrm[1], nrm[2], u2f(next));
+                rec[2 * k + 1] = make_float4(cen[0], cen[1], cen[2], c->td[4 * t]);
             }
         }
     }
@@ -293,7 +310,8 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
     c->boxes_tame = tame;
 
     const uint32_t T = c->nT;
-    std::vector<float4> edge((size_t)T * 3), shade((size_t)T * 5);
+    // (+ zeroed edge records behind the dummy blocks of empty leaves: a NaN ray can pass their plane test)
+    std::vector<float4> edge(((size_t)T + n_dummy) * 3, make_float4(0.f, 0.f, 0.f, 0.f)), shade((size_t)T * 5);
     for (uint32_t j = 0; j < T; j++) {
         const uint32_t t = (uint32_t)triIdx[j];
         const float *d = &c->td[4 * t], *e = &c->te[9 * t];
@@ -321,6 +339,9 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
     c->dev.tri_edge = (const float4 *)c->tri_edge.p;
     c->dev.tri_shade = (const float4 *)c->tri_shade.p;
     c->dev.root_link = link(0);
+    c->dev.root_a = walk[c->dev.root_link & MI_INDEX_MASK];
+    c->dev.root_b = walk[(c->dev.root_link & MI_INDEX_MASK) + 1];
+    c->dev.tri_base = (uint32_t)tri_base;
     c->dev.n_nodes = nN;
     c->has_bvh = true;
     return 0;

@@ -7,9 +7,9 @@
 // aligned 16-byte vectors (one dwordx4 load per lane per vector), and the
 // triangles of a leaf are contiguous:
 //
-//   walk      [...]        float4   traversal records, one buffer so that address = base + 16*link:
-//                                  inner node 32 B (box + hit/miss links), triangle block 48 B
-//                                  (next link, triangle, flags | normal,d | centre,twoSided)
+//   walk      [...]        float4   traversal records, 32 B each, one buffer so that address = base + 16*link:
+//                                  inner nodes first (box + hit/miss links), then one triangle block
+//                                  per triangle in leaf order (normal, next link | centre, d)
 //   tri_edge  [T][3]       float4   leaf test, second half (e1..e3,d1..d3)  48 B
 //   tri_shade [T][5]       float4   closest-hit shading                     80 B
 //   (triangle blocks and both tri_* streams are in LEAF ORDER = position in triIndexList)
@@ -20,25 +20,33 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define MI_END_LINK 0x7fffffffu   // traversal finished
-#define MI_LEAF_BIT 0x80000000u   // link target is a triangle block
+#define MI_END_LINK 0x7fffffffu     // traversal finished (compared for equality; never masked)
+#define MI_LEAF_BIT 0x80000000u     // link target is a triangle block
+#define MI_TWOSIDED_BIT 0x40000000u // (with MI_LEAF_BIT) the target triangle is two-sided
+#define MI_FIRST_BIT 0x20000000u    // (with MI_LEAF_BIT) the target is the first block of its leaf
+#define MI_INDEX_MASK 0x1fffffffu   // float4 index of the target record
 
 #define MI_MAX_LIGHTS 4
 #define MI_MAX_DEPTH 4
 
-// Walk records (float4 units; a link is the float4 index of a record, | MI_LEAF_BIT for a triangle
-// block, or MI_END_LINK):
+// Walk records, two float4 each (a link is the float4 index of a record plus the flag bits above, or
+// MI_END_LINK):
 //   inner node    : (bmin.xyz, link_if_hit) (bmax.xyz, link_if_miss)
-//   triangle block: (next link, triangle j, flags, -) (normal.xyz, d) (centre.xyz, twoSided)
+//   triangle block: (normal.xyz, next link)  (centre.xyz, d)          at index tri_base + 2*j
 // link_if_hit is the left child, link_if_miss / next is the next node of the reference's depth-first,
 // left-first order (Raytracer.cc:217-230) that is not below this one -- so following links visits
 // exactly the nodes the reference pops, in the same order, without a stack.  A leaf of n triangles
-// is a chain of n triangle blocks in list order; flags bit 0 marks the first block of a leaf.
+// is a chain of n triangle blocks in list order.  What a block cannot hold in 32 bytes travels with
+// the link that points at it: the triangle's leaf-order index j is its position, its twoSided flag
+// and "first block of a leaf" (the reference's pop of the leaf node, for the counters) are link bits.
+// The root's record is the same for every ray, so it rides in the kernel arguments.
 struct DevScene {
     const float4 *walk;
     const float4 *tri_edge;
     const float4 *tri_shade;
+    float4 root_a, root_b;    // walk record behind root_link
     uint32_t root_link;
+    uint32_t tri_base;        // float4 index of triangle block 0
     uint32_t n_nodes;
     uint32_t n_tris;
     uint32_t n_verts;
@@ -74,7 +82,7 @@ struct FrameParams {
     int32_t rmin;              // refill once this many lanes are idle (or nobody is alive)
     int32_t chunk;             // pixel indices a wave takes from the dispenser at a time
     int32_t exact_box;         // always use the exact six-division box test
-    int32_t lmin;              // leaf postponement: test leaves once this many lanes wait on one (1 = if-if)
+    int32_t lmin;              // reserved (was: leaf postponement)
     int32_t scatter;           // dispenser hands out pixel slot s of every tile before slot s+1 (load balance)
     unsigned long long *wave_prof; // counting builds: 16 words of phase profile per wave (debug), or NULL
     const uint32_t *tile_order; // dispenser index -> 8x8 tile id (heavy tiles first), or NULL = row-major

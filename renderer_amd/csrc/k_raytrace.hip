@@ -16,12 +16,12 @@
 //    does not depend on the ray, so every record carries the link to follow on a hit and on a miss;
 //    following them visits exactly the reference's node sequence.
 //  * A frame lasts as long as its longest chain of dependent steps (~1000 node visits for the
-//    worst pixel), so the loop is built to never wait on memory inside a step: all records live in
-//    ONE buffer (address = base + 16*link), the records behind BOTH links of a node are requested
-//    as soon as the node's own record is in registers, a leaf is a chain of single-triangle blocks,
-//    and a triangle's edge test is deferred by one step (its edge record is requested when the plane
-//    test passes and consumed at the lane's next step -- legal because a candidate only updates the
-//    running best, never the visiting order).
+//    worst pixel), so a step is built around ONE wait on memory: every record is 32 bytes in one buffer
+//    (address = base + 16*link; the root's record rides in the kernel arguments), the records behind
+//    BOTH links of a node are requested first, then the box / plane arithmetic runs, and a triangle
+//    that passes the plane test has its edge record requested at the end of the step and judged at
+//    the wait point of the lane's NEXT step -- legal because a candidate only updates the running
+//    best, never the visiting order.
 //
 // Arithmetic follows the cited reference lines operation by operation (dev_math.h).
 #include "dev_math.h"
@@ -50,7 +50,7 @@ struct Lane {
     f3 hit;
     float k1, k2, k3;      // kAB, kBC, kCA
     bool shadow_hit;
-    // triangle that passed the plane test at the previous step; its edge test is still to run
+    // triangle that passed the plane test at the previous step; its edge record is in flight
     bool pend;
     int pj;
     f3 ph;
@@ -241,18 +241,23 @@ MI_DEV void shade_begin(const FrameParams &P, const DevScene &S, Lane &L)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Walk records (DevScene::walk, float4 units; a link = index | MI_LEAF_BIT, or MI_END_LINK):
-//     inner node    : a = (bmin, hit link)            b = (bmax, miss link)
-//     triangle block: a = (next link, j, flags, -)    b = (normal, d)    c = (centre, twoSided)
-// A leaf of n triangles is a chain of n triangle blocks in list order; flags bit 0 marks the first
-// block of a leaf (the reference's "pop" of the leaf node, for the counters).
-struct Rec { float4 a, b, c; };
+// Walk records (DevScene::walk, two float4 each; dev_scene.h):
+//     inner node    : a = (bmin, hit link)      b = (bmax, miss link)
+//     triangle block: a = (normal, next link)   b = (centre, d)        at index tri_base + 2*j
+struct Rec { float4 a, b; };
 
 MI_DEV void rec_fetch(const DevScene &S, uint32_t link, Rec &r)
 {
-    const uint32_t idx = link == MI_END_LINK ? 0u : (link & ~MI_LEAF_BIT);
+    const uint32_t idx = link == MI_END_LINK ? 0u : (link & MI_INDEX_MASK);
     const float4 *p = S.walk + (size_t)idx;
-    r.a = p[0]; r.b = p[1]; r.c = p[2];
+    r.a = p[0]; r.b = p[1];
+}
+
+// every walk starts at the root, whose record is a kernel argument
+MI_DEV void begin_walk(const DevScene &S, Lane &L, Rec &R)
+{
+    L.cur = S.root_link;
+    R.a = S.root_a; R.b = S.root_b;
 }
 
 // Box test of an inner node's record (Raytracer.cc:222-230)
@@ -266,18 +271,19 @@ MI_DEV bool inner_test(const Lane &L, const Rec &R)
     return h;
 }
 
-// plane half of the triangle test (Raytracer.cc:245-267): false = rejected, else `hit` is the plane point
-MI_DEV bool tri_plane_test(const Lane &L, float nudge, uint32_t j, const float4 p0, const float4 p1, f3 &hit)
+// plane half of the triangle test (Raytracer.cc:245-267) on block (a, b) reached through `link`:
+// false = rejected, else `hit` is the plane point
+MI_DEV bool tri_plane_test(const Lane &L, float nudge, uint32_t link, int j, const float4 a, const float4 b, f3 &hit)
 {
-    if ((int)j == L.avoid) return false;
-    const f3 n = mk3(p0.x, p0.y, p0.z);
-    if (__float_as_uint(p1.w) == 0u) {                       // !_twoSided
-        const f3 fto = sub3(L.o, mk3(p1.x, p1.y, p1.z));
+    if (j == L.avoid) return false;
+    const f3 n = mk3(a.x, a.y, a.z);
+    if ((link & MI_TWOSIDED_BIT) == 0u) {                    // !_twoSided
+        const f3 fto = sub3(L.o, mk3(b.x, b.y, b.z));
         if (dot3(fto, n) < 0.f) return false;
     }
     const float k = dot3(n, L.d);
     if (k == 0.0f) return false;
-    const float s = (p0.w - dot3(n, L.o)) / k;
+    const float s = (b.w - dot3(n, L.o)) / k;
     if (s <= 0.0f) return false;
     if (s <= nudge) return false;
     hit = add3(mul3(L.d, s), L.o);
@@ -312,9 +318,8 @@ k_raytrace(const DevScene S, const FrameParams P)
     bool alive = false;         // lane owns a pixel
     bool want_pixel = true;     // lane needs a (new) pixel
     bool exhausted = false;     // dispenser ran dry (wave-uniform)
-    bool need_rec = true;       // the record of L.cur has not been fetched yet
     Rec R;                      // record of the node this lane visits next
-    R.a = R.b = R.c = make_float4(0.f, 0.f, 0.f, 0.f);
+    R.a = R.b = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t pool_next = 0, pool_end = 0;   // wave-local pixel pool (wave-uniform)
     L.cur = MI_END_LINK; L.mode = MODE_CLOSEST; L.btri = -1; L.depth = 0; L.samples_left = 0;
     L.fr = L.fg = L.fb = 0.f; L.px = L.py = L.orow = 0; L.avoid = -1; L.best = 0.f;
@@ -388,7 +393,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                                     L.fr = L.fg = L.fb = 0.f;
                                     L.samples_left = P.aa ? 3 : 0;
                                     primary_ray(P, L, L.samples_left);
-                                    L.cur = S.root_link; need_rec = true;
+                                    begin_walk(S, L, R);
                                     n_normal++;
                                     alive = true;
                                     want_pixel = false;
@@ -445,7 +450,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                             L.best = distsq3(L.o, L.lp);            // Raytracer.cc:209
                             L.mode = MODE_SHADOW;
                             L.shadow_hit = false;
-                            L.cur = S.root_link; need_rec = true;
+                            begin_walk(S, L, R);
                             L.avoid = L.btri;                       // avoidSelf = the triangle just hit (Raytracer.cc:335)
                             n_shadow++;
                             launched = true;
@@ -462,7 +467,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                             L.o = L.hit; L.d = L.refl; L.avoid = L.btri;
                             set_ray_aux(L);
                             L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.btri = -1;
-                            L.cur = S.root_link; need_rec = true;
+                            begin_walk(S, L, R);
                             n_normal++;
                         } else finish = true;
                     }
@@ -476,7 +481,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     if (L.samples_left > 0) {
                         L.samples_left--;
                         primary_ray(P, L, L.samples_left);
-                        L.cur = S.root_link; need_rec = true;
+                        begin_walk(S, L, R);
                         n_normal++;
                     } else {
                         float r = L.fr, g = L.fg, b = L.fb;
@@ -504,62 +509,71 @@ k_raytrace(const DevScene S, const FrameParams P)
         MI_PHASE(pc_refill);
         for (;;) {
             if (STATS) it_loops++;
-            // a lane that has just been given a ray does not hold its first record yet
-            if (alive && need_rec && L.cur != MI_END_LINK) { rec_fetch(S, L.cur, R); need_rec = false; }
-            // 1. judge the triangle that passed the plane test at the previous step
-            if (__ballot(L.pend)) {
-                if (L.pend) {
-                    L.pend = false;
-                    if (tri_edge_test(L)) L.cur = MI_END_LINK;      // a blocked shadow ray stops (Raytracer.cc:284)
-                }
-            }
             const bool walking = alive && L.cur != MI_END_LINK;
             const bool inner = walking && (L.cur & MI_LEAF_BIT) == 0;
-            const bool tri_any = walking && (L.cur & MI_LEAF_BIT) != 0;
-            const unsigned long long mI = __ballot(inner), mL = __ballot(tri_any);
-            // triangle lanes may be held back until P.lmin of them have gathered (lmin = 1: plain if-if)
-            const bool tri = tri_any && (!mI || __popcll(mL) >= P.lmin);
-            // 2. request the successors' records before any arithmetic
-            //    inner lane: behind the hit link and behind the miss link; triangle lane: behind the next link
-            const uint32_t link1 = inner ? __float_as_uint(R.a.w) : __float_as_uint(R.a.x);
+            const bool tri = walking && (L.cur & MI_LEAF_BIT) != 0;
+            const unsigned long long mI = __ballot(inner), mL = __ballot(tri);
+            // 1. request the successors' records before any arithmetic: behind the hit / next link for every
+            //    walking lane, behind the miss link for lanes on an inner node
+            const uint32_t link1 = __float_as_uint(R.a.w);
             const uint32_t link2 = __float_as_uint(R.b.w);
             Rec N1, N2;
-            if (inner || tri) rec_fetch(S, link1, N1);
+            N2.a = N2.b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (walking) rec_fetch(S, link1, N1);
             if (inner) rec_fetch(S, link2, N2);
-            // 3. inner nodes
+            // 2. inner nodes: box test (Raytracer.cc:222-230)
+            bool h = true;                  // triangle lanes always follow link1
             if (mI) {
                 if (STATS) { it_a++; ln_a += __popcll(mI); }
                 if (inner) {
-                    const bool h = inner_test<EXACT_BOX>(L, R);
+                    h = inner_test<EXACT_BOX>(L, R);
                     if (STATS) { n_pops++; if (h) n_ihits++; }
-                    L.cur = h ? link1 : link2;
-                    R.a = h ? N1.a : N2.a; R.b = h ? N1.b : N2.b; R.c = h ? N1.c : N2.c;
                 }
                 MI_PHASE(pc_a);
             }
-            // 4. triangle blocks: plane test now, edge test at this lane's next step
-            if (mL && (!mI || __popcll(mL) >= P.lmin)) {
+            // 3. triangle blocks: plane test
+            bool cand = false;
+            f3 ch = mk3(0.f, 0.f, 0.f);
+            const int j = (int)(((L.cur & MI_INDEX_MASK) - S.tri_base) >> 1);
+            if (mL) {
                 if (STATS) { it_b++; ln_b += __popcll(mL); }
                 if (tri) {
-                    const uint32_t j = __float_as_uint(R.a.y);
-                    if (STATS) { n_tris++; if (__float_as_uint(R.a.z) & 1u) n_pops++; }
-                    f3 h;
-                    if (tri_plane_test(L, P.nudge, j, R.b, R.c, h)) {
-                        if (STATS) n_plane++;
-                        L.pe1 = S.tri_edge[(size_t)j * 3]; L.pe2 = S.tri_edge[(size_t)j * 3 + 1]; L.pe3 = S.tri_edge[(size_t)j * 3 + 2];
-                        L.pj = (int)j; L.ph = h; L.pend = true;
-                    }
-                    L.cur = link1;
-                    R = N1;
-                    if (STATS && L.pend) {
-                        // counting builds judge at once so that a blocked shadow ray stops exactly where the
-                        // reference does and the counters stay comparable
-                        L.pend = false;
-                        if (tri_edge_test(L)) L.cur = MI_END_LINK;
-                    }
+                    if (STATS) { n_tris++; if (L.cur & MI_FIRST_BIT) n_pops++; }
+                    cand = tri_plane_test(L, P.nudge, L.cur, j, R.a, R.b, ch);
+                    if (STATS && cand) n_plane++;
                 }
-                MI_PHASE(pc_b);
             }
+            // 4. the step's wait point: judge the candidate of the previous step (its edge record was
+            //    requested then), take the successor's record
+            bool stop = false;
+            if (__ballot(L.pend)) {
+                if (L.pend) {
+                    L.pend = false;
+                    stop = tri_edge_test(L);                        // a blocked shadow ray stops (Raytracer.cc:284)
+                }
+            }
+            if (walking) {
+                L.cur = h ? link1 : link2;
+                R.a = h ? N1.a : N2.a; R.b = h ? N1.b : N2.b;
+            }
+            if (stop) L.cur = MI_END_LINK;
+            // Pin the successor's record here: without this the compiler sinks the selects below the
+            // edge-record request and then waits for that request too, inside the same step.
+            asm volatile("" : "+v"(R.a.x), "+v"(R.a.y), "+v"(R.a.z), "+v"(R.a.w), "+v"(R.b.x), "+v"(R.b.y), "+v"(R.b.z),
+                              "+v"(R.b.w), "+v"(L.cur));
+            // 5. request the edge record of this step's candidate
+            if (cand) {
+                const float4 *e = S.tri_edge + (size_t)j * 3;
+                L.pe1 = e[0]; L.pe2 = e[1]; L.pe3 = e[2];
+                L.pj = j; L.ph = ch; L.pend = true;
+                if (STATS) {
+                    // counting builds judge at once so that a blocked shadow ray stops exactly where the
+                    // reference does and the counters stay comparable
+                    L.pend = false;
+                    if (tri_edge_test(L)) L.cur = MI_END_LINK;
+                }
+            }
+            if (mL) MI_PHASE(pc_b);
             const unsigned long long mDone = __ballot(alive && L.cur == MI_END_LINK && !L.pend);
             const unsigned long long mBusy = __ballot(alive && !(L.cur == MI_END_LINK && !L.pend));
             if (!mBusy || __popcll(mDone) >= xmin_now) break;
