@@ -83,9 +83,13 @@ typedef struct {
      * [0] xmin   lanes waiting for a state transition before the wave services them
      * [1] rmin   idle lanes before the wave refills from the pixel dispenser
      * [2] chunk  pixel indices a wave takes from the dispenser at once
-     * [3] lmin   lanes gathered on triangle blocks before the plane tests run (1 = plain if-if)
+     * [3] reserved
      * [4] blocks per CU (0 = occupancy query)
-     * [5] flags  1 exact box test only | 2 row-major tile order | 16 scattered pixel dispensing
+     * [5] flags  1 exact box test only | 2 row-major tile order | 4 walk the tree in the reference's
+     *            fixed left-first order (default: near child first with distance culling when the tree
+     *            passed the checks of mi355_scene_set_bvh; counting frames always use the reference's
+     *            order so that the counters below mean what they mean in the reference)
+     *            | 16 scattered pixel dispensing
      * [6], [7] reserved */
     int32_t tune[8];
 } mi355_opts;

@@ -161,10 +161,11 @@ def default_opts(width: int, height: int, **kw) -> Opts:
     return o
 
 
-def tune(xmin=0, rmin=0, chunk=0, lmin=0, bpc=0, exact=0, rowmajor=0, scatter=0):
-    """mi355_opts::tune as a list (see include/mi355_render.h); every knob leaves the pixels unchanged."""
-    flags = (1 if exact else 0) | (2 if rowmajor else 0) | (16 if scatter else 0)
-    return [xmin, rmin, chunk, lmin, bpc, flags, 0, 0]
+def tune(xmin=0, rmin=0, chunk=0, lmin=0, bpc=0, exact=0, rowmajor=0, scatter=0, reforder=0):
+    """mi355_opts::tune as a list (see include/mi355_render.h); every knob leaves the pixels unchanged.
+    (lmin is accepted for old scripts and ignored.)"""
+    flags = (1 if exact else 0) | (2 if rowmajor else 0) | (4 if reforder else 0) | (16 if scatter else 0)
+    return [xmin, rmin, chunk, 0, bpc, flags, 0, 0]
 
 
 def device_count() -> int:
@@ -274,6 +275,21 @@ class Scene:
         if not ctx:
             raise Mi355Error(host().mi355h_last_error().decode())
         return ctx
+
+    def walk_info(self):
+        """(ordered walk available, per-lane stack entries, BVH nodes, boxes in the filtered test's range)"""
+        out = (C.c_uint32 * 4)()
+        f = lib().mi355i_scene_info
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        _check(f(self.context(), out), "mi355i_scene_info")
+        return tuple(int(x) for x in out)
+
+    def set_bvh_arrays(self, nodes: np.ndarray, tri_idx: np.ndarray):
+        """mi355_scene_set_bvh with caller-supplied arrays (the reference's 32-byte nodes + triIndexList)."""
+        nodes = np.ascontiguousarray(nodes, np.uint32)
+        tri_idx = np.ascontiguousarray(tri_idx, np.int32)
+        _check(lib().mi355_scene_set_bvh(self.context(), nodes.ctypes.data, nodes.shape[0], tri_idx.ctypes.data,
+                                         tri_idx.shape[0]), "mi355_scene_set_bvh")
 
     def shadowmap_render(self, slot: int, l: Light, size: int = 1024, fetch: bool = False):
         out = np.empty((size, size), np.float32) if fetch else None

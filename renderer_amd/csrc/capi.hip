@@ -17,8 +17,8 @@
 #include <vector>
 
 // kernel launchers (defined next to their kernels)
-extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact);
-extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int n_blocks,
+extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int stack_depth);
+extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int ordered, int n_blocks,
                                              hipStream_t);
 extern "C" hipError_t mi355i_launch_points(const DevScene *, const FrameParams *, int as_triangles, hipStream_t);
 struct RasterScratch;
@@ -204,7 +204,7 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.xmin = t[0] > 0 ? (t[0] > 64 ? 64 : t[0]) : 24;
     P.rmin = t[1] > 0 ? (t[1] > 64 ? 64 : t[1]) : 32;
     P.chunk = t[2] > 0 ? t[2] : 64;
-    P.lmin = 0;     // tune[3] is reserved
+    P.ref_order = (flags & 4) ? 1 : 0;
     P.blocks_per_cu = t[4] > 0 ? t[4] : 0;
     P.exact_box = (flags & 1) ? 1 : 0;
     if (!c->boxes_tame) P.exact_box = 1;     // box coordinates outside the filtered test's validated range
@@ -267,7 +267,14 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
         if (!is_leaf(i)) return off[i];
         return tri_link(((size_t)off[i] - tri_base) / 2, true);
     };
-    std::vector<float4> walk(n4 + 2, make_float4(0.f, 0.f, 0.f, 0.f));
+    const size_t wide_base = n4;                      // wide records of the ordered walk: 4 float4 per inner node
+    const size_t n4_all = n4 + 4 * n_inner;
+    if (n4_all + 8 >= (size_t)MI_VROOT_LINK) return fail(-30, "BVH too large");
+    std::vector<float4> walk(n4_all + 4, make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<uint32_t> order; order.reserve(nN);   // the reference's visiting order
+    bool list_in_visit_order = true;
+    uint32_t list_end = 0;
+    int inner_levels = 0;
     std::vector<uint8_t> visited(nN, 0);
     struct Item { uint32_t node, escape; int depth; };
     std::vector<Item> st;
@@ -278,6 +285,7 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
         if (it.node >= nN || visited[it.node]) return fail(-30, "BVH is not a tree (node %u)", it.node);
         if (it.depth >= 64) return fail(-30, "BVH deeper than 64 levels");
         visited[it.node] = 1; nvis++;
+        order.push_back(it.node);
         const RefNode &n = rn[it.node];
         float4 *rec = &walk[off[it.node]];
         if (!is_leaf(it.node)) {
@@ -286,8 +294,18 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
             rec[1] = make_float4(n.top[0], n.top[1], n.top[2], u2f(link(it.escape)));
             st.push_back({n.b, it.escape, it.depth + 1});
             st.push_back({n.a, n.b, it.depth + 1});
+            if (it.depth + 1 > inner_levels) inner_levels = it.depth + 1;
+            // wide record: both children's boxes
+            auto wlink = [&](uint32_t x) { return is_leaf(x) ? link(x) : (uint32_t)(wide_base + 2 * (size_t)off[x]); };
+            float4 *w = &walk[wide_base + 2 * (size_t)off[it.node]];
+            const RefNode &ca = rn[n.a], &cb = rn[n.b];
+            w[0] = make_float4(ca.bottom[0], ca.bottom[1], ca.bottom[2], u2f(wlink(n.a)));
+            w[1] = make_float4(ca.top[0], ca.top[1], ca.top[2], u2f(wlink(n.b)));
+            w[2] = make_float4(cb.bottom[0], cb.bottom[1], cb.bottom[2], 0.f);
+            w[3] = make_float4(cb.top[0], cb.top[1], cb.top[2], 0.f);
         } else {
             const uint32_t cnt = n.a & 0x7fffffffu, first = n.b;
+            if (cnt) { if (first < list_end) list_in_visit_order = false; list_end = first + cnt; }
             // an empty leaf is a block with a zero normal: its plane rejects every ray (k == 0)
             if (cnt == 0) rec[0] = make_float4(0.f, 0.f, 0.f, u2f(link(it.escape)));
             for (uint32_t k = 0; k < cnt; k++) {
@@ -308,6 +326,48 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
                 if (!(x == 0.f || (x >= 1e-30f && x <= 1e17f))) { tame = false; break; }
             }
     c->boxes_tame = tame;
+    // The ordered walk (near child first, subtrees farther than the best hit skipped) returns the
+    // reference's pixels only if (1) every box contains all triangles below it -- then "the box starts
+    // beyond the best hit" implies "so does every hit in it" -- and (2) a triangle's position in the
+    // list is its rank in the reference's visiting order -- then "lowest j among equal distances" is the
+    // reference's "first found wins".  The reference's own builder guarantees both; a foreign tree that
+    // does not is walked in the reference's order instead.
+    bool bounded = true;
+    float mag = 0.f;
+    {
+        std::vector<float> bb((size_t)nN * 6);
+        for (size_t q = order.size(); q-- > 0 && bounded;) {       // reverse pre-order: children before parents
+            const uint32_t i = order[q];
+            float *b = &bb[(size_t)i * 6];
+            b[0] = b[1] = b[2] = INFINITY; b[3] = b[4] = b[5] = -INFINITY;
+            if (is_leaf(i)) {
+                const uint32_t cnt = rn[i].a & 0x7fffffffu, first = rn[i].b;
+                for (uint32_t k = 0; k < cnt; k++) {
+                    const int32_t *ix = &c->tidx[3 * (size_t)triIdx[first + k]];
+                    for (int v = 0; v < 3; v++)
+                        for (int a = 0; a < 3; a++) {
+                            const float x = c->vpos[3 * (size_t)ix[v] + a];
+                            if (!(x == x)) bounded = false;
+                            if (x < b[a]) b[a] = x;
+                            if (x > b[3 + a]) b[3 + a] = x;
+                        }
+                }
+            } else {
+                const float *l = &bb[(size_t)rn[i].a * 6], *r = &bb[(size_t)rn[i].b * 6];
+                for (int a = 0; a < 3; a++) { b[a] = l[a] < r[a] ? l[a] : r[a]; b[3 + a] = l[3 + a] > r[3 + a] ? l[3 + a] : r[3 + a]; }
+            }
+            for (int a = 0; a < 3; a++) {
+                if (b[a] <= b[3 + a] && !(rn[i].bottom[a] <= b[a] && rn[i].top[a] >= b[3 + a])) bounded = false;
+                const float m0 = fabsf(rn[i].bottom[a]), m1 = fabsf(rn[i].top[a]);
+                if (!(m0 <= 1e17f && m1 <= 1e17f)) bounded = false;
+                if (m0 > mag) mag = m0;
+                if (m1 > mag) mag = m1;
+            }
+        }
+    }
+    c->dev.ordered_ok = (tame && bounded && list_in_visit_order && inner_levels + 1 <= MI_MAX_STACK) ? 1u : 0u;
+    c->dev.stack_depth = (uint32_t)(inner_levels + 1);
+    c->dev.scene_mag = mag;
 
     const uint32_t T = c->nT;
     // (+ zeroed edge records behind the dummy blocks of empty leaves: a NaN ray can pass their plane test)
@@ -342,6 +402,11 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
     c->dev.root_a = walk[c->dev.root_link & MI_INDEX_MASK];
     c->dev.root_b = walk[(c->dev.root_link & MI_INDEX_MASK) + 1];
     c->dev.tri_base = (uint32_t)tri_base;
+    {
+        const uint32_t wroot = is_leaf(0) ? link(0) : (uint32_t)(wide_base + 2 * (size_t)off[0]);
+        c->dev.vroot_a = make_float4(rn[0].bottom[0], rn[0].bottom[1], rn[0].bottom[2], u2f(wroot));
+        c->dev.vroot_b = make_float4(rn[0].top[0], rn[0].top[1], rn[0].top[2], u2f(MI_END_LINK));
+    }
     c->dev.n_nodes = nN;
     c->has_bvh = true;
     return 0;
@@ -363,14 +428,15 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipSt
         break;
     case MI355_MODE_RAYTRACE: case MI355_MODE_RAYTRACE_ANTIALIAS: {
         if (!c->has_bvh) return fail(-41, "raytrace modes need mi355_scene_set_bvh first");
-        int per_cu = mi355i_raytrace_blocks_per_cu(stats, P.exact_box);
+        const int ordered = (!stats && !P.ref_order && c->dev.ordered_ok) ? 1 : 0;
+        int per_cu = mi355i_raytrace_blocks_per_cu(stats, P.exact_box, ordered, (int)c->dev.stack_depth);
         if (P.blocks_per_cu > 0 && P.blocks_per_cu < per_cu) per_cu = P.blocks_per_cu;
         int n_blocks = per_cu * c->n_cus;
         const long long lanes_needed = ((long long)P.W * P.n_rows + 255) / 256;
         if (n_blocks > lanes_needed) n_blocks = (int)(lanes_needed > 0 ? lanes_needed : 1);
         c->last_blocks = n_blocks;
         if (P.wave_prof) HIP_TRY(hipMemsetAsync(c->wave_prof.p, 0, (size_t)n_blocks * 4 * 16 * 8, st), -40);
-        e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, n_blocks, st);
+        e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, n_blocks, st);
         break;
     }
     case MI355_MODE_LINES:
@@ -569,6 +635,19 @@ int mi355i_fetch_profile(mi355_ctx *c, unsigned long long *out16)
     if (!c || !out16) return fail(-3, "mi355i_fetch_profile: null argument");
     if (int r = select_device(c)) return r;
     HIP_TRY(hipMemcpy(out16, (char *)c->ctrl.p + 16 + sizeof(unsigned long long) * CS_PROF0, 20 * sizeof(unsigned long long), hipMemcpyDeviceToHost), -31);
+    return 0;
+}
+
+// Not part of the public ABI: how the raytracer will walk this scene's tree.
+// out[0] = 1 when the ordered walk is available (tree passed the checks), out[1] = per-lane stack entries,
+// out[2] = BVH nodes, out[3] = 1 when every box coordinate is in the filtered box test's range.
+int mi355i_scene_info(mi355_ctx *c, uint32_t *out4)
+{
+    if (!c || !out4) return fail(-3, "mi355i_scene_info: null argument");
+    out4[0] = c->has_bvh ? c->dev.ordered_ok : 0u;
+    out4[1] = c->dev.stack_depth;
+    out4[2] = c->dev.n_nodes;
+    out4[3] = c->boxes_tame ? 1u : 0u;
     return 0;
 }
 

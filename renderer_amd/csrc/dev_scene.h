@@ -25,6 +25,8 @@
 #define MI_TWOSIDED_BIT 0x40000000u // (with MI_LEAF_BIT) the target triangle is two-sided
 #define MI_FIRST_BIT 0x20000000u    // (with MI_LEAF_BIT) the target is the first block of its leaf
 #define MI_INDEX_MASK 0x1fffffffu   // float4 index of the target record
+#define MI_VROOT_LINK 0x1ffffff0u   // L.cur of a lane sitting on the virtual record above the root (ordered walk)
+#define MI_MAX_STACK 48             // deepest tree the ordered walk accepts (LDS: 1 KB per level per block)
 
 #define MI_MAX_LIGHTS 4
 #define MI_MAX_DEPTH 4
@@ -40,13 +42,24 @@
 // the link that points at it: the triangle's leaf-order index j is its position, its twoSided flag
 // and "first block of a leaf" (the reference's pop of the leaf node, for the counters) are link bits.
 // The root's record is the same for every ray, so it rides in the kernel arguments.
+//
+// Ordered traversal (k_raytrace<.., ORDERED>) reads "wide" records from the same buffer, four float4 per
+// inner node, holding BOTH children's boxes so that one step decides two box tests:
+//   wide node     : (minL.xyz, link L) (maxL.xyz, link R) (minR.xyz, -) (maxR.xyz, -)
+// with links to wide records or (MI_LEAF_BIT) to the triangle blocks above.  A walk starts at a virtual
+// record in the kernel arguments whose only child is the root (link R = MI_END_LINK = no child).
+// The wide records are only used when the tree passed the checks of capi.hip (ordered_ok).
 struct DevScene {
     const float4 *walk;
     const float4 *tri_edge;
     const float4 *tri_shade;
     float4 root_a, root_b;    // walk record behind root_link
+    float4 vroot_a, vroot_b;  // virtual wide record above the root: (root min, wide link of the root) (root max, END)
     uint32_t root_link;
     uint32_t tri_base;        // float4 index of triangle block 0
+    uint32_t ordered_ok;      // boxes bound their subtrees, list order = visiting order, depth fits the LDS stack
+    uint32_t stack_depth;     // entries of the per-lane stack the ordered walk needs
+    float scene_mag;          // largest |coordinate| of any box
     uint32_t n_nodes;
     uint32_t n_tris;
     uint32_t n_verts;
@@ -82,7 +95,7 @@ struct FrameParams {
     int32_t rmin;              // refill once this many lanes are idle (or nobody is alive)
     int32_t chunk;             // pixel indices a wave takes from the dispenser at a time
     int32_t exact_box;         // always use the exact six-division box test
-    int32_t lmin;              // reserved (was: leaf postponement)
+    int32_t ref_order;         // walk in the reference's fixed left-first order even when the ordered walk is available
     int32_t scatter;           // dispenser hands out pixel slot s of every tile before slot s+1 (load balance)
     unsigned long long *wave_prof; // counting builds: 16 words of phase profile per wave (debug), or NULL
     const uint32_t *tile_order; // dispenser index -> 8x8 tile id (heavy tiles first), or NULL = row-major

@@ -46,6 +46,10 @@ struct Lane {
     bool tame;             // ray_is_tame(d)
     int avoid;             // leaf-order index of the triangle to skip (avoidSelf), -1 = none
     float best;            // bestTriDist
+    float limit;           // ordered walk: a box whose entry lies beyond this cannot change the result
+    float delta;           // ordered walk: slack for a hit point lying just outside its triangle's box
+    f3 dinv;               // ordered walk: delta * |inv|
+    int sp;                // ordered walk: entries on this lane's LDS stack
     int btri;              // closest triangle so far (leaf order), -1 = none
     f3 hit;
     float k1, k2, k3;      // kAB, kBC, kCA
@@ -139,16 +143,53 @@ MI_DEV bool ray_box_fast(const f3 o, const f3 inv, const float4 lo, const float4
     return pass;
 }
 
+// The same filtered test for the ordered walk, which also needs (for a tame ray)
+//   key : a lower bound of Tnear, used only to pick the child to enter first (any order is correct),
+//   cull: a lower bound of the ray parameter at which the ray enters the box GROWN by L.delta on every
+//         side.  A hit the reference accepts in a triangle below this box lies in the grown box (the
+//         triangle is inside the box, capi.hip checks it; the computed hit point is within rounding of the
+//         triangle), and directions are unit vectors, so its distance from the origin is at least `cull`.
+MI_DEV bool ray_box_fast_ordered(const f3 o, const f3 inv, const f3 dinv, const float4 lo, const float4 hi, bool &sure,
+                                 float &key, float &cull)
+{
+    const float E = 1e-6f;
+    const float x1 = (lo.x - o.x) * inv.x, x2 = (hi.x - o.x) * inv.x;
+    const float y1 = (lo.y - o.y) * inv.y, y2 = (hi.y - o.y) * inv.y;
+    const float z1 = (lo.z - o.z) * inv.z, z2 = (hi.z - o.z) * inv.z;
+    const float xa = __builtin_fminf(x1, x2), xb = __builtin_fmaxf(x1, x2);
+    const float ya = __builtin_fminf(y1, y2), yb = __builtin_fmaxf(y1, y2);
+    const float za = __builtin_fminf(z1, z2), zb = __builtin_fmaxf(z1, z2);
+    const float xl = __builtin_fmaf(-E, __builtin_fabsf(xa), xa), yl = __builtin_fmaf(-E, __builtin_fabsf(ya), ya),
+                zl = __builtin_fmaf(-E, __builtin_fabsf(za), za);
+    const float tn_lo = __builtin_fmaxf(__builtin_fmaxf(xl, yl), zl);
+    const float tn_hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(E, __builtin_fabsf(xa), xa), __builtin_fmaf(E, __builtin_fabsf(ya), ya)),
+                                        __builtin_fmaf(E, __builtin_fabsf(za), za));
+    const float tf_lo = __builtin_fminf(__builtin_fminf(__builtin_fmaf(-E, __builtin_fabsf(xb), xb), __builtin_fmaf(-E, __builtin_fabsf(yb), yb)),
+                                        __builtin_fmaf(-E, __builtin_fabsf(zb), zb));
+    const float tf_hi = __builtin_fminf(__builtin_fminf(__builtin_fmaf(E, __builtin_fabsf(xb), xb), __builtin_fmaf(E, __builtin_fabsf(yb), yb)),
+                                        __builtin_fmaf(E, __builtin_fabsf(zb), zb));
+    const bool pass = (tn_hi <= tf_lo) && (tf_lo >= 0.f);
+    const bool fail = (tn_lo > tf_hi) || (tf_hi < 0.f);
+    sure = pass || fail;
+    key = tn_lo;
+    cull = __builtin_fmaxf(__builtin_fmaxf(xl - dinv.x, yl - dinv.y), zl - dinv.z);
+    return pass;
+}
+
 // per-ray constants of the filtered box test
-MI_DEV void set_ray_aux(Lane &L)
+MI_DEV void set_ray_aux(Lane &L, float scene_mag)
 {
     L.inv = mk3(__builtin_amdgcn_rcpf(L.d.x), __builtin_amdgcn_rcpf(L.d.y), __builtin_amdgcn_rcpf(L.d.z));
     L.tame = ray_is_tame(L.o, L.d);
     L.pend = false;
+    // ordered walk: 1e-4 of the largest coordinate in play -- rounding moves a computed hit point by ~1e-6 of it
+    const float m = __builtin_fmaxf(__builtin_fmaxf(scene_mag, __builtin_fabsf(L.o.x)), __builtin_fmaxf(__builtin_fabsf(L.o.y), __builtin_fabsf(L.o.z)));
+    L.delta = 1e-4f * m;
+    L.dinv = mk3(L.delta * __builtin_fabsf(L.inv.x), L.delta * __builtin_fabsf(L.inv.y), L.delta * __builtin_fabsf(L.inv.z));
 }
 
 // Primary ray of pixel (px,py), sample index `traced` (Raytracer.cc:563-593)
-MI_DEV void primary_ray(const FrameParams &P, Lane &L, int traced)
+MI_DEV void primary_ray(const FrameParams &P, const DevScene &S, Lane &L, int traced)
 {
     float xx = (float)L.px, yy = (float)L.py;
     if (P.aa) {
@@ -165,12 +206,13 @@ MI_DEV void primary_ray(const FrameParams &P, Lane &L, int traced)
     rw = add3(rw, mul3(r3, rc.z));
     L.d = norm3(rw);
     L.o = mk3(P.eye[0], P.eye[1], P.eye[2]);
-    set_ray_aux(L);
+    set_ray_aux(L, S.scene_mag);
     L.depth = 0;
     L.mode = MODE_CLOSEST;
     L.cur = 0;          // patched by caller with the root link
     L.avoid = -1;
     L.best = FLT_MAX;
+    L.limit = FLT_MAX;
     L.btri = -1;
 }
 
@@ -254,10 +296,17 @@ MI_DEV void rec_fetch(const DevScene &S, uint32_t link, Rec &r)
 }
 
 // every walk starts at the root, whose record is a kernel argument
-MI_DEV void begin_walk(const DevScene &S, Lane &L, Rec &R)
+// (ordered walk: at the virtual record above the root, both of whose boxes are the root's)
+template <bool ORDERED>
+MI_DEV void begin_walk(const DevScene &S, Lane &L, Rec &R, Rec &R2)
 {
-    L.cur = S.root_link;
-    R.a = S.root_a; R.b = S.root_b;
+    if (ORDERED) {
+        L.cur = MI_VROOT_LINK; L.sp = 0;
+        R.a = S.vroot_a; R.b = S.vroot_b; R2.a = S.vroot_a; R2.b = S.vroot_b;
+    } else {
+        L.cur = S.root_link;
+        R.a = S.root_a; R.b = S.root_b;
+    }
 }
 
 // Box test of an inner node's record (Raytracer.cc:222-230)
@@ -291,6 +340,9 @@ MI_DEV bool tri_plane_test(const Lane &L, float nudge, uint32_t link, int j, con
 }
 
 // edge half (Raytracer.cc:269-297) of the pending candidate; returns true when a shadow ray is blocked
+// (ordered walk: candidates arrive in any order, so "first found wins among equal distances" becomes
+//  "lowest list position wins" -- the same triangle, list position being the reference's visiting rank)
+template <bool ORDERED>
 MI_DEV bool tri_edge_test(Lane &L)
 {
     const f3 hit = L.ph;
@@ -301,31 +353,39 @@ MI_DEV bool tri_edge_test(Lane &L)
         if (distsq3(L.lp, hit) < L.best) { L.shadow_hit = true; return true; }
     } else {
         const float hitZ = distsq3(L.o, hit);
-        if (hitZ < L.best) { L.best = hitZ; L.btri = L.pj; L.hit = hit; L.k1 = kt1; L.k2 = kt2; L.k3 = kt3; }
+        const bool better = ORDERED ? (hitZ < L.best || (hitZ == L.best && L.pj < L.btri)) : (hitZ < L.best);
+        if (better) {
+            L.best = hitZ; L.btri = L.pj; L.hit = hit; L.k1 = kt1; L.k2 = kt2; L.k3 = kt3;
+            if (ORDERED) L.limit = __builtin_sqrtf(hitZ) * 1.001f + L.delta;
+        }
     }
     return false;
 }
 
 } // namespace
 
-template <bool STATS, bool EXACT_BOX>
+template <bool STATS, bool EXACT_BOX, bool ORDERED>
 __global__ void __launch_bounds__(256)
 k_raytrace(const DevScene S, const FrameParams P)
 {
     // LDS: per-lane colour columns of the ray tree's depth levels
     __shared__ float lds_col[MI_MAX_DEPTH * 3 * 256];
+    // LDS (ordered walk only, sized at launch): per-lane stack of postponed children, one row per level
+    extern __shared__ uint32_t lds_stack[];
     Lane L;
     bool alive = false;         // lane owns a pixel
     bool want_pixel = true;     // lane needs a (new) pixel
     bool exhausted = false;     // dispenser ran dry (wave-uniform)
     Rec R;                      // record of the node this lane visits next
-    R.a = R.b = make_float4(0.f, 0.f, 0.f, 0.f);
+    Rec R2;                     // ordered walk: second half of a wide record (the right child's box)
+    R.a = R.b = R2.a = R2.b = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t pool_next = 0, pool_end = 0;   // wave-local pixel pool (wave-uniform)
     L.cur = MI_END_LINK; L.mode = MODE_CLOSEST; L.btri = -1; L.depth = 0; L.samples_left = 0;
     L.fr = L.fg = L.fb = 0.f; L.px = L.py = L.orow = 0; L.avoid = -1; L.best = 0.f;
     L.shadow_hit = false; L.li = 0; L.cr = L.cg = L.cb = 0.f; L.k1 = L.k2 = L.k3 = 0.f;
     L.o = L.d = L.hit = L.pn = L.refl = L.lp = L.inv = L.ph = mk3(0.f, 0.f, 0.f);
     L.tame = false; L.pend = false; L.pj = -1;
+    L.limit = 0.f; L.delta = 0.f; L.dinv = mk3(0.f, 0.f, 0.f); L.sp = 0;
     L.pe1 = L.pe2 = L.pe3 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     unsigned n_normal = 0, n_shadow = 0;
@@ -392,8 +452,8 @@ k_raytrace(const DevScene S, const FrameParams P)
                                     L.orow = P.compact ? r : L.py;
                                     L.fr = L.fg = L.fb = 0.f;
                                     L.samples_left = P.aa ? 3 : 0;
-                                    primary_ray(P, L, L.samples_left);
-                                    begin_walk(S, L, R);
+                                    primary_ray(P, S, L, L.samples_left);
+                                    begin_walk<ORDERED>(S, L, R, R2);
                                     n_normal++;
                                     alive = true;
                                     want_pixel = false;
@@ -446,11 +506,14 @@ k_raytrace(const DevScene S, const FrameParams P)
                             float distSq = lensq3(ptl);
                             L.d = div3(ptl, __builtin_sqrtf(distSq));
                             L.o = L.hit;
-                            set_ray_aux(L);
+                            set_ray_aux(L, S.scene_mag);
                             L.best = distsq3(L.o, L.lp);            // Raytracer.cc:209
+                            // a hit blocks when it is nearer to the light than the origin is, i.e. at a ray
+                            // parameter below twice the light's distance
+                            L.limit = 2.f * __builtin_sqrtf(L.best) * 1.001f + L.delta;
                             L.mode = MODE_SHADOW;
                             L.shadow_hit = false;
-                            begin_walk(S, L, R);
+                            begin_walk<ORDERED>(S, L, R, R2);
                             L.avoid = L.btri;                       // avoidSelf = the triangle just hit (Raytracer.cc:335)
                             n_shadow++;
                             launched = true;
@@ -465,9 +528,9 @@ k_raytrace(const DevScene S, const FrameParams P)
                         L.depth++;
                         if (P.use_refl && L.depth < P.max_depth) {
                             L.o = L.hit; L.d = L.refl; L.avoid = L.btri;
-                            set_ray_aux(L);
-                            L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.btri = -1;
-                            begin_walk(S, L, R);
+                            set_ray_aux(L, S.scene_mag);
+                            L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
+                            begin_walk<ORDERED>(S, L, R, R2);
                             n_normal++;
                         } else finish = true;
                     }
@@ -480,8 +543,8 @@ k_raytrace(const DevScene S, const FrameParams P)
                     L.fb += ab; L.fg += ag; L.fr += ar;              // finalColor += ...
                     if (L.samples_left > 0) {
                         L.samples_left--;
-                        primary_ray(P, L, L.samples_left);
-                        begin_walk(S, L, R);
+                        primary_ray(P, S, L, L.samples_left);
+                        begin_walk<ORDERED>(S, L, R, R2);
                         n_normal++;
                     } else {
                         float r = L.fr, g = L.fg, b = L.fb;
@@ -507,6 +570,89 @@ k_raytrace(const DevScene S, const FrameParams P)
         // ---------------- traversal burst ------------------------------------------------
         // Keep walking until enough lanes have finished their ray to make servicing them worthwhile.
         MI_PHASE(pc_refill);
+        if constexpr (ORDERED) {
+        // ---- ordered walk: near child first, subtrees beyond the best hit skipped (never a counting build) ----
+        // R/R2 hold the record of L.cur: a wide record (both children's boxes) or, in R alone, a triangle block.
+        uint32_t *const stk = lds_stack + threadIdx.x;
+        for (;;) {
+            const bool walking = alive && L.cur != MI_END_LINK;
+            const bool inner = walking && (L.cur & MI_LEAF_BIT) == 0;
+            const bool tri = walking && (L.cur & MI_LEAF_BIT) != 0;
+            const unsigned long long mI = __ballot(inner), mL = __ballot(tri);
+            // 1. judge the candidate of the previous step (its edge record was requested before this node's record)
+            bool stop = false;
+            if (__ballot(L.pend)) {
+                if (L.pend) {
+                    L.pend = false;
+                    stop = tri_edge_test<true>(L);                  // a blocked shadow ray stops (Raytracer.cc:284)
+                }
+            }
+            uint32_t next = MI_END_LINK;                            // END = nothing to enter from here: pop
+            // 2. wide nodes: both children's box tests (Raytracer.cc:222-230 for each)
+            if (mI) {
+                if (inner) {
+                    const uint32_t linkL = __float_as_uint(R.a.w), linkR = __float_as_uint(R.b.w);
+                    bool hL, hR;
+                    float kL = 0.f, kR = 0.f;
+                    if (EXACT_BOX) {
+                        hL = ray_box_exact(L.o, L.d, R.a, R.b);
+                        hR = ray_box_exact(L.o, L.d, R2.a, R2.b);
+                    } else {
+                        bool sL, sR;
+                        float cL, cR;
+                        hL = ray_box_fast_ordered(L.o, L.inv, L.dinv, R.a, R.b, sL, kL, cL);
+                        hR = ray_box_fast_ordered(L.o, L.inv, L.dinv, R2.a, R2.b, sR, kR, cR);
+                        if (__builtin_expect(!(sL && sR && L.tame), 0)) {
+                            hL = ray_box_exact(L.o, L.d, R.a, R.b);
+                            hR = ray_box_exact(L.o, L.d, R2.a, R2.b);
+                        } else {
+                            hL = hL && !(cL > L.limit);
+                            hR = hR && !(cR > L.limit);
+                        }
+                    }
+                    hR = hR && linkR != MI_END_LINK;                // the virtual record above the root has one child
+                    if (hL && hR) {
+                        const bool left_first = kL <= kR;
+                        next = left_first ? linkL : linkR;
+                        stk[L.sp * 256] = left_first ? linkR : linkL;
+                        L.sp++;
+                    } else if (hL) next = linkL;
+                    else if (hR) next = linkR;
+                }
+            }
+            // 3. triangle blocks: plane test; the chain continues while the next link stays inside the leaf
+            bool cand = false;
+            f3 ch = mk3(0.f, 0.f, 0.f);
+            const int j = (int)(((L.cur & MI_INDEX_MASK) - S.tri_base) >> 1);
+            if (mL) {
+                if (tri) {
+                    cand = tri_plane_test(L, P.nudge, L.cur, j, R.a, R.b, ch);
+                    const uint32_t nx = __float_as_uint(R.a.w);
+                    if ((nx & (MI_LEAF_BIT | MI_FIRST_BIT)) == MI_LEAF_BIT && nx != MI_END_LINK) next = nx;
+                }
+            }
+            // 4. nothing to enter: resume at the most recently postponed child
+            if (walking && next == MI_END_LINK && L.sp > 0) { L.sp--; next = stk[L.sp * 256]; }
+            if (walking) L.cur = next;
+            if (stop) { L.cur = MI_END_LINK; L.sp = 0; }
+            // 5. requests: the candidate's edge record first (judged at the top of the next step), then the
+            //    record of the node to visit next
+            if (cand) {
+                const float4 *e = S.tri_edge + (size_t)j * 3;
+                L.pe1 = e[0]; L.pe2 = e[1]; L.pe3 = e[2];
+                L.pj = j; L.ph = ch; L.pend = true;
+            }
+            if (alive && L.cur != MI_END_LINK) {
+                const float4 *p = S.walk + (size_t)(L.cur & MI_INDEX_MASK);
+                R.a = p[0]; R.b = p[1];
+                if ((L.cur & MI_LEAF_BIT) == 0) { R2.a = p[2]; R2.b = p[3]; }
+            }
+            const unsigned long long mDone = __ballot(alive && L.cur == MI_END_LINK && !L.pend);
+            const unsigned long long mBusy = __ballot(alive && !(L.cur == MI_END_LINK && !L.pend));
+            if (!mBusy || __popcll(mDone) >= xmin_now) break;
+        }
+        } else {
+        // ---- walk in the reference's order (threaded links): counting builds, unchecked trees ----
         for (;;) {
             if (STATS) it_loops++;
             const bool walking = alive && L.cur != MI_END_LINK;
@@ -518,7 +664,6 @@ k_raytrace(const DevScene S, const FrameParams P)
             const uint32_t link1 = __float_as_uint(R.a.w);
             const uint32_t link2 = __float_as_uint(R.b.w);
             Rec N1, N2;
-            N2.a = N2.b = make_float4(0.f, 0.f, 0.f, 0.f);
             if (walking) rec_fetch(S, link1, N1);
             if (inner) rec_fetch(S, link2, N2);
             // 2. inner nodes: box test (Raytracer.cc:222-230)
@@ -549,7 +694,7 @@ k_raytrace(const DevScene S, const FrameParams P)
             if (__ballot(L.pend)) {
                 if (L.pend) {
                     L.pend = false;
-                    stop = tri_edge_test(L);                        // a blocked shadow ray stops (Raytracer.cc:284)
+                    stop = tri_edge_test<false>(L);                        // a blocked shadow ray stops (Raytracer.cc:284)
                 }
             }
             if (walking) {
@@ -570,13 +715,14 @@ k_raytrace(const DevScene S, const FrameParams P)
                     // counting builds judge at once so that a blocked shadow ray stops exactly where the
                     // reference does and the counters stay comparable
                     L.pend = false;
-                    if (tri_edge_test(L)) L.cur = MI_END_LINK;
+                    if (tri_edge_test<false>(L)) L.cur = MI_END_LINK;
                 }
             }
             if (mL) MI_PHASE(pc_b);
             const unsigned long long mDone = __ballot(alive && L.cur == MI_END_LINK && !L.pend);
             const unsigned long long mBusy = __ballot(alive && !(L.cur == MI_END_LINK && !L.pend));
             if (!mBusy || __popcll(mDone) >= xmin_now) break;
+        }
         }
     }
     if (STATS) pc_total = __builtin_readcyclecounter() - tick0;
@@ -622,30 +768,34 @@ k_raytrace(const DevScene S, const FrameParams P)
 }
 
 // ---- launch helper (called from capi.hip) ------------------------------------------------
-template <bool STATS, bool EXACT> static int occ_of()
+namespace {
+typedef void (*rt_kernel)(const DevScene, const FrameParams);
+rt_kernel pick_kernel(int stats, int exact, int ordered)
 {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_raytrace<STATS, EXACT>, 256, 0) != hipSuccess || nb < 1) nb = 2;
-    return nb > 8 ? 8 : nb;
+    if (ordered) return exact ? k_raytrace<false, true, true> : k_raytrace<false, false, true>;
+    if (stats) return exact ? k_raytrace<true, true, false> : k_raytrace<true, false, false>;
+    return exact ? k_raytrace<false, true, false> : k_raytrace<false, false, false>;
+}
+size_t stack_bytes(int ordered, int stack_depth) { return ordered ? (size_t)stack_depth * 256u * sizeof(uint32_t) : 0u; }
+} // namespace
+
+extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int stack_depth)
+{
+    static int cache[2][2][2][MI_MAX_STACK + 1];        // 0 = not asked yet
+    if (stack_depth < 0 || stack_depth > MI_MAX_STACK) stack_depth = MI_MAX_STACK;
+    int &slot = cache[stats ? 1 : 0][exact ? 1 : 0][ordered ? 1 : 0][ordered ? stack_depth : 0];
+    if (!slot) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_kernel(stats, exact, ordered), 256, stack_bytes(ordered, stack_depth)) != hipSuccess || nb < 1)
+            nb = 2;
+        slot = nb > 8 ? 8 : nb;
+    }
+    return slot;
 }
 
-extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact)
-{
-    static int occ[2][2] = {{0, 0}, {0, 0}};
-    int &o = occ[stats ? 1 : 0][exact ? 1 : 0];
-    if (!o) o = stats ? (exact ? occ_of<true, true>() : occ_of<true, false>()) : (exact ? occ_of<false, true>() : occ_of<false, false>());
-    return o;
-}
-
-extern "C" hipError_t mi355i_launch_raytrace(const DevScene *S, const FrameParams *P, int stats, int exact, int n_blocks,
+extern "C" hipError_t mi355i_launch_raytrace(const DevScene *S, const FrameParams *P, int stats, int exact, int ordered, int n_blocks,
                                              hipStream_t st)
 {
-    if (stats) {
-        if (exact) hipLaunchKernelGGL((k_raytrace<true, true>), dim3(n_blocks), dim3(256), 0, st, *S, *P);
-        else hipLaunchKernelGGL((k_raytrace<true, false>), dim3(n_blocks), dim3(256), 0, st, *S, *P);
-    } else {
-        if (exact) hipLaunchKernelGGL((k_raytrace<false, true>), dim3(n_blocks), dim3(256), 0, st, *S, *P);
-        else hipLaunchKernelGGL((k_raytrace<false, false>), dim3(n_blocks), dim3(256), 0, st, *S, *P);
-    }
+    hipLaunchKernelGGL(pick_kernel(stats, exact, ordered), dim3(n_blocks), dim3(256), stack_bytes(ordered, (int)S->stack_depth), st, *S, *P);
     return hipGetLastError();
 }

@@ -111,6 +111,48 @@ def test_raytrace_antialias_and_two_lights(oracle, oracle_scene, gpu_scene):
     assert_same(g, o)
 
 
+@pytest.mark.parametrize("mesh", ["dragon_vis.ply", "statue.ply", "chessboard.tri"])
+def test_shipped_meshes_take_the_ordered_walk(gpu_scene, mesh):
+    """The reference builder's trees pass the checks, so the frames above really ran the ordered kernel."""
+    ok, depth, nodes, tame = gpu_scene(mesh, True).walk_info()
+    assert ok == 1 and tame == 1 and 1 <= depth <= 48 and nodes > 0
+
+
+def test_unchecked_tree_falls_back_to_reference_order(oracle, oracle_scene):
+    """A tree whose boxes do not contain their triangles (legal input: the reference walks whatever boxes it
+    is given) must be walked in the reference's order; one whose boxes are merely larger keeps the ordered walk
+    and must give the pixels of the reference-order walk over the same tree."""
+    s = R.Scene(R.assets.mesh_path("statue.ply"))
+    s.bvh_create()
+    nodes, idx = s.bvh_arrays()
+    nodes, idx = nodes.copy(), idx.copy()
+    cam, lights, n = R.benchmark_frame(4)
+    o = R.default_opts(320, 180)
+    ref = s.render(9, cam, lights, n, o)[0]
+    assert s.walk_info()[0] == 1
+    inner = (nodes[:, 6] & 0x80000000) == 0
+    f = nodes[:, :6].view(np.float32)
+    grown = nodes.copy()
+    gf = grown[:, :6].view(np.float32)
+    gf[:, :3] -= 0.01
+    gf[:, 3:] += 0.01
+    s.set_bvh_arrays(grown, idx)
+    assert s.walk_info()[0] == 1
+    ro = R.default_opts(320, 180, tune=dict(reforder=1))
+    assert (s.render(9, cam, lights, n, o)[0] == s.render(9, cam, lights, n, ro)[0]).all()
+    shrunk = nodes.copy()
+    sf = shrunk[:, :6].view(np.float32)
+    mid = 0.5 * (f[:, :3] + f[:, 3:])
+    sf[inner, :3] = (mid + 0.9 * (f[:, :3] - mid))[inner]
+    sf[inner, 3:] = (mid + 0.9 * (f[:, 3:] - mid))[inner]
+    s.set_bvh_arrays(shrunk, idx)
+    assert s.walk_info()[0] == 0
+    a = s.render(9, cam, lights, n, o)[0]
+    b = s.render(9, cam, lights, n, ro)[0]
+    c = s.render(9, cam, lights, n, R.default_opts(320, 180, collect_stats=1))[0]
+    assert (a == b).all() and (a == c).all()
+
+
 def test_raytrace_stats_variant_matches_and_counts(oracle, oracle_scene, gpu_scene):
     g, o = both_frames(oracle, oracle_scene, gpu_scene, "statue.ply", 9, 640, 360, 2, collect_stats=1)
     assert_same(g, o)
@@ -128,7 +170,7 @@ def test_raytrace_ragged_sizes(oracle, oracle_scene, gpu_scene, size):
 @pytest.mark.parametrize("knobs", [
     dict(xmin=1, rmin=1, chunk=64, lmin=1), dict(xmin=32, rmin=48, chunk=512, lmin=64), dict(xmin=64, rmin=64, chunk=4096),
     dict(exact=1), dict(rowmajor=1), dict(exact=1, lmin=16), dict(scatter=1), dict(bpc=1), dict(bpc=2, exact=1, lmin=4),
-    dict(chunk=64, rmin=64, xmin=1, lmin=2)],
+    dict(chunk=64, rmin=64, xmin=1, lmin=2), dict(reforder=1), dict(reforder=1, exact=1), dict(reforder=1, xmin=1, rmin=1)],
     ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
 def test_raytrace_tuning_knobs_do_not_change_pixels(oracle, oracle_scene, gpu_scene, knobs):
     """Scheduling knobs and the filtered box test are invisible in the output."""
