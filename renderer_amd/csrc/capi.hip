@@ -205,6 +205,7 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.rmin = t[1] > 0 ? (t[1] > 64 ? 64 : t[1]) : 32;
     P.chunk = t[2] > 0 ? t[2] : 64;
     P.ref_order = (flags & 4) ? 1 : 0;
+    P.prof_ordered = (flags & 8) ? 1 : 0;
     P.blocks_per_cu = t[4] > 0 ? t[4] : 0;
     P.exact_box = (flags & 1) ? 1 : 0;
     if (!c->boxes_tame) P.exact_box = 1;     // box coordinates outside the filtered test's validated range
@@ -428,7 +429,7 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipSt
         break;
     case MI355_MODE_RAYTRACE: case MI355_MODE_RAYTRACE_ANTIALIAS: {
         if (!c->has_bvh) return fail(-41, "raytrace modes need mi355_scene_set_bvh first");
-        const int ordered = (!stats && !P.ref_order && c->dev.ordered_ok) ? 1 : 0;
+        const int ordered = ((!stats || P.prof_ordered) && !P.ref_order && c->dev.ordered_ok) ? 1 : 0;
         int per_cu = mi355i_raytrace_blocks_per_cu(stats, P.exact_box, ordered, (int)c->dev.stack_depth);
         if (P.blocks_per_cu > 0 && P.blocks_per_cu < per_cu) per_cu = P.blocks_per_cu;
         int n_blocks = per_cu * c->n_cus;

@@ -49,7 +49,8 @@ struct Lane {
     float limit;           // ordered walk: a box whose entry lies beyond this cannot change the result
     float delta;           // ordered walk: slack for a hit point lying just outside its triangle's box
     f3 dinv;               // ordered walk: delta * |inv|
-    int sp;                // ordered walk: entries on this lane's LDS stack
+    int sp;                // ordered walk: postponed children of this lane (the newest in `top`, the rest in LDS)
+    uint32_t top;
     int btri;              // closest triangle so far (leaf order), -1 = none
     f3 hit;
     float k1, k2, k3;      // kAB, kBC, kCA
@@ -301,7 +302,7 @@ template <bool ORDERED>
 MI_DEV void begin_walk(const DevScene &S, Lane &L, Rec &R, Rec &R2)
 {
     if (ORDERED) {
-        L.cur = MI_VROOT_LINK; L.sp = 0;
+        L.cur = MI_VROOT_LINK; L.sp = 0; L.top = MI_END_LINK;
         R.a = S.vroot_a; R.b = S.vroot_b; R2.a = S.vroot_a; R2.b = S.vroot_b;
     } else {
         L.cur = S.root_link;
@@ -385,13 +386,14 @@ k_raytrace(const DevScene S, const FrameParams P)
     L.shadow_hit = false; L.li = 0; L.cr = L.cg = L.cb = 0.f; L.k1 = L.k2 = L.k3 = 0.f;
     L.o = L.d = L.hit = L.pn = L.refl = L.lp = L.inv = L.ph = mk3(0.f, 0.f, 0.f);
     L.tame = false; L.pend = false; L.pj = -1;
-    L.limit = 0.f; L.delta = 0.f; L.dinv = mk3(0.f, 0.f, 0.f); L.sp = 0;
+    L.limit = 0.f; L.delta = 0.f; L.dinv = mk3(0.f, 0.f, 0.f); L.sp = 0; L.top = MI_END_LINK;
     L.pe1 = L.pe2 = L.pe3 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     unsigned n_normal = 0, n_shadow = 0;
     unsigned n_pops = 0, n_ihits = 0, n_tris = 0, n_plane = 0, n_shaded = 0;
     // phase profile (STATS builds only; wave-uniform): cycles and lane occupancy per phase
-    unsigned long long pc_refill = 0, pc_trans = 0, pc_a = 0, pc_b = 0, pc_total = 0;
+    unsigned long long pc_refill = 0, pc_trans = 0, pc_a = 0, pc_b = 0, pc_total = 0, pc_wait = 0;
+    unsigned n_slow = 0;        // ordered counting build: lanes sent to the exact box test
     unsigned long long it_refill = 0, ln_refill = 0, it_trans = 0, ln_trans = 0, it_a = 0, ln_a = 0, it_b = 0, ln_b = 0;
     unsigned long long tick = STATS ? __builtin_readcyclecounter() : 0ull;
     const unsigned long long tick0 = tick;
@@ -571,25 +573,27 @@ k_raytrace(const DevScene S, const FrameParams P)
         // Keep walking until enough lanes have finished their ray to make servicing them worthwhile.
         MI_PHASE(pc_refill);
         if constexpr (ORDERED) {
-        // ---- ordered walk: near child first, subtrees beyond the best hit skipped (never a counting build) ----
+        // ---- ordered walk: near child first, subtrees beyond the best hit skipped ----
+        // (a counting build of it exists for profiling only: its counters describe THIS walk, not the reference's)
         // R/R2 hold the record of L.cur: a wide record (both children's boxes) or, in R alone, a triangle block.
+        // A step decides where to go next and requests that record at once; the candidate of the previous step
+        // is judged and this step's triangle is plane-tested while the request is in flight.
         uint32_t *const stk = lds_stack + threadIdx.x;
         for (;;) {
+            if (STATS) it_loops++;
             const bool walking = alive && L.cur != MI_END_LINK;
             const bool inner = walking && (L.cur & MI_LEAF_BIT) == 0;
             const bool tri = walking && (L.cur & MI_LEAF_BIT) != 0;
             const unsigned long long mI = __ballot(inner), mL = __ballot(tri);
-            // 1. judge the candidate of the previous step (its edge record was requested before this node's record)
-            bool stop = false;
-            if (__ballot(L.pend)) {
-                if (L.pend) {
-                    L.pend = false;
-                    stop = tri_edge_test<true>(L);                  // a blocked shadow ray stops (Raytracer.cc:284)
-                }
-            }
             uint32_t next = MI_END_LINK;                            // END = nothing to enter from here: pop
-            // 2. wide nodes: both children's box tests (Raytracer.cc:222-230 for each)
+            if (STATS) {                                            // profile: time spent waiting for the record
+                MI_PHASE(pc_b);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                MI_PHASE(pc_wait);
+            }
+            // 1. wide nodes: both children's box tests (Raytracer.cc:222-230 for each)
             if (mI) {
+                if (STATS) { it_a++; ln_a += __popcll(mI); }
                 if (inner) {
                     const uint32_t linkL = __float_as_uint(R.a.w), linkR = __float_as_uint(R.b.w);
                     bool hL, hR;
@@ -603,6 +607,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         hL = ray_box_fast_ordered(L.o, L.inv, L.dinv, R.a, R.b, sL, kL, cL);
                         hR = ray_box_fast_ordered(L.o, L.inv, L.dinv, R2.a, R2.b, sR, kR, cR);
                         if (__builtin_expect(!(sL && sR && L.tame), 0)) {
+                            if (STATS) n_slow++;
                             hL = ray_box_exact(L.o, L.d, R.a, R.b);
                             hR = ray_box_exact(L.o, L.d, R2.a, R2.b);
                         } else {
@@ -611,41 +616,88 @@ k_raytrace(const DevScene S, const FrameParams P)
                         }
                     }
                     hR = hR && linkR != MI_END_LINK;                // the virtual record above the root has one child
+                    if (STATS) { n_pops += linkR != MI_END_LINK ? 2u : 1u; n_ihits += (hL ? 1u : 0u) + (hR ? 1u : 0u); }
                     if (hL && hR) {
                         const bool left_first = kL <= kR;
                         next = left_first ? linkL : linkR;
-                        stk[L.sp * 256] = left_first ? linkR : linkL;
+                        if (L.sp > 0) stk[(L.sp - 1) * 256] = L.top;
+                        L.top = left_first ? linkR : linkL;
                         L.sp++;
                     } else if (hL) next = linkL;
                     else if (hR) next = linkR;
                 }
+                MI_PHASE(pc_a);
             }
-            // 3. triangle blocks: plane test; the chain continues while the next link stays inside the leaf
-            bool cand = false;
-            f3 ch = mk3(0.f, 0.f, 0.f);
-            const int j = (int)(((L.cur & MI_INDEX_MASK) - S.tri_base) >> 1);
-            if (mL) {
-                if (tri) {
-                    cand = tri_plane_test(L, P.nudge, L.cur, j, R.a, R.b, ch);
-                    const uint32_t nx = __float_as_uint(R.a.w);
-                    if ((nx & (MI_LEAF_BIT | MI_FIRST_BIT)) == MI_LEAF_BIT && nx != MI_END_LINK) next = nx;
+            // 2. triangle blocks: the chain continues while the next link stays inside the leaf; keep the block
+            //    for the plane test below (R is about to be overwritten)
+            const uint32_t tcur = L.cur;
+            float4 ta, tb;
+            // (explicit moves: a plain copy makes the compiler load the next record into fresh registers and
+            //  move it home at the loop's end -- behind a wait for the load)
+            asm volatile("v_mov_b32 %0, %8\n\tv_mov_b32 %1, %9\n\tv_mov_b32 %2, %10\n\tv_mov_b32 %3, %11\n\t"
+                         "v_mov_b32 %4, %12\n\tv_mov_b32 %5, %13\n\tv_mov_b32 %6, %14\n\tv_mov_b32 %7, %15"
+                         : "=&v"(ta.x), "=&v"(ta.y), "=&v"(ta.z), "=&v"(ta.w), "=&v"(tb.x), "=&v"(tb.y), "=&v"(tb.z), "=&v"(tb.w)
+                         : "v"(R.a.x), "v"(R.a.y), "v"(R.a.z), "v"(R.a.w), "v"(R.b.x), "v"(R.b.y), "v"(R.b.z), "v"(R.b.w));
+            if (tri) {
+                const uint32_t nx = __float_as_uint(R.a.w);
+                if ((nx & (MI_LEAF_BIT | MI_FIRST_BIT)) == MI_LEAF_BIT) next = nx;
+            }
+            // 3. nothing to enter: resume at the most recently postponed child (the one below it comes up from
+            //    LDS; it is not needed before this lane's next push or pop); then request the next record
+            if (walking && next == MI_END_LINK && L.sp > 0) {
+                next = L.top;
+                L.sp--;
+                if (L.sp > 0) L.top = stk[(L.sp - 1) * 256];
+            }
+            if (walking) {
+                L.cur = next;
+                if (next != MI_END_LINK) {
+                    const float4 *p = S.walk + (size_t)(next & MI_INDEX_MASK);
+                    R.a = p[0]; R.b = p[1];
+                    if ((next & MI_LEAF_BIT) == 0) { R2.a = p[2]; R2.b = p[3]; }
                 }
             }
-            // 4. nothing to enter: resume at the most recently postponed child
-            if (walking && next == MI_END_LINK && L.sp > 0) { L.sp--; next = stk[L.sp * 256]; }
-            if (walking) L.cur = next;
-            if (stop) { L.cur = MI_END_LINK; L.sp = 0; }
-            // 5. requests: the candidate's edge record first (judged at the top of the next step), then the
-            //    record of the node to visit next
-            if (cand) {
-                const float4 *e = S.tri_edge + (size_t)j * 3;
-                L.pe1 = e[0]; L.pe2 = e[1]; L.pe3 = e[2];
-                L.pj = j; L.ph = ch; L.pend = true;
-            }
-            if (alive && L.cur != MI_END_LINK) {
-                const float4 *p = S.walk + (size_t)(L.cur & MI_INDEX_MASK);
-                R.a = p[0]; R.b = p[1];
-                if ((L.cur & MI_LEAF_BIT) == 0) { R2.a = p[2]; R2.b = p[3]; }
+            // 4. while that request is in flight: judge the candidate of the previous step (its edge record has long
+            //    arrived) and plane-test this step's triangle.  Both are written as straight-line predicates -- the
+            //    same float operations in the same order as Raytracer.cc:245-297, without its early returns.
+            if (__ballot(L.pend || tri)) {
+                if (STATS && mL) { it_b++; ln_b += __popcll(mL); }
+                {   // edge half of the previous candidate (Raytracer.cc:269-297)
+                    const f3 hit = L.ph;
+                    const float kt1 = dot3(mk3(L.pe1.x, L.pe1.y, L.pe1.z), hit) - L.pe1.w;
+                    const float kt2 = dot3(mk3(L.pe2.x, L.pe2.y, L.pe2.z), hit) - L.pe2.w;
+                    const float kt3 = dot3(mk3(L.pe3.x, L.pe3.y, L.pe3.z), hit) - L.pe3.w;
+                    const bool inside = L.pend && !(kt1 < 0.0f) && !(kt2 < 0.0f) && !(kt3 < 0.0f);
+                    const bool shadow = L.mode == MODE_SHADOW;
+                    const f3 from = shadow ? L.lp : L.o;
+                    const float dz = distsq3(from, hit);
+                    const bool nearer = dz < L.best;
+                    if (inside && shadow && nearer) {                // a blocked shadow ray stops (Raytracer.cc:284)
+                        L.shadow_hit = true; L.cur = MI_END_LINK; L.sp = 0;
+                    }
+                    // candidates arrive in any order: lowest list position wins among equal distances
+                    if (inside && !shadow && (nearer || (dz == L.best && L.pj < L.btri))) {
+                        L.best = dz; L.btri = L.pj; L.hit = hit; L.k1 = kt1; L.k2 = kt2; L.k3 = kt3;
+                        L.limit = __builtin_sqrtf(dz) * 1.001f + L.delta;
+                    }
+                    L.pend = false;
+                }
+                {   // plane half of this step's triangle (Raytracer.cc:245-267)
+                    const int j = (int)(((tcur & MI_INDEX_MASK) - S.tri_base) >> 1);
+                    const f3 n = mk3(ta.x, ta.y, ta.z);
+                    const f3 fto = sub3(L.o, mk3(tb.x, tb.y, tb.z));
+                    const bool facing = (tcur & MI_TWOSIDED_BIT) != 0u || !(dot3(fto, n) < 0.f);
+                    const float k = dot3(n, L.d);
+                    const float sp = (tb.w - dot3(n, L.o)) / k;
+                    const bool cand = tri && j != L.avoid && facing && !(k == 0.0f) && !(sp <= 0.0f) && !(sp <= P.nudge);
+                    if (STATS && tri) { n_tris++; if (cand) n_plane++; }
+                    if (cand) {
+                        const float4 *e = S.tri_edge + (size_t)j * 3;
+                        L.pe1 = e[0]; L.pe2 = e[1]; L.pe3 = e[2];
+                        L.pj = j; L.ph = add3(mul3(L.d, sp), L.o); L.pend = true;
+                    }
+                }
+                MI_PHASE(pc_b);
             }
             const unsigned long long mDone = __ballot(alive && L.cur == MI_END_LINK && !L.pend);
             const unsigned long long mBusy = __ballot(alive && !(L.cur == MI_END_LINK && !L.pend));
@@ -743,13 +795,14 @@ k_raytrace(const DevScene S, const FrameParams P)
         if (lead) { atomicAdd(&P.counters[CS_NORMAL_RAYS], a); atomicAdd(&P.counters[CS_SHADOW_RAYS], b); }
         if (STATS) {
             const unsigned long long c = wsum(n_pops), d = wsum(n_ihits), e = wsum(n_tris), f = wsum(n_plane),
-                                     g = wsum(n_shaded);
+                                     g = wsum(n_shaded), sl = wsum(n_slow);
             if (lead) {
                 atomicAdd(&P.counters[CS_NODE_POPS], c); atomicAdd(&P.counters[CS_INNER_HITS], d);
                 atomicAdd(&P.counters[CS_TRI_TESTS], e); atomicAdd(&P.counters[CS_PLANE_PASS], f);
                 atomicAdd(&P.counters[CS_SHADED_HITS], g);
+                atomicAdd(&P.counters[CS_PROF0 + 15], sl);
                 const unsigned long long prof[15] = {pc_total, pc_refill, pc_trans, pc_a, pc_b, it_refill, ln_refill,
-                                                     it_trans, ln_trans, it_a, ln_a, it_b, ln_b, 1ull, 0ull};
+                                                     it_trans, ln_trans, it_a, ln_a, it_b, ln_b, 1ull, pc_wait};
                 for (int i = 0; i < 15; i++) atomicAdd(&P.counters[CS_PROF0 + i], prof[i]);
                 // 100 MHz real-time stamps: launch start (min), dispenser dry (min), last wave done (max)
                 atomicMin(&P.counters[CS_TIME0], rt0);
@@ -772,6 +825,7 @@ namespace {
 typedef void (*rt_kernel)(const DevScene, const FrameParams);
 rt_kernel pick_kernel(int stats, int exact, int ordered)
 {
+    if (ordered && stats) return exact ? k_raytrace<true, true, true> : k_raytrace<true, false, true>;
     if (ordered) return exact ? k_raytrace<false, true, true> : k_raytrace<false, false, true>;
     if (stats) return exact ? k_raytrace<true, true, false> : k_raytrace<true, false, false>;
     return exact ? k_raytrace<false, true, false> : k_raytrace<false, false, false>;
