@@ -201,8 +201,8 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     // tuning knobs (mi355_opts::tune, 0 = default)
     const int32_t *t = o->tune;
     const int flags = t[5];
-    P.xmin = t[0] > 0 ? (t[0] > 64 ? 64 : t[0]) : 24;
-    P.rmin = t[1] > 0 ? (t[1] > 64 ? 64 : t[1]) : 32;
+    P.xmin = t[0] > 0 ? (t[0] > 64 ? 64 : t[0]) : 16;
+    P.rmin = t[1] > 0 ? (t[1] > 64 ? 64 : t[1]) : 48;
     P.chunk = t[2] > 0 ? t[2] : 64;
     P.ref_order = (flags & 4) ? 1 : 0;
     P.prof_ordered = (flags & 8) ? 1 : 0;
