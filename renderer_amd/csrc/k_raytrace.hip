@@ -51,6 +51,8 @@ struct Lane {
     f3 dinv;               // ordered walk: delta * |inv|
     int sp;                // ordered walk: postponed children of this lane (the newest in `top`, the rest in LDS)
     uint32_t top;
+    int owner;             // LDS column (block-local thread index) of the pixel this lane works for: its own, or,
+                           // for a lane tracing another pixel's shadow rays, that pixel's
     int btri;              // closest triangle so far (leaf order), -1 = none
     f3 hit;
     float k1, k2, k3;      // kAB, kBC, kCA
@@ -219,9 +221,9 @@ MI_DEV void primary_ray(const FrameParams &P, const DevScene &S, Lane &L, int tr
 
 // Per-depth local colours live in LDS, one column per lane: lds[(depth*3 + channel)*256 + tid].
 // They are written once per shaded hit and read once per pixel, so they are not worth 12 VGPRs.
-MI_DEV void set_c(float *lds, int depth, float r, float g, float b)
+MI_DEV void set_c(float *lds, int col, int depth, float r, float g, float b)
 {
-    float *p = lds + depth * 3 * 256 + threadIdx.x;
+    float *p = lds + depth * 3 * 256 + col;
     p[0] = r; p[256] = g; p[512] = b;
 }
 
@@ -373,6 +375,13 @@ k_raytrace(const DevScene S, const FrameParams P)
     __shared__ float lds_col[MI_MAX_DEPTH * 3 * 256];
     // LDS (ordered walk only, sized at launch): per-lane stack of postponed children, one row per level
     extern __shared__ uint32_t lds_stack[];
+    // LDS (ordered walk): shadow rays handed to idle lanes of the same wave.  lds_pend[c] = shadow jobs of the
+    // pixel in column c that other lanes still owe; lds_don = scratch for matching givers with takers.
+    __shared__ uint32_t lds_pend[256];
+    __shared__ uint32_t lds_don[256];
+    lds_pend[threadIdx.x] = 0u;            // (a wave only ever touches its own 64 entries: no barrier needed)
+    const bool HELP = ORDERED && !P.no_help;
+    bool awaiting = false;      // this lane's ray tree is walked, but handed-out shadow jobs are still running
     Lane L;
     bool alive = false;         // lane owns a pixel
     bool want_pixel = true;     // lane needs a (new) pixel
@@ -386,7 +395,7 @@ k_raytrace(const DevScene S, const FrameParams P)
     L.shadow_hit = false; L.li = 0; L.cr = L.cg = L.cb = 0.f; L.k1 = L.k2 = L.k3 = 0.f;
     L.o = L.d = L.hit = L.pn = L.refl = L.lp = L.inv = L.ph = mk3(0.f, 0.f, 0.f);
     L.tame = false; L.pend = false; L.pj = -1;
-    L.limit = 0.f; L.delta = 0.f; L.dinv = mk3(0.f, 0.f, 0.f); L.sp = 0; L.top = MI_END_LINK;
+    L.limit = 0.f; L.delta = 0.f; L.dinv = mk3(0.f, 0.f, 0.f); L.sp = 0; L.top = MI_END_LINK; L.owner = (int)threadIdx.x;
     L.pe1 = L.pe2 = L.pe3 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     unsigned n_normal = 0, n_shadow = 0;
@@ -469,9 +478,11 @@ k_raytrace(const DevScene S, const FrameParams P)
         }
 
         // a lane's ray is complete when its walk has ended and no candidate is left to judge
-        const bool ray_done = alive && L.cur == MI_END_LINK && !L.pend;
+        // (a lane waiting for handed-out shadow jobs is neither walking nor ready)
+        const bool blocked = awaiting && lds_pend[threadIdx.x] != 0u;
+        const bool ray_done = alive && L.cur == MI_END_LINK && !L.pend && !blocked;
         const unsigned long long mX = __ballot(ray_done);
-        const unsigned long long mT = __ballot(alive && !ray_done);
+        const unsigned long long mT = __ballot(alive && !ray_done && !blocked);
         if (!mX && !mT) {
             if (!__ballot(want_pixel)) break;
             continue;
@@ -483,86 +494,132 @@ k_raytrace(const DevScene S, const FrameParams P)
             // ---------------- transitions ------------------------------------------------
             MI_PHASE(pc_refill);
             if (STATS) { it_trans++; ln_trans += __popcll(mX); }
+            const int self = (int)threadIdx.x;
+            bool finish = false;     // ray tree complete -> fold
+            bool lights = false;     // continue with light loop
+            bool offer = false;      // a fresh hit whose shadow rays another lane could trace
+            bool handed = false;     // ... and one took them
             if (ray_done) {
-                bool finish = false;     // ray tree complete -> fold
-                bool lights = false;     // continue with light loop
-                if (L.mode == MODE_CLOSEST) {
+                if (awaiting) { awaiting = false; finish = true; }          // every level's colour has arrived
+                else if (L.mode == MODE_CLOSEST) {
                     if (L.btri < 0) finish = true;                  // Raytracer.cc:327-331
                     else {
                         if (STATS) n_shaded++;
                         shade_begin(P, S, L);
                         lights = true;
+                        offer = HELP && P.use_shadows && P.n_lights > 0;
                     }
                 } else {
                     if (!L.shadow_hit) add_light(P, S, L);          // Raytracer.cc:458-466
                     L.li++;
                     lights = true;
                 }
-                if (lights) {
-                    bool launched = false;
-                    while (L.li < P.n_lights) {
-                        L.lp = mk3(P.light_pos[L.li][0], P.light_pos[L.li][1], P.light_pos[L.li][2]);
-                        if (P.use_shadows) {
-                            // shadow ray (Raytracer.cc:446-466)
-                            f3 ptl = sub3(L.lp, L.hit);
-                            float distSq = lensq3(ptl);
-                            L.d = div3(ptl, __builtin_sqrtf(distSq));
-                            L.o = L.hit;
-                            set_ray_aux(L, S.scene_mag);
-                            L.best = distsq3(L.o, L.lp);            // Raytracer.cc:209
-                            // a hit blocks when it is nearer to the light than the origin is, i.e. at a ray
-                            // parameter below twice the light's distance
-                            L.limit = 2.f * __builtin_sqrtf(L.best) * 1.001f + L.delta;
-                            L.mode = MODE_SHADOW;
-                            L.shadow_hit = false;
-                            begin_walk<ORDERED>(S, L, R, R2);
-                            L.avoid = L.btri;                       // avoidSelf = the triangle just hit (Raytracer.cc:335)
-                            n_shadow++;
-                            launched = true;
-                            break;
-                        }
-                        add_light(P, S, L);
-                        L.li++;
-                    }
-                    if (!launched) {
-                        // all lights done for this hit: store the level colour, bounce or finish
-                        set_c(lds_col, L.depth, L.cr, L.cg, L.cb);
-                        L.depth++;
-                        if (P.use_refl && L.depth < P.max_depth) {
-                            L.o = L.hit; L.d = L.refl; L.avoid = L.btri;
-                            set_ray_aux(L, S.scene_mag);
-                            L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
-                            begin_walk<ORDERED>(S, L, R, R2);
-                            n_normal++;
-                        } else finish = true;
+            }
+            // A pixel's shadow rays do not feed its reflection ray, only its colour (Raytracer.cc:440-521), and the
+            // frame lasts as long as its slowest pixel -- so a lane without a pixel takes over the light loop of
+            // a fresh hit (same operations, same order, result into the owner's LDS colour column) while the
+            // owner goes on with the reflection.
+            if (HELP) {
+                const unsigned long long mOffer = __ballot(offer), mIdle = __ballot(!alive);
+                if (mOffer && mIdle) {
+                    const int lane = self & 63, wbase = self & ~63;
+                    const int nO = __popcll(mOffer), nI = __popcll(mIdle);
+                    const int n = nO < nI ? nO : nI;
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    const bool give = offer && __popcll(mOffer & below) < n;
+                    const bool take = !alive && __popcll(mIdle & below) < n;
+                    if (give) lds_don[wbase + __popcll(mOffer & below)] = (uint32_t)lane;
+                    const int src = take ? (int)lds_don[wbase + __popcll(mIdle & below)] : lane;
+                    const float hx = __shfl(L.hit.x, src), hy = __shfl(L.hit.y, src), hz = __shfl(L.hit.z, src);
+                    const float nx = __shfl(L.pn.x, src), ny = __shfl(L.pn.y, src), nz = __shfl(L.pn.z, src);
+                    const float c0 = __shfl(L.cr, src), c1 = __shfl(L.cg, src), c2 = __shfl(L.cb, src);
+                    const int bt = __shfl(L.btri, src), dp = __shfl(L.depth, src);
+                    if (give) { atomicAdd(&lds_pend[self], 1u); handed = true; lights = false; }
+                    if (take) {
+                        L.hit = mk3(hx, hy, hz); L.pn = mk3(nx, ny, nz); L.cr = c0; L.cg = c1; L.cb = c2;
+                        L.btri = bt; L.depth = dp; L.li = 0; L.owner = wbase + src;
+                        L.pend = false; L.cur = MI_END_LINK;
+                        alive = true; want_pixel = false; lights = true;
                     }
                 }
-                if (finish) {
-                    // fold c[depth-1] ... c[0] (Raytracer.cc:538-551 with Types.h:137-142)
-                    float ar = 0.f, ag = 0.f, ab = 0.f;
-                    if (P.use_refl) { const f3 a = fold_levels(lds_col, L.depth, P.refl_rate); ar = a.x; ag = a.y; ab = a.z; }
-                    else if (L.depth > 0) { ar = lds_col[threadIdx.x]; ag = lds_col[256 + threadIdx.x]; ab = lds_col[512 + threadIdx.x]; }
-                    L.fb += ab; L.fg += ag; L.fr += ar;              // finalColor += ...
-                    if (L.samples_left > 0) {
-                        L.samples_left--;
-                        primary_ray(P, S, L, L.samples_left);
+            }
+            if (lights) {
+                bool launched = false;
+                while (L.li < P.n_lights) {
+                    L.lp = mk3(P.light_pos[L.li][0], P.light_pos[L.li][1], P.light_pos[L.li][2]);
+                    if (P.use_shadows) {
+                        // shadow ray (Raytracer.cc:446-466)
+                        f3 ptl = sub3(L.lp, L.hit);
+                        float distSq = lensq3(ptl);
+                        L.d = div3(ptl, __builtin_sqrtf(distSq));
+                        L.o = L.hit;
+                        set_ray_aux(L, S.scene_mag);
+                        L.best = distsq3(L.o, L.lp);            // Raytracer.cc:209
+                        // a hit blocks when it is nearer to the light than the origin is, i.e. at a ray
+                        // parameter below twice the light's distance
+                        L.limit = 2.f * __builtin_sqrtf(L.best) * 1.001f + L.delta;
+                        L.mode = MODE_SHADOW;
+                        L.shadow_hit = false;
                         begin_walk<ORDERED>(S, L, R, R2);
-                        n_normal++;
-                    } else {
-                        float r = L.fr, g = L.fg, b = L.fb;
-                        if (P.aa) { b = b / 4.f; g = g / 4.f; r = r / 4.f; }
-                        if (r > 255.0f) r = 255.0f;
-                        if (g > 255.0f) g = 255.0f;
-                        if (b > 255.0f) b = 255.0f;
-                        P.out[(size_t)L.orow * P.pitch_words + L.px] = pack_xrgb(r, g, b);
-                        if (P.outf) {
-                            float *q = P.outf + ((size_t)L.orow * P.W + L.px) * 3;
-                            q[0] = r; q[1] = g; q[2] = b;
-                        }
-                        alive = false;
-                        want_pixel = true;
-                        L.cur = MI_END_LINK;
+                        L.avoid = L.btri;                       // avoidSelf = the triangle just hit (Raytracer.cc:335)
+                        n_shadow++;
+                        launched = true;
+                        break;
                     }
+                    add_light(P, S, L);
+                    L.li++;
+                }
+                if (!launched) {
+                    // all lights done for this hit: store the level colour
+                    set_c(lds_col, L.owner, L.depth, L.cr, L.cg, L.cb);
+                    if (L.owner != self) {
+                        // ... of somebody else's pixel: report and go idle
+                        atomicSub(&lds_pend[L.owner], 1u);
+                        L.owner = self; L.cur = MI_END_LINK; L.mode = MODE_CLOSEST;
+                        alive = false; want_pixel = true;
+                    } else handed = true;                       // ... of our own: bounce or finish below
+                }
+            }
+            if (handed) {
+                L.depth++;
+                if (P.use_refl && L.depth < P.max_depth) {
+                    L.o = L.hit; L.d = L.refl; L.avoid = L.btri;
+                    set_ray_aux(L, S.scene_mag);
+                    L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
+                    begin_walk<ORDERED>(S, L, R, R2);
+                    n_normal++;
+                } else finish = true;
+            }
+            if (finish && HELP && lds_pend[self] != 0u) {
+                // the tree is walked but a level's colour is still being worked out by another lane
+                awaiting = true; finish = false;
+                L.cur = MI_END_LINK; L.pend = false; L.mode = MODE_CLOSEST;
+            }
+            if (finish) {
+                // fold c[depth-1] ... c[0] (Raytracer.cc:538-551 with Types.h:137-142)
+                float ar = 0.f, ag = 0.f, ab = 0.f;
+                if (P.use_refl) { const f3 a = fold_levels(lds_col, L.depth, P.refl_rate); ar = a.x; ag = a.y; ab = a.z; }
+                else if (L.depth > 0) { ar = lds_col[threadIdx.x]; ag = lds_col[256 + threadIdx.x]; ab = lds_col[512 + threadIdx.x]; }
+                L.fb += ab; L.fg += ag; L.fr += ar;              // finalColor += ...
+                if (L.samples_left > 0) {
+                    L.samples_left--;
+                    primary_ray(P, S, L, L.samples_left);
+                    begin_walk<ORDERED>(S, L, R, R2);
+                    n_normal++;
+                } else {
+                    float r = L.fr, g = L.fg, b = L.fb;
+                    if (P.aa) { b = b / 4.f; g = g / 4.f; r = r / 4.f; }
+                    if (r > 255.0f) r = 255.0f;
+                    if (g > 255.0f) g = 255.0f;
+                    if (b > 255.0f) b = 255.0f;
+                    P.out[(size_t)L.orow * P.pitch_words + L.px] = pack_xrgb(r, g, b);
+                    if (P.outf) {
+                        float *q = P.outf + ((size_t)L.orow * P.W + L.px) * 3;
+                        q[0] = r; q[1] = g; q[2] = b;
+                    }
+                    alive = false;
+                    want_pixel = true;
+                    L.cur = MI_END_LINK;
                 }
             }
             MI_PHASE(pc_trans);
@@ -699,7 +756,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                 }
                 MI_PHASE(pc_b);
             }
-            const unsigned long long mDone = __ballot(alive && L.cur == MI_END_LINK && !L.pend);
+            const unsigned long long mDone = __ballot(alive && L.cur == MI_END_LINK && !L.pend && !awaiting);
             const unsigned long long mBusy = __ballot(alive && !(L.cur == MI_END_LINK && !L.pend));
             if (!mBusy || __popcll(mDone) >= xmin_now) break;
         }
@@ -771,7 +828,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                 }
             }
             if (mL) MI_PHASE(pc_b);
-            const unsigned long long mDone = __ballot(alive && L.cur == MI_END_LINK && !L.pend);
+            const unsigned long long mDone = __ballot(alive && L.cur == MI_END_LINK && !L.pend && !awaiting);
             const unsigned long long mBusy = __ballot(alive && !(L.cur == MI_END_LINK && !L.pend));
             if (!mBusy || __popcll(mDone) >= xmin_now) break;
         }
