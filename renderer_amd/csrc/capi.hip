@@ -433,6 +433,12 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipSt
         const int ordered = ((!stats || P.prof_ordered) && !P.ref_order && c->dev.ordered_ok) ? 1 : 0;
         int per_cu = mi355i_raytrace_blocks_per_cu(stats, P.exact_box, ordered, (int)c->dev.stack_depth);
         if (P.blocks_per_cu > 0 && P.blocks_per_cu < per_cu) per_cu = P.blocks_per_cu;
+        else if (P.blocks_per_cu == 0 && per_cu > 2) {
+            // A third wave per SIMD pays when the frame is long enough to be throughput bound (4K, 4 spp: +10 %);
+            // a 1080p frame is bound by its slowest tiles and runs faster with two (measured, profiles/).
+            const long long tiles = (((long long)P.W + 7) / 8) * (((long long)P.n_rows + 7) / 8) * (P.aa ? 4 : 1);
+            if (tiles < 20ll * per_cu * c->n_cus * 4) per_cu = 2;
+        }
         int n_blocks = per_cu * c->n_cus;
         const long long lanes_needed = ((long long)P.W * P.n_rows + 255) / 256;
         if (n_blocks > lanes_needed) n_blocks = (int)(lanes_needed > 0 ? lanes_needed : 1);

@@ -368,7 +368,7 @@ MI_DEV bool tri_edge_test(Lane &L)
 } // namespace
 
 template <bool STATS, bool EXACT_BOX, bool ORDERED>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_raytrace(const DevScene S, const FrameParams P)
 {
     // LDS: per-lane colour columns of the ray tree's depth levels
