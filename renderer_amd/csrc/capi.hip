@@ -92,7 +92,8 @@ struct mi355_ctx {
     bool has_bvh = false;
     // device
     DevBuf walk, tri_edge, tri_shade, rs_tri, rs_col, rs_idx, rs_vert;
-    DevBuf ctrl;            // [0] work counter (16 B) | counters[CS_COUNT]
+    DevBuf ctrl;            // [0] (16 B, unused) | counters[CS_COUNT]
+    DevBuf dispenser;       // raytrace pixel dispenser: MI_DISPENSERS counters, MI_DISPENSER_STRIDE words apart
     DevBuf fb, fbf;         // internal framebuffer for the host-output path
     DevBuf tile_order;      // raytrace dispenser order (ensure_tile_order)
     DevBuf wave_prof;       // per-wave phase profile of counting launches (debug)
@@ -196,7 +197,7 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.out = (uint32_t *)d_out;
     P.pitch_words = pitch_bytes / 4;
     P.outf = (float *)d_outf;
-    P.work_counter = (uint32_t *)c->ctrl.p;
+    P.work_counter = (uint32_t *)c->dispenser.p;
     P.counters = (unsigned long long *)((char *)c->ctrl.p + 16);
     // tuning knobs (mi355_opts::tune, 0 = default)
     const int32_t *t = o->tune;
@@ -210,7 +211,7 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.blocks_per_cu = t[4] > 0 ? t[4] : 0;
     P.exact_box = (flags & 1) ? 1 : 0;
     if (!c->boxes_tame) P.exact_box = 1;     // box coordinates outside the filtered test's validated range
-    P.scatter = (flags & 16) ? 1 : 0;
+    P.scatter = 0;      // flag 16 is reserved
     P.wave_prof = nullptr;
     if (o->collect_stats) {
         if (c->wave_prof.ensure((size_t)8 * c->n_cus * 4 * 16 * 8) == hipSuccess) P.wave_prof = (unsigned long long *)c->wave_prof.p;
@@ -444,6 +445,7 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipSt
         if (n_blocks > lanes_needed) n_blocks = (int)(lanes_needed > 0 ? lanes_needed : 1);
         c->last_blocks = n_blocks;
         if (P.wave_prof) HIP_TRY(hipMemsetAsync(c->wave_prof.p, 0, (size_t)n_blocks * 4 * 16 * 8, st), -40);
+        HIP_TRY(hipMemsetAsync(c->dispenser.p, 0, (size_t)MI_DISPENSERS * MI_DISPENSER_STRIDE * 4, st), -40);
         e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, n_blocks, st);
         break;
     }
@@ -545,6 +547,7 @@ mi355_ctx *mi355_scene_create(const mi355_scene_desc *d, int device)
     if ((e = c->rs_vert.upload(rs_vert)) != hipSuccess) return bail("upload", e);
     if ((e = c->ctrl.ensure(16 + sizeof(unsigned long long) * CS_COUNT)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(c->ctrl.p, 0, c->ctrl.bytes)) != hipSuccess) return bail("hipMemset", e);
+    if ((e = c->dispenser.ensure((size_t)MI_DISPENSERS * MI_DISPENSER_STRIDE * 4)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipStreamCreate(&c->stream)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
@@ -563,7 +566,7 @@ void mi355_scene_destroy(mi355_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->walk, &c->tri_edge, &c->tri_shade, &c->rs_tri, &c->rs_col, &c->rs_idx,
-                      &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->tile_order, &c->wave_prof})
+                      &c->rs_vert, &c->ctrl, &c->dispenser, &c->fb, &c->fbf, &c->tile_order, &c->wave_prof})
         b->release();
     for (auto &m : c->smap) m.release();
     if (c->rscratch) mi355i_raster_scratch_destroy(c->rscratch);

@@ -28,6 +28,12 @@
 #define MI_VROOT_LINK 0x1ffffff0u   // L.cur of a lane sitting on the virtual record above the root (ordered walk)
 #define MI_MAX_STACK 48             // deepest tree the ordered walk accepts (LDS: 1 KB per level per block)
 
+// The pixel dispenser is split into one counter per XCD-sized share of the tile order (tile slot s belongs
+// to counter s % MI_DISPENSERS): a single device-wide atomic counter serialises at ~8-10 ns per grab, which
+// at one grab per 8x8 tile is a quarter of a 1080p frame.
+#define MI_DISPENSERS 8
+#define MI_DISPENSER_STRIDE 1024u
+
 #define MI_MAX_LIGHTS 4
 #define MI_MAX_DEPTH 4
 
@@ -90,7 +96,7 @@ struct FrameParams {
     int32_t pitch_words;
     float *outf;               // optional r,g,b floats (raytrace)
     unsigned long long *counters; // device counters (see CounterSlot)
-    uint32_t *work_counter;    // persistent-kernel pixel dispenser
+    uint32_t *work_counter;    // persistent-kernel pixel dispenser: MI_DISPENSERS counters, MI_DISPENSER_STRIDE words apart
     int32_t xmin;              // service state transitions once this many lanes wait (or nobody traverses)
     int32_t rmin;              // refill once this many lanes are idle (or nobody is alive)
     int32_t chunk;             // pixel indices a wave takes from the dispenser at a time
@@ -98,7 +104,7 @@ struct FrameParams {
     int32_t ref_order;         // walk in the reference's fixed left-first order even when the ordered walk is available
     int32_t no_help;           // ordered walk: never hand shadow rays to idle lanes
     int32_t prof_ordered;      // counting frames profile the ordered walk instead of reproducing the reference's counters
-    int32_t scatter;           // dispenser hands out pixel slot s of every tile before slot s+1 (load balance)
+    int32_t scatter;           // reserved (was: scattered pixel dispensing)
     unsigned long long *wave_prof; // counting builds: 16 words of phase profile per wave (debug), or NULL
     const uint32_t *tile_order; // dispenser index -> 8x8 tile id (heavy tiles first), or NULL = row-major
     int32_t blocks_per_cu;     // 0 = occupancy query

@@ -389,7 +389,10 @@ k_raytrace(const DevScene S, const FrameParams P)
     Rec R;                      // record of the node this lane visits next
     Rec R2;                     // ordered walk: second half of a wide record (the right child's box)
     R.a = R.b = R2.a = R2.b = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t pool_next = 0, pool_end = 0;   // wave-local pixel pool (wave-uniform)
+    uint32_t pool_next = 0, pool_end = 0;   // wave-local pixel pool (wave-uniform): local indices of share pool_share
+    uint32_t pool_share = 0;
+    uint32_t share = blockIdx.x % MI_DISPENSERS;   // the share this wave draws from (consecutive blocks sit on different XCDs)
+    uint32_t dry_shares = 0;
     L.cur = MI_END_LINK; L.mode = MODE_CLOSEST; L.btri = -1; L.depth = 0; L.samples_left = 0;
     L.fr = L.fg = L.fb = 0.f; L.px = L.py = L.orow = 0; L.avoid = -1; L.best = 0.f;
     L.shadow_hit = false; L.li = 0; L.cr = L.cg = L.cb = 0.f; L.k1 = L.k2 = L.k3 = 0.f;
@@ -431,15 +434,26 @@ k_raytrace(const DevScene S, const FrameParams P)
                     const int lane = (int)(threadIdx.x & 63u);
                     if (STATS) { it_refill++; ln_refill += nW; }
                     if (pool_next == pool_end && !exhausted) {
-                        uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(P.work_counter, (uint32_t)P.chunk);
-                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                        if (base >= total) { exhausted = true; if (STATS && !rt_dry) rt_dry = __builtin_amdgcn_s_memrealtime(); }
-                        else {
-                            pool_next = base;
-                            pool_end = base + (uint32_t)P.chunk;
-                            if (pool_end > total) pool_end = total;
+                        // take the next chunk of this wave's share of the tile order; when that share is used up,
+                        // help with the others
+                        bool got = false;
+                        for (int tries = 0; tries < MI_DISPENSERS && !got; tries++) {
+                            if (dry_shares & (1u << share)) { share = (share + 1u) % MI_DISPENSERS; continue; }
+                            // tile slots share, share + 8, share + 16, ... ; local index k -> slot (k >> 6) * 8 + share
+                            const uint32_t n_slots = (n_tiles + (MI_DISPENSERS - 1u) - share) / MI_DISPENSERS;
+                            uint32_t base = 0;
+                            if (lane == 0) base = atomicAdd(P.work_counter + share * MI_DISPENSER_STRIDE, (uint32_t)P.chunk);
+                            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                            if (base >= n_slots * 64u) { dry_shares |= 1u << share; share = (share + 1u) % MI_DISPENSERS; }
+                            else {
+                                pool_next = base;
+                                pool_end = base + (uint32_t)P.chunk;
+                                if (pool_end > n_slots * 64u) pool_end = n_slots * 64u;
+                                pool_share = share;
+                                got = true;
+                            }
                         }
+                        if (!got) { exhausted = true; if (STATS && !rt_dry) rt_dry = __builtin_amdgcn_s_memrealtime(); }
                     }
                     const uint32_t avail = pool_end - pool_next;
                     if (avail == 0) {
@@ -449,11 +463,8 @@ k_raytrace(const DevScene S, const FrameParams P)
                             const uint32_t rank = (uint32_t)__popcll(mW & ((1ull << lane) - 1ull));
                             if (rank < avail) {
                                 const uint32_t idx = pool_next + rank;
-                                // index -> (tile, pixel in tile); optionally scattered (pixel slot s of every tile
-                                // before slot s+1), which balances better but loses ray coherence
-                                uint32_t tslot, sub;
-                                if (P.scatter) { tslot = idx % n_tiles; sub = idx / n_tiles; }
-                                else { tslot = idx >> 6; sub = idx & 63u; }
+                                // local index -> (tile slot, pixel in tile)
+                                const uint32_t tslot = (idx >> 6) * MI_DISPENSERS + pool_share, sub = idx & 63u;
                                 const uint32_t tile = P.tile_order ? P.tile_order[tslot] : tslot;
                                 const int tx = (int)(tile % (uint32_t)tiles_x), ty = (int)(tile / (uint32_t)tiles_x);
                                 const int x = (tx << 3) + (int)(sub & 7u), r = (ty << 3) + (int)(sub >> 3);
