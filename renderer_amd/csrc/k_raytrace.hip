@@ -147,13 +147,15 @@ MI_DEV bool ray_box_fast(const f3 o, const f3 inv, const float4 lo, const float4
 }
 
 // The same filtered test for the ordered walk, which also needs (for a tame ray)
-//   key : a lower bound of Tnear, used only to pick the child to enter first (any order is correct),
-//   cull: a lower bound of the ray parameter at which the ray enters the box GROWN by L.delta on every
+//   key  : a lower bound of Tnear, used only to pick the child to enter first (any order is correct),
+//   near_g / far_g : a lower bound of Tnear and an upper bound of Tfar for the box GROWN by L.delta on every
 //         side.  A hit the reference accepts in a triangle below this box lies in the grown box (the
 //         triangle is inside the box, capi.hip checks it; the computed hit point is within rounding of the
-//         triangle), and directions are unit vectors, so its distance from the origin is at least `cull`.
+//         triangle and of the ray), and directions are unit vectors, so its distance from the origin is at
+//         least near_g -- and if near_g > far_g or far_g < 0 the ray misses the grown box and no triangle
+//         below it can be hit at all.
 MI_DEV bool ray_box_fast_ordered(const f3 o, const f3 inv, const f3 dinv, const float4 lo, const float4 hi, bool &sure,
-                                 float &key, float &cull)
+                                 float &key, float &near_g, float &far_g)
 {
     const float E = 1e-6f;
     const float x1 = (lo.x - o.x) * inv.x, x2 = (hi.x - o.x) * inv.x;
@@ -164,18 +166,20 @@ MI_DEV bool ray_box_fast_ordered(const f3 o, const f3 inv, const f3 dinv, const 
     const float za = __builtin_fminf(z1, z2), zb = __builtin_fmaxf(z1, z2);
     const float xl = __builtin_fmaf(-E, __builtin_fabsf(xa), xa), yl = __builtin_fmaf(-E, __builtin_fabsf(ya), ya),
                 zl = __builtin_fmaf(-E, __builtin_fabsf(za), za);
+    const float xh = __builtin_fmaf(E, __builtin_fabsf(xb), xb), yh = __builtin_fmaf(E, __builtin_fabsf(yb), yb),
+                zh = __builtin_fmaf(E, __builtin_fabsf(zb), zb);
     const float tn_lo = __builtin_fmaxf(__builtin_fmaxf(xl, yl), zl);
     const float tn_hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(E, __builtin_fabsf(xa), xa), __builtin_fmaf(E, __builtin_fabsf(ya), ya)),
                                         __builtin_fmaf(E, __builtin_fabsf(za), za));
     const float tf_lo = __builtin_fminf(__builtin_fminf(__builtin_fmaf(-E, __builtin_fabsf(xb), xb), __builtin_fmaf(-E, __builtin_fabsf(yb), yb)),
                                         __builtin_fmaf(-E, __builtin_fabsf(zb), zb));
-    const float tf_hi = __builtin_fminf(__builtin_fminf(__builtin_fmaf(E, __builtin_fabsf(xb), xb), __builtin_fmaf(E, __builtin_fabsf(yb), yb)),
-                                        __builtin_fmaf(E, __builtin_fabsf(zb), zb));
+    const float tf_hi = __builtin_fminf(__builtin_fminf(xh, yh), zh);
     const bool pass = (tn_hi <= tf_lo) && (tf_lo >= 0.f);
     const bool fail = (tn_lo > tf_hi) || (tf_hi < 0.f);
     sure = pass || fail;
     key = tn_lo;
-    cull = __builtin_fmaxf(__builtin_fmaxf(xl - dinv.x, yl - dinv.y), zl - dinv.z);
+    near_g = __builtin_fmaxf(__builtin_fmaxf(xl - dinv.x, yl - dinv.y), zl - dinv.z);
+    far_g = __builtin_fminf(__builtin_fminf(xh + dinv.x, yh + dinv.y), zh + dinv.z);
     return pass;
 }
 
@@ -666,21 +670,29 @@ k_raytrace(const DevScene S, const FrameParams P)
                     const uint32_t linkL = __float_as_uint(R.a.w), linkR = __float_as_uint(R.b.w);
                     bool hL, hR;
                     float kL = 0.f, kR = 0.f;
+                    // The reference tests a node's box when it pops that node, and only if it is an inner node
+                    // (Raytracer.cc:222-230): a LEAF is entered whenever its parent's box was hit.  So the exact
+                    // predicate decides inner children; a leaf child is entered unless the ray certainly misses
+                    // its grown box (then none of its triangles can be hit).  Both are then subject to the
+                    // distance cull.
+                    const bool leafL = (linkL & MI_LEAF_BIT) != 0u, leafR = (linkR & MI_LEAF_BIT) != 0u;
                     if (EXACT_BOX) {
-                        hL = ray_box_exact(L.o, L.d, R.a, R.b);
-                        hR = ray_box_exact(L.o, L.d, R2.a, R2.b);
+                        hL = leafL || ray_box_exact(L.o, L.d, R.a, R.b);
+                        hR = leafR || ray_box_exact(L.o, L.d, R2.a, R2.b);
                     } else {
                         bool sL, sR;
-                        float cL, cR;
-                        hL = ray_box_fast_ordered(L.o, L.inv, L.dinv, R.a, R.b, sL, kL, cL);
-                        hR = ray_box_fast_ordered(L.o, L.inv, L.dinv, R2.a, R2.b, sR, kR, cR);
-                        if (__builtin_expect(!(sL && sR && L.tame), 0)) {
+                        float nL, nR, fL, fR;
+                        hL = ray_box_fast_ordered(L.o, L.inv, L.dinv, R.a, R.b, sL, kL, nL, fL);
+                        hR = ray_box_fast_ordered(L.o, L.inv, L.dinv, R2.a, R2.b, sR, kR, nR, fR);
+                        if (__builtin_expect(!((sL || leafL) && (sR || leafR) && L.tame), 0)) {
                             if (STATS) n_slow++;
-                            hL = ray_box_exact(L.o, L.d, R.a, R.b);
-                            hR = ray_box_exact(L.o, L.d, R2.a, R2.b);
+                            hL = leafL || ray_box_exact(L.o, L.d, R.a, R.b);
+                            hR = leafR || ray_box_exact(L.o, L.d, R2.a, R2.b);
                         } else {
-                            hL = hL && !(cL > L.limit);
-                            hR = hR && !(cR > L.limit);
+                            if (leafL) hL = !(nL > fL) && !(fL < 0.f);
+                            if (leafR) hR = !(nR > fR) && !(fR < 0.f);
+                            hL = hL && !(nL > L.limit);
+                            hR = hR && !(nR > L.limit);
                         }
                     }
                     hR = hR && linkR != MI_END_LINK;                // the virtual record above the root has one child

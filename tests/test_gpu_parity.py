@@ -140,6 +140,22 @@ def test_unchecked_tree_falls_back_to_reference_order(oracle, oracle_scene):
     assert s.walk_info()[0] == 1
     ro = R.default_opts(320, 180, tune=dict(reforder=1))
     assert (s.render(9, cam, lights, n, o)[0] == s.render(9, cam, lights, n, ro)[0]).all()
+    # The reference never looks at a LEAF's box (Raytracer.cc:222-230 tests the popped node's own box, inner nodes
+    # only), so whatever a tree says there must not change a pixel: larger leaf boxes keep the ordered walk (which
+    # may use them only as a conservative filter), meaningless ones send the tree to the reference-order walk.
+    leaf = ~inner
+    big_leaves = nodes.copy()
+    bf = big_leaves[:, :6].view(np.float32)
+    bf[leaf, :3] -= 0.05
+    bf[leaf, 3:] += 0.05
+    s.set_bvh_arrays(big_leaves, idx)
+    assert s.walk_info()[0] == 1
+    assert (s.render(9, cam, lights, n, o)[0] == ref).all()
+    no_leaves = nodes.copy()
+    no_leaves[leaf, :6] = 0
+    s.set_bvh_arrays(no_leaves, idx)
+    assert s.walk_info()[0] == 0
+    assert (s.render(9, cam, lights, n, o)[0] == ref).all()
     shrunk = nodes.copy()
     sf = shrunk[:, :6].view(np.float32)
     mid = 0.5 * (f[:, :3] + f[:, 3:])
