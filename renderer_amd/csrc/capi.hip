@@ -17,8 +17,8 @@
 #include <vector>
 
 // kernel launchers (defined next to their kernels)
-extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int stack_depth);
-extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int ordered, int n_blocks,
+extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves3, int stack_depth);
+extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int ordered, int waves3, int n_blocks,
                                              hipStream_t);
 extern "C" hipError_t mi355i_launch_points(const DevScene *, const FrameParams *, int as_triangles, hipStream_t);
 struct RasterScratch;
@@ -80,6 +80,11 @@ inline float disth(V3h a, V3h b) { float dx = a.x - b.x, dy = a.y - b.y, dz = a.
 
 } // namespace
 
+// layout of mi355_ctx::ctrl
+static const size_t MI_CTRL_DISPENSER_OFF = 4096;
+static const size_t MI_CTRL_BYTES = MI_CTRL_DISPENSER_OFF + (size_t)MI_DISPENSERS * MI_DISPENSER_STRIDE * 4;
+static_assert(16 + sizeof(unsigned long long) * CS_COUNT <= MI_CTRL_DISPENSER_OFF, "counters overlap the dispenser");
+
 struct mi355_ctx {
     int device = 0;
     int n_cus = 256;
@@ -92,8 +97,8 @@ struct mi355_ctx {
     bool has_bvh = false;
     // device
     DevBuf walk, tri_edge, tri_shade, rs_tri, rs_col, rs_idx, rs_vert;
-    DevBuf ctrl;            // [0] (16 B, unused) | counters[CS_COUNT]
-    DevBuf dispenser;       // raytrace pixel dispenser: MI_DISPENSERS counters, MI_DISPENSER_STRIDE words apart
+    DevBuf ctrl;            // [0] (16 B, unused) | counters[CS_COUNT] | at MI_CTRL_DISPENSER_OFF: the raytrace pixel
+                            // dispenser (MI_DISPENSERS counters, MI_DISPENSER_STRIDE words apart) -- one memset per frame
     DevBuf fb, fbf;         // internal framebuffer for the host-output path
     DevBuf tile_order;      // raytrace dispenser order (ensure_tile_order)
     DevBuf wave_prof;       // per-wave phase profile of counting launches (debug)
@@ -197,7 +202,7 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.out = (uint32_t *)d_out;
     P.pitch_words = pitch_bytes / 4;
     P.outf = (float *)d_outf;
-    P.work_counter = (uint32_t *)c->dispenser.p;
+    P.work_counter = (uint32_t *)((char *)c->ctrl.p + MI_CTRL_DISPENSER_OFF);
     P.counters = (unsigned long long *)((char *)c->ctrl.p + 16);
     // tuning knobs (mi355_opts::tune, 0 = default)
     const int32_t *t = o->tune;
@@ -417,7 +422,9 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
 
 int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipStream_t st)
 {
-    HIP_TRY(hipMemsetAsync(c->ctrl.p, 0, 16 + sizeof(unsigned long long) * CS_COUNT, st), -40);
+    // raytrace frames also reset the pixel dispenser behind the counters (same memset)
+    const bool rt = mode == MI355_MODE_RAYTRACE || mode == MI355_MODE_RAYTRACE_ANTIALIAS;
+    HIP_TRY(hipMemsetAsync(c->ctrl.p, 0, rt ? MI_CTRL_BYTES : 16 + sizeof(unsigned long long) * CS_COUNT, st), -40);
     if (stats)   // the two "min" time stamps start at all-ones
         HIP_TRY(hipMemsetAsync((char *)c->ctrl.p + 16 + sizeof(unsigned long long) * CS_TIME0, 0xff, 2 * sizeof(unsigned long long), st), -40);
     c->last_stats = stats != 0;
@@ -432,21 +439,21 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipSt
     case MI355_MODE_RAYTRACE: case MI355_MODE_RAYTRACE_ANTIALIAS: {
         if (!c->has_bvh) return fail(-41, "raytrace modes need mi355_scene_set_bvh first");
         const int ordered = ((!stats || P.prof_ordered) && !P.ref_order && c->dev.ordered_ok) ? 1 : 0;
-        int per_cu = mi355i_raytrace_blocks_per_cu(stats, P.exact_box, ordered, (int)c->dev.stack_depth);
+        // A third wave per SIMD pays when the frame is long enough to be throughput bound (4K, 4 spp: +10 %); a 1080p
+        // frame is bound by its slowest tiles and runs faster with two (measured, profiles/).  The three-wave build
+        // spills some transition state, so it is only used when three blocks per CU are wanted.
+        const long long work_tiles = (((long long)P.W + 7) / 8) * (((long long)P.n_rows + 7) / 8) * (P.aa ? 4 : 1);
+        int waves3 = 0;
+        if (ordered && !stats && (P.blocks_per_cu == 0 ? work_tiles >= 20ll * 3 * c->n_cus * 4 : P.blocks_per_cu >= 3))
+            waves3 = mi355i_raytrace_blocks_per_cu(0, P.exact_box, 1, 1, (int)c->dev.stack_depth) >= 3 ? 1 : 0;
+        int per_cu = mi355i_raytrace_blocks_per_cu(stats, P.exact_box, ordered, waves3, (int)c->dev.stack_depth);
         if (P.blocks_per_cu > 0 && P.blocks_per_cu < per_cu) per_cu = P.blocks_per_cu;
-        else if (P.blocks_per_cu == 0 && per_cu > 2) {
-            // A third wave per SIMD pays when the frame is long enough to be throughput bound (4K, 4 spp: +10 %);
-            // a 1080p frame is bound by its slowest tiles and runs faster with two (measured, profiles/).
-            const long long tiles = (((long long)P.W + 7) / 8) * (((long long)P.n_rows + 7) / 8) * (P.aa ? 4 : 1);
-            if (tiles < 20ll * per_cu * c->n_cus * 4) per_cu = 2;
-        }
         int n_blocks = per_cu * c->n_cus;
         const long long lanes_needed = ((long long)P.W * P.n_rows + 255) / 256;
         if (n_blocks > lanes_needed) n_blocks = (int)(lanes_needed > 0 ? lanes_needed : 1);
         c->last_blocks = n_blocks;
         if (P.wave_prof) HIP_TRY(hipMemsetAsync(c->wave_prof.p, 0, (size_t)n_blocks * 4 * 16 * 8, st), -40);
-        HIP_TRY(hipMemsetAsync(c->dispenser.p, 0, (size_t)MI_DISPENSERS * MI_DISPENSER_STRIDE * 4, st), -40);
-        e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, n_blocks, st);
+        e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, waves3, n_blocks, st);
         break;
     }
     case MI355_MODE_LINES:
@@ -545,9 +552,8 @@ mi355_ctx *mi355_scene_create(const mi355_scene_desc *d, int device)
     if ((e = c->rs_col.upload(rs_col)) != hipSuccess) return bail("upload", e);
     if ((e = c->rs_idx.upload(rs_idx)) != hipSuccess) return bail("upload", e);
     if ((e = c->rs_vert.upload(rs_vert)) != hipSuccess) return bail("upload", e);
-    if ((e = c->ctrl.ensure(16 + sizeof(unsigned long long) * CS_COUNT)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = c->ctrl.ensure(MI_CTRL_BYTES)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(c->ctrl.p, 0, c->ctrl.bytes)) != hipSuccess) return bail("hipMemset", e);
-    if ((e = c->dispenser.ensure((size_t)MI_DISPENSERS * MI_DISPENSER_STRIDE * 4)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipStreamCreate(&c->stream)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
@@ -566,7 +572,7 @@ void mi355_scene_destroy(mi355_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->walk, &c->tri_edge, &c->tri_shade, &c->rs_tri, &c->rs_col, &c->rs_idx,
-                      &c->rs_vert, &c->ctrl, &c->dispenser, &c->fb, &c->fbf, &c->tile_order, &c->wave_prof})
+                      &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->tile_order, &c->wave_prof})
         b->release();
     for (auto &m : c->smap) m.release();
     if (c->rscratch) mi355i_raster_scratch_destroy(c->rscratch);

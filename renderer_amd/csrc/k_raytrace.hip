@@ -371,8 +371,10 @@ MI_DEV bool tri_edge_test(Lane &L)
 
 } // namespace
 
-template <bool STATS, bool EXACT_BOX, bool ORDERED>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+// WAVES = wavefronts per SIMD the register allocation aims at: 2 keeps everything in registers (1080p frames run
+// two blocks per CU anyway), 3 spills a little transition state to scratch and pays off on long frames.
+template <bool STATS, bool EXACT_BOX, bool ORDERED, int WAVES>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 k_raytrace(const DevScene S, const FrameParams P)
 {
     // LDS: per-lane colour columns of the ray tree's depth levels
@@ -903,33 +905,35 @@ k_raytrace(const DevScene S, const FrameParams P)
 // ---- launch helper (called from capi.hip) ------------------------------------------------
 namespace {
 typedef void (*rt_kernel)(const DevScene, const FrameParams);
-rt_kernel pick_kernel(int stats, int exact, int ordered)
+rt_kernel pick_kernel(int stats, int exact, int ordered, int waves3)
 {
-    if (ordered && stats) return exact ? k_raytrace<true, true, true> : k_raytrace<true, false, true>;
-    if (ordered) return exact ? k_raytrace<false, true, true> : k_raytrace<false, false, true>;
-    if (stats) return exact ? k_raytrace<true, true, false> : k_raytrace<true, false, false>;
-    return exact ? k_raytrace<false, true, false> : k_raytrace<false, false, false>;
+    if (ordered && stats) return exact ? k_raytrace<true, true, true, 2> : k_raytrace<true, false, true, 2>;
+    if (ordered && waves3) return exact ? k_raytrace<false, true, true, 3> : k_raytrace<false, false, true, 3>;
+    if (ordered) return exact ? k_raytrace<false, true, true, 2> : k_raytrace<false, false, true, 2>;
+    if (stats) return exact ? k_raytrace<true, true, false, 2> : k_raytrace<true, false, false, 2>;
+    return exact ? k_raytrace<false, true, false, 2> : k_raytrace<false, false, false, 2>;
 }
 size_t stack_bytes(int ordered, int stack_depth) { return ordered ? (size_t)stack_depth * 256u * sizeof(uint32_t) : 0u; }
 } // namespace
 
-extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int stack_depth)
+// blocks per CU the (stats, exact, ordered, waves3) variant can hold
+extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves3, int stack_depth)
 {
-    static int cache[2][2][2][MI_MAX_STACK + 1];        // 0 = not asked yet
+    static int cache[2][2][2][2][MI_MAX_STACK + 1];        // 0 = not asked yet
     if (stack_depth < 0 || stack_depth > MI_MAX_STACK) stack_depth = MI_MAX_STACK;
-    int &slot = cache[stats ? 1 : 0][exact ? 1 : 0][ordered ? 1 : 0][ordered ? stack_depth : 0];
+    int &slot = cache[stats ? 1 : 0][exact ? 1 : 0][ordered ? 1 : 0][waves3 ? 1 : 0][ordered ? stack_depth : 0];
     if (!slot) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_kernel(stats, exact, ordered), 256, stack_bytes(ordered, stack_depth)) != hipSuccess || nb < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_kernel(stats, exact, ordered, waves3), 256, stack_bytes(ordered, stack_depth)) != hipSuccess || nb < 1)
             nb = 2;
         slot = nb > 8 ? 8 : nb;
     }
     return slot;
 }
 
-extern "C" hipError_t mi355i_launch_raytrace(const DevScene *S, const FrameParams *P, int stats, int exact, int ordered, int n_blocks,
-                                             hipStream_t st)
+extern "C" hipError_t mi355i_launch_raytrace(const DevScene *S, const FrameParams *P, int stats, int exact, int ordered, int waves3,
+                                             int n_blocks, hipStream_t st)
 {
-    hipLaunchKernelGGL(pick_kernel(stats, exact, ordered), dim3(n_blocks), dim3(256), stack_bytes(ordered, (int)S->stack_depth), st, *S, *P);
+    hipLaunchKernelGGL(pick_kernel(stats, exact, ordered, waves3), dim3(n_blocks), dim3(256), stack_bytes(ordered, (int)S->stack_depth), st, *S, *P);
     return hipGetLastError();
 }
