@@ -163,8 +163,8 @@ def default_opts(width: int, height: int, **kw) -> Opts:
 
 def tune(xmin=0, rmin=0, chunk=0, lmin=0, bpc=0, exact=0, rowmajor=0, scatter=0, reforder=0, profordered=0, nohelp=0):
     """mi355_opts::tune as a list (see include/mi355_render.h); every knob leaves the pixels unchanged.
-    (lmin is accepted for old scripts and ignored.)"""
-    flags = (1 if exact else 0) | (2 if rowmajor else 0) | (4 if reforder else 0) | (8 if profordered else 0) | (16 if scatter else 0) | (32 if nohelp else 0)
+    (lmin and scatter are accepted for old scripts and ignored.)"""
+    flags = (1 if exact else 0) | (2 if rowmajor else 0) | (4 if reforder else 0) | (8 if profordered else 0) | (32 if nohelp else 0)
     return [xmin, rmin, chunk, 0, bpc, flags, 0, 0]
 
 

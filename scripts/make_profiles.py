@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Distil the rocprofv3 output of scripts/gpu_round1_full.sh (under gpurun_out/) into the tracked files in profiles/.
+
+    python scripts/make_profiles.py [round-tag, default r01]
+"""
+import collections, csv, glob, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+KERNEL = "k_raytrace<false, false, true, 2>"       # the bench's kernel: ordered walk, two waves per SIMD
+
+
+def newest(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, pattern), recursive=True), key=os.path.getmtime)
+    return files[-1] if files else None
+
+
+def per_launch(kind):
+    f = newest("gpurun_out/%s/**/*counter_collection.csv" % kind)
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    if f:
+        for row in csv.DictReader(open(f)):
+            if KERNEL in row["Kernel_Name"]:
+                a = acc[row["Counter_Name"]]
+                a[0] += float(row["Counter_Value"]); a[1] += 1
+    return {k: v[0] / v[1] for k, v in acc.items()}, {k: v[1] for k, v in acc.items()}
+
+
+def main():
+    out = os.path.join(ROOT, "profiles")
+    ks = newest("gpurun_out/prof_stats/**/*kernel_stats.csv")
+    if ks:
+        shutil.copy(ks, os.path.join(out, "%s_kernel_stats.csv" % TAG))
+    pmc, launches = {}, {}
+    for kind in ("prof_fetch", "prof_write", "prof_sq", "prof_cache"):
+        v, n = per_launch(kind)
+        pmc.update(v); launches.update(n)
+    fetch_kb, write_kb = pmc.get("FETCH_SIZE"), pmc.get("WRITE_SIZE")
+    traffic = None
+    if fetch_kb is not None and write_kb is not None:
+        traffic = 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0
+    json.dump({
+        "kernel": KERNEL,
+        "workload": "dragon_vis.ply mode 9 1920x1080, bench.py --steps 20 --warmup 2 under rocprofv3 --pmc (one pass per counter group)",
+        "FETCH_SIZE_KB_per_launch_raw": fetch_kb, "WRITE_SIZE_KB_per_launch_raw": write_kb,
+        "fetch_correction": "x2 (gfx950 rocprofv3 tallies 128-B requests at 64 B for 16 B/lane loads; MI355X_MICROARCH.md HBM section). WRITE_SIZE uncorrected.",
+        "k_raytrace_hbm_bytes_per_launch": traffic,
+        "pmc_per_launch": pmc, "launches": launches,
+    }, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+    for src, dst in (("gpurun_out/bench_full.log", "%s_bench_n1.jsonl" % TAG), ("gpurun_out/pytest_full.log", "%s_pytest_gpu.log" % TAG)):
+        p = os.path.join(ROOT, src)
+        if os.path.exists(p):
+            lines = [l for l in open(p).read().splitlines() if l.strip()]
+            open(os.path.join(out, dst), "w").write("\n".join(lines[-1:] if dst.endswith("jsonl") else lines) + "\n")
+    print("traffic bytes/launch:", traffic, "| launches:", launches)
+    if ks:
+        for i, row in enumerate(csv.DictReader(open(ks))):
+            if i < 6:
+                print(row["Name"][:80], row["Calls"], row["AverageNs"])
+
+
+if __name__ == "__main__":
+    main()
