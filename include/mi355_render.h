@@ -138,6 +138,13 @@ void mi355_scene_destroy(mi355_ctx *);
 int mi355_scene_set_bvh(mi355_ctx *, const void *nodes32B, uint32_t n_nodes, const int32_t *tri_idx,
                         uint32_t n_idx);
 
+/* Build the BVH on the GPU: Scene::CreateBVH + PopulateCacheFriendlyBVH (BVH.cc:96-371 scalar variant,
+ * Raytracer.cc:651-718).  nodes32B must have room for 2*n_triangles nodes, tri_idx for n_triangles entries; the
+ * result is the reference's own tree (the bytes of its `.bvh` cache) and is also installed in the context, as if
+ * passed to mi355_scene_set_bvh.  max_depth (optional) receives the depth of the deepest node (the reference
+ * refuses trees deeper than its 32-entry stack, Raytracer.cc:711-717 -- the caller decides). */
+int mi355_build_bvh(mi355_ctx *, void *nodes32B, int32_t *tri_idx, uint32_t *n_nodes, int32_t *max_depth);
+
 /* Light::RenderSceneIntoShadowBuffer (Light.h:61, Light.cc:218-244) for light slot `slot`;
  * out_map (optional) receives the size*size floats of Light::_shadowBuffer. */
 int mi355_shadowmap_render(mi355_ctx *, int slot, const mi355_light *light, int size, float *out_map);

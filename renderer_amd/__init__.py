@@ -244,9 +244,15 @@ class Scene:
             tri_e=_np_view(d.tri_e, 9 * T, np.float32).reshape(T, 9))
 
     # -- BVH ---------------------------------------------------------------------------------------
-    def bvh_create(self) -> int:
-        if host().mi355h_bvh_create(self._h) != 0:
+    def bvh_create(self, where: str = "auto") -> int:
+        """Scene::CreateBVH.  where: "auto" (GPU builder if a device is usable, else the host builder), "host", "device".
+        self.bvh_built_on_device tells which one ran."""
+        on = C.c_int(0)
+        f = host().mi355h_bvh_create_on
+        f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        if f(self._h, {"auto": 0, "host": 1, "device": 2}[where], C.byref(on)) != 0:
             raise Mi355Error(host().mi355h_last_error().decode())
+        self.bvh_built_on_device = bool(on.value)
         return self.bvh_info()[0]
 
     def bvh_update(self, filename: str | None = None, force: bool = False) -> int:
@@ -283,6 +289,18 @@ class Scene:
         f.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         _check(f(self.context(), out), "mi355i_scene_info")
         return tuple(int(x) for x in out)
+
+    def build_bvh_device(self):
+        """mi355_build_bvh: the reference's tree built on the GPU.  Returns (nodes[n,8] uint32, tri_idx[T] int32, max depth)
+        and installs the tree in the device context (the host-side Scene keeps whatever tree it had)."""
+        T = self.nt
+        nodes = np.zeros((2 * T + 2, 8), np.uint32)
+        idx = np.zeros(T, np.int32)
+        n, depth = C.c_uint32(0), C.c_int32(0)
+        f = lib().mi355_build_bvh
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
+        _check(f(self.context(), nodes.ctypes.data, idx.ctypes.data, C.byref(n), C.byref(depth)), "mi355_build_bvh")
+        return nodes[:n.value].copy(), idx, depth.value
 
     def set_bvh_arrays(self, nodes: np.ndarray, tri_idx: np.ndarray):
         """mi355_scene_set_bvh with caller-supplied arrays (the reference's 32-byte nodes + triIndexList)."""

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -20,6 +21,11 @@
 extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves3, int stack_depth);
 extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int ordered, int waves3, int n_blocks,
                                              hipStream_t);
+extern "C" hipError_t mi355i_bvh_launch_prims(const float4 *rs_vert, const uint4 *rs_idx, uint32_t T, float4 *prim, uint32_t *list,
+                                              uint32_t *bad, hipStream_t st);
+extern "C" hipError_t mi355i_bvh_launch_level(const void *cur, uint32_t n_cur, void *next, uint32_t *next_count, void *tree,
+                                              uint32_t *tree_count, const float4 *prim, const uint32_t *list_cur, uint32_t *list_next,
+                                              int depth, uint32_t *bad, hipStream_t st);
 extern "C" hipError_t mi355i_launch_points(const DevScene *, const FrameParams *, int as_triangles, hipStream_t);
 struct RasterScratch;
 extern "C" hipError_t mi355i_launch_raster(const DevScene *, const FrameParams *, int mode, RasterScratch *,
@@ -588,6 +594,107 @@ int mi355_scene_set_bvh(mi355_ctx *c, const void *nodes32B, uint32_t n_nodes, co
     if (int r = select_device(c)) return r;
     HIP_TRY(hipStreamSynchronize(c->stream), -40);
     return build_bvh_streams(c, nodes32B, n_nodes, tri_idx, n_idx);
+}
+
+// CreateBVH + PopulateCacheFriendlyBVH (BVH.cc:96-371, Raytracer.cc:651-718) on the device: the SAH sweeps run as
+// k_bvh_level (one launch per tree level), the result is flattened here to the reference's pre-order array and is
+// byte for byte what the reference's scalar builder writes to its `.bvh` cache.  Also installs the tree in the context.
+static double g_bvh_ms[4] = {0, 0, 0, 0};     // last mi355_build_bvh: setup, level kernels (incl. per-level sync), download + flatten, install
+extern "C" void mi355i_bvh_last_times(double *out4) { for (int i = 0; i < 4; i++) out4[i] = g_bvh_ms[i]; }
+
+int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_nodes, int32_t *max_depth)
+{
+    const auto clk = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = clk();
+    if (!c || !nodes32B || !tri_idx || !n_nodes) return fail(-3, "mi355_build_bvh: null argument");
+    if (int r = select_device(c)) return r;
+    const uint32_t T = c->nT;
+    if (T == 0) return fail(-50, "mi355_build_bvh: scene has no triangles");
+    HIP_TRY(hipStreamSynchronize(c->stream), -40);
+    struct LevelNode { uint32_t first, count, tree, pad; float bb[6]; float pad2[2]; };
+    struct TreeNode { float bb[6]; uint32_t a, b; };
+    static_assert(sizeof(LevelNode) == 48 && sizeof(TreeNode) == 32, "layouts shared with k_bvh.hip");
+    DevBuf prim, list[2], lvl[2], tree, cnt;
+    struct Guard { DevBuf *b[7]; ~Guard() { for (DevBuf *x : b) x->release(); } } guard{{&prim, &list[0], &list[1], &lvl[0], &lvl[1], &tree, &cnt}};
+    const size_t max_level_nodes = (size_t)T / 2 + 4;
+    HIP_TRY(prim.ensure((size_t)T * 3 * sizeof(float4)), -31);
+    for (int i = 0; i < 2; i++) { HIP_TRY(list[i].ensure((size_t)T * 4), -31); HIP_TRY(lvl[i].ensure(max_level_nodes * sizeof(LevelNode)), -31); }
+    HIP_TRY(tree.ensure(((size_t)2 * T + 4) * sizeof(TreeNode)), -31);
+    HIP_TRY(cnt.ensure(16), -31);
+    uint32_t *d_cnt = (uint32_t *)cnt.p;      // [0] nodes of the next level, [1] tree nodes, [2] error bits
+    const uint32_t init[4] = {0u, 1u, 0u, 0u};
+    HIP_TRY(hipMemcpy(d_cnt, init, sizeof init, hipMemcpyHostToDevice), -31);
+    hipError_t e = mi355i_bvh_launch_prims((const float4 *)c->rs_vert.p, (const uint4 *)c->rs_idx.p, T, (float4 *)prim.p,
+                                           (uint32_t *)list[0].p, d_cnt + 2, c->stream);
+    if (e != hipSuccess) return fail(-43, "BVH work-item launch failed: %s", hipGetErrorString(e));
+    // the root gets the global box, accumulated over the triangles in index order (BVH.cc:331-368)
+    LevelNode root{};
+    root.first = 0; root.count = T; root.tree = 0;
+    {
+        float gb[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, gt[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (uint32_t t = 0; t < T; t++) {
+            float b[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, tp[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) { const float q = c->vpos[3 * (size_t)c->tidx[3 * (size_t)t + k] + a]; b[a] = (q < b[a]) ? q : b[a]; }
+            for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) { const float q = c->vpos[3 * (size_t)c->tidx[3 * (size_t)t + k] + a]; tp[a] = (tp[a] < q) ? q : tp[a]; }
+            for (int a = 0; a < 3; a++) { gb[a] = (b[a] < gb[a]) ? b[a] : gb[a]; gt[a] = (gt[a] < tp[a]) ? tp[a] : gt[a]; }
+        }
+        for (int a = 0; a < 3; a++) { root.bb[a] = gb[a]; root.bb[3 + a] = gt[a]; }
+    }
+    HIP_TRY(hipMemcpy(lvl[0].p, &root, sizeof root, hipMemcpyHostToDevice), -31);
+    const double t_setup = clk();
+    uint32_t n_cur = 1;
+    int cur = 0, depth = 0;
+    while (n_cur) {
+        if (depth >= 64) return fail(-51, "BVH deeper than 64 levels");
+        if (n_cur > max_level_nodes) return fail(-51, "BVH level %d has %u nodes", depth, n_cur);
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, 4, c->stream), -40);
+        e = mi355i_bvh_launch_level(lvl[cur].p, n_cur, lvl[1 - cur].p, d_cnt, tree.p, d_cnt + 1, (const float4 *)prim.p,
+                                    (const uint32_t *)list[cur].p, (uint32_t *)list[1 - cur].p, depth, d_cnt + 2, c->stream);
+        if (e != hipSuccess) return fail(-43, "BVH level launch failed: %s", hipGetErrorString(e));
+        uint32_t h[3];
+        HIP_TRY(hipMemcpyAsync(h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream), -31);
+        HIP_TRY(hipStreamSynchronize(c->stream), -40);
+        if (h[2] & 1u) return fail(-50, "mi355_build_bvh: non-finite vertex coordinates (use the host builder)");
+        if (h[2] & 2u) return fail(-50, "mi355_build_bvh: more than 1100 candidate planes on an axis");
+        n_cur = h[0];
+        cur = 1 - cur;
+        depth++;
+    }
+    const double t_levels = clk();
+    uint32_t n_tree = 0;
+    HIP_TRY(hipMemcpy(&n_tree, d_cnt + 1, 4, hipMemcpyDeviceToHost), -31);
+    std::vector<TreeNode> tn(n_tree);
+    HIP_TRY(hipMemcpy(tn.data(), tree.p, (size_t)n_tree * sizeof(TreeNode), hipMemcpyDeviceToHost), -31);
+    HIP_TRY(hipMemcpy(tri_idx, list[cur].p, (size_t)T * 4, hipMemcpyDeviceToHost), -31);
+    // flatten (Raytracer.cc:651-682): pre-order, idxLeft = own index + 1, leaves keep their list segment
+    struct RefNode { float bottom[3], top[3]; uint32_t a, b; };
+    RefNode *out = (RefNode *)nodes32B;
+    uint32_t n_out = 0;
+    int deepest = 0;
+    struct Item { uint32_t t; uint32_t parent; int side, depth; };
+    std::vector<Item> st;
+    st.push_back({0u, 0xffffffffu, 0, 0});
+    while (!st.empty()) {
+        const Item it = st.back(); st.pop_back();
+        if (it.t >= n_tree) return fail(-51, "BVH build produced a dangling child index");
+        const uint32_t me = n_out++;
+        if (it.depth > deepest) deepest = it.depth;
+        const TreeNode &s = tn[it.t];
+        for (int k = 0; k < 3; k++) { out[me].bottom[k] = s.bb[k]; out[me].top[k] = s.bb[3 + k]; }
+        if (it.parent != 0xffffffffu) { if (it.side == 0) out[it.parent].a = me; else out[it.parent].b = me; }
+        if (s.a & 0x80000000u) { out[me].a = s.a; out[me].b = s.b; }
+        else {
+            out[me].a = out[me].b = 0;
+            st.push_back({s.b, me, 1, it.depth + 1});       // right is visited after the whole left subtree
+            st.push_back({s.a, me, 0, it.depth + 1});
+        }
+    }
+    *n_nodes = n_out;
+    if (max_depth) *max_depth = deepest;
+    const double t_flat = clk();
+    const int r = build_bvh_streams(c, nodes32B, n_out, tri_idx, T);
+    g_bvh_ms[0] = t_setup - t_start; g_bvh_ms[1] = t_levels - t_setup; g_bvh_ms[2] = t_flat - t_levels; g_bvh_ms[3] = clk() - t_flat;
+    return r;
 }
 
 int mi355_shadowmap_set(mi355_ctx *c, int slot, const float *map, int size)

@@ -48,6 +48,15 @@ int mi355h_set_device(void *h, int device)
 
 // BVH: build (always), or the reference's cache-or-build entry point
 int mi355h_bvh_create(void *h) { return guarded([&] { ((Handle *)h)->scene.CreateBVH(); }); }
+// where: 0 auto, 1 host builder, 2 device builder; *on_device (optional) tells which one ran
+int mi355h_bvh_create_on(void *h, int where, int *on_device)
+{
+    return guarded([&] {
+        Scene &s = ((Handle *)h)->scene;
+        s.CreateBVH((Scene::BvhBuilderChoice)where);
+        if (on_device) *on_device = s._bvhBuiltOnDevice ? 1 : 0;
+    });
+}
 int mi355h_bvh_update(void *h, const char *filename, int force)
 {
     return guarded([&] { ((Handle *)h)->scene.UpdateBoundingVolumeHierarchy(filename, force != 0); });

@@ -569,8 +569,35 @@ struct BvhBuilder {
 
 } // namespace
 
-void Scene::CreateBVH()
+void Scene::CreateBVH(BvhBuilderChoice where)
 {
+    if (where != BVH_HOST) {
+        int n_dev = 0;
+        const bool have_device = mi355_init(0, &n_dev) == 0 && n_dev > 0;
+        if (!have_device && where == BVH_DEVICE) raise(std::string("CreateBVH on the device: ") + mi355_last_error());
+        if (have_device) {
+            std::vector<CacheFriendlyBVHNode> nodes(2 * numTriangles() + 2);
+            std::vector<int32_t> tris(numTriangles());
+            uint32_t n = 0;
+            int32_t depth = 0;
+            _bvhOnDevice = false;
+            const int r = mi355_build_bvh(context(), nodes.data(), tris.data(), &n, &depth);
+            if (r == 0) {
+                if (depth >= 32)                                             // BVH_STACK_SIZE, Raytracer.cc:711-717
+                    raise("Max depth of BVH was " + std::to_string(depth) + ": deeper than BVH_STACK_SIZE (32)");
+                nodes.resize(n);
+                _pCFBVH.swap(nodes);
+                _triIndexList.swap(tris);
+                _bvhMaxDepth = depth;
+                _bvhOnDevice = true;                                         // mi355_build_bvh installed it already
+                _bvhBuiltOnDevice = true;
+                return;
+            }
+            // -50: input the device builder declines (non-finite coordinates): the host builder's naive pass handles it
+            if (r != -50 || where == BVH_DEVICE) raise(std::string("mi355_build_bvh: ") + mi355_last_error());
+        }
+    }
+    _bvhBuiltOnDevice = false;
     BvhBuilder b(*this);
     b.build();
     if (b.leafTris.size() != numTriangles()) raise("Internal bug in CreateCFBVH, please report it...");

@@ -123,7 +123,11 @@ struct Scene {                                         // Scene.h:32-86
 
     void load(const char *filename);                   // Loader.cc:85-494; throws std::string like THROW()
     void fix_normals();                                // Loader.cc:496-518
-    void CreateBVH();                                  // BVH.cc:64-371 + Raytracer.cc:651-718 (same tree, sorted sweep)
+    // BVH.cc:64-371 + Raytracer.cc:651-718.  The same tree either way: built by k_bvh_level on the GPU
+    // (mi355_build_bvh) when a device is usable, by the host's sorted-sweep builder otherwise or on request.
+    enum BvhBuilderChoice { BVH_AUTO = 0, BVH_HOST = 1, BVH_DEVICE = 2 };
+    void CreateBVH(BvhBuilderChoice where = BVH_AUTO);
+    bool _bvhBuiltOnDevice = false;                    // which builder produced the current tree
     void UpdateBoundingVolumeHierarchy(const char *filename, bool forceRecalc = false);   // Raytracer.cc:720-789
 
     void renderPoints(const Camera &, Screen &, bool asTriangles = true);   // Scene.h:76

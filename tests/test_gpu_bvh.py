@@ -1,0 +1,124 @@
+"""GPU SAH builder (mi355_build_bvh): the reference's exact tree, byte for byte.
+
+Pins: the `.bvh` hashes of the reference's own scalar builder (tests/golden/reference_pins.json); beyond the three
+shipped meshes the host builder (itself pinned to those hashes on CPU) is the checker, on meshes built to hit the
+order-dependent corners: equal centroids, signed zeros, flat and tiny nodes."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import renderer_amd as R
+
+pytestmark = pytest.mark.gpu
+PINS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_pins.json")))
+MESHES = ["dragon_vis.ply", "statue.ply", "chessboard.tri"]
+
+
+def both_builders(path):
+    d = R.Scene(path)
+    d.bvh_create("device")
+    assert d.bvh_built_on_device
+    h = R.Scene(path)
+    h.bvh_create("host")
+    assert not h.bvh_built_on_device
+    return d, h
+
+
+def assert_same_tree(d, h):
+    dn, di = d.bvh_arrays()
+    hn, hi = h.bvh_arrays()
+    assert dn.shape == hn.shape, "node count %d vs %d" % (dn.shape[0], hn.shape[0])
+    assert np.array_equal(di, hi), "triangle lists differ"
+    bad = np.argwhere((dn != hn).any(axis=1))
+    assert bad.size == 0, "first differing node %d: %s vs %s" % (bad[0, 0], dn[bad[0, 0]], hn[bad[0, 0]])
+    assert d.bvh_info()[2] == h.bvh_info()[2]        # max depth
+
+
+@pytest.mark.parametrize("mesh", MESHES)
+def test_gpu_builder_emits_the_reference_cache_bytes(mesh):
+    d, h = both_builders(R.assets.mesh_path(mesh))
+    assert_same_tree(d, h)
+    nodes, idx = d.bvh_arrays()
+    pin = PINS["bvh"][mesh]
+    assert nodes.shape[0] == pin["nodes"]
+    blob = np.array([nodes.shape[0], d.nt], np.uint32).tobytes() + nodes.tobytes() + idx.tobytes()
+    sha = hashlib.sha256(blob).hexdigest()
+    assert sha.startswith(pin["sha_prefix"]) and sha.endswith(pin["sha_suffix"])
+
+
+def write_ply(path, verts, faces):
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nelement face %d\nend_header\n" % (len(verts), len(faces)))
+        for v in verts:
+            f.write("%s %s %s 60\n" % tuple(repr(float(x)) for x in v))
+        for t in faces:
+            f.write("3 %d %d %d\n" % tuple(t))
+
+
+def soup(rng, n_tri, snap=None, scale=1.0):
+    """n_tri small random triangles; snap = grid step to force equal coordinates / centroids"""
+    c = rng.uniform(-1, 1, (n_tri, 1, 3)) * scale
+    v = c + rng.uniform(-0.08, 0.08, (n_tri, 3, 3)) * scale
+    if snap:
+        v = np.round(v / snap) * snap
+    verts = v.reshape(-1, 3)
+    faces = np.arange(3 * n_tri).reshape(n_tri, 3)
+    return verts, faces
+
+
+CASES = {
+    "random_3000": lambda rng: soup(rng, 3000),
+    "snapped_grid_2000 (many equal centroids and box faces)": lambda rng: soup(rng, 2000, snap=0.125),
+    "coarse_grid_600 (ties everywhere)": lambda rng: soup(rng, 600, snap=0.5),
+    "three_triangles (single leaf)": lambda rng: soup(rng, 3),
+    "four_triangles": lambda rng: soup(rng, 4),
+    "five_triangles": lambda rng: soup(rng, 5),
+    "seventeen_triangles": lambda rng: soup(rng, 17),
+    "flat_in_z_500 (one axis below the 1e-4 extent)": lambda rng: (lambda vf: (vf[0] * np.array([1, 1, 0.0]), vf[1]))(soup(rng, 500)),
+    "duplicates_300 (identical triangles cannot be separated)": lambda rng: (lambda vf: (np.tile(vf[0], (10, 1)), np.arange(900).reshape(300, 3)))(soup(rng, 30)),
+    "long_thin_1000": lambda rng: (lambda vf: (vf[0] * np.array([40.0, 1, 0.2]), vf[1]))(soup(rng, 1000)),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES), ids=[k.split(" ")[0] for k in CASES])
+def test_gpu_builder_matches_host_builder_on_synthetic_meshes(case, tmp_path):
+    rng = np.random.default_rng(abs(hash(case.split(" ")[0])) % (2 ** 31))
+    verts, faces = CASES[case](rng)
+    p = str(tmp_path / "m.ply")
+    write_ply(p, verts, faces)
+    d, h = both_builders(p)
+    assert_same_tree(d, h)
+
+
+def test_gpu_builder_keeps_the_sign_of_zero_the_reference_keeps(tmp_path):
+    """Boxes are accumulated with std::min/std::max in list order, so among equal extremes the FIRST wins -- which is
+    visible as the sign of a zero coordinate in the stored boxes.  Symmetric coordinates around 0 with both +0 and -0."""
+    rng = np.random.default_rng(7)
+    n = 400
+    base = rng.choice(np.array([-1.0, -0.5, -0.0, 0.0, 0.5, 1.0]), (n, 3, 3))
+    base += rng.choice(np.array([0.0, -0.0]), (n, 3, 3))
+    # make sure the bounding box stays symmetric so that the loader's re-centring keeps the zeros
+    verts = np.concatenate([base.reshape(-1, 3), [[-1, -1, -1], [1, 1, 1], [1, -1, 1]]])
+    faces = np.concatenate([np.arange(3 * n).reshape(n, 3), [[3 * n, 3 * n + 1, 3 * n + 2]]])
+    p = str(tmp_path / "z.ply")
+    write_ply(p, verts, faces)
+    d, h = both_builders(p)
+    dn, _ = d.bvh_arrays()
+    boxes = dn[:, :6]
+    assert ((boxes == 0x80000000).any() or (boxes == 0).any()), "the case is meant to produce zero box coordinates"
+    assert_same_tree(d, h)
+
+
+def test_frames_after_a_device_build_match_the_pins():
+    """The tree mi355_build_bvh installs in the context is the one the frames are traced with."""
+    s = R.Scene(R.assets.mesh_path("dragon_vis.ply"))
+    s.bvh_create("device")
+    pin = [p for p in PINS["frames"] if p.get("mesh", "").startswith("dragon") and p.get("mode") == 9]
+    cam, lights, n = R.benchmark_frame(0)
+    img = s.render(9, cam, lights, n, R.default_opts(640, 360))[0]
+    h = R.Scene(R.assets.mesh_path("dragon_vis.ply"))
+    h.bvh_create("host")
+    assert (img == h.render(9, cam, lights, n, R.default_opts(640, 360))[0]).all()

@@ -87,7 +87,7 @@ def test_loader_and_precompute_bit_exact(oracle_scene, host_scene, mesh):
 def test_bvh_builder_reproduces_reference_tree(host_scene, mesh, tmp_path):
     """The sorted-sweep builder must emit the reference's exact tree: same .bvh bytes (hash pinned)."""
     h = host_scene(mesh)
-    n = h.bvh_create()
+    n = h.bvh_create("host")
     pin = PINS["bvh"][mesh]
     assert n == pin["nodes"]
     nodes, idx = h.bvh_arrays()
