@@ -209,6 +209,21 @@ def main():
                     chess.render_device(mode, cams[k][0], cams[k][1], cams[k][2], o6, buf.data_ptr(), W * 4, 0, stream.cuda_stream)
                 torch.cuda.synchronize(dev)
                 extra[name + "_fps"] = round(n_f / (time.perf_counter() - t1), 2)
+            # BVH build of the benchmark mesh: GPU level kernels + download + flatten, host builder beside it
+            import ctypes as C
+            bs = R.Scene(R.assets.mesh_path(args.mesh), device=local_rank)
+            bs.context()
+            bs.build_bvh_device()
+            best = None
+            for _ in range(5):
+                bs.build_bvh_device()
+                tm = (C.c_double * 4)()
+                R.lib().mi355i_bvh_last_times(tm)
+                best = min(best, tm[1] + tm[2]) if best is not None else tm[1] + tm[2]
+            extra["bvh_build_gpu_ms"] = round(best, 3)
+            t1 = time.perf_counter()
+            bs.bvh_create("host")
+            extra["bvh_build_host_cpu_ms"] = round((time.perf_counter() - t1) * 1e3, 1)
         except Exception as e:      # secondary numbers must never break the headline line
             extra["error"] = str(e)
         result["other_workloads"] = extra

@@ -107,6 +107,7 @@ struct mi355_ctx {
                             // dispenser (MI_DISPENSERS counters, MI_DISPENSER_STRIDE words apart) -- one memset per frame
     DevBuf fb, fbf;         // internal framebuffer for the host-output path
     DevBuf tile_order;      // raytrace dispenser order (ensure_tile_order)
+    DevBuf bvh_prim, bvh_list[2], bvh_lvl[2], bvh_tree, bvh_cnt;   // mi355_build_bvh work buffers (kept for rebuilds)
     DevBuf wave_prof;       // per-wave phase profile of counting launches (debug)
     int last_blocks = 0;
     long long tile_key[6] = {0, 0, 0, 0, 0, 0};
@@ -578,7 +579,8 @@ void mi355_scene_destroy(mi355_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->walk, &c->tri_edge, &c->tri_shade, &c->rs_tri, &c->rs_col, &c->rs_idx,
-                      &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->tile_order, &c->wave_prof})
+                      &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->tile_order, &c->wave_prof, &c->bvh_prim, &c->bvh_list[0], &c->bvh_list[1],
+                      &c->bvh_lvl[0], &c->bvh_lvl[1], &c->bvh_tree, &c->bvh_cnt})
         b->release();
     for (auto &m : c->smap) m.release();
     if (c->rscratch) mi355i_raster_scratch_destroy(c->rscratch);
@@ -599,6 +601,8 @@ int mi355_scene_set_bvh(mi355_ctx *c, const void *nodes32B, uint32_t n_nodes, co
 // CreateBVH + PopulateCacheFriendlyBVH (BVH.cc:96-371, Raytracer.cc:651-718) on the device: the SAH sweeps run as
 // k_bvh_level (one launch per tree level), the result is flattened here to the reference's pre-order array and is
 // byte for byte what the reference's scalar builder writes to its `.bvh` cache.  Also installs the tree in the context.
+static double g_bvh_level_ms[64]; static uint32_t g_bvh_level_nodes[64]; static int g_bvh_levels = 0;
+extern "C" int mi355i_bvh_level_times(double *ms64, uint32_t *nodes64) { for (int i = 0; i < g_bvh_levels; i++) { ms64[i] = g_bvh_level_ms[i]; nodes64[i] = g_bvh_level_nodes[i]; } return g_bvh_levels; }
 static double g_bvh_ms[4] = {0, 0, 0, 0};     // last mi355_build_bvh: setup, level kernels (incl. per-level sync), download + flatten, install
 extern "C" void mi355i_bvh_last_times(double *out4) { for (int i = 0; i < 4; i++) out4[i] = g_bvh_ms[i]; }
 
@@ -614,8 +618,7 @@ int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_
     struct LevelNode { uint32_t first, count, tree, pad; float bb[6]; float pad2[2]; };
     struct TreeNode { float bb[6]; uint32_t a, b; };
     static_assert(sizeof(LevelNode) == 48 && sizeof(TreeNode) == 32, "layouts shared with k_bvh.hip");
-    DevBuf prim, list[2], lvl[2], tree, cnt;
-    struct Guard { DevBuf *b[7]; ~Guard() { for (DevBuf *x : b) x->release(); } } guard{{&prim, &list[0], &list[1], &lvl[0], &lvl[1], &tree, &cnt}};
+    DevBuf &prim = c->bvh_prim, *list = c->bvh_list, *lvl = c->bvh_lvl, &tree = c->bvh_tree, &cnt = c->bvh_cnt;
     const size_t max_level_nodes = (size_t)T / 2 + 4;
     HIP_TRY(prim.ensure((size_t)T * 3 * sizeof(float4)), -31);
     for (int i = 0; i < 2; i++) { HIP_TRY(list[i].ensure((size_t)T * 4), -31); HIP_TRY(lvl[i].ensure(max_level_nodes * sizeof(LevelNode)), -31); }
@@ -647,6 +650,7 @@ int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_
     while (n_cur) {
         if (depth >= 64) return fail(-51, "BVH deeper than 64 levels");
         if (n_cur > max_level_nodes) return fail(-51, "BVH level %d has %u nodes", depth, n_cur);
+        const double t_l0 = clk();
         HIP_TRY(hipMemsetAsync(d_cnt, 0, 4, c->stream), -40);
         e = mi355i_bvh_launch_level(lvl[cur].p, n_cur, lvl[1 - cur].p, d_cnt, tree.p, d_cnt + 1, (const float4 *)prim.p,
                                     (const uint32_t *)list[cur].p, (uint32_t *)list[1 - cur].p, depth, d_cnt + 2, c->stream);
@@ -656,6 +660,7 @@ int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_
         HIP_TRY(hipStreamSynchronize(c->stream), -40);
         if (h[2] & 1u) return fail(-50, "mi355_build_bvh: non-finite vertex coordinates (use the host builder)");
         if (h[2] & 2u) return fail(-50, "mi355_build_bvh: more than 1100 candidate planes on an axis");
+        g_bvh_level_ms[depth] = clk() - t_l0; g_bvh_level_nodes[depth] = n_cur; g_bvh_levels = depth + 1;
         n_cur = h[0];
         cur = 1 - cur;
         depth++;

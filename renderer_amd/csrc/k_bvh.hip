@@ -22,7 +22,7 @@
 
 namespace {
 
-enum { BV_THREADS = 256, BV_MAX_PLANES = 1100 };
+enum { BV_MAX_PLANES = 1100, BV_SMALL = 96 };
 
 struct BvLevelNode { uint32_t first, count, tree, pad; float bb[6]; float pad2[2]; };   // 48 B
 struct BvTreeNode { float bb[6]; uint32_t a, b; };                                       // inner: child tree indices; leaf: 0x80000000|count, first
@@ -70,11 +70,11 @@ __device__ __forceinline__ float prim_center(const float4 *prim, uint32_t t, int
 }
 
 // ---- workgroup-wide inclusive scan of a[0..n) in LDS (n <= 5 * BV_THREADS), forward or backward -------
-template <class Op>
-__device__ void bv_scan(uint32_t *a, int n, bool backward, Op op, uint32_t identity, uint32_t *tmp /* [8] */)
+template <int BV_THREADS, class Op>
+__device__ void bv_scan(uint32_t *a, int n, bool backward, Op op, uint32_t identity, uint32_t *tmp /* [BV_THREADS / 64] */)
 {
     const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int per = (n + BV_THREADS - 1) / BV_THREADS;                 // <= 5
+    const int per = (n + BV_THREADS - 1) / BV_THREADS;
     uint32_t run = identity;
     for (int j = 0; j < per; j++) {
         const int i = tid * per + j;
@@ -112,6 +112,8 @@ struct OpMin { __device__ uint32_t operator()(uint32_t x, uint32_t y) const { re
 struct OpMax { __device__ uint32_t operator()(uint32_t x, uint32_t y) const { return x > y ? x : y; } };
 
 // ---- one level of the build: one workgroup per node ------------------------------------------------------
+// (BV_THREADS = 1024 for the first levels, whose few nodes hold most of the triangles each; 256 below)
+template <int BV_THREADS>
 __global__ void __launch_bounds__(BV_THREADS)
 k_bvh_level(const BvLevelNode *cur, uint32_t n_cur, BvLevelNode *next, uint32_t *next_count, BvTreeNode *tree,
             uint32_t *tree_count, const float4 *prim, const uint32_t *list_cur, uint32_t *list_next, int depth, uint32_t *bad)
@@ -120,7 +122,7 @@ k_bvh_level(const BvLevelNode *cur, uint32_t n_cur, BvLevelNode *next, uint32_t 
     __shared__ uint32_t cnt[BV_MAX_PLANES + 1];
     __shared__ uint32_t lmin[3][BV_MAX_PLANES + 1], lmax[3][BV_MAX_PLANES + 1];     // bins, then inclusive prefix
     __shared__ uint32_t rmin[3][BV_MAX_PLANES + 1], rmax[3][BV_MAX_PLANES + 1];     // inclusive suffix
-    __shared__ uint32_t scan_tmp[8];
+    __shared__ uint32_t scan_tmp[BV_THREADS / 64];
     __shared__ int sh_C;
     __shared__ float red_cost[BV_THREADS];
     __shared__ int red_k[BV_THREADS];
@@ -129,8 +131,10 @@ k_bvh_level(const BvLevelNode *cur, uint32_t n_cur, BvLevelNode *next, uint32_t 
     __shared__ uint32_t best_nl;
     __shared__ uint32_t ckey[12];            // child boxes: left min xyz, left max xyz, right min xyz, right max xyz (keys)
     __shared__ uint32_t czero[12];           // list position of the first zero among the values equal to the extreme
-    __shared__ uint32_t wave_left[4];
+    __shared__ uint32_t wave_left[BV_THREADS / 64];
     __shared__ uint32_t slots[2];
+    __shared__ float sm_prim[BV_SMALL][9];   // small nodes: bottom, top, centre of the node's triangles
+    __shared__ uint32_t sm_nl[BV_THREADS];   // left count of each thread's best candidate
 
     const uint32_t node = blockIdx.x;
     if (node >= n_cur) return;
@@ -154,6 +158,15 @@ k_bvh_level(const BvLevelNode *cur, uint32_t n_cur, BvLevelNode *next, uint32_t 
         best_cost = (float)n * (side1 * side2 + side2 * side3 + side3 * side1);   // BVH.cc:113-117
         best_axis = -1; best_k = 0; best_split = FLT_MAX; best_nl = 0;
     }
+    const bool small = n <= (uint32_t)BV_SMALL;
+    if (small)
+        for (uint32_t i = (uint32_t)tid; i < n; i += BV_THREADS) {
+            const uint32_t t = list_cur[first + i];
+            const float4 b = prim[(size_t)t * 3], tp = prim[(size_t)t * 3 + 1], c2 = prim[(size_t)t * 3 + 2];
+            sm_prim[i][0] = b.x; sm_prim[i][1] = b.y; sm_prim[i][2] = b.z;
+            sm_prim[i][3] = tp.x; sm_prim[i][4] = tp.y; sm_prim[i][5] = tp.z;
+            sm_prim[i][6] = b.w; sm_prim[i][7] = tp.w; sm_prim[i][8] = c2.x;
+        }
     __syncthreads();
 
     for (int axis = 0; axis < 3; axis++) {
@@ -171,6 +184,35 @@ k_bvh_level(const BvLevelNode *cur, uint32_t n_cur, BvLevelNode *next, uint32_t 
         __syncthreads();
         const int C = sh_C;
         if (C == 0) { __syncthreads(); continue; }
+        float my_cost = FLT_MAX;
+        int my_k = -1;
+        if (small) {
+            // few triangles: every thread owns candidate planes and walks the node's triangles itself, as the
+            // reference does (BVH.cc:160-206) -- no bins, no scans
+            for (int k = tid; k < C; k += BV_THREADS) {
+                const float plane = thr[k];
+                float lb[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lt[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+                float rb[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, rt[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+                int countLeft = 0;
+                for (uint32_t i = 0; i < n; i++) {
+                    const bool left = sm_prim[i][6 + axis] < plane;
+                    countLeft += left ? 1 : 0;
+                    for (int a = 0; a < 3; a++) {
+                        const float b = sm_prim[i][a], t = sm_prim[i][3 + a];
+                        if (left) { lb[a] = b < lb[a] ? b : lb[a]; lt[a] = lt[a] < t ? t : lt[a]; }
+                        else { rb[a] = b < rb[a] ? b : rb[a]; rt[a] = rt[a] < t ? t : rt[a]; }
+                    }
+                }
+                const int countRight = (int)n - countLeft;
+                if (countLeft <= 1 || countRight <= 1) continue;
+                const float l1 = lt[0] - lb[0], l2 = lt[1] - lb[1], l3 = lt[2] - lb[2];
+                const float r1 = rt[0] - rb[0], r2 = rt[1] - rb[1], r3 = rt[2] - rb[2];
+                const float surfaceLeft = l1 * l2 + l2 * l3 + l3 * l1;
+                const float surfaceRight = r1 * r2 + r2 * r3 + r3 * r1;
+                const float cost = surfaceLeft * (float)countLeft + surfaceRight * (float)countRight;
+                if (cost < my_cost) { my_cost = cost; my_k = k; sm_nl[tid] = (uint32_t)countLeft; }
+            }
+        } else {
         for (int i = tid; i <= C; i += BV_THREADS) {
             cnt[i] = 0u;
             for (int a = 0; a < 3; a++) { lmin[a][i] = bv_enc(FLT_MAX); lmax[a][i] = bv_enc(-FLT_MAX); }
@@ -191,16 +233,14 @@ k_bvh_level(const BvLevelNode *cur, uint32_t n_cur, BvLevelNode *next, uint32_t 
         for (int i = tid; i <= C; i += BV_THREADS)
             for (int a = 0; a < 3; a++) { rmin[a][i] = lmin[a][i]; rmax[a][i] = lmax[a][i]; }
         __syncthreads();
-        bv_scan(cnt, C + 1, false, OpAdd(), 0u, scan_tmp);
+        bv_scan<BV_THREADS>(cnt, C + 1, false, OpAdd(), 0u, scan_tmp);
         for (int a = 0; a < 3; a++) {
-            bv_scan(lmin[a], C + 1, false, OpMin(), bv_enc(FLT_MAX), scan_tmp);
-            bv_scan(lmax[a], C + 1, false, OpMax(), bv_enc(-FLT_MAX), scan_tmp);
-            bv_scan(rmin[a], C + 1, true, OpMin(), bv_enc(FLT_MAX), scan_tmp);
-            bv_scan(rmax[a], C + 1, true, OpMax(), bv_enc(-FLT_MAX), scan_tmp);
+            bv_scan<BV_THREADS>(lmin[a], C + 1, false, OpMin(), bv_enc(FLT_MAX), scan_tmp);
+            bv_scan<BV_THREADS>(lmax[a], C + 1, false, OpMax(), bv_enc(-FLT_MAX), scan_tmp);
+            bv_scan<BV_THREADS>(rmin[a], C + 1, true, OpMin(), bv_enc(FLT_MAX), scan_tmp);
+            bv_scan<BV_THREADS>(rmax[a], C + 1, true, OpMax(), bv_enc(-FLT_MAX), scan_tmp);
         }
         // candidates (BVH.cc:186-206): cost = areaL * nL + areaR * nR, skipped when a side has <= 1 triangle
-        float my_cost = FLT_MAX;
-        int my_k = -1;
         for (int k = tid; k < C; k += BV_THREADS) {
             const int countLeft = (int)cnt[k], countRight = (int)n - countLeft;
             if (countLeft <= 1 || countRight <= 1) continue;
@@ -211,7 +251,8 @@ k_bvh_level(const BvLevelNode *cur, uint32_t n_cur, BvLevelNode *next, uint32_t 
             const float surfaceLeft = l1 * l2 + l2 * l3 + l3 * l1;
             const float surfaceRight = r1 * r2 + r2 * r3 + r3 * r1;
             const float cost = surfaceLeft * (float)countLeft + surfaceRight * (float)countRight;
-            if (cost < my_cost) { my_cost = cost; my_k = k; }             // increasing k: the first minimum stays
+            if (cost < my_cost) { my_cost = cost; my_k = k; sm_nl[tid] = (uint32_t)countLeft; }   // increasing k: the first minimum stays
+        }
         }
         red_cost[tid] = my_cost; red_k[tid] = my_k;
         __syncthreads();
@@ -220,12 +261,12 @@ k_bvh_level(const BvLevelNode *cur, uint32_t n_cur, BvLevelNode *next, uint32_t 
                 const float oc = red_cost[tid + s]; const int ok = red_k[tid + s];
                 const float mc = red_cost[tid]; const int mk = red_k[tid];
                 const bool take = ok >= 0 && (mk < 0 || oc < mc || (oc == mc && ok < mk));
-                if (take) { red_cost[tid] = oc; red_k[tid] = ok; }
+                if (take) { red_cost[tid] = oc; red_k[tid] = ok; sm_nl[tid] = sm_nl[tid + s]; }
             }
             __syncthreads();
         }
         if (tid == 0 && red_k[0] >= 0 && red_cost[0] < best_cost) {      // strict: an earlier axis keeps a tie
-            best_cost = red_cost[0]; best_axis = axis; best_k = red_k[0]; best_split = thr[red_k[0]]; best_nl = cnt[red_k[0]];
+            best_cost = red_cost[0]; best_axis = axis; best_k = red_k[0]; best_split = thr[red_k[0]]; best_nl = sm_nl[0];
         }
         __syncthreads();
     }
@@ -249,7 +290,7 @@ k_bvh_level(const BvLevelNode *cur, uint32_t n_cur, BvLevelNode *next, uint32_t 
         if (lane == 0) wave_left[wid] = (uint32_t)__popcll(m);
         __syncthreads();
         uint32_t before = 0, chunk_left = 0;
-        for (int w = 0; w < 4; w++) { if (w < wid) before += wave_left[w]; chunk_left += wave_left[w]; }
+        for (int w = 0; w < BV_THREADS / 64; w++) { if (w < wid) before += wave_left[w]; chunk_left += wave_left[w]; }
         const uint32_t lrank = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         if (valid) {
             const uint32_t pos = isLeft ? done_left + lrank : nL + (base - done_left) + ((uint32_t)tid - lrank);
@@ -311,7 +352,12 @@ extern "C" hipError_t mi355i_bvh_launch_level(const void *cur, uint32_t n_cur, v
                                               uint32_t *tree_count, const float4 *prim, const uint32_t *list_cur, uint32_t *list_next,
                                               int depth, uint32_t *bad, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_bvh_level, dim3(n_cur), dim3(BV_THREADS), 0, st, (const BvLevelNode *)cur, n_cur, (BvLevelNode *)next, next_count,
-                       (BvTreeNode *)tree, tree_count, prim, list_cur, list_next, depth, bad);
+    // few, large nodes: 1024 threads each; later levels: 256
+    if (n_cur <= 48u)
+        hipLaunchKernelGGL(k_bvh_level<1024>, dim3(n_cur), dim3(1024), 0, st, (const BvLevelNode *)cur, n_cur, (BvLevelNode *)next, next_count,
+                           (BvTreeNode *)tree, tree_count, prim, list_cur, list_next, depth, bad);
+    else
+        hipLaunchKernelGGL(k_bvh_level<256>, dim3(n_cur), dim3(256), 0, st, (const BvLevelNode *)cur, n_cur, (BvLevelNode *)next, next_count,
+                           (BvTreeNode *)tree, tree_count, prim, list_cur, list_next, depth, bad);
     return hipGetLastError();
 }
