@@ -85,6 +85,31 @@ def test_reference_frame_hashes(gpu_scene, pin):
         assert {k: got[k] for k in want} == want
     if pin["id"] == "cfg2":
         assert st.tris_drawn == PINS["counters"]["raster_cfg2"]["tris_drawn"]
+    if pin["mode"] >= 9:
+        # the counting frame above walks in the reference's order; the production kernel (ordered walk, shadow rays
+        # handed to idle lanes) must hash to the same reference frame and trace the same rays
+        assert hs.walk_info()[0] == 1
+        img2, _, st2 = hs.render(pin["mode"], cam, lights, n, R.default_opts(pin["w"], pin["h"], max_ray_depth=pin["depth"]))
+        assert hashlib.sha256(R.rgb_bytes(img2)).hexdigest() == pin["sha256"]
+        assert (st2.normal_rays, st2.shadow_rays) == (st.normal_rays, st.shadow_rays)
+
+
+@pytest.mark.parametrize("cfg", [
+    ("cfg5", "dragon_vis.ply", 9, 3840, 2160, 3), ("statue_depth3_1080p", "statue.ply", 9, 1920, 1080, 3),
+    ("chessboard_depth3_1080p", "chessboard.tri", 9, 1920, 1080, 3), ("dragon_aa_1080p", "dragon_vis.ply", 10, 1920, 1080, 3)],
+    ids=lambda c: c[0])
+def test_full_size_configs_counters_and_oracle(oracle, oracle_scene, gpu_scene, cfg):
+    """BASELINE config 5 (4K) and the other full-size rows of SURVEY 8(d): the reference's own counters (counting
+    frame, reference order) and the oracle's pixels (production kernel) at full size."""
+    key, mesh, mode, W, H, depth = cfg
+    hs = gpu_scene(mesh, True)
+    cam, lights, n = R.benchmark_frame(0)
+    st = hs.render(mode, cam, lights, n, R.default_opts(W, H, max_ray_depth=depth, collect_stats=1))[2].as_dict()
+    want = PINS["counters"][key]
+    assert {k: st[k] for k in want} == want
+    g, o = both_frames(oracle, oracle_scene, gpu_scene, mesh, mode, W, H, 0, want_f32=True, max_ray_depth=depth)
+    assert_same(g, o)
+    assert (g[2].normal_rays, g[2].shadow_rays) == (want["normal_rays"], want["shadow_rays"])
 
 
 @pytest.mark.parametrize("mesh", ["dragon_vis.ply", "statue.ply", "chessboard.tri"])
