@@ -212,6 +212,7 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.work_counter = (uint32_t *)((char *)c->ctrl.p + MI_CTRL_DISPENSER_OFF);
     P.counters = (unsigned long long *)((char *)c->ctrl.p + 16);
     // tuning knobs (mi355_opts::tune, 0 = default)
+    P.raster_stats = o->collect_stats ? 1 : 0;
     const int32_t *t = o->tune;
     const int flags = t[5];
     P.xmin = t[0] > 0 ? (t[0] > 64 ? 64 : t[0]) : 16;
@@ -223,7 +224,6 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.blocks_per_cu = t[4] > 0 ? t[4] : 0;
     P.exact_box = (flags & 1) ? 1 : 0;
     if (!c->boxes_tame) P.exact_box = 1;     // box coordinates outside the filtered test's validated range
-    P.scatter = 0;      // flag 16 is reserved
     P.wave_prof = nullptr;
     if (o->collect_stats) {
         if (c->wave_prof.ensure((size_t)8 * c->n_cus * 4 * 16 * 8) == hipSuccess) P.wave_prof = (unsigned long long *)c->wave_prof.p;

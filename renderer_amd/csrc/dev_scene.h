@@ -97,6 +97,7 @@ struct FrameParams {
     float *outf;               // optional r,g,b floats (raytrace)
     unsigned long long *counters; // device counters (see CounterSlot)
     uint32_t *work_counter;    // persistent-kernel pixel dispenser: MI_DISPENSERS counters, MI_DISPENSER_STRIDE words apart
+    int32_t raster_stats;      // rasterizer: fill the tris_drawn / spans / ztests / plots counters (collect_stats)
     int32_t xmin;              // service state transitions once this many lanes wait (or nobody traverses)
     int32_t rmin;              // refill once this many lanes are idle (or nobody is alive)
     int32_t chunk;             // pixel indices a wave takes from the dispenser at a time
@@ -104,7 +105,6 @@ struct FrameParams {
     int32_t ref_order;         // walk in the reference's fixed left-first order even when the ordered walk is available
     int32_t no_help;           // ordered walk: never hand shadow rays to idle lanes
     int32_t prof_ordered;      // counting frames profile the ordered walk instead of reproducing the reference's counters
-    int32_t scatter;           // reserved (was: scattered pixel dispensing)
     unsigned long long *wave_prof; // counting builds: 16 words of phase profile per wave (debug), or NULL
     const uint32_t *tile_order; // dispenser index -> 8x8 tile id (heavy tiles first), or NULL = row-major
     int32_t blocks_per_cu;     // 0 = occupancy query

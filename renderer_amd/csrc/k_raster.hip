@@ -477,7 +477,7 @@ __global__ void __launch_bounds__(128) k_rs_tri(const DevScene S, const FramePar
             f[k][5] = nc.x; f[k][6] = nc.y; f[k][7] = nc.z;
         }
     }
-    if (P.counters) atomicAdd(&P.counters[CS_TRIS_DRAWN], 1ull);
+    if (P.counters && P.raster_stats) atomicAdd(&P.counters[CS_TRIS_DRAWN], 1ull);
     tri_alloc<N>(iy[0], iy[1], iy[2], f[0], f[1], f[2], P.H, P.W, t, rows_cap, work_cap, tris, tris_cap, rcwork, rcwork_cap, ctl);
 }
 
@@ -589,11 +589,11 @@ __global__ void __launch_bounds__(256) k_rs_spans(const DevScene S, const FrameP
         }
     }
     if (P.counters && !ATTR) {
-        if (ztests) atomicAdd(&P.counters[CS_ZTESTS], ztests);
+        if (ztests && P.raster_stats) atomicAdd(&P.counters[CS_ZTESTS], ztests);
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             uint32_t n_rows = ctl[0];
             if (n_rows > P.rows_cap) n_rows = P.rows_cap;
-            atomicAdd(&P.counters[CS_SPANS], (unsigned long long)n_rows);
+            if (P.raster_stats) atomicAdd(&P.counters[CS_SPANS], (unsigned long long)n_rows);
             if (ctl[1]) atomicAdd(&P.counters[CS_OVERFLOW], (unsigned long long)ctl[1]);
         }
     }
@@ -633,7 +633,7 @@ __global__ void __launch_bounds__(256) k_rs_shade(const DevScene S, const FrameP
         P.out[(size_t)orow * P.pitch_words + x] = out;
         plots++;
     }
-    if (P.counters && plots) atomicAdd(&P.counters[CS_PLOTS], plots);
+    if (P.counters && plots && P.raster_stats) atomicAdd(&P.counters[CS_PLOTS], plots);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -4,24 +4,32 @@
 // and RayIntersectsBox (Raytracer.cc:99-606) and the scanline loop of Scene::renderRaytracer
 // (Raytracer.cc:791-868).  One launch renders a whole frame (or this GPU's screen bands).
 //
-// MI355X design (DESIGN.md 4.1; every choice below is backed by a measurement in profiles/):
+// MI355X design (DESIGN.md 3 and 4.1; every choice below is backed by a measurement in profiles/):
 //  * A lane owns one PIXEL and walks its whole ray tree as a small state machine:
 //    closest-hit walk -> shading -> one any-hit shadow walk per light -> reflection walk ... ->
 //    fold the per-depth colours.  The reference's recursion (Raytracer.cc:315-553) becomes
 //    forward evaluation + a backward fold with the same clamping Pixel::operator+ at each level.
 //  * Wavefronts are persistent: a lane that finishes its pixel pulls the next one from a dispenser
-//    (ballot + mbcnt ranking, one global atomic per 64 pixels), so the 64 lanes stay packed although
-//    ~88 % of primary rays die at the root box.
-//  * The walk is STACKLESS: the reference pops an explicit stack in a fixed left-first order that
-//    does not depend on the ray, so every record carries the link to follow on a hit and on a miss;
-//    following them visits exactly the reference's node sequence.
-//  * A frame lasts as long as its longest chain of dependent steps (~1000 node visits for the
-//    worst pixel), so a step is built around ONE wait on memory: every record is 32 bytes in one buffer
-//    (address = base + 16*link; the root's record rides in the kernel arguments), the records behind
-//    BOTH links of a node are requested first, then the box / plane arithmetic runs, and a triangle
-//    that passes the plane test has its edge record requested at the end of the step and judged at
-//    the wait point of the lane's NEXT step -- legal because a candidate only updates the running
-//    best, never the visiting order.
+//    (ballot + mbcnt ranking, one global atomic per 8x8 tile, eight counters), so the 64 lanes stay
+//    packed although ~88 % of primary rays die at the root box.
+//  * Two walks over the same tree, both bit-identical to the reference:
+//    - ORDERED (production): near child first with a per-lane stack (top in a register, rest in LDS),
+//      both children's boxes tested per step from a 64-byte wide record, subtrees beyond the best hit
+//      skipped.  Legal because the reference's result is an order-free function of the accepted hits
+//      (smallest squared distance, ties to the lowest list position; shadow rays: an OR) -- what has
+//      to be preserved is WHICH triangles are tested, and that is decided with the reference's own
+//      box predicate on inner nodes and a provably conservative cull (dev_scene.h, capi.hip checks).
+//    - reference order (counting frames, unchecked trees): the reference pops an explicit stack in a
+//      fixed left-first order that does not depend on the ray, so every record carries the link to
+//      follow on a hit and on a miss; following them visits exactly the reference's node sequence.
+//  * The loop is instruction bound (~400 instructions per step, one wave issues a dependent VALU
+//    instruction every ~4.6 cycles), so a step is built around ONE wait on memory: 32-byte records in
+//    one buffer (address = base + 16*link; the root's record rides in the kernel arguments), the next
+//    record is requested as soon as it is known, and a triangle that passes the plane test has its
+//    edge record requested at the end of the step and judged during the lane's NEXT step -- legal
+//    because a candidate only updates the running best, never the visiting order.
+//  * A pixel's shadow rays feed its colour, not its reflection ray: at a fresh hit a lane without a
+//    pixel takes over the light loop while the owner goes on with the reflection.
 //
 // Arithmetic follows the cited reference lines operation by operation (dev_math.h).
 #include "dev_math.h"

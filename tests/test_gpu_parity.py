@@ -227,6 +227,8 @@ def test_raster_modes(oracle, oracle_scene, gpu_scene, mesh, mode):
     g, o = both_frames(oracle, oracle_scene, gpu_scene, mesh, mode, 800, 600, 4)
     assert_same(g, o)
     if mode >= 4:
+        g, o = both_frames(oracle, oracle_scene, gpu_scene, mesh, mode, 800, 600, 4, collect_stats=1)
+        assert_same(g, o)
         assert g[2].tris_drawn == o[2].tris_drawn and g[2].spans == o[2].spans and g[2].ztests == o[2].ztests
 
 
