@@ -317,29 +317,61 @@ MI_DEV void emit_rows(int iy0, int iy1, int iy2, const float (&A)[N], const floa
 // tri_alloc: row range, row records and span-chunk slots of one triangle; one (record, row chunk) item per
 // MI_ROW_CHUNK scanlines.  rows_emit: one such item -- the three edge walkers are re-initialised and their
 // serial `vtc += d12` additions (ScanConverter.h:112-116) replayed in registers up to the chunk's first row.
+// Block-cooperative: every thread of the 256-thread block calls it (valid = this thread has a triangle to draw).  The
+// four reservations are summed over the block first, so the device-wide counters see four atomics per block, not
+// per wave -- same-address atomics serialise at ~10 ns each and were most of this kernel's time.
 template <int N>
-MI_DEV void tri_alloc(int iy0, int iy1, int iy2, const float (&A)[N], const float (&B)[N], const float (&C)[N], int height,
+MI_DEV void tri_alloc(bool valid, int iy0, int iy1, int iy2, const float (&A)[N], const float (&B)[N], const float (&C)[N], int height,
                       int W, uint32_t tri, uint32_t rows_cap, uint32_t work_cap, TriRec *tris, uint32_t tris_cap,
                       uint2 *rcwork, uint32_t rcwork_cap, uint32_t *ctl)
 {
+    __shared__ uint32_t wave_tot[4][4];
+    __shared__ uint32_t block_base[4];
     const int INT_MIN_ = (int)0x80000000;
-    if (iy0 == INT_MIN_ || iy1 == INT_MIN_ || iy2 == INT_MIN_) return;    // NaN / overflowed projections
+    if (iy0 == INT_MIN_ || iy1 == INT_MIN_ || iy2 == INT_MIN_) valid = false;    // NaN / overflowed projections
     int miny = min(iy0, min(iy1, iy2)), maxy = max(iy0, max(iy1, iy2));
     if (miny < 0) miny = 0;
     if (maxy > height - 1) maxy = height - 1;
-    if (miny > maxy) return;
-    const uint32_t nrows = (uint32_t)(maxy - miny + 1);
-    float xlo = A[0] < B[0] ? A[0] : B[0]; xlo = xlo < C[0] ? xlo : C[0];
-    float xhi = A[0] > B[0] ? A[0] : B[0]; xhi = xhi > C[0] ? xhi : C[0];
-    if (!(xlo > -1.f)) xlo = -1.f;
-    if (!(xhi < (float)W)) xhi = (float)W;
-    const float wpx = xhi - xlo;
-    const uint32_t slots_per_row = (wpx > 0.f ? (uint32_t)(wpx * (1.0f / MI_SPAN_CHUNK)) : 0u) + 2u;
-    const uint32_t nrc = (nrows + MI_ROW_CHUNK - 1) / MI_ROW_CHUNK;
-    const uint32_t rows_base = atomicAdd(&ctl[0], nrows);
-    const uint32_t work_base = atomicAdd(&ctl[2], slots_per_row * nrows);
-    const uint32_t ti = atomicAdd(&ctl[3], 1u);
-    const uint32_t rcb = atomicAdd(&ctl[4], nrc);
+    if (miny > maxy) valid = false;
+    uint32_t nrows = 0, slots_per_row = 0, nrc = 0;
+    if (valid) {
+        nrows = (uint32_t)(maxy - miny + 1);
+        float xlo = A[0] < B[0] ? A[0] : B[0]; xlo = xlo < C[0] ? xlo : C[0];
+        float xhi = A[0] > B[0] ? A[0] : B[0]; xhi = xhi > C[0] ? xhi : C[0];
+        if (!(xlo > -1.f)) xlo = -1.f;
+        if (!(xhi < (float)W)) xhi = (float)W;
+        const float wpx = xhi - xlo;
+        slots_per_row = (wpx > 0.f ? (uint32_t)(wpx * (1.0f / MI_SPAN_CHUNK)) : 0u) + 2u;
+        nrc = (nrows + MI_ROW_CHUNK - 1) / MI_ROW_CHUNK;
+    }
+    // ctl words: [0] rows, [2] span slots, [3] triangle records, [4] row-chunk items
+    const uint32_t want[4] = {nrows, slots_per_row * nrows, valid ? 1u : 0u, nrc};
+    const int lane = (int)(threadIdx.x & 63u), wid = (int)(threadIdx.x >> 6);
+    uint32_t incl[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t v = want[k];
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)v, off); if (lane >= off) v += o; }
+        incl[k] = v;
+        if (lane == 63) wave_tot[wid][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4u) {
+        const int k = (int)threadIdx.x;
+        const uint32_t total = wave_tot[0][k] + wave_tot[1][k] + wave_tot[2][k] + wave_tot[3][k];
+        const int word = k == 0 ? 0 : k + 1;
+        block_base[k] = total ? atomicAdd(&ctl[word], total) : 0u;
+    }
+    __syncthreads();
+    if (!valid) return;
+    uint32_t base[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t before = 0;
+        for (int w = 0; w < wid; w++) before += wave_tot[w][k];
+        base[k] = block_base[k] + before + incl[k] - want[k];
+    }
+    const uint32_t rows_base = base[0], work_base = base[1], ti = base[2], rcb = base[3];
     if (rows_base + nrows > rows_cap || work_base + slots_per_row * nrows > work_cap || ti >= tris_cap || rcb + nrc > rcwork_cap) {
         atomicAdd(&ctl[1], nrows);
         // keep the item lists consistent: the items of a dropped triangle are marked invalid
@@ -415,19 +447,16 @@ MI_DEV int out_row(const FrameParams &P, int y)
 
 // ---------------------------------------------------------------------------------------------
 // Triangle setup: Rasterizers.cc:253-309 + Filler<> (Fillers.h:176-300) + edge walk
+// (false = the reference does not draw this triangle)
 template <int MODE>
-__global__ void __launch_bounds__(128) k_rs_tri(const DevScene S, const FrameParams P, uint32_t rows_cap, uint32_t *ctl,
-                                                uint32_t work_cap, TriRec *tris, uint32_t tris_cap, uint2 *rcwork,
-                                                uint32_t rcwork_cap)
+MI_DEV bool tri_prepare(const DevScene &S, const FrameParams &P, uint32_t t, float (&f)[3][FatN<MODE>::N], int (&iy)[3])
 {
     constexpr int N = FatN<MODE>::N;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= S.n_tris) return;
     const float4 c4 = S.rs_tri[(size_t)t * 2], n4 = S.rs_tri[(size_t)t * 2 + 1];
     const f3 eye = mk3(P.eye[0], P.eye[1], P.eye[2]);
     if (__float_as_uint(c4.w) == 0u) {                                   // !_twoSided
         const f3 triToEye = sub3(eye, mk3(c4.x, c4.y, c4.z));
-        if (dot3(triToEye, mk3(n4.x, n4.y, n4.z)) < 0.f) return;
+        if (dot3(triToEye, mk3(n4.x, n4.y, n4.z)) < 0.f) return false;
     }
     const uint4 id = S.rs_idx[t];
     const uint32_t vid[3] = {id.x, id.y, id.z};
@@ -438,15 +467,15 @@ __global__ void __launch_bounds__(128) k_rs_tri(const DevScene S, const FramePar
         cs[k] = mulright(P.mv, sub3(mk3(pv.x, pv.y, pv.z), eye));
         ao[k] = pv.w;
     }
-    if (cs[0].z < P.clip_z) return;                                       // Rasterizers.cc:275-281
-    if (cs[1].z < P.clip_z) return;
-    if (cs[2].z < P.clip_z) return;
+    if (cs[0].z < P.clip_z) return false;                                 // Rasterizers.cc:275-281
+    if (cs[1].z < P.clip_z) return false;
+    if (cs[2].z < P.clip_z) return false;
     float py[3], pxs[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) py[k] = (float)(P.H / 2) - (float)P.SD * cs[k].x / cs[k].z;
-    if (py[0] < 0.f && py[1] < 0.f && py[2] < 0.f) return;
+    if (py[0] < 0.f && py[1] < 0.f && py[2] < 0.f) return false;
     const float fH = (float)P.H;
-    if (py[0] >= fH && py[1] >= fH && py[2] >= fH) return;
+    if (py[0] >= fH && py[1] >= fH && py[2] >= fH) return false;
 #pragma unroll
     for (int k = 0; k < 3; k++) pxs[k] = (float)(P.W / 2) + (float)P.SD * cs[k].y / cs[k].z;
     if (MODE != M_AMBIENT) {
@@ -454,7 +483,6 @@ __global__ void __launch_bounds__(128) k_rs_tri(const DevScene S, const FramePar
         for (int k = 0; k < 3; k++) { const float4 nv = S.rs_vert[(size_t)vid[k] * 2 + 1]; vn[k] = mk3(nv.x, nv.y, nv.z); }
     }
     const float4 col = S.rs_col[t];
-    float f[3][N]; int iy[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         iy[k] = cvtt_i32(py[k]);
@@ -477,8 +505,25 @@ __global__ void __launch_bounds__(128) k_rs_tri(const DevScene S, const FramePar
             f[k][5] = nc.x; f[k][6] = nc.y; f[k][7] = nc.z;
         }
     }
-    if (P.counters && P.raster_stats) atomicAdd(&P.counters[CS_TRIS_DRAWN], 1ull);
-    tri_alloc<N>(iy[0], iy[1], iy[2], f[0], f[1], f[2], P.H, P.W, t, rows_cap, work_cap, tris, tris_cap, rcwork, rcwork_cap, ctl);
+    return true;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_rs_tri(const DevScene S, const FrameParams P, uint32_t rows_cap, uint32_t *ctl,
+                                                uint32_t work_cap, TriRec *tris, uint32_t tris_cap, uint2 *rcwork,
+                                                uint32_t rcwork_cap)
+{
+    constexpr int N = FatN<MODE>::N;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    float f[3][N];
+    int iy[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int i = 0; i < N; i++) f[k][i] = 0.f;
+    const bool valid = t < S.n_tris && tri_prepare<MODE>(S, P, t, f, iy);
+    if (valid && P.counters && P.raster_stats) atomicAdd(&P.counters[CS_TRIS_DRAWN], 1ull);
+    tri_alloc<N>(valid, iy[0], iy[1], iy[2], f[0], f[1], f[2], P.H, P.W, t, rows_cap, work_cap, tris, tris_cap, rcwork, rcwork_cap, ctl);
 }
 
 // Edge walk of MI_ROW_CHUNK scanlines of one drawn triangle (ScanConverter.h:27-137 + row clipping of Screen.h:244-275)
@@ -794,8 +839,8 @@ static hipError_t raster_frame(const DevScene *S, const FrameParams *Pin, Raster
     FrameParams Pv = *Pin;
     Pv.rows_cap = s->rows_cap;
     const FrameParams *P = &Pv;
-    const int nbT = (int)((S->n_tris + 127) / 128);
-    hipLaunchKernelGGL((k_rs_tri<MODE>), dim3(nbT > 0 ? nbT : 1), dim3(128), 0, st, *S, *P, s->rows_cap, s->ctl, s->work_cap, s->tris, s->tris_cap, s->rcwork, s->rcwork_cap);
+    const int nbT = (int)((S->n_tris + 255) / 256);
+    hipLaunchKernelGGL((k_rs_tri<MODE>), dim3(nbT > 0 ? nbT : 1), dim3(256), 0, st, *S, *P, s->rows_cap, s->ctl, s->work_cap, s->tris, s->tris_cap, s->rcwork, s->rcwork_cap);
     hipLaunchKernelGGL((k_rs_rows<MODE>), dim3(1024), dim3(128), 0, st, *P, s->tris, s->rcwork, s->rcwork_cap, s->ctl, s->rows, s->work);
     hipLaunchKernelGGL((k_rs_spans<MODE, false>), dim3(2048), dim3(256), 0, st, *S, *P, s->rows, s->ctl, s->work, s->work_cap, s->keys, s->gbuf);
     hipLaunchKernelGGL((k_rs_spans<MODE, true>), dim3(2048), dim3(256), 0, st, *S, *P, s->rows, s->ctl, s->work, s->work_cap, s->keys, s->gbuf);
