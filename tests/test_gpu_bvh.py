@@ -122,3 +122,53 @@ def test_frames_after_a_device_build_match_the_pins():
     h = R.Scene(R.assets.mesh_path("dragon_vis.ply"))
     h.bvh_create("host")
     assert (img == h.render(9, cam, lights, n, R.default_opts(640, 360))[0]).all()
+
+
+# ---- traced frames over synthetic trees: the tie rules of the ordered walk ---------------------------------------------
+def write_coloured_ply(path, verts, faces, colours):
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nelement face %d\nend_header\n" % (len(verts), len(faces)))
+        for v in verts:
+            f.write("%s %s %s 200\n" % tuple(repr(float(x)) for x in v))
+        for t, c in zip(faces, colours):
+            f.write("3 %d %d %d %d %d %d\n" % (tuple(t) + tuple(c)))
+
+
+@pytest.mark.parametrize("case", ["stacked_duplicates", "coplanar_overlaps", "random_soup"])
+def test_traced_frames_on_synthetic_meshes_match_the_oracle(case, tmp_path, oracle):
+    """Equal hit distances are where an order-free walk could differ from the reference's first-found-wins: identical
+    triangles in different colours (every ray has several hits at exactly the same distance) and overlapping coplanar
+    ones.  The production kernel (near-first walk, shadow rays on helper lanes) must give the oracle's pixels."""
+    rng = np.random.default_rng({"stacked_duplicates": 11, "coplanar_overlaps": 12, "random_soup": 13}[case])
+    if case == "stacked_duplicates":
+        v0, f0 = soup(rng, 60, scale=1.0)
+        verts = np.tile(v0 * 4.0, (5, 1))                                   # five copies of every triangle
+        faces = np.arange(verts.shape[0]).reshape(-1, 3)
+    elif case == "coplanar_overlaps":
+        n = 250
+        c = rng.uniform(-1, 1, (n, 1, 3)) * np.array([1, 1, 0.0])
+        tri = c + rng.uniform(-0.4, 0.4, (n, 3, 3)) * np.array([1, 1, 0.0])
+        tri[:, :, 2] = np.round(rng.uniform(-1, 1, (n, 1)) * 2) / 2          # a few shared planes z = -1, -0.5, .. 1
+        verts = tri.reshape(-1, 3)
+        faces = np.arange(3 * n).reshape(n, 3)
+    else:
+        verts, faces = soup(rng, 1500)
+        verts = verts * np.array([1.0, 1.0, 1.0])
+    colours = rng.integers(30, 255, (faces.shape[0], 3))
+    p = str(tmp_path / (case + ".ply"))
+    write_coloured_ply(p, verts, faces, colours)
+    g = R.Scene(p)
+    g.bvh_create("device")
+    o = oracle.Scene(p)
+    o.bvh_build()
+    assert g.walk_info()[0] == 1
+    for frame in (0, 23, 61):
+        cam, lights, n = R.benchmark_frame(frame)
+        ocam, olights, on = oracle.benchmark_frame(frame)
+        W, H = 400, 300
+        img, f32, st = g.render(9, cam, lights, n, R.default_opts(W, H), want_f32=True)
+        oimg, of32, ost = o.render(9, ocam, olights, on, oracle.default_opts(W, H, threads=os.cpu_count() or 1), want_f32=True)
+        assert int((img != oimg).sum()) == 0, "%s frame %d: %d pixels differ" % (case, frame, int((img != oimg).sum()))
+        assert float(np.abs(f32 - of32).max()) == 0.0
+        assert (st.normal_rays, st.shadow_rays) == (ost.normal_rays, ost.shadow_rays)
+        assert int((img != 0).sum()) > 500, "the case is meant to put the mesh on screen"
