@@ -6,6 +6,7 @@ order-dependent corners: equal centroids, signed zeros, flat and tiny nodes."""
 import hashlib
 import json
 import os
+import zlib
 
 import numpy as np
 import pytest
@@ -85,7 +86,7 @@ CASES = {
 
 @pytest.mark.parametrize("case", list(CASES), ids=[k.split(" ")[0] for k in CASES])
 def test_gpu_builder_matches_host_builder_on_synthetic_meshes(case, tmp_path):
-    rng = np.random.default_rng(abs(hash(case.split(" ")[0])) % (2 ** 31))
+    rng = np.random.default_rng(zlib.crc32(case.encode()))         # fixed inputs from run to run
     verts, faces = CASES[case](rng)
     p = str(tmp_path / "m.ply")
     write_ply(p, verts, faces)
