@@ -161,6 +161,18 @@ def default_opts(width: int, height: int, **kw) -> Opts:
     return o
 
 
+_EXITING = False
+
+
+def _mark_exit():
+    global _EXITING
+    _EXITING = True
+
+
+import atexit as _atexit  # noqa: E402
+_atexit.register(_mark_exit)
+
+
 def tune(xmin=0, rmin=0, chunk=0, lmin=0, bpc=0, exact=0, rowmajor=0, scatter=0, reforder=0, profordered=0, nohelp=0):
     """mi355_opts::tune as a list (see include/mi355_render.h); every knob leaves the pixels unchanged.
     (lmin and scatter are accepted for old scripts and ignored.)"""
@@ -222,6 +234,10 @@ class Scene:
             self._h = None
 
     def __del__(self):
+        # at interpreter exit the HIP runtime may already be gone: freeing device memory then can crash the process
+        # after all the work is done, so scenes still alive at exit are left to the OS
+        if _EXITING:
+            return
         try:
             self.close()
         except Exception:

@@ -25,7 +25,7 @@ extern "C" hipError_t mi355i_bvh_launch_prims(const float4 *rs_vert, const uint4
                                               uint32_t *bad, hipStream_t st);
 extern "C" hipError_t mi355i_bvh_launch_level(const void *cur, uint32_t n_cur, void *next, uint32_t *next_count, void *tree,
                                               uint32_t *tree_count, const float4 *prim, const uint32_t *list_cur, uint32_t *list_next,
-                                              int depth, uint32_t *bad, hipStream_t st);
+                                              int depth, int many_planes, uint32_t *bad, hipStream_t st);
 extern "C" hipError_t mi355i_launch_points(const DevScene *, const FrameParams *, int as_triangles, hipStream_t);
 struct RasterScratch;
 extern "C" hipError_t mi355i_launch_raster(const DevScene *, const FrameParams *, int mode, RasterScratch *,
@@ -644,22 +644,33 @@ int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_
         for (int a = 0; a < 3; a++) { root.bb[a] = gb[a]; root.bb[3 + a] = gt[a]; }
     }
     HIP_TRY(hipMemcpy(lvl[0].p, &root, sizeof root, hipMemcpyHostToDevice), -31);
+    {
+        uint32_t flags = 0;
+        HIP_TRY(hipMemcpy(&flags, d_cnt + 2, 4, hipMemcpyDeviceToHost), -31);     // (also waits for k_bvh_prims)
+        if (flags & 1u) return fail(-50, "mi355_build_bvh: non-finite vertex coordinates (use the host builder)");
+    }
     const double t_setup = clk();
+    uint32_t tree_before = 1;          // tree nodes allocated so far (the root)
     uint32_t n_cur = 1;
     int cur = 0, depth = 0;
     while (n_cur) {
         if (depth >= 64) return fail(-51, "BVH deeper than 64 levels");
         if (n_cur > max_level_nodes) return fail(-51, "BVH level %d has %u nodes", depth, n_cur);
         const double t_l0 = clk();
-        HIP_TRY(hipMemsetAsync(d_cnt, 0, 4, c->stream), -40);
-        e = mi355i_bvh_launch_level(lvl[cur].p, n_cur, lvl[1 - cur].p, d_cnt, tree.p, d_cnt + 1, (const float4 *)prim.p,
-                                    (const uint32_t *)list[cur].p, (uint32_t *)list[1 - cur].p, depth, d_cnt + 2, c->stream);
-        if (e != hipSuccess) return fail(-43, "BVH level launch failed: %s", hipGetErrorString(e));
         uint32_t h[3];
-        HIP_TRY(hipMemcpyAsync(h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream), -31);
-        HIP_TRY(hipStreamSynchronize(c->stream), -40);
-        if (h[2] & 1u) return fail(-50, "mi355_build_bvh: non-finite vertex coordinates (use the host builder)");
-        if (h[2] & 2u) return fail(-50, "mi355_build_bvh: more than 1100 candidate planes on an axis");
+        for (int many = 0; many < 2; many++) {
+            // a node with more candidate planes than the fast build holds: redo the level with the large one
+            const uint32_t reset[3] = {0u, tree_before, 0u};
+            HIP_TRY(hipMemcpyAsync(d_cnt, reset, sizeof reset, hipMemcpyHostToDevice, c->stream), -31);
+            e = mi355i_bvh_launch_level(lvl[cur].p, n_cur, lvl[1 - cur].p, d_cnt, tree.p, d_cnt + 1, (const float4 *)prim.p,
+                                        (const uint32_t *)list[cur].p, (uint32_t *)list[1 - cur].p, depth, many, d_cnt + 2, c->stream);
+            if (e != hipSuccess) return fail(-43, "BVH level launch failed: %s", hipGetErrorString(e));
+            HIP_TRY(hipMemcpyAsync(h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream), -31);
+            HIP_TRY(hipStreamSynchronize(c->stream), -40);
+            if (!(h[2] & 2u)) break;
+        }
+        if (h[2] & 6u) return fail(-50, "mi355_build_bvh: more than 2200 candidate planes on an axis (use the host builder)");
+        tree_before = h[1];
         g_bvh_level_ms[depth] = clk() - t_l0; g_bvh_level_nodes[depth] = n_cur; g_bvh_levels = depth + 1;
         n_cur = h[0];
         cur = 1 - cur;

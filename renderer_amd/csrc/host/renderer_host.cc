@@ -598,6 +598,10 @@ void Scene::CreateBVH(BvhBuilderChoice where)
         }
     }
     _bvhBuiltOnDevice = false;
+    // The reference's plane loop (`testSplit += step`, BVH.cc:154) never ends on a box with non-finite corners, which is
+    // what a mesh collapsed to a point becomes in the loader's rescale (Loader.cc:418-454 divides by its extent): refuse.
+    for (float x : _vertexPos)
+        if (!(std::fabs(x) <= FLT_MAX)) raise("CreateBVH: the scene has non-finite vertex coordinates (a mesh without extent?)");
     BvhBuilder b(*this);
     b.build();
     if (b.leafTris.size() != numTriangles()) raise("Internal bug in CreateCFBVH, please report it...");

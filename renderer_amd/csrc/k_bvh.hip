@@ -22,7 +22,10 @@
 
 namespace {
 
-enum { BV_MAX_PLANES = 1100, BV_SMALL = 96 };
+enum { BV_SMALL = 96 };
+// Candidate planes per axis: nominally 1024/(depth+1), but `testSplit += step` rounds, and on a thin axis (extent just
+// above the 1e-4 cut) the step is about one ulp of the coordinate, so up to ~2x as many.  The level kernel is built for
+// 1100 (two workgroups per CU) and for 2200 planes; the host reruns a level with the larger one when a node needs it.
 
 struct BvLevelNode { uint32_t first, count, tree, pad; float bb[6]; float pad2[2]; };   // 48 B
 struct BvTreeNode { float bb[6]; uint32_t a, b; };                                       // inner: child tree indices; leaf: 0x80000000|count, first
@@ -40,10 +43,11 @@ k_bvh_prims(const float4 *rs_vert, const uint4 *rs_idx, uint32_t T, float4 *prim
     const uint4 ix = rs_idx[t];
     const uint32_t v[3] = {ix.x, ix.y, ix.z};
     float b[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, tp[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    bool ok = true;
     for (int k = 0; k < 3; k++) {
         const float4 p = rs_vert[(size_t)v[k] * 2];
         const float q[3] = {p.x, p.y, p.z};
-        for (int a = 0; a < 3; a++) { b[a] = (q[a] < b[a]) ? q[a] : b[a]; }
+        for (int a = 0; a < 3; a++) { b[a] = (q[a] < b[a]) ? q[a] : b[a]; ok = ok && __builtin_fabsf(q[a]) <= FLT_MAX; }   // (false for NaN)
     }
     for (int k = 0; k < 3; k++) {
         const float4 p = rs_vert[(size_t)v[k] * 2];
@@ -51,7 +55,6 @@ k_bvh_prims(const float4 *rs_vert, const uint4 *rs_idx, uint32_t T, float4 *prim
         for (int a = 0; a < 3; a++) { tp[a] = (tp[a] < q[a]) ? q[a] : tp[a]; }
     }
     float c[3];
-    bool ok = true;
     for (int a = 0; a < 3; a++) {
         float x = tp[a]; x += b[a]; x *= 0.5f;
         c[a] = x;
@@ -113,7 +116,7 @@ struct OpMax { __device__ uint32_t operator()(uint32_t x, uint32_t y) const { re
 
 // ---- one level of the build: one workgroup per node ------------------------------------------------------
 // (BV_THREADS = 1024 for the first levels, whose few nodes hold most of the triangles each; 256 below)
-template <int BV_THREADS>
+template <int BV_THREADS, int BV_MAX_PLANES>
 __global__ void __launch_bounds__(BV_THREADS)
 k_bvh_level(const BvLevelNode *cur, uint32_t n_cur, BvLevelNode *next, uint32_t *next_count, BvTreeNode *tree,
             uint32_t *tree_count, const float4 *prim, const uint32_t *list_cur, uint32_t *list_next, int depth, uint32_t *bad)
@@ -176,7 +179,7 @@ k_bvh_level(const BvLevelNode *cur, uint32_t n_cur, BvLevelNode *next, uint32_t 
         if (tid == 0) {
             int C = 0;
             for (float testSplit = start + step; testSplit < stop - step; testSplit += step) {   // BVH.cc:154
-                if (C >= BV_MAX_PLANES) { atomicOr(bad, 2u); break; }
+                if (C >= BV_MAX_PLANES) { atomicOr(bad, BV_MAX_PLANES < 2000 ? 2u : 4u); break; }
                 thr[C++] = testSplit;
             }
             sh_C = C;
@@ -350,14 +353,13 @@ extern "C" hipError_t mi355i_bvh_launch_prims(const float4 *rs_vert, const uint4
 
 extern "C" hipError_t mi355i_bvh_launch_level(const void *cur, uint32_t n_cur, void *next, uint32_t *next_count, void *tree,
                                               uint32_t *tree_count, const float4 *prim, const uint32_t *list_cur, uint32_t *list_next,
-                                              int depth, uint32_t *bad, hipStream_t st)
+                                              int depth, int many_planes, uint32_t *bad, hipStream_t st)
 {
     // few, large nodes: 1024 threads each; later levels: 256
-    if (n_cur <= 48u)
-        hipLaunchKernelGGL(k_bvh_level<1024>, dim3(n_cur), dim3(1024), 0, st, (const BvLevelNode *)cur, n_cur, (BvLevelNode *)next, next_count,
-                           (BvTreeNode *)tree, tree_count, prim, list_cur, list_next, depth, bad);
-    else
-        hipLaunchKernelGGL(k_bvh_level<256>, dim3(n_cur), dim3(256), 0, st, (const BvLevelNode *)cur, n_cur, (BvLevelNode *)next, next_count,
-                           (BvTreeNode *)tree, tree_count, prim, list_cur, list_next, depth, bad);
+#define BV_LAUNCH(T, M) hipLaunchKernelGGL((k_bvh_level<T, M>), dim3(n_cur), dim3(T), 0, st, (const BvLevelNode *)cur, n_cur, (BvLevelNode *)next, \
+                                           next_count, (BvTreeNode *)tree, tree_count, prim, list_cur, list_next, depth, bad)
+    if (n_cur <= 48u) { if (many_planes) BV_LAUNCH(1024, 2200); else BV_LAUNCH(1024, 1100); }
+    else { if (many_planes) BV_LAUNCH(256, 2200); else BV_LAUNCH(256, 1100); }
+#undef BV_LAUNCH
     return hipGetLastError();
 }

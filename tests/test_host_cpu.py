@@ -161,3 +161,16 @@ def test_tiny_ply_with_and_without_colours(tmp_path, oracle):
     assert np.array_equal(bits(a["vertex_normal"]), bits(o.vertices()[1]))
     assert np.array_equal(bits(a["tri_e"]), bits(t["plane"][:, 4:13]))
     assert h.bvh_create() == 1      # < 4 triangles: a single leaf
+
+
+@pytest.mark.timeout(120)
+def test_mesh_without_extent_is_refused_not_hung(tmp_path):
+    """A mesh collapsed to a point becomes NaN in the loader's rescale (division by its extent, Loader.cc:418-454); the
+    reference's plane loop (BVH.cc:154) then never ends.  The builders here refuse such a scene instead."""
+    ply = tmp_path / "point.ply"
+    ply.write_text("ply\nformat ascii 1.0\nelement vertex 15\nelement face 5\nend_header\n" + "1 2 3 10\n" * 15 +
+                   "".join("3 %d %d %d\n" % (3 * i, 3 * i + 1, 3 * i + 2) for i in range(5)))
+    s = R.Scene(str(ply))
+    assert not np.isfinite(s.arrays()["vertex_pos"]).all()
+    with pytest.raises(R.Mi355Error, match="non-finite"):
+        s.bvh_create("host")
