@@ -188,6 +188,9 @@ def main():
         if world == 1 and os.path.exists(tfile):
             try:
                 result["roofline"]["traffic"] = json.load(open(tfile)).get("k_raytrace_hbm_bytes_per_launch")
+                if result["roofline"]["traffic"]:
+                    # measured HBM rate of the traversal kernel (PMC bytes of profiles/traffic.json over this run's kernel time)
+                    result["roofline"]["measured_hbm_GBs"] = round(result["roofline"]["traffic"] / (kernel_ms * 1e-3) / 1e9, 2)
             except Exception:
                 pass
 
