@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- the reference's headline benchmark on MI355X.
 
-A "step" is one frame of the hot path: `renderer -b -m 9 dragon_vis.ply` at 1920x1080 (BVH raytrace
-with shadow rays and 2 reflection bounces, BASELINE.json configs[3]), camera k of the reference's
-auto-spin orbit, scene + BVH resident in HBM, frame left in HBM.  value = Mrays/s over all GPUs
-(a ray = one BVH_IntersectTriangles call); frames/s is reported beside it, and the
-chessboard Phong rasterizer (configs[1]) is timed as a second workload at N=1.
+A "step" is one pass of the hot path over one batch of input: `renderer -b -m 9 dragon_vis.ply` at 1920x1080
+(BVH raytrace with shadow rays and 2 reflection bounces, BASELINE.json configs[3]) for the next
+--frames-per-step (default 8) cameras of the reference's auto-spin orbit, rendered by ONE launch
+(mi355_render_batch_device: every frame's pixels are those of a single-frame render), scene + BVH resident in
+HBM, frames left in HBM.  value = Mrays/s over all GPUs (a ray = one BVH_IntersectTriangles call);
+frames/s is reported beside it, and the chessboard Phong rasterizer (configs[1]) is timed as a second workload at N=1.
+--frames-per-step 1 renders frame by frame (one launch per frame).
 
-N>1: one process per GPU; every rank renders its interleaved 15-row screen bands of the SAME frame
-and a single RCCL gather per frame assembles it on rank 0 (strong scaling).
+N>1: one process per GPU; every rank renders its interleaved 15-row screen bands of the SAME frames
+and a single RCCL gather per step assembles them on rank 0 (strong scaling).
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W]
        (N>1 is launched by torch.distributed.run, one rank per GPU)
@@ -42,6 +44,8 @@ def main():
     ap.add_argument("--mesh", default="dragon_vis.ply")
     ap.add_argument("--mode", type=int, default=9)
     ap.add_argument("--tune", default="{}", help="JSON dict of renderer_amd.tune() knobs")
+    ap.add_argument("--frames-per-step", type=int, default=8,
+                    help="frames of the orbit rendered by one launch (raytrace modes; mi355_render_batch_device, 1..8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (rasterizer) workloads")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -68,10 +72,12 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     W, H, K, WU = args.width, args.height, args.steps, args.warmup
+    B = max(1, min(8, args.frames_per_step)) if args.mode >= 9 else 1      # frames per step (= per launch)
     scene = R.Scene(R.assets.mesh_path(args.mesh), device=local_rank)
     if args.mode >= 9:
         scene.bvh_update()                 # <mesh>.bvh cache in the scratch dir, else build (untimed, like -b)
-    cams = [R.benchmark_frame(k) for k in range(max(K, WU))]
+    N_CAMS = 200                                  # the reference's benchmark orbit: frames f0..f199, then it repeats
+    cams = [R.benchmark_frame(k) for k in range(N_CAMS)]
 
     def opts(**kw):
         o = R.default_opts(W, H, tune=json.loads(args.tune), **kw)
@@ -79,42 +85,55 @@ def main():
             o.band_rows, o.band_index, o.band_count, o.compact_rows = multigpu.BAND_ROWS, rank, world, 1
         return o
 
-    gather = multigpu.FrameGatherer(W, H, dev)
+    gather = multigpu.FrameGatherer(W, H, dev, frames=B)
     my_rows = gather.my_rows
     stream = torch.cuda.current_stream(dev)
 
     if args.mode in (7, 8):
         scene.shadowmap_render(0, cams[0][1][0])
 
+    def frames_of_step(k):
+        return [(k * B + j) % N_CAMS for j in range(B)]
+
     def enqueue(k, o, slot):
-        cam, lights, n = cams[k]
+        """One step: the next B frames of the orbit in one launch, then one gather (N>1)."""
         buf = gather.send_buffer(slot)
-        scene.render_device(args.mode, cam, lights, n, o, buf.data_ptr(), W * 4, 0, stream.cuda_stream)
+        if B == 1:
+            cam, lights, n = cams[k % N_CAMS]
+            scene.render_device(args.mode, cam, lights, n, o, buf.data_ptr(), W * 4, 0, stream.cuda_stream)
+        else:
+            fs = frames_of_step(k)
+            scene.render_batch_device(args.mode, [cams[f][0] for f in fs], [cams[f][1] for f in fs], cams[fs[0]][2], o,
+                                      [buf[j].data_ptr() for j in range(B)], W * 4, None, stream.cuda_stream)
         gather.gather(slot)
 
-    # ---- untimed pre-pass: per-frame ray counts and algorithmic bytes from the counting kernel variant
+    # ---- untimed pre-pass: per-frame ray counts and algorithmic bytes from the counting kernel variant (which walks
+    #      the tree in the reference's order: these ARE the reference algorithm's counts), once per orbit camera used
     o_stats = opts(collect_stats=1)
-    rays = np.zeros(K, np.float64)
-    abytes = np.zeros(K, np.float64)
-    for k in range(K):
-        cam, lights, n = cams[k]
-        buf = gather.send_buffer(0)
-        scene.render_device(args.mode, cam, lights, n, o_stats, buf.data_ptr(), W * 4, 0, stream.cuda_stream)
+    used = sorted({f for k in range(K) for f in frames_of_step(k)})
+    rays_f = np.zeros(N_CAMS, np.float64)
+    abytes_f = np.zeros(N_CAMS, np.float64)
+    scratch = torch.zeros((gather.max_rows, W), dtype=torch.int32, device=dev)
+    for f in used:
+        cam, lights, n = cams[f]
+        scene.render_device(args.mode, cam, lights, n, o_stats, scratch.data_ptr(), W * 4, 0, stream.cuda_stream)
         torch.cuda.synchronize(dev)
         st = scene.fetch_stats().as_dict()
-        rays[k] = st["normal_rays"] + st["shadow_rays"]
-        abytes[k] = algorithmic_bytes(st, W, my_rows)
+        rays_f[f] = st["normal_rays"] + st["shadow_rays"]
+        abytes_f[f] = algorithmic_bytes(st, W, my_rows)
+    my_rays = sum(rays_f[f] for k in range(K) for f in frames_of_step(k))
+    my_abytes = sum(abytes_f[f] for k in range(K) for f in frames_of_step(k))
     if world > 1:
-        t = torch.tensor([rays.sum(), abytes.sum()], dtype=torch.float64, device=dev)
+        t = torch.tensor([my_rays, my_abytes], dtype=torch.float64, device=dev)
         dist.all_reduce(t)
         total_rays, total_abytes = float(t[0]), float(t[1])
     else:
-        total_rays, total_abytes = float(rays.sum()), float(abytes.sum())
+        total_rays, total_abytes = float(my_rays), float(my_abytes)
 
     # ---- warmup
     o_run = opts()
     for k in range(WU):
-        enqueue(k % len(cams), o_run, k & 1)
+        enqueue(k, o_run, k & 1)
     gather.drain()
 
     # ---- timed region: exactly K frames, barrier + synchronize on both sides, max over ranks
@@ -143,6 +162,8 @@ def main():
     if rank == 0:
         last = gather.frame((K - 1) & 1)
         nonblack = int((last != 0).sum().item())
+        if B > 1:
+            assert all(int((last[j] != 0).sum().item()) > 0 for j in range(B)), "a frame of the last batch is empty"
         assert nonblack > 0, "rendered frame is empty"
 
     result = None
@@ -161,12 +182,14 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic orbit: reference mesh %s (shipped asset), reference benchmark cameras f0..f%d, BVH built by the host library" % (args.mesh, K - 1),
+            "data": "synthetic orbit: reference mesh %s (shipped asset), the reference's benchmark cameras f0..f199 (the orbit repeats), "
+                    "BVH built on the GPU by the library" % args.mesh,
             "config": {"workload": "%s, BVH raytrace mode %d (primary + shadow rays + 2 reflection bounces), %dx%d, 1 light"
                                    % (args.mesh, args.mode, W, H),
                        "parallelism": "screen bands x%d, 1 RCCL gather/frame" % world if world > 1 else "single GPU",
-                       "rays_per_frame": round(total_rays / K, 1), "tune": json.loads(args.tune)},
-            "frames_per_sec": round(K / dt, 3),
+                       "frames_per_step": B, "frames": K * B,
+                       "rays_per_frame": round(total_rays / (K * B), 1), "tune": json.loads(args.tune)},
+            "frames_per_sec": round(K * B / dt, 3),
             "roofline": {
                 "bound": "hbm",
                 "achieved": round(total_abytes / K / (kernel_ms * 1e-3) / 1e9 / max(world, 1), 3),
@@ -177,7 +200,9 @@ def main():
                 "kernel": "k_raytrace<false,false,true> (ordered walk)",
                 "kernel_ms": round(kernel_ms, 5),
                 "algorithmic_bytes_per_launch": round(total_abytes / K / max(world, 1), 1),
-                "note": "achieved = SURVEY 8(d) algorithmic bytes per launch (the REFERENCE algorithm's node pops / "
+                "frames_per_launch": B,
+                "note": "one launch = one step = %d consecutive frames of the orbit (mi355_render_batch_device). " % B +
+                        "achieved = SURVEY 8(d) algorithmic bytes per launch (the REFERENCE algorithm's node pops / "
                         "triangle tests / hits, counted by the reference-order kernel variant on the same frames) / "
                         "HIP-event time per launch on the launch stream (rank 0). The timed kernel walks the tree near "
                         "child first with distance culling (identical pixels, fewer visits); the scene (~8 MB) is "

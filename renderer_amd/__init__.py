@@ -358,6 +358,24 @@ class Scene:
                                          d_out, pitch_bytes, d_outf or None, stream or None),
                "mi355_render_device")
 
+    def render_batch_device(self, mode: int, cams, lights_per_frame, n_lights: int, opts: Opts, d_outs, pitch_bytes: int,
+                            d_outfs=None, stream: int = 0):
+        """mi355_render_batch_device: len(cams) frames in one launch.  cams: list of Camera; lights_per_frame: list of
+        Light arrays (n_lights used of each); d_outs / d_outfs: device pointers per frame."""
+        n = len(cams)
+        cam_arr = (Camera * n)(*cams)
+        light_arr = (Light * (n * max(n_lights, 1)))()
+        for f in range(n):
+            for i in range(n_lights):
+                light_arr[f * n_lights + i] = lights_per_frame[f][i]
+        outs = (C.c_void_p * n)(*[int(p) for p in d_outs])
+        outfs = (C.c_void_p * n)(*[int(p) for p in d_outfs]) if d_outfs else None
+        f = lib().mi355_render_batch_device
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                      C.c_void_p, C.c_void_p]
+        _check(f(self.context(), mode, n, cam_arr, light_arr, n_lights, C.byref(opts), outs, pitch_bytes, outfs, stream or None),
+               "mi355_render_batch_device")
+
     def fetch_stats(self) -> Stats:
         st = Stats()
         _check(lib().mi355_fetch_stats(self.context(), C.byref(st)), "mi355_fetch_stats")

@@ -18,8 +18,8 @@
 #include <vector>
 
 // kernel launchers (defined next to their kernels)
-extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves3, int stack_depth);
-extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int ordered, int waves3, int n_blocks,
+extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves3, int batch, int stack_depth);
+extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int ordered, int waves3, int batch, int n_blocks,
                                              hipStream_t);
 extern "C" hipError_t mi355i_bvh_launch_prims(const float4 *rs_vert, const uint4 *rs_idx, uint32_t T, float4 *prim, uint32_t *list,
                                               uint32_t *bad, hipStream_t st);
@@ -107,6 +107,7 @@ struct mi355_ctx {
                             // dispenser (MI_DISPENSERS counters, MI_DISPENSER_STRIDE words apart) -- one memset per frame
     DevBuf fb, fbf;         // internal framebuffer for the host-output path
     DevBuf tile_order;      // raytrace dispenser order (ensure_tile_order)
+    DevBuf cam_table;       // batched launches: FrameCam[MI355_MAX_BATCH]
     DevBuf bvh_prim, bvh_list[2], bvh_lvl[2], bvh_tree, bvh_cnt;   // mi355_build_bvh work buffers (kept for rebuilds)
     DevBuf wave_prof;       // per-wave phase profile of counting launches (debug)
     int last_blocks = 0;
@@ -210,6 +211,7 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.pitch_words = pitch_bytes / 4;
     P.outf = (float *)d_outf;
     P.work_counter = (uint32_t *)((char *)c->ctrl.p + MI_CTRL_DISPENSER_OFF);
+    P.cams = nullptr; P.n_frames = 1;
     P.counters = (unsigned long long *)((char *)c->ctrl.p + 16);
     // tuning knobs (mi355_opts::tune, 0 = default)
     P.raster_stats = o->collect_stats ? 1 : 0;
@@ -449,18 +451,20 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipSt
         // A third wave per SIMD pays when the frame is long enough to be throughput bound (4K, 4 spp: +10 %); a 1080p
         // frame is bound by its slowest tiles and runs faster with two (measured, profiles/).  The three-wave build
         // spills some transition state, so it is only used when three blocks per CU are wanted.
-        const long long work_tiles = (((long long)P.W + 7) / 8) * (((long long)P.n_rows + 7) / 8) * (P.aa ? 4 : 1);
+        const int batch = (P.n_frames > 1 && P.cams) ? 1 : 0;
+        if (batch && !(ordered && !stats)) return fail(-41, "batched frames need the ordered walk (checked tree, no collect_stats, no reference-order flag)");
+        const long long work_tiles = (((long long)P.W + 7) / 8) * (((long long)P.n_rows + 7) / 8) * (P.aa ? 4 : 1) * P.n_frames;
         int waves3 = 0;
         if (ordered && !stats && (P.blocks_per_cu == 0 ? work_tiles >= 20ll * 3 * c->n_cus * 4 : P.blocks_per_cu >= 3))
-            waves3 = mi355i_raytrace_blocks_per_cu(0, P.exact_box, 1, 1, (int)c->dev.stack_depth) >= 3 ? 1 : 0;
-        int per_cu = mi355i_raytrace_blocks_per_cu(stats, P.exact_box, ordered, waves3, (int)c->dev.stack_depth);
+            waves3 = mi355i_raytrace_blocks_per_cu(0, P.exact_box, 1, 1, batch, (int)c->dev.stack_depth) >= 3 ? 1 : 0;
+        int per_cu = mi355i_raytrace_blocks_per_cu(stats, P.exact_box, ordered, waves3, batch, (int)c->dev.stack_depth);
         if (P.blocks_per_cu > 0 && P.blocks_per_cu < per_cu) per_cu = P.blocks_per_cu;
         int n_blocks = per_cu * c->n_cus;
-        const long long lanes_needed = ((long long)P.W * P.n_rows + 255) / 256;
+        const long long lanes_needed = ((long long)P.W * P.n_rows * P.n_frames + 255) / 256;
         if (n_blocks > lanes_needed) n_blocks = (int)(lanes_needed > 0 ? lanes_needed : 1);
         c->last_blocks = n_blocks;
         if (P.wave_prof) HIP_TRY(hipMemsetAsync(c->wave_prof.p, 0, (size_t)n_blocks * 4 * 16 * 8, st), -40);
-        e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, waves3, n_blocks, st);
+        e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, waves3, batch, n_blocks, st);
         break;
     }
     case MI355_MODE_LINES:
@@ -579,7 +583,7 @@ void mi355_scene_destroy(mi355_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->walk, &c->tri_edge, &c->tri_shade, &c->rs_tri, &c->rs_col, &c->rs_idx,
-                      &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->tile_order, &c->wave_prof, &c->bvh_prim, &c->bvh_list[0], &c->bvh_list[1],
+                      &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->tile_order, &c->cam_table, &c->wave_prof, &c->bvh_prim, &c->bvh_list[0], &c->bvh_list[1],
                       &c->bvh_lvl[0], &c->bvh_lvl[1], &c->bvh_tree, &c->bvh_cnt})
         b->release();
     for (auto &m : c->smap) m.release();
@@ -750,6 +754,39 @@ int mi355_render_device(mi355_ctx *c, int mode, const mi355_camera *cam, const m
     FrameParams P;
     if (int r = fill_params(c, mode, cam, lights, n_lights, o, d_out, pitch_bytes, d_outf, P)) return r;
     return enqueue_frame(c, mode, P, o->collect_stats, (hipStream_t)hip_stream);
+}
+
+int mi355_render_batch_device(mi355_ctx *c, int mode, int n_frames, const mi355_camera *cams, const mi355_light *lights,
+                              int n_lights, const mi355_opts *o, void *const *d_out, int pitch_bytes, void *const *d_outf,
+                              void *hip_stream)
+{
+    if (!c || !cams || !o || !d_out || (n_lights > 0 && !lights)) return fail(-3, "mi355_render_batch_device: null argument");
+    if (mode != MI355_MODE_RAYTRACE && mode != MI355_MODE_RAYTRACE_ANTIALIAS) return fail(-42, "batched frames: raytrace modes only (got mode %d)", mode);
+    if (n_frames < 1 || n_frames > MI355_MAX_BATCH) return fail(-21, "n_frames %d outside 1..%d", n_frames, MI355_MAX_BATCH);
+    if (o->collect_stats) return fail(-21, "batched frames cannot collect the traversal counters");
+    for (int f = 0; f < n_frames; f++) if (!d_out[f]) return fail(-3, "mi355_render_batch_device: frame %d has no output buffer", f);
+    if (n_frames == 1) return mi355_render_device(c, mode, cams, lights, n_lights, o, d_out[0], pitch_bytes, d_outf ? d_outf[0] : nullptr, hip_stream);
+    if (int r = validate_opts(*o, mode)) return r;
+    if (int r = select_device(c)) return r;
+    FrameParams P;
+    if (int r = fill_params(c, mode, &cams[0], lights, n_lights, o, d_out[0], pitch_bytes, d_outf ? d_outf[0] : nullptr, P)) return r;
+    FrameCam tab[MI355_MAX_BATCH];
+    memset(tab, 0, sizeof tab);
+    for (int f = 0; f < n_frames; f++) {
+        for (int k = 0; k < 3; k++) tab[f].eye[k] = cams[f].eye[k];
+        for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) tab[f].mv[r][k] = cams[f].mv[3 * r + k];
+        for (int i = 0; i < n_lights; i++) for (int k = 0; k < 3; k++) tab[f].light_pos[i][k] = lights[(size_t)f * n_lights + i].pos[k];
+        tab[f].out = (uint32_t *)d_out[f];
+        tab[f].outf = d_outf ? (float *)d_outf[f] : nullptr;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(c->cam_table.ensure(sizeof tab), -31);
+    // (pageable source: the runtime stages the bytes before returning, so `tab` may go out of scope; the copy is ordered
+    //  after the previous launch on this stream, which may still be reading the table)
+    HIP_TRY(hipMemcpyAsync(c->cam_table.p, tab, sizeof(FrameCam) * (size_t)n_frames, hipMemcpyHostToDevice, st), -31);
+    P.cams = (const FrameCam *)c->cam_table.p;
+    P.n_frames = n_frames;
+    return enqueue_frame(c, mode, P, 0, st);
 }
 
 int mi355_fetch_stats(mi355_ctx *c, mi355_stats *s)

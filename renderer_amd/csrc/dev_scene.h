@@ -76,6 +76,18 @@ struct DevScene {
     const float4 *rs_vert;    // [V][2]: (pos.xyz, ao as float), (normal.xyz, -)
 };
 
+// Per-frame data of a batched launch (mi355_render_batch_device): the frames of a batch share everything else
+// (scene, frame size, options).  160 bytes, 16-byte aligned, so a lane reads its frame's camera with dwordx4 loads.
+struct alignas(16) FrameCam {
+    float eye[4];                          // xyz
+    float mv[3][4];                        // rows of Camera::_mv, xyz
+    float light_pos[MI_MAX_LIGHTS][4];     // xyz
+    uint32_t *out;                         // XRGB words of this frame
+    float *outf;                           // optional r,g,b floats
+    unsigned long long pad;
+};
+static_assert(sizeof(FrameCam) == 160, "FrameCam is read with 16-byte loads");
+
 struct FrameParams {
     float eye[3];
     float mv[9];
@@ -106,6 +118,8 @@ struct FrameParams {
     int32_t no_help;           // ordered walk: never hand shadow rays to idle lanes
     int32_t prof_ordered;      // counting frames profile the ordered walk instead of reproducing the reference's counters
     unsigned long long *wave_prof; // counting builds: 16 words of phase profile per wave (debug), or NULL
+    const FrameCam *cams;      // batched launch: per-frame cameras / lights / outputs (device memory), else NULL
+    int32_t n_frames;          // frames rendered by this launch (1 unless batched)
     const uint32_t *tile_order; // dispenser index -> 8x8 tile id (heavy tiles first), or NULL = row-major
     int32_t blocks_per_cu;     // 0 = occupancy query
 };

@@ -42,6 +42,7 @@ enum { MODE_CLOSEST = 0, MODE_SHADOW = 1 };
 struct Lane {
     // pixel
     int px, py, orow;      // screen x, screen y, output row
+    int fid;               // batched launch: which frame of the batch this pixel belongs to
     int samples_left;      // AA: samples still to trace after the current one
     float fr, fg, fb;      // finalColor accumulator (Raytracer.cc:562)
     // ray tree
@@ -203,7 +204,26 @@ MI_DEV void set_ray_aux(Lane &L, float scene_mag)
     L.dinv = mk3(L.delta * __builtin_fabsf(L.inv.x), L.delta * __builtin_fabsf(L.inv.y), L.delta * __builtin_fabsf(L.inv.z));
 }
 
+// Camera, lights and output of the frame a lane works on: kernel arguments for a single frame, a small table in
+// device memory when one launch renders several frames (the lanes of a wave may then be on different frames).
+template <bool BATCH> MI_DEV f3 cam_eye(const FrameParams &P, int fid)
+{
+    if (BATCH) { const float4 v = *(const float4 *)P.cams[fid].eye; return mk3(v.x, v.y, v.z); }
+    return mk3(P.eye[0], P.eye[1], P.eye[2]);
+}
+template <bool BATCH> MI_DEV f3 cam_row(const FrameParams &P, int fid, int r)
+{
+    if (BATCH) { const float4 v = *(const float4 *)P.cams[fid].mv[r]; return mk3(v.x, v.y, v.z); }
+    return mk3(P.mv[3 * r], P.mv[3 * r + 1], P.mv[3 * r + 2]);
+}
+template <bool BATCH> MI_DEV f3 cam_light(const FrameParams &P, int fid, int li)
+{
+    if (BATCH) { const float4 v = *(const float4 *)P.cams[fid].light_pos[li]; return mk3(v.x, v.y, v.z); }
+    return mk3(P.light_pos[li][0], P.light_pos[li][1], P.light_pos[li][2]);
+}
+
 // Primary ray of pixel (px,py), sample index `traced` (Raytracer.cc:563-593)
+template <bool BATCH>
 MI_DEV void primary_ray(const FrameParams &P, const DevScene &S, Lane &L, int traced)
 {
     float xx = (float)L.px, yy = (float)L.py;
@@ -214,13 +234,12 @@ MI_DEV void primary_ray(const FrameParams &P, const DevScene &S, Lane &L, int tr
     float lx = ((float)(P.H / 2) - yy) / (float)P.SD;
     float ly = (xx - (float)(P.W / 2)) / (float)P.SD;
     f3 rc = norm3(mk3(lx, ly, 1.0f));
-    f3 r1 = mk3(P.mv[0], P.mv[1], P.mv[2]), r2 = mk3(P.mv[3], P.mv[4], P.mv[5]),
-       r3 = mk3(P.mv[6], P.mv[7], P.mv[8]);
+    const f3 r1 = cam_row<BATCH>(P, L.fid, 0), r2 = cam_row<BATCH>(P, L.fid, 1), r3 = cam_row<BATCH>(P, L.fid, 2);
     f3 rw = mul3(r1, rc.x);
     rw = add3(rw, mul3(r2, rc.y));
     rw = add3(rw, mul3(r3, rc.z));
     L.d = norm3(rw);
-    L.o = mk3(P.eye[0], P.eye[1], P.eye[2]);
+    L.o = cam_eye<BATCH>(P, L.fid);
     set_ray_aux(L, S.scene_mag);
     L.depth = 0;
     L.mode = MODE_CLOSEST;
@@ -252,6 +271,7 @@ MI_DEV f3 fold_levels(const float *lds, int depth, float rate)
 }
 
 // Light i's diffuse + specular contribution at the current hit (Raytracer.cc:468-505)
+template <bool BATCH>
 MI_DEV void add_light(const FrameParams &P, const DevScene &S, Lane &L)
 {
     f3 ptl = norm3(sub3(L.lp, L.hit));
@@ -261,7 +281,7 @@ MI_DEV void add_light(const FrameParams &P, const DevScene &S, Lane &L)
         float dr = 0.f, dg = 0.f, db = 0.f;
         float f = (float)((double)(P.diffuse * intensity) / 255.);
         dr += f * sh4.x; dg += f * sh4.y; db += f * sh4.z;      // dColor(0) += diffuse
-        f3 ptc = norm3(sub3(mk3(P.eye[0], P.eye[1], P.eye[2]), L.hit));
+        f3 ptc = norm3(sub3(cam_eye<BATCH>(P, L.fid), L.hit));
         f3 half = norm3(add3(ptl, ptc));
         float i2 = dot3(half, L.pn);
         if (i2 > 0.f) {
@@ -381,7 +401,9 @@ MI_DEV bool tri_edge_test(Lane &L)
 
 // WAVES = wavefronts per SIMD the register allocation aims at: 2 keeps everything in registers (1080p frames run
 // two blocks per CU anyway), 3 spills a little transition state to scratch and pays off on long frames.
-template <bool STATS, bool EXACT_BOX, bool ORDERED, int WAVES>
+// BATCH = the launch renders P.n_frames frames (tile slot s belongs to frame s % n_frames: every frame's heavy centre
+// tiles are handed out first); the waves then never run dry while one frame's slowest tiles finish.
+template <bool STATS, bool EXACT_BOX, bool ORDERED, int WAVES, bool BATCH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 k_raytrace(const DevScene S, const FrameParams P)
 {
@@ -408,7 +430,7 @@ k_raytrace(const DevScene S, const FrameParams P)
     uint32_t share = blockIdx.x % MI_DISPENSERS;   // the share this wave draws from (consecutive blocks sit on different XCDs)
     uint32_t dry_shares = 0;
     L.cur = MI_END_LINK; L.mode = MODE_CLOSEST; L.btri = -1; L.depth = 0; L.samples_left = 0;
-    L.fr = L.fg = L.fb = 0.f; L.px = L.py = L.orow = 0; L.avoid = -1; L.best = 0.f;
+    L.fr = L.fg = L.fb = 0.f; L.px = L.py = L.orow = 0; L.fid = 0; L.avoid = -1; L.best = 0.f;
     L.shadow_hit = false; L.li = 0; L.cr = L.cg = L.cb = 0.f; L.k1 = L.k2 = L.k3 = 0.f;
     L.o = L.d = L.hit = L.pn = L.refl = L.lp = L.inv = L.ph = mk3(0.f, 0.f, 0.f);
     L.tame = false; L.pend = false; L.pj = -1;
@@ -431,7 +453,7 @@ k_raytrace(const DevScene S, const FrameParams P)
     const int tiles_x = (P.W + 7) >> 3;
     const int tiles_y = (P.n_rows + 7) >> 3;
     const uint32_t n_tiles = (uint32_t)tiles_x * (uint32_t)tiles_y;
-    const uint32_t total = n_tiles * 64u;
+    const uint32_t n_slots_all = BATCH ? n_tiles * (uint32_t)P.n_frames : n_tiles;     // (tile, frame) pairs to hand out
 
     for (;;) {
         // ---------------- refill: hand new pixels to idle lanes --------------------------
@@ -454,7 +476,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         for (int tries = 0; tries < MI_DISPENSERS && !got; tries++) {
                             if (dry_shares & (1u << share)) { share = (share + 1u) % MI_DISPENSERS; continue; }
                             // tile slots share, share + 8, share + 16, ... ; local index k -> slot (k >> 6) * 8 + share
-                            const uint32_t n_slots = (n_tiles + (MI_DISPENSERS - 1u) - share) / MI_DISPENSERS;
+                            const uint32_t n_slots = (n_slots_all + (MI_DISPENSERS - 1u) - share) / MI_DISPENSERS;
                             uint32_t base = 0;
                             if (lane == 0) base = atomicAdd(P.work_counter + share * MI_DISPENSER_STRIDE, (uint32_t)P.chunk);
                             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -478,17 +500,20 @@ k_raytrace(const DevScene S, const FrameParams P)
                             if (rank < avail) {
                                 const uint32_t idx = pool_next + rank;
                                 // local index -> (tile slot, pixel in tile)
-                                const uint32_t tslot = (idx >> 6) * MI_DISPENSERS + pool_share, sub = idx & 63u;
+                                uint32_t tslot = (idx >> 6) * MI_DISPENSERS + pool_share;
+                                const uint32_t sub = idx & 63u;
+                                int fid = 0;
+                                if (BATCH) { fid = (int)(tslot % (uint32_t)P.n_frames); tslot /= (uint32_t)P.n_frames; }
                                 const uint32_t tile = P.tile_order ? P.tile_order[tslot] : tslot;
                                 const int tx = (int)(tile % (uint32_t)tiles_x), ty = (int)(tile / (uint32_t)tiles_x);
                                 const int x = (tx << 3) + (int)(sub & 7u), r = (ty << 3) + (int)(sub >> 3);
                                 if (x < P.W && r < P.n_rows) {   // ragged right / bottom edge
-                                    L.px = x;
+                                    L.px = x; L.fid = fid;
                                     L.py = band_row_to_y(r, P.band_rows, P.band_index, P.band_count);
                                     L.orow = P.compact ? r : L.py;
                                     L.fr = L.fg = L.fb = 0.f;
                                     L.samples_left = P.aa ? 3 : 0;
-                                    primary_ray(P, S, L, L.samples_left);
+                                    primary_ray<BATCH>(P, S, L, L.samples_left);
                                     begin_walk<ORDERED>(S, L, R, R2);
                                     n_normal++;
                                     alive = true;
@@ -535,7 +560,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         offer = HELP && P.use_shadows && P.n_lights > 0;
                     }
                 } else {
-                    if (!L.shadow_hit) add_light(P, S, L);          // Raytracer.cc:458-466
+                    if (!L.shadow_hit) add_light<BATCH>(P, S, L);          // Raytracer.cc:458-466
                     L.li++;
                     lights = true;
                 }
@@ -558,11 +583,11 @@ k_raytrace(const DevScene S, const FrameParams P)
                     const float hx = __shfl(L.hit.x, src), hy = __shfl(L.hit.y, src), hz = __shfl(L.hit.z, src);
                     const float nx = __shfl(L.pn.x, src), ny = __shfl(L.pn.y, src), nz = __shfl(L.pn.z, src);
                     const float c0 = __shfl(L.cr, src), c1 = __shfl(L.cg, src), c2 = __shfl(L.cb, src);
-                    const int bt = __shfl(L.btri, src), dp = __shfl(L.depth, src);
+                    const int bt = __shfl(L.btri, src), dp = __shfl(L.depth, src), fi = __shfl(L.fid, src);
                     if (give) { atomicAdd(&lds_pend[self], 1u); handed = true; lights = false; }
                     if (take) {
                         L.hit = mk3(hx, hy, hz); L.pn = mk3(nx, ny, nz); L.cr = c0; L.cg = c1; L.cb = c2;
-                        L.btri = bt; L.depth = dp; L.li = 0; L.owner = wbase + src;
+                        L.btri = bt; L.depth = dp; L.fid = fi; L.li = 0; L.owner = wbase + src;
                         L.pend = false; L.cur = MI_END_LINK;
                         alive = true; want_pixel = false; lights = true;
                     }
@@ -571,7 +596,7 @@ k_raytrace(const DevScene S, const FrameParams P)
             if (lights) {
                 bool launched = false;
                 while (L.li < P.n_lights) {
-                    L.lp = mk3(P.light_pos[L.li][0], P.light_pos[L.li][1], P.light_pos[L.li][2]);
+                    L.lp = cam_light<BATCH>(P, L.fid, L.li);
                     if (P.use_shadows) {
                         // shadow ray (Raytracer.cc:446-466)
                         f3 ptl = sub3(L.lp, L.hit);
@@ -591,7 +616,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         launched = true;
                         break;
                     }
-                    add_light(P, S, L);
+                    add_light<BATCH>(P, S, L);
                     L.li++;
                 }
                 if (!launched) {
@@ -628,7 +653,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                 L.fb += ab; L.fg += ag; L.fr += ar;              // finalColor += ...
                 if (L.samples_left > 0) {
                     L.samples_left--;
-                    primary_ray(P, S, L, L.samples_left);
+                    primary_ray<BATCH>(P, S, L, L.samples_left);
                     begin_walk<ORDERED>(S, L, R, R2);
                     n_normal++;
                 } else {
@@ -637,9 +662,11 @@ k_raytrace(const DevScene S, const FrameParams P)
                     if (r > 255.0f) r = 255.0f;
                     if (g > 255.0f) g = 255.0f;
                     if (b > 255.0f) b = 255.0f;
-                    P.out[(size_t)L.orow * P.pitch_words + L.px] = pack_xrgb(r, g, b);
-                    if (P.outf) {
-                        float *q = P.outf + ((size_t)L.orow * P.W + L.px) * 3;
+                    uint32_t *const fout = BATCH ? P.cams[L.fid].out : P.out;
+                    float *const foutf = BATCH ? P.cams[L.fid].outf : P.outf;
+                    fout[(size_t)L.orow * P.pitch_words + L.px] = pack_xrgb(r, g, b);
+                    if (foutf) {
+                        float *q = foutf + ((size_t)L.orow * P.W + L.px) * 3;
                         q[0] = r; q[1] = g; q[2] = b;
                     }
                     alive = false;
@@ -913,26 +940,33 @@ k_raytrace(const DevScene S, const FrameParams P)
 // ---- launch helper (called from capi.hip) ------------------------------------------------
 namespace {
 typedef void (*rt_kernel)(const DevScene, const FrameParams);
-rt_kernel pick_kernel(int stats, int exact, int ordered, int waves3)
+rt_kernel pick_kernel(int stats, int exact, int ordered, int waves3, int batch)
 {
-    if (ordered && stats) return exact ? k_raytrace<true, true, true, 2> : k_raytrace<true, false, true, 2>;
-    if (ordered && waves3) return exact ? k_raytrace<false, true, true, 3> : k_raytrace<false, false, true, 3>;
-    if (ordered) return exact ? k_raytrace<false, true, true, 2> : k_raytrace<false, false, true, 2>;
-    if (stats) return exact ? k_raytrace<true, true, false, 2> : k_raytrace<true, false, false, 2>;
-    return exact ? k_raytrace<false, true, false, 2> : k_raytrace<false, false, false, 2>;
+    if (ordered && !stats && batch) {
+        if (waves3) return exact ? k_raytrace<false, true, true, 3, true> : k_raytrace<false, false, true, 3, true>;
+        return exact ? k_raytrace<false, true, true, 2, true> : k_raytrace<false, false, true, 2, true>;
+    }
+    if (ordered && stats) return exact ? k_raytrace<true, true, true, 2, false> : k_raytrace<true, false, true, 2, false>;
+    if (ordered && waves3) return exact ? k_raytrace<false, true, true, 3, false> : k_raytrace<false, false, true, 3, false>;
+    if (ordered) return exact ? k_raytrace<false, true, true, 2, false> : k_raytrace<false, false, true, 2, false>;
+    if (stats) return exact ? k_raytrace<true, true, false, 2, false> : k_raytrace<true, false, false, 2, false>;
+    return exact ? k_raytrace<false, true, false, 2, false> : k_raytrace<false, false, false, 2, false>;
 }
 size_t stack_bytes(int ordered, int stack_depth) { return ordered ? (size_t)stack_depth * 256u * sizeof(uint32_t) : 0u; }
 } // namespace
 
-// blocks per CU the (stats, exact, ordered, waves3) variant can hold
-extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves3, int stack_depth)
+// can this build render several frames per launch?  (the ordered, non-counting kernels only)
+extern "C" int mi355i_raytrace_can_batch(int stats, int ordered) { return ordered && !stats; }
+
+// blocks per CU the (stats, exact, ordered, waves3, batch) variant can hold
+extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves3, int batch, int stack_depth)
 {
-    static int cache[2][2][2][2][MI_MAX_STACK + 1];        // 0 = not asked yet
+    static int cache[2][2][2][2][2][MI_MAX_STACK + 1];        // 0 = not asked yet
     if (stack_depth < 0 || stack_depth > MI_MAX_STACK) stack_depth = MI_MAX_STACK;
-    int &slot = cache[stats ? 1 : 0][exact ? 1 : 0][ordered ? 1 : 0][waves3 ? 1 : 0][ordered ? stack_depth : 0];
+    int &slot = cache[stats ? 1 : 0][exact ? 1 : 0][ordered ? 1 : 0][waves3 ? 1 : 0][batch ? 1 : 0][ordered ? stack_depth : 0];
     if (!slot) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_kernel(stats, exact, ordered, waves3), 256, stack_bytes(ordered, stack_depth)) != hipSuccess || nb < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_kernel(stats, exact, ordered, waves3, batch), 256, stack_bytes(ordered, stack_depth)) != hipSuccess || nb < 1)
             nb = 2;
         slot = nb > 8 ? 8 : nb;
     }
@@ -940,8 +974,8 @@ extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, 
 }
 
 extern "C" hipError_t mi355i_launch_raytrace(const DevScene *S, const FrameParams *P, int stats, int exact, int ordered, int waves3,
-                                             int n_blocks, hipStream_t st)
+                                             int batch, int n_blocks, hipStream_t st)
 {
-    hipLaunchKernelGGL(pick_kernel(stats, exact, ordered, waves3), dim3(n_blocks), dim3(256), stack_bytes(ordered, (int)S->stack_depth), st, *S, *P);
+    hipLaunchKernelGGL(pick_kernel(stats, exact, ordered, waves3, batch), dim3(n_blocks), dim3(256), stack_bytes(ordered, (int)S->stack_depth), st, *S, *P);
     return hipGetLastError();
 }

@@ -42,21 +42,23 @@ def assemble_numpy(parts, height: int, band_rows: int) -> np.ndarray:
 class FrameGatherer:
     """Gathers per-rank compact band buffers on rank 0 and de-interleaves them (torch tensors)."""
 
-    def __init__(self, width: int, height: int, device, band_rows: int = BAND_ROWS, group=None):
+    def __init__(self, width: int, height: int, device, band_rows: int = BAND_ROWS, group=None, frames: int = 1):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.W, self.H, self.band_rows, self.device = width, height, band_rows, device
+        self.frames = frames            # frames per gather (a batched launch renders several at once)
         self.my_rows = rows_of_rank(height, band_rows, self.world, self.rank)
         self.max_rows = max(rows_of_rank(height, band_rows, self.world, r) for r in range(self.world))
         owner, local = row_map(height, band_rows, self.world)
         # frame row y lives at flat row owner*max_rows + local of the gathered [world, max_rows, W] block
         self.src_rows = torch.as_tensor(owner * self.max_rows + local, device=device)
         # double-buffered so frame k+1 can render while frame k is on the wire
-        self.send = [torch.zeros((self.max_rows, width), dtype=torch.int32, device=device) for _ in range(2)]
-        self.recv = [torch.zeros((self.world, self.max_rows, width), dtype=torch.int32, device=device)
+        shape = (self.max_rows, width) if frames == 1 else (frames, self.max_rows, width)
+        self.send = [torch.zeros(shape, dtype=torch.int32, device=device) for _ in range(2)]
+        self.recv = [torch.zeros((self.world,) + shape, dtype=torch.int32, device=device)
                      if self.rank == 0 else None for _ in range(2)]
         self.pending = [None, None]
 
@@ -86,10 +88,16 @@ class FrameGatherer:
             self.pending[slot] = None
         if self.rank != 0:
             return None
+        if self.frames == 1:
+            if self.world == 1:
+                return self.send[slot][: self.H]
+            flat = self.recv[slot].view(self.world * self.max_rows, self.W)
+            return flat.index_select(0, self.src_rows)
+        # [frames, H, W]: frame f's row y lives at recv[owner, f, local]
         if self.world == 1:
-            return self.send[slot][: self.H]
-        flat = self.recv[slot].view(self.world * self.max_rows, self.W)
-        return flat.index_select(0, self.src_rows)
+            return self.send[slot][:, : self.H]
+        flat = self.recv[slot].permute(1, 0, 2, 3).reshape(self.frames, self.world * self.max_rows, self.W)
+        return flat.index_select(1, self.src_rows)
 
     def drain(self):
         for s in (0, 1):

@@ -19,13 +19,33 @@ from renderer_amd import assets, multigpu      # noqa: E402
 
 def main():
     out_path, W, H, frames = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    batch = int(sys.argv[5]) if len(sys.argv) > 5 else 1      # frames per gather (a batched launch on the GPU)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     s = O.Scene(assets.mesh_path("dragon_vis.ply"))
     s.bvh_ensure(os.path.join(assets.cache_dir(), "dragon_vis.ply.oracle.bvh"))
-    g = multigpu.FrameGatherer(W, H, torch.device("cpu"))
+    g = multigpu.FrameGatherer(W, H, torch.device("cpu"), frames=batch)
     assert g.my_rows == multigpu.rows_of_rank(H, multigpu.BAND_ROWS, world, rank)
     ok = True
+    if batch > 1:
+        ys = np.arange(H)
+        mine = (ys // multigpu.BAND_ROWS) % world == rank
+        for step in range(frames):
+            buf = g.send_buffer(step & 1)
+            buf.zero_()
+            fulls = []
+            for j in range(batch):
+                cam, lights, n = O.benchmark_frame(step * batch + j)
+                o = O.default_opts(W, H, band_rows=multigpu.BAND_ROWS, band_index=rank, band_count=world)
+                img, _, _ = s.render(9, cam, lights, n, o)
+                buf[j, : g.my_rows] = torch.from_numpy(img[mine].astype(np.int32))
+                if rank == 0:
+                    fulls.append(s.render(9, cam, lights, n, O.default_opts(W, H))[0])
+            g.gather(step & 1)
+            if rank == 0:
+                got = g.frame(step & 1).numpy().astype(np.uint32)
+                ok = ok and got.shape == (batch, H, W) and all(bool(np.array_equal(got[j], fulls[j])) for j in range(batch))
+        frames = 0
     for k in range(frames):
         cam, lights, n = O.benchmark_frame(k)
         o = O.default_opts(W, H, band_rows=multigpu.BAND_ROWS, band_index=rank, band_count=world)
