@@ -217,8 +217,11 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.raster_stats = o->collect_stats ? 1 : 0;
     const int32_t *t = o->tune;
     const int flags = t[5];
-    P.xmin = t[0] > 0 ? (t[0] > 64 ? 64 : t[0]) : 16;
-    P.rmin = t[1] > 0 ? (t[1] > 64 ? 64 : t[1]) : 48;
+    // defaults: serve transitions when every lane of the wave has finished its ray, take pixels when every lane is
+    // free -- a wave then works through one tile in lockstep generations, with the fewest (expensive) transition and
+    // refill phases; measured best for single frames and batches alike (profiles/r01_analysis.md)
+    P.xmin = t[0] > 0 ? (t[0] > 64 ? 64 : t[0]) : 64;
+    P.rmin = t[1] > 0 ? (t[1] > 64 ? 64 : t[1]) : 64;
     P.chunk = t[2] > 0 ? t[2] : 64;
     P.ref_order = (flags & 4) ? 1 : 0;
     P.no_help = (flags & 32) ? 1 : 0;
