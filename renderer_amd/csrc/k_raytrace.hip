@@ -57,7 +57,7 @@ struct Lane {
     float best;            // bestTriDist
     float limit;           // ordered walk: a box whose entry lies beyond this cannot change the result
     float delta;           // ordered walk: slack for a hit point lying just outside its triangle's box
-    f3 dinv;               // ordered walk: delta * |inv|
+    float dmax;            // ordered walk: delta * max |inv| -- how far (in ray parameter) growing a box by delta can move its faces
     int sp;                // ordered walk: postponed children of this lane (the newest in `top`, the rest in LDS)
     uint32_t top;
     int owner;             // LDS column (block-local thread index) of the pixel this lane works for: its own, or,
@@ -163,7 +163,7 @@ MI_DEV bool ray_box_fast(const f3 o, const f3 inv, const float4 lo, const float4
 //         triangle and of the ray), and directions are unit vectors, so its distance from the origin is at
 //         least near_g -- and if near_g > far_g or far_g < 0 the ray misses the grown box and no triangle
 //         below it can be hit at all.
-MI_DEV bool ray_box_fast_ordered(const f3 o, const f3 inv, const f3 dinv, const float4 lo, const float4 hi, bool &sure,
+MI_DEV bool ray_box_fast_ordered(const f3 o, const f3 inv, const float dmax, const float4 lo, const float4 hi, bool &sure,
                                  float &key, float &near_g, float &far_g)
 {
     const float E = 1e-6f;
@@ -187,8 +187,9 @@ MI_DEV bool ray_box_fast_ordered(const f3 o, const f3 inv, const f3 dinv, const 
     const bool fail = (tn_lo > tf_hi) || (tf_hi < 0.f);
     sure = pass || fail;
     key = tn_lo;
-    near_g = __builtin_fmaxf(__builtin_fmaxf(xl - dinv.x, yl - dinv.y), zl - dinv.z);
-    far_g = __builtin_fminf(__builtin_fminf(xh + dinv.x, yh + dinv.y), zh + dinv.z);
+    // (grown by the largest of the three per-axis slacks, dmax: a weaker bound than axis by axis, still a bound)
+    near_g = tn_lo - dmax;
+    far_g = tf_hi + dmax;
     return pass;
 }
 
@@ -201,7 +202,7 @@ MI_DEV void set_ray_aux(Lane &L, float scene_mag)
     // ordered walk: 1e-4 of the largest coordinate in play -- rounding moves a computed hit point by ~1e-6 of it
     const float m = __builtin_fmaxf(__builtin_fmaxf(scene_mag, __builtin_fabsf(L.o.x)), __builtin_fmaxf(__builtin_fabsf(L.o.y), __builtin_fabsf(L.o.z)));
     L.delta = 1e-4f * m;
-    L.dinv = mk3(L.delta * __builtin_fabsf(L.inv.x), L.delta * __builtin_fabsf(L.inv.y), L.delta * __builtin_fabsf(L.inv.z));
+    L.dmax = L.delta * __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(L.inv.x), __builtin_fabsf(L.inv.y)), __builtin_fabsf(L.inv.z));
 }
 
 // Camera, lights and output of the frame a lane works on: kernel arguments for a single frame, a small table in
@@ -434,7 +435,7 @@ k_raytrace(const DevScene S, const FrameParams P)
     L.shadow_hit = false; L.li = 0; L.cr = L.cg = L.cb = 0.f; L.k1 = L.k2 = L.k3 = 0.f;
     L.o = L.d = L.hit = L.pn = L.refl = L.lp = L.inv = L.ph = mk3(0.f, 0.f, 0.f);
     L.tame = false; L.pend = false; L.pj = -1;
-    L.limit = 0.f; L.delta = 0.f; L.dinv = mk3(0.f, 0.f, 0.f); L.sp = 0; L.top = MI_END_LINK; L.owner = (int)threadIdx.x;
+    L.limit = 0.f; L.delta = 0.f; L.dmax = 0.f; L.sp = 0; L.top = MI_END_LINK; L.owner = (int)threadIdx.x;
     L.pe1 = L.pe2 = L.pe3 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     unsigned n_normal = 0, n_shadow = 0;
@@ -719,8 +720,8 @@ k_raytrace(const DevScene S, const FrameParams P)
                     } else {
                         bool sL, sR;
                         float nL, nR, fL, fR;
-                        hL = ray_box_fast_ordered(L.o, L.inv, L.dinv, R.a, R.b, sL, kL, nL, fL);
-                        hR = ray_box_fast_ordered(L.o, L.inv, L.dinv, R2.a, R2.b, sR, kR, nR, fR);
+                        hL = ray_box_fast_ordered(L.o, L.inv, L.dmax, R.a, R.b, sL, kL, nL, fL);
+                        hR = ray_box_fast_ordered(L.o, L.inv, L.dmax, R2.a, R2.b, sR, kR, nR, fR);
                         if (__builtin_expect(!((sL || leafL) && (sR || leafR) && L.tame), 0)) {
                             if (STATS) n_slow++;
                             hL = leafL || ray_box_exact(L.o, L.d, R.a, R.b);
