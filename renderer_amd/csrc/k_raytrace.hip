@@ -817,9 +817,9 @@ k_raytrace(const DevScene S, const FrameParams P)
                 }
                 MI_PHASE(pc_b);
             }
-            const unsigned long long mDone = __ballot(alive && L.cur == MI_END_LINK && !L.pend && !awaiting);
             const unsigned long long mBusy = __ballot(alive && !(L.cur == MI_END_LINK && !L.pend));
-            if (!mBusy || __popcll(mDone) >= xmin_now) break;
+            if (!mBusy) break;
+            if (xmin_now < 64 && __popcll(__ballot(alive && L.cur == MI_END_LINK && !L.pend && !awaiting)) >= xmin_now) break;
         }
         } else {
         // ---- walk in the reference's order (threaded links): counting builds, unchecked trees ----
@@ -889,9 +889,9 @@ k_raytrace(const DevScene S, const FrameParams P)
                 }
             }
             if (mL) MI_PHASE(pc_b);
-            const unsigned long long mDone = __ballot(alive && L.cur == MI_END_LINK && !L.pend && !awaiting);
             const unsigned long long mBusy = __ballot(alive && !(L.cur == MI_END_LINK && !L.pend));
-            if (!mBusy || __popcll(mDone) >= xmin_now) break;
+            if (!mBusy) break;
+            if (xmin_now < 64 && __popcll(__ballot(alive && L.cur == MI_END_LINK && !L.pend && !awaiting)) >= xmin_now) break;
         }
         }
     }
