@@ -691,7 +691,8 @@ k_raytrace(const DevScene S, const FrameParams P)
         uint32_t *const stk = lds_stack + threadIdx.x;
         for (;;) {
             if (STATS) it_loops++;
-            const bool walking = alive && L.cur != MI_END_LINK;
+            // (a lane without a ray has L.cur == END and no pending candidate, so `alive` need not be looked at here)
+            const bool walking = L.cur != MI_END_LINK;
             const bool inner = walking && (L.cur & MI_LEAF_BIT) == 0;
             const bool tri = walking && (L.cur & MI_LEAF_BIT) != 0;
             const unsigned long long mI = __ballot(inner), mL = __ballot(tri);
@@ -817,7 +818,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                 }
                 MI_PHASE(pc_b);
             }
-            const unsigned long long mBusy = __ballot(alive && !(L.cur == MI_END_LINK && !L.pend));
+            const unsigned long long mBusy = __ballot(L.cur != MI_END_LINK || L.pend);
             if (!mBusy) break;
             if (xmin_now < 64 && __popcll(__ballot(alive && L.cur == MI_END_LINK && !L.pend && !awaiting)) >= xmin_now) break;
         }
