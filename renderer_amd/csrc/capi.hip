@@ -319,10 +319,11 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
             auto wlink = [&](uint32_t x) { return is_leaf(x) ? link(x) : (uint32_t)(wide_base + 2 * (size_t)off[x]); };
             float4 *w = &walk[wide_base + 2 * (size_t)off[it.node]];
             const RefNode &ca = rn[n.a], &cb = rn[n.b];
-            w[0] = make_float4(ca.bottom[0], ca.bottom[1], ca.bottom[2], u2f(wlink(n.a)));
-            w[1] = make_float4(ca.top[0], ca.top[1], ca.top[2], u2f(wlink(n.b)));
-            w[2] = make_float4(cb.bottom[0], cb.bottom[1], cb.bottom[2], 0.f);
-            w[3] = make_float4(cb.top[0], cb.top[1], cb.top[2], 0.f);
+            // (min and max of an axis side by side: the two slab distances of an axis are then one packed operation)
+            w[0] = make_float4(ca.bottom[0], ca.top[0], ca.bottom[1], ca.top[1]);
+            w[1] = make_float4(ca.bottom[2], ca.top[2], u2f(wlink(n.a)), u2f(wlink(n.b)));
+            w[2] = make_float4(cb.bottom[0], cb.top[0], cb.bottom[1], cb.top[1]);
+            w[3] = make_float4(cb.bottom[2], cb.top[2], 0.f, 0.f);
         } else {
             const uint32_t cnt = n.a & 0x7fffffffu, first = n.b;
             if (cnt) { if (first < list_end) list_in_visit_order = false; list_end = first + cnt; }
@@ -424,8 +425,8 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
     c->dev.tri_base = (uint32_t)tri_base;
     {
         const uint32_t wroot = is_leaf(0) ? link(0) : (uint32_t)(wide_base + 2 * (size_t)off[0]);
-        c->dev.vroot_a = make_float4(rn[0].bottom[0], rn[0].bottom[1], rn[0].bottom[2], u2f(wroot));
-        c->dev.vroot_b = make_float4(rn[0].top[0], rn[0].top[1], rn[0].top[2], u2f(MI_END_LINK));
+        c->dev.vroot_a = make_float4(rn[0].bottom[0], rn[0].top[0], rn[0].bottom[1], rn[0].top[1]);
+        c->dev.vroot_b = make_float4(rn[0].bottom[2], rn[0].top[2], u2f(wroot), u2f(MI_END_LINK));
     }
     c->dev.n_nodes = nN;
     c->has_bvh = true;

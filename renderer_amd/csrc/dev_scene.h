@@ -51,7 +51,8 @@
 //
 // Ordered traversal (k_raytrace<.., ORDERED>) reads "wide" records from the same buffer, four float4 per
 // inner node, holding BOTH children's boxes so that one step decides two box tests:
-//   wide node     : (minL.xyz, link L) (maxL.xyz, link R) (minR.xyz, -) (maxR.xyz, -)
+//   wide node     : (minL.x, maxL.x, minL.y, maxL.y) (minL.z, maxL.z, link L, link R)
+//                   (minR.x, maxR.x, minR.y, maxR.y) (minR.z, maxR.z, -, -)
 // with links to wide records or (MI_LEAF_BIT) to the triangle blocks above.  A walk starts at a virtual
 // record in the kernel arguments whose only child is the root (link R = MI_END_LINK = no child).
 // The wide records are only used when the tree passed the checks of capi.hip (ordered_ok).
@@ -60,7 +61,7 @@ struct DevScene {
     const float4 *tri_edge;
     const float4 *tri_shade;
     float4 root_a, root_b;    // walk record behind root_link
-    float4 vroot_a, vroot_b;  // virtual wide record above the root: (root min, wide link of the root) (root max, END)
+    float4 vroot_a, vroot_b;  // virtual wide record above the root: the root's box as the left child, END as the right link
     uint32_t root_link;
     uint32_t tri_base;        // float4 index of triangle block 0
     uint32_t ordered_ok;      // boxes bound their subtrees, list order = visiting order, depth fits the LDS stack

@@ -706,7 +706,10 @@ k_raytrace(const DevScene S, const FrameParams P)
             if (mI) {
                 if (STATS) { it_a++; ln_a += __popcll(mI); }
                 if (inner) {
-                    const uint32_t linkL = __float_as_uint(R.a.w), linkR = __float_as_uint(R.b.w);
+                    const uint32_t linkL = __float_as_uint(R.b.z), linkR = __float_as_uint(R.b.w);
+                    // wide record: (min.x, max.x, min.y, max.y) (min.z, max.z, ..) per child
+                    const float4 loL = make_float4(R.a.x, R.a.z, R.b.x, 0.f), hiL = make_float4(R.a.y, R.a.w, R.b.y, 0.f);
+                    const float4 loR = make_float4(R2.a.x, R2.a.z, R2.b.x, 0.f), hiR = make_float4(R2.a.y, R2.a.w, R2.b.y, 0.f);
                     bool hL, hR;
                     float kL = 0.f, kR = 0.f;
                     // The reference tests a node's box when it pops that node, and only if it is an inner node
@@ -716,17 +719,17 @@ k_raytrace(const DevScene S, const FrameParams P)
                     // distance cull.
                     const bool leafL = (linkL & MI_LEAF_BIT) != 0u, leafR = (linkR & MI_LEAF_BIT) != 0u;
                     if (EXACT_BOX) {
-                        hL = leafL || ray_box_exact(L.o, L.d, R.a, R.b);
-                        hR = leafR || ray_box_exact(L.o, L.d, R2.a, R2.b);
+                        hL = leafL || ray_box_exact(L.o, L.d, loL, hiL);
+                        hR = leafR || ray_box_exact(L.o, L.d, loR, hiR);
                     } else {
                         bool sL, sR;
                         float nL, nR, fL, fR;
-                        hL = ray_box_fast_ordered(L.o, L.inv, L.dmax, R.a, R.b, sL, kL, nL, fL);
-                        hR = ray_box_fast_ordered(L.o, L.inv, L.dmax, R2.a, R2.b, sR, kR, nR, fR);
+                        hL = ray_box_fast_ordered(L.o, L.inv, L.dmax, loL, hiL, sL, kL, nL, fL);
+                        hR = ray_box_fast_ordered(L.o, L.inv, L.dmax, loR, hiR, sR, kR, nR, fR);
                         if (__builtin_expect(!((sL || leafL) && (sR || leafR) && L.tame), 0)) {
                             if (STATS) n_slow++;
-                            hL = leafL || ray_box_exact(L.o, L.d, R.a, R.b);
-                            hR = leafR || ray_box_exact(L.o, L.d, R2.a, R2.b);
+                            hL = leafL || ray_box_exact(L.o, L.d, loL, hiL);
+                            hR = leafR || ray_box_exact(L.o, L.d, loR, hiR);
                         } else {
                             if (leafL) hL = !(nL > fL) && !(fL < 0.f);
                             if (leafR) hR = !(nR > fR) && !(fR < 0.f);
