@@ -207,10 +207,17 @@ def light(pos, cam: Camera) -> Light:
     return l
 
 
-def _np_view(ptr, n, dtype):
+class _OwnedArray(np.ndarray):
+    """A view into memory owned by a C++ object: keeps that object alive as long as the view (or a view of it) lives."""
+    _owner = None
+
+
+def _np_view(ptr, n, dtype, owner=None):
     if n == 0:
         return np.zeros(0, dtype)
-    return np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype)
+    a = np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype).view(_OwnedArray)
+    a._owner = owner
+    return a
 
 
 class Scene:
@@ -247,17 +254,17 @@ class Scene:
     def arrays(self):
         d, V, T = self.desc, self.nv, self.nt
         return dict(
-            vertex_pos=_np_view(d.vertex_pos, 3 * V, np.float32).reshape(V, 3),
-            vertex_normal=_np_view(d.vertex_normal, 3 * V, np.float32).reshape(V, 3),
-            vertex_ao=_np_view(d.vertex_ao, V, np.uint32),
-            tri_index=_np_view(d.tri_index, 3 * T, np.int32).reshape(T, 3),
-            tri_center=_np_view(d.tri_center, 3 * T, np.float32).reshape(T, 3),
-            tri_normal=_np_view(d.tri_normal, 3 * T, np.float32).reshape(T, 3),
-            tri_colorf=_np_view(d.tri_colorf, 3 * T, np.float32).reshape(T, 3),
-            tri_color32=_np_view(d.tri_color32, T, np.uint32),
-            tri_two_sided=_np_view(d.tri_two_sided, T, np.uint8),
-            tri_d=_np_view(d.tri_d, 4 * T, np.float32).reshape(T, 4),
-            tri_e=_np_view(d.tri_e, 9 * T, np.float32).reshape(T, 9))
+            vertex_pos=_np_view(d.vertex_pos, 3 * V, np.float32, self).reshape(V, 3),
+            vertex_normal=_np_view(d.vertex_normal, 3 * V, np.float32, self).reshape(V, 3),
+            vertex_ao=_np_view(d.vertex_ao, V, np.uint32, self),
+            tri_index=_np_view(d.tri_index, 3 * T, np.int32, self).reshape(T, 3),
+            tri_center=_np_view(d.tri_center, 3 * T, np.float32, self).reshape(T, 3),
+            tri_normal=_np_view(d.tri_normal, 3 * T, np.float32, self).reshape(T, 3),
+            tri_colorf=_np_view(d.tri_colorf, 3 * T, np.float32, self).reshape(T, 3),
+            tri_color32=_np_view(d.tri_color32, T, np.uint32, self),
+            tri_two_sided=_np_view(d.tri_two_sided, T, np.uint8, self),
+            tri_d=_np_view(d.tri_d, 4 * T, np.float32, self).reshape(T, 4),
+            tri_e=_np_view(d.tri_e, 9 * T, np.float32, self).reshape(T, 9))
 
     # -- BVH ---------------------------------------------------------------------------------------
     def bvh_create(self, where: str = "auto") -> int:
@@ -287,8 +294,9 @@ class Scene:
         nn, ni, _, pn, pi = self.bvh_info()
         if nn == 0:
             return np.zeros((0, 8), np.uint32), np.zeros(0, np.int32)
-        nodes = np.ctypeslib.as_array(C.cast(pn, C.POINTER(C.c_uint32)), shape=(nn * 8,)).reshape(nn, 8)
-        idx = np.ctypeslib.as_array(C.cast(pi, C.POINTER(C.c_int32)), shape=(ni,))
+        # copies: the C++ vectors behind these pointers are replaced by the next build
+        nodes = np.ctypeslib.as_array(C.cast(pn, C.POINTER(C.c_uint32)), shape=(nn * 8,)).reshape(nn, 8).copy()
+        idx = np.ctypeslib.as_array(C.cast(pi, C.POINTER(C.c_int32)), shape=(ni,)).copy()
         return nodes, idx
 
     # -- device ------------------------------------------------------------------------------------
