@@ -237,6 +237,23 @@ def main():
                     chess.render_device(mode, cams[k][0], cams[k][1], cams[k][2], o6, buf.data_ptr(), W * 4, 0, stream.cuda_stream)
                 torch.cuda.synchronize(dev)
                 extra[name + "_fps"] = round(n_f / (time.perf_counter() - t1), 2)
+            # the same raster frames eight at a time (mi355_render_batch_device: side by side on internal streams)
+            for mode, name in ((6, "chessboard_phong_1080p_batch8"), (8, "chessboard_softshadow_1080p_batch8")):
+                o6 = R.default_opts(W, H)
+                bufs8 = [torch.zeros((H, W), dtype=torch.int32, device=dev) for _ in range(8)]
+
+                def raster_step(i):
+                    fs = [(8 * i + j) % N_CAMS for j in range(8)]
+                    chess.render_batch_device(mode, [cams[f][0] for f in fs], [cams[f][1] for f in fs], cams[fs[0]][2], o6,
+                                              [b.data_ptr() for b in bufs8], W * 4, None, stream.cuda_stream)
+                for i in range(3):
+                    raster_step(i)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for i in range(25):
+                    raster_step(i)
+                torch.cuda.synchronize(dev)
+                extra[name + "_fps"] = round(200 / (time.perf_counter() - t1), 2)
             # BVH build of the benchmark mesh: GPU level kernels + download + flatten, host builder beside it
             import ctypes as C
             bs = R.Scene(R.assets.mesh_path(args.mesh), device=local_rank)

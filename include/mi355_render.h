@@ -173,8 +173,10 @@ int mi355_fetch_stats(mi355_ctx *, mi355_stats *stats);
  * the auto-spin orbit, k = 0..N-1, same scene, same size) for n_frames consecutive cameras.  A 1080p frame lasts as long
  * as its slowest tiles while most of the GPU has run dry; with the tiles of a few frames behind one dispenser the waves
  * always have work.  cams[f], lights[f * n_lights + i], d_out_xrgb[f], d_out_rgb_f32[f] (array or NULL) belong to frame f;
- * every frame's pixels are exactly those of mi355_render_device with the same arguments.  Modes 9 and 10 only,
- * 1 <= n_frames <= MI355_MAX_BATCH, no collect_stats.  Ray counters of mi355_fetch_stats are totals over the batch. */
+ * every frame's pixels are exactly those of mi355_render_device with the same arguments.  Raytrace modes 9, 10 (one
+ * launch for the batch) and raster modes 4-8 (the frames run side by side on internal streams, forked from and joined to
+ * hip_stream: the rasterizer's short kernels cannot fill the GPU one frame at a time); 1 <= n_frames <= MI355_MAX_BATCH,
+ * no collect_stats.  Ray counters of mi355_fetch_stats are totals over the batch. */
 #define MI355_MAX_BATCH 8
 int mi355_render_batch_device(mi355_ctx *, int mode, int n_frames, const mi355_camera *cams, const mi355_light *lights,
                               int n_lights, const mi355_opts *, void *const *d_out_xrgb, int pitch_bytes,

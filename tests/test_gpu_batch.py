@@ -111,8 +111,8 @@ def test_batch_argument_errors(dragon):
     dev = torch.device("cuda", 0)
     buf = torch.zeros((H, W), dtype=torch.int32, device=dev)
     cam, lights, n = R.benchmark_frame(0)
-    with pytest.raises(R.Mi355Error, match="raytrace modes only"):
-        dragon.render_batch_device(6, [cam, cam], [lights, lights], n, R.default_opts(W, H), [buf.data_ptr()] * 2, W * 4)
+    with pytest.raises(R.Mi355Error, match="raster and raytrace modes only"):
+        dragon.render_batch_device(2, [cam, cam], [lights, lights], n, R.default_opts(W, H), [buf.data_ptr()] * 2, W * 4)
     with pytest.raises(R.Mi355Error, match="n_frames"):
         dragon.render_batch_device(9, [cam] * 9, [lights] * 9, n, R.default_opts(W, H), [buf.data_ptr()] * 9, W * 4)
     with pytest.raises(R.Mi355Error, match="cannot collect"):
@@ -120,3 +120,31 @@ def test_batch_argument_errors(dragon):
     with pytest.raises(R.Mi355Error, match="ordered walk"):
         dragon.render_batch_device(9, [cam, cam], [lights, lights], n, R.default_opts(W, H, tune=dict(reforder=1)), [buf.data_ptr()] * 2, W * 4)
     torch.cuda.synchronize(dev)
+
+
+@pytest.mark.parametrize("mode", [4, 5, 6, 7, 8])
+def test_raster_batch_equals_single_frames(mode):
+    """Raster modes: the frames of a batch run side by side on internal streams, each with its own scratch; every frame
+    is bit for bit the single-frame render (which the parity tests compare with the oracle)."""
+    s = R.Scene(R.assets.mesh_path("chessboard.tri"))
+    W, H = 800, 600
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream(dev)
+    o = R.default_opts(W, H)
+    frames = [1, 30, 31, 77, 150]
+    if mode in (7, 8):
+        s.shadowmap_render(0, R.benchmark_frame(0)[1][0])
+    single = []
+    for f in frames:
+        cam, lights, n = R.benchmark_frame(f)
+        b = torch.zeros((H, W), dtype=torch.int32, device=dev)
+        s.render_device(mode, cam, lights, n, o, b.data_ptr(), W * 4, 0, st.cuda_stream)
+        single.append(b)
+    for rep in range(3):                  # repeated: the frames share nothing but the scene and the shadow map
+        bufs = [torch.full((H, W), 12345, dtype=torch.int32, device=dev) for _ in frames]
+        cl = [R.benchmark_frame(f) for f in frames]
+        s.render_batch_device(mode, [c[0] for c in cl], [c[1] for c in cl], cl[0][2], o, [b.data_ptr() for b in bufs], W * 4, None, st.cuda_stream)
+        torch.cuda.synchronize(dev)
+        for j in range(len(frames)):
+            assert bool((single[j] == bufs[j]).all()), "mode %d: frame %d of the batch differs (repeat %d)" % (mode, j, rep)
+            assert int((bufs[j] != 0).sum()) > 1000
