@@ -90,7 +90,7 @@ typedef struct {
      *            passed the checks of mi355_scene_set_bvh; counting frames always use the reference's
      *            order so that the counters below mean what they mean in the reference)
      *            | 8 (debug) counting frames profile the ordered walk: counters then describe that walk
-     *            | 16 reserved | 32 never hand a pixel's shadow rays to idle lanes
+     *            | 16, 32 reserved
      * [6], [7] reserved */
     int32_t tune[8];
 } mi355_opts;

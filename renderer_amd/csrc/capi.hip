@@ -228,7 +228,6 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.rmin = t[1] > 0 ? (t[1] > 64 ? 64 : t[1]) : 64;
     P.chunk = t[2] > 0 ? t[2] : 64;
     P.ref_order = (flags & 4) ? 1 : 0;
-    P.no_help = (flags & 32) ? 1 : 0;
     P.prof_ordered = (flags & 8) ? 1 : 0;
     P.blocks_per_cu = t[4] > 0 ? t[4] : 0;
     P.exact_box = (flags & 1) ? 1 : 0;

@@ -116,7 +116,6 @@ struct FrameParams {
     int32_t chunk;             // pixel indices a wave takes from the dispenser at a time
     int32_t exact_box;         // always use the exact six-division box test
     int32_t ref_order;         // walk in the reference's fixed left-first order even when the ordered walk is available
-    int32_t no_help;           // ordered walk: never hand shadow rays to idle lanes
     int32_t prof_ordered;      // counting frames profile the ordered walk instead of reproducing the reference's counters
     unsigned long long *wave_prof; // counting builds: 16 words of phase profile per wave (debug), or NULL
     const FrameCam *cams;      // batched launch: per-frame cameras / lights / outputs (device memory), else NULL

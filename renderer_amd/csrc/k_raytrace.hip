@@ -28,8 +28,6 @@
 //    record is requested as soon as it is known, and a triangle that passes the plane test has its
 //    edge record requested at the end of the step and judged during the lane's NEXT step -- legal
 //    because a candidate only updates the running best, never the visiting order.
-//  * A pixel's shadow rays feed its colour, not its reflection ray: at a fresh hit a lane without a
-//    pixel takes over the light loop while the owner goes on with the reflection.
 //
 // Arithmetic follows the cited reference lines operation by operation (dev_math.h).
 #include "dev_math.h"
@@ -60,8 +58,6 @@ struct Lane {
     float dmax;            // ordered walk: delta * max |inv| -- how far (in ray parameter) growing a box by delta can move its faces
     int sp;                // ordered walk: postponed children of this lane (the newest in `top`, the rest in LDS)
     uint32_t top;
-    int owner;             // LDS column (block-local thread index) of the pixel this lane works for: its own, or,
-                           // for a lane tracing another pixel's shadow rays, that pixel's
     int btri;              // closest triangle so far (leaf order), -1 = none
     f3 hit;
     float k1, k2, k3;      // kAB, kBC, kCA
@@ -412,13 +408,6 @@ k_raytrace(const DevScene S, const FrameParams P)
     __shared__ float lds_col[MI_MAX_DEPTH * 3 * 256];
     // LDS (ordered walk only, sized at launch): per-lane stack of postponed children, one row per level
     extern __shared__ uint32_t lds_stack[];
-    // LDS (ordered walk): shadow rays handed to idle lanes of the same wave.  lds_pend[c] = shadow jobs of the
-    // pixel in column c that other lanes still owe; lds_don = scratch for matching givers with takers.
-    __shared__ uint32_t lds_pend[256];
-    __shared__ uint32_t lds_don[256];
-    lds_pend[threadIdx.x] = 0u;            // (a wave only ever touches its own 64 entries: no barrier needed)
-    const bool HELP = ORDERED && !P.no_help;
-    bool awaiting = false;      // this lane's ray tree is walked, but handed-out shadow jobs are still running
     Lane L;
     bool alive = false;         // lane owns a pixel
     bool want_pixel = true;     // lane needs a (new) pixel
@@ -435,7 +424,7 @@ k_raytrace(const DevScene S, const FrameParams P)
     L.shadow_hit = false; L.li = 0; L.cr = L.cg = L.cb = 0.f; L.k1 = L.k2 = L.k3 = 0.f;
     L.o = L.d = L.hit = L.pn = L.refl = L.lp = L.inv = L.ph = mk3(0.f, 0.f, 0.f);
     L.tame = false; L.pend = false; L.pj = -1;
-    L.limit = 0.f; L.delta = 0.f; L.dmax = 0.f; L.sp = 0; L.top = MI_END_LINK; L.owner = (int)threadIdx.x;
+    L.limit = 0.f; L.delta = 0.f; L.dmax = 0.f; L.sp = 0; L.top = MI_END_LINK;
     L.pe1 = L.pe2 = L.pe3 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     unsigned n_normal = 0, n_shadow = 0;
@@ -529,11 +518,9 @@ k_raytrace(const DevScene S, const FrameParams P)
         }
 
         // a lane's ray is complete when its walk has ended and no candidate is left to judge
-        // (a lane waiting for handed-out shadow jobs is neither walking nor ready)
-        const bool blocked = awaiting && lds_pend[threadIdx.x] != 0u;
-        const bool ray_done = alive && L.cur == MI_END_LINK && !L.pend && !blocked;
+        const bool ray_done = alive && L.cur == MI_END_LINK && !L.pend;
         const unsigned long long mX = __ballot(ray_done);
-        const unsigned long long mT = __ballot(alive && !ray_done && !blocked);
+        const unsigned long long mT = __ballot(alive && !ray_done);
         if (!mX && !mT) {
             if (!__ballot(want_pixel)) break;
             continue;
@@ -545,53 +532,20 @@ k_raytrace(const DevScene S, const FrameParams P)
             // ---------------- transitions ------------------------------------------------
             MI_PHASE(pc_refill);
             if (STATS) { it_trans++; ln_trans += __popcll(mX); }
-            const int self = (int)threadIdx.x;
             bool finish = false;     // ray tree complete -> fold
             bool lights = false;     // continue with light loop
-            bool offer = false;      // a fresh hit whose shadow rays another lane could trace
-            bool handed = false;     // ... and one took them
             if (ray_done) {
-                if (awaiting) { awaiting = false; finish = true; }          // every level's colour has arrived
-                else if (L.mode == MODE_CLOSEST) {
+                if (L.mode == MODE_CLOSEST) {
                     if (L.btri < 0) finish = true;                  // Raytracer.cc:327-331
                     else {
                         if (STATS) n_shaded++;
                         shade_begin(P, S, L);
                         lights = true;
-                        offer = HELP && P.use_shadows && P.n_lights > 0;
                     }
                 } else {
-                    if (!L.shadow_hit) add_light<BATCH>(P, S, L);          // Raytracer.cc:458-466
+                    if (!L.shadow_hit) add_light<BATCH>(P, S, L);   // Raytracer.cc:458-466
                     L.li++;
                     lights = true;
-                }
-            }
-            // A pixel's shadow rays do not feed its reflection ray, only its colour (Raytracer.cc:440-521), and the
-            // frame lasts as long as its slowest pixel -- so a lane without a pixel takes over the light loop of
-            // a fresh hit (same operations, same order, result into the owner's LDS colour column) while the
-            // owner goes on with the reflection.
-            if (HELP) {
-                const unsigned long long mOffer = __ballot(offer), mIdle = __ballot(!alive);
-                if (mOffer && mIdle) {
-                    const int lane = self & 63, wbase = self & ~63;
-                    const int nO = __popcll(mOffer), nI = __popcll(mIdle);
-                    const int n = nO < nI ? nO : nI;
-                    const unsigned long long below = (1ull << lane) - 1ull;
-                    const bool give = offer && __popcll(mOffer & below) < n;
-                    const bool take = !alive && __popcll(mIdle & below) < n;
-                    if (give) lds_don[wbase + __popcll(mOffer & below)] = (uint32_t)lane;
-                    const int src = take ? (int)lds_don[wbase + __popcll(mIdle & below)] : lane;
-                    const float hx = __shfl(L.hit.x, src), hy = __shfl(L.hit.y, src), hz = __shfl(L.hit.z, src);
-                    const float nx = __shfl(L.pn.x, src), ny = __shfl(L.pn.y, src), nz = __shfl(L.pn.z, src);
-                    const float c0 = __shfl(L.cr, src), c1 = __shfl(L.cg, src), c2 = __shfl(L.cb, src);
-                    const int bt = __shfl(L.btri, src), dp = __shfl(L.depth, src), fi = __shfl(L.fid, src);
-                    if (give) { atomicAdd(&lds_pend[self], 1u); handed = true; lights = false; }
-                    if (take) {
-                        L.hit = mk3(hx, hy, hz); L.pn = mk3(nx, ny, nz); L.cr = c0; L.cg = c1; L.cb = c2;
-                        L.btri = bt; L.depth = dp; L.fid = fi; L.li = 0; L.owner = wbase + src;
-                        L.pend = false; L.cur = MI_END_LINK;
-                        alive = true; want_pixel = false; lights = true;
-                    }
                 }
             }
             if (lights) {
@@ -621,30 +575,17 @@ k_raytrace(const DevScene S, const FrameParams P)
                     L.li++;
                 }
                 if (!launched) {
-                    // all lights done for this hit: store the level colour
-                    set_c(lds_col, L.owner, L.depth, L.cr, L.cg, L.cb);
-                    if (L.owner != self) {
-                        // ... of somebody else's pixel: report and go idle
-                        atomicSub(&lds_pend[L.owner], 1u);
-                        L.owner = self; L.cur = MI_END_LINK; L.mode = MODE_CLOSEST;
-                        alive = false; want_pixel = true;
-                    } else handed = true;                       // ... of our own: bounce or finish below
+                    // all lights done for this hit: store the level colour, bounce or finish
+                    set_c(lds_col, (int)threadIdx.x, L.depth, L.cr, L.cg, L.cb);
+                    L.depth++;
+                    if (P.use_refl && L.depth < P.max_depth) {
+                        L.o = L.hit; L.d = L.refl; L.avoid = L.btri;
+                        set_ray_aux(L, S.scene_mag);
+                        L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
+                        begin_walk<ORDERED>(S, L, R, R2);
+                        n_normal++;
+                    } else finish = true;
                 }
-            }
-            if (handed) {
-                L.depth++;
-                if (P.use_refl && L.depth < P.max_depth) {
-                    L.o = L.hit; L.d = L.refl; L.avoid = L.btri;
-                    set_ray_aux(L, S.scene_mag);
-                    L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
-                    begin_walk<ORDERED>(S, L, R, R2);
-                    n_normal++;
-                } else finish = true;
-            }
-            if (finish && HELP && lds_pend[self] != 0u) {
-                // the tree is walked but a level's colour is still being worked out by another lane
-                awaiting = true; finish = false;
-                L.cur = MI_END_LINK; L.pend = false; L.mode = MODE_CLOSEST;
             }
             if (finish) {
                 // fold c[depth-1] ... c[0] (Raytracer.cc:538-551 with Types.h:137-142)
@@ -823,7 +764,7 @@ k_raytrace(const DevScene S, const FrameParams P)
             }
             const unsigned long long mBusy = __ballot(L.cur != MI_END_LINK || L.pend);
             if (!mBusy) break;
-            if (xmin_now < 64 && __popcll(__ballot(alive && L.cur == MI_END_LINK && !L.pend && !awaiting)) >= xmin_now) break;
+            if (xmin_now < 64 && __popcll(__ballot(alive && L.cur == MI_END_LINK && !L.pend)) >= xmin_now) break;
         }
         } else {
         // ---- walk in the reference's order (threaded links): counting builds, unchecked trees ----
@@ -895,7 +836,7 @@ k_raytrace(const DevScene S, const FrameParams P)
             if (mL) MI_PHASE(pc_b);
             const unsigned long long mBusy = __ballot(alive && !(L.cur == MI_END_LINK && !L.pend));
             if (!mBusy) break;
-            if (xmin_now < 64 && __popcll(__ballot(alive && L.cur == MI_END_LINK && !L.pend && !awaiting)) >= xmin_now) break;
+            if (xmin_now < 64 && __popcll(__ballot(alive && L.cur == MI_END_LINK && !L.pend)) >= xmin_now) break;
         }
         }
     }
