@@ -10,7 +10,9 @@ frames/s is reported beside it, and the chessboard Phong rasterizer (configs[1])
 --frames-per-step 1 renders frame by frame (one launch per frame).
 
 N>1: one process per GPU; every rank renders its interleaved 15-row screen bands of the SAME frames
-and a single RCCL gather per step assembles them on rank 0 (strong scaling).
+and a single RCCL gather per step assembles them on rank 0.  By default a step carries 8 frames per GPU
+(8*N frames: the work per GPU is fixed, "scaling": "weak"); --frames-per-step F fixes the step at F frames
+whatever N is ("strong").
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W]
        (N>1 is launched by torch.distributed.run, one rank per GPU)
@@ -44,8 +46,9 @@ def main():
     ap.add_argument("--mesh", default="dragon_vis.ply")
     ap.add_argument("--mode", type=int, default=9)
     ap.add_argument("--tune", default="{}", help="JSON dict of renderer_amd.tune() knobs")
-    ap.add_argument("--frames-per-step", type=int, default=8,
-                    help="frames of the orbit rendered by one launch (raytrace modes; mi355_render_batch_device, 1..8)")
+    ap.add_argument("--frames-per-step", type=int, default=0,
+                    help="frames of the orbit rendered by one launch per GPU (raytrace modes; mi355_render_batch_device, 1..64); "
+                         "default 8 per GPU: with N GPUs a step is 8*N frames, each GPU renders its bands of all of them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (rasterizer) workloads")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -72,7 +75,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     W, H, K, WU = args.width, args.height, args.steps, args.warmup
-    B = max(1, min(8, args.frames_per_step)) if args.mode >= 9 else 1      # frames per step (= per launch)
+    # frames per step (= per launch on every GPU): the work per GPU stays that of 8 whole frames as GPUs are added
+    B = max(1, min(64, args.frames_per_step if args.frames_per_step > 0 else 8 * max(world, 1))) if args.mode >= 9 else 1
     scene = R.Scene(R.assets.mesh_path(args.mesh), device=local_rank)
     if args.mode >= 9:
         scene.bvh_update()                 # <mesh>.bvh cache in the scratch dir, else build (untimed, like -b)
@@ -179,14 +183,14 @@ def main():
             "warmup": WU,
             "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if args.frames_per_step <= 0 else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic orbit: reference mesh %s (shipped asset), the reference's benchmark cameras f0..f199 (the orbit repeats), "
                     "BVH built on the GPU by the library" % args.mesh,
             "config": {"workload": "%s, BVH raytrace mode %d (primary + shadow rays + 2 reflection bounces), %dx%d, 1 light"
                                    % (args.mesh, args.mode, W, H),
-                       "parallelism": "screen bands x%d, 1 RCCL gather/frame" % world if world > 1 else "single GPU",
+                       "parallelism": "screen bands x%d, 1 RCCL gather/step" % world if world > 1 else "single GPU",
                        "frames_per_step": B, "frames": K * B,
                        "rays_per_frame": round(total_rays / (K * B), 1), "tune": json.loads(args.tune)},
             "frames_per_sec": round(K * B / dt, 3),

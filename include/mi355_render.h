@@ -177,7 +177,7 @@ int mi355_fetch_stats(mi355_ctx *, mi355_stats *stats);
  * launch for the batch) and raster modes 4-8 (the frames run side by side on internal streams, forked from and joined to
  * hip_stream: the rasterizer's short kernels cannot fill the GPU one frame at a time); 1 <= n_frames <= MI355_MAX_BATCH,
  * no collect_stats.  Ray counters of mi355_fetch_stats are totals over the batch. */
-#define MI355_MAX_BATCH 8
+#define MI355_MAX_BATCH 64
 int mi355_render_batch_device(mi355_ctx *, int mode, int n_frames, const mi355_camera *cams, const mi355_light *lights,
                               int n_lights, const mi355_opts *, void *const *d_out_xrgb, int pitch_bytes,
                               void *const *d_out_rgb_f32, void *hip_stream);

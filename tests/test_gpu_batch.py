@@ -47,7 +47,7 @@ def render_batch(s, mode, frames, opts, W, H, want_f32=False, second_light=False
     return bufs, bfs, stt.normal_rays + stt.shadow_rays
 
 
-@pytest.mark.parametrize("n", [2, 3, 8])
+@pytest.mark.parametrize("n", [2, 3, 8, 20])
 def test_batch_equals_single_frames(dragon, n):
     W, H = 640, 360
     o = R.default_opts(W, H)
@@ -114,7 +114,7 @@ def test_batch_argument_errors(dragon):
     with pytest.raises(R.Mi355Error, match="raster and raytrace modes only"):
         dragon.render_batch_device(2, [cam, cam], [lights, lights], n, R.default_opts(W, H), [buf.data_ptr()] * 2, W * 4)
     with pytest.raises(R.Mi355Error, match="n_frames"):
-        dragon.render_batch_device(9, [cam] * 9, [lights] * 9, n, R.default_opts(W, H), [buf.data_ptr()] * 9, W * 4)
+        dragon.render_batch_device(9, [cam] * 65, [lights] * 65, n, R.default_opts(W, H), [buf.data_ptr()] * 65, W * 4)
     with pytest.raises(R.Mi355Error, match="cannot collect"):
         dragon.render_batch_device(9, [cam, cam], [lights, lights], n, R.default_opts(W, H, collect_stats=1), [buf.data_ptr()] * 2, W * 4)
     with pytest.raises(R.Mi355Error, match="ordered walk"):
