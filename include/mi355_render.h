@@ -80,8 +80,8 @@ typedef struct {
     int32_t band_rows, band_index, band_count, compact_rows;
     int32_t collect_stats;   /* fill the traversal counters of mi355_stats (slower kernel variant) */
     /* Kernel tuning knobs; all 0 = defaults.  They never change a pixel (tests/test_gpu_parity.py).
-     * [0] xmin   lanes waiting for a state transition before the wave services them
-     * [1] rmin   idle lanes before the wave refills from the pixel dispenser
+     * [0] xmin   lanes waiting for a state transition before the wave services them (default 64: whole wave)
+     * [1] rmin   idle lanes before the wave refills from the pixel dispenser (default 64: whole wave)
      * [2] chunk  pixel indices a wave takes from the dispenser at once
      * [3] reserved
      * [4] blocks per CU (0 = occupancy query)

@@ -9,9 +9,12 @@
 //    closest-hit walk -> shading -> one any-hit shadow walk per light -> reflection walk ... ->
 //    fold the per-depth colours.  The reference's recursion (Raytracer.cc:315-553) becomes
 //    forward evaluation + a backward fold with the same clamping Pixel::operator+ at each level.
-//  * Wavefronts are persistent: a lane that finishes its pixel pulls the next one from a dispenser
-//    (ballot + mbcnt ranking, one global atomic per 8x8 tile, eight counters), so the 64 lanes stay
-//    packed although ~88 % of primary rays die at the root box.
+//  * Wavefronts are persistent and pull 8x8 tiles from a dispenser (one global atomic per tile, eight
+//    counters; ballot + mbcnt ranking hands the pixels to lanes).  By default a wave takes pixels when all
+//    its lanes are free and runs a transition phase when all its rays have ended (xmin = rmin = 64): it
+//    works through a tile in lockstep generations, with the fewest of the expensive phases.  One launch
+//    can carry the tiles of several frames (BATCH), so the waves do not run dry while one frame's slowest
+//    tiles finish.
 //  * Two walks over the same tree, both bit-identical to the reference:
 //    - ORDERED (production): near child first with a per-lane stack (top in a register, rest in LDS),
 //      both children's boxes tested per step from a 64-byte wide record, subtrees beyond the best hit
