@@ -723,6 +723,45 @@ k_raytrace(const DevScene S, const FrameParams P)
                     if ((next & MI_LEAF_BIT) == 0) { R2.a = p[2]; R2.b = p[3]; }
                 }
             }
+            if constexpr (WAVES >= 3) {
+            // 4. while that request is in flight: this step's triangle -- plane half, and for the lanes that pass it the
+            //    edge half at once (Raytracer.cc:245-297 as straight-line predicates: the same float operations in the
+            //    same order, without the early returns).  Throughput builds (three waves per SIMD): the wait for the edge
+            //    record is covered by the other waves, and without a deferred candidate the lane state fits 168 registers.
+            if (mL) {
+                if (STATS) { it_b++; ln_b += __popcll(mL); }
+                const int j = (int)(((tcur & MI_INDEX_MASK) - S.tri_base) >> 1);
+                const f3 n = mk3(ta.x, ta.y, ta.z);
+                const f3 fto = sub3(L.o, mk3(tb.x, tb.y, tb.z));
+                const bool facing = (tcur & MI_TWOSIDED_BIT) != 0u || !(dot3(fto, n) < 0.f);
+                const float k = dot3(n, L.d);
+                const float sp = (tb.w - dot3(n, L.o)) / k;
+                const bool cand = tri && j != L.avoid && facing && !(k == 0.0f) && !(sp <= 0.0f) && !(sp <= P.nudge);
+                if (STATS && tri) { n_tris++; if (cand) n_plane++; }
+                if (__ballot(cand)) {
+                    float4 e1 = make_float4(0.f, 0.f, 0.f, 0.f), e2 = e1, e3 = e1;
+                    if (cand) { const float4 *e = S.tri_edge + (size_t)j * 3; e1 = e[0]; e2 = e[1]; e3 = e[2]; }
+                    const f3 hit = add3(mul3(L.d, sp), L.o);
+                    const float kt1 = dot3(mk3(e1.x, e1.y, e1.z), hit) - e1.w;
+                    const float kt2 = dot3(mk3(e2.x, e2.y, e2.z), hit) - e2.w;
+                    const float kt3 = dot3(mk3(e3.x, e3.y, e3.z), hit) - e3.w;
+                    const bool inside = cand && !(kt1 < 0.0f) && !(kt2 < 0.0f) && !(kt3 < 0.0f);
+                    const bool shadow = L.mode == MODE_SHADOW;
+                    const f3 from = shadow ? L.lp : L.o;
+                    const float dz = distsq3(from, hit);
+                    const bool nearer = dz < L.best;
+                    if (inside && shadow && nearer) {                // a blocked shadow ray stops (Raytracer.cc:284)
+                        L.shadow_hit = true; L.cur = MI_END_LINK; L.sp = 0;
+                    }
+                    // candidates arrive in any order: lowest list position wins among equal distances
+                    if (inside && !shadow && (nearer || (dz == L.best && j < L.btri))) {
+                        L.best = dz; L.btri = j; L.hit = hit; L.k1 = kt1; L.k2 = kt2; L.k3 = kt3;
+                        L.limit = __builtin_sqrtf(dz) * 1.001f + L.delta;
+                    }
+                }
+                MI_PHASE(pc_b);
+            }
+            } else {
             // 4. while that request is in flight: judge the candidate of the previous step (its edge record has long
             //    arrived) and plane-test this step's triangle.  Both are written as straight-line predicates -- the
             //    same float operations in the same order as Raytracer.cc:245-297, without its early returns.
@@ -764,6 +803,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     }
                 }
                 MI_PHASE(pc_b);
+            }
             }
             const unsigned long long mBusy = __ballot(L.cur != MI_END_LINK || L.pend);
             if (!mBusy) break;
