@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (not part of the test suite): GPU BVH builder vs host builder byte for byte, and traced
 frames of the production kernel vs the oracle, over random triangle soups (snapped to grids to force ties)."""
-import argparse, os, sys, tempfile
+import argparse, json, os, sys, tempfile
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import renderer_amd as R
@@ -10,6 +10,7 @@ from oracle import oracle_ctypes as O
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=60)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--tune", default="{}", help="JSON dict of renderer_amd.tune() knobs, e.g. '{\"bpc\": 3}' to force the three-wave build")
 args = ap.parse_args()
 O.build()
 tmp = tempfile.mkdtemp()
@@ -48,7 +49,7 @@ for it in range(args.n):
         cam, lights, n = R.benchmark_frame(frame); ocam, ol, on = O.benchmark_frame(frame)
         W, H = 320, 240
         mode = 10 if rng.random() < 0.25 else 9
-        img, f32, st = d.render(mode, cam, lights, n, R.default_opts(W, H), want_f32=True)
+        img, f32, st = d.render(mode, cam, lights, n, R.default_opts(W, H, tune=json.loads(args.tune)), want_f32=True)
         oi, of32, ost = o.render(mode, ocam, ol, on, O.default_opts(W, H, threads=os.cpu_count() or 1), want_f32=True)
         diff += int((img != oi).sum()) + int((f32 != of32).sum()) + int(st.normal_rays != ost.normal_rays) + int(st.shadow_rays != ost.shadow_rays)
     ok = same_tree and diff == 0
