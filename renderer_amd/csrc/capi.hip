@@ -18,8 +18,8 @@
 #include <vector>
 
 // kernel launchers (defined next to their kernels)
-extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves3, int batch, int stack_depth);
-extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int ordered, int waves3, int batch, int n_blocks,
+extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth);
+extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int ordered, int waves, int batch, int n_blocks,
                                              hipStream_t);
 extern "C" hipError_t mi355i_bvh_launch_prims(const float4 *rs_vert, const uint4 *rs_idx, uint32_t T, float4 *prim, uint32_t *list,
                                               uint32_t *bad, hipStream_t st);
@@ -455,23 +455,28 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipSt
     case MI355_MODE_RAYTRACE: case MI355_MODE_RAYTRACE_ANTIALIAS: {
         if (!c->has_bvh) return fail(-41, "raytrace modes need mi355_scene_set_bvh first");
         const int ordered = ((!stats || P.prof_ordered) && !P.ref_order && c->dev.ordered_ok) ? 1 : 0;
-        // A third wave per SIMD pays when the frame is long enough to be throughput bound (4K, 4 spp: +10 %); a 1080p
-        // frame is bound by its slowest tiles and runs faster with two (measured, profiles/).  The three-wave build
-        // spills some transition state, so it is only used when three blocks per CU are wanted.
+        // More waves per SIMD pay when the launch is long enough to be throughput bound (batches, 4K, 4 spp: three waves
+        // +10-18 %, four another +6 %); a single 1080p frame is bound by its slowest tiles and runs fastest with two
+        // (measured, profiles/).  A build is only used if that many blocks of it fit a CU (registers, LDS stack).
         const int batch = (P.n_frames > 1 && P.cams) ? 1 : 0;
         if (batch && !(ordered && !stats)) return fail(-41, "batched frames need the ordered walk (checked tree, no collect_stats, no reference-order flag)");
         const long long work_tiles = (((long long)P.W + 7) / 8) * (((long long)P.n_rows + 7) / 8) * (P.aa ? 4 : 1) * P.n_frames;
-        int waves3 = 0;
-        if (ordered && !stats && (P.blocks_per_cu == 0 ? work_tiles >= 20ll * 3 * c->n_cus * 4 : P.blocks_per_cu >= 3))
-            waves3 = mi355i_raytrace_blocks_per_cu(0, P.exact_box, 1, 1, batch, (int)c->dev.stack_depth) >= 3 ? 1 : 0;
-        int per_cu = mi355i_raytrace_blocks_per_cu(stats, P.exact_box, ordered, waves3, batch, (int)c->dev.stack_depth);
+        int waves = 2;
+        if (ordered && !stats) {
+            for (int w = 4; w >= 3; w--) {
+                const bool wanted = P.blocks_per_cu == 0 ? work_tiles >= 20ll * w * c->n_cus * 4 : P.blocks_per_cu >= w;
+                if (wanted && mi355i_raytrace_blocks_per_cu(0, P.exact_box, 1, w, batch, (int)c->dev.stack_depth) >= w) { waves = w; break; }
+            }
+        }
+        int per_cu = mi355i_raytrace_blocks_per_cu(stats, P.exact_box, ordered, waves, batch, (int)c->dev.stack_depth);
+        if (per_cu > waves) per_cu = waves;
         if (P.blocks_per_cu > 0 && P.blocks_per_cu < per_cu) per_cu = P.blocks_per_cu;
         int n_blocks = per_cu * c->n_cus;
         const long long lanes_needed = ((long long)P.W * P.n_rows * P.n_frames + 255) / 256;
         if (n_blocks > lanes_needed) n_blocks = (int)(lanes_needed > 0 ? lanes_needed : 1);
         c->last_blocks = n_blocks;
         if (P.wave_prof) HIP_TRY(hipMemsetAsync(c->wave_prof.p, 0, (size_t)n_blocks * 4 * 16 * 8, st), -40);
-        e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, waves3, batch, n_blocks, st);
+        e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, waves, batch, n_blocks, st);
         break;
     }
     case MI355_MODE_LINES:

@@ -399,8 +399,9 @@ MI_DEV bool tri_edge_test(Lane &L)
 
 } // namespace
 
-// WAVES = wavefronts per SIMD the register allocation aims at: 2 keeps everything in registers (1080p frames run
-// two blocks per CU anyway), 3 spills a little transition state to scratch and pays off on long frames.
+// WAVES = wavefronts per SIMD the register allocation aims at: 2 for the latency of a single 1080p frame (deferred edge
+// test, everything in registers), 3 and 4 for launches long enough to be throughput bound (edge test in the same step;
+// the 128-register build spills ~100 bytes of transition state per lane and still wins by 6 %).
 // BATCH = the launch renders P.n_frames frames (tile slot s belongs to frame s % n_frames: every frame's heavy centre
 // tiles are handed out first); the waves then never run dry while one frame's slowest tiles finish.
 template <bool STATS, bool EXACT_BOX, bool ORDERED, int WAVES, bool BATCH>
@@ -929,15 +930,20 @@ k_raytrace(const DevScene S, const FrameParams P)
 // ---- launch helper (called from capi.hip) ------------------------------------------------
 namespace {
 typedef void (*rt_kernel)(const DevScene, const FrameParams);
-rt_kernel pick_kernel(int stats, int exact, int ordered, int waves3, int batch)
+// waves = wavefronts per SIMD the build is allocated for (2, 3 or 4; counting and reference-order builds: 2)
+template <bool EXACT, bool BATCH> rt_kernel ordered_kernel(int waves)
 {
-    if (ordered && !stats && batch) {
-        if (waves3) return exact ? k_raytrace<false, true, true, 3, true> : k_raytrace<false, false, true, 3, true>;
-        return exact ? k_raytrace<false, true, true, 2, true> : k_raytrace<false, false, true, 2, true>;
+    if (waves >= 4) return k_raytrace<false, EXACT, true, 4, BATCH>;
+    if (waves == 3) return k_raytrace<false, EXACT, true, 3, BATCH>;
+    return k_raytrace<false, EXACT, true, 2, BATCH>;
+}
+rt_kernel pick_kernel(int stats, int exact, int ordered, int waves, int batch)
+{
+    if (ordered && !stats) {
+        if (batch) return exact ? ordered_kernel<true, true>(waves) : ordered_kernel<false, true>(waves);
+        return exact ? ordered_kernel<true, false>(waves) : ordered_kernel<false, false>(waves);
     }
-    if (ordered && stats) return exact ? k_raytrace<true, true, true, 2, false> : k_raytrace<true, false, true, 2, false>;
-    if (ordered && waves3) return exact ? k_raytrace<false, true, true, 3, false> : k_raytrace<false, false, true, 3, false>;
-    if (ordered) return exact ? k_raytrace<false, true, true, 2, false> : k_raytrace<false, false, true, 2, false>;
+    if (ordered) return exact ? k_raytrace<true, true, true, 2, false> : k_raytrace<true, false, true, 2, false>;
     if (stats) return exact ? k_raytrace<true, true, false, 2, false> : k_raytrace<true, false, false, 2, false>;
     return exact ? k_raytrace<false, true, false, 2, false> : k_raytrace<false, false, false, 2, false>;
 }
@@ -947,24 +953,25 @@ size_t stack_bytes(int ordered, int stack_depth) { return ordered ? (size_t)stac
 // can this build render several frames per launch?  (the ordered, non-counting kernels only)
 extern "C" int mi355i_raytrace_can_batch(int stats, int ordered) { return ordered && !stats; }
 
-// blocks per CU the (stats, exact, ordered, waves3, batch) variant can hold
-extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves3, int batch, int stack_depth)
+// blocks per CU the (stats, exact, ordered, waves, batch) variant can hold
+extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth)
 {
-    static int cache[2][2][2][2][2][MI_MAX_STACK + 1];        // 0 = not asked yet
+    static int cache[2][2][2][3][2][MI_MAX_STACK + 1];        // 0 = not asked yet
     if (stack_depth < 0 || stack_depth > MI_MAX_STACK) stack_depth = MI_MAX_STACK;
-    int &slot = cache[stats ? 1 : 0][exact ? 1 : 0][ordered ? 1 : 0][waves3 ? 1 : 0][batch ? 1 : 0][ordered ? stack_depth : 0];
+    const int w = waves >= 4 ? 2 : (waves == 3 ? 1 : 0);
+    int &slot = cache[stats ? 1 : 0][exact ? 1 : 0][ordered ? 1 : 0][w][batch ? 1 : 0][ordered ? stack_depth : 0];
     if (!slot) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_kernel(stats, exact, ordered, waves3, batch), 256, stack_bytes(ordered, stack_depth)) != hipSuccess || nb < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_kernel(stats, exact, ordered, waves, batch), 256, stack_bytes(ordered, stack_depth)) != hipSuccess || nb < 1)
             nb = 2;
         slot = nb > 8 ? 8 : nb;
     }
     return slot;
 }
 
-extern "C" hipError_t mi355i_launch_raytrace(const DevScene *S, const FrameParams *P, int stats, int exact, int ordered, int waves3,
+extern "C" hipError_t mi355i_launch_raytrace(const DevScene *S, const FrameParams *P, int stats, int exact, int ordered, int waves,
                                              int batch, int n_blocks, hipStream_t st)
 {
-    hipLaunchKernelGGL(pick_kernel(stats, exact, ordered, waves3, batch), dim3(n_blocks), dim3(256), stack_bytes(ordered, (int)S->stack_depth), st, *S, *P);
+    hipLaunchKernelGGL(pick_kernel(stats, exact, ordered, waves, batch), dim3(n_blocks), dim3(256), stack_bytes(ordered, (int)S->stack_depth), st, *S, *P);
     return hipGetLastError();
 }

@@ -7,7 +7,7 @@ import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
-KERNEL = "k_raytrace<false, false, true, 3, true>"   # the bench kernel: ordered walk, batched launch, three waves per SIMD
+KERNEL = "k_raytrace<false, false, true, 4, true>"   # the bench kernel: ordered walk, batched launch, three waves per SIMD
 
 
 def newest(pattern):

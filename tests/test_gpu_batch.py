@@ -77,7 +77,7 @@ def test_batch_antialias_two_lights_and_knobs(oracle, oracle_scene):
     s.bvh_update()
     W, H = 320, 240
     for mode, second, tune in ((10, False, {}), (9, True, {}), (9, False, dict(xmin=1, rmin=1)), (9, False, dict(exact=1)),
-                               (9, False, dict(nohelp=1, bpc=1))):
+                               (9, False, dict(nohelp=1, bpc=1)), (9, True, dict(bpc=3)), (10, False, dict(bpc=4)), (9, True, dict(bpc=4, exact=1))):
         o = R.default_opts(W, H, tune=tune)
         frames = [2, 40, 41]
         dev = torch.device("cuda", 0)
