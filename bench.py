@@ -201,7 +201,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(total_abytes / K / (kernel_ms * 1e-3) / 1e9 / max(world, 1) / HBM_PEAK_GBS, 5),
                 "traffic": None,
-                "kernel": "k_raytrace<false,false,true> (ordered walk)",
+                "kernel": "k_raytrace<STATS=false, EXACT_BOX=false, ORDERED=true, WAVES=2|3|4 by launch size, BATCH=frames>1> (ordered walk)",
                 "kernel_ms": round(kernel_ms, 5),
                 "algorithmic_bytes_per_launch": round(total_abytes / K / max(world, 1), 1),
                 "frames_per_launch": B,

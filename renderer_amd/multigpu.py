@@ -42,13 +42,15 @@ def assemble_numpy(parts, height: int, band_rows: int) -> np.ndarray:
 class FrameGatherer:
     """Gathers per-rank compact band buffers on rank 0 and de-interleaves them (torch tensors)."""
 
-    def __init__(self, width: int, height: int, device, band_rows: int = BAND_ROWS, group=None, frames: int = 1):
+    def __init__(self, width: int, height: int, device, band_rows: int = BAND_ROWS, group=None, frames: int = 1,
+                 collective_when_alone: bool = False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.W, self.H, self.band_rows, self.device = width, height, band_rows, device
+        self.alone = self.world == 1 and not collective_when_alone   # a lone rank skips the collective (unless asked: hardware checks)
         self.frames = frames            # frames per gather (a batched launch renders several at once)
         self.my_rows = rows_of_rank(height, band_rows, self.world, self.rank)
         self.max_rows = max(rows_of_rank(height, band_rows, self.world, r) for r in range(self.world))
@@ -71,7 +73,7 @@ class FrameGatherer:
 
     def gather(self, slot: int, async_op: bool = True):
         """Launch the gather of buffer `slot` to rank 0 (one collective per frame)."""
-        if self.world == 1:
+        if self.alone:
             return None
         if self.rank == 0:
             lst = list(self.recv[slot].unbind(0))
@@ -89,12 +91,12 @@ class FrameGatherer:
         if self.rank != 0:
             return None
         if self.frames == 1:
-            if self.world == 1:
+            if self.alone:
                 return self.send[slot][: self.H]
             flat = self.recv[slot].view(self.world * self.max_rows, self.W)
             return flat.index_select(0, self.src_rows)
         # [frames, H, W]: frame f's row y lives at recv[owner, f, local]
-        if self.world == 1:
+        if self.alone:
             return self.send[slot][:, : self.H]
         flat = self.recv[slot].permute(1, 0, 2, 3).reshape(self.frames, self.world * self.max_rows, self.W)
         return flat.index_select(1, self.src_rows)
