@@ -399,9 +399,10 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
     for (uint32_t j = 0; j < T; j++) {
         const uint32_t t = (uint32_t)triIdx[j];
         const float *d = &c->td[4 * t], *e = &c->te[9 * t];
+        // e1 whole, e2 and e3 side by side component by component: their two half-plane tests run as packed arithmetic
         edge[(size_t)j * 3] = make_float4(e[0], e[1], e[2], d[1]);
-        edge[(size_t)j * 3 + 1] = make_float4(e[3], e[4], e[5], d[2]);
-        edge[(size_t)j * 3 + 2] = make_float4(e[6], e[7], e[8], d[3]);
+        edge[(size_t)j * 3 + 1] = make_float4(e[3], e[6], e[4], e[7]);
+        edge[(size_t)j * 3 + 2] = make_float4(e[5], e[8], d[2], d[3]);
         const int32_t *ix = &c->tidx[3 * t];
         const V3h A = {c->vpos[3 * ix[0]], c->vpos[3 * ix[0] + 1], c->vpos[3 * ix[0] + 2]};
         const V3h B = {c->vpos[3 * ix[1]], c->vpos[3 * ix[1] + 1], c->vpos[3 * ix[1] + 2]};

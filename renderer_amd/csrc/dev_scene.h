@@ -10,7 +10,7 @@
 //   walk      [...]        float4   traversal records, 32 B each, one buffer so that address = base + 16*link:
 //                                  inner nodes first (box + hit/miss links), then one triangle block
 //                                  per triangle in leaf order (normal, next link | centre, d)
-//   tri_edge  [T][3]       float4   leaf test, second half (e1..e3,d1..d3)  48 B
+//   tri_edge  [T][3]       float4   leaf test, second half: (e1,d1) (e2.x,e3.x,e2.y,e3.y) (e2.z,e3.z,d2,d3)  48 B
 //   tri_shade [T][5]       float4   closest-hit shading                     80 B
 //   (triangle blocks and both tri_* streams are in LEAF ORDER = position in triIndexList)
 //

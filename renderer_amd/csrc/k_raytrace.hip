@@ -374,6 +374,17 @@ MI_DEV bool tri_plane_test(const Lane &L, float nudge, uint32_t link, int j, con
     return true;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// edge record -> (e_i, d_i) as float4s (dev_scene.h: e2 and e3 are stored interleaved)
+MI_DEV void load_edges(const float4 *e, float4 &e1, float4 &e2, float4 &e3)
+{
+    const float4 q = e[1], r = e[2];
+    e1 = e[0];
+    e2 = make_float4(q.x, q.z, r.x, r.z);
+    e3 = make_float4(q.y, q.w, r.y, r.w);
+}
+
 // edge half (Raytracer.cc:269-297) of the pending candidate; returns true when a shadow ray is blocked
 // (ordered walk: candidates arrive in any order, so "first found wins among equal distances" becomes
 //  "lowest list position wins" -- the same triangle, list position being the reference's visiting rank)
@@ -740,12 +751,16 @@ k_raytrace(const DevScene S, const FrameParams P)
                 const bool cand = tri && j != L.avoid && facing && !(k == 0.0f) && !(sp <= 0.0f) && !(sp <= P.nudge);
                 if (STATS && tri) { n_tris++; if (cand) n_plane++; }
                 if (__ballot(cand)) {
-                    float4 e1 = make_float4(0.f, 0.f, 0.f, 0.f), e2 = e1, e3 = e1;
-                    if (cand) { const float4 *e = S.tri_edge + (size_t)j * 3; e1 = e[0]; e2 = e[1]; e3 = e[2]; }
+                    // (every lane loads: the others read triangle 0's record, one broadcast line, instead of twelve
+                    //  register clears and a divergent region)
+                    const float4 *e = S.tri_edge + (size_t)(cand ? j : 0) * 3;
+                    const float4 e1 = e[0], q = e[1], r = e[2];
                     const f3 hit = add3(mul3(L.d, sp), L.o);
                     const float kt1 = dot3(mk3(e1.x, e1.y, e1.z), hit) - e1.w;
-                    const float kt2 = dot3(mk3(e2.x, e2.y, e2.z), hit) - e2.w;
-                    const float kt3 = dot3(mk3(e3.x, e3.y, e3.z), hit) - e3.w;
+                    // e2 and e3 together (each half is dot3(e_i, hit) - d_i, operation for operation)
+                    const v2f xs = {q.x, q.y}, ys = {q.z, q.w}, zs = {r.x, r.y}, ds = {r.z, r.w};
+                    const v2f kt23 = ((xs * hit.x + ys * hit.y) + zs * hit.z) - ds;
+                    const float kt2 = kt23.x, kt3 = kt23.y;
                     const bool inside = cand && !(kt1 < 0.0f) && !(kt2 < 0.0f) && !(kt3 < 0.0f);
                     const bool shadow = L.mode == MODE_SHADOW;
                     const f3 from = shadow ? L.lp : L.o;
@@ -798,8 +813,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     const bool cand = tri && j != L.avoid && facing && !(k == 0.0f) && !(sp <= 0.0f) && !(sp <= P.nudge);
                     if (STATS && tri) { n_tris++; if (cand) n_plane++; }
                     if (cand) {
-                        const float4 *e = S.tri_edge + (size_t)j * 3;
-                        L.pe1 = e[0]; L.pe2 = e[1]; L.pe3 = e[2];
+                        load_edges(S.tri_edge + (size_t)j * 3, L.pe1, L.pe2, L.pe3);
                         L.pj = j; L.ph = add3(mul3(L.d, sp), L.o); L.pend = true;
                     }
                 }
@@ -867,8 +881,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                               "+v"(R.b.w), "+v"(L.cur));
             // 5. request the edge record of this step's candidate
             if (cand) {
-                const float4 *e = S.tri_edge + (size_t)j * 3;
-                L.pe1 = e[0]; L.pe2 = e[1]; L.pe3 = e[2];
+                load_edges(S.tri_edge + (size_t)j * 3, L.pe1, L.pe2, L.pe3);
                 L.pj = j; L.ph = ch; L.pend = true;
                 if (STATS) {
                     // counting builds judge at once so that a blocked shadow ray stops exactly where the
