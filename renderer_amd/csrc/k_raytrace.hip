@@ -131,6 +131,8 @@ MI_DEV bool ray_is_tame(const f3 o, const f3 d)
 // so this equals the verdict on the final Tnear / Tfar.  If the two intervals are separated and
 // Tfar's interval does not straddle 0 the verdict is known (`sure`); otherwise the caller runs the
 // exact test.  fma is fine here: these are bounds, not results.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 MI_DEV bool ray_box_fast(const f3 o, const f3 inv, const float4 lo, const float4 hi, bool &sure)
 {
     const float E = 1e-6f;
@@ -162,26 +164,21 @@ MI_DEV bool ray_box_fast(const f3 o, const f3 inv, const float4 lo, const float4
 //         triangle and of the ray), and directions are unit vectors, so its distance from the origin is at
 //         least near_g -- and if near_g > far_g or far_g < 0 the ray misses the grown box and no triangle
 //         below it can be hit at all.
-MI_DEV bool ray_box_fast_ordered(const f3 o, const f3 inv, const float dmax, const float4 lo, const float4 hi, bool &sure,
+MI_DEV bool ray_box_fast_ordered(const f3 o, const f3 inv, const float dmax, const float4 a, const float4 b, bool &sure,
                                  float &key, float &near_g, float &far_g)
 {
+    // (a, b) = one child's half of a wide record: (min.x, max.x, min.y, max.y) (min.z, max.z, ..): both planes of an
+    // axis go through the packed subtract and multiply side by side -- each half is (plane - o) * inv as before
     const float E = 1e-6f;
-    const float x1 = (lo.x - o.x) * inv.x, x2 = (hi.x - o.x) * inv.x;
-    const float y1 = (lo.y - o.y) * inv.y, y2 = (hi.y - o.y) * inv.y;
-    const float z1 = (lo.z - o.z) * inv.z, z2 = (hi.z - o.z) * inv.z;
-    const float xa = __builtin_fminf(x1, x2), xb = __builtin_fmaxf(x1, x2);
-    const float ya = __builtin_fminf(y1, y2), yb = __builtin_fmaxf(y1, y2);
-    const float za = __builtin_fminf(z1, z2), zb = __builtin_fmaxf(z1, z2);
-    const float xl = __builtin_fmaf(-E, __builtin_fabsf(xa), xa), yl = __builtin_fmaf(-E, __builtin_fabsf(ya), ya),
-                zl = __builtin_fmaf(-E, __builtin_fabsf(za), za);
-    const float xh = __builtin_fmaf(E, __builtin_fabsf(xb), xb), yh = __builtin_fmaf(E, __builtin_fabsf(yb), yb),
-                zh = __builtin_fmaf(E, __builtin_fabsf(zb), zb);
-    const float tn_lo = __builtin_fmaxf(__builtin_fmaxf(xl, yl), zl);
-    const float tn_hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(E, __builtin_fabsf(xa), xa), __builtin_fmaf(E, __builtin_fabsf(ya), ya)),
-                                        __builtin_fmaf(E, __builtin_fabsf(za), za));
-    const float tf_lo = __builtin_fminf(__builtin_fminf(__builtin_fmaf(-E, __builtin_fabsf(xb), xb), __builtin_fmaf(-E, __builtin_fabsf(yb), yb)),
-                                        __builtin_fmaf(-E, __builtin_fabsf(zb), zb));
-    const float tf_hi = __builtin_fminf(__builtin_fminf(xh, yh), zh);
+    const v2f x = (v2f{a.x, a.y} - o.x) * inv.x;
+    const v2f y = (v2f{a.z, a.w} - o.y) * inv.y;
+    const v2f z = (v2f{b.x, b.y} - o.z) * inv.z;
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x.x, x.y), __builtin_fminf(y.x, y.y)), __builtin_fminf(z.x, z.y));
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x.x, x.y), __builtin_fmaxf(y.x, y.y)), __builtin_fmaxf(z.x, z.y));
+    // interval ends of Tnear and Tfar: t -> fma(+-E, |t|, t) is non-decreasing (also after rounding), so widening the
+    // largest entry point equals the largest widened entry point (what ray_box_fast spells out axis by axis)
+    const float tn_lo = __builtin_fmaf(-E, __builtin_fabsf(tn), tn), tn_hi = __builtin_fmaf(E, __builtin_fabsf(tn), tn);
+    const float tf_lo = __builtin_fmaf(-E, __builtin_fabsf(tf), tf), tf_hi = __builtin_fmaf(E, __builtin_fabsf(tf), tf);
     const bool pass = (tn_hi <= tf_lo) && (tf_lo >= 0.f);
     const bool fail = (tn_lo > tf_hi) || (tf_hi < 0.f);
     sure = pass || fail;
@@ -373,8 +370,6 @@ MI_DEV bool tri_plane_test(const Lane &L, float nudge, uint32_t link, int j, con
     hit = add3(mul3(L.d, s), L.o);
     return true;
 }
-
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 // edge record -> (e_i, d_i) as float4s (dev_scene.h: e2 and e3 are stored interleaved)
 MI_DEV void load_edges(const float4 *e, float4 &e1, float4 &e2, float4 &e3)
@@ -680,8 +675,8 @@ k_raytrace(const DevScene S, const FrameParams P)
                     } else {
                         bool sL, sR;
                         float nL, nR, fL, fR;
-                        hL = ray_box_fast_ordered(L.o, L.inv, L.dmax, loL, hiL, sL, kL, nL, fL);
-                        hR = ray_box_fast_ordered(L.o, L.inv, L.dmax, loR, hiR, sR, kR, nR, fR);
+                        hL = ray_box_fast_ordered(L.o, L.inv, L.dmax, R.a, R.b, sL, kL, nL, fL);
+                        hR = ray_box_fast_ordered(L.o, L.inv, L.dmax, R2.a, R2.b, sR, kR, nR, fR);
                         if (__builtin_expect(!((sL || leafL) && (sR || leafR) && L.tame), 0)) {
                             if (STATS) n_slow++;
                             hL = leafL || ray_box_exact(L.o, L.d, loL, hiL);
