@@ -291,6 +291,32 @@ static bool load_ply(orc_scene &s, const char *path, std::string &err)
     return true;
 }
 
+/* Loader.cc:276-353 from the point where lib3ds has done its part: an .r3ds file is a dump of what the reference's
+ * .3ds branch pushes into _vertices/_triangles (made by the REAL lib3ds, oracle/ref3ds/dump3ds.c: "R3DS", n_tri,
+ * per triangle 3 x (pos, normal) f32, r, g, b, two_sided u32).  Vertices keep the default ambient 60 (Base3d.h:32),
+ * normals are given (no fix_normals), the triangle normal passed to the ctor is overwritten by post_load anyway. */
+static bool load_r3ds(orc_scene &s, const char *path, std::string &err)
+{
+    FILE *fp = fopen(path, "rb");
+    if (!fp) { err = std::string("Missing ") + path; return false; }
+    char magic[4]; uint32_t n = 0;
+    if (fread(magic, 1, 4, fp) != 4 || memcmp(magic, "R3DS", 4) || fread(&n, 4, 1, fp) != 1) { fclose(fp); err = "Malformed .r3ds"; return false; }
+    for (uint32_t i = 0; i < n; i++) {
+        float c[18]; uint32_t m[4];
+        if (fread(c, 4, 18, fp) != 18 || fread(m, 4, 4, fp) != 4) { fclose(fp); err = "Malformed .r3ds"; return false; }
+        for (int k = 0; k < 3; k++) {
+            Vert v; v.p = V3(c[6 * k], c[6 * k + 1], c[6 * k + 2]); v.n = V3(c[6 * k + 3], c[6 * k + 4], c[6 * k + 5]);
+            v.ao = 60;
+            s.verts.push_back(v);
+        }
+        Tri t = make_tri(s.verts, (int)(3 * i), (int)(3 * i + 1), (int)(3 * i + 2), m[0], m[1], m[2]);
+        t.twoSided = m[3] != 0;
+        s.tris.push_back(t);
+    }
+    fclose(fp);
+    return true;
+}
+
 /* Loader.cc:411-494: centre, rescale, per-triangle bbox, Kuchkuda precompute */
 static void post_load(orc_scene &s)
 {
@@ -1011,7 +1037,8 @@ orc_scene *orc_scene_load(const char *path, char *err, int errlen)
     const char *dt = strrchr(path, '.');
     if (dt && !strcmp(dt + 1, "tri")) ok = load_tri(*s, path, e);
     else if (dt && (!strcmp(dt + 1, "ply") || !strcmp(dt + 1, "PLY"))) ok = load_ply(*s, path, e);
-    else e = "Unknown extension (only .tri or .ply accepted)";
+    else if (dt && !strcmp(dt + 1, "r3ds")) ok = load_r3ds(*s, path, e);
+    else e = "Unknown extension (only .tri, .ply or an .r3ds dump accepted)";
     if (!ok) {
         if (err && errlen > 0) { strncpy(err, e.c_str(), errlen - 1); err[errlen - 1] = 0; }
         delete s;

@@ -11,7 +11,9 @@
  * SURVEY.md 8(c)/8(d) recorded from the real reference (strict single-thread
  * build); see tests/test_oracle_pins.py.  The reference itself cannot be
  * built in this image without writing stand-ins for SDL 1.2 headers, which
- * the build rules forbid, so there is no oracle/_ref.
+ * the build rules forbid, so there is no oracle/_ref build of the renderer (only of
+ * its vendored lib3ds: oracle/ref3ds, which pins the product's .3ds reader and made
+ * the .r3ds dump this oracle loads for .3ds models).
  */
 #ifndef ORACLE_H
 #define ORACLE_H

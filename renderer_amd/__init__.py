@@ -125,6 +125,7 @@ def host():
         H.mi355h_scene_load.restype = C.c_void_p
         H.mi355h_scene_load.argtypes = [C.c_char_p]
         H.mi355h_scene_free.argtypes = [C.c_void_p]
+        H.mi355h_dump_3ds.argtypes = [C.c_char_p, C.c_char_p]
         H.mi355h_scene_desc.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
         H.mi355h_set_device.argtypes = [C.c_void_p, C.c_int]
         H.mi355h_bvh_create.argtypes = [C.c_void_p]
@@ -218,6 +219,12 @@ def _np_view(ptr, n, dtype, owner=None):
     a = np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype).view(_OwnedArray)
     a._owner = owner
     return a
+
+
+def dump_3ds(path_3ds: str, path_out: str) -> None:
+    """Test hook: write what the .3ds reader hands to Scene::load (before the loader's common tail) as an .r3ds dump."""
+    if host().mi355h_dump_3ds(path_3ds.encode(), path_out.encode()) != 0:
+        raise Mi355Error(host().mi355h_last_error().decode())
 
 
 class Scene:

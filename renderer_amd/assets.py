@@ -22,7 +22,13 @@ SHA256 = {
     "chessboard.tri": "83fc4d47e47ab93526d671eed00a4f7e6115f423a450c98b6e420205a09c5386",
     "statue.ply": "ca4906aeaef5646f69612a41fbab21922cb7512162f571ef65e220dd27a3af9b",
     "dragon_vis.ply": "4d70bb53c2fe06df59d8d8c8087196446919ccc3324c9f286bfcdf0f181027fb",
+    "legocar.3ds": "407311b55df3d390a3f66348d06966cd48fb8f249170ca122a83b1f0a65033b9",
 }
+
+# Test fixtures (tests/golden/): what the REAL lib3ds hands the reference's loader for a .3ds asset, dumped by
+# oracle/ref3ds/dump3ds.c (scripts/make_3ds_golden.sh).  The oracle loads this instead of parsing .3ds itself.
+GOLDEN_DIR = os.path.join(_ROOT, "tests", "golden")
+R3DS_OF = {"legocar.3ds": ("legocar_3ds.r3ds", "4f6414dff890a6923d6182f3e6ccb846b8902ff5b0c6f0ca3ec30bf3e8de0de7")}
 
 
 def cache_dir() -> str:
@@ -30,6 +36,28 @@ def cache_dir() -> str:
         tempfile.gettempdir(), "renderer_amd_cache_%d" % os.getuid())
     os.makedirs(d, exist_ok=True)
     return d
+
+
+def _unpack(src_xz: str, dst: str, sha: str) -> str:
+    if not os.path.exists(dst):
+        with lzma.open(src_xz, "rb") as f:
+            data = f.read()
+        if hashlib.sha256(data).hexdigest() != sha:
+            raise RuntimeError("%s is corrupt" % src_xz)
+        tmp = dst + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(data)
+        os.replace(tmp, dst)
+    return dst
+
+
+def oracle_path(name: str) -> str:
+    """What the ORACLE loads for mesh ``name`` (tests only): the mesh itself, or for a .3ds asset the dump of what
+    the real lib3ds reads out of it."""
+    if name in R3DS_OF:
+        fn, sha = R3DS_OF[name]
+        return _unpack(os.path.join(GOLDEN_DIR, fn + ".xz"), os.path.join(cache_dir(), fn), sha)
+    return mesh_path(name)
 
 
 def mesh_path(name: str) -> str:

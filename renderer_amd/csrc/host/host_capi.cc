@@ -3,6 +3,7 @@
 // the mi355::Scene / Camera / Light API of renderer_host.h and converts its std::string
 // exceptions (the reference's THROW(), Exceptions.h:28-33) into an error return.
 #include "renderer_host.h"
+#include "load_3ds.h"
 
 #include <cstring>
 #include <memory>
@@ -35,6 +36,34 @@ void *mi355h_scene_load(const char *path)
     return h;
 }
 void mi355h_scene_free(void *h) { delete (Handle *)h; }
+
+// Test hook: what the .3ds reader hands to Scene::load, BEFORE the loader's common tail, in the dump format of
+// oracle/ref3ds/dump3ds.c ("R3DS", n_tri, per triangle 3 x (pos, normal) f32, r, g, b, two_sided u32)
+int mi355h_dump_3ds(const char *path_3ds, const char *path_out)
+{
+    return guarded([&] {
+        FILE *fp = fopen(path_3ds, "rb");
+        if (!fp) throw std::string("File '") + path_3ds + "' not found!";
+        std::vector<unsigned char> d;
+        unsigned char buf[1 << 16];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, fp)) > 0) d.insert(d.end(), buf, buf + n);
+        fclose(fp);
+        std::vector<Corner3ds> corners;
+        std::vector<Face3ds> faces;
+        load3ds(d, corners, faces);
+        FILE *out = fopen(path_out, "wb");
+        if (!out) throw std::string("cannot write ") + path_out;
+        const uint32_t nt = (uint32_t)faces.size();
+        fwrite("R3DS", 1, 4, out);
+        fwrite(&nt, 4, 1, out);
+        for (uint32_t i = 0; i < nt; i++) {
+            fwrite(&corners[3 * (size_t)i], sizeof(Corner3ds), 3, out);
+            fwrite(&faces[i], sizeof(Face3ds), 1, out);
+        }
+        fclose(out);
+    });
+}
 
 int mi355h_scene_desc(void *h, mi355_scene_desc *out) { *out = ((Handle *)h)->scene.desc(); return 0; }
 

@@ -5,6 +5,7 @@
 // (binary32, one rounding per op, no FMA: this file is compiled with -ffp-contract=off), and
 // mixed float/double expressions keep the reference's promotion, cited per line.
 #include "renderer_host.h"
+#include "load_3ds.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -299,8 +300,20 @@ void Scene::load(const char *filename)
             }
             p = nl ? nl + 1 : end;
         }
+    } else if (!strcmp(dt, "3ds") || !strcmp(dt, "3DS")) {
+        // Loader.cc:276-353: every face gets three vertices of its own (position + smoothing-group normal); the
+        // provided triangle normal is overwritten by the common tail, the material gives colour and two-sidedness
+        std::vector<Corner3ds> corners;
+        std::vector<Face3ds> faces;
+        try { load3ds(slurp(filename), corners, faces); } catch (const std::string &e) { raise(e); }
+        for (const Corner3ds &c : corners) addVertex(c.pos[0], c.pos[1], c.pos[2], c.normal[0], c.normal[1], c.normal[2], 60);
+        for (size_t i = 0; i < faces.size(); i++) {
+            addTriangle((unsigned)(3 * i), (unsigned)(3 * i + 1), (unsigned)(3 * i + 2), faces[i].r, faces[i].g, faces[i].b);
+            _triTwoSided.back() = faces[i].two_sided ? 1 : 0;
+        }
+        normalsGiven = true;
     } else
-        raise("Unknown extension (only .tri or .ply are on the accelerated path)");
+        raise("Unknown extension (only .tri .3ds or .ply accepted)");
 
     const size_t V = numVertices();
     for (int32_t ix : _triIndex)

@@ -30,7 +30,7 @@ def oracle_scene(oracle):
     def get(name, bvh=False):
         key = name
         if key not in _SCENES:
-            _SCENES[key] = oracle.Scene(assets.mesh_path(name))
+            _SCENES[key] = oracle.Scene(assets.oracle_path(name))
         s = _SCENES[key]
         if bvh and s.num_nodes == 0:
             s.bvh_ensure(os.path.join(assets.cache_dir(), name + ".oracle.bvh"))

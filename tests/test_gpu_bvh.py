@@ -50,6 +50,12 @@ def test_gpu_builder_emits_the_reference_cache_bytes(mesh):
     assert sha.startswith(pin["sha_prefix"]) and sha.endswith(pin["sha_suffix"])
 
 
+def test_gpu_builder_on_the_3ds_model():
+    """legocar.3ds (many small parts, exact-duplicate vertices per face): both builders, same tree."""
+    d, h = both_builders(R.assets.mesh_path("legocar.3ds"))
+    assert_same_tree(d, h)
+
+
 def write_ply(path, verts, faces):
     with open(path, "w") as f:
         f.write("ply\nformat ascii 1.0\nelement vertex %d\nelement face %d\nend_header\n" % (len(verts), len(faces)))

@@ -232,6 +232,22 @@ def test_raster_modes(oracle, oracle_scene, gpu_scene, mesh, mode):
         assert g[2].tris_drawn == o[2].tris_drawn and g[2].spans == o[2].spans and g[2].ztests == o[2].ztests
 
 
+@pytest.mark.parametrize("mode", [1, 2, 4, 5, 6, 7, 8, 9, 10])
+def test_model_loaded_from_3ds(oracle, oracle_scene, gpu_scene, mode):
+    """legocar.3ds through the host layer's own .3ds reader vs the oracle fed with the REAL lib3ds' dump of the same
+    file (tests/test_host_3ds.py): every face has its own three vertices, normals come from smoothing groups, and 120
+    faces are two-sided (no back-face culling for them: Raytracer.cc:247, Rasterizers.cc:259)."""
+    for frame in (0, 57):
+        g, o = both_frames(oracle, oracle_scene, gpu_scene, "legocar.3ds", mode, 640, 480, frame, want_f32=mode >= 9,
+                           second_light=mode in (6, 9))
+        assert_same(g, o)
+    if mode == 9:
+        g, o = both_frames(oracle, oracle_scene, gpu_scene, "legocar.3ds", mode, 320, 240, 3, collect_stats=1)
+        assert_same(g, o)
+        for k in ("normal_rays", "shadow_rays", "node_pops", "tri_tests", "plane_pass"):
+            assert getattr(g[2], k) == getattr(o[2], k), k
+
+
 @pytest.mark.parametrize("mode", [6, 8])
 def test_raster_two_lights_full_hd(oracle, oracle_scene, gpu_scene, mode):
     g, o = both_frames(oracle, oracle_scene, gpu_scene, "chessboard.tri", mode, 1920, 1080, 20, second_light=True)
