@@ -48,7 +48,11 @@ def main():
     ap.add_argument("--tune", default="{}", help="JSON dict of renderer_amd.tune() knobs")
     ap.add_argument("--frames-per-step", type=int, default=0,
                     help="frames of the orbit rendered by one launch per GPU (raytrace modes; mi355_render_batch_device, 1..64); "
-                         "default 8 per GPU: with N GPUs a step is 8*N frames, each GPU renders its bands of all of them")
+                         "default 8 per GPU: with N GPUs a step is 8*N frames")
+    ap.add_argument("--shard", choices=("auto", "frames", "bands"), default="auto",
+                    help="N > 1: 'frames' = every GPU renders whole frames of the step (every N-th one; throughput mode, the "
+                         "default for batched raytracing), 'bands' = every GPU renders its interleaved screen bands of every "
+                         "frame (SURVEY 8e; the latency mode, and the only one for single-frame steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (rasterizer) workloads")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -85,11 +89,15 @@ def main():
 
     def opts(**kw):
         o = R.default_opts(W, H, tune=json.loads(args.tune), **kw)
-        if world > 1:
+        if world > 1 and not by_frames:
             o.band_rows, o.band_index, o.band_count, o.compact_rows = multigpu.BAND_ROWS, rank, world, 1
         return o
 
-    gather = multigpu.FrameGatherer(W, H, dev, frames=B)
+    by_frames = world > 1 and args.mode >= 9 and B % world == 0 and args.shard in ("auto", "frames")
+    if args.shard == "frames" and world > 1 and not by_frames:
+        raise SystemExit("--shard frames needs a raytrace mode and frames-per-step divisible by the number of GPUs")
+    B_local = B // world if by_frames else B          # frames per launch on this GPU
+    gather = multigpu.BatchGatherer(W, H, dev, B_local) if by_frames else multigpu.FrameGatherer(W, H, dev, frames=B)
     my_rows = gather.my_rows
     stream = torch.cuda.current_stream(dev)
 
@@ -97,18 +105,23 @@ def main():
         scene.shadowmap_render(0, cams[0][1][0])
 
     def frames_of_step(k):
-        return [(k * B + j) % N_CAMS for j in range(B)]
+        """Orbit frames this GPU renders in step k (all B of them in band mode, every world-th one in frame mode)."""
+        fs = [(k * B + j) % N_CAMS for j in range(B)]
+        return multigpu.frames_of_rank(fs, world, rank) if by_frames else fs
 
     def enqueue(k, o, slot):
         """One step: the next B frames of the orbit in one launch, then one gather (N>1)."""
         buf = gather.send_buffer(slot)
+        fs = frames_of_step(k)
         if B == 1:
-            cam, lights, n = cams[k % N_CAMS]
+            cam, lights, n = cams[fs[0]]
             scene.render_device(args.mode, cam, lights, n, o, buf.data_ptr(), W * 4, 0, stream.cuda_stream)
+        elif B_local == 1:
+            cam, lights, n = cams[fs[0]]
+            scene.render_device(args.mode, cam, lights, n, o, buf[0].data_ptr(), W * 4, 0, stream.cuda_stream)
         else:
-            fs = frames_of_step(k)
             scene.render_batch_device(args.mode, [cams[f][0] for f in fs], [cams[f][1] for f in fs], cams[fs[0]][2], o,
-                                      [buf[j].data_ptr() for j in range(B)], W * 4, None, stream.cuda_stream)
+                                      [buf[j].data_ptr() for j in range(B_local)], W * 4, None, stream.cuda_stream)
         gather.gather(slot)
 
     # ---- untimed pre-pass: per-frame ray counts and algorithmic bytes from the counting kernel variant (which walks
@@ -190,7 +203,9 @@ def main():
                     "BVH built on the GPU by the library" % args.mesh,
             "config": {"workload": "%s, BVH raytrace mode %d (primary + shadow rays + 2 reflection bounces), %dx%d, 1 light"
                                    % (args.mesh, args.mode, W, H),
-                       "parallelism": "screen bands x%d, 1 RCCL gather/step" % world if world > 1 else "single GPU",
+                       "parallelism": ("single GPU" if world == 1 else
+                                       "whole frames x%d (GPU r renders every %d-th frame of a step), 1 RCCL gather/step" % (world, world)
+                                       if by_frames else "screen bands x%d, 1 RCCL gather/step" % world),
                        "frames_per_step": B, "frames": K * B,
                        "rays_per_frame": round(total_rays / (K * B), 1), "tune": json.loads(args.tune)},
             "frames_per_sec": round(K * B / dt, 3),
@@ -204,8 +219,8 @@ def main():
                 "kernel": "k_raytrace<STATS=false, EXACT_BOX=false, ORDERED=true, WAVES=2|3|4 by launch size, BATCH=frames>1> (ordered walk)",
                 "kernel_ms": round(kernel_ms, 5),
                 "algorithmic_bytes_per_launch": round(total_abytes / K / max(world, 1), 1),
-                "frames_per_launch": B,
-                "note": "one launch = one step = %d consecutive frames of the orbit (mi355_render_batch_device). " % B +
+                "frames_per_launch": B_local,
+                "note": "one launch = one GPU's share of a step = %d frames of the orbit (mi355_render_batch_device). " % B_local +
                         "achieved = SURVEY 8(d) algorithmic bytes per launch (the REFERENCE algorithm's node pops / "
                         "triangle tests / hits, counted by the reference-order kernel variant on the same frames) / "
                         "HIP-event time per launch on the launch stream (rank 0). The timed kernel walks the tree near "

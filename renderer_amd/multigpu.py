@@ -106,3 +106,61 @@ class FrameGatherer:
             if self.pending[s] is not None:
                 self.pending[s].wait()
                 self.pending[s] = None
+
+
+def frames_of_rank(frames, world: int, rank: int):
+    """Whole-frame sharding of a batch: rank r takes every world-th frame (a uniform sample of the orbit segment, so
+    the ranks' loads stay alike)."""
+    return list(frames)[rank::world]
+
+
+class BatchGatherer:
+    """Throughput mode: a step is a batch of frames, every rank renders WHOLE frames of it (frames_of_rank) with one
+    batched launch, and one gather per step moves them to rank 0 in orbit order.  Frames are independent, so the
+    per-GPU work is exactly that of a single-GPU step; bands (FrameGatherer) are for the latency of one frame."""
+
+    def __init__(self, width: int, height: int, device, frames_per_rank: int, group=None, collective_when_alone: bool = False):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.alone = self.world == 1 and not collective_when_alone
+        self.W, self.H, self.n_local = width, height, frames_per_rank
+        self.my_rows = self.max_rows = height
+        shape = (frames_per_rank, height, width)
+        self.send = [torch.zeros(shape, dtype=torch.int32, device=device) for _ in range(2)]
+        self.recv = [torch.zeros((self.world,) + shape, dtype=torch.int32, device=device)
+                     if self.rank == 0 and not self.alone else None for _ in range(2)]
+        self.pending = [None, None]
+
+    def send_buffer(self, slot: int):
+        if self.pending[slot] is not None:
+            self.pending[slot].wait()
+            self.pending[slot] = None
+        return self.send[slot]
+
+    def gather(self, slot: int, async_op: bool = True):
+        if self.alone:
+            return None
+        lst = list(self.recv[slot].unbind(0)) if self.rank == 0 else None
+        w = self.dist.gather(self.send[slot], gather_list=lst, dst=0, group=self.group, async_op=async_op)
+        self.pending[slot] = w if async_op else None
+        return w
+
+    def frame(self, slot: int):
+        """Rank 0: the step's frames [n_local * world, H, W] in orbit order (frame j*world + r came from rank r)."""
+        if self.pending[slot] is not None:
+            self.pending[slot].wait()
+            self.pending[slot] = None
+        if self.rank != 0:
+            return None
+        if self.alone:
+            return self.send[slot]
+        return self.recv[slot].permute(1, 0, 2, 3).reshape(self.n_local * self.world, self.H, self.W)
+
+    def drain(self):
+        for s in (0, 1):
+            if self.pending[s] is not None:
+                self.pending[s].wait()
+                self.pending[s] = None

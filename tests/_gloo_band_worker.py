@@ -24,6 +24,29 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     s = O.Scene(assets.mesh_path("dragon_vis.ply"))
     s.bvh_ensure(os.path.join(assets.cache_dir(), "dragon_vis.ply.oracle.bvh"))
+    if len(sys.argv) > 6 and sys.argv[6] == "frames":          # whole-frame sharding of a batch (BatchGatherer)
+        per_rank = batch // world
+        g = multigpu.BatchGatherer(W, H, torch.device("cpu"), per_rank)
+        ok = True
+        for step in range(frames):
+            fs = [step * batch + j for j in range(batch)]
+            buf = g.send_buffer(step & 1)
+            for j, f in enumerate(multigpu.frames_of_rank(fs, world, rank)):
+                cam, lights, n = O.benchmark_frame(f)
+                buf[j] = torch.from_numpy(s.render(9, cam, lights, n, O.default_opts(W, H))[0].astype(np.int32))
+            g.gather(step & 1)
+            if rank == 0:
+                got = g.frame(step & 1).numpy().astype(np.uint32)
+                ok = ok and got.shape == (batch, H, W)
+                for j, f in enumerate(fs):
+                    cam, lights, n = O.benchmark_frame(f)
+                    ok = ok and bool(np.array_equal(got[j], s.render(9, cam, lights, n, O.default_opts(W, H))[0]))
+        g.drain()
+        dist.barrier()
+        if rank == 0:
+            open(out_path, "w").write("OK" if ok else "MISMATCH")
+        dist.destroy_process_group()
+        return
     g = multigpu.FrameGatherer(W, H, torch.device("cpu"), frames=batch)
     assert g.my_rows == multigpu.rows_of_rank(H, multigpu.BAND_ROWS, world, rank)
     ok = True

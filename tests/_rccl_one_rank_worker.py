@@ -36,6 +36,24 @@ for step in range(4):                                  # double-buffered: step k
             torch.cuda.synchronize(dev)
             assert torch.equal(fr[j], want), "frame %d differs after the gather" % f
 g.drain()
+# throughput mode: whole frames of a batch through the same collective
+bg = multigpu.BatchGatherer(W, H, dev, B, collective_when_alone=True)
+for step in range(3):
+    slot = step & 1
+    fs = multigpu.frames_of_rank([(step * B + j) % 200 for j in range(B)], 1, 0)
+    cl = [R.benchmark_frame(f) for f in fs]
+    buf = bg.send_buffer(slot)
+    s.render_batch_device(9, [c[0] for c in cl], [c[1] for c in cl], 1, R.default_opts(W, H), [buf[j].data_ptr() for j in range(B)], W * 4, None, stream.cuda_stream)
+    bg.gather(slot)
+    fr = bg.frame(slot).clone()
+    assert fr.shape == (B, H, W)
+    for j, f in enumerate(fs):
+        want = torch.zeros((H, W), dtype=torch.int32, device=dev)
+        cam, lights, n = R.benchmark_frame(f)
+        s.render_device(9, cam, lights, n, R.default_opts(W, H), want.data_ptr(), W * 4, 0, stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        assert torch.equal(fr[j], want), "frame %d differs after the whole-frame gather" % f
+bg.drain()
 t = torch.ones(4, device=dev); dist.all_reduce(t); assert float(t.sum()) == 4.0
 dist.destroy_process_group()
 print("RCCL_ONE_RANK_OK")

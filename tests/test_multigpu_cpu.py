@@ -53,3 +53,17 @@ def test_gloo_band_gather_of_batched_frames(tmp_path):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert out.read_text() == "OK"
+
+
+def test_gloo_whole_frame_sharding_of_a_batch(tmp_path):
+    """Throughput mode: every rank renders whole frames of the batch (every world-th one), one gather per step puts them
+    back in orbit order on rank 0."""
+    out = tmp_path / "result.txt"
+    port = 29500 + (os.getpid() % 2000) + 11
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(os.path.dirname(__file__), "_gloo_band_worker.py"), str(out), "160", "90", "2", "4", "frames"]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert out.read_text() == "OK"
