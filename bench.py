@@ -9,7 +9,7 @@ HBM, frames left in HBM.  value = Mrays/s over all GPUs (a ray = one BVH_Interse
 frames/s is reported beside it, and the chessboard Phong rasterizer (configs[1]) is timed as a second workload at N=1.
 --frames-per-step 1 renders frame by frame (one launch per frame).
 
-N>1: one process per GPU; every rank renders its interleaved 15-row screen bands of the SAME frames
+N>1: one process per GPU; every rank renders its interleaved 8-row screen bands (rows of 8x8 tiles) of the SAME frames
 and a single RCCL gather per step assembles them on rank 0.  By default a step carries 8 frames per GPU
 (8*N frames: the work per GPU is fixed, "scaling": "weak"); --frames-per-step F fixes the step at F frames
 whatever N is ("strong").
@@ -50,9 +50,9 @@ def main():
                     help="frames of the orbit rendered by one launch per GPU (raytrace modes; mi355_render_batch_device, 1..64); "
                          "default 8 per GPU: with N GPUs a step is 8*N frames")
     ap.add_argument("--shard", choices=("auto", "frames", "bands"), default="auto",
-                    help="N > 1: 'frames' = every GPU renders whole frames of the step (every N-th one; throughput mode, the "
-                         "default for batched raytracing), 'bands' = every GPU renders its interleaved screen bands of every "
-                         "frame (SURVEY 8e; the latency mode, and the only one for single-frame steps)")
+                    help="N > 1: 'bands' (= auto) every GPU renders its interleaved screen bands (rows of 8x8 tiles) of every frame "
+                         "of the step, one gather assembles the framebuffers (north_star, SURVEY 8e); 'frames' = every GPU renders "
+                         "whole frames of the step (every N-th one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (rasterizer) workloads")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -93,7 +93,7 @@ def main():
             o.band_rows, o.band_index, o.band_count, o.compact_rows = multigpu.BAND_ROWS, rank, world, 1
         return o
 
-    by_frames = world > 1 and args.mode >= 9 and B % world == 0 and args.shard in ("auto", "frames")
+    by_frames = world > 1 and args.mode >= 9 and B % world == 0 and args.shard == "frames"
     if args.shard == "frames" and world > 1 and not by_frames:
         raise SystemExit("--shard frames needs a raytrace mode and frames-per-step divisible by the number of GPUs")
     B_local = B // world if by_frames else B          # frames per launch on this GPU

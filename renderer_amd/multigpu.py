@@ -2,7 +2,7 @@
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" in CPU tests).
 The scene is replicated; rank r renders the bands b with b % world == r (bands of `band_rows`
-scanlines, interleaved so the model's silhouette is spread over all GPUs) into a compact
+scanlines = rows of 8x8 pixel tiles, interleaved so the model's silhouette is spread over all GPUs) into a compact
 [rows_r, W] XRGB buffer; a single gather moves the buffers to rank 0, which de-interleaves them
 into the frame.  There is no exchange inside a frame.  Nothing here renders: the render callback
 is the C ABI's mi355_render_device (or, in CPU tests, the oracle).
@@ -11,7 +11,8 @@ from __future__ import annotations
 
 import numpy as np
 
-BAND_ROWS = 15      # divides 1080 and 2160 into 72 / 144 bands: even for 1, 2, 4, 8 GPUs
+BAND_ROWS = 8       # a band = one row of the kernels' 8x8 pixel tiles: no tile straddles two GPUs (15-row bands, which split
+                    # 1080 evenly, cost 12-22 % per rank in half-empty tiles; 135 bands over 2/4/8 GPUs differ by one band at most)
 
 
 def rows_of_rank(height: int, band_rows: int, world: int, rank: int) -> int:

@@ -267,8 +267,9 @@ def test_shadow_map_bit_exact(oracle, oracle_scene, gpu_scene, mesh):
         assert int((gm > -1e30).sum()) > 1000
 
 
+@pytest.mark.parametrize("band_rows", [8, 15])       # multigpu.BAND_ROWS (tile rows) and a height that straddles tiles
 @pytest.mark.parametrize("mode", [9, 6, 2])
-def test_band_sharding_reassembles_the_frame(oracle, oracle_scene, gpu_scene, mode):
+def test_band_sharding_reassembles_the_frame(oracle, oracle_scene, gpu_scene, mode, band_rows):
     """Screen bands rendered as 4 'GPUs' and interleaved back == the unsharded frame (multi-GPU layout)."""
     from renderer_amd import multigpu
     mesh, W, H = "dragon_vis.ply", 640, 360
@@ -277,16 +278,16 @@ def test_band_sharding_reassembles_the_frame(oracle, oracle_scene, gpu_scene, mo
     full, _, _ = hs.render(mode, cam, lights, n, R.default_opts(W, H))
     parts = []
     for r in range(4):
-        o = R.default_opts(W, H, band_rows=15, band_index=r, band_count=4, compact_rows=1)
+        o = R.default_opts(W, H, band_rows=band_rows, band_index=r, band_count=4, compact_rows=1)
         img, _, _ = hs.render(mode, cam, lights, n, o)
-        assert img.shape[0] == multigpu.rows_of_rank(H, 15, 4, r)
+        assert img.shape[0] == multigpu.rows_of_rank(H, band_rows, 4, r)
         parts.append(img)
-    assert np.array_equal(multigpu.assemble_numpy(parts, H, 15), full)
+    assert np.array_equal(multigpu.assemble_numpy(parts, H, band_rows), full)
     # non-compact: rows of other bands stay black
-    o = R.default_opts(W, H, band_rows=15, band_index=1, band_count=4, compact_rows=0)
+    o = R.default_opts(W, H, band_rows=band_rows, band_index=1, band_count=4, compact_rows=0)
     img, _, _ = hs.render(mode, cam, lights, n, o)
     ys = np.arange(H)
-    mine = (ys // 15) % 4 == 1
+    mine = (ys // band_rows) % 4 == 1
     assert np.array_equal(img[mine], full[mine]) and not img[~mine].any()
 
 
