@@ -279,12 +279,17 @@ def main():
             bs.context()
             bs.build_bvh_device()
             best = None
-            for _ in range(5):
+            for _ in range(6):
+                t1 = time.perf_counter()
                 bs.build_bvh_device()
+                wall = (time.perf_counter() - t1) * 1e3          # the whole mi355_build_bvh call, tree installed
                 tm = (C.c_double * 4)()
                 R.lib().mi355i_bvh_last_times(tm)
-                best = min(best, tm[1] + tm[2]) if best is not None else tm[1] + tm[2]
-            extra["bvh_build_gpu_ms"] = round(best, 3)
+                if best is None or wall < best[0]:
+                    best = (wall, tm[1], tm[2], tm[3])
+            extra["bvh_build_gpu_ms"] = round(best[0], 3)
+            extra["bvh_build_gpu_parts_ms"] = {"level_kernels": round(best[1], 3), "download_flatten": round(best[2], 3),
+                                               "install_in_context": round(best[3], 3)}
             t1 = time.perf_counter()
             bs.bvh_create("host")
             extra["bvh_build_host_cpu_ms"] = round((time.perf_counter() - t1) * 1e3, 1)

@@ -78,6 +78,23 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
 
+// page-locked host staging, kept per context: copies from / to it are DMA transfers on the context's stream (a plain
+// hipMemcpy of pageable memory goes through the runtime's own staging and pinning, measured at up to 25 ms per call)
+struct PinBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t n)
+    {
+        if (n <= bytes) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; bytes = 0;
+        hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+};
+
 struct V3h { float x, y, z; };
 inline V3h subh(V3h a, V3h b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 inline V3h crossh(V3h l, V3h r) { return {l.y * r.z - r.y * l.z, r.x * l.z - l.x * r.z, l.x * r.y - l.y * r.x}; }
@@ -109,6 +126,7 @@ struct mi355_ctx {
     DevBuf tile_order;      // raytrace dispenser order (ensure_tile_order)
     DevBuf cam_table;       // batched launches: FrameCam[MI355_MAX_BATCH]
     DevBuf bvh_prim, bvh_list[2], bvh_lvl[2], bvh_tree, bvh_cnt;   // mi355_build_bvh work buffers (kept for rebuilds)
+    PinBuf pin_walk, pin_edge, pin_shade, pin_tree, pin_list, pin_ctl;   // host staging of the BVH streams and the builder
     DevBuf wave_prof;       // per-wave phase profile of counting launches (debug)
     int last_blocks = 0;
     long long tile_key[6] = {0, 0, 0, 0, 0, 0};
@@ -293,7 +311,9 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
     const size_t wide_base = n4;                      // wide records of the ordered walk: 4 float4 per inner node
     const size_t n4_all = n4 + 4 * n_inner;
     if (n4_all + 8 >= (size_t)MI_VROOT_LINK) return fail(-30, "BVH too large");
-    std::vector<float4> walk(n4_all + 4, make_float4(0.f, 0.f, 0.f, 0.f));
+    HIP_TRY(c->pin_walk.ensure((n4_all + 4) * sizeof(float4)), -31);
+    float4 *walk = (float4 *)c->pin_walk.p;
+    memset(walk, 0, (n4_all + 4) * sizeof(float4));
     std::vector<uint32_t> order; order.reserve(nN);   // the reference's visiting order
     bool list_in_visit_order = true;
     uint32_t list_end = 0;
@@ -395,7 +415,11 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
 
     const uint32_t T = c->nT;
     // (+ zeroed edge records behind the dummy blocks of empty leaves: a NaN ray can pass their plane test)
-    std::vector<float4> edge(((size_t)T + n_dummy) * 3, make_float4(0.f, 0.f, 0.f, 0.f)), shade((size_t)T * 5);
+    const size_t n_edge = ((size_t)T + n_dummy) * 3, n_shade = (size_t)T * 5;
+    HIP_TRY(c->pin_edge.ensure(n_edge * sizeof(float4) + 16), -31);
+    HIP_TRY(c->pin_shade.ensure(n_shade * sizeof(float4) + 16), -31);
+    float4 *edge = (float4 *)c->pin_edge.p, *shade = (float4 *)c->pin_shade.p;
+    memset(edge + (size_t)T * 3, 0, n_dummy * 3 * sizeof(float4));
     for (uint32_t j = 0; j < T; j++) {
         const uint32_t t = (uint32_t)triIdx[j];
         const float *d = &c->td[4 * t], *e = &c->te[9 * t];
@@ -417,10 +441,14 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
         }
         shade[(size_t)j * 5 + 4] = make_float4(c->tcolorf[3 * t], c->tcolorf[3 * t + 1], c->tcolorf[3 * t + 2], 0.f);
     }
-    HIP_TRY(c->walk.upload(walk), -31);
+    HIP_TRY(c->walk.ensure((n4_all + 4) * sizeof(float4) + 16), -31);
+    HIP_TRY(c->tri_edge.ensure(n_edge * sizeof(float4) + 16), -31);
+    HIP_TRY(c->tri_shade.ensure(n_shade * sizeof(float4) + 16), -31);
+    HIP_TRY(hipMemcpyAsync(c->walk.p, walk, (n4_all + 4) * sizeof(float4), hipMemcpyHostToDevice, c->stream), -31);
+    HIP_TRY(hipMemcpyAsync(c->tri_edge.p, edge, n_edge * sizeof(float4), hipMemcpyHostToDevice, c->stream), -31);
+    HIP_TRY(hipMemcpyAsync(c->tri_shade.p, shade, n_shade * sizeof(float4), hipMemcpyHostToDevice, c->stream), -31);
+    HIP_TRY(hipStreamSynchronize(c->stream), -40);
     c->dev.walk = (const float4 *)c->walk.p;
-    HIP_TRY(c->tri_edge.upload(edge), -31);
-    HIP_TRY(c->tri_shade.upload(shade), -31);
     c->dev.tri_edge = (const float4 *)c->tri_edge.p;
     c->dev.tri_shade = (const float4 *)c->tri_shade.p;
     c->dev.root_link = link(0);
@@ -599,6 +627,7 @@ void mi355_scene_destroy(mi355_ctx *c)
                       &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->tile_order, &c->cam_table, &c->wave_prof, &c->bvh_prim, &c->bvh_list[0], &c->bvh_list[1],
                       &c->bvh_lvl[0], &c->bvh_lvl[1], &c->bvh_tree, &c->bvh_cnt})
         b->release();
+    for (PinBuf *b : {&c->pin_walk, &c->pin_edge, &c->pin_shade, &c->pin_tree, &c->pin_list, &c->pin_ctl}) b->release();
     for (auto &m : c->smap) m.release();
     if (c->rscratch) mi355i_raster_scratch_destroy(c->rscratch);
     for (int f = 0; f < MI355_MAX_BATCH; f++) {
@@ -637,7 +666,11 @@ int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_
     if (int r = select_device(c)) return r;
     const uint32_t T = c->nT;
     if (T == 0) return fail(-50, "mi355_build_bvh: scene has no triangles");
+    static const bool trace = getenv("MI355_BVH_TRACE") != nullptr;
+    double t_mark = t_start;
+    auto mark = [&](const char *what) { if (trace) { const double t = clk(); fprintf(stderr, "[bvh] %-28s %.3f ms\n", what, t - t_mark); t_mark = t; } };
     HIP_TRY(hipStreamSynchronize(c->stream), -40);
+    mark("stream sync");
     struct LevelNode { uint32_t first, count, tree, pad; float bb[6]; float pad2[2]; };
     struct TreeNode { float bb[6]; uint32_t a, b; };
     static_assert(sizeof(LevelNode) == 48 && sizeof(TreeNode) == 32, "layouts shared with k_bvh.hip");
@@ -648,8 +681,16 @@ int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_
     HIP_TRY(tree.ensure(((size_t)2 * T + 4) * sizeof(TreeNode)), -31);
     HIP_TRY(cnt.ensure(16), -31);
     uint32_t *d_cnt = (uint32_t *)cnt.p;      // [0] nodes of the next level, [1] tree nodes, [2] error bits
-    const uint32_t init[4] = {0u, 1u, 0u, 0u};
-    HIP_TRY(hipMemcpy(d_cnt, init, sizeof init, hipMemcpyHostToDevice), -31);
+    // every small transfer of the build goes through one page-locked block on the context's stream
+    struct Ctl { uint32_t init[4]; LevelNode root; uint32_t flags, n_tree, pad[2]; uint32_t reset[4]; uint32_t h[4]; };
+    HIP_TRY(c->pin_ctl.ensure(sizeof(Ctl)), -31);
+    HIP_TRY(c->pin_tree.ensure(((size_t)2 * T + 4) * sizeof(TreeNode)), -31);
+    HIP_TRY(c->pin_list.ensure((size_t)T * 4), -31);
+    Ctl *ctl = (Ctl *)c->pin_ctl.p;
+    ctl->init[0] = 0u; ctl->init[1] = 1u; ctl->init[2] = 0u; ctl->init[3] = 0u;
+    mark("buffers");
+    HIP_TRY(hipMemcpyAsync(d_cnt, ctl->init, sizeof ctl->init, hipMemcpyHostToDevice, c->stream), -31);
+    mark("counter upload");
     hipError_t e = mi355i_bvh_launch_prims((const float4 *)c->rs_vert.p, (const uint4 *)c->rs_idx.p, T, (float4 *)prim.p,
                                            (uint32_t *)list[0].p, d_cnt + 2, c->stream);
     if (e != hipSuccess) return fail(-43, "BVH work-item launch failed: %s", hipGetErrorString(e));
@@ -666,12 +707,13 @@ int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_
         }
         for (int a = 0; a < 3; a++) { root.bb[a] = gb[a]; root.bb[3 + a] = gt[a]; }
     }
-    HIP_TRY(hipMemcpy(lvl[0].p, &root, sizeof root, hipMemcpyHostToDevice), -31);
-    {
-        uint32_t flags = 0;
-        HIP_TRY(hipMemcpy(&flags, d_cnt + 2, 4, hipMemcpyDeviceToHost), -31);     // (also waits for k_bvh_prims)
-        if (flags & 1u) return fail(-50, "mi355_build_bvh: non-finite vertex coordinates (use the host builder)");
-    }
+    mark("prims launch + global box");
+    ctl->root = root;
+    HIP_TRY(hipMemcpyAsync(lvl[0].p, &ctl->root, sizeof root, hipMemcpyHostToDevice, c->stream), -31);
+    HIP_TRY(hipMemcpyAsync(&ctl->flags, d_cnt + 2, 4, hipMemcpyDeviceToHost, c->stream), -31);
+    HIP_TRY(hipStreamSynchronize(c->stream), -40);
+    mark("root upload");
+    if (ctl->flags & 1u) return fail(-50, "mi355_build_bvh: non-finite vertex coordinates (use the host builder)");
     const double t_setup = clk();
     uint32_t tree_before = 1;          // tree nodes allocated so far (the root)
     uint32_t n_cur = 1;
@@ -683,13 +725,14 @@ int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_
         uint32_t h[3];
         for (int many = 0; many < 2; many++) {
             // a node with more candidate planes than the fast build holds: redo the level with the large one
-            const uint32_t reset[3] = {0u, tree_before, 0u};
-            HIP_TRY(hipMemcpyAsync(d_cnt, reset, sizeof reset, hipMemcpyHostToDevice, c->stream), -31);
+            ctl->reset[0] = 0u; ctl->reset[1] = tree_before; ctl->reset[2] = 0u;
+            HIP_TRY(hipMemcpyAsync(d_cnt, ctl->reset, 12, hipMemcpyHostToDevice, c->stream), -31);
             e = mi355i_bvh_launch_level(lvl[cur].p, n_cur, lvl[1 - cur].p, d_cnt, tree.p, d_cnt + 1, (const float4 *)prim.p,
                                         (const uint32_t *)list[cur].p, (uint32_t *)list[1 - cur].p, depth, many, d_cnt + 2, c->stream);
             if (e != hipSuccess) return fail(-43, "BVH level launch failed: %s", hipGetErrorString(e));
-            HIP_TRY(hipMemcpyAsync(h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream), -31);
+            HIP_TRY(hipMemcpyAsync(ctl->h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream), -31);
             HIP_TRY(hipStreamSynchronize(c->stream), -40);
+            h[0] = ctl->h[0]; h[1] = ctl->h[1]; h[2] = ctl->h[2];
             if (!(h[2] & 2u)) break;
         }
         if (h[2] & 6u) return fail(-50, "mi355_build_bvh: more than 2200 candidate planes on an axis (use the host builder)");
@@ -700,11 +743,13 @@ int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_
         depth++;
     }
     const double t_levels = clk();
-    uint32_t n_tree = 0;
-    HIP_TRY(hipMemcpy(&n_tree, d_cnt + 1, 4, hipMemcpyDeviceToHost), -31);
-    std::vector<TreeNode> tn(n_tree);
-    HIP_TRY(hipMemcpy(tn.data(), tree.p, (size_t)n_tree * sizeof(TreeNode), hipMemcpyDeviceToHost), -31);
-    HIP_TRY(hipMemcpy(tri_idx, list[cur].p, (size_t)T * 4, hipMemcpyDeviceToHost), -31);
+    const uint32_t n_tree = tree_before;          // tree nodes allocated when the last level finished
+    if ((size_t)n_tree > (size_t)2 * T + 4) return fail(-51, "BVH build produced %u tree nodes for %u triangles", n_tree, T);
+    const TreeNode *tn = (const TreeNode *)c->pin_tree.p;
+    HIP_TRY(hipMemcpyAsync(c->pin_tree.p, tree.p, (size_t)n_tree * sizeof(TreeNode), hipMemcpyDeviceToHost, c->stream), -31);
+    HIP_TRY(hipMemcpyAsync(c->pin_list.p, list[cur].p, (size_t)T * 4, hipMemcpyDeviceToHost, c->stream), -31);
+    HIP_TRY(hipStreamSynchronize(c->stream), -40);
+    memcpy(tri_idx, c->pin_list.p, (size_t)T * 4);
     // flatten (Raytracer.cc:651-682): pre-order, idxLeft = own index + 1, leaves keep their list segment
     struct RefNode { float bottom[3], top[3]; uint32_t a, b; };
     RefNode *out = (RefNode *)nodes32B;
