@@ -9,4 +9,6 @@ cd /tmp && export TMPDIR=/tmp
 (timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extra 2>&1 | tail -2) > $R/gpurun_out/prof_write.log
 (timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD --output-format csv -d $R/gpurun_out/prof_sq -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extra 2>&1 | tail -2) > $R/gpurun_out/prof_sq.log
 (timeout 600 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum --output-format csv -d $R/gpurun_out/prof_cache -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extra 2>&1 | tail -2) > $R/gpurun_out/prof_cache.log
-cd $R; find gpurun_out/prof_* -name "*.csv" | head -30
+(timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES --output-format csv -d $R/gpurun_out/prof_valu1 -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extra 2>&1 | tail -2) > $R/gpurun_out/prof_valu1.log
+(timeout 600 rocprofv3 --kernel-trace --pmc VALUBusy VALUUtilization SALUBusy --output-format csv -d $R/gpurun_out/prof_valu2 -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extra 2>&1 | tail -2) > $R/gpurun_out/prof_valu2.log
+cd $R; find gpurun_out/prof_* -name "*.csv" | head -40

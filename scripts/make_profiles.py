@@ -7,7 +7,7 @@ import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
-KERNEL = "k_raytrace<false, false, true, 4, true>"   # the bench kernel: ordered walk, batched launch, three waves per SIMD
+KERNEL = "k_raytrace<false, false, true, 4, true>"   # the bench kernel: ordered walk, batched launch, four waves per SIMD
 
 
 def newest(pattern):
@@ -32,7 +32,7 @@ def main():
     if ks:
         shutil.copy(ks, os.path.join(out, "%s_kernel_stats.csv" % TAG))
     pmc, launches = {}, {}
-    for kind in ("prof_fetch", "prof_write", "prof_sq", "prof_cache"):
+    for kind in ("prof_fetch", "prof_write", "prof_sq", "prof_cache", "prof_valu1", "prof_valu2"):
         v, n = per_launch(kind)
         pmc.update(v); launches.update(n)
     fetch_kb, write_kb = pmc.get("FETCH_SIZE"), pmc.get("WRITE_SIZE")
