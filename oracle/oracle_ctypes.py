@@ -104,6 +104,21 @@ def benchmark_frame(k: int, second_light: bool = False):
     return cam, lights, n.value
 
 
+def camera(eye, lookat) -> Camera:
+    """Camera at `eye` looking at `lookat` (Camera.cc:24-42)."""
+    cam = Camera()
+    lib().orc_camera_set(C.byref(cam), (C.c_float * 3)(*eye), (C.c_float * 3)(*lookat))
+    return cam
+
+
+def light(pos, cam: Camera) -> Light:
+    """Light at `pos` with its camera-space members derived for `cam` (Light.cc:162-216)."""
+    l = Light()
+    l.pos[:] = list(pos)
+    lib().orc_light_update(C.byref(l), C.byref(cam))
+    return l
+
+
 class Scene:
     def __init__(self, path: str):
         err = C.create_string_buffer(256)

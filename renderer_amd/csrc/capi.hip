@@ -35,6 +35,7 @@ extern "C" hipError_t mi355i_launch_shadowmap(const DevScene *, const float *lig
 extern "C" RasterScratch *mi355i_raster_scratch_create(void);
 extern "C" void mi355i_raster_scratch_destroy(RasterScratch *);
 extern "C" uint32_t mi355i_raster_overflow(RasterScratch *);
+extern "C" int mi355i_raster_grow(RasterScratch *);
 
 namespace {
 
@@ -798,12 +799,16 @@ int mi355_shadowmap_render(mi355_ctx *c, int slot, const mi355_light *light, int
     if (slot < 0 || slot >= MI355_MAX_LIGHTS || size <= 0 || size > 16384) return fail(-3, "bad light slot %d / size %d", slot, size);
     if (int r = select_device(c)) return r;
     HIP_TRY(c->smap[slot].ensure((size_t)size * size * 4), -31);
-    hipError_t e = mi355i_launch_shadowmap(&c->dev, light->pos, light->world_to_light, size, (float *)c->smap[slot].p,
-                                           c->rscratch, c->stream);
-    if (e != hipSuccess) return fail(-43, "shadow map launch failed: %s", hipGetErrorString(e));
-    HIP_TRY(hipStreamSynchronize(c->stream), -40);
-    if (uint32_t dropped = mi355i_raster_overflow(c->rscratch))
+    for (int attempt = 0;; attempt++) {
+        hipError_t e = mi355i_launch_shadowmap(&c->dev, light->pos, light->world_to_light, size, (float *)c->smap[slot].p,
+                                               c->rscratch, c->stream);
+        if (e != hipSuccess) return fail(-43, "shadow map launch failed: %s", hipGetErrorString(e));
+        HIP_TRY(hipStreamSynchronize(c->stream), -40);
+        const uint32_t dropped = mi355i_raster_overflow(c->rscratch);
+        if (!dropped) break;
+        if (attempt < 6 && mi355i_raster_grow(c->rscratch)) continue;      // twice the span buffer, draw again
         return fail(-44, "shadow map span buffer overflowed (%u rows dropped)", dropped);
+    }
     c->smap_size[slot] = size;
     if (out_map) HIP_TRY(hipMemcpy(out_map, c->smap[slot].p, (size_t)size * size * 4, hipMemcpyDeviceToHost), -31);
     return 0;
@@ -893,7 +898,13 @@ int mi355_fetch_stats(mi355_ctx *c, mi355_stats *s)
     s->node_pops = h[CS_NODE_POPS]; s->inner_box_hits = h[CS_INNER_HITS]; s->tri_tests = h[CS_TRI_TESTS];
     s->plane_pass = h[CS_PLANE_PASS]; s->shaded_hits = h[CS_SHADED_HITS];
     s->tris_drawn = h[CS_TRIS_DRAWN]; s->spans = h[CS_SPANS]; s->ztests = h[CS_ZTESTS]; s->plots = h[CS_PLOTS];
-    if (h[CS_OVERFLOW]) return fail(-44, "rasterizer span buffer overflowed (%llu rows dropped)", h[CS_OVERFLOW]);
+    if (h[CS_OVERFLOW]) {
+        // the frame is incomplete; the next one gets span buffers twice as large (mi355_render retries by itself)
+        const int grown = mi355i_raster_grow(c->rscratch);
+        for (int f = 0; f < MI355_MAX_BATCH; f++) if (c->rs_batch[f]) (void)mi355i_raster_grow(c->rs_batch[f]);
+        return fail(-44, "rasterizer span buffer overflowed (%llu rows dropped)%s", h[CS_OVERFLOW],
+                    grown ? "; the buffers grow for the next frame" : "");
+    }
     return 0;
 }
 
@@ -949,20 +960,24 @@ int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_li
     }
     FrameParams P;
     if (int r = fill_params(c, mode, cam, lights, n_lights, o, c->fb.p, W * 4, wantf ? c->fbf.p : nullptr, P)) return r;
-    HIP_TRY(hipEventRecord(c->ev0, c->stream), -40);
-    if (int r = enqueue_frame(c, mode, P, o->collect_stats, c->stream)) return r;
-    HIP_TRY(hipEventRecord(c->ev1, c->stream), -40);
-    HIP_TRY(hipStreamSynchronize(c->stream), -40);
+    mi355_stats tmp;
+    mi355_stats *st = stats ? stats : &tmp;
+    for (int attempt = 0;; attempt++) {
+        HIP_TRY(hipEventRecord(c->ev0, c->stream), -40);
+        if (int r = enqueue_frame(c, mode, P, o->collect_stats, c->stream)) return r;
+        HIP_TRY(hipEventRecord(c->ev1, c->stream), -40);
+        HIP_TRY(hipStreamSynchronize(c->stream), -40);
+        const int r = mi355_fetch_stats(c, st);              // also surfaces a rasterizer span-buffer overflow ...
+        if (r == -44 && attempt < 6) continue;               // ... after which the buffers have grown: draw the frame again
+        if (r) return r;
+        break;
+    }
     HIP_TRY(hipMemcpy2D(out_xrgb, (size_t)pitch_bytes, c->fb.p, (size_t)W * 4, (size_t)W * 4, (size_t)rows, hipMemcpyDeviceToHost), -31);
     if (wantf) HIP_TRY(hipMemcpy(out_rgb_f32, c->fbf.p, (size_t)W * rows * 12, hipMemcpyDeviceToHost), -31);
     if (stats) {
-        if (int r = mi355_fetch_stats(c, stats)) return r;
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1), -40);
         stats->kernel_ms = ms;
-    } else {
-        mi355_stats tmp;
-        if (int r = mi355_fetch_stats(c, &tmp)) return r;    // surfaces rasterizer overflow
     }
     return 0;
 }

@@ -66,6 +66,7 @@ struct RasterScratch {
     TriRec *tris = nullptr; uint32_t tris_cap = 0;   // drawn triangles; ctl[3] = count
     uint2 *rcwork = nullptr; uint32_t rcwork_cap = 0; // (triangle record, row chunk) items of k_rs_rows; ctl[4] = count
     uint32_t *smkeys = nullptr; size_t sm_words = 0;
+    int grow = 0;                  // doublings of the span buffers asked for after an overflow (mi355i_raster_grow)
 };
 
 namespace {
@@ -264,7 +265,10 @@ MI_DEV void emit_rows(int iy0, int iy1, int iy2, const float (&A)[N], const floa
     const uint32_t nrows = (uint32_t)(maxy - miny + 1);
     const uint32_t base = atomicAdd(&ctl[0], nrows);
     if (base + nrows > rows_cap) {
+        // dropped (the caller reports it and grows the buffers): the part of the reservation that lies inside the
+        // buffer is marked so that no span pass reads records nobody wrote
         atomicAdd(&ctl[1], nrows);
+        for (uint32_t i = base; i < rows_cap && i - base < nrows; i++) { rows[i].pad = 1u; rows[i].cnt = 0u; rows[i].y = 0; }
         return;
     }
     Edge<N> e0, e1, e2;
@@ -288,7 +292,11 @@ MI_DEV void emit_rows(int iy0, int iy1, int iy2, const float (&A)[N], const floa
         slots_per_row = (wpx > 0.f ? (uint32_t)(wpx * (1.0f / MI_SPAN_CHUNK)) : 0u) + 2u;
         const uint32_t need = slots_per_row * nrows;
         wbase = atomicAdd(&ctl[2], need);
-        if (wbase + need > work_cap) { atomicAdd(&ctl[1], nrows); work = nullptr; }
+        if (wbase + need > work_cap) {
+            atomicAdd(&ctl[1], nrows);
+            for (uint32_t i = wbase; i < work_cap && i - wbase < need; i++) work[i] = make_uint2(0xffffffffu, 0u);
+            work = nullptr;
+        }
     }
     for (int y = miny; y <= maxy; y++) {
         float l[N], r[N];
@@ -322,7 +330,7 @@ MI_DEV void emit_rows(int iy0, int iy1, int iy2, const float (&A)[N], const floa
 // per wave -- same-address atomics serialise at ~10 ns each and were most of this kernel's time.
 template <int N>
 MI_DEV void tri_alloc(bool valid, int iy0, int iy1, int iy2, const float (&A)[N], const float (&B)[N], const float (&C)[N], int height,
-                      int W, uint32_t tri, uint32_t rows_cap, uint32_t work_cap, TriRec *tris, uint32_t tris_cap,
+                      int W, uint32_t tri, uint32_t rows_cap, uint2 *work, uint32_t work_cap, TriRec *tris, uint32_t tris_cap,
                       uint2 *rcwork, uint32_t rcwork_cap, uint32_t *ctl)
 {
     __shared__ uint32_t wave_tot[4][4];
@@ -374,8 +382,11 @@ MI_DEV void tri_alloc(bool valid, int iy0, int iy1, int iy2, const float (&A)[N]
     const uint32_t rows_base = base[0], work_base = base[1], ti = base[2], rcb = base[3];
     if (rows_base + nrows > rows_cap || work_base + slots_per_row * nrows > work_cap || ti >= tris_cap || rcb + nrc > rcwork_cap) {
         atomicAdd(&ctl[1], nrows);
-        // keep the item lists consistent: the items of a dropped triangle are marked invalid
+        // keep the item lists consistent: the items of a dropped triangle are marked invalid, in both lists (the
+        // counters already include them, and the buffers are not cleared between frames)
         for (uint32_t c = 0; c < nrc && rcb + c < rcwork_cap; c++) rcwork[rcb + c] = make_uint2(0xffffffffu, 0u);
+        const uint32_t need = slots_per_row * nrows;
+        for (uint32_t i = work_base; i < work_cap && i - work_base < need; i++) work[i] = make_uint2(0xffffffffu, 0u);
         return;
     }
     TriRec &T = tris[ti];
@@ -510,7 +521,7 @@ MI_DEV bool tri_prepare(const DevScene &S, const FrameParams &P, uint32_t t, flo
 
 template <int MODE>
 __global__ void __launch_bounds__(256) k_rs_tri(const DevScene S, const FrameParams P, uint32_t rows_cap, uint32_t *ctl,
-                                                uint32_t work_cap, TriRec *tris, uint32_t tris_cap, uint2 *rcwork,
+                                                uint2 *work, uint32_t work_cap, TriRec *tris, uint32_t tris_cap, uint2 *rcwork,
                                                 uint32_t rcwork_cap)
 {
     constexpr int N = FatN<MODE>::N;
@@ -523,7 +534,7 @@ __global__ void __launch_bounds__(256) k_rs_tri(const DevScene S, const FramePar
         for (int i = 0; i < N; i++) f[k][i] = 0.f;
     const bool valid = t < S.n_tris && tri_prepare<MODE>(S, P, t, f, iy);
     if (valid && P.counters && P.raster_stats) atomicAdd(&P.counters[CS_TRIS_DRAWN], 1ull);
-    tri_alloc<N>(valid, iy[0], iy[1], iy[2], f[0], f[1], f[2], P.H, P.W, t, rows_cap, work_cap, tris, tris_cap, rcwork, rcwork_cap, ctl);
+    tri_alloc<N>(valid, iy[0], iy[1], iy[2], f[0], f[1], f[2], P.H, P.W, t, rows_cap, work, work_cap, tris, tris_cap, rcwork, rcwork_cap, ctl);
 }
 
 // Edge walk of MI_ROW_CHUNK scanlines of one drawn triangle (ScanConverter.h:27-137 + row clipping of Screen.h:244-275)
@@ -726,6 +737,7 @@ __global__ void __launch_bounds__(256) k_sm_spans(const ShadowParams Q, const Ro
     const int SM = Q.size;
     for (uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x; ri < n_rows; ri += gridDim.x * blockDim.x) {
         const RowRec &R = rows[ri];
+        if (R.pad) continue;                                              // reserved by a dropped triangle, never written
         uint32_t *row = smkeys + (size_t)R.y * SM;
         auto plot = [&](float x, float z) {                               // PlotShadowPixel, Light.cc:253-259
             const int idx = cvtt_i32(x);
@@ -772,12 +784,11 @@ extern "C" void mi355i_raster_scratch_destroy(RasterScratch *s)
     delete s;
 }
 
-static hipError_t scratch_ensure(RasterScratch *s, size_t key_words, size_t sm_words, uint32_t n_tris, int height)
+static hipError_t scratch_ensure(RasterScratch *s, size_t key_words, size_t sm_words, uint32_t n_tris, int height, int width)
 {
     hipError_t e;
     if (key_words > s->keys_words) {
         if (s->keys) (void)hipFree(s->keys);
-    if (s->gbuf) (void)hipFree(s->gbuf);
         s->keys = nullptr; s->keys_words = 0;
         if ((e = hipMalloc((void **)&s->keys, key_words * 8)) != hipSuccess) return e;
         if (s->gbuf) (void)hipFree(s->gbuf);
@@ -792,22 +803,31 @@ static hipError_t scratch_ensure(RasterScratch *s, size_t key_words, size_t sm_w
         s->sm_words = sm_words;
     }
     // Span rows: every drawn triangle owns (rows it touches) records.  Size for an average of
-    // 64 rows per triangle, at least 4 M rows, at most height rows per triangle.
-    unsigned long long want = (unsigned long long)n_tris * 64ull;
-    if (want < (4ull << 20)) want = 4ull << 20;
+    // 64 rows per triangle, at least 4 M rows, at most height rows per triangle; doubled `grow` times after an
+    // overflow was reported (mi355i_raster_grow).
+    unsigned long long want = ((unsigned long long)n_tris * 64ull) << s->grow;
+    if (want < ((4ull << 20) << s->grow)) want = (4ull << 20) << s->grow;
     const unsigned long long worst = (unsigned long long)n_tris * (unsigned long long)height;
     if (want > worst) want = worst;
     if (want < 1024) want = 1024;
     if (want > 0xfffffff0ull) want = 0xfffffff0ull;
+    // span-chunk slots: 4 per row on average, never more than the worst case (every row of every triangle as wide as
+    // the frame) -- which is what a handful of screen-filling triangles need
+    const unsigned long long slots_worst = worst * ((unsigned long long)(width > 0 ? width : 1) / MI_SPAN_CHUNK + 3ull);
+    unsigned long long wwant = want * 4ull;
+    if (wwant < ((16ull << 20) << s->grow)) wwant = (16ull << 20) << s->grow;
+    if (wwant > slots_worst) wwant = slots_worst;
+    if (wwant < 4096) wwant = 4096;
+    if (wwant > 0xfffffff0ull) wwant = 0xfffffff0ull;
     if ((uint32_t)want > s->rows_cap) {
         if (s->rows) (void)hipFree(s->rows);
-    if (s->work) (void)hipFree(s->work);
         s->rows = nullptr; s->rows_cap = 0;
         if ((e = hipMalloc((void **)&s->rows, (size_t)want * sizeof(RowRec))) != hipSuccess) return e;
         s->rows_cap = (uint32_t)want;
+    }
+    if ((uint32_t)wwant > s->work_cap) {
         if (s->work) (void)hipFree(s->work);
         s->work = nullptr; s->work_cap = 0;
-        const unsigned long long wwant = want * 4ull < 0xfffffff0ull ? want * 4ull : 0xfffffff0ull;
         if ((e = hipMalloc((void **)&s->work, (size_t)wwant * sizeof(uint2))) != hipSuccess) return e;
         s->work_cap = (uint32_t)wwant;
     }
@@ -840,7 +860,7 @@ static hipError_t raster_frame(const DevScene *S, const FrameParams *Pin, Raster
     Pv.rows_cap = s->rows_cap;
     const FrameParams *P = &Pv;
     const int nbT = (int)((S->n_tris + 255) / 256);
-    hipLaunchKernelGGL((k_rs_tri<MODE>), dim3(nbT > 0 ? nbT : 1), dim3(256), 0, st, *S, *P, s->rows_cap, s->ctl, s->work_cap, s->tris, s->tris_cap, s->rcwork, s->rcwork_cap);
+    hipLaunchKernelGGL((k_rs_tri<MODE>), dim3(nbT > 0 ? nbT : 1), dim3(256), 0, st, *S, *P, s->rows_cap, s->ctl, s->work, s->work_cap, s->tris, s->tris_cap, s->rcwork, s->rcwork_cap);
     hipLaunchKernelGGL((k_rs_rows<MODE>), dim3(1024), dim3(128), 0, st, *P, s->tris, s->rcwork, s->rcwork_cap, s->ctl, s->rows, s->work);
     hipLaunchKernelGGL((k_rs_spans<MODE, false>), dim3(2048), dim3(256), 0, st, *S, *P, s->rows, s->ctl, s->work, s->work_cap, s->keys, s->gbuf);
     hipLaunchKernelGGL((k_rs_spans<MODE, true>), dim3(2048), dim3(256), 0, st, *S, *P, s->rows, s->ctl, s->work, s->work_cap, s->keys, s->gbuf);
@@ -851,7 +871,7 @@ static hipError_t raster_frame(const DevScene *S, const FrameParams *Pin, Raster
 extern "C" hipError_t mi355i_launch_raster(const DevScene *S, const FrameParams *P, int mode, RasterScratch *s,
                                            hipStream_t st)
 {
-    hipError_t e = scratch_ensure(s, (size_t)P->W * P->H, 0, S->n_tris, P->H);
+    hipError_t e = scratch_ensure(s, (size_t)P->W * P->H, 0, S->n_tris, P->H, P->W);
     if (e != hipSuccess) return e;
     // Screen::ClearScreen + ClearZbuffer (Rasterizers.cc:326-327)
     if ((e = hipMemset2DAsync(P->out, (size_t)P->pitch_words * 4, 0, (size_t)P->W * 4, (size_t)P->out_rows, st)) != hipSuccess) return e;
@@ -871,7 +891,7 @@ extern "C" hipError_t mi355i_launch_shadowmap(const DevScene *S, const float *li
                                               float *d_map, RasterScratch *s, hipStream_t st)
 {
     const size_t n = (size_t)size * size;
-    hipError_t e = scratch_ensure(s, 0, n, S->n_tris, size);
+    hipError_t e = scratch_ensure(s, 0, n, S->n_tris, size, size);
     if (e != hipSuccess) return e;
     ShadowParams Q;
     memcpy(Q.light, light_pos, 12);
@@ -885,6 +905,14 @@ extern "C" hipError_t mi355i_launch_shadowmap(const DevScene *S, const float *li
     hipLaunchKernelGGL(k_sm_spans, dim3(2048), dim3(256), 0, st, Q, s->rows, s->ctl, s->rows_cap, s->smkeys);
     hipLaunchKernelGGL(k_sm_resolve, dim3(1024), dim3(256), 0, st, s->smkeys, d_map, n);
     return hipGetLastError();
+}
+
+// after an overflow: the next frame's span buffers are twice as large (up to 2^6 times the default)
+extern "C" int mi355i_raster_grow(RasterScratch *s)
+{
+    if (!s || s->grow >= 6) return 0;
+    s->grow++;
+    return 1;
 }
 
 // rows dropped by the last raster / shadow-map launch on this scratch (0 = none); synchronises

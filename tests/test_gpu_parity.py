@@ -14,6 +14,7 @@ import pytest
 import renderer_amd as R
 
 pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
 PINS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_pins.json")))
 NCPU = os.cpu_count() or 1
 FLOAT_TOL = 1e-4
@@ -246,6 +247,88 @@ def test_model_loaded_from_3ds(oracle, oracle_scene, gpu_scene, mode):
         assert_same(g, o)
         for k in ("normal_rays", "shadow_rays", "node_pops", "tri_tests", "plane_pass"):
             assert getattr(g[2], k) == getattr(o[2], k), k
+
+
+def test_raster_scratch_regrows_between_frames(oracle, oracle_scene):
+    """One context, growing demands: tiny frame, larger frame, shadow map (1024 rows per triangle at most), larger frame
+    again.  Every regrowth of the raster scratch must leave the context usable (a double free here once left a sticky
+    'invalid argument' behind that failed the next launch)."""
+    s = R.Scene(R.assets.mesh_path("chessboard.tri"))
+    osc = oracle_scene("chessboard.tri")
+    cam, lights, n = R.benchmark_frame(4)
+    ocam, ol, on = oracle.benchmark_frame(4)
+    for mode, (W, H) in ((6, (64, 48)), (4, (640, 480)), (8, (333, 217)), (6, (1920, 1080)), (7, (800, 600))):
+        maps = None
+        if mode in (7, 8):
+            maps = [osc.shadowmap(ol[0])]
+            s.shadowmap_render(0, lights[0])
+        img = s.render(mode, cam, lights, n, R.default_opts(W, H))[0]
+        want = osc.render(mode, ocam, ol, on, oracle.default_opts(W, H, threads=NCPU), shadow_maps=maps)[0]
+        assert np.array_equal(img, want), "mode %d at %dx%d" % (mode, W, H)
+
+
+def _write_soup(path, verts, faces, cols):
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nelement face %d\nend_header\n" % (len(verts), len(faces)))
+        for q in verts:
+            f.write("%r %r %r 200\n" % (float(q[0]), float(q[1]), float(q[2])))
+        for t, c in zip(faces, cols):
+            f.write("3 %d %d %d %d %d %d\n" % (t[0], t[1], t[2], c[0], c[1], c[2]))
+
+
+def test_few_screen_filling_triangles(oracle, tmp_path):
+    """Seven triangles larger than the view, seen from inside the cloud (found by scripts/fuzz_raster.py: the span-chunk
+    buffer used to be sized for 4 chunks per row, the dropped triangles' reservations were read as garbage and the GPU
+    faulted).  Small scenes now get worst-case buffers."""
+    rng = np.random.default_rng(11)
+    v = rng.uniform(-1, 1, (7, 1, 3)) + rng.uniform(-2.5, 2.5, (7, 3, 3))
+    p = str(tmp_path / "huge.ply")
+    _write_soup(p, v.reshape(-1, 3), np.arange(21).reshape(7, 3), rng.integers(30, 255, (7, 3)))
+    s, o = R.Scene(p), oracle.Scene(p)
+    eye, look = np.array([-0.6, 0.9, 0.4], np.float32), np.array([0.1, 0.0, -0.1], np.float32)
+    cam, ocam = R.camera(eye, look), oracle.camera(eye, look)
+    lp = np.array([2.0, -1.0, 2.5], np.float32)
+    lights, ol = (R.Light * 2)(R.light(lp, cam)), (oracle.Light * 2)(oracle.light(lp, ocam))
+    for mode in (4, 5, 6, 7, 8):
+        maps = None
+        if mode in (7, 8):
+            maps = [o.shadowmap(ol[0])]
+            s.shadowmap_render(0, lights[0])
+        img = s.render(mode, cam, lights, 1, R.default_opts(333, 217))[0]
+        want = o.render(mode, ocam, ol, 1, oracle.default_opts(333, 217), shadow_maps=maps)[0]
+        assert np.array_equal(img, want), "mode %d" % mode
+
+
+def test_span_buffers_grow_after_an_overflow(oracle, tmp_path):
+    """150 000 triangles (half of them facing the camera) that each cover most of a 200x150 view need more span chunks than
+    the default buffer holds:
+    mi355_render notices the overflow, doubles the buffers and draws the frame again -- the caller sees a complete
+    frame; the asynchronous entry point reports the overflow (-44) and the next frame has the room."""
+    rng = np.random.default_rng(5)
+    n = 150000
+    c = rng.uniform(-0.2, 0.2, (n, 1, 3))
+    v = c + rng.uniform(-1.0, 1.0, (n, 3, 3)) * np.array([0.05, 1.0, 1.0])
+    p = str(tmp_path / "layers.ply")
+    _write_soup(p, v.reshape(-1, 3), np.arange(3 * n).reshape(n, 3), rng.integers(30, 255, (n, 3)))
+    s, o = R.Scene(p), oracle.Scene(p)
+    eye, look = np.array([2.2, 0.2, 0.1], np.float32), np.array([0.0, 0.0, 0.0], np.float32)
+    cam, ocam = R.camera(eye, look), oracle.camera(eye, look)
+    lp = np.array([3.0, 1.0, 1.0], np.float32)
+    lights, ol = (R.Light * 2)(R.light(lp, cam)), (oracle.Light * 2)(oracle.light(lp, ocam))
+    W, H = 200, 150
+    dev = torch.device("cuda", 0)
+    buf = torch.zeros((H, W), dtype=torch.int32, device=dev)
+    s.render_device(4, cam, lights, 1, R.default_opts(W, H), buf.data_ptr(), W * 4, 0, torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    with pytest.raises(R.Mi355Error, match="overflowed"):
+        s.fetch_stats()
+    img = s.render(4, cam, lights, 1, R.default_opts(W, H))[0]          # retries inside until the frame is complete
+    want = o.render(4, ocam, ol, 1, oracle.default_opts(W, H))[0]
+    assert np.array_equal(img, want)
+    s.render_device(4, cam, lights, 1, R.default_opts(W, H), buf.data_ptr(), W * 4, 0, torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    s.fetch_stats()                                                      # no overflow any more
+    assert np.array_equal(buf.cpu().numpy().astype(np.uint32), want)
 
 
 @pytest.mark.parametrize("mode", [6, 8])
