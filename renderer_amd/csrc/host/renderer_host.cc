@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <sstream>
+#include <cerrno>
 
 namespace mi355 {
 
@@ -179,17 +181,32 @@ struct Tokens {
     bool ok = true;
     Tokens(const char *b, const char *e) : p(b), end(e) {}
     void skip() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n' || *p == '\f' || *p == '\v')) p++; }
+    // Strict fast paths: a token is accepted only if it is a plain decimal number that `operator>>` would read to the
+    // same value; anything else clears `ok` and the caller re-reads the whole line through a std::istringstream.
     float f()
     {
         if (!ok) return 0.f;
         skip();
-        char tmp[128]; size_t n = 0;
+        char tmp[64]; size_t n = 0;
         while (p + n < end && n < sizeof tmp - 1 && !strchr(" \t\r\n\f\v", p[n])) { tmp[n] = p[n]; n++; }
         tmp[n] = 0;
+        size_t i = 0, digits = 0;
+        if (tmp[i] == '-') i++;
+        while (tmp[i] >= '0' && tmp[i] <= '9') { i++; digits++; }
+        if (tmp[i] == '.') { i++; while (tmp[i] >= '0' && tmp[i] <= '9') { i++; digits++; } }
+        if (digits && (tmp[i] == 'e' || tmp[i] == 'E')) {
+            size_t j = i + 1, ed = 0;
+            if (tmp[j] == '+' || tmp[j] == '-') j++;
+            while (tmp[j] >= '0' && tmp[j] <= '9') { j++; ed++; }
+            if (!ed) { ok = false; return 0.f; }
+            i = j;
+        }
+        if (!digits || i != n || n == 0 || n >= sizeof tmp - 1) { ok = false; return 0.f; }
+        errno = 0;
         char *q = nullptr;
-        float v = strtof(tmp, &q);               // what num_get<float> ends up calling
-        if (q == tmp) { ok = false; return 0.f; }
-        p += (q - tmp);
+        const float v = strtof(tmp, &q);               // what num_get<float> ends up calling for such a token
+        if (q != tmp + n || errno != 0 || !std::isfinite(v)) { ok = false; return 0.f; }
+        p += n;
         return v;
     }
     unsigned u()
@@ -197,13 +214,12 @@ struct Tokens {
         if (!ok) return 0;
         skip();
         const char *q = p;
-        bool neg = false;
-        if (q < end && (*q == '+' || *q == '-')) { neg = *q == '-'; q++; }
-        if (!(q < end && *q >= '0' && *q <= '9')) { ok = false; return 0; }
         unsigned long long v = 0;
-        while (q < end && *q >= '0' && *q <= '9') { v = v * 10 + (unsigned)(*q - '0'); q++; }
+        int nd = 0;
+        while (q < end && *q >= '0' && *q <= '9' && nd < 10) { v = v * 10 + (unsigned)(*q - '0'); q++; nd++; }
+        if (!nd || v > 0xffffffffull || (q < end && !strchr(" \t\r\n\f\v", *q))) { ok = false; return 0; }
         p = q;
-        return neg ? (unsigned)(0ull - v) : (unsigned)v;
+        return (unsigned)v;
     }
 };
 
@@ -245,6 +261,7 @@ void Scene::load(const char *filename)
         normalsGiven = withNormals;
         uint32_t totalPoints = 0;
         while (!rd.eof()) {
+            if (rd.off + 4 > data.size()) break;      // 1-3 stray bytes: the reference's fread hits EOF and stops (Loader.cc:163-166)
             const uint32_t nP = rd.get<uint32_t>();
             for (uint32_t i = 0; i < nP; i++) {
                 float p[6] = {0, 0, 0, 0, 0, 0};
@@ -268,7 +285,10 @@ void Scene::load(const char *filename)
             totalPoints += nP;
         }
     } else if (!strcmp(dt, "ply") || !strcmp(dt, "PLY")) {
-        // Loader.cc:354-409: "shadevis" ASCII subset -- x y z ao per vertex, n i j k [r g b] per face
+        // Loader.cc:354-409: "shadevis" ASCII subset -- x y z ao per vertex, n i j k [r g b] per face.  The reference
+        // reads every line with `std::istringstream >>`; plain decimal lines (all of a real file) take a fast scanner
+        // that gives the same values, anything else (signs on unsigned fields, "inf", "1e", overflow, ...) goes through
+        // the same stream extraction, with the variables zero-initialised where the reference leaves them undefined.
         const std::vector<unsigned char> data = slurp(filename);
         const char *p = (const char *)data.data(), *end = p + data.size();
         unsigned totalVertices = 0, totalTriangles = 0;
@@ -278,25 +298,44 @@ void Scene::load(const char *filename)
             const char *le = nl ? nl : end;
             const size_t len = le - p;
             if (!inside) {
-                if (len >= 14 && !memcmp(p, "element vertex", 14)) { Tokens t(p + 14, le); totalVertices = t.u(); }
-                else if (len >= 12 && !memcmp(p, "element face", 12)) { Tokens t(p + 12, le); totalTriangles = t.u(); }
-                else if (len >= 10 && !memcmp(p, "end_header", 10)) inside = true;
+                if (len >= 14 && !memcmp(p, "element vertex", 14)) {
+                    std::istringstream str(std::string(p, le)); std::string w; str >> w; str >> w; str >> totalVertices;
+                } else if (len >= 12 && !memcmp(p, "element face", 12)) {
+                    std::istringstream str(std::string(p, le)); std::string w; str >> w; str >> w; str >> totalTriangles;
+                } else if (len >= 10 && !memcmp(p, "end_header", 10)) inside = true;
             } else if (totalVertices) {
                 totalVertices--;
                 Tokens t(p, le);
-                const float x = t.f(), y = t.f(), z = t.f();
-                const unsigned ao = t.u();
+                float x = t.f(), y = t.f(), z = t.f();
+                unsigned ao = t.u();
+                if (!t.ok) {
+                    x = y = z = 0.f; ao = 0;
+                    std::istringstream str(std::string(p, le));
+                    str >> x >> y >> z >> ao;
+                }
                 addVertex(x, y, z, 0.f, 0.f, 0.f, ao & 0xffu);               // Vertex(..., unsigned char amb)
             } else if (totalTriangles) {
                 totalTriangles--;
                 Tokens t(p, le);
                 t.u();
-                const unsigned i1 = t.u(), i2 = t.u(), i3 = t.u();
-                if (t.ok) {
-                    unsigned r = t.u(), g = t.u(), b = t.u();
-                    if (!t.ok) r = g = b = 255;
-                    addTriangle(i1, i2, i3, r, g, b);
+                unsigned i1 = t.u(), i2 = t.u(), i3 = t.u();
+                bool face = t.ok, strict = t.ok;
+                unsigned r = 255, g = 255, b = 255;
+                if (strict) {
+                    t.skip();
+                    if (t.p < t.end) {                                        // colours follow: all three, plainly, or the stream decides
+                        r = t.u(); g = t.u(); b = t.u();
+                        strict = t.ok;
+                    }
                 }
+                if (!strict) {
+                    unsigned dummy = 0;
+                    i1 = i2 = i3 = 0;
+                    std::istringstream str(std::string(p, le));
+                    face = (bool)(str >> dummy >> i1 >> i2 >> i3);
+                    if (face && !(str >> r >> g >> b)) r = g = b = 255;
+                }
+                if (face) addTriangle(i1, i2, i3, r, g, b);
             }
             p = nl ? nl + 1 : end;
         }
