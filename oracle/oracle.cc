@@ -1034,6 +1034,19 @@ orc_scene *orc_scene_load(const char *path, char *err, int errlen)
     orc_scene *s = new orc_scene;
     std::string e;
     bool ok = false;
+    if (path[0] == '@' && path[1] == 'p') {
+        /* Loader.cc:87-97: the built-in platform; Scene::load returns BEFORE the common tail, so the triangles keep
+         * what the ctor gave them (make_tri: centre, normal from the vertex normals, boxes at +-FLT_MAX) and the
+         * plane / edge members the tail would write -- uninitialised in the reference -- are the zeros make_tri set. */
+        const float q[4][2] = {{0.5f, -0.5f}, {0.5f, 0.5f}, {-0.5f, 0.5f}, {-0.5f, -0.5f}};
+        for (int i = 0; i < 4; i++) {
+            Vert v; v.p = V3(q[i][0], q[i][1], 0.f); v.n = V3(0.f, 0.f, 1.f); v.ao = 60;
+            s->verts.push_back(v);
+        }
+        s->tris.push_back(make_tri(s->verts, 0, 1, 2, 255, 0, 0));
+        s->tris.push_back(make_tri(s->verts, 0, 2, 3, 255, 0, 0));
+        return s;
+    }
     const char *dt = strrchr(path, '.');
     if (dt && !strcmp(dt + 1, "tri")) ok = load_tri(*s, path, e);
     else if (dt && (!strcmp(dt + 1, "ply") || !strcmp(dt + 1, "PLY"))) ok = load_ply(*s, path, e);

@@ -246,6 +246,33 @@ void Scene::load(const char *filename)
         _vertexAO.push_back(ao);
     };
 
+    if (filename[0] == '@' && filename[1] == 'p') {
+        // Loader.cc:87-97, the built-in "platform": a unit square of two red triangles, and the loader RETURNS before its
+        // common tail -- no centring / rescale, no bounding boxes, no plane / edge precompute.  What the Triangle ctor
+        // set stays (Base3d.cc:27-55: centre, normal = normalised mean of the vertex normals, boxes at +-FLT_MAX); the
+        // members only the tail would have written are uninitialised in the reference and read as zero here.
+        addVertex(0.5f, -0.5f, 0.f, 0.f, 0.f, 1.f, 60);
+        addVertex(0.5f, 0.5f, 0.f, 0.f, 0.f, 1.f, 60);
+        addVertex(-0.5f, 0.5f, 0.f, 0.f, 0.f, 1.f, 60);
+        addVertex(-0.5f, -0.5f, 0.f, 0.f, 0.f, 1.f, 60);
+        addTriangle(0, 1, 2, 255, 0, 0);
+        addTriangle(0, 2, 3, 255, 0, 0);
+        const size_t T = 2;
+        _triCenter.assign(3 * T, 0.f); _triNormal.assign(3 * T, 0.f); _triD.assign(4 * T, 0.f); _triE.assign(9 * T, 0.f);
+        _triBottom.assign(3 * T, FLT_MAX); _triTop.assign(3 * T, -FLT_MAX);
+        for (size_t t = 0; t < T; t++) {
+            const int32_t *ix = &_triIndex[3 * t];
+            Vector3 n(0.f, 0.f, 0.f);
+            for (int k = 0; k < 3; k++) {
+                _triCenter[3 * t + k] = (_vertexPos[3 * ix[0] + k] + _vertexPos[3 * ix[1] + k] + _vertexPos[3 * ix[2] + k]) / 3.0f;
+                (&n._x)[k] = (_vertexNormal[3 * ix[0] + k] + _vertexNormal[3 * ix[1] + k] + _vertexNormal[3 * ix[2] + k]) / 3.0f;
+            }
+            n.normalize();
+            store3(&_triNormal[3 * t], n);
+        }
+        return;
+    }
+
     const char *dt = strrchr(filename, '.');
     if (!dt) raise("No extension in filename (only .tri .3ds or .ply accepted)");
     dt++;

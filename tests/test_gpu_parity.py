@@ -249,6 +249,23 @@ def test_model_loaded_from_3ds(oracle, oracle_scene, gpu_scene, mode):
             assert getattr(g[2], k) == getattr(o[2], k), k
 
 
+@pytest.mark.parametrize("mode", [1, 2, 4, 5, 6, 7, 8])
+def test_builtin_platform_scene(oracle, mode):
+    """The loader's built-in `@platform` square (two triangles, never rescaled) in every raster mode."""
+    s, o = R.Scene("@platform"), oracle.Scene("@platform")
+    eye, look = np.array([1.1, 0.4, 0.9], np.float32), np.array([0.0, 0.0, 0.0], np.float32)
+    cam, ocam = R.camera(eye, look), oracle.camera(eye, look)
+    lp = np.array([0.5, -1.0, 2.0], np.float32)
+    lights, ol = (R.Light * 2)(R.light(lp, cam)), (oracle.Light * 2)(oracle.light(lp, ocam))
+    maps = None
+    if mode in (7, 8):
+        maps = [o.shadowmap(ol[0])]
+        s.shadowmap_render(0, lights[0])
+    img = s.render(mode, cam, lights, 1, R.default_opts(320, 240))[0]
+    want = o.render(mode, ocam, ol, 1, oracle.default_opts(320, 240), shadow_maps=maps)[0]
+    assert np.array_equal(img, want) and img.any()
+
+
 def test_raster_scratch_regrows_between_frames(oracle, oracle_scene):
     """One context, growing demands: tiny frame, larger frame, shadow map (1024 rows per triangle at most), larger frame
     again.  Every regrowth of the raster scratch must leave the context usable (a double free here once left a sticky

@@ -174,3 +174,18 @@ def test_mesh_without_extent_is_refused_not_hung(tmp_path):
     assert not np.isfinite(s.arrays()["vertex_pos"]).all()
     with pytest.raises(R.Mi355Error, match="non-finite"):
         s.bvh_create("host")
+
+
+def test_builtin_platform_scene(oracle):
+    """`@p...` is the loader's built-in unit square (Loader.cc:87-97); it skips the loader's common tail."""
+    h, o = R.Scene("@platform"), oracle.Scene("@platform")
+    assert (h.nv, h.nt) == (o.nv, o.nt) == (4, 2)
+    a = h.arrays()
+    vpos, vnrm, vao = o.vertices()
+    t = o.triangles()
+    assert np.array_equal(bits(a["vertex_pos"]), bits(vpos)) and np.array_equal(bits(a["vertex_normal"]), bits(vnrm))
+    assert np.array_equal(a["vertex_ao"], vao) and np.array_equal(a["tri_index"], t["idx"])
+    assert np.array_equal(bits(a["tri_center"]), bits(t["center"])) and np.array_equal(bits(a["tri_normal"]), bits(t["normal"]))
+    assert np.array_equal(a["tri_color32"], t["color32"]) and int(a["tri_color32"][0]) == 0xFF0000
+    assert float(np.abs(a["vertex_pos"]).max()) == 0.5          # not rescaled to 1.2
+    assert not a["tri_d"].any() and not a["tri_e"].any()         # the tail never ran
