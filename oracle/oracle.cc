@@ -238,6 +238,28 @@ static bool load_tri(orc_scene &s, const char *path, std::string &err)
     return true;
 }
 
+/* Loader.cc:224-275 (.ra2: raw triangles, vertices stored y, z, x; white; $RA2 flips the winding) */
+static bool load_ra2(orc_scene &s, const char *path, std::string &err)
+{
+    FILE *fp = fopen(path, "rb");
+    if (!fp) { err = std::string("File '") + path + "' not found!"; return false; }
+    fseek(fp, 0, SEEK_END);
+    const uint32_t totalTriangles = (uint32_t)(ftell(fp) / 36), totalPoints = 3 * totalTriangles;
+    fseek(fp, 0, SEEK_SET);
+    for (uint32_t i = 0; i < totalPoints; i++) {
+        float yzx[3];
+        if (fread(yzx, 4, 3, fp) != 3) { fclose(fp); err = "Malformed 3D file"; return false; }
+        Vert v; v.p = V3(yzx[2], yzx[0], yzx[1]); v.n = V3(0, 0, 0); v.ao = 60;
+        s.verts.push_back(v);
+    }
+    fclose(fp);
+    const bool flip = getenv("RA2") != NULL;
+    for (uint32_t i = 0; i < totalTriangles; i++)
+        s.tris.push_back(make_tri(s.verts, (int)(3 * i), (int)(flip ? 3 * i + 2 : 3 * i + 1), (int)(flip ? 3 * i + 1 : 3 * i + 2), 255, 255, 255));
+    fix_normals(s);
+    return true;
+}
+
 /* Loader.cc:354-409 (.ply "shadevis" subset) */
 static bool load_ply(orc_scene &s, const char *path, std::string &err)
 {
@@ -1050,6 +1072,7 @@ orc_scene *orc_scene_load(const char *path, char *err, int errlen)
     const char *dt = strrchr(path, '.');
     if (dt && !strcmp(dt + 1, "tri")) ok = load_tri(*s, path, e);
     else if (dt && (!strcmp(dt + 1, "ply") || !strcmp(dt + 1, "PLY"))) ok = load_ply(*s, path, e);
+    else if (dt && !strcmp(dt + 1, "ra2")) ok = load_ra2(*s, path, e);
     else if (dt && !strcmp(dt + 1, "r3ds")) ok = load_r3ds(*s, path, e);
     else e = "Unknown extension (only .tri, .ply or an .r3ds dump accepted)";
     if (!ok) {

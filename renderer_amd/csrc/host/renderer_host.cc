@@ -311,6 +311,19 @@ void Scene::load(const char *filename)
             }
             totalPoints += nP;
         }
+    } else if (!strcmp(dt, "ra2")) {
+        // Loader.cc:224-275: raw triangles, 9 floats each, every vertex stored as (y, z, x); white; the RA2 environment
+        // variable flips the winding; a trailing partial triangle is ignored (size / 36)
+        const std::vector<unsigned char> data = slurp(filename);
+        Reader rd(data);
+        const uint32_t totalTriangles = (uint32_t)(data.size() / 36), totalPoints = 3 * totalTriangles;
+        for (uint32_t i = 0; i < totalPoints; i++) {
+            const float y = rd.get<float>(), z = rd.get<float>(), x = rd.get<float>();
+            addVertex(x, y, z, 0.f, 0.f, 0.f, 60);
+        }
+        const bool flip = getenv("RA2") != nullptr;
+        for (uint32_t i = 0; i < totalTriangles; i++)
+            addTriangle(3 * i, flip ? 3 * i + 2 : 3 * i + 1, flip ? 3 * i + 1 : 3 * i + 2, 255, 255, 255);
     } else if (!strcmp(dt, "ply") || !strcmp(dt, "PLY")) {
         // Loader.cc:354-409: "shadevis" ASCII subset -- x y z ao per vertex, n i j k [r g b] per face.  The reference
         // reads every line with `std::istringstream >>`; plain decimal lines (all of a real file) take a fast scanner

@@ -137,3 +137,25 @@ def test_host_bvh_builder_equals_the_oracle_builder_on_random_soups(oracle, tmp_
         hn, hi = h.bvh_arrays()
         blob = np.array([hn.shape[0], h.nt], np.uint32).tobytes() + hn.tobytes() + hi.tobytes()
         assert blob == open(p + ".obvh", "rb").read(), "soup %d (%d triangles, snap %s, stretch %s)" % (it, len(verts) // 3, snap, stretch)
+
+
+@pytest.mark.parametrize("flip", [False, True])
+def test_ra2_files(oracle, tmp_path, monkeypatch, flip):
+    """`.ra2` (Loader.cc:224-275): raw 36-byte triangles, vertices stored (y, z, x), a trailing partial triangle ignored,
+    `$RA2` flips the winding."""
+    if flip:
+        monkeypatch.setenv("RA2", "1")
+    else:
+        monkeypatch.delenv("RA2", raising=False)
+    rng = np.random.default_rng(7)
+    for it, extra in enumerate((0, 0, 5, 35)):
+        n = int(rng.integers(1, 40))
+        blob = rng.uniform(-3, 3, (n, 9)).astype("<f4").tobytes() + bytes(extra)
+        p = str(tmp_path / ("m%d.ra2" % it))
+        open(p, "wb").write(blob)
+        h, o, herr, oerr = both(p, oracle)
+        assert herr is None and oerr is None
+        assert (h.nv, h.nt) == (3 * n, n) and same_scene(h, o)
+        t = o.triangles()
+        a = h.arrays()
+        assert np.array_equal(bits(a["tri_normal"]), bits(t["normal"])) and np.array_equal(bits(a["tri_e"]), bits(t["plane"][:, 4:13]))
