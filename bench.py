@@ -232,6 +232,13 @@ def main():
         if world == 1 and os.path.exists(tfile):
             try:
                 result["roofline"]["traffic"] = json.load(open(tfile)).get("k_raytrace_hbm_bytes_per_launch")
+                pmc = json.load(open(tfile)).get("pmc_per_launch", {})
+                if "VALUBusy" in pmc:
+                    # what actually bounds the kernel (rocprofv3 --pmc, profiles/): vector-ALU issue, not HBM
+                    result["roofline"]["issue_bound"] = {"valu_busy_pct": round(pmc["VALUBusy"], 1),
+                                                         "valu_active_lanes_pct": round(pmc.get("VALUUtilization", 0.0), 1),
+                                                         "salu_busy_pct": round(pmc.get("SALUBusy", 0.0), 1),
+                                                         "source": "profiles/traffic.json (counters of the committed rocprofv3 passes)"}
                 if result["roofline"]["traffic"]:
                     # measured HBM rate of the traversal kernel (PMC bytes of profiles/traffic.json over this run's kernel time)
                     result["roofline"]["measured_hbm_GBs"] = round(result["roofline"]["traffic"] / (kernel_ms * 1e-3) / 1e9, 2)
@@ -273,6 +280,19 @@ def main():
                     raster_step(i)
                 torch.cuda.synchronize(dev)
                 extra[name + "_fps"] = round(200 / (time.perf_counter() - t1), 2)
+            # the headline workload frame by frame (one launch per frame: the latency-bound way to run the same frames)
+            if args.mode >= 9:
+                o1 = R.default_opts(W, H, tune=json.loads(args.tune))
+                for k in range(5):
+                    scene.render_device(args.mode, cams[k][0], cams[k][1], cams[k][2], o1, buf.data_ptr(), W * 4, 0, stream.cuda_stream)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for k in range(200):
+                    scene.render_device(args.mode, cams[k][0], cams[k][1], cams[k][2], o1, buf.data_ptr(), W * 4, 0, stream.cuda_stream)
+                torch.cuda.synchronize(dev)
+                dt1 = time.perf_counter() - t1
+                extra["frame_by_frame_fps"] = round(200 / dt1, 2)
+                extra["frame_by_frame_Mrays_per_s"] = round(float(sum(rays_f[k] for k in range(200) if rays_f[k] > 0)) / max(1, sum(1 for k in range(200) if rays_f[k] > 0)) * 200 / dt1 / 1e6, 1)
             # BVH build of the benchmark mesh: GPU level kernels + download + flatten, host builder beside it
             import ctypes as C
             bs = R.Scene(R.assets.mesh_path(args.mesh), device=local_rank)
