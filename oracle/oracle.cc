@@ -1309,4 +1309,23 @@ int orc_render(const orc_scene *s, int mode, const orc_camera *cam, const orc_li
     return 0;
 }
 
+/* LightingEquation<mode>::ComputePixel (LightingEq.h:45-170) on caller-supplied points: rows of
+ * (inCameraSpace[3], normal[3], material r,g,b, ao) -> r,g,b.  shadow_mode 0 none, 1 shadow maps, 2 soft.
+ * Exists so that tests can compare this restatement with the reference's own template (oracle/refcore). */
+void orc_lighting(const orc_light *lights, int n_lights, const float *const *shadow_maps, const orc_opts *o,
+                  int shadow_mode, int n, const float *pts10, float *rgb)
+{
+    LightCtx L{lights, n_lights, shadow_maps, o};
+    for (int i = 0; i < n; i++) {
+        const float *q = pts10 + 10 * (size_t)i;
+        const V3 point(q[0], q[1], q[2]), normal(q[3], q[4], q[5]);
+        const Px material(q[6], q[7], q[8]);
+        Px t;
+        if (shadow_mode == 0) compute_pixel<NoShadows>(L, point, normal, material, q[9], t);
+        else if (shadow_mode == 1) compute_pixel<ShadowMapping>(L, point, normal, material, q[9], t);
+        else compute_pixel<SoftShadowMapping>(L, point, normal, material, q[9], t);
+        rgb[3 * (size_t)i] = t.r; rgb[3 * (size_t)i + 1] = t.g; rgb[3 * (size_t)i + 2] = t.b;
+    }
+}
+
 } /* extern "C" */

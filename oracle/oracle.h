@@ -6,14 +6,17 @@
  * checker for the HIP path and as the "port" CPU baseline in bench.py.
  * Nothing under renderer_amd/ (the product) may include, link or call it.
  *
- * Parity pin: the restatement is checked against the SHA-256 frame pins,
- * ray/node/triangle counters, camera probes and BVH statistics that
- * SURVEY.md 8(c)/8(d) recorded from the real reference (strict single-thread
- * build); see tests/test_oracle_pins.py.  The reference itself cannot be
- * built in this image without writing stand-ins for SDL 1.2 headers, which
- * the build rules forbid, so there is no oracle/_ref build of the renderer (only of
- * its vendored lib3ds: oracle/ref3ds, which pins the product's .3ds reader and made
- * the .r3ds dump this oracle loads for .3ds models).
+ * Parity pin: (1) the REAL reference code, run here: oracle/_ref/refcore compiles
+ * the SDL-free parts of the reference from where they lie (oracle/refcore/) and
+ * tests/test_refcore_pins.py demands bit-identical floats from this restatement for
+ * Raytrace<> (full-size frames of the headline configs), the shadow map, the camera
+ * and light bases, LightingEquation<> and the BVH builder (small meshes);
+ * (2) for what the reference cannot run without SDL's library (Scene::load, the
+ * rasterizer's span walk and plotters, the builder on big meshes): the SHA-256 frame
+ * pins, counters, camera probes and BVH statistics that SURVEY.md 8(c)/8(d) recorded
+ * from the reference -- survey provenance, see tests/test_oracle_pins.py.
+ * The vendored lib3ds is built too (oracle/ref3ds): it pins the product's .3ds reader
+ * and made the .r3ds dump this oracle loads for .3ds models.
  */
 #ifndef ORACLE_H
 #define ORACLE_H
@@ -107,6 +110,11 @@ void orc_shadowmap_render(const orc_scene *, const orc_light *, int size, float 
 int orc_render(const orc_scene *, int mode, const orc_camera *, const orc_light *lights,
                int n_lights, const float *const *shadow_maps, const orc_opts *,
                uint32_t *out_xrgb, int pitch_words, float *out_f32, orc_stats *stats);
+
+/* LightingEquation<mode>::ComputePixel (LightingEq.h:45-170) on caller-supplied points, rows of
+ * (inCameraSpace[3], normal[3], material r,g,b, ao) -> r,g,b; shadow_mode 0 none, 1 shadow maps, 2 soft */
+void orc_lighting(const orc_light *lights, int n_lights, const float *const *shadow_maps, const orc_opts *o,
+                  int shadow_mode, int n, const float *pts10, float *rgb);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,8 @@ def lib():
                                  C.c_void_p, C.POINTER(Opts), C.c_void_p, C.c_int, C.c_void_p,
                                  C.POINTER(Stats)]
         L.orc_render.restype = C.c_int
+        L.orc_lighting.argtypes = [C.POINTER(Light), C.c_int, C.c_void_p, C.POINTER(Opts), C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -211,6 +213,18 @@ class Scene:
         if rc != 0:
             raise RuntimeError("orc_render failed (%d)" % rc)
         return out, outf, st
+
+
+def lighting(lights, n_lights: int, opts: Opts, shadow_mode: int, points, shadow_maps=None) -> np.ndarray:
+    """LightingEquation<mode>::ComputePixel for rows (inCameraSpace[3], normal[3], material r,g,b, ao)."""
+    pts = np.ascontiguousarray(points, np.float32)
+    out = np.empty((len(pts), 3), np.float32)
+    maps_arg = None
+    if shadow_maps is not None:
+        arr = (C.c_void_p * len(shadow_maps))(*[m.ctypes.data for m in shadow_maps])
+        maps_arg = C.cast(arr, C.c_void_p)
+    lib().orc_lighting(lights, n_lights, maps_arg, C.byref(opts), shadow_mode, len(pts), pts.ctypes.data, out.ctypes.data)
+    return out
 
 
 def rgb_bytes(xrgb: np.ndarray) -> bytes:

@@ -1,0 +1,125 @@
+"""Python side of oracle/_ref/refcore: the SDL-free parts of the REAL reference renderer (oracle/refcore/refcore.cc).
+
+TEST INFRASTRUCTURE ONLY.  The binary is built from /root/reference by oracle/refcore/Makefile (in this container; the GPU
+box receives the built file).  It pins the oracle: tests/test_refcore_pins.py runs the same inputs through the reference's
+own Raytrace<>, RenderSceneIntoShadowBuffer, Camera / Light bases, LightingEquation<> and MLAA and through the oracle's
+restatement, and compares bit for bit.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+BINARY = os.path.join(_HERE, "_ref", "refcore")
+REFERENCE_SRC = "/root/reference/src"
+
+
+def build() -> str | None:
+    """Build the binary where the reference tree is present; returns its path, or None when it cannot exist here."""
+    if os.path.isdir(REFERENCE_SRC):
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "refcore"), "-s"])
+    return BINARY if os.path.exists(BINARY) else None
+
+
+def available() -> bool:
+    return os.path.exists(BINARY)
+
+
+def _run(cmd: str, blobs, out_dtype, timeout=1800):
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in"), os.path.join(d, "out")
+        with open(fin, "wb") as f:
+            for b in blobs:
+                f.write(b if isinstance(b, (bytes, bytearray)) else np.ascontiguousarray(b).tobytes())
+        subprocess.run([BINARY, cmd, fin, fout], check=True, timeout=timeout, stdout=subprocess.DEVNULL)
+        return np.fromfile(fout, dtype=out_dtype)
+
+
+def _u32(v):
+    return np.uint32(v).tobytes()
+
+
+def _i32(v):
+    return np.int32(v).tobytes()
+
+
+def scene_blobs(osc):
+    """The state after Scene::load, as the oracle's loader exports it (oracle_ctypes.Scene)."""
+    vpos, vnrm, vao = osc.vertices()
+    t = osc.triangles()
+    return [_u32(osc.nv), _u32(osc.nt), vpos, vnrm, vao, t["idx"], t["center"], t["normal"], t["colorf"], t["color32"],
+            t["two_sided"], t["plane"]]
+
+
+def bvh_blobs(osc):
+    nodes, tri_idx = osc.bvh()
+    return [_u32(len(nodes)), _u32(len(tri_idx)), nodes, tri_idx]
+
+
+def primary_rays(cam, W, H, SD, xs=None, ys=None, sub=None):
+    """Raytracer.cc:563-593 in float32 numpy (one IEEE operation per numpy operation): origins and directions of the
+    primary rays of pixels (ys x xs), or of sub-sample `sub` (0..3) of the 4 spp pattern."""
+    f = np.float32
+    xs = np.arange(W) if xs is None else np.asarray(xs)
+    ys = np.arange(H) if ys is None else np.asarray(ys)
+    xx, yy = np.meshgrid(xs.astype(f), ys.astype(f))
+    if sub is not None:
+        xx = xx + f(0.25 - 0.5 * (sub & 1))
+        yy = yy + f(0.25 - 0.5 * ((sub & 2) >> 1))
+    lx = (f(H // 2) - yy) / f(SD)
+    ly = (xx - f(W // 2)) / f(SD)
+    lz = np.ones_like(lx)
+    n = np.sqrt(lx * lx + ly * ly + lz * lz)
+    lx, ly, lz = lx / n, ly / n, lz / n
+    mv = np.array(list(cam.mv), f).reshape(3, 3)
+    d = [mv[0, k] * lx for k in range(3)]
+    d = [d[k] + mv[1, k] * ly for k in range(3)]
+    d = [d[k] + mv[2, k] * lz for k in range(3)]
+    n = np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
+    d = np.stack([d[k] / n for k in range(3)], axis=-1)
+    o = np.broadcast_to(np.array(list(cam.eye), f), d.shape)
+    return np.concatenate([o, d], axis=-1).reshape(-1, 6).astype(f)
+
+
+def raytrace(osc, cam, lights, n_lights, rays, max_depth=3):
+    """Raytrace<true>(origin, dir, NULL, 3 - max_depth) of the reference for every ray -> (n, 3) r,g,b floats.
+    (MAX_RAY_DEPTH is a #define of 3 in Raytracer.cc:56; starting the recursion at depth 3 - k leaves k levels.)"""
+    lp = np.array([list(lights[i].pos) for i in range(n_lights)], np.float32).reshape(-1)
+    blobs = scene_blobs(osc) + bvh_blobs(osc) + [_u32(n_lights), lp, np.array(list(cam.eye), np.float32),
+                                                 np.array(list(cam.mv), np.float32), _i32(3 - max_depth), _u32(len(rays)), rays]
+    return _run("raytrace", blobs, np.float32).reshape(-1, 3)
+
+
+def shadowmap(osc, light_pos):
+    out = _run("shadowmap", scene_blobs(osc) + [np.array(light_pos, np.float32)], np.float32)
+    return out[:9].copy(), out[9:].reshape(1024, 1024)
+
+
+def camera_bases(eyes, lookats, lights):
+    rows = np.concatenate([np.asarray(eyes, np.float32), np.asarray(lookats, np.float32), np.asarray(lights, np.float32)], axis=1)
+    out = _run("camera", [_u32(len(rows)), rows], np.float32).reshape(len(rows), 30)
+    return dict(mv=out[:, :9], in_camera_space=out[:, 9:12], camera_to_light=out[:, 12:21], world_to_light=out[:, 21:30])
+
+
+def lighting(osc, light_positions, eye, lookat, mode, points):
+    """LightingEquation<mode>::ComputePixel for rows (inCameraSpace[3], normal[3], material r,g,b, ao)."""
+    lp = np.asarray(light_positions, np.float32).reshape(-1)
+    blobs = scene_blobs(osc) + [_u32(len(lp) // 3), lp, np.array(list(eye) + list(lookat), np.float32), _i32(mode),
+                                _u32(len(points)), np.asarray(points, np.float32)]
+    return _run("lighting", blobs, np.float32).reshape(-1, 3)
+
+
+def mlaa(pixels):
+    h, w = pixels.shape
+    return _run("mlaa", [_i32(w), _i32(h), pixels.astype(np.uint32)], np.uint32).reshape(h, w)
+
+
+def bvh(osc):
+    """CreateBVH + CreateCFBVH of the reference (scalar builder) -> (nodes[n, 8] uint32, tri_idx); small meshes only."""
+    out = _run("bvh", scene_blobs(osc), np.uint32)
+    n, ni = int(out[0]), int(out[1])
+    return out[2:2 + 8 * n].reshape(n, 8).copy(), out[2 + 8 * n:2 + 8 * n + ni].astype(np.int32)

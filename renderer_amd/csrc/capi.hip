@@ -3,6 +3,7 @@
 // There is no CPU rendering path in this library: every mode runs as HIP kernels and every
 // entry point fails (negative return + mi355_last_error) when no HIP device is usable.
 #include "../../include/mi355_render.h"
+#include "dev_math.h"
 #include "dev_scene.h"
 
 #include <hip/hip_runtime.h>
@@ -905,6 +906,44 @@ int mi355_fetch_stats(mi355_ctx *c, mi355_stats *s)
         return fail(-44, "rasterizer span buffer overflowed (%llu rows dropped)%s", h[CS_OVERFLOW],
                     grown ? "; the buffers grow for the next frame" : "");
     }
+    return 0;
+}
+
+// Not part of the public ABI: known-answer test of the device's float arithmetic (tests/test_gpu_parity.py).  Every
+// pixel of every mode rests on these operations rounding exactly like the strict x86-64 build of the reference:
+// out[0..8][i] = a/b, sqrt(a), a*b+c (two roundings: no contraction), a+b, a*b, cvtt_i32(a), myfloor(a), u8cast(a),
+// (float)((double)(a*b)/255.0)
+__global__ void k_float_kat(const float *a, const float *b, const float *c, uint32_t *out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i], y = b[i], z = c[i];
+    out[i] = __float_as_uint(x / y);
+    out[n + i] = __float_as_uint(__builtin_sqrtf(x));
+    out[2 * n + i] = __float_as_uint(x * y + z);
+    out[3 * n + i] = __float_as_uint(x + y);
+    out[4 * n + i] = __float_as_uint(x * y);
+    out[5 * n + i] = (uint32_t)cvtt_i32(x);
+    out[6 * n + i] = (uint32_t)myfloor_i(x);
+    out[7 * n + i] = u8cast(x);
+    out[8 * n + i] = __float_as_uint((float)((double)(x * y) / 255.0));
+}
+
+int mi355i_float_kat(const float *a, const float *b, const float *c, uint32_t *out9n, uint32_t n)
+{
+    if (!a || !b || !c || !out9n || !n) return fail(-3, "mi355i_float_kat: null argument");
+    int ndev = 0;
+    if (int r = mi355_init(0, &ndev)) return r;
+    float *d_in = nullptr; uint32_t *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_in, (size_t)n * 12), -31);
+    HIP_TRY(hipMalloc((void **)&d_out, (size_t)n * 36), -31);
+    HIP_TRY(hipMemcpy(d_in, a, (size_t)n * 4, hipMemcpyHostToDevice), -31);
+    HIP_TRY(hipMemcpy(d_in + n, b, (size_t)n * 4, hipMemcpyHostToDevice), -31);
+    HIP_TRY(hipMemcpy(d_in + 2 * (size_t)n, c, (size_t)n * 4, hipMemcpyHostToDevice), -31);
+    hipLaunchKernelGGL(k_float_kat, dim3((n + 255) / 256), dim3(256), 0, 0, d_in, d_in + n, d_in + 2 * (size_t)n, d_out, n);
+    HIP_TRY(hipGetLastError(), -43);
+    HIP_TRY(hipMemcpy(out9n, d_out, (size_t)n * 36, hipMemcpyDeviceToHost), -31);
+    (void)hipFree(d_in); (void)hipFree(d_out);
     return 0;
 }
 

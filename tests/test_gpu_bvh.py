@@ -1,8 +1,9 @@
 """GPU SAH builder (mi355_build_bvh): the reference's exact tree, byte for byte.
 
 Pins: the `.bvh` hashes of the reference's own scalar builder (tests/golden/reference_pins.json); beyond the three
-shipped meshes the host builder (itself pinned to those hashes on CPU) is the checker, on meshes built to hit the
-order-dependent corners: equal centroids, signed zeros, flat and tiny nodes."""
+shipped meshes the ORACLE's builder is the checker (oracle/oracle.cc, itself compared with the reference's own
+CreateBVH on small soups in tests/test_refcore_pins.py), on meshes built to hit the order-dependent corners: equal
+centroids, signed zeros, flat and tiny nodes.  The host layer's sorted-sweep builder must agree with both."""
 import hashlib
 import json
 import os
@@ -18,6 +19,20 @@ PINS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "referen
 MESHES = ["dragon_vis.ply", "statue.ply", "chessboard.tri"]
 
 
+class OracleTree:
+    """The checker: the oracle's restatement of BVH.cc:96-371 + Raytracer.cc:651-718 on the same file."""
+    def __init__(self, path):
+        from oracle import oracle_ctypes as O
+        self.s = O.Scene(R.assets.oracle_path(os.path.basename(path)) if path.endswith(".3ds") else path)
+        self.s.bvh_build()
+
+    def bvh_arrays(self):
+        return self.s.bvh()
+
+    def bvh_info(self):
+        return (self.s.num_nodes, self.s.nt, self.s.max_depth)
+
+
 def both_builders(path):
     d = R.Scene(path)
     d.bvh_create("device")
@@ -28,20 +43,23 @@ def both_builders(path):
     return d, h
 
 
-def assert_same_tree(d, h):
+def assert_same_tree(d, h, path=None):
+    """device builder == oracle builder (the checker) == host builder"""
+    trees = [("host", h)] + ([("oracle", OracleTree(path))] if path else [])
     dn, di = d.bvh_arrays()
-    hn, hi = h.bvh_arrays()
-    assert dn.shape == hn.shape, "node count %d vs %d" % (dn.shape[0], hn.shape[0])
-    assert np.array_equal(di, hi), "triangle lists differ"
-    bad = np.argwhere((dn != hn).any(axis=1))
-    assert bad.size == 0, "first differing node %d: %s vs %s" % (bad[0, 0], dn[bad[0, 0]], hn[bad[0, 0]])
-    assert d.bvh_info()[2] == h.bvh_info()[2]        # max depth
+    for name, t in trees:
+        hn, hi = t.bvh_arrays()
+        assert dn.shape == hn.shape, "%s: node count %d vs %d" % (name, dn.shape[0], hn.shape[0])
+        assert np.array_equal(di, hi), "%s: triangle lists differ" % name
+        bad = np.argwhere((dn != hn).any(axis=1))
+        assert bad.size == 0, "%s: first differing node %d: %s vs %s" % (name, bad[0, 0], dn[bad[0, 0]], hn[bad[0, 0]])
+        assert d.bvh_info()[2] == t.bvh_info()[2]        # max depth
 
 
 @pytest.mark.parametrize("mesh", MESHES)
 def test_gpu_builder_emits_the_reference_cache_bytes(mesh):
     d, h = both_builders(R.assets.mesh_path(mesh))
-    assert_same_tree(d, h)
+    assert_same_tree(d, h, R.assets.mesh_path(mesh))
     nodes, idx = d.bvh_arrays()
     pin = PINS["bvh"][mesh]
     assert nodes.shape[0] == pin["nodes"]
@@ -53,7 +71,7 @@ def test_gpu_builder_emits_the_reference_cache_bytes(mesh):
 def test_gpu_builder_on_the_3ds_model():
     """legocar.3ds (many small parts, exact-duplicate vertices per face): both builders, same tree."""
     d, h = both_builders(R.assets.mesh_path("legocar.3ds"))
-    assert_same_tree(d, h)
+    assert_same_tree(d, h, R.assets.mesh_path("legocar.3ds"))
 
 
 def write_ply(path, verts, faces):
@@ -97,7 +115,7 @@ def test_gpu_builder_matches_host_builder_on_synthetic_meshes(case, tmp_path):
     p = str(tmp_path / "m.ply")
     write_ply(p, verts, faces)
     d, h = both_builders(p)
-    assert_same_tree(d, h)
+    assert_same_tree(d, h, p)
 
 
 def test_gpu_builder_keeps_the_sign_of_zero_the_reference_keeps(tmp_path):
@@ -116,7 +134,7 @@ def test_gpu_builder_keeps_the_sign_of_zero_the_reference_keeps(tmp_path):
     dn, _ = d.bvh_arrays()
     boxes = dn[:, :6]
     assert ((boxes == 0x80000000).any() or (boxes == 0).any()), "the case is meant to produce zero box coordinates"
-    assert_same_tree(d, h)
+    assert_same_tree(d, h, p)
 
 
 def test_frames_after_a_device_build_match_the_pins():

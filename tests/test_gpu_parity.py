@@ -61,10 +61,46 @@ def assert_same(g, o):
 
 
 def test_device_float_ops_match_host():
-    """IEEE div / sqrt / denormals on gfx950 == host: exercised through a 1-triangle scene's shading would be
-    indirect, so check the library's numbers directly on the camera->ray path of a 3x3 frame."""
-    # (covered implicitly by every bit-exact frame below; this test pins the smallest one)
-    pass
+    """Known answers for the float operations every pixel rests on (SURVEY.md 7 "float parity" / "float->int"): IEEE
+    division and square root, separately rounded multiply-add (no FMA contraction), denormals kept, and the x86
+    cvttss2si casts (out-of-range and NaN -> 0x80000000), on gfx950 against IEEE float32 arithmetic computed on the
+    host (numpy: one correctly rounded operation per call; the casts spelled out as the x86 instruction defines them)."""
+    import ctypes as C
+    rng = np.random.default_rng(99)
+    n = 1 << 18
+    f = np.float32
+    def mix():
+        x = rng.uniform(-1, 1, n) * np.exp2(rng.integers(-149, 128, n).astype(np.float64))
+        x = x.astype(f)
+        edge = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 1.5, 2.5, -2.5, 255.0, 255.5, 256.0, 2147483520.0, 2147483648.0,
+                         -2147483648.0, -2147483904.0, 4294967296.0, 1e-45, -1e-45, 1.1754942e-38, 1.17549435e-38, 3.4028235e38,
+                         np.inf, -np.inf, np.nan, 0.49999997, -0.49999997, 8388607.5, 8388608.0, 16777216.0, 0.1, 1 / 3], f)
+        x[rng.integers(0, n, 4096)] = edge[rng.integers(0, len(edge), 4096)]
+        return x
+    a, b, c = mix(), mix(), mix()
+    a[:n // 4] = np.abs(a[:n // 4]); a[n // 4:n // 2] = rng.uniform(-300, 300, n // 4).astype(f)   # square roots, colour range
+    out = np.zeros((9, n), np.uint32)
+    rc = R.lib().mi355i_float_kat(C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), C.c_void_p(c.ctypes.data),
+                                  C.c_void_p(out.ctypes.data), C.c_uint32(n))
+    assert rc == 0, R.lib().mi355_last_error().decode()
+    with np.errstate(all="ignore"):
+        def cvtt(x):
+            ok = (x >= f(-2147483648.0)) & (x < f(2147483648.0))
+            return np.where(ok, np.trunc(np.where(ok, x, 0)).astype(np.int64), -2147483648).astype(np.int64).astype(np.uint32)
+        prod = a * b
+        want = [a / b, np.sqrt(a), prod + c, a + b, prod]
+        names = ["div", "sqrt", "mul_then_add", "add", "mul"]
+        for k, (w, name) in enumerate(zip(want, names)):
+            got = out[k].view(f)
+            same = (out[k] == w.view(np.uint32)) | (np.isnan(got) & np.isnan(w))
+            assert same.all(), "%s: %d of %d results differ, e.g. %r" % (name, int((~same).sum()), n, (a[~same][0], b[~same][0], c[~same][0]))
+        assert np.array_equal(out[5], cvtt(a)), "cvtt_i32"
+        assert np.array_equal(out[6], cvtt(np.where(a < 0, a - f(0.5), a + f(0.5)).astype(f))), "myfloor"
+        assert np.array_equal(out[7], cvtt(a) & 0xff), "u8cast"
+        w = (prod.astype(np.float64) / 255.0).astype(f)
+        got = out[8].view(f)
+        assert ((out[8] == w.view(np.uint32)) | (np.isnan(got) & np.isnan(w))).all(), "double-promoted division"
+    assert (np.abs(a[np.isfinite(a)]) < 1.1754944e-38).sum() > 1000      # denormal operands were in the mix
 
 
 @pytest.mark.parametrize("pin", PINS["frames"], ids=[p["id"] for p in PINS["frames"]])
