@@ -31,6 +31,8 @@ extern "C" hipError_t mi355i_launch_points(const DevScene *, const FrameParams *
 struct RasterScratch;
 extern "C" hipError_t mi355i_launch_raster(const DevScene *, const FrameParams *, int mode, RasterScratch *,
                                            hipStream_t);
+extern "C" hipError_t mi355i_launch_raster_batch(const DevScene *, const FrameParams *frames, int n_frames, int mode, RasterScratch *,
+                                                 hipStream_t);
 extern "C" hipError_t mi355i_launch_shadowmap(const DevScene *, const float *light_pos, const float *w2l, int size,
                                               float *d_map, RasterScratch *, hipStream_t);
 extern "C" RasterScratch *mi355i_raster_scratch_create(void);
@@ -136,10 +138,6 @@ struct mi355_ctx {
     DevBuf smap[MI355_MAX_LIGHTS];
     int smap_size[MI355_MAX_LIGHTS] = {0, 0, 0, 0};
     RasterScratch *rscratch = nullptr;
-    // batched raster frames: one scratch set and one stream per frame in flight (frame 0 uses rscratch)
-    RasterScratch *rs_batch[MI355_MAX_BATCH] = {};
-    hipStream_t bstream[MI355_MAX_BATCH] = {};
-    hipEvent_t bev_start = nullptr, bev_done[MI355_MAX_BATCH] = {};
     DevScene dev{};
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -632,12 +630,6 @@ void mi355_scene_destroy(mi355_ctx *c)
     for (PinBuf *b : {&c->pin_walk, &c->pin_edge, &c->pin_shade, &c->pin_tree, &c->pin_list, &c->pin_ctl}) b->release();
     for (auto &m : c->smap) m.release();
     if (c->rscratch) mi355i_raster_scratch_destroy(c->rscratch);
-    for (int f = 0; f < MI355_MAX_BATCH; f++) {
-        if (c->rs_batch[f]) mi355i_raster_scratch_destroy(c->rs_batch[f]);
-        if (c->bstream[f]) (void)hipStreamDestroy(c->bstream[f]);
-        if (c->bev_done[f]) (void)hipEventDestroy(c->bev_done[f]);
-    }
-    if (c->bev_start) (void)hipEventDestroy(c->bev_start);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -833,30 +825,20 @@ int mi355_render_batch_device(mi355_ctx *c, int mode, int n_frames, const mi355_
     if (!c || !cams || !o || !d_out || (n_lights > 0 && !lights)) return fail(-3, "mi355_render_batch_device: null argument");
     const bool raster = mode >= MI355_MODE_AMBIENT && mode <= MI355_MODE_PHONG_SOFTSHADOWMAPS;
     if (raster) {
-        // The rasterizer's kernels are a few hundred short waves each: one frame cannot fill the GPU, so the frames of a
-        // batch run side by side, each on its own stream with its own scratch (keys, G-buffer, span records), forked
-        // from and joined to the caller's stream.  Every frame is the frame mi355_render_device produces.
+        // The tiles of all frames of the batch are work items of ONE set of launches (k_raster.hip); every frame is the
+        // frame mi355_render_device produces.
         if (n_frames < 1 || n_frames > MI355_MAX_BATCH) return fail(-21, "n_frames %d outside 1..%d", n_frames, MI355_MAX_BATCH);
         if (o->collect_stats) return fail(-21, "batched frames cannot collect the counters");
         for (int f = 0; f < n_frames; f++) if (!d_out[f]) return fail(-3, "mi355_render_batch_device: frame %d has no output buffer", f);
         if (int r = validate_opts(*o, mode)) return r;
         if (int r = select_device(c)) return r;
         hipStream_t user = (hipStream_t)hip_stream;
-        if (!c->bev_start) HIP_TRY(hipEventCreateWithFlags(&c->bev_start, hipEventDisableTiming), -11);
         HIP_TRY(hipMemsetAsync(c->ctrl.p, 0, 16 + sizeof(unsigned long long) * CS_COUNT, user), -40);
-        HIP_TRY(hipEventRecord(c->bev_start, user), -40);
-        for (int f = 0; f < n_frames; f++) {
-            if (!c->bstream[f]) HIP_TRY(hipStreamCreateWithFlags(&c->bstream[f], hipStreamNonBlocking), -11);
-            if (!c->bev_done[f]) HIP_TRY(hipEventCreateWithFlags(&c->bev_done[f], hipEventDisableTiming), -11);
-            if (!c->rs_batch[f]) { c->rs_batch[f] = mi355i_raster_scratch_create(); if (!c->rs_batch[f]) return fail(-11, "out of memory"); }
-            FrameParams P;
-            if (int r = fill_params(c, mode, &cams[f], lights + (size_t)f * n_lights, n_lights, o, d_out[f], pitch_bytes, nullptr, P)) return r;
-            HIP_TRY(hipStreamWaitEvent(c->bstream[f], c->bev_start, 0), -40);
-            hipError_t e = mi355i_launch_raster(&c->dev, &P, mode, c->rs_batch[f], c->bstream[f]);
-            if (e != hipSuccess) return fail(-43, "kernel launch failed: %s", hipGetErrorString(e));
-            HIP_TRY(hipEventRecord(c->bev_done[f], c->bstream[f]), -40);
-            HIP_TRY(hipStreamWaitEvent(user, c->bev_done[f], 0), -40);
-        }
+        std::vector<FrameParams> frames((size_t)n_frames);
+        for (int f = 0; f < n_frames; f++)
+            if (int r = fill_params(c, mode, &cams[f], lights + (size_t)f * n_lights, n_lights, o, d_out[f], pitch_bytes, nullptr, frames[f])) return r;
+        hipError_t e = mi355i_launch_raster_batch(&c->dev, frames.data(), n_frames, mode, c->rscratch, user);
+        if (e != hipSuccess) return fail(-43, "kernel launch failed: %s", hipGetErrorString(e));
         c->last_stats = false;
         return 0;
     }
@@ -902,8 +884,7 @@ int mi355_fetch_stats(mi355_ctx *c, mi355_stats *s)
     if (h[CS_OVERFLOW]) {
         // the frame is incomplete; the next one gets span buffers twice as large (mi355_render retries by itself)
         const int grown = mi355i_raster_grow(c->rscratch);
-        for (int f = 0; f < MI355_MAX_BATCH; f++) if (c->rs_batch[f]) (void)mi355i_raster_grow(c->rs_batch[f]);
-        return fail(-44, "rasterizer span buffer overflowed (%llu rows dropped)%s", h[CS_OVERFLOW],
+        return fail(-44, "rasterizer triangle bins overflowed (%llu entries dropped)%s", h[CS_OVERFLOW],
                     grown ? "; the buffers grow for the next frame" : "");
     }
     return 0;
