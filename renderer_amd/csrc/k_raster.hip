@@ -25,6 +25,7 @@ struct RasterScratch {
     size_t rec_slots = 0;          // capacity of B.rec / B.box in (frame, triangle) slots
     size_t bin_words = 0;          // capacity of B.count (B.offset has frames more)
     size_t bins_words = 0;         // capacity of B.bins in entries
+    int count_bins = 0, count_frames = 0;   // geometry B.count was last cleared for
     FrameParams *d_frames = nullptr, *h_frames = nullptr; int frames_cap = 0;   // batched launches: per-frame parameters
     hipEvent_t frames_free = nullptr;   // the last batch that read d_frames / h_frames has been enqueued behind this event
     bool frames_pending = false;
@@ -38,6 +39,58 @@ struct RasterScratch {
 namespace {
 
 // ---- shadow-map edge walk: ScanConverter on {x, y, z} fat points, Light.cc:261-296 ------------------------------
+// One edge of the triangle as ScanConverter::ScanConvert / InnerLoop walk it (ScanConverter.h:90-136), advanced scanline
+// by scanline: rows y0..y1 inclusive after clipping (y0 > y1: contributes nothing); a horizontal edge adds both end points.
+template <int N> struct RsEdge {
+    float v[N], d[N];
+    int y0, y1;
+    bool horiz;
+};
+
+template <int N>
+MI_DEV void rs_edge_init(RsEdge<N> &E, int ya, const float (&va)[N], int yb, const float (&vb)[N], int height)
+{
+    E.horiz = false; E.y0 = 1; E.y1 = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) { E.v[i] = 0.f; E.d[i] = 0.f; }
+    if (ya == yb) {
+        if (ya >= 0 && ya < height) { E.horiz = true; E.y0 = E.y1 = ya; }
+        return;
+    }
+    const bool sw = ya > yb;                    // InnerLoop(y1 < y2): walk from the smaller y
+    int y1 = sw ? yb : ya, y2 = sw ? ya : yb;
+    if (y1 < 0 && y2 < 0) return;
+    if (y1 >= height && y2 >= height) return;
+    const float dy = (float)(y2 - y1);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const float a = sw ? vb[i] : va[i], b = sw ? va[i] : vb[i];
+        E.v[i] = a;
+        E.d[i] = (b - a) / dy;
+    }
+    if (y1 < 0) {
+        const float k = (float)-y1;
+#pragma unroll
+        for (int i = 0; i < N; i++) E.v[i] += E.d[i] * k;
+        y1 = 0;
+    }
+    if (height - 1 < y2) y2 = height - 1;
+    E.y0 = y1; E.y1 = y2;
+}
+
+// feed row y with this edge's point(s); advances the walker
+template <int N>
+MI_DEV void rs_edge_row(RsEdge<N> &E, int y, const float (&fa)[N], const float (&fb)[N], float (&l)[N], float (&r)[N], uint32_t &cnt)
+{
+    if (y < E.y0 || y > E.y1) return;
+    if (E.horiz) { scan_add<N>(l, r, cnt, fa); scan_add<N>(l, r, cnt, fb); return; }
+    if (y != E.y0) {
+#pragma unroll
+        for (int i = 0; i < N; i++) E.v[i] += E.d[i];
+    }
+    scan_add<N>(l, r, cnt, E.v);
+}
+
 template <int N>
 MI_DEV void emit_rows(int iy0, int iy1, int iy2, const float (&A)[N], const float (&B)[N], const float (&C)[N],
                       int height, uint32_t tri, RowRec *rows, uint32_t rows_cap, uint32_t *ctl)
@@ -77,13 +130,49 @@ MI_DEV void emit_rows(int iy0, int iy1, int iy2, const float (&A)[N], const floa
 
 // ---------------------------------------------------------------------------------------------
 // Tiled pipeline, modes 4..8 (bodies: rs_core.h)
+
+// One atomic per wave and distinct bin instead of one per lane: neighbouring triangles of a mesh fall into the same
+// coarse bin, and same-address atomics serialise at ~10 ns each device-wide.  Returns the lane's position among the
+// wave's additions to its bin plus the bin's value before the wave's atomic (RET), or nothing.
+template <bool RET>
+MI_DEV uint32_t wave_bin_add(uint32_t *counters, int bin, bool act)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    unsigned long long todo = __ballot(act);
+    uint32_t pos = 0;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lb = __shfl(bin, leader);
+        const unsigned long long same = __ballot(act && bin == lb);
+        uint32_t base = 0;
+        if (lane == leader) {
+            if (RET) base = atomicAdd(&counters[lb], (uint32_t)__popcll(same));
+            else atomicAdd(&counters[lb], (uint32_t)__popcll(same));
+        }
+        if (RET) {
+            base = (uint32_t)__shfl((int)base, leader);
+            if (act && bin == lb) pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        }
+        todo &= ~same;
+    }
+    return pos;
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256) k_rs_setup(const DevScene S, const FrameParams P, const FrameParams *batch, const RsGrid g,
                                                   const RsBuffers B)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
-    if (t >= S.n_tris) return;
-    rs_setup_thread<MODE>(S, batch ? batch[f] : P, g, B, f, t);
+    if (blockIdx.x == 0)                                  // rs_fill's cursors start at zero
+        for (uint32_t i = threadIdx.x; i < (uint32_t)g.n_bins; i += blockDim.x) B.cursor[(size_t)f * g.n_bins + i] = 0u;
+    uint2 box = make_uint2(0xffffffffu, 0u);
+    if (t < S.n_tris) box = rs_setup_thread<MODE>(S, batch ? batch[f] : P, B, f, t);
+    const int nb = box.x == 0xffffffffu ? 0 : rs_bin_count(box);
+    uint32_t *cnt = B.count + (size_t)f * g.n_bins;
+    for (int k = 0; __any(k < nb); k++) {
+        const bool act = k < nb;
+        wave_bin_add<false>(cnt, act ? rs_bin_at(g, box, k) : -1, act);
+    }
 }
 
 // exclusive scan of one frame's bin counts (block f = frame f); offset[n] = the frame's total
@@ -94,7 +183,7 @@ __global__ void __launch_bounds__(1024) k_rs_scan(const RsGrid g, const RsBuffer
     const uint32_t *cnt = B.count + (size_t)f * n;
     uint32_t *off = B.offset + (size_t)f * (n + 1);
     const uint32_t per = (n + 1023u) / 1024u;
-    const uint32_t b = threadIdx.x * per, e = b + per < n ? b + per : n;
+    const uint32_t b = threadIdx.x * per < n ? threadIdx.x * per : n, e = b + per < n ? b + per : n;
     uint32_t s = 0;
     for (uint32_t i = b; i < e; i++) s += cnt[i];
     const int lane = (int)(threadIdx.x & 63u), wid = (int)(threadIdx.x >> 6);
@@ -115,8 +204,21 @@ __global__ void __launch_bounds__(1024) k_rs_scan(const RsGrid g, const RsBuffer
 __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers B, uint32_t n_tris)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
-    if (t >= n_tris) return;
-    rs_fill_thread(g, B, n_tris, f, t);
+    uint2 box = make_uint2(0xffffffffu, 0u);
+    if (t < n_tris) box = B.box[(size_t)f * n_tris + t];
+    const int nb = box.x == 0xffffffffu ? 0 : rs_bin_count(box);
+    uint32_t *cur = B.cursor + (size_t)f * g.n_bins;
+    const uint32_t *off = B.offset + (size_t)f * (g.n_bins + 1);
+    uint4 *bins = B.bins + (size_t)f * B.bins_cap;
+    for (int k = 0; __any(k < nb); k++) {
+        const bool act = k < nb;
+        const int bin = act ? rs_bin_at(g, box, k) : -1;
+        const uint32_t pos = wave_bin_add<true>(cur, bin, act);
+        if (act) {
+            const uint32_t at = off[bin] + pos;
+            if (at < B.bins_cap) bins[at] = make_uint4(t, box.x, box.y, 0u);      // (else: the scan has reported the overflow)
+        }
+    }
 }
 
 template <int MODE>
@@ -124,25 +226,39 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_tile(const DevScene S, const 
                                                         const RsGrid g, const RsBuffers B)
 {
     __shared__ RsTileLds lds;
-    const uint32_t total = (uint32_t)n_frames * (uint32_t)g.n_fine;
     const int tid = (int)threadIdx.x;
+    const uint32_t w = blockIdx.x;
+    const uint32_t f = w % (uint32_t)n_frames, tile = w / (uint32_t)n_frames;
+    const int tx = (int)(tile % (uint32_t)g.tiles_x), ty = (int)(tile / (uint32_t)g.tiles_x);
+    const FrameParams &F = batch ? batch[f] : P;
+    if (tile == 0)                                        // the next frame's rs_setup counts from zero
+        for (uint32_t i = (uint32_t)tid; i < (uint32_t)g.n_bins; i += RS_THREADS) B.count[(size_t)f * g.n_bins + i] = 0u;
+    const RsTileBins L = rs_tile_bins(g, B, f, tx, ty);
+    const uint32_t total = L.total();
+    if (!total) { rs_tile_blank(F, tx, ty, tid); return; }
     unsigned long long ztests = 0, plots = 0;
-    for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
-        const uint32_t f = w % (uint32_t)n_frames, tile = w / (uint32_t)n_frames;
-        const int tx = (int)(tile % (uint32_t)g.tiles_x), ty = (int)(tile / (uint32_t)g.tiles_x);
-        const FrameParams &F = batch ? batch[f] : P;
-        const RsTileList L = rs_tile_list(g, B, f, tx, ty);
-        if (!L.total()) { rs_tile_blank(F, tx, ty, tid); continue; }
-        rs_tile_clear(lds, tid);
+    rs_tile_clear(lds, tid);
+    __syncthreads();
+    bool any = false;
+    int parity = 0;
+    for (uint32_t first = 0; first < total; first += RS_LIST_CAP) {
+        rs_tile_filter(B, f, tx, ty, L, first, lds, tid);
         __syncthreads();
-        rs_tile_walk<MODE, false>(F, g, B, S.n_tris, f, tx, ty, L, lds, tid, ztests);
-        __syncthreads();
-        unsigned long long unused = 0;
-        rs_tile_walk<MODE, true>(F, g, B, S.n_tris, f, tx, ty, L, lds, tid, unused);
-        __syncthreads();
-        rs_tile_shade<MODE>(S, F, tx, ty, lds, tid, plots);
-        __syncthreads();
+        const uint32_t nl = lds.n_list;
+        any = any || nl != 0u;
+        for (uint32_t chunk = 0; chunk < nl; chunk += RS_THREADS) {
+            rs_tile_stage<MODE>(F, B, S.n_tris, f, ty, chunk, nl, parity, lds, tid);
+            __syncthreads();
+            rs_tile_depth<MODE>(F, tx, ty, parity, lds, tid, ztests);
+            if (tid == 0) { lds.n_items[parity ^ 1] = 0u; if (chunk + RS_THREADS >= nl) lds.n_list = 0u; }
+            parity ^= 1;
+            __syncthreads();
+        }
     }
+    if (!any) { rs_tile_blank(F, tx, ty, tid); return; }
+    rs_tile_attr<MODE>(F, B, S.n_tris, f, tx, ty, lds, tid);
+    __syncthreads();
+    rs_tile_shade<MODE>(S, F, tx, ty, lds, tid, plots);
     if (P.counters && P.raster_stats) {
         if (ztests) atomicAdd(&P.counters[CS_ZTESTS], ztests);
         if (plots) atomicAdd(&P.counters[CS_PLOTS], plots);
@@ -229,7 +345,7 @@ extern "C" RasterScratch *mi355i_raster_scratch_create(void) { return new Raster
 extern "C" void mi355i_raster_scratch_destroy(RasterScratch *s)
 {
     if (!s) return;
-    for (void *p : {(void *)s->B.rec, (void *)s->B.box, (void *)s->B.count, (void *)s->B.offset, (void *)s->B.bins, (void *)s->B.ctl,
+    for (void *p : {(void *)s->B.rec, (void *)s->B.box, (void *)s->B.count, (void *)s->B.cursor, (void *)s->B.offset, (void *)s->B.bins,
                     (void *)s->d_frames, (void *)s->rows, (void *)s->ctl, (void *)s->smkeys})
         if (p) (void)hipFree(p);
     if (s->h_frames) (void)hipHostFree(s->h_frames);
@@ -264,33 +380,32 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
     }
     const size_t words = (size_t)n_frames * (size_t)g.n_bins;
     if (words > s->bin_words || !s->B.count) {
-        if (s->B.count) (void)hipFree(s->B.count);
-        if (s->B.offset) (void)hipFree(s->B.offset);
-        s->B.count = nullptr; s->B.offset = nullptr; s->bin_words = 0;
+        for (uint32_t **p : {&s->B.count, &s->B.cursor, &s->B.offset}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        s->bin_words = 0;
         if ((e = hipMalloc((void **)&s->B.count, words * 4)) != hipSuccess) return e;
+        if ((e = hipMalloc((void **)&s->B.cursor, words * 4)) != hipSuccess) return e;
         if ((e = hipMalloc((void **)&s->B.offset, (words + (size_t)n_frames) * 4)) != hipSuccess) return e;
-        // rs_fill leaves every count at zero again: the counts are cleared once, here (on the frame's stream)
-        if ((e = hipMemsetAsync(s->B.count, 0, words * 4, st)) != hipSuccess) return e;
         s->bin_words = words;
     }
-    // Bin entries per frame: six per triangle cover meshes of small triangles (chessboard, dragon: 1.6-2.1 per drawn
-    // triangle) with room to spare, a few screen-filling triangles need one per tile; doubled after an overflow.
-    unsigned long long cap = ((unsigned long long)n_tris * 6ull + (unsigned long long)g.n_fine * 4ull + 4096ull) << s->grow;
-    const unsigned long long worst = (unsigned long long)n_tris * (unsigned long long)(g.n_fine > RS_FINE_MAX ? RS_COARSE_MAX : g.n_fine) + 16ull;
+    // k_rs_tile leaves every count at zero for the next frame of the same geometry; a new geometry (or a frame that was
+    // cut short) starts from a cleared array
+    if (s->count_bins != g.n_bins || s->count_frames != n_frames) {
+        if ((e = hipMemsetAsync(s->B.count, 0, words * 4, st)) != hipSuccess) return e;
+        s->count_bins = g.n_bins; s->count_frames = n_frames;
+    }
+    // Bin entries per frame (16 bytes each): three per triangle cover meshes of small triangles (chessboard, dragon:
+    // 1.2-1.3 coarse bins per drawn triangle) with room to spare; a triangle is in at most RS_COARSE_MAX bins; doubled
+    // after an overflow.
+    unsigned long long cap = ((unsigned long long)n_tris * 3ull + 4096ull) << s->grow;
+    const unsigned long long worst = (unsigned long long)n_tris * (unsigned long long)(g.n_coarse > RS_COARSE_MAX ? RS_COARSE_MAX : g.n_coarse) + 16ull;
     if (cap > worst) cap = worst;
     if (cap > 0x7ffffff0ull) cap = 0x7ffffff0ull;
     if ((size_t)cap * n_frames > s->bins_words || !s->B.bins) {
         if ((e = regrow(s->B.bins, s->bins_words, (size_t)cap * n_frames)) != hipSuccess) return e;
     }
     s->B.bins_cap = (uint32_t)(s->bins_words / (size_t)n_frames < cap ? s->bins_words / (size_t)n_frames : cap);
-    if (!s->B.ctl) {
-        if ((e = hipMalloc((void **)&s->B.ctl, 64)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(s->B.ctl, 0, 64, st)) != hipSuccess) return e;
-    }
     return hipSuccess;
 }
-
-static int g_tile_blocks[16] = {0};      // resident blocks per CU of k_rs_tile<MODE>, by mode
 
 template <int MODE>
 static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const FrameParams *d_batch, int n_frames, RasterScratch *s,
@@ -304,15 +419,8 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     hipLaunchKernelGGL((k_rs_setup<MODE>), per_tri, dim3(256), 0, st, *S, *P, d_batch, g, s->B);
     hipLaunchKernelGGL(k_rs_scan, dim3(n_frames), dim3(1024), 0, st, g, s->B, P->counters);
     hipLaunchKernelGGL(k_rs_fill, per_tri, dim3(256), 0, st, g, s->B, S->n_tris);
-    if (!g_tile_blocks[MODE]) {
-        int nb = 0, dev = 0, cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_rs_tile<MODE>, RS_THREADS, 0) != hipSuccess || nb < 1) nb = 2;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-        g_tile_blocks[MODE] = nb * cus;
-    }
-    long long blocks = (long long)n_frames * g.n_fine;
-    if (blocks > g_tile_blocks[MODE]) blocks = g_tile_blocks[MODE];
+    // one block per tile: the hardware hands tiles to CUs as blocks retire, an empty tile costs one short block
+    const long long blocks = (long long)n_frames * g.n_tiles;
     hipLaunchKernelGGL((k_rs_tile<MODE>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3(RS_THREADS), 0, st, *S, *P, d_batch, n_frames, g, s->B);
     return hipGetLastError();
 }
@@ -441,6 +549,6 @@ extern "C" uint32_t mi355i_raster_overflow(RasterScratch *s)
 extern "C" size_t mi355i_raster_scratch_bytes(const RasterScratch *s)
 {
     if (!s) return 0;
-    return s->rec_slots * (RS_REC4 * sizeof(float4) + sizeof(uint2)) + s->bin_words * 8 + s->bins_words * 4 +
+    return s->rec_slots * (RS_REC4 * sizeof(float4) + sizeof(uint2)) + s->bin_words * 12 + s->bins_words * 16 +
            (size_t)s->rows_cap * sizeof(RowRec) + s->sm_words * 4;
 }

@@ -9,23 +9,24 @@
 // this; the single-thread order is the parity target).  Here that order is a 64-bit key
 // (bits of 1/z << 32 | ~triangle) and the frame is cut into RS_TW x RS_TH pixel tiles whose keys live in LDS:
 //
-//   rs_setup  1 thread / triangle   cull, transform, near reject, project, Filler<>  -> 112-byte record; tile box;
-//                                   per-bin counts
-//   rs_scan   1 block               exclusive scan of the bin counts -> bin offsets
-//   rs_fill   1 thread / triangle   triangle ids into the bins
-//   rs_tile   1 block / tile        depth: every triangle of the tile's bins walks ITS rows of the tile (edge walk and
-//                                   span walk are the reference's serial float chains, entered in the middle through
-//                                   ff_add.h) and does an LDS atomicMax of its keys; attributes: the same walk over all
-//                                   interpolants on the rows where the triangle owns a pixel, winner's fat point into an
-//                                   LDS G-buffer; shade: one thread per pixel, Plot<> / LightingEquation, every pixel of
-//                                   the tile written once (background included: no clear pass)
+//   rs_setup  1 thread / triangle   cull, transform, near reject, project, Filler<>  -> 112-byte record, tile box;
+//                                   counts the triangle into the COARSE bins (64 x 64 pixels) its box touches
+//   rs_fill   1 thread / triangle   scan of the (few) coarse counts, (triangle, box) entries into the coarse bins
+//   rs_tile   1 block / tile        bin : the tile's coarse bin is filtered by box into an LDS list -- the fine binning
+//                                         never leaves the CU;
+//                                   depth: one work item per (triangle, scanline of the tile): the three edges' values
+//                                         on that scanline and the span's value at the tile's first pixel are positions
+//                                         in the reference's serial float chains (`vtc += d12`, `start += dLR`),
+//                                         reached through ff_add.h; LDS atomicMax of the keys;
+//                                   attr : one work item per run of pixels a triangle owns on a scanline: the same
+//                                         evaluation over all interpolants, fat points into an LDS G-buffer;
+//                                   shade: one thread per pixel, Plot<> / LightingEquation; every pixel of the tile is
+//                                         written once, background included (no clear pass, no global depth buffer).
 //
-// Bins are two-level so that no thread loops over many tiles: a triangle whose box covers <= 16 tiles goes into those
-// tiles' bins, a larger one into the bins of the 8x8-tile blocks it covers (<= 64), anything larger into one global bin;
-// a tile reads its own bin, its block's bin and the global bin and rejects what does not touch it.
+// A triangle whose box covers more than RS_COARSE_MAX coarse bins goes into one global bin that every tile filters too.
 //
 // Everything in this header is MI_HD: the same source is compiled for the host by tests/emu (a block = a loop over
-// threads between the kernels' barriers), which runs the CPU test-suite's raster frames against the oracle.
+// threads between the kernels' barriers), which runs raster frames against the oracle in the CPU test-suite.
 #pragma once
 #include "dev_math.h"
 #include "dev_scene.h"
@@ -34,12 +35,12 @@
 #define RS_TW 16              // tile width  (pixels)
 #define RS_TH 16              // tile height (pixels)
 #define RS_TPIX (RS_TW * RS_TH)
-#define RS_CB 8               // a coarse bin covers RS_CB x RS_CB tiles
-#define RS_FINE_MAX 16        // largest tile box binned tile by tile
-#define RS_COARSE_MAX 64      // largest coarse box binned block by block; beyond: the global bin
+#define RS_CB 4               // a coarse bin covers RS_CB x RS_CB tiles
+#define RS_COARSE_MAX 64      // largest coarse box binned bin by bin; beyond: the global bin
 #define RS_REC4 7             // float4 per triangle record
-#define RS_MASK_CAP 1024      // entries per tile whose row masks are kept between the depth and the attribute pass
 #define RS_THREADS 256
+#define RS_LIST_CAP 2048      // bin entries filtered per pass of a tile (LDS list of accepted triangles)
+#define RS_STAGE 10           // dwords staged per triangle of a depth chunk: (projx, 1/z) x 3, iy[3], triangle id
 
 enum { M_AMBIENT = 4, M_GOURAUD = 5, M_PHONG = 6, M_PHONG_SH = 7, M_PHONG_SOFT = 8, M_SHADOWMAP = 100 };
 enum { SH_NONE = 0, SH_HARD = 1, SH_SOFT = 2 };
@@ -50,7 +51,6 @@ template <int MODE> struct FatZ { static const int ZI = (MODE == M_AMBIENT || MO
 // atomics: device instructions, or their sequential meaning when a block is emulated thread by thread on the host
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RS_ATOMIC_ADD_U32(p, v) atomicAdd((p), (v))
-#define RS_ATOMIC_SUB_U32(p, v) atomicSub((p), (v))
 #define RS_ATOMIC_ADD_U64(p, v) atomicAdd((p), (v))
 #define RS_ATOMIC_MAX_U64(p, v) atomicMax((p), (v))
 #else
@@ -58,17 +58,16 @@ MI_HD uint32_t rs_host_add32(uint32_t *p, uint32_t v) { const uint32_t o = *p; *
 MI_HD unsigned long long rs_host_add64(unsigned long long *p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
 MI_HD unsigned long long rs_host_max64(unsigned long long *p, unsigned long long v) { const unsigned long long o = *p; if (v > o) *p = v; return o; }
 #define RS_ATOMIC_ADD_U32(p, v) rs_host_add32((p), (v))
-#define RS_ATOMIC_SUB_U32(p, v) rs_host_add32((p), 0u - (v))
 #define RS_ATOMIC_ADD_U64(p, v) rs_host_add64((p), (v))
 #define RS_ATOMIC_MAX_U64(p, v) rs_host_max64((p), (v))
 #endif
 
-// Geometry of the bins of one frame
+// Geometry of the tiles and bins of one frame
 struct RsGrid {
-    int32_t tiles_x, tiles_y;      // fine tiles
+    int32_t tiles_x, tiles_y;      // tiles
     int32_t cx, cy;                // coarse bins
-    int32_t n_fine, n_coarse;      // tiles_x * tiles_y, cx * cy
-    int32_t n_bins;                // n_fine + n_coarse + 1 (the global bin is the last)
+    int32_t n_tiles, n_coarse;     // tiles_x * tiles_y, cx * cy
+    int32_t n_bins;                // n_coarse + 1 (the global bin is the last)
 };
 
 MI_HD RsGrid rs_grid(int W, int H)
@@ -76,8 +75,8 @@ MI_HD RsGrid rs_grid(int W, int H)
     RsGrid g;
     g.tiles_x = (W + RS_TW - 1) / RS_TW; g.tiles_y = (H + RS_TH - 1) / RS_TH;
     g.cx = (g.tiles_x + RS_CB - 1) / RS_CB; g.cy = (g.tiles_y + RS_CB - 1) / RS_CB;
-    g.n_fine = g.tiles_x * g.tiles_y; g.n_coarse = g.cx * g.cy;
-    g.n_bins = g.n_fine + g.n_coarse + 1;
+    g.n_tiles = g.tiles_x * g.tiles_y; g.n_coarse = g.cx * g.cy;
+    g.n_bins = g.n_coarse + 1;
     return g;
 }
 
@@ -85,11 +84,11 @@ MI_HD RsGrid rs_grid(int W, int H)
 struct RsBuffers {
     float4 *rec;                   // [frames][T][RS_REC4]   fat points A, B, C (8 floats each), iy[3], -
     uint2 *box;                    // [frames][T]            tile box: x = tx0 | tx1 << 16, y = ty0 | ty1 << 16; x = ~0: not drawn
-    uint32_t *count;               // [frames][n_bins]       entries per bin (rs_setup counts up, rs_fill counts down to 0)
-    uint32_t *offset;              // [frames][n_bins + 1]   exclusive scan of a frame's counts
-    uint32_t *bins;                // [frames][bins_cap]     triangle ids
+    uint32_t *count;               // [frames][n_bins]       entries per bin (rs_setup; zeroed again by rs_tile)
+    uint32_t *cursor;              // [frames][n_bins]       entries written so far (rs_fill; zeroed by rs_setup)
+    uint32_t *offset;              // [frames][n_bins + 1]   exclusive scan of a frame's counts (rs_fill)
+    uint4 *bins;                   // [frames][bins_cap]     (triangle, box.x, box.y, -)
     uint32_t bins_cap;             // per frame
-    uint32_t *ctl;                 // [0] entries dropped because bins_cap was too small
 };
 
 // y -> output row, or -1 when the row belongs to another GPU's band
@@ -193,69 +192,88 @@ MI_HD void scan_add(float (&l)[N], float (&r)[N], uint32_t &cnt, const float (&v
     }
 }
 
-// One edge of the triangle as ScanConverter::ScanConvert / InnerLoop walk it (ScanConverter.h:90-136):
-// rows y0..y1 inclusive after clipping (y0 > y1: contributes nothing); a horizontal edge adds both its end points.
-template <int N> struct RsEdge {
-    float v[N], d[N];
-    int y0, y1;
-    bool horiz;
-};
-
+// One edge's point(s) on scanline y, as ScanConverter::ScanConvert / InnerLoop produce them (ScanConverter.h:90-136):
+// the walk starts at the edge's smaller y (after clipping to the frame: `vtc += d12 * (-y1)`) and adds d12 once per
+// scanline -- row y holds the value after (y - first row) serial additions, which ff_add reaches directly.
+// A horizontal edge adds both its end points.
 template <int N>
-MI_HD void rs_edge_init(RsEdge<N> &E, int ya, const float (&va)[N], int yb, const float (&vb)[N], int height)
+MI_HD void rs_edge_at(int ya, const float (&va)[N], int yb, const float (&vb)[N], int height, int y, float (&l)[N], float (&r)[N],
+                      uint32_t &cnt)
 {
-    E.horiz = false; E.y0 = 1; E.y1 = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) { E.v[i] = 0.f; E.d[i] = 0.f; }
     if (ya == yb) {
-        if (ya >= 0 && ya < height) { E.horiz = true; E.y0 = E.y1 = ya; }
+        if (ya == y) { scan_add<N>(l, r, cnt, va); scan_add<N>(l, r, cnt, vb); }      // (y is a row of the frame)
         return;
     }
     const bool sw = ya > yb;                    // InnerLoop(y1 < y2): walk from the smaller y
     int y1 = sw ? yb : ya, y2 = sw ? ya : yb;
     if (y1 < 0 && y2 < 0) return;
     if (y1 >= height && y2 >= height) return;
+    const int first = y1 < 0 ? 0 : y1, last = height - 1 < y2 ? height - 1 : y2;
+    if (y < first || y > last) return;
     const float dy = (float)(y2 - y1);
+    float v[N];
 #pragma unroll
     for (int i = 0; i < N; i++) {
         const float a = sw ? vb[i] : va[i], b = sw ? va[i] : vb[i];
-        E.v[i] = a;
-        E.d[i] = (b - a) / dy;
+        const float d = (b - a) / dy;
+        float x = a;
+        if (y1 < 0) x += d * (float)-y1;
+        v[i] = ff_add(x, d, y - first);
     }
-    if (y1 < 0) {
-        const float k = (float)-y1;
-#pragma unroll
-        for (int i = 0; i < N; i++) E.v[i] += E.d[i] * k;
-        y1 = 0;
-    }
-    if (height - 1 < y2) y2 = height - 1;
-    E.y0 = y1; E.y1 = y2;
+    scan_add<N>(l, r, cnt, v);
 }
 
-// bring the walker to the state it has after feeding row ystart-1: the additions `vtc += d12` of rows y0+1 .. ystart-1
+// Scanline y of a triangle: left / right end points and ScanConverter's lines[y].  Screen.h:239-241: AB, AC, BC.
 template <int N>
-MI_HD void rs_edge_skip(RsEdge<N> &E, int ystart)
+MI_HD uint32_t rs_row_at(const int (&iy)[3], const float (&A)[N], const float (&B)[N], const float (&C)[N], int height, int y,
+                         float (&l)[N], float (&r)[N])
 {
-    if (E.horiz || E.y0 > E.y1) return;
-    int last = ystart - 1;
-    if (last > E.y1) last = E.y1;
-    const int k = last - E.y0;
-    if (k <= 0) return;
+    uint32_t cnt = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) E.v[i] = ff_add(E.v[i], E.d[i], k);
+    for (int i = 0; i < N; i++) { l[i] = 0.f; r[i] = 0.f; }
+    rs_edge_at<N>(iy[0], A, iy[1], B, height, y, l, r, cnt);
+    rs_edge_at<N>(iy[0], A, iy[2], C, height, y, l, r, cnt);
+    rs_edge_at<N>(iy[1], B, iy[2], C, height, y, l, r, cnt);
+    return cnt;
 }
 
-// feed row y with this edge's point(s); advances the walker
-template <int N>
-MI_HD void rs_edge_row(RsEdge<N> &E, int y, const float (&fa)[N], const float (&fb)[N], float (&l)[N], float (&r)[N], uint32_t &cnt)
+// The pixels of a scanline's span, as Screen::RasterizeTriangle clips them (Screen.h:244-279): pixels x1 .. x1 + steps.
+// Interpolant i at pixel x1 + j is   ff_add(l_i [+ dLR_i * clip], dLR_i, j)   with dLR_i = (r_i - l_i) / fsteps;
+// `single`: one pixel holding l itself.  false: nothing of the span lies in the frame.
+struct RsSpan {
+    int x1;
+    int steps;
+    float fsteps, clip;        // clip > 0: the span starts left of the frame, `start += dLR * clip` (Screen.h:268-272)
+    bool single;
+};
+
+MI_HD bool rs_span(float lx, float rx, uint32_t cnt, int W, RsSpan &s)
 {
-    if (y < E.y0 || y > E.y1) return;
-    if (E.horiz) { scan_add<N>(l, r, cnt, fa); scan_add<N>(l, r, cnt, fb); return; }
-    if (y != E.y0) {
-#pragma unroll
-        for (int i = 0; i < N; i++) E.v[i] += E.d[i];
-    }
-    scan_add<N>(l, r, cnt, E.v);
+    s.single = true; s.steps = 0; s.fsteps = 1.f; s.clip = 0.f;
+    if (cnt == 1) { s.x1 = myfloor_i(lx); return s.x1 >= 0 && s.x1 < W; }
+    int x1 = myfloor_i(lx); if (x1 >= W) return false;
+    const int x2 = myfloor_i(rx); if (x2 < 0) return false;
+    // the reference's int arithmetic, kept in 64 bit so degenerate spans cannot overflow
+    long long steps = (long long)x2 - (long long)x1;
+    if (steps < 0) steps = -steps;
+    if (!steps) { s.x1 = x1; return x1 >= 0 && x1 < W; }
+    s.single = false;
+    s.fsteps = (float)(int)steps;
+    if (x1 < 0) { s.clip = (float)-x1; steps -= (-(long long)x1); x1 = 0; }
+    if (x2 >= W) steps -= ((long long)x2 - W + 1);
+    if (steps < 0) return false;
+    if (steps > (long long)(W - 1 - x1)) steps = W - 1 - x1;        // never beyond the frame (unordered end points)
+    s.x1 = x1; s.steps = (int)steps;
+    return true;
+}
+
+// interpolant at pixel s.x1 + j of the span
+MI_HD float rs_span_value(const RsSpan &s, float l, float r, int j, float &dLR)
+{
+    dLR = (r - l) / s.fsteps;
+    float start = l;
+    if (s.clip > 0.f) start += dLR * s.clip;
+    return ff_add(start, dLR, j);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -332,34 +350,40 @@ MI_HD bool rs_tri_rows(const int (&iy)[3], int H, int &miny, int &maxy)
     return miny <= maxy;
 }
 
-// Which bins a tile box goes to: 0 = its tiles' bins, 1 = the coarse bins it covers, 2 = the global bin
-MI_HD int rs_box_class(int tx0, int tx1, int ty0, int ty1)
-{
-    if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= RS_FINE_MAX) return 0;
-    const int cx0 = tx0 / RS_CB, cx1 = tx1 / RS_CB, cy0 = ty0 / RS_CB, cy1 = ty1 / RS_CB;
-    if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) <= RS_COARSE_MAX) return 1;
-    return 2;
-}
-
-// for each bin of the box: fn(bin index within the frame)
+// ---- binning ------------------------------------------------------------------------------------------------------
+// for each bin of a tile box: fn(bin index within the frame)
 template <class F>
 MI_HD void rs_for_bins(const RsGrid &g, uint2 box, F fn)
 {
-    const int tx0 = (int)(box.x & 0xffffu), tx1 = (int)(box.x >> 16), ty0 = (int)(box.y & 0xffffu), ty1 = (int)(box.y >> 16);
-    const int cls = rs_box_class(tx0, tx1, ty0, ty1);
-    if (cls == 0) {
-        for (int ty = ty0; ty <= ty1; ty++)
-            for (int tx = tx0; tx <= tx1; tx++) fn(ty * g.tiles_x + tx);
-    } else if (cls == 1) {
-        for (int cy = ty0 / RS_CB; cy <= ty1 / RS_CB; cy++)
-            for (int cx = tx0 / RS_CB; cx <= tx1 / RS_CB; cx++) fn(g.n_fine + cy * g.cx + cx);
-    } else fn(g.n_fine + g.n_coarse);
+    const int cx0 = (int)(box.x & 0xffffu) / RS_CB, cx1 = (int)(box.x >> 16) / RS_CB;
+    const int cy0 = (int)(box.y & 0xffffu) / RS_CB, cy1 = (int)(box.y >> 16) / RS_CB;
+    if ((cx1 - cx0 + 1) * (cy1 - cy0 + 1) > RS_COARSE_MAX) { fn(g.n_coarse); return; }      // the global bin
+    for (int cy = cy0; cy <= cy1; cy++)
+        for (int cx = cx0; cx <= cx1; cx++) fn(cy * g.cx + cx);
 }
 
-// ---- rs_setup: one thread per (frame, triangle) ---------------------------------------------------------
-// Writes the triangle's record and tile box, counts it into its bins.
+MI_HD int rs_bin_count(uint2 box)
+{
+    const int cx0 = (int)(box.x & 0xffffu) / RS_CB, cx1 = (int)(box.x >> 16) / RS_CB;
+    const int cy0 = (int)(box.y & 0xffffu) / RS_CB, cy1 = (int)(box.y >> 16) / RS_CB;
+    const int n = (cx1 - cx0 + 1) * (cy1 - cy0 + 1);
+    return n > RS_COARSE_MAX ? 1 : n;
+}
+
+// k-th bin of a tile box (k < rs_bin_count)
+MI_HD int rs_bin_at(const RsGrid &g, uint2 box, int k)
+{
+    const int cx0 = (int)(box.x & 0xffffu) / RS_CB, cx1 = (int)(box.x >> 16) / RS_CB;
+    const int cy0 = (int)(box.y & 0xffffu) / RS_CB, cy1 = (int)(box.y >> 16) / RS_CB;
+    const int w = cx1 - cx0 + 1;
+    if (w * (cy1 - cy0 + 1) > RS_COARSE_MAX) return g.n_coarse;
+    return (cy0 + k / w) * g.cx + cx0 + k % w;
+}
+
+// ---- rs_setup: one thread per (frame, triangle) ------------------------------------------------------------------
+// Writes the triangle's record and tile box; returns the box (x = ~0: nothing to bin).  The caller counts it into its bins.
 template <int MODE>
-MI_HD void rs_setup_thread(const DevScene &S, const FrameParams &P, const RsGrid &g, const RsBuffers &B, uint32_t frame, uint32_t t)
+MI_HD uint2 rs_setup_thread(const DevScene &S, const FrameParams &P, const RsBuffers &B, uint32_t frame, uint32_t t)
 {
     constexpr int N = FatN<MODE>::N;
     const size_t slot = (size_t)frame * S.n_tris + t;
@@ -396,7 +420,7 @@ MI_HD void rs_setup_thread(const DevScene &S, const FrameParams &P, const RsGrid
         }
     }
     B.box[slot] = box;
-    if (box.x == 0xffffffffu) return;
+    if (box.x == 0xffffffffu) return box;
     float4 *rec = B.rec + slot * RS_REC4;
     float w[24];
 #pragma unroll
@@ -406,214 +430,167 @@ MI_HD void rs_setup_thread(const DevScene &S, const FrameParams &P, const RsGrid
 #pragma unroll
     for (int q = 0; q < 6; q++) rec[q] = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
     rec[6] = make_float4(ff_u2f((uint32_t)iy[0]), ff_u2f((uint32_t)iy[1]), ff_u2f((uint32_t)iy[2]), 0.f);
-    uint32_t *cnt = B.count + (size_t)frame * g.n_bins;
-    rs_for_bins(g, box, [&](int b) { RS_ATOMIC_ADD_U32(&cnt[b], 1u); });
+    return box;
 }
 
-// ---- rs_fill: one thread per (frame, triangle) ------------------------------------------------------------
-MI_HD void rs_fill_thread(const RsGrid &g, const RsBuffers &B, uint32_t n_tris, uint32_t frame, uint32_t t)
-{
-    const uint2 box = B.box[(size_t)frame * n_tris + t];
-    if (box.x == 0xffffffffu) return;
-    uint32_t *cnt = B.count + (size_t)frame * g.n_bins;
-    const uint32_t *off = B.offset + (size_t)frame * (g.n_bins + 1);
-    uint32_t *bins = B.bins + (size_t)frame * B.bins_cap;
-    rs_for_bins(g, box, [&](int b) {
-        const uint32_t pos = off[b] + (RS_ATOMIC_SUB_U32(&cnt[b], 1u) - 1u);
-        if (pos < B.bins_cap) bins[pos] = t;
-        else RS_ATOMIC_ADD_U32(&B.ctl[0], 1u);
-    });
-}
-
-// ---- rs_tile ------------------------------------------------------------------------------------------------
+// ---- rs_tile ------------------------------------------------------------------------------------------------------
 // LDS of one tile's block
 struct RsTileLds {
     unsigned long long keys[RS_TPIX];          // (bits of 1/z) << 32 | ~triangle, 0 = background
     float gbuf[8][RS_TPIX];                    // winner's interpolants
-    uint32_t rowmask[RS_MASK_CAP];             // per entry: rows of the tile on which it was the best so far at least once
+    uint32_t list[RS_LIST_CAP];                // triangles of the current pass whose box touches the tile
+    uint32_t stage[RS_THREADS][RS_STAGE + 1];  // depth data of the current chunk's triangles (+1: bank spread)
+    uint16_t items[RS_THREADS * RS_TH];        // (chunk slot << 4 | row of the tile) work items of the current chunk
+    uint32_t n_list, n_items[2];               // (two item counters: the idle one is reset while the other is in use)
 };
 
-// The entries of a tile: its own bin, then its block's coarse bin, then the global bin
-struct RsTileList {
-    uint32_t o0, n0, o1, n1, o2, n2;
-    MI_HD uint32_t total() const { return n0 + n1 + n2; }
-    MI_HD uint32_t pos(uint32_t e) const { return e < n0 ? o0 + e : (e < n0 + n1 ? o1 + (e - n0) : o2 + (e - n0 - n1)); }
+// The bins a tile reads: its coarse bin, then the global bin
+struct RsTileBins {
+    uint32_t o0, n0, o1, n1;
+    MI_HD uint32_t total() const { return n0 + n1; }
+    MI_HD uint32_t pos(uint32_t e) const { return e < n0 ? o0 + e : o1 + (e - n0); }
 };
 
-MI_HD RsTileList rs_tile_list(const RsGrid &g, const RsBuffers &B, uint32_t frame, int tx, int ty)
+MI_HD RsTileBins rs_tile_bins(const RsGrid &g, const RsBuffers &B, uint32_t frame, int tx, int ty)
 {
     const uint32_t *off = B.offset + (size_t)frame * (g.n_bins + 1);
-    const int b0 = ty * g.tiles_x + tx, b1 = g.n_fine + (ty / RS_CB) * g.cx + tx / RS_CB, b2 = g.n_fine + g.n_coarse;
-    RsTileList L;
+    const int b0 = (ty / RS_CB) * g.cx + tx / RS_CB, b1 = g.n_coarse;
+    RsTileBins L;
     L.o0 = off[b0]; L.n0 = off[b0 + 1] - L.o0;
     L.o1 = off[b1]; L.n1 = off[b1 + 1] - L.o1;
-    L.o2 = off[b2]; L.n2 = off[b2 + 1] - L.o2;
     // (a bin cut short by bins_cap: the frame reports the overflow; never read beyond the buffer)
     if (L.o0 > B.bins_cap) L.o0 = B.bins_cap;
     if (L.o1 > B.bins_cap) L.o1 = B.bins_cap;
-    if (L.o2 > B.bins_cap) L.o2 = B.bins_cap;
     if (L.n0 > B.bins_cap - L.o0) L.n0 = B.bins_cap - L.o0;
     if (L.n1 > B.bins_cap - L.o1) L.n1 = B.bins_cap - L.o1;
-    if (L.n2 > B.bins_cap - L.o2) L.n2 = B.bins_cap - L.o2;
     return L;
 }
 
-// One entry's walk over its rows of the tile (Screen.h:223-291 restricted to the tile's rectangle).
-//   ATTR = false: interpolants {projx, 1/z}; every fragment does atomicMax on its pixel's key; returns the mask of rows on
-//                 which the entry was the best so far at least once (only those can hold a pixel it owns at the end)
-//   ATTR = true : all N interpolants, only on the rows of `rows`; the fragment whose key IS the pixel's key stores its fat point
-template <int MODE, bool ATTR>
-MI_HD uint32_t rs_walk_entry(const FrameParams &P, const float4 *rec, uint32_t tri, int X0, int Y0, RsTileLds &lds, uint32_t rows,
-                             unsigned long long &ztests)
-{
-    constexpr int N = FatN<MODE>::N;
-    constexpr int ZI = FatZ<MODE>::ZI;
-    constexpr int NW = ATTR ? N : 2;                     // depth pass: projx and 1/z only
-    const int W = P.W, H = P.H;
-    const float4 r6 = rec[6];
-    const int iy[3] = {(int)ff_f2u(r6.x), (int)ff_f2u(r6.y), (int)ff_f2u(r6.z)};
-    int miny, maxy;
-    if (!rs_tri_rows(iy, H, miny, maxy)) return 0u;
-    int ys = miny > Y0 ? miny : Y0, ye = maxy < Y0 + RS_TH - 1 ? maxy : Y0 + RS_TH - 1;
-    if (ys > ye) return 0u;
-    if (ATTR) {                                          // narrow to the rows that can hold a pixel of this entry
-        while (ys <= ye && !((rows >> (ys - Y0)) & 1u)) ys++;
-        while (ye >= ys && !((rows >> (ye - Y0)) & 1u)) ye--;
-        if (ys > ye) return 0u;
-    }
-    const int X1 = (X0 + RS_TW < W ? X0 + RS_TW : W) - 1;
-    float A[NW], Bv[NW], C[NW];
-    {
-        float w[24];
-#pragma unroll
-        for (int q = 0; q < 6; q++) { const float4 v = rec[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
-        if constexpr (ATTR) {
-#pragma unroll
-            for (int i = 0; i < N; i++) { A[i] = w[i]; Bv[i] = w[8 + i]; C[i] = w[16 + i]; }
-        } else {
-            A[0] = w[0]; A[1] = w[ZI]; Bv[0] = w[8]; Bv[1] = w[8 + ZI]; C[0] = w[16]; C[1] = w[16 + ZI];
-        }
-    }
-    constexpr int ZW = ATTR ? ZI : 1;                    // where 1/z sits among the walked interpolants
-    RsEdge<NW> e0, e1, e2;                               // Screen.h:239-241: AB, AC, BC
-    rs_edge_init<NW>(e0, iy[0], A, iy[1], Bv, H);
-    rs_edge_init<NW>(e1, iy[0], A, iy[2], C, H);
-    rs_edge_init<NW>(e2, iy[1], Bv, iy[2], C, H);
-    rs_edge_skip<NW>(e0, ys); rs_edge_skip<NW>(e1, ys); rs_edge_skip<NW>(e2, ys);
-    const unsigned long long trikey = (unsigned long long)(0xffffffffu - tri);
-    uint32_t won = 0u;
-    for (int y = ys; y <= ye; y++) {
-        float l[NW], r[NW];
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int i = 0; i < NW; i++) { l[i] = 0.f; r[i] = 0.f; }
-        rs_edge_row<NW>(e0, y, A, Bv, l, r, cnt);
-        rs_edge_row<NW>(e1, y, A, C, l, r, cnt);
-        rs_edge_row<NW>(e2, y, Bv, C, l, r, cnt);
-        if (!cnt) continue;
-        if (ATTR && !((rows >> (y - Y0)) & 1u)) continue;
-        if (rs_out_row(P, y) < 0) continue;              // another GPU's band
-        const int prow = (y - Y0) * RS_TW - X0;          // pixel index in the tile = prow + x
-
-        auto frag = [&](int x, const float (&v)[NW]) {
-            const float z = v[ZW];
-            if (!(z > 0.f)) return;                      // cannot beat the cleared Z-buffer (Screen.h:209)
-            const unsigned long long key = ((unsigned long long)ff_f2u(z) << 32) | trikey;
-            if constexpr (!ATTR) {
-                if (RS_ATOMIC_MAX_U64(&lds.keys[prow + x], key) < key) won |= 1u << (y - Y0);
-            } else {
-                if (lds.keys[prow + x] != key) return;
-#pragma unroll
-                for (int i = 0; i < N; i++) lds.gbuf[i][prow + x] = v[i];
-            }
-        };
-
-        if (cnt == 1) {
-            const int x = myfloor_i(l[0]);
-            if (x >= 0 && x < W) { if (x >= X0 && x <= X1) { ztests++; frag(x, l); } }
-            continue;
-        }
-        int x1 = myfloor_i(l[0]); if (x1 >= W) continue;
-        const int x2 = myfloor_i(r[0]); if (x2 < 0) continue;
-        // the reference's int arithmetic, kept in 64 bit so degenerate spans cannot overflow
-        long long steps = (long long)x2 - (long long)x1;
-        if (steps < 0) steps = -steps;
-        if (!steps) {
-            if (x1 >= 0 && x1 < W) { if (x1 >= X0 && x1 <= X1) { ztests++; frag(x1, l); } }
-            continue;
-        }
-        // does the span reach this tile at all?  (before the divisions)
-        {
-            const long long first = x1 < 0 ? 0 : x1;
-            long long last = (long long)x1 + steps;      // = max(x1, x2) for an ordered span
-            if (last > W - 1) last = W - 1;
-            if (first > X1 || last < X0) continue;
-        }
-        // (interpolant 0, projx, only orders the edges: x advances by whole pixels)
-        float start[NW], dLR[NW];
-        const float fsteps = (float)(int)steps;
-        start[0] = 0.f; dLR[0] = 0.f;
-#pragma unroll
-        for (int i = 1; i < NW; i++) { start[i] = l[i]; dLR[i] = (r[i] - l[i]) / fsteps; }
-        if (x1 < 0) {
-            const float k = (float)-x1;
-#pragma unroll
-            for (int i = 1; i < NW; i++) start[i] += dLR[i] * k;
-            steps -= (-(long long)x1);
-            x1 = 0;
-        }
-        if (x2 >= W) steps -= ((long long)x2 - W + 1);
-        // the tile's part of the pixels x1 .. x1 + steps: enter the serial `start += dLR` chain (Screen.h:280-287) at
-        // the tile's first pixel
-        long long skip = (long long)X0 - x1;
-        if (skip < 0) skip = 0;
-        if (skip > steps) continue;
-        long long todo = steps - skip;                   // additions left after the first pixel of the tile
-        int x = x1 + (int)skip;
-        if (todo > (long long)(X1 - x)) todo = X1 - x;
-        if (skip > 0) {
-#pragma unroll
-            for (int i = 1; i < NW; i++) start[i] = ff_add(start[i], dLR[i], (int)skip);
-        }
-        if (x < W) { ztests++; frag(x, start); }
-        while (todo-- > 0) {
-            x++;
-#pragma unroll
-            for (int i = 1; i < NW; i++) start[i] += dLR[i];
-            if (x >= W) break;                           // unreachable for left <= right; guards the frame
-            ztests++; frag(x, start);
-        }
-    }
-    return won;
-}
-
-// does the triangle's tile box touch tile (tx, ty)?  (entries of the coarse and global bins)
-MI_HD bool rs_box_touches(uint2 box, int tx, int ty)
-{
-    const int tx0 = (int)(box.x & 0xffffu), tx1 = (int)(box.x >> 16), ty0 = (int)(box.y & 0xffffu), ty1 = (int)(box.y >> 16);
-    return tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1;
-}
-
-// phase 0: clear the tile's keys (thread = pixel)
+// phase 0 (thread = pixel): clear the tile's keys
 MI_HD void rs_tile_clear(RsTileLds &lds, int tid)
 {
     for (int i = tid; i < RS_TPIX; i += RS_THREADS) lds.keys[i] = 0ull;
+    if (tid == 0) { lds.n_list = 0u; lds.n_items[0] = 0u; lds.n_items[1] = 0u; }
 }
 
-// phase 1 / phase 2: thread tid takes entries tid, tid + RS_THREADS, ...
-template <int MODE, bool ATTR>
-MI_HD void rs_tile_walk(const FrameParams &P, const RsGrid &g, const RsBuffers &B, uint32_t n_tris, uint32_t frame, int tx, int ty,
-                        const RsTileList &L, RsTileLds &lds, int tid, unsigned long long &ztests)
+// phase 1: bin entries [first, first + RS_LIST_CAP) of the tile's bins -> LDS list of the triangles whose box touches the tile
+MI_HD void rs_tile_filter(const RsBuffers &B, uint32_t frame, int tx, int ty, const RsTileBins &L, uint32_t first, RsTileLds &lds, int tid)
 {
     const uint32_t n = L.total();
-    for (uint32_t e = (uint32_t)tid; e < n; e += RS_THREADS) {
-        uint32_t rows = 0xffffffffu;
-        if (ATTR && e < RS_MASK_CAP) { rows = lds.rowmask[e]; if (!rows) continue; }
-        const uint32_t tri = B.bins[(size_t)frame * B.bins_cap + L.pos(e)];
-        const size_t slot = (size_t)frame * n_tris + tri;
-        if (e >= L.n0 && !rs_box_touches(B.box[slot], tx, ty)) { if (!ATTR && e < RS_MASK_CAP) lds.rowmask[e] = 0u; continue; }
-        const uint32_t won = rs_walk_entry<MODE, ATTR>(P, B.rec + slot * RS_REC4, tri, tx * RS_TW, ty * RS_TH, lds, rows, ztests);
-        if (!ATTR && e < RS_MASK_CAP) lds.rowmask[e] = won;
+    uint32_t end = first + RS_LIST_CAP;
+    if (end > n) end = n;
+    const uint4 *bins = B.bins + (size_t)frame * B.bins_cap;
+    for (uint32_t e = first + (uint32_t)tid; e < end; e += RS_THREADS) {
+        const uint4 b = bins[L.pos(e)];
+        const int tx0 = (int)(b.y & 0xffffu), tx1 = (int)(b.y >> 16), ty0 = (int)(b.z & 0xffffu), ty1 = (int)(b.z >> 16);
+        if (tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1) lds.list[RS_ATOMIC_ADD_U32(&lds.n_list, 1u)] = b.x;
+    }
+}
+
+// phase 2a (thread = slot of the chunk): triangle `chunk + tid` of the list -> its depth data into LDS, one work item per
+// scanline of the tile it touches
+template <int MODE>
+MI_HD void rs_tile_stage(const FrameParams &P, const RsBuffers &B, uint32_t n_tris, uint32_t frame, int ty, uint32_t chunk, uint32_t n_list,
+                         int parity, RsTileLds &lds, int tid)
+{
+    constexpr int ZI = FatZ<MODE>::ZI;
+    const uint32_t e = chunk + (uint32_t)tid;
+    if (e >= n_list) return;
+    const uint32_t tri = lds.list[e];
+    const float4 *rec = B.rec + ((size_t)frame * n_tris + tri) * RS_REC4;
+    const float4 a = rec[0], b = rec[2], c = rec[4], r6 = rec[6];
+    uint32_t *st = lds.stage[tid];
+    st[0] = ff_f2u(a.x); st[1] = ff_f2u(ZI == 1 ? a.y : a.w);
+    st[2] = ff_f2u(b.x); st[3] = ff_f2u(ZI == 1 ? b.y : b.w);
+    st[4] = ff_f2u(c.x); st[5] = ff_f2u(ZI == 1 ? c.y : c.w);
+    st[6] = ff_f2u(r6.x); st[7] = ff_f2u(r6.y); st[8] = ff_f2u(r6.z);
+    st[9] = tri;
+    const int iy[3] = {(int)st[6], (int)st[7], (int)st[8]};
+    int miny, maxy;
+    if (!rs_tri_rows(iy, P.H, miny, maxy)) return;
+    const int Y0 = ty * RS_TH;
+    const int ys = miny > Y0 ? miny : Y0, ye = maxy < Y0 + RS_TH - 1 ? maxy : Y0 + RS_TH - 1;
+    if (ys > ye) return;
+    const uint32_t base = RS_ATOMIC_ADD_U32(&lds.n_items[parity], (uint32_t)(ye - ys + 1));
+    for (int y = ys; y <= ye; y++) lds.items[base + (uint32_t)(y - ys)] = (uint16_t)(((uint32_t)tid << 4) | (uint32_t)(y - Y0));
+}
+
+// phase 2b: one work item = one scanline of one triangle: Screen.h:244-290 restricted to the tile's columns, depth only
+template <int MODE>
+MI_HD void rs_tile_depth(const FrameParams &P, int tx, int ty, int parity, RsTileLds &lds, int tid, unsigned long long &ztests)
+{
+    const int W = P.W, H = P.H;
+    const int X0 = tx * RS_TW, X1 = (X0 + RS_TW < W ? X0 + RS_TW : W) - 1;
+    const uint32_t n = lds.n_items[parity];
+    for (uint32_t it = (uint32_t)tid; it < n; it += RS_THREADS) {
+        const uint32_t item = lds.items[it];
+        const uint32_t *st = lds.stage[item >> 4];
+        const int row = (int)(item & 15u), y = ty * RS_TH + row;
+        if (rs_out_row(P, y) < 0) continue;              // another GPU's band
+        const float A[2] = {ff_u2f(st[0]), ff_u2f(st[1])}, Bv[2] = {ff_u2f(st[2]), ff_u2f(st[3])}, C[2] = {ff_u2f(st[4]), ff_u2f(st[5])};
+        const int iy[3] = {(int)st[6], (int)st[7], (int)st[8]};
+        float l[2], r[2];
+        const uint32_t cnt = rs_row_at<2>(iy, A, Bv, C, H, y, l, r);
+        if (!cnt) continue;
+        RsSpan s;
+        if (!rs_span(l[0], r[0], cnt, W, s)) continue;
+        int xa = s.x1 > X0 ? s.x1 : X0, xb = s.x1 + s.steps < X1 ? s.x1 + s.steps : X1;
+        if (xa > xb) continue;
+        const unsigned long long trikey = (unsigned long long)(0xffffffffu - st[9]);
+        unsigned long long *krow = lds.keys + row * RS_TW - X0;
+        float d = 0.f, z = l[1];
+        if (!s.single) z = rs_span_value(s, l[1], r[1], xa - s.x1, d);
+        for (int x = xa;; x++) {
+            ztests++;
+            if (z > 0.f)                                 // only 1/z > 0 can beat the cleared Z-buffer (Screen.h:209)
+                RS_ATOMIC_MAX_U64(&krow[x], ((unsigned long long)ff_f2u(z) << 32) | trikey);
+            if (x == xb) break;
+            z += d;
+        }
+    }
+}
+
+// phase 3 (thread = pixel): a thread whose pixel starts a run of pixels of one triangle on its scanline evaluates the
+// scanline over all interpolants and stores the run's fat points
+template <int MODE>
+MI_HD void rs_tile_attr(const FrameParams &P, const RsBuffers &B, uint32_t n_tris, uint32_t frame, int tx, int ty, RsTileLds &lds, int tid)
+{
+    constexpr int N = FatN<MODE>::N;
+    for (int i = tid; i < RS_TPIX; i += RS_THREADS) {
+        const unsigned long long key = lds.keys[i];
+        if (!key) continue;
+        const uint32_t low = (uint32_t)(key & 0xffffffffull);
+        const int px = i % RS_TW, row = i / RS_TW;
+        if (px > 0 && lds.keys[i - 1] && (uint32_t)(lds.keys[i - 1] & 0xffffffffull) == low) continue;   // not the first of its run
+        int len = 1;
+        while (px + len < RS_TW && lds.keys[i + len] && (uint32_t)(lds.keys[i + len] & 0xffffffffull) == low) len++;
+        const uint32_t tri = 0xffffffffu - low;
+        const float4 *rec = B.rec + ((size_t)frame * n_tris + tri) * RS_REC4;
+        float A[N], Bv[N], C[N];
+        {
+            float w[24];
+#pragma unroll
+            for (int q = 0; q < 6; q++) { const float4 v = rec[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+#pragma unroll
+            for (int k = 0; k < N; k++) { A[k] = w[k]; Bv[k] = w[8 + k]; C[k] = w[16 + k]; }
+        }
+        const float4 r6 = rec[6];
+        const int iy[3] = {(int)ff_f2u(r6.x), (int)ff_f2u(r6.y), (int)ff_f2u(r6.z)};
+        const int y = ty * RS_TH + row, x = tx * RS_TW + px;
+        float l[N], r[N];
+        const uint32_t cnt = rs_row_at<N>(iy, A, Bv, C, P.H, y, l, r);
+        RsSpan s;
+        if (!cnt || !rs_span(l[0], r[0], cnt, P.W, s)) continue;            // (cannot happen: the key came from this scanline)
+#pragma unroll
+        for (int k = 1; k < N; k++) {                                        // (interpolant 0, projx, only orders the edges)
+            float d = 0.f, v = l[k];
+            if (!s.single) v = rs_span_value(s, l[k], r[k], x - s.x1, d);
+            for (int j = 0;; j++) {
+                lds.gbuf[k][i + j] = v;
+                if (j == len - 1) break;
+                v += d;
+            }
+        }
     }
 }
 
@@ -628,7 +605,7 @@ MI_HD void rs_tile_blank(const FrameParams &P, int tx, int ty, int tid)
     }
 }
 
-// phase 3: thread = pixel.  Screen::Plot<> (Screen.cc:34-56) for the colour-interpolating modes, IlluminatePixel +
+// phase 4 (thread = pixel): Screen::Plot<> (Screen.cc:34-56) for the colour-interpolating modes, IlluminatePixel +
 // LightingEquation (Screen.cc:77-93, LightingEq.h:45-170) for the Phong modes.  Every pixel of the tile is written.
 template <int MODE>
 MI_HD void rs_tile_shade(const DevScene &S, const FrameParams &P, int tx, int ty, const RsTileLds &lds, int tid, unsigned long long &plots)

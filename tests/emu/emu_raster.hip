@@ -51,8 +51,14 @@ template <int MODE>
 void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, RsBuffers &B)
 {
     const int n_frames = (int)F.size();
-    for (int f = 0; f < n_frames; f++)
-        for (uint32_t t = 0; t < S.n_tris; t++) rs_setup_thread<MODE>(S, F[f], g, B, (uint32_t)f, t);
+    for (int f = 0; f < n_frames; f++) {                       // k_rs_setup
+        for (int b = 0; b < g.n_bins; b++) B.cursor[(size_t)f * g.n_bins + b] = 0u;
+        for (uint32_t t = 0; t < S.n_tris; t++) {
+            const uint2 box = rs_setup_thread<MODE>(S, F[f], B, (uint32_t)f, t);
+            if (box.x == 0xffffffffu) continue;
+            for (int k = 0; k < rs_bin_count(box); k++) B.count[(size_t)f * g.n_bins + rs_bin_at(g, box, k)]++;
+        }
+    }
     for (int f = 0; f < n_frames; f++) {                       // k_rs_scan
         const uint32_t *cnt = B.count + (size_t)f * g.n_bins;
         uint32_t *off = B.offset + (size_t)f * (g.n_bins + 1);
@@ -61,20 +67,46 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
         off[g.n_bins] = run_;
         if (run_ > B.bins_cap && F[0].counters) F[0].counters[CS_OVERFLOW] += run_ - B.bins_cap;
     }
-    for (int f = 0; f < n_frames; f++)
-        for (uint32_t t = 0; t < S.n_tris; t++) rs_fill_thread(g, B, S.n_tris, (uint32_t)f, t);
+    for (int f = 0; f < n_frames; f++)                         // k_rs_fill
+        for (uint32_t t = 0; t < S.n_tris; t++) {
+            const uint2 box = B.box[(size_t)f * S.n_tris + t];
+            if (box.x == 0xffffffffu) continue;
+            for (int k = 0; k < rs_bin_count(box); k++) {
+                const int bin = rs_bin_at(g, box, k);
+                const uint32_t at = B.offset[(size_t)f * (g.n_bins + 1) + bin] + B.cursor[(size_t)f * g.n_bins + bin]++;
+                if (at < B.bins_cap) B.bins[(size_t)f * B.bins_cap + at] = make_uint4(t, box.x, box.y, 0u);
+            }
+        }
     static RsTileLds lds;                                      // the block's LDS
-    for (int f = 0; f < n_frames; f++)
+    for (int f = 0; f < n_frames; f++)                         // k_rs_tile, one block per tile
         for (int ty = 0; ty < g.tiles_y; ty++)
             for (int tx = 0; tx < g.tiles_x; tx++) {
-                const RsTileList L = rs_tile_list(g, B, (uint32_t)f, tx, ty);
-                unsigned long long zt = 0, unused = 0, plots = 0;
-                if (!L.total()) { for (int tid = 0; tid < RS_THREADS; tid++) rs_tile_blank(F[f], tx, ty, tid); continue; }
+                if (tx == 0 && ty == 0) for (int b = 0; b < g.n_bins; b++) B.count[(size_t)f * g.n_bins + b] = 0u;
+                const RsTileBins L = rs_tile_bins(g, B, (uint32_t)f, tx, ty);
+                const uint32_t total = L.total();
+                unsigned long long zt = 0, plots = 0;
+#define ALL_THREADS(stmt) for (int tid = 0; tid < RS_THREADS; tid++) { stmt; }
+#define ALL_THREADS_REVERSED(stmt) for (int tid = RS_THREADS - 1; tid >= 0; tid--) { stmt; }
+                if (!total) { ALL_THREADS(rs_tile_blank(F[f], tx, ty, tid)); continue; }
                 memset(&lds, 0xcd, sizeof lds);                // LDS is not initialised on the device either
-                for (int tid = 0; tid < RS_THREADS; tid++) rs_tile_clear(lds, tid);
-                for (int tid = RS_THREADS - 1; tid >= 0; tid--) rs_tile_walk<MODE, false>(F[f], g, B, S.n_tris, (uint32_t)f, tx, ty, L, lds, tid, zt);   // (any thread order)
-                for (int tid = 0; tid < RS_THREADS; tid++) rs_tile_walk<MODE, true>(F[f], g, B, S.n_tris, (uint32_t)f, tx, ty, L, lds, tid, unused);
-                for (int tid = 0; tid < RS_THREADS; tid++) rs_tile_shade<MODE>(S, F[f], tx, ty, lds, tid, plots);
+                ALL_THREADS(rs_tile_clear(lds, tid));
+                bool any = false;
+                int parity = 0;
+                for (uint32_t first = 0; first < total; first += RS_LIST_CAP) {
+                    ALL_THREADS_REVERSED(rs_tile_filter(B, (uint32_t)f, tx, ty, L, first, lds, tid));      // (any thread order)
+                    const uint32_t nl = lds.n_list;
+                    any = any || nl != 0u;
+                    for (uint32_t chunk = 0; chunk < nl; chunk += RS_THREADS) {
+                        ALL_THREADS_REVERSED(rs_tile_stage<MODE>(F[f], B, S.n_tris, (uint32_t)f, ty, chunk, nl, parity, lds, tid));
+                        ALL_THREADS(rs_tile_depth<MODE>(F[f], tx, ty, parity, lds, tid, zt));
+                        lds.n_items[parity ^ 1] = 0u;
+                        if (chunk + RS_THREADS >= nl) lds.n_list = 0u;
+                        parity ^= 1;
+                    }
+                }
+                if (!any) { ALL_THREADS(rs_tile_blank(F[f], tx, ty, tid)); continue; }
+                ALL_THREADS(rs_tile_attr<MODE>(F[f], B, S.n_tris, (uint32_t)f, tx, ty, lds, tid));
+                ALL_THREADS(rs_tile_shade<MODE>(S, F[f], tx, ty, lds, tid, plots));
                 if (F[0].counters && F[0].raster_stats) { F[0].counters[CS_ZTESTS] += zt; F[0].counters[CS_PLOTS] += plots; }
             }
 }
@@ -99,12 +131,11 @@ extern "C" int emu_raster(uint32_t n_tris, uint32_t n_verts, const float *rs_tri
     const size_t slots = (size_t)n_frames * (n_tris ? n_tris : 1);
     std::vector<float4> rec(slots * RS_REC4);
     std::vector<uint2> box(slots);
-    std::vector<uint32_t> count((size_t)n_frames * g.n_bins, 0u), offset((size_t)n_frames * (g.n_bins + 1), 0u);
-    if (!bins_cap) bins_cap = n_tris * 6u + (uint32_t)g.n_fine * 4u + 4096u;
-    std::vector<uint32_t> bins((size_t)bins_cap * n_frames, 0xdeadbeefu);
-    uint32_t ctl[16] = {0};
+    std::vector<uint32_t> count((size_t)n_frames * g.n_bins, 0u), cursor((size_t)n_frames * g.n_bins, 0xdeadbeefu), offset((size_t)n_frames * (g.n_bins + 1), 0u);
+    if (!bins_cap) bins_cap = n_tris * 3u + 4096u;
+    std::vector<uint4> bins((size_t)bins_cap * n_frames, make_uint4(0xdeadbeefu, 0xdeadbeefu, 0xdeadbeefu, 0u));
     RsBuffers B;
-    B.rec = rec.data(); B.box = box.data(); B.count = count.data(); B.offset = offset.data(); B.bins = bins.data(); B.bins_cap = bins_cap; B.ctl = ctl;
+    B.rec = rec.data(); B.box = box.data(); B.count = count.data(); B.cursor = cursor.data(); B.offset = offset.data(); B.bins = bins.data(); B.bins_cap = bins_cap;
     switch (mode) {
     case M_AMBIENT: run<M_AMBIENT>(S, F, g, B); break;
     case M_GOURAUD: run<M_GOURAUD>(S, F, g, B); break;
@@ -113,7 +144,7 @@ extern "C" int emu_raster(uint32_t n_tris, uint32_t n_verts, const float *rs_tri
     case M_PHONG_SOFT: run<M_PHONG_SOFT>(S, F, g, B); break;
     default: return -1;
     }
-    for (uint32_t c : count) if (c) return -2;                 // rs_fill must leave every count at zero
+    for (uint32_t c : count) if (c) return -2;                 // rs_tile must leave every count at zero
     if (stats4) { stats4[0] = counters[CS_TRIS_DRAWN]; stats4[1] = counters[CS_SPANS]; stats4[2] = counters[CS_ZTESTS]; stats4[3] = counters[CS_PLOTS]; }
     if (overflow) *overflow = counters[CS_OVERFLOW];
     return 0;
