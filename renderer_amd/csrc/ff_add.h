@@ -24,10 +24,14 @@
 MI_HD uint32_t ff_f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 MI_HD float ff_u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 
+#ifndef FF_ADD_LOOP_MAX
+#define FF_ADD_LOOP_MAX 20
+#endif
+
 // x after k times `x = x + d` (round to nearest even, no contraction), k >= 0
 MI_HD float ff_add(float x, const float d, int k)
 {
-    if (k <= 6) {                                   // short chains: the loop is cheaper than the set-up
+    if (k <= FF_ADD_LOOP_MAX) {                     // short chains: the loop is cheaper than the set-up
         for (; k > 0; k--) x = x + d;
         return x;
     }
@@ -64,10 +68,17 @@ MI_HD float ff_add(float x, const float d, int k)
                 const int32_t Qc = Q + (frac ? 1 : 0);          // ceil(q')
                 // steps i = 0..n-1 are exact integer steps while lo <= M_i + q' <= 2^24 (then the rounding unit is u)
                 const int32_t lo = exf > 1 ? 0x800000 : 1;      // lowest binades: stay on this side of zero
-                int32_t n;
-                if (D > 0) n = (0x1000000 - Qc - M) / D + 1;    // M_i + ceil(q') <= 2^24
-                else n = (M + Q - lo) / (-D) + 1;               // M_i + floor(q') >= lo
-                if ((D > 0 && M + Qc > 0x1000000) || (D < 0 && M + Q < lo)) n = 0;
+                const int32_t room = D > 0 ? 0x1000000 - Qc - M         // M_i + ceil(q') <= 2^24
+                                           : M + Q - lo;                // M_i + floor(q') >= lo
+                const int32_t aD = D > 0 ? D : -D;
+                // steps allowed: floor(room / |D|) + 1.  The whole chain at once if it fits (no division at all);
+                // otherwise the float quotient, which is at most one above the integer one (both operands are exact
+                // in float, the division is correctly rounded) -- exactly the "+ 1".
+                int32_t n = 0;
+                if (room >= 0) {
+                    if ((long long)(k - 1) * (long long)aD <= (long long)room) n = k;
+                    else n = (int32_t)((float)room / (float)aD);
+                }
                 if (n > 0) {
                     if (n > k) n = k;
                     M += n * D;

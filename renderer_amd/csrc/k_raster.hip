@@ -158,24 +158,64 @@ MI_DEV uint32_t wave_bin_add(uint32_t *counters, int bin, bool act)
     return pos;
 }
 
+// The (triangle, bin) pairs of a block's 256 triangles, one pair per thread and round: a triangle in many bins does not
+// make its wave loop over them.  pairs.begin() (all threads; syncs), then for (base...) { pair(base + tid, owner, k) }.
+struct BlockPairs {
+    uint32_t pre[257];            // exclusive prefix of the threads' bin counts
+    uint2 box[256];
+    uint32_t wave_tot[4];
+};
+
+MI_DEV uint32_t block_pairs_begin(BlockPairs &bp, uint2 box, int nb)
+{
+    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    bp.box[tid] = box;
+    uint32_t incl = (uint32_t)nb;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) bp.wave_tot[wid] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < wid; w++) before += bp.wave_tot[w];
+    bp.pre[tid] = before + incl - (uint32_t)nb;
+    if (tid == 255) bp.pre[256] = before + incl;
+    __syncthreads();
+    return bp.pre[256];
+}
+
+// pair p (< total): the thread that owns it and the index of the bin within that thread's box
+MI_DEV void block_pair(const BlockPairs &bp, uint32_t p, int &owner, int &k)
+{
+    int lo = 0, hi = 255;                      // largest i with pre[i] <= p (threads with no bins share a prefix: the last wins)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (bp.pre[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    owner = lo; k = (int)(p - bp.pre[lo]);
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256) k_rs_setup(const DevScene S, const FrameParams P, const FrameParams *batch, const RsGrid g,
                                                   const RsBuffers B)
 {
+    __shared__ BlockPairs bp;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
     if (blockIdx.x == 0)                                  // rs_fill's cursors start at zero
         for (uint32_t i = threadIdx.x; i < (uint32_t)g.n_bins; i += blockDim.x) B.cursor[(size_t)f * g.n_bins + i] = 0u;
     uint2 box = make_uint2(0xffffffffu, 0u);
     if (t < S.n_tris) box = rs_setup_thread<MODE>(S, batch ? batch[f] : P, B, f, t);
-    const int nb = box.x == 0xffffffffu ? 0 : rs_bin_count(box);
+    const uint32_t total = block_pairs_begin(bp, box, box.x == 0xffffffffu ? 0 : rs_bin_count(box));
     uint32_t *cnt = B.count + (size_t)f * g.n_bins;
-    for (int k = 0; __any(k < nb); k++) {
-        const bool act = k < nb;
-        wave_bin_add<false>(cnt, act ? rs_bin_at(g, box, k) : -1, act);
+    for (uint32_t base = 0; base < total; base += 256u) {
+        const uint32_t p = base + threadIdx.x;
+        const bool act = p < total;
+        int owner = 0, k = 0;
+        if (act) block_pair(bp, p, owner, k);
+        wave_bin_add<false>(cnt, act ? rs_bin_at(g, bp.box[owner], k) : -1, act);
     }
 }
 
-// exclusive scan of one frame's bin counts (block f = frame f); offset[n] = the frame's total
+// exclusive scan of one frame's bin counts (block f = frame f); offset[n] = the frame's total.  Only for frames with more
+// bins than k_rs_fill scans by itself.
 __global__ void __launch_bounds__(1024) k_rs_scan(const RsGrid g, const RsBuffers B, unsigned long long *counters)
 {
     __shared__ uint32_t wave_tot[16];
@@ -201,22 +241,60 @@ __global__ void __launch_bounds__(1024) k_rs_scan(const RsGrid g, const RsBuffer
     }
 }
 
-__global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers B, uint32_t n_tris)
+#define RS_SCAN_LDS 2048          // frames with at most this many bins (1080p: 511, 4K: 2041): every block of k_rs_fill scans the counts itself
+
+// LDS_SCAN: the bin offsets are the block's own exclusive scan of the frame's counts (block 0 also stores them for
+// k_rs_tile); otherwise they come from k_rs_scan.
+template <bool LDS_SCAN>
+__global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers B, uint32_t n_tris, unsigned long long *counters)
 {
+    __shared__ BlockPairs bp;
+    __shared__ uint32_t soff[LDS_SCAN ? RS_SCAN_LDS + 1 : 1];
+    __shared__ uint32_t stot[4];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t *off = B.offset + (size_t)f * (g.n_bins + 1);
+    if (LDS_SCAN) {
+        const uint32_t n = (uint32_t)g.n_bins, per = (n + 255u) / 256u;      // <= 8 consecutive counts per thread
+        const uint32_t *cnt = B.count + (size_t)f * n;
+        const uint32_t b = (uint32_t)tid * per < n ? (uint32_t)tid * per : n, e = b + per < n ? b + per : n;
+        uint32_t c[(RS_SCAN_LDS + 255) / 256], s = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < (RS_SCAN_LDS + 255) / 256; i++) { c[i] = b + i < e ? cnt[b + i] : 0u; s += c[i]; }
+        uint32_t incl = s;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += v; }
+        if (lane == 63) stot[wid] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (int w = 0; w < 4; w++) { const uint32_t v = stot[w]; if (w < wid) before += v; total += v; }
+        uint32_t run = before + incl - s;
+#pragma unroll
+        for (uint32_t i = 0; i < (RS_SCAN_LDS + 255) / 256; i++) if (b + i < e) { soff[b + i] = run; run += c[i]; }
+        if (tid == 0) soff[n] = total;
+        __syncthreads();
+        if (blockIdx.x == 0) {
+            uint32_t *goff = B.offset + (size_t)f * (n + 1);
+            for (uint32_t i = (uint32_t)tid; i <= n; i += 256u) goff[i] = soff[i];
+            if (tid == 0 && total > B.bins_cap && counters) atomicAdd(&counters[CS_OVERFLOW], (unsigned long long)(total - B.bins_cap));
+        }
+        off = soff;
+    }
     uint2 box = make_uint2(0xffffffffu, 0u);
     if (t < n_tris) box = B.box[(size_t)f * n_tris + t];
-    const int nb = box.x == 0xffffffffu ? 0 : rs_bin_count(box);
+    const uint32_t total = block_pairs_begin(bp, box, box.x == 0xffffffffu ? 0 : rs_bin_count(box));
     uint32_t *cur = B.cursor + (size_t)f * g.n_bins;
-    const uint32_t *off = B.offset + (size_t)f * (g.n_bins + 1);
     uint4 *bins = B.bins + (size_t)f * B.bins_cap;
-    for (int k = 0; __any(k < nb); k++) {
-        const bool act = k < nb;
-        const int bin = act ? rs_bin_at(g, box, k) : -1;
+    for (uint32_t base = 0; base < total; base += 256u) {
+        const uint32_t p = base + (uint32_t)tid;
+        const bool act = p < total;
+        int owner = 0, k = 0;
+        if (act) block_pair(bp, p, owner, k);
+        const uint2 pb = bp.box[owner];
+        const int bin = act ? rs_bin_at(g, pb, k) : -1;
         const uint32_t pos = wave_bin_add<true>(cur, bin, act);
         if (act) {
             const uint32_t at = off[bin] + pos;
-            if (at < B.bins_cap) bins[at] = make_uint4(t, box.x, box.y, 0u);      // (else: the scan has reported the overflow)
+            if (at < B.bins_cap) bins[at] = make_uint4(blockIdx.x * blockDim.x + (uint32_t)owner, pb.x, pb.y, 0u);   // (else: the overflow has been reported)
         }
     }
 }
@@ -256,6 +334,8 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_tile(const DevScene S, const 
         }
     }
     if (!any) { rs_tile_blank(F, tx, ty, tid); return; }
+    rs_tile_runs(lds, tid);
+    __syncthreads();
     rs_tile_attr<MODE>(F, B, S.n_tris, f, tx, ty, lds, tid);
     __syncthreads();
     rs_tile_shade<MODE>(S, F, tx, ty, lds, tid, plots);
@@ -417,8 +497,11 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     const int nbT = (int)((S->n_tris + 255) / 256);
     const dim3 per_tri(nbT > 0 ? nbT : 1, n_frames);
     hipLaunchKernelGGL((k_rs_setup<MODE>), per_tri, dim3(256), 0, st, *S, *P, d_batch, g, s->B);
-    hipLaunchKernelGGL(k_rs_scan, dim3(n_frames), dim3(1024), 0, st, g, s->B, P->counters);
-    hipLaunchKernelGGL(k_rs_fill, per_tri, dim3(256), 0, st, g, s->B, S->n_tris);
+    if (g.n_bins <= RS_SCAN_LDS) hipLaunchKernelGGL(k_rs_fill<true>, per_tri, dim3(256), 0, st, g, s->B, S->n_tris, P->counters);
+    else {
+        hipLaunchKernelGGL(k_rs_scan, dim3(n_frames), dim3(1024), 0, st, g, s->B, P->counters);
+        hipLaunchKernelGGL(k_rs_fill<false>, per_tri, dim3(256), 0, st, g, s->B, S->n_tris, P->counters);
+    }
     // one block per tile: the hardware hands tiles to CUs as blocks retire, an empty tile costs one short block
     const long long blocks = (long long)n_frames * g.n_tiles;
     hipLaunchKernelGGL((k_rs_tile<MODE>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3(RS_THREADS), 0, st, *S, *P, d_batch, n_frames, g, s->B);

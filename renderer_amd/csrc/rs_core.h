@@ -18,8 +18,8 @@
 //                                         on that scanline and the span's value at the tile's first pixel are positions
 //                                         in the reference's serial float chains (`vtc += d12`, `start += dLR`),
 //                                         reached through ff_add.h; LDS atomicMax of the keys;
-//                                   attr : one work item per run of pixels a triangle owns on a scanline: the same
-//                                         evaluation over all interpolants, fat points into an LDS G-buffer;
+//                                   attr : one work item per (run of pixels a triangle owns on a scanline, interpolant):
+//                                         the same evaluation, fat points into an LDS G-buffer;
 //                                   shade: one thread per pixel, Plot<> / LightingEquation; every pixel of the tile is
 //                                         written once, background included (no clear pass, no global depth buffer).
 //
@@ -442,6 +442,7 @@ struct RsTileLds {
     uint32_t stage[RS_THREADS][RS_STAGE + 1];  // depth data of the current chunk's triangles (+1: bank spread)
     uint16_t items[RS_THREADS * RS_TH];        // (chunk slot << 4 | row of the tile) work items of the current chunk
     uint32_t n_list, n_items[2];               // (two item counters: the idle one is reset while the other is in use)
+    uint32_t n_runs;
 };
 
 // The bins a tile reads: its coarse bin, then the global bin
@@ -470,7 +471,7 @@ MI_HD RsTileBins rs_tile_bins(const RsGrid &g, const RsBuffers &B, uint32_t fram
 MI_HD void rs_tile_clear(RsTileLds &lds, int tid)
 {
     for (int i = tid; i < RS_TPIX; i += RS_THREADS) lds.keys[i] = 0ull;
-    if (tid == 0) { lds.n_list = 0u; lds.n_items[0] = 0u; lds.n_items[1] = 0u; }
+    if (tid == 0) { lds.n_list = 0u; lds.n_items[0] = 0u; lds.n_items[1] = 0u; lds.n_runs = 0u; }
 }
 
 // phase 1: bin entries [first, first + RS_LIST_CAP) of the tile's bins -> LDS list of the triangles whose box touches the tile
@@ -550,46 +551,49 @@ MI_HD void rs_tile_depth(const FrameParams &P, int tx, int ty, int parity, RsTil
     }
 }
 
-// phase 3 (thread = pixel): a thread whose pixel starts a run of pixels of one triangle on its scanline evaluates the
-// scanline over all interpolants and stores the run's fat points
-template <int MODE>
-MI_HD void rs_tile_attr(const FrameParams &P, const RsBuffers &B, uint32_t n_tris, uint32_t frame, int tx, int ty, RsTileLds &lds, int tid)
+// phase 3a (thread = pixel): list the runs of pixels one triangle owns on a scanline (pixel of the first | length - 1 << 8)
+MI_HD void rs_tile_runs(RsTileLds &lds, int tid)
 {
-    constexpr int N = FatN<MODE>::N;
     for (int i = tid; i < RS_TPIX; i += RS_THREADS) {
         const unsigned long long key = lds.keys[i];
         if (!key) continue;
         const uint32_t low = (uint32_t)(key & 0xffffffffull);
-        const int px = i % RS_TW, row = i / RS_TW;
+        const int px = i % RS_TW;
         if (px > 0 && lds.keys[i - 1] && (uint32_t)(lds.keys[i - 1] & 0xffffffffull) == low) continue;   // not the first of its run
         int len = 1;
         while (px + len < RS_TW && lds.keys[i + len] && (uint32_t)(lds.keys[i + len] & 0xffffffffull) == low) len++;
-        const uint32_t tri = 0xffffffffu - low;
-        const float4 *rec = B.rec + ((size_t)frame * n_tris + tri) * RS_REC4;
-        float A[N], Bv[N], C[N];
-        {
-            float w[24];
-#pragma unroll
-            for (int q = 0; q < 6; q++) { const float4 v = rec[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
-#pragma unroll
-            for (int k = 0; k < N; k++) { A[k] = w[k]; Bv[k] = w[8 + k]; C[k] = w[16 + k]; }
-        }
-        const float4 r6 = rec[6];
-        const int iy[3] = {(int)ff_f2u(r6.x), (int)ff_f2u(r6.y), (int)ff_f2u(r6.z)};
+        lds.items[RS_ATOMIC_ADD_U32(&lds.n_runs, 1u)] = (uint16_t)((uint32_t)i | ((uint32_t)(len - 1) << 8));
+    }
+}
+
+// phase 3b: one work item = one interpolant of one run: the scanline's end points for {projx, interpolant} (projx orders
+// the edges), the span's value at the run's first pixel, then the run -- the same evaluation as the depth pass
+template <int MODE>
+MI_HD void rs_tile_attr(const FrameParams &P, const RsBuffers &B, uint32_t n_tris, uint32_t frame, int tx, int ty, RsTileLds &lds, int tid)
+{
+    constexpr int N = FatN<MODE>::N;
+    const uint32_t n = lds.n_runs * (uint32_t)(N - 1);
+    for (uint32_t it = (uint32_t)tid; it < n; it += RS_THREADS) {
+        const uint32_t run = lds.items[it / (uint32_t)(N - 1)];
+        const int k = 1 + (int)(it % (uint32_t)(N - 1));          // (interpolant 0, projx, is not an attribute)
+        const int i = (int)(run & 255u), len = (int)(run >> 8) + 1;
+        const int px = i % RS_TW, row = i / RS_TW;
+        const uint32_t tri = 0xffffffffu - (uint32_t)(lds.keys[i] & 0xffffffffull);
+        const float *rec = (const float *)(B.rec + ((size_t)frame * n_tris + tri) * RS_REC4);
+        const float A[2] = {rec[0], rec[k]}, Bv[2] = {rec[8], rec[8 + k]}, C[2] = {rec[16], rec[16 + k]};
+        const int iy[3] = {(int)ff_f2u(rec[24]), (int)ff_f2u(rec[25]), (int)ff_f2u(rec[26])};
         const int y = ty * RS_TH + row, x = tx * RS_TW + px;
-        float l[N], r[N];
-        const uint32_t cnt = rs_row_at<N>(iy, A, Bv, C, P.H, y, l, r);
+        float l[2], r[2];
+        const uint32_t cnt = rs_row_at<2>(iy, A, Bv, C, P.H, y, l, r);
         RsSpan s;
         if (!cnt || !rs_span(l[0], r[0], cnt, P.W, s)) continue;            // (cannot happen: the key came from this scanline)
-#pragma unroll
-        for (int k = 1; k < N; k++) {                                        // (interpolant 0, projx, only orders the edges)
-            float d = 0.f, v = l[k];
-            if (!s.single) v = rs_span_value(s, l[k], r[k], x - s.x1, d);
-            for (int j = 0;; j++) {
-                lds.gbuf[k][i + j] = v;
-                if (j == len - 1) break;
-                v += d;
-            }
+        float d = 0.f, v = l[1];
+        if (!s.single) v = rs_span_value(s, l[1], r[1], x - s.x1, d);
+        float *g = lds.gbuf[k] + i;
+        for (int j = 0;; j++) {
+            g[j] = v;
+            if (j == len - 1) break;
+            v += d;
         }
     }
 }

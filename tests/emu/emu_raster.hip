@@ -105,6 +105,7 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
                     }
                 }
                 if (!any) { ALL_THREADS(rs_tile_blank(F[f], tx, ty, tid)); continue; }
+                ALL_THREADS_REVERSED(rs_tile_runs(lds, tid));
                 ALL_THREADS(rs_tile_attr<MODE>(F[f], B, S.n_tris, (uint32_t)f, tx, ty, lds, tid));
                 ALL_THREADS(rs_tile_shade<MODE>(S, F[f], tx, ty, lds, tid, plots));
                 if (F[0].counters && F[0].raster_stats) { F[0].counters[CS_ZTESTS] += zt; F[0].counters[CS_PLOTS] += plots; }
