@@ -139,23 +139,28 @@ MI_DEV uint32_t wave_bin_add(uint32_t *counters, int bin, bool act)
 {
     const int lane = (int)(threadIdx.x & 63u);
     unsigned long long todo = __ballot(act);
-    uint32_t pos = 0;
-    while (todo) {
+    int my_leader = lane;
+    uint32_t my_rank = 0, my_cnt = 0;
+    while (todo) {                               // (no memory operation in here: one trip per distinct bin of the wave)
         const int leader = __ffsll((long long)todo) - 1;
         const int lb = __shfl(bin, leader);
         const unsigned long long same = __ballot(act && bin == lb);
-        uint32_t base = 0;
-        if (lane == leader) {
-            if (RET) base = atomicAdd(&counters[lb], (uint32_t)__popcll(same));
-            else atomicAdd(&counters[lb], (uint32_t)__popcll(same));
-        }
-        if (RET) {
-            base = (uint32_t)__shfl((int)base, leader);
-            if (act && bin == lb) pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        if (act && bin == lb) {
+            my_leader = leader;
+            my_rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            my_cnt = (uint32_t)__popcll(same);
         }
         todo &= ~same;
     }
-    return pos;
+    // every leader's atomic in ONE instruction: one round trip for the whole wave, not one per bin
+    uint32_t base = 0;
+    if (act && lane == my_leader) {
+        if (RET) base = atomicAdd(&counters[bin], my_cnt);
+        else atomicAdd(&counters[bin], my_cnt);
+    }
+    if (!RET) return 0u;
+    base = (uint32_t)__shfl((int)base, my_leader);
+    return base + my_rank;
 }
 
 // The (triangle, bin) pairs of a block's 256 triangles, one pair per thread and round: a triangle in many bins does not
@@ -299,6 +304,13 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
     }
 }
 
+// Phase profile of counting frames (collect_stats): sums over the blocks of the cycles between the barriers, into the
+// counters behind CS_PROF0: [0] bins + clear, [1] filter, [2] stage, [3] depth, [4] runs, [5] attributes, [6] shade,
+// [7] whole block, [8] blocks with entries, [9] longest block, [10] triangles kept by the filters, [11] depth items,
+// [12] runs, [13] bin entries read.
+#define RS_PROF_MARK(i) do { if (prof) { __syncthreads(); if (tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
+    atomicAdd(&P.counters[CS_PROF0 + (i)], now_ - t_mark); t_mark = now_; } } } while (0)
+
 template <int MODE>
 __global__ void __launch_bounds__(RS_THREADS) k_rs_tile(const DevScene S, const FrameParams P, const FrameParams *batch, int n_frames,
                                                         const RsGrid g, const RsBuffers B)
@@ -309,6 +321,9 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_tile(const DevScene S, const 
     const uint32_t f = w % (uint32_t)n_frames, tile = w / (uint32_t)n_frames;
     const int tx = (int)(tile % (uint32_t)g.tiles_x), ty = (int)(tile / (uint32_t)g.tiles_x);
     const FrameParams &F = batch ? batch[f] : P;
+    const bool prof = P.counters && P.raster_stats;
+    unsigned long long t_mark = prof ? __builtin_readcyclecounter() : 0ull;
+    const unsigned long long t_begin = t_mark;
     if (tile == 0)                                        // the next frame's rs_setup counts from zero
         for (uint32_t i = (uint32_t)tid; i < (uint32_t)g.n_bins; i += RS_THREADS) B.count[(size_t)f * g.n_bins + i] = 0u;
     const RsTileBins L = rs_tile_bins(g, B, f, tx, ty);
@@ -317,31 +332,48 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_tile(const DevScene S, const 
     unsigned long long ztests = 0, plots = 0;
     rs_tile_clear(lds, tid);
     __syncthreads();
+    RS_PROF_MARK(0);
     bool any = false;
     int parity = 0;
     for (uint32_t first = 0; first < total; first += RS_LIST_CAP) {
         rs_tile_filter(B, f, tx, ty, L, first, lds, tid);
         __syncthreads();
+        RS_PROF_MARK(1);
         const uint32_t nl = lds.n_list;
         any = any || nl != 0u;
+        if (prof && tid == 0) atomicAdd(&P.counters[CS_PROF0 + 10], (unsigned long long)nl);
         for (uint32_t chunk = 0; chunk < nl; chunk += RS_THREADS) {
             rs_tile_stage<MODE>(F, B, S.n_tris, f, ty, chunk, nl, parity, lds, tid);
             __syncthreads();
+            RS_PROF_MARK(2);
+            if (prof && tid == 0) atomicAdd(&P.counters[CS_PROF0 + 11], (unsigned long long)lds.n_items[parity]);
             rs_tile_depth<MODE>(F, tx, ty, parity, lds, tid, ztests);
             if (tid == 0) { lds.n_items[parity ^ 1] = 0u; if (chunk + RS_THREADS >= nl) lds.n_list = 0u; }
             parity ^= 1;
             __syncthreads();
+            RS_PROF_MARK(3);
         }
     }
+    if (prof && tid == 0) atomicAdd(&P.counters[CS_PROF0 + 13], (unsigned long long)total);
     if (!any) { rs_tile_blank(F, tx, ty, tid); return; }
     rs_tile_runs(lds, tid);
     __syncthreads();
+    RS_PROF_MARK(4);
+    if (prof && tid == 0) atomicAdd(&P.counters[CS_PROF0 + 12], (unsigned long long)lds.n_runs);
     rs_tile_attr<MODE>(F, B, S.n_tris, f, tx, ty, lds, tid);
     __syncthreads();
+    RS_PROF_MARK(5);
     rs_tile_shade<MODE>(S, F, tx, ty, lds, tid, plots);
-    if (P.counters && P.raster_stats) {
+    RS_PROF_MARK(6);
+    if (prof) {
         if (ztests) atomicAdd(&P.counters[CS_ZTESTS], ztests);
         if (plots) atomicAdd(&P.counters[CS_PLOTS], plots);
+        if (tid == 0) {
+            const unsigned long long dt = __builtin_readcyclecounter() - t_begin;
+            atomicAdd(&P.counters[CS_PROF0 + 7], dt);
+            atomicAdd(&P.counters[CS_PROF0 + 8], 1ull);
+            atomicMax(&P.counters[CS_PROF0 + 9], dt);
+        }
     }
 }
 
