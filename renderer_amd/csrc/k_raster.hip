@@ -26,6 +26,8 @@ struct RasterScratch {
     size_t bin_words = 0;          // capacity of B.count (B.offset has frames more)
     size_t bins_words = 0;         // capacity of B.bins in entries
     int count_bins = 0, count_frames = 0;   // geometry B.count was last cleared for
+    size_t band_words = 0;         // capacity of B.band in records
+    int band_frames = 0;
     FrameParams *d_frames = nullptr, *h_frames = nullptr; int frames_cap = 0;   // batched launches: per-frame parameters
     hipEvent_t frames_free = nullptr;   // the last batch that read d_frames / h_frames has been enqueued behind this event
     bool frames_pending = false;
@@ -217,6 +219,26 @@ __global__ void __launch_bounds__(256) k_rs_setup(const DevScene S, const FrameP
         if (act) block_pair(bp, p, owner, k);
         wave_bin_add<false>(cnt, act ? rs_bin_at(g, bp.box[owner], k) : -1, act);
     }
+    // band records: one (triangle, tile row, edge) per thread and round; the block's records are one allocation
+    __shared__ uint32_t band_base;
+    __syncthreads();                                      // (bp is reused)
+    const uint32_t n_edges = block_pairs_begin(bp, box, 3 * rs_band_count(box));
+    if (threadIdx.x == 0) {
+        band_base = n_edges ? atomicAdd(&B.band_top[f], n_edges / 3u) : 0u;
+        if (n_edges && band_base + n_edges / 3u > B.band_cap && P.counters) atomicAdd(&P.counters[CS_OVERFLOW], 1ull);
+    }
+    __syncthreads();
+    const uint32_t my_base = band_base + bp.pre[threadIdx.x] / 3u;
+    if (box.x != 0xffffffffu) rs_set_band_base(B, S.n_tris, f, t, my_base);
+    __syncthreads();                                      // the records' float data and bases are read back below (same block)
+    const int H = (batch ? batch[f] : P).H;
+    for (uint32_t base = 0; base < n_edges; base += 256u) {
+        const uint32_t p = base + threadIdx.x;
+        if (p >= n_edges) break;
+        int owner = 0, k = 0;
+        block_pair(bp, p, owner, k);
+        rs_band_fill(B, S.n_tris, f, blockIdx.x * blockDim.x + (uint32_t)owner, band_base + bp.pre[owner] / 3u, k / 3, k % 3, H);
+    }
 }
 
 // exclusive scan of one frame's bin counts (block f = frame f); offset[n] = the frame's total.  Only for frames with more
@@ -324,8 +346,10 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_tile(const DevScene S, const 
     const bool prof = P.counters && P.raster_stats;
     unsigned long long t_mark = prof ? __builtin_readcyclecounter() : 0ull;
     const unsigned long long t_begin = t_mark;
-    if (tile == 0)                                        // the next frame's rs_setup counts from zero
+    if (tile == 0) {                                      // the next frame's rs_setup counts from zero
         for (uint32_t i = (uint32_t)tid; i < (uint32_t)g.n_bins; i += RS_THREADS) B.count[(size_t)f * g.n_bins + i] = 0u;
+        if (tid == 0) B.band_top[f] = 0u;
+    }
     const RsTileBins L = rs_tile_bins(g, B, f, tx, ty);
     const uint32_t total = L.total();
     if (!total) { rs_tile_blank(F, tx, ty, tid); return; }
@@ -347,7 +371,7 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_tile(const DevScene S, const 
             __syncthreads();
             RS_PROF_MARK(2);
             if (prof && tid == 0) atomicAdd(&P.counters[CS_PROF0 + 11], (unsigned long long)lds.n_items[parity]);
-            rs_tile_depth<MODE>(F, tx, ty, parity, lds, tid, ztests);
+            rs_tile_depth<MODE>(F, B, S.n_tris, f, tx, ty, parity, lds, tid, ztests);
             if (tid == 0) { lds.n_items[parity ^ 1] = 0u; if (chunk + RS_THREADS >= nl) lds.n_list = 0u; }
             parity ^= 1;
             __syncthreads();
@@ -457,7 +481,7 @@ extern "C" RasterScratch *mi355i_raster_scratch_create(void) { return new Raster
 extern "C" void mi355i_raster_scratch_destroy(RasterScratch *s)
 {
     if (!s) return;
-    for (void *p : {(void *)s->B.rec, (void *)s->B.box, (void *)s->B.count, (void *)s->B.cursor, (void *)s->B.offset, (void *)s->B.bins,
+    for (void *p : {(void *)s->B.rec, (void *)s->B.box, (void *)s->B.count, (void *)s->B.cursor, (void *)s->B.offset, (void *)s->B.bins, (void *)s->B.band, (void *)s->B.band_top,
                     (void *)s->d_frames, (void *)s->rows, (void *)s->ctl, (void *)s->smkeys})
         if (p) (void)hipFree(p);
     if (s->h_frames) (void)hipHostFree(s->h_frames);
@@ -503,6 +527,7 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
     // cut short) starts from a cleared array
     if (s->count_bins != g.n_bins || s->count_frames != n_frames) {
         if ((e = hipMemsetAsync(s->B.count, 0, words * 4, st)) != hipSuccess) return e;
+        if (s->B.band_top && (e = hipMemsetAsync(s->B.band_top, 0, (size_t)s->band_frames * 4, st)) != hipSuccess) return e;
         s->count_bins = g.n_bins; s->count_frames = n_frames;
     }
     // Bin entries per frame (16 bytes each): three per triangle cover meshes of small triangles (chessboard, dragon:
@@ -516,6 +541,26 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
         if ((e = regrow(s->B.bins, s->bins_words, (size_t)cap * n_frames)) != hipSuccess) return e;
     }
     s->B.bins_cap = (uint32_t)(s->bins_words / (size_t)n_frames < cap ? s->bins_words / (size_t)n_frames : cap);
+    // Band records per frame (192 bytes each): one per tile row a drawn triangle touches -- two per triangle cover meshes
+    // of small triangles (chessboard, dragon: ~1.4 per DRAWN triangle, half of the triangles face away); doubled after an overflow.
+    unsigned long long bcap = ((unsigned long long)n_tris * 2ull + 8192ull) << s->grow;
+    const unsigned long long bworst = (unsigned long long)n_tris * (unsigned long long)g.tiles_y + 16ull;
+    if (bcap > bworst) bcap = bworst;
+    if (bcap > 0x3ffffff0ull) bcap = 0x3ffffff0ull;
+    if ((size_t)bcap * n_frames > s->band_words || !s->B.band) {
+        if (s->B.band) (void)hipFree(s->B.band);
+        s->B.band = nullptr; s->band_words = 0;
+        if ((e = hipMalloc((void **)&s->B.band, (size_t)bcap * n_frames * RS_BAND4 * sizeof(float4))) != hipSuccess) return e;
+        s->band_words = (size_t)bcap * n_frames;
+    }
+    s->B.band_cap = (uint32_t)(s->band_words / (size_t)n_frames < bcap ? s->band_words / (size_t)n_frames : bcap);
+    if (n_frames > s->band_frames || !s->B.band_top) {
+        if (s->B.band_top) (void)hipFree(s->B.band_top);
+        s->B.band_top = nullptr; s->band_frames = 0;
+        if ((e = hipMalloc((void **)&s->B.band_top, (size_t)n_frames * 4)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(s->B.band_top, 0, (size_t)n_frames * 4, st)) != hipSuccess) return e;
+        s->band_frames = n_frames;
+    }
     return hipSuccess;
 }
 
@@ -664,6 +709,6 @@ extern "C" uint32_t mi355i_raster_overflow(RasterScratch *s)
 extern "C" size_t mi355i_raster_scratch_bytes(const RasterScratch *s)
 {
     if (!s) return 0;
-    return s->rec_slots * (RS_REC4 * sizeof(float4) + sizeof(uint2)) + s->bin_words * 12 + s->bins_words * 16 +
+    return s->rec_slots * (RS_REC4 * sizeof(float4) + sizeof(uint2)) + s->bin_words * 12 + s->bins_words * 16 + s->band_words * RS_BAND4 * sizeof(float4) +
            (size_t)s->rows_cap * sizeof(RowRec) + s->sm_words * 4;
 }

@@ -40,7 +40,8 @@
 #define RS_REC4 7             // float4 per triangle record
 #define RS_THREADS 256
 #define RS_LIST_CAP 2048      // bin entries filtered per pass of a tile (LDS list of accepted triangles)
-#define RS_STAGE 10           // dwords staged per triangle of a depth chunk: (projx, 1/z) x 3, iy[3], triangle id
+#define RS_STAGE 5            // dwords staged per triangle of a depth chunk: iy[3], first band record, triangle id
+#define RS_BAND4 12           // float4 per band record: 3 edges x 8 interpolants x (value, step), interpolants 2j, 2j+1 in one float4
 
 enum { M_AMBIENT = 4, M_GOURAUD = 5, M_PHONG = 6, M_PHONG_SH = 7, M_PHONG_SOFT = 8, M_SHADOWMAP = 100 };
 enum { SH_NONE = 0, SH_HARD = 1, SH_SOFT = 2 };
@@ -89,6 +90,9 @@ struct RsBuffers {
     uint32_t *offset;              // [frames][n_bins + 1]   exclusive scan of a frame's counts (rs_fill)
     uint4 *bins;                   // [frames][bins_cap]     (triangle, box.x, box.y, -)
     uint32_t bins_cap;             // per frame
+    float4 *band;                  // [frames][band_cap][RS_BAND4]  edge walkers of a triangle at the first scanline of a tile row
+    uint32_t band_cap;             // per frame
+    uint32_t *band_top;            // [frames]               band records handed out (rs_setup; zeroed again by rs_tile)
 };
 
 // y -> output row, or -1 when the row belongs to another GPU's band
@@ -192,48 +196,85 @@ MI_HD void scan_add(float (&l)[N], float (&r)[N], uint32_t &cnt, const float (&v
     }
 }
 
-// One edge's point(s) on scanline y, as ScanConverter::ScanConvert / InnerLoop produce them (ScanConverter.h:90-136):
-// the walk starts at the edge's smaller y (after clipping to the frame: `vtc += d12 * (-y1)`) and adds d12 once per
-// scanline -- row y holds the value after (y - first row) serial additions, which ff_add reaches directly.
-// A horizontal edge adds both its end points.
-template <int N>
-MI_HD void rs_edge_at(int ya, const float (&va)[N], int yb, const float (&vb)[N], int height, int y, float (&l)[N], float (&r)[N],
-                      uint32_t &cnt)
+// The scanlines one edge of a triangle feeds, as ScanConverter::ScanConvert / InnerLoop walk it (ScanConverter.h:90-136):
+// from the smaller y (after clipping to the frame) one scanline at a time; a horizontal edge feeds both its end points to
+// its one scanline.
+struct RsEdgeRange {
+    int y1, y2;            // the edge's own rows, smaller first (before clipping)
+    int first, last;       // rows it feeds (first > last: none)
+    bool horiz, sw;        // sw: the walk starts at the second end point
+};
+
+MI_HD RsEdgeRange rs_edge_range(int ya, int yb, int height)
 {
-    if (ya == yb) {
-        if (ya == y) { scan_add<N>(l, r, cnt, va); scan_add<N>(l, r, cnt, vb); }      // (y is a row of the frame)
-        return;
-    }
-    const bool sw = ya > yb;                    // InnerLoop(y1 < y2): walk from the smaller y
-    int y1 = sw ? yb : ya, y2 = sw ? ya : yb;
-    if (y1 < 0 && y2 < 0) return;
-    if (y1 >= height && y2 >= height) return;
-    const int first = y1 < 0 ? 0 : y1, last = height - 1 < y2 ? height - 1 : y2;
-    if (y < first || y > last) return;
-    const float dy = (float)(y2 - y1);
-    float v[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        const float a = sw ? vb[i] : va[i], b = sw ? va[i] : vb[i];
-        const float d = (b - a) / dy;
-        float x = a;
-        if (y1 < 0) x += d * (float)-y1;
-        v[i] = ff_add(x, d, y - first);
-    }
-    scan_add<N>(l, r, cnt, v);
+    RsEdgeRange R;
+    R.horiz = ya == yb; R.sw = ya > yb;
+    R.y1 = R.sw ? yb : ya; R.y2 = R.sw ? ya : yb;
+    R.first = 1; R.last = 0;
+    if (R.horiz) { if (ya >= 0 && ya < height) R.first = R.last = ya; return R; }
+    if (R.y1 < 0 && R.y2 < 0) return R;
+    if (R.y1 >= height && R.y2 >= height) return R;
+    R.first = R.y1 < 0 ? 0 : R.y1;
+    R.last = height - 1 < R.y2 ? height - 1 : R.y2;
+    return R;
 }
 
-// Scanline y of a triangle: left / right end points and ScanConverter's lines[y].  Screen.h:239-241: AB, AC, BC.
-template <int N>
-MI_HD uint32_t rs_row_at(const int (&iy)[3], const float (&A)[N], const float (&B)[N], const float (&C)[N], int height, int y,
-                         float (&l)[N], float (&r)[N])
+// end points of edge e (Screen.h:239-241: AB, AC, BC) of a record: indices into iy[] / offsets of the fat points
+MI_HD int rs_edge_a(int e) { return e == 2 ? 1 : 0; }
+MI_HD int rs_edge_b(int e) { return e == 0 ? 1 : 2; }
+
+// Band record of edge e for the tile row starting at scanline Y0: the walker's value on the first scanline of the band
+// the edge feeds, and its per-scanline step, for every interpolant.  The value is (rb - first) serial additions
+// `vtc += d12` away from the walk's start (ScanConverter.h:99-116): ff_add.  rec = the triangle's record as floats.
+MI_HD void rs_band_edge(const float *rec, int e, int height, int Y0, float4 *out)
+{
+    const int iy[3] = {(int)ff_f2u(rec[24]), (int)ff_f2u(rec[25]), (int)ff_f2u(rec[26])};
+    const int ia = rs_edge_a(e), ib = rs_edge_b(e);
+    const RsEdgeRange R = rs_edge_range(iy[ia], iy[ib], height);
+    if (R.horiz || R.first > R.last) return;
+    const int rb = R.first > Y0 ? R.first : Y0;
+    const int re = R.last < Y0 + RS_TH - 1 ? R.last : Y0 + RS_TH - 1;
+    if (rb > re) return;
+    const float *va = rec + 8 * (R.sw ? ib : ia), *vb = rec + 8 * (R.sw ? ia : ib);
+    const float dy = (float)(R.y2 - R.y1);
+    float w[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float d = (vb[i] - va[i]) / dy;
+        float x = va[i];
+        if (R.y1 < 0) x += d * (float)-R.y1;
+        w[2 * i] = ff_add(x, d, rb - R.first);
+        w[2 * i + 1] = d;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) out[q] = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+
+// Scanline y of a triangle, interpolants {0 (projx), k}: left / right end points and ScanConverter's lines[y], from the
+// band record of the tile row y lies in (Y0 = its first scanline): each feeding edge's value is (y - rb) additions away
+// from the record's.  `pts` = the triangle's fat points as floats (used by horizontal edges only).
+MI_HD uint32_t rs_row_from_band(const int (&iy)[3], const float4 *band, const float *pts, int k, int height, int Y0, int y,
+                                float (&l)[2], float (&r)[2])
 {
     uint32_t cnt = 0;
+    l[0] = l[1] = r[0] = r[1] = 0.f;
 #pragma unroll
-    for (int i = 0; i < N; i++) { l[i] = 0.f; r[i] = 0.f; }
-    rs_edge_at<N>(iy[0], A, iy[1], B, height, y, l, r, cnt);
-    rs_edge_at<N>(iy[0], A, iy[2], C, height, y, l, r, cnt);
-    rs_edge_at<N>(iy[1], B, iy[2], C, height, y, l, r, cnt);
+    for (int e = 0; e < 3; e++) {
+        const int ia = rs_edge_a(e), ib = rs_edge_b(e);
+        const RsEdgeRange R = rs_edge_range(iy[ia], iy[ib], height);
+        if (y < R.first || y > R.last) continue;
+        if (R.horiz) {
+            const float pa[2] = {pts[8 * ia], pts[8 * ia + k]}, pb[2] = {pts[8 * ib], pts[8 * ib + k]};
+            scan_add<2>(l, r, cnt, pa); scan_add<2>(l, r, cnt, pb);
+            continue;
+        }
+        const int rb = R.first > Y0 ? R.first : Y0;
+        const float4 q0 = band[e * 4], qk = band[e * 4 + (k >> 1)];
+        float v[2] = {q0.x, (k & 1) ? qk.z : qk.x};
+        const float d0 = q0.y, dk = (k & 1) ? qk.w : qk.y;
+        for (int j = y - rb; j > 0; j--) { v[0] += d0; v[1] += dk; }
+        scan_add<2>(l, r, cnt, v);
+    }
     return cnt;
 }
 
@@ -429,8 +470,27 @@ MI_HD uint2 rs_setup_thread(const DevScene &S, const FrameParams &P, const RsBuf
         for (int i = 0; i < 8; i++) w[k * 8 + i] = i < N ? f[k][i < N ? i : 0] : 0.f;
 #pragma unroll
     for (int q = 0; q < 6; q++) rec[q] = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
-    rec[6] = make_float4(ff_u2f((uint32_t)iy[0]), ff_u2f((uint32_t)iy[1]), ff_u2f((uint32_t)iy[2]), 0.f);
+    rec[6] = make_float4(ff_u2f((uint32_t)iy[0]), ff_u2f((uint32_t)iy[1]), ff_u2f((uint32_t)iy[2]), 0.f);   // (.w: first band record, below)
     return box;
+}
+
+// tile rows a box covers = band records of the triangle
+MI_HD int rs_band_count(uint2 box) { return box.x == 0xffffffffu ? 0 : (int)(box.y >> 16) - (int)(box.y & 0xffffu) + 1; }
+
+// the triangle's band records start at `base` (rs_setup: after the block's allocation)
+MI_HD void rs_set_band_base(const RsBuffers &B, uint32_t n_tris, uint32_t frame, uint32_t t, uint32_t base)
+{
+    ((uint32_t *)(B.rec + ((size_t)frame * n_tris + t) * RS_REC4 + 6))[3] = base;
+}
+
+// band record j (tile row ty0 + j), edge e of triangle t
+MI_HD void rs_band_fill(const RsBuffers &B, uint32_t n_tris, uint32_t frame, uint32_t t, uint32_t base, int j, int e, int height)
+{
+    if (base + (uint32_t)j >= B.band_cap) return;                 // (the frame reports the overflow)
+    const size_t slot = (size_t)frame * n_tris + t;
+    const int ty0 = (int)(B.box[slot].y & 0xffffu);
+    rs_band_edge((const float *)(B.rec + slot * RS_REC4), e, height, (ty0 + j) * RS_TH,
+                 B.band + ((size_t)frame * B.band_cap + base + (uint32_t)j) * RS_BAND4 + e * 4);
 }
 
 // ---- rs_tile ------------------------------------------------------------------------------------------------------
@@ -488,25 +548,19 @@ MI_HD void rs_tile_filter(const RsBuffers &B, uint32_t frame, int tx, int ty, co
     }
 }
 
-// phase 2a (thread = slot of the chunk): triangle `chunk + tid` of the list -> its depth data into LDS, one work item per
-// scanline of the tile it touches
+// phase 2a (thread = slot of the chunk): triangle `chunk + tid` of the list -> what its depth items share into LDS, one
+// work item per scanline of the tile it touches
 template <int MODE>
 MI_HD void rs_tile_stage(const FrameParams &P, const RsBuffers &B, uint32_t n_tris, uint32_t frame, int ty, uint32_t chunk, uint32_t n_list,
                          int parity, RsTileLds &lds, int tid)
 {
-    constexpr int ZI = FatZ<MODE>::ZI;
     const uint32_t e = chunk + (uint32_t)tid;
     if (e >= n_list) return;
     const uint32_t tri = lds.list[e];
-    const float4 *rec = B.rec + ((size_t)frame * n_tris + tri) * RS_REC4;
-    const float4 a = rec[0], b = rec[2], c = rec[4], r6 = rec[6];
+    const float4 r6 = B.rec[((size_t)frame * n_tris + tri) * RS_REC4 + 6];
     uint32_t *st = lds.stage[tid];
-    st[0] = ff_f2u(a.x); st[1] = ff_f2u(ZI == 1 ? a.y : a.w);
-    st[2] = ff_f2u(b.x); st[3] = ff_f2u(ZI == 1 ? b.y : b.w);
-    st[4] = ff_f2u(c.x); st[5] = ff_f2u(ZI == 1 ? c.y : c.w);
-    st[6] = ff_f2u(r6.x); st[7] = ff_f2u(r6.y); st[8] = ff_f2u(r6.z);
-    st[9] = tri;
-    const int iy[3] = {(int)st[6], (int)st[7], (int)st[8]};
+    st[0] = ff_f2u(r6.x); st[1] = ff_f2u(r6.y); st[2] = ff_f2u(r6.z); st[3] = ff_f2u(r6.w); st[4] = tri;
+    const int iy[3] = {(int)st[0], (int)st[1], (int)st[2]};
     int miny, maxy;
     if (!rs_tri_rows(iy, P.H, miny, maxy)) return;
     const int Y0 = ty * RS_TH;
@@ -516,10 +570,22 @@ MI_HD void rs_tile_stage(const FrameParams &P, const RsBuffers &B, uint32_t n_tr
     for (int y = ys; y <= ye; y++) lds.items[base + (uint32_t)(y - ys)] = (uint16_t)(((uint32_t)tid << 4) | (uint32_t)(y - Y0));
 }
 
+// the band record of tile row ty for a triangle whose records start at `base`
+MI_HD const float4 *rs_band_of(const RsBuffers &B, uint32_t frame, const int (&iy)[3], uint32_t base, int ty)
+{
+    int miny = iy[0] < iy[1] ? iy[0] : iy[1]; miny = miny < iy[2] ? miny : iy[2];
+    if (miny < 0) miny = 0;
+    uint32_t idx = base + (uint32_t)(ty - miny / RS_TH);
+    if (idx >= B.band_cap) idx = B.band_cap - 1;                  // (overflowed frame: reported; stay inside the buffer)
+    return B.band + ((size_t)frame * B.band_cap + idx) * RS_BAND4;
+}
+
 // phase 2b: one work item = one scanline of one triangle: Screen.h:244-290 restricted to the tile's columns, depth only
 template <int MODE>
-MI_HD void rs_tile_depth(const FrameParams &P, int tx, int ty, int parity, RsTileLds &lds, int tid, unsigned long long &ztests)
+MI_HD void rs_tile_depth(const FrameParams &P, const RsBuffers &B, uint32_t n_tris, uint32_t frame, int tx, int ty, int parity, RsTileLds &lds,
+                         int tid, unsigned long long &ztests)
 {
+    constexpr int ZI = FatZ<MODE>::ZI;
     const int W = P.W, H = P.H;
     const int X0 = tx * RS_TW, X1 = (X0 + RS_TW < W ? X0 + RS_TW : W) - 1;
     const uint32_t n = lds.n_items[parity];
@@ -528,16 +594,17 @@ MI_HD void rs_tile_depth(const FrameParams &P, int tx, int ty, int parity, RsTil
         const uint32_t *st = lds.stage[item >> 4];
         const int row = (int)(item & 15u), y = ty * RS_TH + row;
         if (rs_out_row(P, y) < 0) continue;              // another GPU's band
-        const float A[2] = {ff_u2f(st[0]), ff_u2f(st[1])}, Bv[2] = {ff_u2f(st[2]), ff_u2f(st[3])}, C[2] = {ff_u2f(st[4]), ff_u2f(st[5])};
-        const int iy[3] = {(int)st[6], (int)st[7], (int)st[8]};
+        const int iy[3] = {(int)st[0], (int)st[1], (int)st[2]};
+        const uint32_t tri = st[4];
         float l[2], r[2];
-        const uint32_t cnt = rs_row_at<2>(iy, A, Bv, C, H, y, l, r);
+        const uint32_t cnt = rs_row_from_band(iy, rs_band_of(B, frame, iy, st[3], ty), (const float *)(B.rec + ((size_t)frame * n_tris + tri) * RS_REC4),
+                                              ZI, H, ty * RS_TH, y, l, r);
         if (!cnt) continue;
         RsSpan s;
         if (!rs_span(l[0], r[0], cnt, W, s)) continue;
         int xa = s.x1 > X0 ? s.x1 : X0, xb = s.x1 + s.steps < X1 ? s.x1 + s.steps : X1;
         if (xa > xb) continue;
-        const unsigned long long trikey = (unsigned long long)(0xffffffffu - st[9]);
+        const unsigned long long trikey = (unsigned long long)(0xffffffffu - tri);
         unsigned long long *krow = lds.keys + row * RS_TW - X0;
         float d = 0.f, z = l[1];
         if (!s.single) z = rs_span_value(s, l[1], r[1], xa - s.x1, d);
@@ -580,11 +647,10 @@ MI_HD void rs_tile_attr(const FrameParams &P, const RsBuffers &B, uint32_t n_tri
         const int px = i % RS_TW, row = i / RS_TW;
         const uint32_t tri = 0xffffffffu - (uint32_t)(lds.keys[i] & 0xffffffffull);
         const float *rec = (const float *)(B.rec + ((size_t)frame * n_tris + tri) * RS_REC4);
-        const float A[2] = {rec[0], rec[k]}, Bv[2] = {rec[8], rec[8 + k]}, C[2] = {rec[16], rec[16 + k]};
         const int iy[3] = {(int)ff_f2u(rec[24]), (int)ff_f2u(rec[25]), (int)ff_f2u(rec[26])};
         const int y = ty * RS_TH + row, x = tx * RS_TW + px;
         float l[2], r[2];
-        const uint32_t cnt = rs_row_at<2>(iy, A, Bv, C, P.H, y, l, r);
+        const uint32_t cnt = rs_row_from_band(iy, rs_band_of(B, frame, iy, ff_f2u(rec[27]), ty), rec, k, P.H, ty * RS_TH, y, l, r);
         RsSpan s;
         if (!cnt || !rs_span(l[0], r[0], cnt, P.W, s)) continue;            // (cannot happen: the key came from this scanline)
         float d = 0.f, v = l[1];

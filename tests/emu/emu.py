@@ -43,7 +43,7 @@ def scene_streams(hs):
     return rs_tri, rs_col, rs_idx, rs_vert
 
 
-def render(hs, mode, cams, lights_per_frame, n_lights, opts, shadow_maps=None, bins_cap=0, streams=None):
+def render(hs, mode, cams, lights_per_frame, n_lights, opts, shadow_maps=None, bins_cap=0, streams=None, band_cap=0):
     """Frames of `cams` (a list) -> (list of images, stats dict, dropped bin entries)."""
     rs_tri, rs_col, rs_idx, rs_vert = streams or scene_streams(hs)
     n = len(cams)
@@ -65,7 +65,7 @@ def render(hs, mode, cams, lights_per_frame, n_lights, opts, shadow_maps=None, b
     over = C.c_ulonglong(0)
     rc = lib().emu_raster(C.c_uint32(hs.nt), C.c_uint32(hs.nv), C.c_void_p(rs_tri.ctypes.data), C.c_void_p(rs_col.ctypes.data),
                           C.c_void_p(rs_idx.ctypes.data), C.c_void_p(rs_vert.ctypes.data), C.c_int(mode), C.c_int(n), cam_arr, light_arr,
-                          C.c_int(n_lights), C.byref(opts), maps, out_ptrs, C.c_int(W), stats, C.c_uint32(bins_cap), C.byref(over))
+                          C.c_int(n_lights), C.byref(opts), maps, out_ptrs, C.c_int(W), stats, C.c_uint32(bins_cap), C.byref(over), C.c_uint32(band_cap))
     if rc != 0:
         raise RuntimeError("emu_raster failed (%d)" % rc)
     return outs, dict(tris_drawn=stats[0], spans=stats[1], ztests=stats[2], plots=stats[3]), int(over.value)

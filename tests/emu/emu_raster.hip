@@ -57,6 +57,12 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
             const uint2 box = rs_setup_thread<MODE>(S, F[f], B, (uint32_t)f, t);
             if (box.x == 0xffffffffu) continue;
             for (int k = 0; k < rs_bin_count(box); k++) B.count[(size_t)f * g.n_bins + rs_bin_at(g, box, k)]++;
+            const uint32_t base = B.band_top[f];
+            B.band_top[f] += (uint32_t)rs_band_count(box);
+            if (B.band_top[f] > B.band_cap && F[0].counters) F[0].counters[CS_OVERFLOW] += 1;
+            rs_set_band_base(B, S.n_tris, (uint32_t)f, t, base);
+            for (int j = 0; j < rs_band_count(box); j++)
+                for (int e = 0; e < 3; e++) rs_band_fill(B, S.n_tris, (uint32_t)f, t, base, j, e, F[f].H);
         }
     }
     for (int f = 0; f < n_frames; f++) {                       // k_rs_scan
@@ -81,7 +87,7 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
     for (int f = 0; f < n_frames; f++)                         // k_rs_tile, one block per tile
         for (int ty = 0; ty < g.tiles_y; ty++)
             for (int tx = 0; tx < g.tiles_x; tx++) {
-                if (tx == 0 && ty == 0) for (int b = 0; b < g.n_bins; b++) B.count[(size_t)f * g.n_bins + b] = 0u;
+                if (tx == 0 && ty == 0) { for (int b = 0; b < g.n_bins; b++) B.count[(size_t)f * g.n_bins + b] = 0u; B.band_top[f] = 0u; }
                 const RsTileBins L = rs_tile_bins(g, B, (uint32_t)f, tx, ty);
                 const uint32_t total = L.total();
                 unsigned long long zt = 0, plots = 0;
@@ -98,7 +104,7 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
                     any = any || nl != 0u;
                     for (uint32_t chunk = 0; chunk < nl; chunk += RS_THREADS) {
                         ALL_THREADS_REVERSED(rs_tile_stage<MODE>(F[f], B, S.n_tris, (uint32_t)f, ty, chunk, nl, parity, lds, tid));
-                        ALL_THREADS(rs_tile_depth<MODE>(F[f], tx, ty, parity, lds, tid, zt));
+                        ALL_THREADS(rs_tile_depth<MODE>(F[f], B, S.n_tris, (uint32_t)f, tx, ty, parity, lds, tid, zt));
                         lds.n_items[parity ^ 1] = 0u;
                         if (chunk + RS_THREADS >= nl) lds.n_list = 0u;
                         parity ^= 1;
@@ -119,7 +125,7 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
 extern "C" int emu_raster(uint32_t n_tris, uint32_t n_verts, const float *rs_tri, const float *rs_col, const uint32_t *rs_idx,
                           const float *rs_vert, int mode, int n_frames, const mi355_camera *cams, const mi355_light *lights, int n_lights,
                           const mi355_opts *o, const float *const *shadow_maps, uint32_t *const *outs, int pitch_words,
-                          unsigned long long *stats4, uint32_t bins_cap, unsigned long long *overflow)
+                          unsigned long long *stats4, uint32_t bins_cap, unsigned long long *overflow, uint32_t band_cap_arg)
 {
     DevScene S;
     memset(&S, 0, sizeof S);
@@ -135,7 +141,11 @@ extern "C" int emu_raster(uint32_t n_tris, uint32_t n_verts, const float *rs_tri
     std::vector<uint32_t> count((size_t)n_frames * g.n_bins, 0u), cursor((size_t)n_frames * g.n_bins, 0xdeadbeefu), offset((size_t)n_frames * (g.n_bins + 1), 0u);
     if (!bins_cap) bins_cap = n_tris * 3u + 4096u;
     std::vector<uint4> bins((size_t)bins_cap * n_frames, make_uint4(0xdeadbeefu, 0xdeadbeefu, 0xdeadbeefu, 0u));
+    const uint32_t band_cap = band_cap_arg ? band_cap_arg : n_tris * 2u + 8192u;
+    std::vector<float4> band((size_t)band_cap * n_frames * RS_BAND4, make_float4(-7.f, -7.f, -7.f, -7.f));
+    std::vector<uint32_t> band_top((size_t)n_frames, 0u);
     RsBuffers B;
+    B.band = band.data(); B.band_cap = band_cap; B.band_top = band_top.data();
     B.rec = rec.data(); B.box = box.data(); B.count = count.data(); B.cursor = cursor.data(); B.offset = offset.data(); B.bins = bins.data(); B.bins_cap = bins_cap;
     switch (mode) {
     case M_AMBIENT: run<M_AMBIENT>(S, F, g, B); break;
