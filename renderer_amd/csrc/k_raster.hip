@@ -169,11 +169,11 @@ MI_DEV uint32_t wave_bin_add(uint32_t *counters, int bin, bool act)
 // make its wave loop over them.  pairs.begin() (all threads; syncs), then for (base...) { pair(base + tid, owner, k) }.
 struct BlockPairs {
     uint32_t pre[257];            // exclusive prefix of the threads' bin counts
-    uint2 box[256];
+    uint4 box[256];
     uint32_t wave_tot[4];
 };
 
-MI_DEV uint32_t block_pairs_begin(BlockPairs &bp, uint2 box, int nb)
+MI_DEV uint32_t block_pairs_begin(BlockPairs &bp, uint4 box, int nb)
 {
     const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
     bp.box[tid] = box;
@@ -205,10 +205,11 @@ __global__ void __launch_bounds__(256) k_rs_setup(const DevScene S, const FrameP
                                                   const RsBuffers B)
 {
     __shared__ BlockPairs bp;
+    __shared__ uint32_t band_base;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
     if (blockIdx.x == 0)                                  // rs_fill's cursors start at zero
         for (uint32_t i = threadIdx.x; i < (uint32_t)g.n_bins; i += blockDim.x) B.cursor[(size_t)f * g.n_bins + i] = 0u;
-    uint2 box = make_uint2(0xffffffffu, 0u);
+    uint4 box = make_uint4(0xffffffffu, 0u, 0u, 0u);
     if (t < S.n_tris) box = rs_setup_thread<MODE>(S, batch ? batch[f] : P, B, f, t);
     const uint32_t total = block_pairs_begin(bp, box, box.x == 0xffffffffu ? 0 : rs_bin_count(box));
     uint32_t *cnt = B.count + (size_t)f * g.n_bins;
@@ -219,25 +220,24 @@ __global__ void __launch_bounds__(256) k_rs_setup(const DevScene S, const FrameP
         if (act) block_pair(bp, p, owner, k);
         wave_bin_add<false>(cnt, act ? rs_bin_at(g, bp.box[owner], k) : -1, act);
     }
-    // band records: one (triangle, tile row, edge) per thread and round; the block's records are one allocation
-    __shared__ uint32_t band_base;
+    // band records: the block's records are one allocation; (triangle, tile row) of each record for k_rs_fill, which
+    // computes them
     __syncthreads();                                      // (bp is reused)
-    const uint32_t n_edges = block_pairs_begin(bp, box, 3 * rs_band_count(box));
+    const uint32_t n_bands = block_pairs_begin(bp, box, rs_band_count(box));
     if (threadIdx.x == 0) {
-        band_base = n_edges ? atomicAdd(&B.band_top[f], n_edges / 3u) : 0u;
-        if (n_edges && band_base + n_edges / 3u > B.band_cap && P.counters) atomicAdd(&P.counters[CS_OVERFLOW], 1ull);
+        band_base = n_bands ? atomicAdd(&B.band_top[f], n_bands) : 0u;
+        if (n_bands && band_base + n_bands > B.band_cap && P.counters) atomicAdd(&P.counters[CS_OVERFLOW], 1ull);
     }
     __syncthreads();
-    const uint32_t my_base = band_base + bp.pre[threadIdx.x] / 3u;
-    if (box.x != 0xffffffffu) rs_set_band_base(B, S.n_tris, f, t, my_base);
-    __syncthreads();                                      // the records' float data and bases are read back below (same block)
-    const int H = (batch ? batch[f] : P).H;
-    for (uint32_t base = 0; base < n_edges; base += 256u) {
+    if (box.x != 0xffffffffu) rs_set_band_base(B, S.n_tris, f, t, band_base + bp.pre[threadIdx.x]);
+    uint2 *owner_of = B.band_owner + (size_t)f * B.band_cap;
+    for (uint32_t base = 0; base < n_bands; base += 256u) {
         const uint32_t p = base + threadIdx.x;
-        if (p >= n_edges) break;
-        int owner = 0, k = 0;
-        block_pair(bp, p, owner, k);
-        rs_band_fill(B, S.n_tris, f, blockIdx.x * blockDim.x + (uint32_t)owner, band_base + bp.pre[owner] / 3u, k / 3, k % 3, H);
+        if (p >= n_bands) break;
+        int owner = 0, j = 0;
+        block_pair(bp, p, owner, j);
+        if (band_base + p < B.band_cap)
+            owner_of[band_base + p] = make_uint2(blockIdx.x * blockDim.x + (uint32_t)owner, (bp.box[owner].y & 0xffffu) + (uint32_t)j);
     }
 }
 
@@ -270,60 +270,67 @@ __global__ void __launch_bounds__(1024) k_rs_scan(const RsGrid g, const RsBuffer
 
 #define RS_SCAN_LDS 2048          // frames with at most this many bins (1080p: 511, 4K: 2041): every block of k_rs_fill scans the counts itself
 
-// LDS_SCAN: the bin offsets are the block's own exclusive scan of the frame's counts (block 0 also stores them for
-// k_rs_tile); otherwise they come from k_rs_scan.
+// Bin entries and band records.  LDS_SCAN: the bin offsets are the block's own exclusive scan of the frame's counts
+// (block 0 also stores them for k_rs_tile); otherwise they come from k_rs_scan.  Then every thread of the grid takes
+// band items (one interpolant of one edge of one record each) until they are done.
 template <bool LDS_SCAN>
-__global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers B, uint32_t n_tris, unsigned long long *counters)
+__global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers B, uint32_t n_tris, int height, unsigned long long *counters)
 {
     __shared__ BlockPairs bp;
     __shared__ uint32_t soff[LDS_SCAN ? RS_SCAN_LDS + 1 : 1];
     __shared__ uint32_t stot[4];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
     const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const uint32_t *off = B.offset + (size_t)f * (g.n_bins + 1);
-    if (LDS_SCAN) {
-        const uint32_t n = (uint32_t)g.n_bins, per = (n + 255u) / 256u;      // <= 8 consecutive counts per thread
-        const uint32_t *cnt = B.count + (size_t)f * n;
-        const uint32_t b = (uint32_t)tid * per < n ? (uint32_t)tid * per : n, e = b + per < n ? b + per : n;
-        uint32_t c[(RS_SCAN_LDS + 255) / 256], s = 0;
+    if (blockIdx.x * blockDim.x < n_tris) {
+        const uint32_t *off = B.offset + (size_t)f * (g.n_bins + 1);
+        if (LDS_SCAN) {
+            const uint32_t n = (uint32_t)g.n_bins, per = (n + 255u) / 256u;      // <= 8 consecutive counts per thread
+            const uint32_t *cnt = B.count + (size_t)f * n;
+            const uint32_t b = (uint32_t)tid * per < n ? (uint32_t)tid * per : n, e = b + per < n ? b + per : n;
+            uint32_t c[(RS_SCAN_LDS + 255) / 256], s = 0;
 #pragma unroll
-        for (uint32_t i = 0; i < (RS_SCAN_LDS + 255) / 256; i++) { c[i] = b + i < e ? cnt[b + i] : 0u; s += c[i]; }
-        uint32_t incl = s;
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += v; }
-        if (lane == 63) stot[wid] = incl;
-        __syncthreads();
-        uint32_t before = 0, total = 0;
-        for (int w = 0; w < 4; w++) { const uint32_t v = stot[w]; if (w < wid) before += v; total += v; }
-        uint32_t run = before + incl - s;
+            for (uint32_t i = 0; i < (RS_SCAN_LDS + 255) / 256; i++) { c[i] = b + i < e ? cnt[b + i] : 0u; s += c[i]; }
+            uint32_t incl = s;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += v; }
+            if (lane == 63) stot[wid] = incl;
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+            for (int w = 0; w < 4; w++) { const uint32_t v = stot[w]; if (w < wid) before += v; total += v; }
+            uint32_t run = before + incl - s;
 #pragma unroll
-        for (uint32_t i = 0; i < (RS_SCAN_LDS + 255) / 256; i++) if (b + i < e) { soff[b + i] = run; run += c[i]; }
-        if (tid == 0) soff[n] = total;
-        __syncthreads();
-        if (blockIdx.x == 0) {
-            uint32_t *goff = B.offset + (size_t)f * (n + 1);
-            for (uint32_t i = (uint32_t)tid; i <= n; i += 256u) goff[i] = soff[i];
-            if (tid == 0 && total > B.bins_cap && counters) atomicAdd(&counters[CS_OVERFLOW], (unsigned long long)(total - B.bins_cap));
+            for (uint32_t i = 0; i < (RS_SCAN_LDS + 255) / 256; i++) if (b + i < e) { soff[b + i] = run; run += c[i]; }
+            if (tid == 0) soff[n] = total;
+            __syncthreads();
+            if (blockIdx.x == 0) {
+                uint32_t *goff = B.offset + (size_t)f * (n + 1);
+                for (uint32_t i = (uint32_t)tid; i <= n; i += 256u) goff[i] = soff[i];
+                if (tid == 0 && total > B.bins_cap && counters) atomicAdd(&counters[CS_OVERFLOW], (unsigned long long)(total - B.bins_cap));
+            }
+            off = soff;
         }
-        off = soff;
-    }
-    uint2 box = make_uint2(0xffffffffu, 0u);
-    if (t < n_tris) box = B.box[(size_t)f * n_tris + t];
-    const uint32_t total = block_pairs_begin(bp, box, box.x == 0xffffffffu ? 0 : rs_bin_count(box));
-    uint32_t *cur = B.cursor + (size_t)f * g.n_bins;
-    uint4 *bins = B.bins + (size_t)f * B.bins_cap;
-    for (uint32_t base = 0; base < total; base += 256u) {
-        const uint32_t p = base + (uint32_t)tid;
-        const bool act = p < total;
-        int owner = 0, k = 0;
-        if (act) block_pair(bp, p, owner, k);
-        const uint2 pb = bp.box[owner];
-        const int bin = act ? rs_bin_at(g, pb, k) : -1;
-        const uint32_t pos = wave_bin_add<true>(cur, bin, act);
-        if (act) {
-            const uint32_t at = off[bin] + pos;
-            if (at < B.bins_cap) bins[at] = make_uint4(blockIdx.x * blockDim.x + (uint32_t)owner, pb.x, pb.y, 0u);   // (else: the overflow has been reported)
+        uint4 box = make_uint4(0xffffffffu, 0u, 0u, 0u);
+        if (t < n_tris) box = B.box[(size_t)f * n_tris + t];
+        const uint32_t total = block_pairs_begin(bp, box, box.x == 0xffffffffu ? 0 : rs_bin_count(box));
+        uint32_t *cur = B.cursor + (size_t)f * g.n_bins;
+        uint4 *bins = B.bins + (size_t)f * B.bins_cap;
+        for (uint32_t base = 0; base < total; base += 256u) {
+            const uint32_t p = base + (uint32_t)tid;
+            const bool act = p < total;
+            int owner = 0, k = 0;
+            if (act) block_pair(bp, p, owner, k);
+            const uint4 pb = bp.box[owner];
+            const int bin = act ? rs_bin_at(g, pb, k) : -1;
+            const uint32_t pos = wave_bin_add<true>(cur, bin, act);
+            if (act) {
+                const uint32_t at = off[bin] + pos;
+                if (at < B.bins_cap) bins[at] = make_uint4(blockIdx.x * blockDim.x + (uint32_t)owner, pb.x, pb.z, pb.w);   // (else: the overflow has been reported)
+            }
         }
     }
+    uint32_t n_rec = B.band_top[f];
+    if (n_rec > B.band_cap) n_rec = B.band_cap;
+    const uint32_t n_items = n_rec * 24u;
+    for (uint32_t p = blockIdx.x * blockDim.x + (uint32_t)tid; p < n_items; p += gridDim.x * blockDim.x) rs_band_item(B, n_tris, f, p, height);
 }
 
 // Phase profile of counting frames (collect_stats): sums over the blocks of the cycles between the barriers, into the
@@ -366,13 +373,13 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_tile(const DevScene S, const 
         const uint32_t nl = lds.n_list;
         any = any || nl != 0u;
         if (prof && tid == 0) atomicAdd(&P.counters[CS_PROF0 + 10], (unsigned long long)nl);
-        for (uint32_t chunk = 0; chunk < nl; chunk += RS_THREADS) {
-            rs_tile_stage<MODE>(F, B, S.n_tris, f, ty, chunk, nl, parity, lds, tid);
+        for (uint32_t chunk = 0; chunk < nl; chunk += RS_CHUNK) {
+            rs_tile_stage(ty, chunk, nl, parity, lds, tid);
             __syncthreads();
             RS_PROF_MARK(2);
             if (prof && tid == 0) atomicAdd(&P.counters[CS_PROF0 + 11], (unsigned long long)lds.n_items[parity]);
-            rs_tile_depth<MODE>(F, B, S.n_tris, f, tx, ty, parity, lds, tid, ztests);
-            if (tid == 0) { lds.n_items[parity ^ 1] = 0u; if (chunk + RS_THREADS >= nl) lds.n_list = 0u; }
+            rs_tile_depth<MODE>(F, B, S.n_tris, f, tx, ty, chunk, parity, lds, tid, ztests);
+            if (tid == 0) { lds.n_items[parity ^ 1] = 0u; if (chunk + RS_CHUNK >= nl) lds.n_list = 0u; }
             parity ^= 1;
             __syncthreads();
             RS_PROF_MARK(3);
@@ -481,7 +488,7 @@ extern "C" RasterScratch *mi355i_raster_scratch_create(void) { return new Raster
 extern "C" void mi355i_raster_scratch_destroy(RasterScratch *s)
 {
     if (!s) return;
-    for (void *p : {(void *)s->B.rec, (void *)s->B.box, (void *)s->B.count, (void *)s->B.cursor, (void *)s->B.offset, (void *)s->B.bins, (void *)s->B.band, (void *)s->B.band_top,
+    for (void *p : {(void *)s->B.rec, (void *)s->B.box, (void *)s->B.count, (void *)s->B.cursor, (void *)s->B.offset, (void *)s->B.bins, (void *)s->B.band, (void *)s->B.band_top, (void *)s->B.band_owner,
                     (void *)s->d_frames, (void *)s->rows, (void *)s->ctl, (void *)s->smkeys})
         if (p) (void)hipFree(p);
     if (s->h_frames) (void)hipHostFree(s->h_frames);
@@ -510,7 +517,7 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
         if (s->B.box) (void)hipFree(s->B.box);
         s->B.rec = nullptr; s->B.box = nullptr; s->rec_slots = 0;
         if ((e = hipMalloc((void **)&s->B.rec, slots * RS_REC4 * sizeof(float4))) != hipSuccess) return e;
-        if ((e = hipMalloc((void **)&s->B.box, slots * sizeof(uint2))) != hipSuccess) return e;
+        if ((e = hipMalloc((void **)&s->B.box, slots * sizeof(uint4))) != hipSuccess) return e;
         (void)have;
         s->rec_slots = slots;
     }
@@ -549,8 +556,10 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
     if (bcap > 0x3ffffff0ull) bcap = 0x3ffffff0ull;
     if ((size_t)bcap * n_frames > s->band_words || !s->B.band) {
         if (s->B.band) (void)hipFree(s->B.band);
-        s->B.band = nullptr; s->band_words = 0;
+        if (s->B.band_owner) (void)hipFree(s->B.band_owner);
+        s->B.band = nullptr; s->B.band_owner = nullptr; s->band_words = 0;
         if ((e = hipMalloc((void **)&s->B.band, (size_t)bcap * n_frames * RS_BAND4 * sizeof(float4))) != hipSuccess) return e;
+        if ((e = hipMalloc((void **)&s->B.band_owner, (size_t)bcap * n_frames * sizeof(uint2))) != hipSuccess) return e;
         s->band_words = (size_t)bcap * n_frames;
     }
     s->B.band_cap = (uint32_t)(s->band_words / (size_t)n_frames < bcap ? s->band_words / (size_t)n_frames : bcap);
@@ -574,10 +583,12 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     const int nbT = (int)((S->n_tris + 255) / 256);
     const dim3 per_tri(nbT > 0 ? nbT : 1, n_frames);
     hipLaunchKernelGGL((k_rs_setup<MODE>), per_tri, dim3(256), 0, st, *S, *P, d_batch, g, s->B);
-    if (g.n_bins <= RS_SCAN_LDS) hipLaunchKernelGGL(k_rs_fill<true>, per_tri, dim3(256), 0, st, g, s->B, S->n_tris, P->counters);
+    // (the fill kernel's grid also has to carry the band items: at least four blocks per CU)
+    const dim3 fill_grid(per_tri.x > 1024u ? per_tri.x : 1024u, n_frames);
+    if (g.n_bins <= RS_SCAN_LDS) hipLaunchKernelGGL(k_rs_fill<true>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, P->H, P->counters);
     else {
         hipLaunchKernelGGL(k_rs_scan, dim3(n_frames), dim3(1024), 0, st, g, s->B, P->counters);
-        hipLaunchKernelGGL(k_rs_fill<false>, per_tri, dim3(256), 0, st, g, s->B, S->n_tris, P->counters);
+        hipLaunchKernelGGL(k_rs_fill<false>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, P->H, P->counters);
     }
     // one block per tile: the hardware hands tiles to CUs as blocks retire, an empty tile costs one short block
     const long long blocks = (long long)n_frames * g.n_tiles;
@@ -709,6 +720,6 @@ extern "C" uint32_t mi355i_raster_overflow(RasterScratch *s)
 extern "C" size_t mi355i_raster_scratch_bytes(const RasterScratch *s)
 {
     if (!s) return 0;
-    return s->rec_slots * (RS_REC4 * sizeof(float4) + sizeof(uint2)) + s->bin_words * 12 + s->bins_words * 16 + s->band_words * RS_BAND4 * sizeof(float4) +
+    return s->rec_slots * (RS_REC4 * sizeof(float4) + sizeof(uint4)) + s->bin_words * 12 + s->bins_words * 16 + s->band_words * (RS_BAND4 * sizeof(float4) + sizeof(uint2)) +
            (size_t)s->rows_cap * sizeof(RowRec) + s->sm_words * 4;
 }

@@ -38,9 +38,9 @@
 #define RS_CB 4               // a coarse bin covers RS_CB x RS_CB tiles
 #define RS_COARSE_MAX 64      // largest coarse box binned bin by bin; beyond: the global bin
 #define RS_REC4 7             // float4 per triangle record
-#define RS_THREADS 256
-#define RS_LIST_CAP 2048      // bin entries filtered per pass of a tile (LDS list of accepted triangles)
-#define RS_STAGE 5            // dwords staged per triangle of a depth chunk: iy[3], first band record, triangle id
+#define RS_THREADS 512
+#define RS_LIST_CAP 1024      // bin entries filtered per pass of a tile (LDS list of accepted triangles)
+#define RS_CHUNK 256          // list entries whose scanlines are one round of depth items
 #define RS_BAND4 12           // float4 per band record: 3 edges x 8 interpolants x (value, step), interpolants 2j, 2j+1 in one float4
 
 enum { M_AMBIENT = 4, M_GOURAUD = 5, M_PHONG = 6, M_PHONG_SH = 7, M_PHONG_SOFT = 8, M_SHADOWMAP = 100 };
@@ -84,15 +84,17 @@ MI_HD RsGrid rs_grid(int W, int H)
 // Device buffers of the pipeline; the frames of a batch lie side by side and do not share anything
 struct RsBuffers {
     float4 *rec;                   // [frames][T][RS_REC4]   fat points A, B, C (8 floats each), iy[3], -
-    uint2 *box;                    // [frames][T]            tile box: x = tx0 | tx1 << 16, y = ty0 | ty1 << 16; x = ~0: not drawn
+    uint4 *box;                    // [frames][T]            x = tx0 | tx1 << 16, y = ty0 | ty1 << 16 (tile box), z = miny | maxy << 16
+                                   //                        (scanlines), w = first band record; x = ~0: not drawn
     uint32_t *count;               // [frames][n_bins]       entries per bin (rs_setup; zeroed again by rs_tile)
     uint32_t *cursor;              // [frames][n_bins]       entries written so far (rs_fill; zeroed by rs_setup)
     uint32_t *offset;              // [frames][n_bins + 1]   exclusive scan of a frame's counts (rs_fill)
-    uint4 *bins;                   // [frames][bins_cap]     (triangle, box.x, box.y, -)
+    uint4 *bins;                   // [frames][bins_cap]     (triangle, box.x, box.z, box.w)
     uint32_t bins_cap;             // per frame
     float4 *band;                  // [frames][band_cap][RS_BAND4]  edge walkers of a triangle at the first scanline of a tile row
     uint32_t band_cap;             // per frame
     uint32_t *band_top;            // [frames]               band records handed out (rs_setup; zeroed again by rs_tile)
+    uint2 *band_owner;             // [frames][band_cap]     (triangle, tile row of its box) of each band record
 };
 
 // y -> output row, or -1 when the row belongs to another GPU's band
@@ -223,32 +225,9 @@ MI_HD RsEdgeRange rs_edge_range(int ya, int yb, int height)
 MI_HD int rs_edge_a(int e) { return e == 2 ? 1 : 0; }
 MI_HD int rs_edge_b(int e) { return e == 0 ? 1 : 2; }
 
-// Band record of edge e for the tile row starting at scanline Y0: the walker's value on the first scanline of the band
-// the edge feeds, and its per-scanline step, for every interpolant.  The value is (rb - first) serial additions
-// `vtc += d12` away from the walk's start (ScanConverter.h:99-116): ff_add.  rec = the triangle's record as floats.
-MI_HD void rs_band_edge(const float *rec, int e, int height, int Y0, float4 *out)
-{
-    const int iy[3] = {(int)ff_f2u(rec[24]), (int)ff_f2u(rec[25]), (int)ff_f2u(rec[26])};
-    const int ia = rs_edge_a(e), ib = rs_edge_b(e);
-    const RsEdgeRange R = rs_edge_range(iy[ia], iy[ib], height);
-    if (R.horiz || R.first > R.last) return;
-    const int rb = R.first > Y0 ? R.first : Y0;
-    const int re = R.last < Y0 + RS_TH - 1 ? R.last : Y0 + RS_TH - 1;
-    if (rb > re) return;
-    const float *va = rec + 8 * (R.sw ? ib : ia), *vb = rec + 8 * (R.sw ? ia : ib);
-    const float dy = (float)(R.y2 - R.y1);
-    float w[16];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const float d = (vb[i] - va[i]) / dy;
-        float x = va[i];
-        if (R.y1 < 0) x += d * (float)-R.y1;
-        w[2 * i] = ff_add(x, d, rb - R.first);
-        w[2 * i + 1] = d;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) out[q] = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
-}
+// Band record of a triangle for a tile row (first scanline Y0): for each edge the walker's value on the first scanline rb of
+// the band the edge feeds and its per-scanline step, for every interpolant -- the value is (rb - first) serial additions
+// `vtc += d12` away from the walk's start (ScanConverter.h:99-116): ff_add (rs_band_item below).
 
 // Scanline y of a triangle, interpolants {0 (projx), k}: left / right end points and ScanConverter's lines[y], from the
 // band record of the tile row y lies in (Y0 = its first scanline): each feeding edge's value is (y - rb) additions away
@@ -394,7 +373,7 @@ MI_HD bool rs_tri_rows(const int (&iy)[3], int H, int &miny, int &maxy)
 // ---- binning ------------------------------------------------------------------------------------------------------
 // for each bin of a tile box: fn(bin index within the frame)
 template <class F>
-MI_HD void rs_for_bins(const RsGrid &g, uint2 box, F fn)
+MI_HD void rs_for_bins(const RsGrid &g, uint4 box, F fn)
 {
     const int cx0 = (int)(box.x & 0xffffu) / RS_CB, cx1 = (int)(box.x >> 16) / RS_CB;
     const int cy0 = (int)(box.y & 0xffffu) / RS_CB, cy1 = (int)(box.y >> 16) / RS_CB;
@@ -403,7 +382,7 @@ MI_HD void rs_for_bins(const RsGrid &g, uint2 box, F fn)
         for (int cx = cx0; cx <= cx1; cx++) fn(cy * g.cx + cx);
 }
 
-MI_HD int rs_bin_count(uint2 box)
+MI_HD int rs_bin_count(uint4 box)
 {
     const int cx0 = (int)(box.x & 0xffffu) / RS_CB, cx1 = (int)(box.x >> 16) / RS_CB;
     const int cy0 = (int)(box.y & 0xffffu) / RS_CB, cy1 = (int)(box.y >> 16) / RS_CB;
@@ -412,7 +391,7 @@ MI_HD int rs_bin_count(uint2 box)
 }
 
 // k-th bin of a tile box (k < rs_bin_count)
-MI_HD int rs_bin_at(const RsGrid &g, uint2 box, int k)
+MI_HD int rs_bin_at(const RsGrid &g, uint4 box, int k)
 {
     const int cx0 = (int)(box.x & 0xffffu) / RS_CB, cx1 = (int)(box.x >> 16) / RS_CB;
     const int cy0 = (int)(box.y & 0xffffu) / RS_CB, cy1 = (int)(box.y >> 16) / RS_CB;
@@ -422,9 +401,10 @@ MI_HD int rs_bin_at(const RsGrid &g, uint2 box, int k)
 }
 
 // ---- rs_setup: one thread per (frame, triangle) ------------------------------------------------------------------
-// Writes the triangle's record and tile box; returns the box (x = ~0: nothing to bin).  The caller counts it into its bins.
+// Writes the triangle's record and box; returns the box (x = ~0: nothing to bin).  The caller counts it into its bins
+// and hands out its band records (box.w, rs_set_band_base).
 template <int MODE>
-MI_HD uint2 rs_setup_thread(const DevScene &S, const FrameParams &P, const RsBuffers &B, uint32_t frame, uint32_t t)
+MI_HD uint4 rs_setup_thread(const DevScene &S, const FrameParams &P, const RsBuffers &B, uint32_t frame, uint32_t t)
 {
     constexpr int N = FatN<MODE>::N;
     const size_t slot = (size_t)frame * S.n_tris + t;
@@ -434,7 +414,7 @@ MI_HD uint2 rs_setup_thread(const DevScene &S, const FrameParams &P, const RsBuf
     for (int k = 0; k < 3; k++)
 #pragma unroll
         for (int i = 0; i < N; i++) f[k][i] = 0.f;
-    uint2 box = make_uint2(0xffffffffu, 0u);
+    uint4 box = make_uint4(0xffffffffu, 0u, 0u, 0u);
     if (tri_prepare<MODE>(S, P, t, f, iy)) {
         if (P.counters && P.raster_stats) RS_ATOMIC_ADD_U64(&P.counters[CS_TRIS_DRAWN], 1ull);
         int miny, maxy;
@@ -456,7 +436,8 @@ MI_HD uint2 rs_setup_thread(const DevScene &S, const FrameParams &P, const RsBuf
             if (xlo > fW1 || xhi < 0.f) any = false;       // entirely beside the frame
             if (any) {
                 const int tx0 = (int)xlo / RS_TW, tx1 = (int)xhi / RS_TW, ty0 = miny / RS_TH, ty1 = maxy / RS_TH;
-                box = make_uint2((uint32_t)tx0 | ((uint32_t)tx1 << 16), (uint32_t)ty0 | ((uint32_t)ty1 << 16));
+                box = make_uint4((uint32_t)tx0 | ((uint32_t)tx1 << 16), (uint32_t)ty0 | ((uint32_t)ty1 << 16),
+                                 (uint32_t)miny | ((uint32_t)maxy << 16), 0u);
             }
         }
     }
@@ -475,22 +456,40 @@ MI_HD uint2 rs_setup_thread(const DevScene &S, const FrameParams &P, const RsBuf
 }
 
 // tile rows a box covers = band records of the triangle
-MI_HD int rs_band_count(uint2 box) { return box.x == 0xffffffffu ? 0 : (int)(box.y >> 16) - (int)(box.y & 0xffffu) + 1; }
+MI_HD int rs_band_count(uint4 box) { return box.x == 0xffffffffu ? 0 : (int)(box.y >> 16) - (int)(box.y & 0xffffu) + 1; }
 
 // the triangle's band records start at `base` (rs_setup: after the block's allocation)
 MI_HD void rs_set_band_base(const RsBuffers &B, uint32_t n_tris, uint32_t frame, uint32_t t, uint32_t base)
 {
-    ((uint32_t *)(B.rec + ((size_t)frame * n_tris + t) * RS_REC4 + 6))[3] = base;
+    const size_t slot = (size_t)frame * n_tris + t;
+    ((uint32_t *)(B.rec + slot * RS_REC4 + 6))[3] = base;
+    ((uint32_t *)(B.box + slot))[3] = base;
 }
 
-// band record j (tile row ty0 + j), edge e of triangle t
-MI_HD void rs_band_fill(const RsBuffers &B, uint32_t n_tris, uint32_t frame, uint32_t t, uint32_t base, int j, int e, int height)
+// one interpolant of one edge of one band record: item p = (record * 3 + edge) * 8 + interpolant
+MI_HD void rs_band_item(const RsBuffers &B, uint32_t n_tris, uint32_t frame, uint32_t p, int height)
 {
-    if (base + (uint32_t)j >= B.band_cap) return;                 // (the frame reports the overflow)
-    const size_t slot = (size_t)frame * n_tris + t;
-    const int ty0 = (int)(B.box[slot].y & 0xffffu);
-    rs_band_edge((const float *)(B.rec + slot * RS_REC4), e, height, (ty0 + j) * RS_TH,
-                 B.band + ((size_t)frame * B.band_cap + base + (uint32_t)j) * RS_BAND4 + e * 4);
+    const uint32_t r = p / 24u;
+    const int e = (int)(p / 8u % 3u), c = (int)(p % 8u);
+    if (r >= B.band_cap) return;                                  // (the frame reports the overflow)
+    const uint2 own = B.band_owner[(size_t)frame * B.band_cap + r];
+    const size_t slot = (size_t)frame * n_tris + own.x;
+    const float *rec = (const float *)(B.rec + slot * RS_REC4);
+    const int iy[3] = {(int)ff_f2u(rec[24]), (int)ff_f2u(rec[25]), (int)ff_f2u(rec[26])};
+    const int ia = rs_edge_a(e), ib = rs_edge_b(e);
+    const RsEdgeRange R = rs_edge_range(iy[ia], iy[ib], height);
+    if (R.horiz || R.first > R.last) return;
+    const int Y0 = (int)own.y * RS_TH;
+    const int rb = R.first > Y0 ? R.first : Y0;
+    const int re = R.last < Y0 + RS_TH - 1 ? R.last : Y0 + RS_TH - 1;
+    if (rb > re) return;
+    const float a = rec[8 * (R.sw ? ib : ia) + c], b = rec[8 * (R.sw ? ia : ib) + c];
+    const float d = (b - a) / (float)(R.y2 - R.y1);
+    float x = a;
+    if (R.y1 < 0) x += d * (float)-R.y1;
+    float *out = (float *)(B.band + ((size_t)frame * B.band_cap + r) * RS_BAND4 + e * 4) + 2 * c;
+    out[0] = ff_add(x, d, rb - R.first);
+    out[1] = d;
 }
 
 // ---- rs_tile ------------------------------------------------------------------------------------------------------
@@ -498,9 +497,8 @@ MI_HD void rs_band_fill(const RsBuffers &B, uint32_t n_tris, uint32_t frame, uin
 struct RsTileLds {
     unsigned long long keys[RS_TPIX];          // (bits of 1/z) << 32 | ~triangle, 0 = background
     float gbuf[8][RS_TPIX];                    // winner's interpolants
-    uint32_t list[RS_LIST_CAP];                // triangles of the current pass whose box touches the tile
-    uint32_t stage[RS_THREADS][RS_STAGE + 1];  // depth data of the current chunk's triangles (+1: bank spread)
-    uint16_t items[RS_THREADS * RS_TH];        // (chunk slot << 4 | row of the tile) work items of the current chunk
+    uint32_t list[RS_LIST_CAP][3];             // triangles of the current pass whose box touches the tile: id, scanlines, first band record
+    uint16_t items[RS_CHUNK * RS_TH];          // (slot of the chunk << 4 | row of the tile) work items of the current chunk; then the runs
     uint32_t n_list, n_items[2];               // (two item counters: the idle one is reset while the other is in use)
     uint32_t n_runs;
 };
@@ -543,26 +541,20 @@ MI_HD void rs_tile_filter(const RsBuffers &B, uint32_t frame, int tx, int ty, co
     const uint4 *bins = B.bins + (size_t)frame * B.bins_cap;
     for (uint32_t e = first + (uint32_t)tid; e < end; e += RS_THREADS) {
         const uint4 b = bins[L.pos(e)];
-        const int tx0 = (int)(b.y & 0xffffu), tx1 = (int)(b.y >> 16), ty0 = (int)(b.z & 0xffffu), ty1 = (int)(b.z >> 16);
-        if (tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1) lds.list[RS_ATOMIC_ADD_U32(&lds.n_list, 1u)] = b.x;
+        const int tx0 = (int)(b.y & 0xffffu), tx1 = (int)(b.y >> 16), ty0 = (int)(b.z & 0xffffu) / RS_TH, ty1 = (int)(b.z >> 16) / RS_TH;
+        if (tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1) {
+            uint32_t *li = lds.list[RS_ATOMIC_ADD_U32(&lds.n_list, 1u)];
+            li[0] = b.x; li[1] = b.z; li[2] = b.w;
+        }
     }
 }
 
-// phase 2a (thread = slot of the chunk): triangle `chunk + tid` of the list -> what its depth items share into LDS, one
-// work item per scanline of the tile it touches
-template <int MODE>
-MI_HD void rs_tile_stage(const FrameParams &P, const RsBuffers &B, uint32_t n_tris, uint32_t frame, int ty, uint32_t chunk, uint32_t n_list,
-                         int parity, RsTileLds &lds, int tid)
+// phase 2a (thread = slot of the chunk): list entry `chunk + tid` -> one work item per scanline of the tile it touches
+MI_HD void rs_tile_stage(int ty, uint32_t chunk, uint32_t n_list, int parity, RsTileLds &lds, int tid)
 {
     const uint32_t e = chunk + (uint32_t)tid;
-    if (e >= n_list) return;
-    const uint32_t tri = lds.list[e];
-    const float4 r6 = B.rec[((size_t)frame * n_tris + tri) * RS_REC4 + 6];
-    uint32_t *st = lds.stage[tid];
-    st[0] = ff_f2u(r6.x); st[1] = ff_f2u(r6.y); st[2] = ff_f2u(r6.z); st[3] = ff_f2u(r6.w); st[4] = tri;
-    const int iy[3] = {(int)st[0], (int)st[1], (int)st[2]};
-    int miny, maxy;
-    if (!rs_tri_rows(iy, P.H, miny, maxy)) return;
+    if (tid >= RS_CHUNK || e >= n_list) return;
+    const int miny = (int)(lds.list[e][1] & 0xffffu), maxy = (int)(lds.list[e][1] >> 16);
     const int Y0 = ty * RS_TH;
     const int ys = miny > Y0 ? miny : Y0, ye = maxy < Y0 + RS_TH - 1 ? maxy : Y0 + RS_TH - 1;
     if (ys > ye) return;
@@ -570,11 +562,9 @@ MI_HD void rs_tile_stage(const FrameParams &P, const RsBuffers &B, uint32_t n_tr
     for (int y = ys; y <= ye; y++) lds.items[base + (uint32_t)(y - ys)] = (uint16_t)(((uint32_t)tid << 4) | (uint32_t)(y - Y0));
 }
 
-// the band record of tile row ty for a triangle whose records start at `base`
-MI_HD const float4 *rs_band_of(const RsBuffers &B, uint32_t frame, const int (&iy)[3], uint32_t base, int ty)
+// the band record of tile row ty for a triangle whose records start at `base` and whose first scanline is miny
+MI_HD const float4 *rs_band_of(const RsBuffers &B, uint32_t frame, int miny, uint32_t base, int ty)
 {
-    int miny = iy[0] < iy[1] ? iy[0] : iy[1]; miny = miny < iy[2] ? miny : iy[2];
-    if (miny < 0) miny = 0;
     uint32_t idx = base + (uint32_t)(ty - miny / RS_TH);
     if (idx >= B.band_cap) idx = B.band_cap - 1;                  // (overflowed frame: reported; stay inside the buffer)
     return B.band + ((size_t)frame * B.band_cap + idx) * RS_BAND4;
@@ -582,8 +572,8 @@ MI_HD const float4 *rs_band_of(const RsBuffers &B, uint32_t frame, const int (&i
 
 // phase 2b: one work item = one scanline of one triangle: Screen.h:244-290 restricted to the tile's columns, depth only
 template <int MODE>
-MI_HD void rs_tile_depth(const FrameParams &P, const RsBuffers &B, uint32_t n_tris, uint32_t frame, int tx, int ty, int parity, RsTileLds &lds,
-                         int tid, unsigned long long &ztests)
+MI_HD void rs_tile_depth(const FrameParams &P, const RsBuffers &B, uint32_t n_tris, uint32_t frame, int tx, int ty, uint32_t chunk, int parity,
+                         RsTileLds &lds, int tid, unsigned long long &ztests)
 {
     constexpr int ZI = FatZ<MODE>::ZI;
     const int W = P.W, H = P.H;
@@ -591,14 +581,14 @@ MI_HD void rs_tile_depth(const FrameParams &P, const RsBuffers &B, uint32_t n_tr
     const uint32_t n = lds.n_items[parity];
     for (uint32_t it = (uint32_t)tid; it < n; it += RS_THREADS) {
         const uint32_t item = lds.items[it];
-        const uint32_t *st = lds.stage[item >> 4];
+        const uint32_t *li = lds.list[chunk + (item >> 4)];
         const int row = (int)(item & 15u), y = ty * RS_TH + row;
         if (rs_out_row(P, y) < 0) continue;              // another GPU's band
-        const int iy[3] = {(int)st[0], (int)st[1], (int)st[2]};
-        const uint32_t tri = st[4];
+        const uint32_t tri = li[0];
+        const float *rec = (const float *)(B.rec + ((size_t)frame * n_tris + tri) * RS_REC4);
+        const int iy[3] = {(int)ff_f2u(rec[24]), (int)ff_f2u(rec[25]), (int)ff_f2u(rec[26])};
         float l[2], r[2];
-        const uint32_t cnt = rs_row_from_band(iy, rs_band_of(B, frame, iy, st[3], ty), (const float *)(B.rec + ((size_t)frame * n_tris + tri) * RS_REC4),
-                                              ZI, H, ty * RS_TH, y, l, r);
+        const uint32_t cnt = rs_row_from_band(iy, rs_band_of(B, frame, (int)(li[1] & 0xffffu), li[2], ty), rec, ZI, H, ty * RS_TH, y, l, r);
         if (!cnt) continue;
         RsSpan s;
         if (!rs_span(l[0], r[0], cnt, W, s)) continue;
@@ -650,7 +640,8 @@ MI_HD void rs_tile_attr(const FrameParams &P, const RsBuffers &B, uint32_t n_tri
         const int iy[3] = {(int)ff_f2u(rec[24]), (int)ff_f2u(rec[25]), (int)ff_f2u(rec[26])};
         const int y = ty * RS_TH + row, x = tx * RS_TW + px;
         float l[2], r[2];
-        const uint32_t cnt = rs_row_from_band(iy, rs_band_of(B, frame, iy, ff_f2u(rec[27]), ty), rec, k, P.H, ty * RS_TH, y, l, r);
+        int miny = iy[0] < iy[1] ? iy[0] : iy[1]; miny = miny < iy[2] ? miny : iy[2];
+        const uint32_t cnt = rs_row_from_band(iy, rs_band_of(B, frame, miny < 0 ? 0 : miny, ff_f2u(rec[27]), ty), rec, k, P.H, ty * RS_TH, y, l, r);
         RsSpan s;
         if (!cnt || !rs_span(l[0], r[0], cnt, P.W, s)) continue;            // (cannot happen: the key came from this scanline)
         float d = 0.f, v = l[1];

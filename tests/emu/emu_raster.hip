@@ -54,7 +54,7 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
     for (int f = 0; f < n_frames; f++) {                       // k_rs_setup
         for (int b = 0; b < g.n_bins; b++) B.cursor[(size_t)f * g.n_bins + b] = 0u;
         for (uint32_t t = 0; t < S.n_tris; t++) {
-            const uint2 box = rs_setup_thread<MODE>(S, F[f], B, (uint32_t)f, t);
+            const uint4 box = rs_setup_thread<MODE>(S, F[f], B, (uint32_t)f, t);
             if (box.x == 0xffffffffu) continue;
             for (int k = 0; k < rs_bin_count(box); k++) B.count[(size_t)f * g.n_bins + rs_bin_at(g, box, k)]++;
             const uint32_t base = B.band_top[f];
@@ -62,7 +62,7 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
             if (B.band_top[f] > B.band_cap && F[0].counters) F[0].counters[CS_OVERFLOW] += 1;
             rs_set_band_base(B, S.n_tris, (uint32_t)f, t, base);
             for (int j = 0; j < rs_band_count(box); j++)
-                for (int e = 0; e < 3; e++) rs_band_fill(B, S.n_tris, (uint32_t)f, t, base, j, e, F[f].H);
+                if (base + (uint32_t)j < B.band_cap) B.band_owner[(size_t)f * B.band_cap + base + j] = make_uint2(t, (box.y & 0xffffu) + (uint32_t)j);
         }
     }
     for (int f = 0; f < n_frames; f++) {                       // k_rs_scan
@@ -75,14 +75,18 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
     }
     for (int f = 0; f < n_frames; f++)                         // k_rs_fill
         for (uint32_t t = 0; t < S.n_tris; t++) {
-            const uint2 box = B.box[(size_t)f * S.n_tris + t];
+            const uint4 box = B.box[(size_t)f * S.n_tris + t];
             if (box.x == 0xffffffffu) continue;
             for (int k = 0; k < rs_bin_count(box); k++) {
                 const int bin = rs_bin_at(g, box, k);
                 const uint32_t at = B.offset[(size_t)f * (g.n_bins + 1) + bin] + B.cursor[(size_t)f * g.n_bins + bin]++;
-                if (at < B.bins_cap) B.bins[(size_t)f * B.bins_cap + at] = make_uint4(t, box.x, box.y, 0u);
+                if (at < B.bins_cap) B.bins[(size_t)f * B.bins_cap + at] = make_uint4(t, box.x, box.z, box.w);
             }
         }
+    for (int f = 0; f < n_frames; f++) {                       // k_rs_fill, second half: the band records
+        const uint32_t n_rec = B.band_top[f] < B.band_cap ? B.band_top[f] : B.band_cap;
+        for (uint32_t p = 0; p < n_rec * 24u; p++) rs_band_item(B, S.n_tris, (uint32_t)f, p, F[f].H);
+    }
     static RsTileLds lds;                                      // the block's LDS
     for (int f = 0; f < n_frames; f++)                         // k_rs_tile, one block per tile
         for (int ty = 0; ty < g.tiles_y; ty++)
@@ -102,11 +106,11 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
                     ALL_THREADS_REVERSED(rs_tile_filter(B, (uint32_t)f, tx, ty, L, first, lds, tid));      // (any thread order)
                     const uint32_t nl = lds.n_list;
                     any = any || nl != 0u;
-                    for (uint32_t chunk = 0; chunk < nl; chunk += RS_THREADS) {
-                        ALL_THREADS_REVERSED(rs_tile_stage<MODE>(F[f], B, S.n_tris, (uint32_t)f, ty, chunk, nl, parity, lds, tid));
-                        ALL_THREADS(rs_tile_depth<MODE>(F[f], B, S.n_tris, (uint32_t)f, tx, ty, parity, lds, tid, zt));
+                    for (uint32_t chunk = 0; chunk < nl; chunk += RS_CHUNK) {
+                        ALL_THREADS_REVERSED(rs_tile_stage(ty, chunk, nl, parity, lds, tid));
+                        ALL_THREADS(rs_tile_depth<MODE>(F[f], B, S.n_tris, (uint32_t)f, tx, ty, chunk, parity, lds, tid, zt));
                         lds.n_items[parity ^ 1] = 0u;
-                        if (chunk + RS_THREADS >= nl) lds.n_list = 0u;
+                        if (chunk + RS_CHUNK >= nl) lds.n_list = 0u;
                         parity ^= 1;
                     }
                 }
@@ -137,15 +141,16 @@ extern "C" int emu_raster(uint32_t n_tris, uint32_t n_verts, const float *rs_tri
     const RsGrid g = rs_grid(o->width, o->height);
     const size_t slots = (size_t)n_frames * (n_tris ? n_tris : 1);
     std::vector<float4> rec(slots * RS_REC4);
-    std::vector<uint2> box(slots);
+    std::vector<uint4> box(slots);
     std::vector<uint32_t> count((size_t)n_frames * g.n_bins, 0u), cursor((size_t)n_frames * g.n_bins, 0xdeadbeefu), offset((size_t)n_frames * (g.n_bins + 1), 0u);
     if (!bins_cap) bins_cap = n_tris * 3u + 4096u;
     std::vector<uint4> bins((size_t)bins_cap * n_frames, make_uint4(0xdeadbeefu, 0xdeadbeefu, 0xdeadbeefu, 0u));
     const uint32_t band_cap = band_cap_arg ? band_cap_arg : n_tris * 2u + 8192u;
     std::vector<float4> band((size_t)band_cap * n_frames * RS_BAND4, make_float4(-7.f, -7.f, -7.f, -7.f));
     std::vector<uint32_t> band_top((size_t)n_frames, 0u);
+    std::vector<uint2> band_owner((size_t)band_cap * n_frames, make_uint2(0xdeadbeefu, 0xdeadbeefu));
     RsBuffers B;
-    B.band = band.data(); B.band_cap = band_cap; B.band_top = band_top.data();
+    B.band = band.data(); B.band_cap = band_cap; B.band_top = band_top.data(); B.band_owner = band_owner.data();
     B.rec = rec.data(); B.box = box.data(); B.count = count.data(); B.cursor = cursor.data(); B.offset = offset.data(); B.bins = bins.data(); B.bins_cap = bins_cap;
     switch (mode) {
     case M_AMBIENT: run<M_AMBIENT>(S, F, g, B); break;
