@@ -26,6 +26,7 @@ struct RasterScratch {
     size_t bin_words = 0;          // capacity of B.count (B.offset has frames more)
     size_t bins_words = 0;         // capacity of B.bins in entries
     int count_bins = 0, count_frames = 0;   // geometry B.count was last cleared for
+    size_t order_words = 0;        // capacity of B.order
     size_t band_words = 0;         // capacity of B.band in records
     int band_frames = 0;
     FrameParams *d_frames = nullptr, *h_frames = nullptr; int frames_cap = 0;   // batched launches: per-frame parameters
@@ -270,6 +271,34 @@ __global__ void __launch_bounds__(1024) k_rs_scan(const RsGrid g, const RsBuffer
 
 #define RS_SCAN_LDS 2048          // frames with at most this many bins (1080p: 511, 4K: 2041): every block of k_rs_fill scans the counts itself
 
+// The tiles of a frame, those whose bins hold entries first: k_rs_tile starts with them and knows the others to be
+// background without reading anything.  One block; off = the frame's bin offsets; tot = 4 words of LDS.
+MI_DEV void tile_order(const RsGrid &g, const RsBuffers &B, uint32_t f, const uint32_t *off, uint32_t *tot)
+{
+    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t n = (uint32_t)g.n_tiles, per = (n + 255u) / 256u;
+    const uint32_t b = (uint32_t)tid * per < n ? (uint32_t)tid * per : n, e = b + per < n ? b + per : n;
+    const bool global_any = off[g.n_coarse + 1] != off[g.n_coarse];
+    auto active = [&](uint32_t tile) {
+        const int tx = (int)(tile % (uint32_t)g.tiles_x), ty = (int)(tile / (uint32_t)g.tiles_x);
+        const int cb = (ty / RS_CB) * g.cx + tx / RS_CB;
+        return global_any || off[cb + 1] != off[cb];
+    };
+    uint32_t mine = 0;
+    for (uint32_t i = b; i < e; i++) mine += active(i) ? 1u : 0u;
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += v; }
+    __syncthreads();
+    if (lane == 63) tot[wid] = incl;
+    __syncthreads();
+    uint32_t before = 0, n_active = 0;
+    for (int w = 0; w < 4; w++) { const uint32_t v = tot[w]; if (w < wid) before += v; n_active += v; }
+    uint32_t *order = B.order + (size_t)f * (n + 1);
+    uint32_t ia = before + incl - mine, ib = n_active + (b - ia);          // (tiles before b that are not active: b - ia)
+    for (uint32_t i = b; i < e; i++) { if (active(i)) order[1 + ia++] = i; else order[1 + ib++] = i; }
+    if (tid == 0) order[0] = n_active;
+}
+
 // Bin entries and band records.  LDS_SCAN: the bin offsets are the block's own exclusive scan of the frame's counts
 // (block 0 also stores them for k_rs_tile); otherwise they come from k_rs_scan.  Then every thread of the grid takes
 // band items (one interpolant of one edge of one record each) until they are done.
@@ -308,6 +337,7 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
             }
             off = soff;
         }
+        if (blockIdx.x == 0) tile_order(g, B, f, off, stot);      // (off: this block's scan, or k_rs_scan's)
         uint4 box = make_uint4(0xffffffffu, 0u, 0u, 0u);
         if (t < n_tris) box = B.box[(size_t)f * n_tris + t];
         const uint32_t total = block_pairs_begin(bp, box, box.x == 0xffffffffu ? 0 : rs_bin_count(box));
@@ -333,12 +363,11 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
     for (uint32_t p = blockIdx.x * blockDim.x + (uint32_t)tid; p < n_items; p += gridDim.x * blockDim.x) rs_band_item(B, n_tris, f, p, height);
 }
 
-// Phase profile of counting frames (collect_stats): sums over the blocks of the cycles between the barriers, into the
-// counters behind CS_PROF0: [0] bins + clear, [1] filter, [2] stage, [3] depth, [4] runs, [5] attributes, [6] shade,
-// [7] whole block, [8] blocks with entries, [9] longest block, [10] triangles kept by the filters, [11] depth items,
-// [12] runs, [13] bin entries read.
-#define RS_PROF_MARK(i) do { if (prof) { __syncthreads(); if (tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
-    atomicAdd(&P.counters[CS_PROF0 + (i)], now_ - t_mark); t_mark = now_; } } } while (0)
+// Phase profile of counting frames (collect_stats): thread 0 of every block sums the cycles between the barriers and adds
+// them to the counters behind CS_PROF0 when it is done: [0] bins + clear, [1] filter, [2] stage, [3] depth, [4] runs,
+// [5] attributes, [6] shade, [7] tiles with entries (whole), [8] their number, [9] the longest, [10] triangles kept by the
+// filters, [11] depth items, [12] runs, [13] bin entries read, [14] background tiles (cycles), [15] their number.
+#define RS_PROF_MARK(i) do { if (prof && tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); acc[i] += now_ - t_mark; t_mark = now_; } } while (0)
 
 template <int MODE>
 __global__ void __launch_bounds__(RS_THREADS) k_rs_tile(const DevScene S, const FrameParams P, const FrameParams *batch, int n_frames,
@@ -346,64 +375,83 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_tile(const DevScene S, const 
 {
     __shared__ RsTileLds lds;
     const int tid = (int)threadIdx.x;
-    const uint32_t w = blockIdx.x;
-    const uint32_t f = w % (uint32_t)n_frames, tile = w / (uint32_t)n_frames;
-    const int tx = (int)(tile % (uint32_t)g.tiles_x), ty = (int)(tile / (uint32_t)g.tiles_x);
-    const FrameParams &F = batch ? batch[f] : P;
     const bool prof = P.counters && P.raster_stats;
-    unsigned long long t_mark = prof ? __builtin_readcyclecounter() : 0ull;
-    const unsigned long long t_begin = t_mark;
-    if (tile == 0) {                                      // the next frame's rs_setup counts from zero
-        for (uint32_t i = (uint32_t)tid; i < (uint32_t)g.n_bins; i += RS_THREADS) B.count[(size_t)f * g.n_bins + i] = 0u;
-        if (tid == 0) B.band_top[f] = 0u;
-    }
-    const RsTileBins L = rs_tile_bins(g, B, f, tx, ty);
-    const uint32_t total = L.total();
-    if (!total) { rs_tile_blank(F, tx, ty, tid); return; }
+    unsigned long long acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0ull;
     unsigned long long ztests = 0, plots = 0;
-    rs_tile_clear(lds, tid);
-    __syncthreads();
-    RS_PROF_MARK(0);
-    bool any = false;
-    int parity = 0;
-    for (uint32_t first = 0; first < total; first += RS_LIST_CAP) {
-        rs_tile_filter(B, f, tx, ty, L, first, lds, tid);
+    const uint32_t total_tiles = (uint32_t)n_frames * (uint32_t)g.n_tiles;
+    for (uint32_t w = blockIdx.x; w < total_tiles; w += gridDim.x) {
+        const uint32_t f = w % (uint32_t)n_frames, slot = w / (uint32_t)n_frames;
+        const uint32_t *order = B.order + (size_t)f * ((size_t)g.n_tiles + 1);
+        const uint32_t tile = order[1 + slot];
+        const int tx = (int)(tile % (uint32_t)g.tiles_x), ty = (int)(tile / (uint32_t)g.tiles_x);
+        const FrameParams &F = batch ? batch[f] : P;
+        unsigned long long t_mark = prof ? __builtin_readcyclecounter() : 0ull;
+        const unsigned long long t_begin = t_mark;
+        if (slot == 0) {                                      // the next frame's rs_setup counts from zero
+            for (uint32_t i = (uint32_t)tid; i < (uint32_t)g.n_bins; i += RS_THREADS) B.count[(size_t)f * g.n_bins + i] = 0u;
+            if (tid == 0) B.band_top[f] = 0u;
+        }
+        if (slot >= order[0]) {                               // no bin entries: background
+            rs_tile_blank(F, tx, ty, tid);
+            if (prof && tid == 0) { acc[14] += __builtin_readcyclecounter() - t_begin; acc[15]++; }
+            continue;
+        }
+        const RsTileBins L = rs_tile_bins(g, B, f, tx, ty);
+        const uint32_t total = L.total();
+        rs_tile_clear(lds, tid);
         __syncthreads();
-        RS_PROF_MARK(1);
-        const uint32_t nl = lds.n_list;
-        any = any || nl != 0u;
-        if (prof && tid == 0) atomicAdd(&P.counters[CS_PROF0 + 10], (unsigned long long)nl);
-        for (uint32_t chunk = 0; chunk < nl; chunk += RS_CHUNK) {
-            rs_tile_stage(ty, chunk, nl, parity, lds, tid);
+        RS_PROF_MARK(0);
+        bool any = false;
+        int parity = 0;
+        for (uint32_t first = 0; first < total; first += RS_LIST_CAP) {
+            rs_tile_filter(B, f, tx, ty, L, first, lds, tid);
             __syncthreads();
-            RS_PROF_MARK(2);
-            if (prof && tid == 0) atomicAdd(&P.counters[CS_PROF0 + 11], (unsigned long long)lds.n_items[parity]);
-            rs_tile_depth<MODE>(F, B, S.n_tris, f, tx, ty, chunk, parity, lds, tid, ztests);
-            if (tid == 0) { lds.n_items[parity ^ 1] = 0u; if (chunk + RS_CHUNK >= nl) lds.n_list = 0u; }
-            parity ^= 1;
+            RS_PROF_MARK(1);
+            const uint32_t nl = lds.n_list;
+            any = any || nl != 0u;
+            if (prof && tid == 0) acc[10] += nl;
+            for (uint32_t chunk = 0; chunk < nl; chunk += RS_CHUNK) {
+                rs_tile_stage(ty, chunk, nl, parity, lds, tid);
+                __syncthreads();
+                RS_PROF_MARK(2);
+                if (prof && tid == 0) acc[11] += lds.n_items[parity];
+                rs_tile_depth<MODE>(F, B, S.n_tris, f, tx, ty, chunk, parity, lds, tid, ztests);
+                if (tid == 0) { lds.n_items[parity ^ 1] = 0u; if (chunk + RS_CHUNK >= nl) lds.n_list = 0u; }
+                parity ^= 1;
+                __syncthreads();
+                RS_PROF_MARK(3);
+            }
+        }
+        if (prof && tid == 0) acc[13] += total;
+        if (any) {
+            rs_tile_runs(lds, tid);
             __syncthreads();
-            RS_PROF_MARK(3);
+            RS_PROF_MARK(4);
+            if (prof && tid == 0) acc[12] += lds.n_runs;
+            rs_tile_attr<MODE>(F, B, S.n_tris, f, tx, ty, lds, tid);
+            __syncthreads();
+            RS_PROF_MARK(5);
+            rs_tile_shade<MODE>(S, F, tx, ty, lds, tid, plots);
+        } else rs_tile_blank(F, tx, ty, tid);
+        __syncthreads();                                      // (the next tile clears the keys)
+        RS_PROF_MARK(6);
+        if (prof && tid == 0) {
+            const unsigned long long dt = __builtin_readcyclecounter() - t_begin;
+            acc[7] += dt; acc[8]++;
+            if (dt > acc[9]) acc[9] = dt;
         }
     }
-    if (prof && tid == 0) atomicAdd(&P.counters[CS_PROF0 + 13], (unsigned long long)total);
-    if (!any) { rs_tile_blank(F, tx, ty, tid); return; }
-    rs_tile_runs(lds, tid);
-    __syncthreads();
-    RS_PROF_MARK(4);
-    if (prof && tid == 0) atomicAdd(&P.counters[CS_PROF0 + 12], (unsigned long long)lds.n_runs);
-    rs_tile_attr<MODE>(F, B, S.n_tris, f, tx, ty, lds, tid);
-    __syncthreads();
-    RS_PROF_MARK(5);
-    rs_tile_shade<MODE>(S, F, tx, ty, lds, tid, plots);
-    RS_PROF_MARK(6);
     if (prof) {
         if (ztests) atomicAdd(&P.counters[CS_ZTESTS], ztests);
         if (plots) atomicAdd(&P.counters[CS_PLOTS], plots);
         if (tid == 0) {
-            const unsigned long long dt = __builtin_readcyclecounter() - t_begin;
-            atomicAdd(&P.counters[CS_PROF0 + 7], dt);
-            atomicAdd(&P.counters[CS_PROF0 + 8], 1ull);
-            atomicMax(&P.counters[CS_PROF0 + 9], dt);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if (i == 9) atomicMax(&P.counters[CS_PROF0 + 9], acc[9]);
+                else if (acc[i]) atomicAdd(&P.counters[CS_PROF0 + i], acc[i]);
+            }
         }
     }
 }
@@ -488,7 +536,7 @@ extern "C" RasterScratch *mi355i_raster_scratch_create(void) { return new Raster
 extern "C" void mi355i_raster_scratch_destroy(RasterScratch *s)
 {
     if (!s) return;
-    for (void *p : {(void *)s->B.rec, (void *)s->B.box, (void *)s->B.count, (void *)s->B.cursor, (void *)s->B.offset, (void *)s->B.bins, (void *)s->B.band, (void *)s->B.band_top, (void *)s->B.band_owner,
+    for (void *p : {(void *)s->B.rec, (void *)s->B.box, (void *)s->B.count, (void *)s->B.cursor, (void *)s->B.offset, (void *)s->B.bins, (void *)s->B.band, (void *)s->B.band_top, (void *)s->B.band_owner, (void *)s->B.order,
                     (void *)s->d_frames, (void *)s->rows, (void *)s->ctl, (void *)s->smkeys})
         if (p) (void)hipFree(p);
     if (s->h_frames) (void)hipHostFree(s->h_frames);
@@ -529,6 +577,13 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
         if ((e = hipMalloc((void **)&s->B.cursor, words * 4)) != hipSuccess) return e;
         if ((e = hipMalloc((void **)&s->B.offset, (words + (size_t)n_frames) * 4)) != hipSuccess) return e;
         s->bin_words = words;
+    }
+    const size_t order_words = (size_t)n_frames * ((size_t)g.n_tiles + 1);
+    if (order_words > s->order_words || !s->B.order) {
+        if (s->B.order) (void)hipFree(s->B.order);
+        s->B.order = nullptr; s->order_words = 0;
+        if ((e = hipMalloc((void **)&s->B.order, order_words * 4)) != hipSuccess) return e;
+        s->order_words = order_words;
     }
     // k_rs_tile leaves every count at zero for the next frame of the same geometry; a new geometry (or a frame that was
     // cut short) starts from a cleared array
@@ -573,6 +628,8 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
     return hipSuccess;
 }
 
+static int g_tile_blocks[16] = {0};      // resident blocks of k_rs_tile<MODE> on this device, by mode
+
 template <int MODE>
 static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const FrameParams *d_batch, int n_frames, RasterScratch *s,
                                 hipStream_t st)
@@ -590,8 +647,16 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
         hipLaunchKernelGGL(k_rs_scan, dim3(n_frames), dim3(1024), 0, st, g, s->B, P->counters);
         hipLaunchKernelGGL(k_rs_fill<false>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, P->H, P->counters);
     }
-    // one block per tile: the hardware hands tiles to CUs as blocks retire, an empty tile costs one short block
-    const long long blocks = (long long)n_frames * g.n_tiles;
+    // resident blocks walk the tiles in rs_fill's order: those with bin entries first, the background after them
+    if (!g_tile_blocks[MODE]) {
+        int nb = 0, dev = 0, cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_rs_tile<MODE>, RS_THREADS, 0) != hipSuccess || nb < 1) nb = 2;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        g_tile_blocks[MODE] = nb * cus;
+    }
+    long long blocks = (long long)n_frames * g.n_tiles;
+    if (blocks > g_tile_blocks[MODE]) blocks = g_tile_blocks[MODE];
     hipLaunchKernelGGL((k_rs_tile<MODE>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3(RS_THREADS), 0, st, *S, *P, d_batch, n_frames, g, s->B);
     return hipGetLastError();
 }
@@ -720,6 +785,6 @@ extern "C" uint32_t mi355i_raster_overflow(RasterScratch *s)
 extern "C" size_t mi355i_raster_scratch_bytes(const RasterScratch *s)
 {
     if (!s) return 0;
-    return s->rec_slots * (RS_REC4 * sizeof(float4) + sizeof(uint4)) + s->bin_words * 12 + s->bins_words * 16 + s->band_words * (RS_BAND4 * sizeof(float4) + sizeof(uint2)) +
+    return s->rec_slots * (RS_REC4 * sizeof(float4) + sizeof(uint4)) + s->bin_words * 12 + s->order_words * 4 + s->bins_words * 16 + s->band_words * (RS_BAND4 * sizeof(float4) + sizeof(uint2)) +
            (size_t)s->rows_cap * sizeof(RowRec) + s->sm_words * 4;
 }

@@ -95,6 +95,7 @@ struct RsBuffers {
     uint32_t band_cap;             // per frame
     uint32_t *band_top;            // [frames]               band records handed out (rs_setup; zeroed again by rs_tile)
     uint2 *band_owner;             // [frames][band_cap]     (triangle, tile row of its box) of each band record
+    uint32_t *order;               // [frames][n_tiles + 1]  [0] = number of tiles with bin entries, then those tiles, then the others (rs_fill)
 };
 
 // y -> output row, or -1 when the row belongs to another GPU's band

@@ -12,7 +12,7 @@ mesh = sys.argv[1] if len(sys.argv) > 1 else "chessboard.tri"
 s = R.Scene(R.assets.mesh_path(mesh))
 cam, lights, n = R.benchmark_frame(0)
 s.shadowmap_render(0, lights[0])
-names = ["bins+clear", "filter", "stage", "depth", "runs", "attr", "shade", "block_total", "active_blocks", "longest_block", "kept", "items", "runs", "entries_read"]
+names = ["bins+clear", "filter", "stage", "depth", "runs", "attr", "shade", "tile_total", "active_tiles", "longest_tile", "kept", "items", "runs", "entries_read"]
 for mode in (4, 6, 8):
     img, _, st = s.render(mode, cam, lights, n, R.default_opts(W, H, collect_stats=1))
     prof = (C.c_uint64 * 20)()
@@ -21,8 +21,8 @@ for mode in (4, 6, 8):
     nb = max(1, p[8])
     print("mode %d: kernel_ms %.3f (counting frame)" % (mode, st.kernel_ms))
     print("   per active block, cycles: " + ", ".join("%s %.0f" % (names[i], p[i] / nb) for i in range(8)))
-    print("   active blocks %d, longest block %d cycles; kept %d (%.1f / block), depth items %d (%.1f), runs %d (%.1f), bin entries read %d (%.1f)" % (
-        p[8], p[9], p[10], p[10] / nb, p[11], p[11] / nb, p[12], p[12] / nb, p[13], p[13] / nb))
+    print("   tiles with entries %d, longest %d cycles; kept %d (%.1f / tile), depth items %d (%.1f), runs %d (%.1f), bin entries read %d (%.1f); background tiles %d, %.0f cycles each" % (
+        p[8], p[9], p[10], p[10] / nb, p[11], p[11] / nb, p[12], p[12] / nb, p[13], p[13] / nb, p[15], p[14] / max(1, p[15])))
 dev = torch.device("cuda", 0); stream = torch.cuda.current_stream(dev)
 buf = torch.zeros((H, W), dtype=torch.int32, device=dev)
 cams = [R.benchmark_frame(k) for k in range(200)]
