@@ -440,7 +440,8 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_tile(const DevScene S, const 
         if (prof && tid == 0) {
             const unsigned long long dt = __builtin_readcyclecounter() - t_begin;
             acc[7] += dt; acc[8]++;
-            if (dt > acc[9]) acc[9] = dt;
+            const unsigned long long packed = (dt << 32) | ((unsigned long long)(total > 0xffffu ? 0xffffu : total) << 16) | (unsigned long long)(lds.n_runs & 0xffffu);
+            if (packed > acc[9]) acc[9] = packed;             // the longest tile with its bin entries and runs
         }
     }
     if (prof) {
@@ -628,8 +629,6 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
     return hipSuccess;
 }
 
-static int g_tile_blocks[16] = {0};      // resident blocks of k_rs_tile<MODE> on this device, by mode
-
 template <int MODE>
 static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const FrameParams *d_batch, int n_frames, RasterScratch *s,
                                 hipStream_t st)
@@ -647,16 +646,9 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
         hipLaunchKernelGGL(k_rs_scan, dim3(n_frames), dim3(1024), 0, st, g, s->B, P->counters);
         hipLaunchKernelGGL(k_rs_fill<false>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, P->H, P->counters);
     }
-    // resident blocks walk the tiles in rs_fill's order: those with bin entries first, the background after them
-    if (!g_tile_blocks[MODE]) {
-        int nb = 0, dev = 0, cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_rs_tile<MODE>, RS_THREADS, 0) != hipSuccess || nb < 1) nb = 2;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-        g_tile_blocks[MODE] = nb * cus;
-    }
+    // One block per tile, in rs_fill's order (tiles with bin entries first): the hardware hands the next tile to whichever
+    // CU retires a block, which balances unequal tiles better than a fixed assignment to resident blocks (measured).
     long long blocks = (long long)n_frames * g.n_tiles;
-    if (blocks > g_tile_blocks[MODE]) blocks = g_tile_blocks[MODE];
     hipLaunchKernelGGL((k_rs_tile<MODE>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3(RS_THREADS), 0, st, *S, *P, d_batch, n_frames, g, s->B);
     return hipGetLastError();
 }

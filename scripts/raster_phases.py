@@ -21,8 +21,9 @@ for mode in (4, 6, 8):
     nb = max(1, p[8])
     print("mode %d: kernel_ms %.3f (counting frame)" % (mode, st.kernel_ms))
     print("   per active block, cycles: " + ", ".join("%s %.0f" % (names[i], p[i] / nb) for i in range(8)))
+    print("   longest tile: %d cycles, %d bin entries read, %d runs" % (p[9] >> 32, (p[9] >> 16) & 0xffff, p[9] & 0xffff))
     print("   tiles with entries %d, longest %d cycles; kept %d (%.1f / tile), depth items %d (%.1f), runs %d (%.1f), bin entries read %d (%.1f); background tiles %d, %.0f cycles each" % (
-        p[8], p[9], p[10], p[10] / nb, p[11], p[11] / nb, p[12], p[12] / nb, p[13], p[13] / nb, p[15], p[14] / max(1, p[15])))
+        p[8], p[9] >> 32, p[10], p[10] / nb, p[11], p[11] / nb, p[12], p[12] / nb, p[13], p[13] / nb, p[15], p[14] / max(1, p[15])))
 dev = torch.device("cuda", 0); stream = torch.cuda.current_stream(dev)
 buf = torch.zeros((H, W), dtype=torch.int32, device=dev)
 cams = [R.benchmark_frame(k) for k in range(200)]
