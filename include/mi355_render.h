@@ -83,7 +83,7 @@ typedef struct {
      * [0] xmin   lanes waiting for a state transition before the wave services them (default 64: whole wave)
      * [1] rmin   idle lanes before the wave refills from the pixel dispenser (default 64: whole wave)
      * [2] chunk  pixel indices a wave takes from the dispenser at once
-     * [3] reserved
+     * [3] rasterizer (modes 4-8): threads per 16x16-pixel tile, 64..512 in whole waves (default 256)
      * [4] blocks per CU (0 = chosen from the launch size: 2, 3 or 4 waves per SIMD; >=3 also selects the 3- or 4-wave register build)
      * [5] flags  1 exact box test only | 2 row-major tile order | 4 walk the tree in the reference's
      *            fixed left-first order (default: near child first with distance culling when the tree

@@ -248,6 +248,7 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.ref_order = (flags & 4) ? 1 : 0;
     P.prof_ordered = (flags & 8) ? 1 : 0;
     P.blocks_per_cu = t[4] > 0 ? t[4] : 0;
+    P.rs_threads = t[3];
     P.exact_box = (flags & 1) ? 1 : 0;
     if (!c->boxes_tame) P.exact_box = 1;     // box coordinates outside the filtered test's validated range
     P.wave_prof = nullptr;

@@ -122,6 +122,7 @@ struct FrameParams {
     int32_t n_frames;          // frames rendered by this launch (1 unless batched)
     const uint32_t *tile_order; // dispenser index -> 8x8 tile id (heavy tiles first), or NULL = row-major
     int32_t blocks_per_cu;     // 0 = occupancy query
+    int32_t rs_threads;        // rasterizer: threads per tile block (0 = default)
 };
 
 enum CounterSlot {

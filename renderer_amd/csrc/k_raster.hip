@@ -370,11 +370,11 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
 #define RS_PROF_MARK(i) do { if (prof && tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); acc[i] += now_ - t_mark; t_mark = now_; } } while (0)
 
 template <int MODE>
-__global__ void __launch_bounds__(RS_THREADS) k_rs_tile(const DevScene S, const FrameParams P, const FrameParams *batch, int n_frames,
+__global__ void __launch_bounds__(RS_MAX_THREADS) k_rs_tile(const DevScene S, const FrameParams P, const FrameParams *batch, int n_frames,
                                                         const RsGrid g, const RsBuffers B)
 {
     __shared__ RsTileLds lds;
-    const int tid = (int)threadIdx.x;
+    const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
     const bool prof = P.counters && P.raster_stats;
     unsigned long long acc[16];
 #pragma unroll
@@ -390,23 +390,23 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_tile(const DevScene S, const 
         unsigned long long t_mark = prof ? __builtin_readcyclecounter() : 0ull;
         const unsigned long long t_begin = t_mark;
         if (slot == 0) {                                      // the next frame's rs_setup counts from zero
-            for (uint32_t i = (uint32_t)tid; i < (uint32_t)g.n_bins; i += RS_THREADS) B.count[(size_t)f * g.n_bins + i] = 0u;
+            for (uint32_t i = (uint32_t)tid; i < (uint32_t)g.n_bins; i += (uint32_t)nt) B.count[(size_t)f * g.n_bins + i] = 0u;
             if (tid == 0) B.band_top[f] = 0u;
         }
         if (slot >= order[0]) {                               // no bin entries: background
-            rs_tile_blank(F, tx, ty, tid);
+            rs_tile_blank(F, tx, ty, tid, nt);
             if (prof && tid == 0) { acc[14] += __builtin_readcyclecounter() - t_begin; acc[15]++; }
             continue;
         }
         const RsTileBins L = rs_tile_bins(g, B, f, tx, ty);
         const uint32_t total = L.total();
-        rs_tile_clear(lds, tid);
+        rs_tile_clear(lds, tid, nt);
         __syncthreads();
         RS_PROF_MARK(0);
         bool any = false;
         int parity = 0;
         for (uint32_t first = 0; first < total; first += RS_LIST_CAP) {
-            rs_tile_filter(B, f, tx, ty, L, first, lds, tid);
+            rs_tile_filter(B, f, tx, ty, L, first, lds, tid, nt);
             __syncthreads();
             RS_PROF_MARK(1);
             const uint32_t nl = lds.n_list;
@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_tile(const DevScene S, const 
                 __syncthreads();
                 RS_PROF_MARK(2);
                 if (prof && tid == 0) acc[11] += lds.n_items[parity];
-                rs_tile_depth<MODE>(F, B, S.n_tris, f, tx, ty, chunk, parity, lds, tid, ztests);
+                rs_tile_depth<MODE>(F, B, S.n_tris, f, tx, ty, chunk, parity, lds, tid, nt, ztests);
                 if (tid == 0) { lds.n_items[parity ^ 1] = 0u; if (chunk + RS_CHUNK >= nl) lds.n_list = 0u; }
                 parity ^= 1;
                 __syncthreads();
@@ -426,15 +426,15 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_tile(const DevScene S, const 
         }
         if (prof && tid == 0) acc[13] += total;
         if (any) {
-            rs_tile_runs(lds, tid);
+            rs_tile_runs(lds, tid, nt);
             __syncthreads();
             RS_PROF_MARK(4);
             if (prof && tid == 0) acc[12] += lds.n_runs;
-            rs_tile_attr<MODE>(F, B, S.n_tris, f, tx, ty, lds, tid);
+            rs_tile_attr<MODE>(F, B, S.n_tris, f, tx, ty, lds, tid, nt);
             __syncthreads();
             RS_PROF_MARK(5);
-            rs_tile_shade<MODE>(S, F, tx, ty, lds, tid, plots);
-        } else rs_tile_blank(F, tx, ty, tid);
+            rs_tile_shade<MODE>(S, F, tx, ty, lds, tid, nt, plots);
+        } else rs_tile_blank(F, tx, ty, tid, nt);
         __syncthreads();                                      // (the next tile clears the keys)
         RS_PROF_MARK(6);
         if (prof && tid == 0) {
@@ -649,7 +649,9 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     // One block per tile, in rs_fill's order (tiles with bin entries first): the hardware hands the next tile to whichever
     // CU retires a block, which balances unequal tiles better than a fixed assignment to resident blocks (measured).
     long long blocks = (long long)n_frames * g.n_tiles;
-    hipLaunchKernelGGL((k_rs_tile<MODE>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3(RS_THREADS), 0, st, *S, *P, d_batch, n_frames, g, s->B);
+    // threads per tile: mi355_opts::tune[3] (64..512, whole waves), default 256
+    const int nt = P->rs_threads >= 64 && P->rs_threads <= RS_MAX_THREADS && (P->rs_threads & 63) == 0 ? P->rs_threads : 256;
+    hipLaunchKernelGGL((k_rs_tile<MODE>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B);
     return hipGetLastError();
 }
 

@@ -38,7 +38,7 @@
 #define RS_CB 4               // a coarse bin covers RS_CB x RS_CB tiles
 #define RS_COARSE_MAX 64      // largest coarse box binned bin by bin; beyond: the global bin
 #define RS_REC4 7             // float4 per triangle record
-#define RS_THREADS 512
+#define RS_MAX_THREADS 512    // largest block k_rs_tile is built for (threads per tile: a launch parameter, FrameParams::chunk)
 #define RS_LIST_CAP 1024      // bin entries filtered per pass of a tile (LDS list of accepted triangles)
 #define RS_CHUNK 256          // list entries whose scanlines are one round of depth items
 #define RS_BAND4 12           // float4 per band record: 3 edges x 8 interpolants x (value, step), interpolants 2j, 2j+1 in one float4
@@ -527,20 +527,20 @@ MI_HD RsTileBins rs_tile_bins(const RsGrid &g, const RsBuffers &B, uint32_t fram
 }
 
 // phase 0 (thread = pixel): clear the tile's keys
-MI_HD void rs_tile_clear(RsTileLds &lds, int tid)
+MI_HD void rs_tile_clear(RsTileLds &lds, int tid, int nt)
 {
-    for (int i = tid; i < RS_TPIX; i += RS_THREADS) lds.keys[i] = 0ull;
+    for (int i = tid; i < RS_TPIX; i += nt) lds.keys[i] = 0ull;
     if (tid == 0) { lds.n_list = 0u; lds.n_items[0] = 0u; lds.n_items[1] = 0u; lds.n_runs = 0u; }
 }
 
 // phase 1: bin entries [first, first + RS_LIST_CAP) of the tile's bins -> LDS list of the triangles whose box touches the tile
-MI_HD void rs_tile_filter(const RsBuffers &B, uint32_t frame, int tx, int ty, const RsTileBins &L, uint32_t first, RsTileLds &lds, int tid)
+MI_HD void rs_tile_filter(const RsBuffers &B, uint32_t frame, int tx, int ty, const RsTileBins &L, uint32_t first, RsTileLds &lds, int tid, int nt)
 {
     const uint32_t n = L.total();
     uint32_t end = first + RS_LIST_CAP;
     if (end > n) end = n;
     const uint4 *bins = B.bins + (size_t)frame * B.bins_cap;
-    for (uint32_t e = first + (uint32_t)tid; e < end; e += RS_THREADS) {
+    for (uint32_t e = first + (uint32_t)tid; e < end; e += (uint32_t)nt) {
         const uint4 b = bins[L.pos(e)];
         const int tx0 = (int)(b.y & 0xffffu), tx1 = (int)(b.y >> 16), ty0 = (int)(b.z & 0xffffu) / RS_TH, ty1 = (int)(b.z >> 16) / RS_TH;
         if (tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1) {
@@ -574,13 +574,13 @@ MI_HD const float4 *rs_band_of(const RsBuffers &B, uint32_t frame, int miny, uin
 // phase 2b: one work item = one scanline of one triangle: Screen.h:244-290 restricted to the tile's columns, depth only
 template <int MODE>
 MI_HD void rs_tile_depth(const FrameParams &P, const RsBuffers &B, uint32_t n_tris, uint32_t frame, int tx, int ty, uint32_t chunk, int parity,
-                         RsTileLds &lds, int tid, unsigned long long &ztests)
+                         RsTileLds &lds, int tid, int nt, unsigned long long &ztests)
 {
     constexpr int ZI = FatZ<MODE>::ZI;
     const int W = P.W, H = P.H;
     const int X0 = tx * RS_TW, X1 = (X0 + RS_TW < W ? X0 + RS_TW : W) - 1;
     const uint32_t n = lds.n_items[parity];
-    for (uint32_t it = (uint32_t)tid; it < n; it += RS_THREADS) {
+    for (uint32_t it = (uint32_t)tid; it < n; it += (uint32_t)nt) {
         const uint32_t item = lds.items[it];
         const uint32_t *li = lds.list[chunk + (item >> 4)];
         const int row = (int)(item & 15u), y = ty * RS_TH + row;
@@ -610,9 +610,9 @@ MI_HD void rs_tile_depth(const FrameParams &P, const RsBuffers &B, uint32_t n_tr
 }
 
 // phase 3a (thread = pixel): list the runs of pixels one triangle owns on a scanline (pixel of the first | length - 1 << 8)
-MI_HD void rs_tile_runs(RsTileLds &lds, int tid)
+MI_HD void rs_tile_runs(RsTileLds &lds, int tid, int nt)
 {
-    for (int i = tid; i < RS_TPIX; i += RS_THREADS) {
+    for (int i = tid; i < RS_TPIX; i += nt) {
         const unsigned long long key = lds.keys[i];
         if (!key) continue;
         const uint32_t low = (uint32_t)(key & 0xffffffffull);
@@ -627,11 +627,11 @@ MI_HD void rs_tile_runs(RsTileLds &lds, int tid)
 // phase 3b: one work item = one interpolant of one run: the scanline's end points for {projx, interpolant} (projx orders
 // the edges), the span's value at the run's first pixel, then the run -- the same evaluation as the depth pass
 template <int MODE>
-MI_HD void rs_tile_attr(const FrameParams &P, const RsBuffers &B, uint32_t n_tris, uint32_t frame, int tx, int ty, RsTileLds &lds, int tid)
+MI_HD void rs_tile_attr(const FrameParams &P, const RsBuffers &B, uint32_t n_tris, uint32_t frame, int tx, int ty, RsTileLds &lds, int tid, int nt)
 {
     constexpr int N = FatN<MODE>::N;
     const uint32_t n = lds.n_runs * (uint32_t)(N - 1);
-    for (uint32_t it = (uint32_t)tid; it < n; it += RS_THREADS) {
+    for (uint32_t it = (uint32_t)tid; it < n; it += (uint32_t)nt) {
         const uint32_t run = lds.items[it / (uint32_t)(N - 1)];
         const int k = 1 + (int)(it % (uint32_t)(N - 1));          // (interpolant 0, projx, is not an attribute)
         const int i = (int)(run & 255u), len = (int)(run >> 8) + 1;
@@ -657,9 +657,9 @@ MI_HD void rs_tile_attr(const FrameParams &P, const RsBuffers &B, uint32_t n_tri
 }
 
 // a tile without entries: the background (Screen::ClearScreen, Rasterizers.cc:326)
-MI_HD void rs_tile_blank(const FrameParams &P, int tx, int ty, int tid)
+MI_HD void rs_tile_blank(const FrameParams &P, int tx, int ty, int tid, int nt)
 {
-    for (int i = tid; i < RS_TPIX; i += RS_THREADS) {
+    for (int i = tid; i < RS_TPIX; i += nt) {
         const int x = tx * RS_TW + (i % RS_TW), y = ty * RS_TH + (i / RS_TW);
         if (x >= P.W || y >= P.H) continue;
         const int orow = rs_out_row(P, y);
@@ -670,9 +670,9 @@ MI_HD void rs_tile_blank(const FrameParams &P, int tx, int ty, int tid)
 // phase 4 (thread = pixel): Screen::Plot<> (Screen.cc:34-56) for the colour-interpolating modes, IlluminatePixel +
 // LightingEquation (Screen.cc:77-93, LightingEq.h:45-170) for the Phong modes.  Every pixel of the tile is written.
 template <int MODE>
-MI_HD void rs_tile_shade(const DevScene &S, const FrameParams &P, int tx, int ty, const RsTileLds &lds, int tid, unsigned long long &plots)
+MI_HD void rs_tile_shade(const DevScene &S, const FrameParams &P, int tx, int ty, const RsTileLds &lds, int tid, int nt, unsigned long long &plots)
 {
-    for (int i = tid; i < RS_TPIX; i += RS_THREADS) {
+    for (int i = tid; i < RS_TPIX; i += nt) {
         const int x = tx * RS_TW + (i % RS_TW), y = ty * RS_TH + (i / RS_TW);
         if (x >= P.W || y >= P.H) continue;
         const int orow = rs_out_row(P, y);

@@ -28,10 +28,12 @@ dev = torch.device("cuda", 0); stream = torch.cuda.current_stream(dev)
 buf = torch.zeros((H, W), dtype=torch.int32, device=dev)
 cams = [R.benchmark_frame(k) for k in range(200)]
 out = {}
-for mode in (4, 6, 8):
+for nt in (64, 128, 256, 512):
+  for mode in (4, 6, 8):
     o = R.default_opts(W, H)
+    o.tune[3] = nt
     for k in range(5): s.render_device(mode, *cams[k], o, buf.data_ptr(), W * 4, 0, stream.cuda_stream)
     torch.cuda.synchronize(dev); t = time.perf_counter()
     for k in range(200): s.render_device(mode, *cams[k], o, buf.data_ptr(), W * 4, 0, stream.cuda_stream)
-    torch.cuda.synchronize(dev); out["mode%d_fps" % mode] = round(200 / (time.perf_counter() - t), 1)
+    torch.cuda.synchronize(dev); out["mode%d_nt%d_fps" % (mode, nt)] = round(200 / (time.perf_counter() - t), 1)
 print(json.dumps(out))

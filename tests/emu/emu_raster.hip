@@ -44,6 +44,7 @@ void fill(FrameParams &P, const mi355_camera &cam, const mi355_light *lights, in
     P.out = out; P.pitch_words = pitch_words;
     P.counters = counters;
     P.raster_stats = o.collect_stats ? 1 : 0;
+    P.rs_threads = o.tune[3];
     P.n_frames = 1;
 }
 
@@ -51,6 +52,7 @@ template <int MODE>
 void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, RsBuffers &B)
 {
     const int n_frames = (int)F.size();
+    const int nt = F[0].rs_threads >= 64 && F[0].rs_threads <= RS_MAX_THREADS && (F[0].rs_threads & 63) == 0 ? F[0].rs_threads : 256;   // threads per tile (tune[3])
     for (int f = 0; f < n_frames; f++) {                       // k_rs_setup
         for (int b = 0; b < g.n_bins; b++) B.cursor[(size_t)f * g.n_bins + b] = 0u;
         for (uint32_t t = 0; t < S.n_tris; t++) {
@@ -95,29 +97,29 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
                 const RsTileBins L = rs_tile_bins(g, B, (uint32_t)f, tx, ty);
                 const uint32_t total = L.total();
                 unsigned long long zt = 0, plots = 0;
-#define ALL_THREADS(stmt) for (int tid = 0; tid < RS_THREADS; tid++) { stmt; }
-#define ALL_THREADS_REVERSED(stmt) for (int tid = RS_THREADS - 1; tid >= 0; tid--) { stmt; }
-                if (!total) { ALL_THREADS(rs_tile_blank(F[f], tx, ty, tid)); continue; }
+#define ALL_THREADS(stmt) for (int tid = 0; tid < nt; tid++) { stmt; }
+#define ALL_THREADS_REVERSED(stmt) for (int tid = nt - 1; tid >= 0; tid--) { stmt; }
+                if (!total) { ALL_THREADS(rs_tile_blank(F[f], tx, ty, tid, nt)); continue; }
                 memset(&lds, 0xcd, sizeof lds);                // LDS is not initialised on the device either
-                ALL_THREADS(rs_tile_clear(lds, tid));
+                ALL_THREADS(rs_tile_clear(lds, tid, nt));
                 bool any = false;
                 int parity = 0;
                 for (uint32_t first = 0; first < total; first += RS_LIST_CAP) {
-                    ALL_THREADS_REVERSED(rs_tile_filter(B, (uint32_t)f, tx, ty, L, first, lds, tid));      // (any thread order)
+                    ALL_THREADS_REVERSED(rs_tile_filter(B, (uint32_t)f, tx, ty, L, first, lds, tid, nt));      // (any thread order)
                     const uint32_t nl = lds.n_list;
                     any = any || nl != 0u;
                     for (uint32_t chunk = 0; chunk < nl; chunk += RS_CHUNK) {
                         ALL_THREADS_REVERSED(rs_tile_stage(ty, chunk, nl, parity, lds, tid));
-                        ALL_THREADS(rs_tile_depth<MODE>(F[f], B, S.n_tris, (uint32_t)f, tx, ty, chunk, parity, lds, tid, zt));
+                        ALL_THREADS(rs_tile_depth<MODE>(F[f], B, S.n_tris, (uint32_t)f, tx, ty, chunk, parity, lds, tid, nt, zt));
                         lds.n_items[parity ^ 1] = 0u;
                         if (chunk + RS_CHUNK >= nl) lds.n_list = 0u;
                         parity ^= 1;
                     }
                 }
-                if (!any) { ALL_THREADS(rs_tile_blank(F[f], tx, ty, tid)); continue; }
-                ALL_THREADS_REVERSED(rs_tile_runs(lds, tid));
-                ALL_THREADS(rs_tile_attr<MODE>(F[f], B, S.n_tris, (uint32_t)f, tx, ty, lds, tid));
-                ALL_THREADS(rs_tile_shade<MODE>(S, F[f], tx, ty, lds, tid, plots));
+                if (!any) { ALL_THREADS(rs_tile_blank(F[f], tx, ty, tid, nt)); continue; }
+                ALL_THREADS_REVERSED(rs_tile_runs(lds, tid, nt));
+                ALL_THREADS(rs_tile_attr<MODE>(F[f], B, S.n_tris, (uint32_t)f, tx, ty, lds, tid, nt));
+                ALL_THREADS(rs_tile_shade<MODE>(S, F[f], tx, ty, lds, tid, nt, plots));
                 if (F[0].counters && F[0].raster_stats) { F[0].counters[CS_ZTESTS] += zt; F[0].counters[CS_PLOTS] += plots; }
             }
 }
