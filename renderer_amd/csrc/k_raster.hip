@@ -208,10 +208,18 @@ __global__ void __launch_bounds__(256) k_rs_setup(const DevScene S, const FrameP
     __shared__ BlockPairs bp;
     __shared__ uint32_t band_base;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
-    if (blockIdx.x == 0)                                  // rs_fill's cursors start at zero
+    const FrameParams &F = batch ? batch[f] : P;
+    if (blockIdx.x == 0) {                                // rs_fill's cursors and rs_tile's dispenser start at zero
         for (uint32_t i = threadIdx.x; i < (uint32_t)g.n_bins; i += blockDim.x) B.cursor[(size_t)f * g.n_bins + i] = 0u;
+        if (f == 0 && threadIdx.x == 0) B.band_top[gridDim.y] = 0u;
+    }
+    {   // this block's share of the background: the tile kernel only visits tiles that hold triangles
+        const unsigned long long total = (unsigned long long)F.out_rows * (unsigned long long)F.W;
+        const unsigned long long per = (total + gridDim.x - 1) / gridDim.x;
+        rs_clear_out(F, per * blockIdx.x, per, (int)threadIdx.x, (int)blockDim.x);
+    }
     uint4 box = make_uint4(0xffffffffu, 0u, 0u, 0u);
-    if (t < S.n_tris) box = rs_setup_thread<MODE>(S, batch ? batch[f] : P, B, f, t);
+    if (t < S.n_tris) box = rs_setup_thread<MODE>(S, F, B, f, t);
     const uint32_t total = block_pairs_begin(bp, box, box.x == 0xffffffffu ? 0 : rs_bin_count(box));
     uint32_t *cnt = B.count + (size_t)f * g.n_bins;
     for (uint32_t base = 0; base < total; base += 256u) {
@@ -360,7 +368,12 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
     uint32_t n_rec = B.band_top[f];
     if (n_rec > B.band_cap) n_rec = B.band_cap;
     const uint32_t n_items = n_rec * 24u;
-    for (uint32_t p = blockIdx.x * blockDim.x + (uint32_t)tid; p < n_items; p += gridDim.x * blockDim.x) rs_band_item(B, n_tris, f, p, height);
+    // (the blocks that filled bins are late already: the others take the band items when there are enough of them)
+    const uint32_t fill_blocks = (n_tris + blockDim.x - 1) / blockDim.x;
+    uint32_t first_block = 0, n_blocks = gridDim.x;
+    if (gridDim.x >= 2u * fill_blocks) { first_block = fill_blocks; n_blocks = gridDim.x - fill_blocks; }
+    if (blockIdx.x < first_block) return;
+    for (uint32_t p = (blockIdx.x - first_block) * blockDim.x + (uint32_t)tid; p < n_items; p += n_blocks * blockDim.x) rs_band_item(B, n_tris, f, p, height);
 }
 
 // Phase profile of counting frames (collect_stats): thread 0 of every block sums the cycles between the barriers and adds
@@ -380,24 +393,28 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) k_rs_tile(const DevScene S, co
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0ull;
     unsigned long long ztests = 0, plots = 0;
-    const uint32_t total_tiles = (uint32_t)n_frames * (uint32_t)g.n_tiles;
-    for (uint32_t w = blockIdx.x; w < total_tiles; w += gridDim.x) {
+    // Work items: slot s of frame f = the s-th tile of the frame that holds triangles (rs_fill's order), frames
+    // interleaved; the block's first item is its index, further ones come from a dispenser (batches, frames with more
+    // such tiles than the grid).  Everything else is background, cleared by rs_setup.
+    __shared__ uint32_t next_w;
+    uint32_t max_active = 0;
+    for (int ff = 0; ff < n_frames; ff++) { const uint32_t a = B.order[(size_t)ff * ((size_t)g.n_tiles + 1)]; max_active = a > max_active ? a : max_active; }
+    const uint32_t total_items = max_active * (uint32_t)n_frames;
+    if (blockIdx.x == 0)                                      // the next frame's rs_setup counts from zero
+        for (int ff = 0; ff < n_frames; ff++) {
+            for (uint32_t i = (uint32_t)tid; i < (uint32_t)g.n_bins; i += (uint32_t)nt) B.count[(size_t)ff * g.n_bins + i] = 0u;
+            if (tid == 0) B.band_top[ff] = 0u;
+        }
+    for (uint32_t w = blockIdx.x; w < total_items;) {
         const uint32_t f = w % (uint32_t)n_frames, slot = w / (uint32_t)n_frames;
         const uint32_t *order = B.order + (size_t)f * ((size_t)g.n_tiles + 1);
+        if (tid == 0) next_w = gridDim.x + atomicAdd(&B.band_top[n_frames], 1u);     // (arrives while this tile is worked on)
+        if (slot >= order[0]) { __syncthreads(); const uint32_t nw = next_w; __syncthreads(); w = nw; continue; }
         const uint32_t tile = order[1 + slot];
         const int tx = (int)(tile % (uint32_t)g.tiles_x), ty = (int)(tile / (uint32_t)g.tiles_x);
         const FrameParams &F = batch ? batch[f] : P;
         unsigned long long t_mark = prof ? __builtin_readcyclecounter() : 0ull;
         const unsigned long long t_begin = t_mark;
-        if (slot == 0) {                                      // the next frame's rs_setup counts from zero
-            for (uint32_t i = (uint32_t)tid; i < (uint32_t)g.n_bins; i += (uint32_t)nt) B.count[(size_t)f * g.n_bins + i] = 0u;
-            if (tid == 0) B.band_top[f] = 0u;
-        }
-        if (slot >= order[0]) {                               // no bin entries: background
-            rs_tile_blank(F, tx, ty, tid, nt);
-            if (prof && tid == 0) { acc[14] += __builtin_readcyclecounter() - t_begin; acc[15]++; }
-            continue;
-        }
         const RsTileBins L = rs_tile_bins(g, B, f, tx, ty);
         const uint32_t total = L.total();
         rs_tile_clear(lds, tid, nt);
@@ -434,8 +451,10 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) k_rs_tile(const DevScene S, co
             __syncthreads();
             RS_PROF_MARK(5);
             rs_tile_shade<MODE>(S, F, tx, ty, lds, tid, nt, plots);
-        } else rs_tile_blank(F, tx, ty, tid, nt);
-        __syncthreads();                                      // (the next tile clears the keys)
+        }
+        const uint32_t nw = next_w;                           // (written by thread 0 at the top of this tile, barriers ago)
+        __syncthreads();                                      // (the next tile clears the keys and draws the next item)
+        w = nw;
         RS_PROF_MARK(6);
         if (prof && tid == 0) {
             const unsigned long long dt = __builtin_readcyclecounter() - t_begin;
@@ -590,7 +609,7 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
     // cut short) starts from a cleared array
     if (s->count_bins != g.n_bins || s->count_frames != n_frames) {
         if ((e = hipMemsetAsync(s->B.count, 0, words * 4, st)) != hipSuccess) return e;
-        if (s->B.band_top && (e = hipMemsetAsync(s->B.band_top, 0, (size_t)s->band_frames * 4, st)) != hipSuccess) return e;
+        if (s->B.band_top && (e = hipMemsetAsync(s->B.band_top, 0, ((size_t)s->band_frames + 1) * 4, st)) != hipSuccess) return e;
         s->count_bins = g.n_bins; s->count_frames = n_frames;
     }
     // Bin entries per frame (16 bytes each): three per triangle cover meshes of small triangles (chessboard, dragon:
@@ -619,11 +638,11 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
         s->band_words = (size_t)bcap * n_frames;
     }
     s->B.band_cap = (uint32_t)(s->band_words / (size_t)n_frames < bcap ? s->band_words / (size_t)n_frames : bcap);
-    if (n_frames > s->band_frames || !s->B.band_top) {
+    if (n_frames != s->band_frames || !s->B.band_top) {
         if (s->B.band_top) (void)hipFree(s->B.band_top);
         s->B.band_top = nullptr; s->band_frames = 0;
-        if ((e = hipMalloc((void **)&s->B.band_top, (size_t)n_frames * 4)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(s->B.band_top, 0, (size_t)n_frames * 4, st)) != hipSuccess) return e;
+        if ((e = hipMalloc((void **)&s->B.band_top, ((size_t)n_frames + 1) * 4)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(s->B.band_top, 0, ((size_t)n_frames + 1) * 4, st)) != hipSuccess) return e;
         s->band_frames = n_frames;
     }
     return hipSuccess;
@@ -646,9 +665,10 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
         hipLaunchKernelGGL(k_rs_scan, dim3(n_frames), dim3(1024), 0, st, g, s->B, P->counters);
         hipLaunchKernelGGL(k_rs_fill<false>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, P->H, P->counters);
     }
-    // One block per tile, in rs_fill's order (tiles with bin entries first): the hardware hands the next tile to whichever
-    // CU retires a block, which balances unequal tiles better than a fixed assignment to resident blocks (measured).
+    // Tiles that hold triangles are handed out by a dispenser (a fixed assignment to resident blocks balances unequal
+    // tiles badly: measured); 2048 blocks = eight per CU cover a 1080p frame's ~1100 such tiles with one tile per block.
     long long blocks = (long long)n_frames * g.n_tiles;
+    if (blocks > 2048) blocks = 2048;
     // threads per tile: mi355_opts::tune[3] (64..512, whole waves), default 256
     const int nt = P->rs_threads >= 64 && P->rs_threads <= RS_MAX_THREADS && (P->rs_threads & 63) == 0 ? P->rs_threads : 256;
     hipLaunchKernelGGL((k_rs_tile<MODE>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B);
@@ -668,19 +688,8 @@ static hipError_t raster_dispatch(const DevScene *S, const FrameParams *P, const
     return hipErrorInvalidValue;
 }
 
-// rows of a band-sharded, non-compact output that belong to other bands are defined as black (the tiles only write
-// this GPU's rows)
-static hipError_t clear_foreign_rows(const FrameParams *P, hipStream_t st)
-{
-    if (P->band_count > 1 && !P->compact)
-        return hipMemset2DAsync(P->out, (size_t)P->pitch_words * 4, 0, (size_t)P->W * 4, (size_t)P->out_rows, st);
-    return hipSuccess;
-}
-
 extern "C" hipError_t mi355i_launch_raster(const DevScene *S, const FrameParams *P, int mode, RasterScratch *s, hipStream_t st)
 {
-    hipError_t e = clear_foreign_rows(P, st);
-    if (e != hipSuccess) return e;
     return raster_dispatch(S, P, nullptr, 1, mode, s, st);
 }
 
@@ -702,8 +711,6 @@ extern "C" hipError_t mi355i_launch_raster_batch(const DevScene *S, const FrameP
     // the page-locked staging copy is reused from batch to batch: wait until the previous batch's upload has read it
     if (s->frames_pending && (e = hipEventSynchronize(s->frames_free)) != hipSuccess) return e;
     memcpy(s->h_frames, frames, sizeof(FrameParams) * (size_t)n_frames);
-    for (int f = 0; f < n_frames; f++)
-        if ((e = clear_foreign_rows(&frames[f], st)) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(s->d_frames, s->h_frames, sizeof(FrameParams) * (size_t)n_frames, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
     if ((e = hipEventRecord(s->frames_free, st)) != hipSuccess) return e;
     s->frames_pending = true;

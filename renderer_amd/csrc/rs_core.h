@@ -93,7 +93,8 @@ struct RsBuffers {
     uint32_t bins_cap;             // per frame
     float4 *band;                  // [frames][band_cap][RS_BAND4]  edge walkers of a triangle at the first scanline of a tile row
     uint32_t band_cap;             // per frame
-    uint32_t *band_top;            // [frames]               band records handed out (rs_setup; zeroed again by rs_tile)
+    uint32_t *band_top;            // [frames + 1]           band records handed out (rs_setup; zeroed again by rs_tile); the last
+                                   //                        word: k_rs_tile's tile dispenser (zeroed by rs_setup)
     uint2 *band_owner;             // [frames][band_cap]     (triangle, tile row of its box) of each band record
     uint32_t *order;               // [frames][n_tiles + 1]  [0] = number of tiles with bin entries, then those tiles, then the others (rs_fill)
 };
@@ -369,6 +370,19 @@ MI_HD bool rs_tri_rows(const int (&iy)[3], int H, int &miny, int &maxy)
     if (miny < 0) miny = 0;
     if (maxy > H - 1) maxy = H - 1;
     return miny <= maxy;
+}
+
+// Screen::ClearScreen (Rasterizers.cc:326): words [first, first + count) of the frame's output rows (row-major over the
+// out_rows x W words the frame owns), strided over `nt` threads
+MI_HD void rs_clear_out(const FrameParams &P, unsigned long long first, unsigned long long count, int tid, int nt)
+{
+    const unsigned long long total = (unsigned long long)P.out_rows * (unsigned long long)P.W;
+    unsigned long long end = first + count;
+    if (end > total) end = total;
+    for (unsigned long long i = first + (unsigned long long)tid; i < end; i += (unsigned long long)nt) {
+        const unsigned long long r = i / (unsigned long long)P.W;
+        P.out[r * (unsigned long long)P.pitch_words + (i - r * (unsigned long long)P.W)] = 0u;
+    }
 }
 
 // ---- binning ------------------------------------------------------------------------------------------------------

@@ -55,6 +55,7 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
     const int nt = F[0].rs_threads >= 64 && F[0].rs_threads <= RS_MAX_THREADS && (F[0].rs_threads & 63) == 0 ? F[0].rs_threads : 256;   // threads per tile (tune[3])
     for (int f = 0; f < n_frames; f++) {                       // k_rs_setup
         for (int b = 0; b < g.n_bins; b++) B.cursor[(size_t)f * g.n_bins + b] = 0u;
+        for (int tid = 0; tid < 256; tid++) rs_clear_out(F[f], 0ull, (unsigned long long)F[f].out_rows * F[f].W, tid, 256);
         for (uint32_t t = 0; t < S.n_tris; t++) {
             const uint4 box = rs_setup_thread<MODE>(S, F[f], B, (uint32_t)f, t);
             if (box.x == 0xffffffffu) continue;
@@ -99,7 +100,7 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
                 unsigned long long zt = 0, plots = 0;
 #define ALL_THREADS(stmt) for (int tid = 0; tid < nt; tid++) { stmt; }
 #define ALL_THREADS_REVERSED(stmt) for (int tid = nt - 1; tid >= 0; tid--) { stmt; }
-                if (!total) { ALL_THREADS(rs_tile_blank(F[f], tx, ty, tid, nt)); continue; }
+                if (!total) continue;                          // background: cleared by rs_setup
                 memset(&lds, 0xcd, sizeof lds);                // LDS is not initialised on the device either
                 ALL_THREADS(rs_tile_clear(lds, tid, nt));
                 bool any = false;
@@ -116,7 +117,7 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
                         parity ^= 1;
                     }
                 }
-                if (!any) { ALL_THREADS(rs_tile_blank(F[f], tx, ty, tid, nt)); continue; }
+                if (!any) continue;
                 ALL_THREADS_REVERSED(rs_tile_runs(lds, tid, nt));
                 ALL_THREADS(rs_tile_attr<MODE>(F[f], B, S.n_tris, (uint32_t)f, tx, ty, lds, tid, nt));
                 ALL_THREADS(rs_tile_shade<MODE>(S, F[f], tx, ty, lds, tid, nt, plots));
