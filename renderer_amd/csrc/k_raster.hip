@@ -213,11 +213,6 @@ __global__ void __launch_bounds__(256) k_rs_setup(const DevScene S, const FrameP
         for (uint32_t i = threadIdx.x; i < (uint32_t)g.n_bins; i += blockDim.x) B.cursor[(size_t)f * g.n_bins + i] = 0u;
         if (f == 0 && threadIdx.x == 0) B.band_top[gridDim.y] = 0u;
     }
-    {   // this block's share of the background: the tile kernel only visits tiles that hold triangles
-        const unsigned long long total = (unsigned long long)F.out_rows * (unsigned long long)F.W;
-        const unsigned long long per = (total + gridDim.x - 1) / gridDim.x;
-        rs_clear_out(F, per * blockIdx.x, per, (int)threadIdx.x, (int)blockDim.x);
-    }
     uint4 box = make_uint4(0xffffffffu, 0u, 0u, 0u);
     if (t < S.n_tris) box = rs_setup_thread<MODE>(S, F, B, f, t);
     const uint32_t total = block_pairs_begin(bp, box, box.x == 0xffffffffu ? 0 : rs_bin_count(box));
@@ -246,7 +241,7 @@ __global__ void __launch_bounds__(256) k_rs_setup(const DevScene S, const FrameP
         int owner = 0, j = 0;
         block_pair(bp, p, owner, j);
         if (band_base + p < B.band_cap)
-            owner_of[band_base + p] = make_uint2(blockIdx.x * blockDim.x + (uint32_t)owner, (bp.box[owner].y & 0xffffu) + (uint32_t)j);
+            owner_of[band_base + p] = make_uint2(blockIdx.x * blockDim.x + (uint32_t)owner, (bp.box[owner].z & 0xffffu) / RS_BH + (uint32_t)j);
     }
 }
 
@@ -311,8 +306,11 @@ MI_DEV void tile_order(const RsGrid &g, const RsBuffers &B, uint32_t f, const ui
 // (block 0 also stores them for k_rs_tile); otherwise they come from k_rs_scan.  Then every thread of the grid takes
 // band items (one interpolant of one edge of one record each) until they are done.
 template <bool LDS_SCAN>
-__global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers B, uint32_t n_tris, int height, unsigned long long *counters)
+__global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers B, uint32_t n_tris, const FrameParams P, const FrameParams *batch,
+                                                 unsigned long long *counters)
 {
+    const FrameParams &F = batch ? batch[blockIdx.y] : P;
+    const int height = F.H;
     __shared__ BlockPairs bp;
     __shared__ uint32_t soff[LDS_SCAN ? RS_SCAN_LDS + 1 : 1];
     __shared__ uint32_t stot[4];
@@ -373,6 +371,11 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
     uint32_t first_block = 0, n_blocks = gridDim.x;
     if (gridDim.x >= 2u * fill_blocks) { first_block = fill_blocks; n_blocks = gridDim.x - fill_blocks; }
     if (blockIdx.x < first_block) return;
+    {   // this block's share of the background (Screen::ClearScreen): the tile kernel only visits tiles that hold triangles
+        const unsigned long long total = (unsigned long long)F.out_rows * (unsigned long long)F.W;
+        const unsigned long long per = ((total + n_blocks - 1) / n_blocks + 3ull) & ~3ull;
+        rs_clear_out(F, per * (blockIdx.x - first_block), per, tid, (int)blockDim.x);
+    }
     for (uint32_t p = (blockIdx.x - first_block) * blockDim.x + (uint32_t)tid; p < n_items; p += n_blocks * blockDim.x) rs_band_item(B, n_tris, f, p, height);
 }
 
@@ -623,10 +626,11 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
         if ((e = regrow(s->B.bins, s->bins_words, (size_t)cap * n_frames)) != hipSuccess) return e;
     }
     s->B.bins_cap = (uint32_t)(s->bins_words / (size_t)n_frames < cap ? s->bins_words / (size_t)n_frames : cap);
-    // Band records per frame (192 bytes each): one per tile row a drawn triangle touches -- two per triangle cover meshes
-    // of small triangles (chessboard, dragon: ~1.4 per DRAWN triangle, half of the triangles face away); doubled after an overflow.
+    // Band records per frame (192 bytes each): one per RS_BH scanlines a drawn triangle touches -- two per triangle cover
+    // meshes of small triangles (chessboard, dragon: ~2 per DRAWN triangle, half of the triangles face away); doubled after
+    // an overflow.
     unsigned long long bcap = ((unsigned long long)n_tris * 2ull + 8192ull) << s->grow;
-    const unsigned long long bworst = (unsigned long long)n_tris * (unsigned long long)g.tiles_y + 16ull;
+    const unsigned long long bworst = (unsigned long long)n_tris * (unsigned long long)(g.tiles_y * (RS_TH / RS_BH)) + 16ull;
     if (bcap > bworst) bcap = bworst;
     if (bcap > 0x3ffffff0ull) bcap = 0x3ffffff0ull;
     if ((size_t)bcap * n_frames > s->band_words || !s->B.band) {
@@ -660,10 +664,10 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     hipLaunchKernelGGL((k_rs_setup<MODE>), per_tri, dim3(256), 0, st, *S, *P, d_batch, g, s->B);
     // (the fill kernel's grid also has to carry the band items: at least four blocks per CU)
     const dim3 fill_grid(per_tri.x > 1024u ? per_tri.x : 1024u, n_frames);
-    if (g.n_bins <= RS_SCAN_LDS) hipLaunchKernelGGL(k_rs_fill<true>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, P->H, P->counters);
+    if (g.n_bins <= RS_SCAN_LDS) hipLaunchKernelGGL(k_rs_fill<true>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters);
     else {
         hipLaunchKernelGGL(k_rs_scan, dim3(n_frames), dim3(1024), 0, st, g, s->B, P->counters);
-        hipLaunchKernelGGL(k_rs_fill<false>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, P->H, P->counters);
+        hipLaunchKernelGGL(k_rs_fill<false>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters);
     }
     // Tiles that hold triangles are handed out by a dispenser (a fixed assignment to resident blocks balances unequal
     // tiles badly: measured); 2048 blocks = eight per CU cover a 1080p frame's ~1100 such tiles with one tile per block.

@@ -41,6 +41,7 @@
 #define RS_MAX_THREADS 512    // largest block k_rs_tile is built for (threads per tile: a launch parameter, FrameParams::chunk)
 #define RS_LIST_CAP 1024      // bin entries filtered per pass of a tile (LDS list of accepted triangles)
 #define RS_CHUNK 256          // list entries whose scanlines are one round of depth items
+#define RS_BH 8               // scanlines per band record
 #define RS_BAND4 12           // float4 per band record: 3 edges x 8 interpolants x (value, step), interpolants 2j, 2j+1 in one float4
 
 enum { M_AMBIENT = 4, M_GOURAUD = 5, M_PHONG = 6, M_PHONG_SH = 7, M_PHONG_SOFT = 8, M_SHADOWMAP = 100 };
@@ -95,7 +96,7 @@ struct RsBuffers {
     uint32_t band_cap;             // per frame
     uint32_t *band_top;            // [frames + 1]           band records handed out (rs_setup; zeroed again by rs_tile); the last
                                    //                        word: k_rs_tile's tile dispenser (zeroed by rs_setup)
-    uint2 *band_owner;             // [frames][band_cap]     (triangle, tile row of its box) of each band record
+    uint2 *band_owner;             // [frames][band_cap]     (triangle, band = scanline / RS_BH) of each band record
     uint32_t *order;               // [frames][n_tiles + 1]  [0] = number of tiles with bin entries, then those tiles, then the others (rs_fill)
 };
 
@@ -231,30 +232,49 @@ MI_HD int rs_edge_b(int e) { return e == 0 ? 1 : 2; }
 // the band the edge feeds and its per-scanline step, for every interpolant -- the value is (rb - first) serial additions
 // `vtc += d12` away from the walk's start (ScanConverter.h:99-116): ff_add (rs_band_item below).
 
-// Scanline y of a triangle, interpolants {0 (projx), k}: left / right end points and ScanConverter's lines[y], from the
-// band record of the tile row y lies in (Y0 = its first scanline): each feeding edge's value is (y - rb) additions away
-// from the record's.  `pts` = the triangle's fat points as floats (used by horizontal edges only).
-MI_HD uint32_t rs_row_from_band(const int (&iy)[3], const float4 *band, const float *pts, int k, int height, int Y0, int y,
-                                float (&l)[2], float (&r)[2])
+// ScanConverter::ScanlineAdd on a register-held row whose first NC + 1 entries are in use (entry 0 = projx)
+template <int NC>
+MI_HD void scan_add_n(float (&l)[NC + 1], float (&r)[NC + 1], uint32_t &cnt, const float (&v)[NC + 1])
 {
+    scan_add<NC + 1>(l, r, cnt, v);
+}
+
+// Scanline y of a triangle, interpolants {0 (projx), k0 .. k0 + nc - 1} (nc <= NC): left / right end points and
+// ScanConverter's lines[y], from the band record of the band y lies in: each feeding edge's value is (y - rb) additions away
+// from the record's.  `pts` = the triangle's fat points as floats (used by horizontal edges only).
+template <int NC>
+MI_HD uint32_t rs_row_from_band(const int (&iy)[3], const float4 *band4, const float *pts, int k0, int nc, int height, int y,
+                                float (&l)[NC + 1], float (&r)[NC + 1])
+{
+    const float *band = (const float *)band4;
+    const int Y0 = (y / RS_BH) * RS_BH;
     uint32_t cnt = 0;
-    l[0] = l[1] = r[0] = r[1] = 0.f;
+#pragma unroll
+    for (int c = 0; c <= NC; c++) { l[c] = 0.f; r[c] = 0.f; }
 #pragma unroll
     for (int e = 0; e < 3; e++) {
         const int ia = rs_edge_a(e), ib = rs_edge_b(e);
         const RsEdgeRange R = rs_edge_range(iy[ia], iy[ib], height);
         if (y < R.first || y > R.last) continue;
         if (R.horiz) {
-            const float pa[2] = {pts[8 * ia], pts[8 * ia + k]}, pb[2] = {pts[8 * ib], pts[8 * ib + k]};
-            scan_add<2>(l, r, cnt, pa); scan_add<2>(l, r, cnt, pb);
+            float pa[NC + 1], pb[NC + 1];
+            pa[0] = pts[8 * ia]; pb[0] = pts[8 * ib];
+#pragma unroll
+            for (int c = 0; c < NC; c++) { pa[1 + c] = c < nc ? pts[8 * ia + k0 + c] : 0.f; pb[1 + c] = c < nc ? pts[8 * ib + k0 + c] : 0.f; }
+            scan_add_n<NC>(l, r, cnt, pa); scan_add_n<NC>(l, r, cnt, pb);
             continue;
         }
         const int rb = R.first > Y0 ? R.first : Y0;
-        const float4 q0 = band[e * 4], qk = band[e * 4 + (k >> 1)];
-        float v[2] = {q0.x, (k & 1) ? qk.z : qk.x};
-        const float d0 = q0.y, dk = (k & 1) ? qk.w : qk.y;
-        for (int j = y - rb; j > 0; j--) { v[0] += d0; v[1] += dk; }
-        scan_add<2>(l, r, cnt, v);
+        const float *be = band + e * 16;
+        float v[NC + 1], d[NC + 1];
+        v[0] = be[0]; d[0] = be[1];
+#pragma unroll
+        for (int c = 0; c < NC; c++) { v[1 + c] = c < nc ? be[2 * (k0 + c)] : 0.f; d[1 + c] = c < nc ? be[2 * (k0 + c) + 1] : 0.f; }
+        for (int j = y - rb; j > 0; j--) {
+#pragma unroll
+            for (int c = 0; c <= NC; c++) v[c] += d[c];
+        }
+        scan_add_n<NC>(l, r, cnt, v);
     }
     return cnt;
 }
@@ -379,6 +399,16 @@ MI_HD void rs_clear_out(const FrameParams &P, unsigned long long first, unsigned
     const unsigned long long total = (unsigned long long)P.out_rows * (unsigned long long)P.W;
     unsigned long long end = first + count;
     if (end > total) end = total;
+    if (!(P.W & 3) && !(P.pitch_words & 3) && !((unsigned long long)P.out & 15ull) && !(first & 3ull)) {
+        // whole 16-byte groups (a group never straddles a row: W is a multiple of four)
+        const unsigned long long g1 = end >> 2;
+        for (unsigned long long q = (first >> 2) + (unsigned long long)tid; q < g1; q += (unsigned long long)nt) {
+            const unsigned long long i = q << 2, r = i / (unsigned long long)P.W;
+            *(uint4 *)(P.out + r * (unsigned long long)P.pitch_words + (i - r * (unsigned long long)P.W)) = make_uint4(0u, 0u, 0u, 0u);
+        }
+        first = g1 << 2;                        // (the last share may end inside a group: word by word)
+        if (first >= end) return;
+    }
     for (unsigned long long i = first + (unsigned long long)tid; i < end; i += (unsigned long long)nt) {
         const unsigned long long r = i / (unsigned long long)P.W;
         P.out[r * (unsigned long long)P.pitch_words + (i - r * (unsigned long long)P.W)] = 0u;
@@ -470,8 +500,8 @@ MI_HD uint4 rs_setup_thread(const DevScene &S, const FrameParams &P, const RsBuf
     return box;
 }
 
-// tile rows a box covers = band records of the triangle
-MI_HD int rs_band_count(uint4 box) { return box.x == 0xffffffffu ? 0 : (int)(box.y >> 16) - (int)(box.y & 0xffffu) + 1; }
+// bands (RS_BH scanlines each) a triangle's scanlines touch = its band records
+MI_HD int rs_band_count(uint4 box) { return box.x == 0xffffffffu ? 0 : (int)(box.z >> 16) / RS_BH - (int)(box.z & 0xffffu) / RS_BH + 1; }
 
 // the triangle's band records start at `base` (rs_setup: after the block's allocation)
 MI_HD void rs_set_band_base(const RsBuffers &B, uint32_t n_tris, uint32_t frame, uint32_t t, uint32_t base)
@@ -494,9 +524,9 @@ MI_HD void rs_band_item(const RsBuffers &B, uint32_t n_tris, uint32_t frame, uin
     const int ia = rs_edge_a(e), ib = rs_edge_b(e);
     const RsEdgeRange R = rs_edge_range(iy[ia], iy[ib], height);
     if (R.horiz || R.first > R.last) return;
-    const int Y0 = (int)own.y * RS_TH;
+    const int Y0 = (int)own.y * RS_BH;
     const int rb = R.first > Y0 ? R.first : Y0;
-    const int re = R.last < Y0 + RS_TH - 1 ? R.last : Y0 + RS_TH - 1;
+    const int re = R.last < Y0 + RS_BH - 1 ? R.last : Y0 + RS_BH - 1;
     if (rb > re) return;
     const float a = rec[8 * (R.sw ? ib : ia) + c], b = rec[8 * (R.sw ? ia : ib) + c];
     const float d = (b - a) / (float)(R.y2 - R.y1);
@@ -577,10 +607,10 @@ MI_HD void rs_tile_stage(int ty, uint32_t chunk, uint32_t n_list, int parity, Rs
     for (int y = ys; y <= ye; y++) lds.items[base + (uint32_t)(y - ys)] = (uint16_t)(((uint32_t)tid << 4) | (uint32_t)(y - Y0));
 }
 
-// the band record of tile row ty for a triangle whose records start at `base` and whose first scanline is miny
-MI_HD const float4 *rs_band_of(const RsBuffers &B, uint32_t frame, int miny, uint32_t base, int ty)
+// the band record of scanline y for a triangle whose records start at `base` and whose first scanline is miny
+MI_HD const float4 *rs_band_of(const RsBuffers &B, uint32_t frame, int miny, uint32_t base, int y)
 {
-    uint32_t idx = base + (uint32_t)(ty - miny / RS_TH);
+    uint32_t idx = base + (uint32_t)(y / RS_BH - miny / RS_BH);
     if (idx >= B.band_cap) idx = B.band_cap - 1;                  // (overflowed frame: reported; stay inside the buffer)
     return B.band + ((size_t)frame * B.band_cap + idx) * RS_BAND4;
 }
@@ -603,7 +633,7 @@ MI_HD void rs_tile_depth(const FrameParams &P, const RsBuffers &B, uint32_t n_tr
         const float *rec = (const float *)(B.rec + ((size_t)frame * n_tris + tri) * RS_REC4);
         const int iy[3] = {(int)ff_f2u(rec[24]), (int)ff_f2u(rec[25]), (int)ff_f2u(rec[26])};
         float l[2], r[2];
-        const uint32_t cnt = rs_row_from_band(iy, rs_band_of(B, frame, (int)(li[1] & 0xffffu), li[2], ty), rec, ZI, H, ty * RS_TH, y, l, r);
+        const uint32_t cnt = rs_row_from_band<1>(iy, rs_band_of(B, frame, (int)(li[1] & 0xffffu), li[2], y), rec, ZI, 1, H, y, l, r);
         if (!cnt) continue;
         RsSpan s;
         if (!rs_span(l[0], r[0], cnt, W, s)) continue;
@@ -638,34 +668,41 @@ MI_HD void rs_tile_runs(RsTileLds &lds, int tid, int nt)
     }
 }
 
-// phase 3b: one work item = one interpolant of one run: the scanline's end points for {projx, interpolant} (projx orders
-// the edges), the span's value at the run's first pixel, then the run -- the same evaluation as the depth pass
+// phase 3b: one work item = one group of interpolants of one run: the scanline's end points for projx (it orders the
+// edges) and the group, the span's values at the run's first pixel, then the run -- the same evaluation as the depth pass.
+// Groups: {1,2,3} {4,5,6,7} of the Phong fat point, {1,2} {3,4} of the colour one.
 template <int MODE>
 MI_HD void rs_tile_attr(const FrameParams &P, const RsBuffers &B, uint32_t n_tris, uint32_t frame, int tx, int ty, RsTileLds &lds, int tid, int nt)
 {
     constexpr int N = FatN<MODE>::N;
-    const uint32_t n = lds.n_runs * (uint32_t)(N - 1);
+    constexpr int NC = N == 8 ? 4 : 2;
+    const uint32_t n = lds.n_runs * 2u;
     for (uint32_t it = (uint32_t)tid; it < n; it += (uint32_t)nt) {
-        const uint32_t run = lds.items[it / (uint32_t)(N - 1)];
-        const int k = 1 + (int)(it % (uint32_t)(N - 1));          // (interpolant 0, projx, is not an attribute)
+        const uint32_t run = lds.items[it >> 1];
+        const int grp = (int)(it & 1u);
+        const int k0 = N == 8 ? (grp ? 4 : 1) : (grp ? 3 : 1), nc = N == 8 ? (grp ? 4 : 3) : 2;
         const int i = (int)(run & 255u), len = (int)(run >> 8) + 1;
         const int px = i % RS_TW, row = i / RS_TW;
         const uint32_t tri = 0xffffffffu - (uint32_t)(lds.keys[i] & 0xffffffffull);
         const float *rec = (const float *)(B.rec + ((size_t)frame * n_tris + tri) * RS_REC4);
         const int iy[3] = {(int)ff_f2u(rec[24]), (int)ff_f2u(rec[25]), (int)ff_f2u(rec[26])};
         const int y = ty * RS_TH + row, x = tx * RS_TW + px;
-        float l[2], r[2];
+        float l[NC + 1], r[NC + 1];
         int miny = iy[0] < iy[1] ? iy[0] : iy[1]; miny = miny < iy[2] ? miny : iy[2];
-        const uint32_t cnt = rs_row_from_band(iy, rs_band_of(B, frame, miny < 0 ? 0 : miny, ff_f2u(rec[27]), ty), rec, k, P.H, ty * RS_TH, y, l, r);
+        const uint32_t cnt = rs_row_from_band<NC>(iy, rs_band_of(B, frame, miny < 0 ? 0 : miny, ff_f2u(rec[27]), y), rec, k0, nc, P.H, y, l, r);
         RsSpan s;
         if (!cnt || !rs_span(l[0], r[0], cnt, P.W, s)) continue;            // (cannot happen: the key came from this scanline)
-        float d = 0.f, v = l[1];
-        if (!s.single) v = rs_span_value(s, l[1], r[1], x - s.x1, d);
-        float *g = lds.gbuf[k] + i;
-        for (int j = 0;; j++) {
-            g[j] = v;
-            if (j == len - 1) break;
-            v += d;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            if (c >= nc) break;
+            float d = 0.f, v = l[1 + c];
+            if (!s.single) v = rs_span_value(s, l[1 + c], r[1 + c], x - s.x1, d);
+            float *g = lds.gbuf[k0 + c] + i;
+            for (int j = 0;; j++) {
+                g[j] = v;
+                if (j == len - 1) break;
+                v += d;
+            }
         }
     }
 }

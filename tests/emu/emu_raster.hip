@@ -65,7 +65,7 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
             if (B.band_top[f] > B.band_cap && F[0].counters) F[0].counters[CS_OVERFLOW] += 1;
             rs_set_band_base(B, S.n_tris, (uint32_t)f, t, base);
             for (int j = 0; j < rs_band_count(box); j++)
-                if (base + (uint32_t)j < B.band_cap) B.band_owner[(size_t)f * B.band_cap + base + j] = make_uint2(t, (box.y & 0xffffu) + (uint32_t)j);
+                if (base + (uint32_t)j < B.band_cap) B.band_owner[(size_t)f * B.band_cap + base + j] = make_uint2(t, (box.z & 0xffffu) / RS_BH + (uint32_t)j);
         }
     }
     for (int f = 0; f < n_frames; f++) {                       // k_rs_scan
