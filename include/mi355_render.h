@@ -20,6 +20,7 @@
 #ifndef MI355_RENDER_H
 #define MI355_RENDER_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -159,11 +160,33 @@ int mi355_render(mi355_ctx *, int mode, const mi355_camera *, const mi355_light 
                  const mi355_opts *, uint32_t *out_xrgb, int pitch_bytes, float *out_rgb_f32,
                  mi355_stats *stats);
 
+/* Pipelined frames: the same call split in two, for a front-end that issues frame k+1 before it presents frame k
+ * (the reference's loop, renderer.cc:481-585, is synchronous: one Scene::render* per iteration).  Up to
+ * MI355_MAX_IN_FLIGHT frames are in flight, each on its own stream with its own framebuffer; their kernels and their
+ * transfers to the host overlap.  The frame is complete in out_xrgb when mi355_render_wait(ticket) returns, and is the
+ * frame mi355_render produces.  No collect_stats, no out_rgb_f32.  -45: every slot is busy (wait first) / unknown ticket. */
+#define MI355_MAX_IN_FLIGHT 3
+int mi355_render_async(mi355_ctx *, int mode, const mi355_camera *, const mi355_light *lights, int n_lights,
+                       const mi355_opts *, uint32_t *out_xrgb, int pitch_bytes, int *ticket);
+int mi355_render_wait(mi355_ctx *, int ticket, mi355_stats *stats);
+
+/* Page-lock an output buffer of the caller (SDL_Surface::pixels stays put from frame to frame): mi355_render and
+ * mi355_render_async then copy frames straight into it with one DMA transfer instead of through the runtime's staging
+ * (pageable memory) or the library's (async).  Unregister before freeing the memory.  At most 8 ranges per context. */
+int mi355_host_register(mi355_ctx *, void *p, size_t bytes);
+int mi355_host_unregister(mi355_ctx *, void *p);
+
 /* Same frame, but asynchronous and device-resident: d_out_xrgb / d_out_rgb_f32 are device pointers
  * (e.g. a torch tensor's data_ptr()) and all work is enqueued on `hip_stream` (a hipStream_t; NULL =
  * the default stream).  Nothing is copied to the host and the call does not synchronise; this is the
  * entry the multi-GPU gather and the benchmark use.  Counters, if requested, are accumulated into
- * device memory and fetched with mi355_fetch_stats() after the caller synchronises. */
+ * device memory and fetched with mi355_fetch_stats() after the caller synchronises.
+ * Raster modes 4-8: the triangle bins and band records are sized from the triangle count; a frame that needs more
+ * (many screen-filling triangles) is INCOMPLETE and says so only through mi355_fetch_stats(), which then returns -44
+ * and makes the next frame's buffers twice as large -- a caller of the device entry points checks it once per scene /
+ * camera regime, or sizes for the worst case by drawing the frame through mi355_render first (which retries by itself).
+ * Frames of ONE context must not run concurrently on different streams (they share the context's control block and
+ * rasterizer scratch): use one stream per context, mi355_render_batch_device, or mi355_render_async. */
 int mi355_render_device(mi355_ctx *, int mode, const mi355_camera *, const mi355_light *lights, int n_lights,
                         const mi355_opts *, void *d_out_xrgb, int pitch_bytes, void *d_out_rgb_f32,
                         void *hip_stream);

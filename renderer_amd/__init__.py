@@ -366,6 +366,41 @@ class Scene:
                "mi355_render")
         return out[:, :W], outf, st
 
+    def render_into(self, mode: int, cam: Camera, lights, n_lights: int, opts: Opts, out: np.ndarray) -> Stats:
+        """mi355_render() into a caller-owned uint32 array (rows x pitch words), e.g. one registered with host_register."""
+        st = Stats()
+        _check(lib().mi355_render(self.context(), mode, C.byref(cam), lights, n_lights, C.byref(opts), out.ctypes.data,
+                                  out.strides[0], None, C.byref(st)), "mi355_render")
+        return st
+
+    def render_async(self, mode: int, cam: Camera, lights, n_lights: int, opts: Opts, out: np.ndarray) -> int:
+        """mi355_render_async(): enqueue a frame that lands in `out` (uint32, rows x pitch words); returns its ticket."""
+        f = lib().mi355_render_async
+        f.argtypes = [C.c_void_p, C.c_int, C.POINTER(Camera), C.POINTER(Light), C.c_int, C.POINTER(Opts), C.c_void_p, C.c_int,
+                      C.POINTER(C.c_int)]
+        t = C.c_int(0)
+        _check(f(self.context(), mode, C.byref(cam), lights, n_lights, C.byref(opts), out.ctypes.data, out.strides[0], C.byref(t)),
+               "mi355_render_async")
+        return t.value
+
+    def render_wait(self, ticket: int) -> Stats:
+        f = lib().mi355_render_wait
+        f.argtypes = [C.c_void_p, C.c_int, C.POINTER(Stats)]
+        st = Stats()
+        _check(f(self.context(), ticket, C.byref(st)), "mi355_render_wait")
+        return st
+
+    def host_register(self, a: np.ndarray) -> None:
+        """Page-lock a caller-owned output array (mi355_host_register)."""
+        f = lib().mi355_host_register
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        _check(f(self.context(), a.ctypes.data, a.nbytes), "mi355_host_register")
+
+    def host_unregister(self, a: np.ndarray) -> None:
+        f = lib().mi355_host_unregister
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        _check(f(self.context(), a.ctypes.data), "mi355_host_unregister")
+
     def render_device(self, mode: int, cam: Camera, lights, n_lights: int, opts: Opts, d_out: int,
                       pitch_bytes: int, d_outf: int = 0, stream: int = 0):
         """Asynchronous frame into device memory (torch tensor data_ptr) on HIP stream `stream`."""

@@ -32,14 +32,37 @@ R3DS_OF = {"legocar.3ds": ("legocar_3ds.r3ds", "4f6414dff890a6923d6182f3e6ccb846
 
 
 def cache_dir() -> str:
+    """Private scratch directory of this user (mode 0700, owned by us: a directory somebody else planted is refused)."""
     d = os.environ.get("RENDERER_AMD_CACHE") or os.path.join(
         tempfile.gettempdir(), "renderer_amd_cache_%d" % os.getuid())
-    os.makedirs(d, exist_ok=True)
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.stat(d)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        raise RuntimeError("cache directory %s is not a private directory of uid %d (owner %d, mode %o): set "
+                           "RENDERER_AMD_CACHE to one" % (d, os.getuid(), st.st_uid, st.st_mode & 0o777))
     return d
 
 
+_VERIFIED = set()
+
+
+def _intact(path: str, sha: str) -> bool:
+    """An unpacked file is trusted once per process, after its hash has been checked (a partial file left by a crash or
+    a planted one is unpacked again)."""
+    if path in _VERIFIED:
+        return True
+    try:
+        with open(path, "rb") as f:
+            ok = hashlib.sha256(f.read()).hexdigest() == sha
+    except OSError:
+        ok = False
+    if ok:
+        _VERIFIED.add(path)
+    return ok
+
+
 def _unpack(src_xz: str, dst: str, sha: str) -> str:
-    if not os.path.exists(dst):
+    if not _intact(dst, sha):
         with lzma.open(src_xz, "rb") as f:
             data = f.read()
         if hashlib.sha256(data).hexdigest() != sha:
@@ -65,7 +88,7 @@ def mesh_path(name: str) -> str:
     if name not in SHA256:
         raise KeyError("unknown mesh asset %r (have: %s)" % (name, ", ".join(SHA256)))
     dst = os.path.join(cache_dir(), name)
-    if not os.path.exists(dst):
+    if not _intact(dst, SHA256[name]):
         with lzma.open(os.path.join(ASSET_DIR, name + ".xz"), "rb") as f:
             data = f.read()
         if hashlib.sha256(data).hexdigest() != SHA256[name]:

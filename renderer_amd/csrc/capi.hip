@@ -127,17 +127,37 @@ struct mi355_ctx {
     DevBuf ctrl;            // [0] (16 B, unused) | counters[CS_COUNT] | at MI_CTRL_DISPENSER_OFF: the raytrace pixel
                             // dispenser (MI_DISPENSERS counters, MI_DISPENSER_STRIDE words apart) -- one memset per frame
     DevBuf fb, fbf;         // internal framebuffer for the host-output path
-    DevBuf tile_order;      // raytrace dispenser order (ensure_tile_order)
     DevBuf cam_table;       // batched launches: FrameCam[MI355_MAX_BATCH]
     DevBuf bvh_prim, bvh_list[2], bvh_lvl[2], bvh_tree, bvh_cnt;   // mi355_build_bvh work buffers (kept for rebuilds)
     PinBuf pin_walk, pin_edge, pin_shade, pin_tree, pin_list, pin_ctl;   // host staging of the BVH streams and the builder
     DevBuf wave_prof;       // per-wave phase profile of counting launches (debug)
     int last_blocks = 0;
-    long long tile_key[6] = {0, 0, 0, 0, 0, 0};
     bool boxes_tame = false; // every BVH box coordinate is 0 or within [1e-30, 1e17] in magnitude
     DevBuf smap[MI355_MAX_LIGHTS];
     int smap_size[MI355_MAX_LIGHTS] = {0, 0, 0, 0};
     RasterScratch *rscratch = nullptr;
+    // pipelined frames (mi355_render_async / _wait): each slot is a stream with its own control block (counters, pixel
+    // dispenser), framebuffer, page-locked staging and rasterizer scratch
+    struct AsyncSlot {
+        hipStream_t st = nullptr;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        DevBuf ctrl, fb;
+        PinBuf pin;
+        RasterScratch *rs = nullptr;
+        bool busy = false;
+        int ticket = 0, mode = 0, n_lights = 0, pitch_bytes = 0;
+        uint32_t *user = nullptr;
+        bool staged = false;          // the frame lands in `pin` and is copied to `user` by mi355_render_wait
+        mi355_camera cam{};
+        mi355_light lights[MI355_MAX_LIGHTS]{};
+        mi355_opts opts{};
+    } slot[MI355_MAX_IN_FLIGHT];
+    int next_ticket = 1;
+    // caller's page-locked output buffers (mi355_host_register): frames are copied straight into them
+    struct HostRange { char *p = nullptr; size_t bytes = 0; } host_reg[8];
+    // dispenser orders of the last few frame geometries (a buffer in use by an enqueued frame is never rewritten)
+    struct TileOrder { DevBuf buf; long long key[6] = {0, 0, 0, 0, 0, 0}; unsigned long long used = 0; } orders[4];
+    unsigned long long order_clock = 0;
     DevScene dev{};
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -179,10 +199,21 @@ int validate_opts(const mi355_opts &o, int mode)
 // Dispenser order of the 8x8 pixel tiles of a raytraced frame: nearest to the screen centre first.
 // The benchmark camera (and any look-at camera) keeps the model around the centre, so the
 // expensive tiles are handed out first and the cheap background tiles fill the tail of the launch.
-int ensure_tile_order(mi355_ctx *c, const FrameParams &P)
+int ensure_tile_order(mi355_ctx *c, const FrameParams &P, const uint32_t **out)
 {
     const long long key[6] = {P.W, P.H, P.n_rows, P.band_rows, P.band_index, P.band_count};
-    if (c->tile_order.p && !memcmp(key, c->tile_key, sizeof key)) return 0;
+    mi355_ctx::TileOrder *slot = nullptr;
+    for (auto &o : c->orders)
+        if (o.buf.p && !memcmp(key, o.key, sizeof key)) { o.used = ++c->order_clock; *out = (const uint32_t *)o.buf.p; return 0; }
+    for (auto &o : c->orders) if (!o.buf.p) { slot = &o; break; }
+    if (!slot) {
+        // every slot holds another geometry: the least recently used one goes -- frames enqueued on ANY stream may still
+        // read it (the device entry points are asynchronous), so the device is drained first; four geometries alternate
+        // without ever coming here
+        slot = &c->orders[0];
+        for (auto &o : c->orders) if (o.used < slot->used) slot = &o;
+        HIP_TRY(hipDeviceSynchronize(), -40);
+    }
     const int tiles_x = (P.W + 7) >> 3, tiles_y = (P.n_rows + 7) >> 3;
     std::vector<std::pair<float, uint32_t>> t((size_t)tiles_x * tiles_y);
     for (int ty = 0; ty < tiles_y; ty++) {
@@ -196,14 +227,18 @@ int ensure_tile_order(mi355_ctx *c, const FrameParams &P)
     std::sort(t.begin(), t.end());
     std::vector<uint32_t> order(t.size());
     for (size_t i = 0; i < t.size(); i++) order[i] = t[i].second;
-    HIP_TRY(c->tile_order.upload(order), -31);
-    memcpy(c->tile_key, key, sizeof key);
+    // (a fresh or drained buffer: nothing reads it, the blocking copy orders itself before every later launch)
+    HIP_TRY(slot->buf.upload(order), -31);
+    memcpy(slot->key, key, sizeof key);
+    slot->used = ++c->order_clock;
+    *out = (const uint32_t *)slot->buf.p;
     return 0;
 }
 
 int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_light *lights, int n_lights,
-                const mi355_opts *o, void *d_out, int pitch_bytes, void *d_outf, FrameParams &P)
+                const mi355_opts *o, void *d_out, int pitch_bytes, void *d_outf, FrameParams &P, void *ctrl = nullptr)
 {
+    if (!ctrl) ctrl = c->ctrl.p;
     memset(&P, 0, sizeof P);
     if (n_lights < 0 || n_lights > MI355_MAX_LIGHTS) return fail(-21, "n_lights %d outside 0..%d", n_lights, MI355_MAX_LIGHTS);
     if (pitch_bytes < o->width * 4 || (pitch_bytes & 3)) return fail(-21, "bad pitch %d for width %d", pitch_bytes, o->width);
@@ -232,9 +267,9 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.out = (uint32_t *)d_out;
     P.pitch_words = pitch_bytes / 4;
     P.outf = (float *)d_outf;
-    P.work_counter = (uint32_t *)((char *)c->ctrl.p + MI_CTRL_DISPENSER_OFF);
+    P.work_counter = (uint32_t *)((char *)ctrl + MI_CTRL_DISPENSER_OFF);
     P.cams = nullptr; P.n_frames = 1;
-    P.counters = (unsigned long long *)((char *)c->ctrl.p + 16);
+    P.counters = (unsigned long long *)((char *)ctrl + 16);
     // tuning knobs (mi355_opts::tune, 0 = default)
     P.raster_stats = o->collect_stats ? 1 : 0;
     const int32_t *t = o->tune;
@@ -257,8 +292,7 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     }
     P.tile_order = nullptr;
     if (mode >= MI355_MODE_RAYTRACE && !(flags & 2)) {
-        if (int r = ensure_tile_order(c, P)) return r;
-        P.tile_order = (const uint32_t *)c->tile_order.p;
+        if (int r = ensure_tile_order(c, P, &P.tile_order)) return r;
     }
     return 0;
 }
@@ -466,13 +500,15 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
     return 0;
 }
 
-int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipStream_t st)
+int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipStream_t st, void *ctrl = nullptr, RasterScratch *rs = nullptr)
 {
+    if (!ctrl) ctrl = c->ctrl.p;
+    if (!rs) rs = c->rscratch;
     // raytrace frames also reset the pixel dispenser behind the counters (same memset)
     const bool rt = mode == MI355_MODE_RAYTRACE || mode == MI355_MODE_RAYTRACE_ANTIALIAS;
-    HIP_TRY(hipMemsetAsync(c->ctrl.p, 0, rt ? MI_CTRL_BYTES : 16 + sizeof(unsigned long long) * CS_COUNT, st), -40);
+    HIP_TRY(hipMemsetAsync(ctrl, 0, rt ? MI_CTRL_BYTES : 16 + sizeof(unsigned long long) * CS_COUNT, st), -40);
     if (stats)   // the two "min" time stamps start at all-ones
-        HIP_TRY(hipMemsetAsync((char *)c->ctrl.p + 16 + sizeof(unsigned long long) * CS_TIME0, 0xff, 2 * sizeof(unsigned long long), st), -40);
+        HIP_TRY(hipMemsetAsync((char *)ctrl + 16 + sizeof(unsigned long long) * CS_TIME0, 0xff, 2 * sizeof(unsigned long long), st), -40);
     c->last_stats = stats != 0;
     hipError_t e = hipSuccess;
     switch (mode) {
@@ -480,7 +516,7 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipSt
     case MI355_MODE_POINTS_FROM_TRIANGLES: e = mi355i_launch_points(&c->dev, &P, 1, st); break;
     case MI355_MODE_AMBIENT: case MI355_MODE_GOURAUD: case MI355_MODE_PHONG:
     case MI355_MODE_PHONG_SHADOWMAPS: case MI355_MODE_PHONG_SOFTSHADOWMAPS:
-        e = mi355i_launch_raster(&c->dev, &P, mode, c->rscratch, st);
+        e = mi355i_launch_raster(&c->dev, &P, mode, rs, st);
         break;
     case MI355_MODE_RAYTRACE: case MI355_MODE_RAYTRACE_ANTIALIAS: {
         if (!c->has_bvh) return fail(-41, "raytrace modes need mi355_scene_set_bvh first");
@@ -625,11 +661,21 @@ void mi355_scene_destroy(mi355_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->walk, &c->tri_edge, &c->tri_shade, &c->rs_tri, &c->rs_col, &c->rs_idx,
-                      &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->tile_order, &c->cam_table, &c->wave_prof, &c->bvh_prim, &c->bvh_list[0], &c->bvh_list[1],
+                      &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->cam_table, &c->wave_prof, &c->bvh_prim, &c->bvh_list[0], &c->bvh_list[1],
                       &c->bvh_lvl[0], &c->bvh_lvl[1], &c->bvh_tree, &c->bvh_cnt})
         b->release();
     for (PinBuf *b : {&c->pin_walk, &c->pin_edge, &c->pin_shade, &c->pin_tree, &c->pin_list, &c->pin_ctl}) b->release();
     for (auto &m : c->smap) m.release();
+    for (auto &o : c->orders) o.buf.release();
+    for (auto &a : c->slot) {
+        if (a.st) (void)hipStreamSynchronize(a.st);
+        a.ctrl.release(); a.fb.release(); a.pin.release();
+        if (a.rs) mi355i_raster_scratch_destroy(a.rs);
+        if (a.ev0) (void)hipEventDestroy(a.ev0);
+        if (a.ev1) (void)hipEventDestroy(a.ev1);
+        if (a.st) (void)hipStreamDestroy(a.st);
+    }
+    for (auto &h : c->host_reg) if (h.p) (void)hipHostUnregister(h.p);
     if (c->rscratch) mi355i_raster_scratch_destroy(c->rscratch);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -648,9 +694,9 @@ int mi355_scene_set_bvh(mi355_ctx *c, const void *nodes32B, uint32_t n_nodes, co
 // CreateBVH + PopulateCacheFriendlyBVH (BVH.cc:96-371, Raytracer.cc:651-718) on the device: the SAH sweeps run as
 // k_bvh_level (one launch per tree level), the result is flattened here to the reference's pre-order array and is
 // byte for byte what the reference's scalar builder writes to its `.bvh` cache.  Also installs the tree in the context.
-static double g_bvh_level_ms[64]; static uint32_t g_bvh_level_nodes[64]; static int g_bvh_levels = 0;
+static thread_local double g_bvh_level_ms[64]; static thread_local uint32_t g_bvh_level_nodes[64]; static thread_local int g_bvh_levels = 0;   // (of the calling thread's last build)
 extern "C" int mi355i_bvh_level_times(double *ms64, uint32_t *nodes64) { for (int i = 0; i < g_bvh_levels; i++) { ms64[i] = g_bvh_level_ms[i]; nodes64[i] = g_bvh_level_nodes[i]; } return g_bvh_levels; }
-static double g_bvh_ms[4] = {0, 0, 0, 0};     // last mi355_build_bvh: setup, level kernels (incl. per-level sync), download + flatten, install
+static thread_local double g_bvh_ms[4] = {0, 0, 0, 0};     // last mi355_build_bvh: setup, level kernels (incl. per-level sync), download + flatten, install
 extern "C" void mi355i_bvh_last_times(double *out4) { for (int i = 0; i < 4; i++) out4[i] = g_bvh_ms[i]; }
 
 int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_nodes, int32_t *max_depth)
@@ -781,6 +827,8 @@ int mi355_shadowmap_set(mi355_ctx *c, int slot, const float *map, int size)
     if (!c || !map) return fail(-3, "mi355_shadowmap_set: null argument");
     if (slot < 0 || slot >= MI355_MAX_LIGHTS || size <= 0) return fail(-3, "bad light slot %d / size %d", slot, size);
     if (int r = select_device(c)) return r;
+    // frames enqueued on any stream (the device entry points do not synchronise) may still read this light's map
+    HIP_TRY(hipDeviceSynchronize(), -40);
     HIP_TRY(c->smap[slot].ensure((size_t)size * size * 4), -31);
     HIP_TRY(hipMemcpy(c->smap[slot].p, map, (size_t)size * size * 4, hipMemcpyHostToDevice), -31);
     c->smap_size[slot] = size;
@@ -792,6 +840,8 @@ int mi355_shadowmap_render(mi355_ctx *c, int slot, const mi355_light *light, int
     if (!c || !light) return fail(-3, "mi355_shadowmap_render: null argument");
     if (slot < 0 || slot >= MI355_MAX_LIGHTS || size <= 0 || size > 16384) return fail(-3, "bad light slot %d / size %d", slot, size);
     if (int r = select_device(c)) return r;
+    // frames enqueued on any stream (the device entry points do not synchronise) may still read this light's map
+    HIP_TRY(hipDeviceSynchronize(), -40);
     HIP_TRY(c->smap[slot].ensure((size_t)size * size * 4), -31);
     for (int attempt = 0;; attempt++) {
         hipError_t e = mi355i_launch_shadowmap(&c->dev, light->pos, light->world_to_light, size, (float *)c->smap[slot].p,
@@ -964,6 +1014,41 @@ int mi355i_fetch_wave_profiles(mi355_ctx *c, unsigned long long *out, int max_wa
     return n;
 }
 
+static bool host_range_registered(const mi355_ctx *c, const void *p, size_t bytes)
+{
+    for (const auto &h : c->host_reg)
+        if (h.p && (const char *)p >= h.p && (const char *)p + bytes <= h.p + h.bytes) return true;
+    return false;
+}
+
+int mi355_host_register(mi355_ctx *c, void *p, size_t bytes)
+{
+    if (!c || !p || !bytes) return fail(-3, "mi355_host_register: null argument");
+    if (int r = select_device(c)) return r;
+    for (auto &h : c->host_reg)
+        if (!h.p) {
+            HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault), -46);
+            h.p = (char *)p; h.bytes = bytes;
+            return 0;
+        }
+    return fail(-46, "mi355_host_register: all %d slots are in use", (int)(sizeof c->host_reg / sizeof c->host_reg[0]));
+}
+
+int mi355_host_unregister(mi355_ctx *c, void *p)
+{
+    if (!c || !p) return fail(-3, "mi355_host_unregister: null argument");
+    if (int r = select_device(c)) return r;
+    for (auto &h : c->host_reg)
+        if (h.p == (char *)p) {
+            for (auto &a : c->slot) if (a.busy && a.st) HIP_TRY(hipStreamSynchronize(a.st), -40);   // no copy may still target it
+            HIP_TRY(hipStreamSynchronize(c->stream), -40);
+            HIP_TRY(hipHostUnregister(p), -46);
+            h.p = nullptr; h.bytes = 0;
+            return 0;
+        }
+    return fail(-46, "mi355_host_unregister: %p was not registered", p);
+}
+
 int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_light *lights, int n_lights,
                  const mi355_opts *o, uint32_t *out_xrgb, int pitch_bytes, float *out_rgb_f32, mi355_stats *stats)
 {
@@ -988,16 +1073,110 @@ int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_li
         if (int r = enqueue_frame(c, mode, P, o->collect_stats, c->stream)) return r;
         HIP_TRY(hipEventRecord(c->ev1, c->stream), -40);
         HIP_TRY(hipStreamSynchronize(c->stream), -40);
-        const int r = mi355_fetch_stats(c, st);              // also surfaces a rasterizer span-buffer overflow ...
-        if (r == -44 && attempt < 6) continue;               // ... after which the buffers have grown: draw the frame again
+        const int r = mi355_fetch_stats(c, st);              // also surfaces a rasterizer bin overflow ...
+        if (r == -44 && attempt < 8) continue;               // ... after which the buffers have grown: draw the frame again
         if (r) return r;
         break;
     }
-    HIP_TRY(hipMemcpy2D(out_xrgb, (size_t)pitch_bytes, c->fb.p, (size_t)W * 4, (size_t)W * 4, (size_t)rows, hipMemcpyDeviceToHost), -31);
+    if (pitch_bytes > 0 && host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4)) {
+        // page-locked by the caller (mi355_host_register): one DMA transfer, no staging by the runtime
+        HIP_TRY(hipMemcpy2DAsync(out_xrgb, (size_t)pitch_bytes, c->fb.p, (size_t)W * 4, (size_t)W * 4, (size_t)rows, hipMemcpyDeviceToHost, c->stream), -31);
+        HIP_TRY(hipStreamSynchronize(c->stream), -40);
+    } else
+        HIP_TRY(hipMemcpy2D(out_xrgb, (size_t)pitch_bytes, c->fb.p, (size_t)W * 4, (size_t)W * 4, (size_t)rows, hipMemcpyDeviceToHost), -31);
     if (wantf) HIP_TRY(hipMemcpy(out_rgb_f32, c->fbf.p, (size_t)W * rows * 12, hipMemcpyDeviceToHost), -31);
     if (stats) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1), -40);
+        stats->kernel_ms = ms;
+    }
+    return 0;
+}
+
+// Pipelined frames.  The reference's seam is one synchronous frame per call (renderer.cc:522-583); a front-end that
+// draws frame k+1 while frame k is on its way to the host splits the call in two.  Up to MI355_MAX_IN_FLIGHT frames
+// are in flight, each on its own stream with its own control block, framebuffer and rasterizer scratch: their kernels
+// overlap (a single 1080p raytraced frame leaves most of the GPU idle while its slowest tiles finish) and so do the
+// transfers.  The frame is in out_xrgb when mi355_render_wait(ticket) returns; the pixels are those of mi355_render.
+int mi355_render_async(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_light *lights, int n_lights, const mi355_opts *o,
+                       uint32_t *out_xrgb, int pitch_bytes, int *ticket)
+{
+    if (!c || !cam || !o || !out_xrgb || !ticket || (n_lights > 0 && !lights)) return fail(-3, "mi355_render_async: null argument");
+    if (int r = validate_opts(*o, mode)) return r;
+    if (n_lights < 0 || n_lights > MI355_MAX_LIGHTS) return fail(-21, "n_lights %d outside 0..%d", n_lights, MI355_MAX_LIGHTS);
+    if (o->collect_stats) return fail(-21, "pipelined frames cannot collect the counters");
+    if (int r = select_device(c)) return r;
+    mi355_ctx::AsyncSlot *a = nullptr;
+    for (auto &s : c->slot) if (!s.busy) { a = &s; break; }
+    if (!a) return fail(-45, "%d frames are in flight: call mi355_render_wait first", MI355_MAX_IN_FLIGHT);
+    const int W = o->width;
+    const int rows = (o->band_count > 1 && o->compact_rows) ? count_rows(*o) : o->height;
+    if (!a->st) {
+        HIP_TRY(hipStreamCreateWithFlags(&a->st, hipStreamNonBlocking), -11);
+        HIP_TRY(hipEventCreate(&a->ev0), -11);
+        HIP_TRY(hipEventCreate(&a->ev1), -11);
+        HIP_TRY(a->ctrl.ensure(MI_CTRL_BYTES), -31);
+        HIP_TRY(hipMemsetAsync(a->ctrl.p, 0, MI_CTRL_BYTES, a->st), -40);
+        a->rs = mi355i_raster_scratch_create();
+        if (!a->rs) return fail(-11, "out of memory");
+    }
+    HIP_TRY(a->fb.ensure((size_t)W * o->height * 4), -31);
+    if (o->band_count > 1) HIP_TRY(hipMemsetAsync(a->fb.p, 0, (size_t)W * o->height * 4, a->st), -40);
+    FrameParams P;
+    if (int r = fill_params(c, mode, cam, lights, n_lights, o, a->fb.p, W * 4, nullptr, P, a->ctrl.p)) return r;
+    HIP_TRY(hipEventRecord(a->ev0, a->st), -40);
+    if (int r = enqueue_frame(c, mode, P, 0, a->st, a->ctrl.p, a->rs)) return r;
+    HIP_TRY(hipEventRecord(a->ev1, a->st), -40);
+    a->staged = !host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4);
+    if (a->staged) {
+        HIP_TRY(a->pin.ensure((size_t)W * rows * 4), -31);
+        HIP_TRY(hipMemcpyAsync(a->pin.p, a->fb.p, (size_t)W * rows * 4, hipMemcpyDeviceToHost, a->st), -31);
+    } else
+        HIP_TRY(hipMemcpy2DAsync(out_xrgb, (size_t)pitch_bytes, a->fb.p, (size_t)W * 4, (size_t)W * 4, (size_t)rows, hipMemcpyDeviceToHost, a->st), -31);
+    a->busy = true; a->ticket = c->next_ticket++; a->mode = mode; a->n_lights = n_lights; a->pitch_bytes = pitch_bytes;
+    a->user = out_xrgb; a->cam = *cam; a->opts = *o;
+    for (int i = 0; i < n_lights; i++) a->lights[i] = lights[i];
+    *ticket = a->ticket;
+    return 0;
+}
+
+int mi355_render_wait(mi355_ctx *c, int ticket, mi355_stats *stats)
+{
+    if (!c) return fail(-3, "mi355_render_wait: null argument");
+    if (int r = select_device(c)) return r;
+    mi355_ctx::AsyncSlot *a = nullptr;
+    for (auto &s : c->slot) if (s.busy && s.ticket == ticket) { a = &s; break; }
+    if (!a) return fail(-45, "mi355_render_wait: no frame with ticket %d is in flight", ticket);
+    HIP_TRY(hipStreamSynchronize(a->st), -40);
+    a->busy = false;
+    unsigned long long h[CS_COUNT];
+    HIP_TRY(hipMemcpy(h, (char *)a->ctrl.p + 16, sizeof h, hipMemcpyDeviceToHost), -31);
+    if (h[CS_OVERFLOW]) {
+        // the rasterizer's bins were too small for this frame: this slot's grow, and the frame is drawn again (synchronously)
+        for (int attempt = 0; attempt < 8; attempt++) {
+            if (!mi355i_raster_grow(a->rs)) break;
+            FrameParams P;
+            if (int r = fill_params(c, a->mode, &a->cam, a->lights, a->n_lights, &a->opts, a->fb.p, a->opts.width * 4, nullptr, P, a->ctrl.p)) return r;
+            if (int r = enqueue_frame(c, a->mode, P, 0, a->st, a->ctrl.p, a->rs)) return r;
+            HIP_TRY(hipStreamSynchronize(a->st), -40);
+            HIP_TRY(hipMemcpy(h, (char *)a->ctrl.p + 16, sizeof h, hipMemcpyDeviceToHost), -31);
+            if (!h[CS_OVERFLOW]) break;
+        }
+        if (h[CS_OVERFLOW]) return fail(-44, "rasterizer triangle bins overflowed (%llu entries dropped)", h[CS_OVERFLOW]);
+        a->staged = true;
+        const int W = a->opts.width, rows = (a->opts.band_count > 1 && a->opts.compact_rows) ? count_rows(a->opts) : a->opts.height;
+        HIP_TRY(a->pin.ensure((size_t)W * rows * 4), -31);
+        HIP_TRY(hipMemcpy(a->pin.p, a->fb.p, (size_t)W * rows * 4, hipMemcpyDeviceToHost), -31);
+    }
+    if (a->staged) {
+        const int W = a->opts.width, rows = (a->opts.band_count > 1 && a->opts.compact_rows) ? count_rows(a->opts) : a->opts.height;
+        for (int r = 0; r < rows; r++) memcpy((char *)a->user + (size_t)r * a->pitch_bytes, (char *)a->pin.p + (size_t)r * W * 4, (size_t)W * 4);
+    }
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->normal_rays = h[CS_NORMAL_RAYS]; stats->shadow_rays = h[CS_SHADOW_RAYS];
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, a->ev0, a->ev1), -40);
         stats->kernel_ms = ms;
     }
     return 0;

@@ -1,0 +1,88 @@
+"""Pipelined frames (mi355_render_async / mi355_render_wait) and caller-registered output buffers: the frames are the
+frames mi355_render produces, whatever is in flight beside them."""
+import numpy as np
+import pytest
+
+import renderer_amd as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode,mesh", [(9, "dragon_vis.ply"), (6, "chessboard.tri"), (8, "chessboard.tri"), (2, "chessboard.tri")])
+@pytest.mark.parametrize("registered", [False, True])
+def test_pipelined_frames_equal_synchronous_frames(mode, mesh, registered):
+    W, H = 640, 360
+    s = R.Scene(R.assets.mesh_path(mesh))
+    if mode >= 9:
+        s.bvh_create()
+    cams = [R.benchmark_frame(k) for k in range(0, 40, 4)]
+    if mode in (7, 8):
+        s.shadowmap_render(0, cams[0][1][0])
+    o = R.default_opts(W, H)
+    want = [s.render(mode, *c, o)[0] for c in cams]
+    bufs = [np.full((H, W + 8), 0xdeadbeef, np.uint32) for _ in range(3)]        # (pitch wider than the frame)
+    if registered:
+        for b in bufs:
+            s.host_register(b)
+    try:
+        tickets = []
+        got = []
+        for k, c in enumerate(cams):
+            if len(tickets) == 3:
+                t, slot = tickets.pop(0)
+                st = s.render_wait(t)
+                assert mode < 9 or st.normal_rays > 0
+                got.append(bufs[slot][:, :W].copy())
+                assert (bufs[slot][:, W:] == 0xdeadbeef).all()
+            slot = k % 3
+            tickets.append((s.render_async(mode, *c, o, bufs[slot]), slot))
+        with pytest.raises(R.Mi355Error, match="in flight"):
+            s.render_async(mode, *cams[0], o, np.zeros((H, W), np.uint32))
+        for t, slot in tickets:
+            s.render_wait(t)
+            got.append(bufs[slot][:, :W].copy())
+        with pytest.raises(R.Mi355Error, match="no frame with ticket"):
+            s.render_wait(12345)
+    finally:
+        if registered:
+            for b in bufs:
+                s.host_unregister(b)
+    assert len(got) == len(want)
+    for k in range(len(want)):
+        assert np.array_equal(got[k], want[k]), "frame %d" % k
+
+
+def test_synchronous_render_into_a_registered_buffer():
+    W, H = 800, 600
+    s = R.Scene(R.assets.mesh_path("dragon_vis.ply"))
+    s.bvh_create()
+    cam, lights, n = R.benchmark_frame(3)
+    o = R.default_opts(W, H)
+    want = s.render(9, cam, lights, n, o)[0]
+    buf = np.zeros((H, W), np.uint32)
+    s.host_register(buf)
+    try:
+        s.render_into(9, cam, lights, n, o, buf)
+    finally:
+        s.host_unregister(buf)
+    assert np.array_equal(buf, want)
+    with pytest.raises(R.Mi355Error, match="was not registered"):
+        s.host_unregister(buf)
+
+
+def test_many_frame_geometries_in_one_context():
+    """More frame sizes than the dispenser-order cache holds, revisited: every frame still equals a fresh context's."""
+    s = R.Scene(R.assets.mesh_path("dragon_vis.ply"))
+    s.bvh_create()
+    cam, lights, n = R.benchmark_frame(1)
+    sizes = [(64, 48), (320, 200), (333, 217), (640, 360), (800, 600), (64, 48), (1024, 768), (320, 200)]
+    first = {}
+    for (W, H) in sizes:
+        img = s.render(9, cam, lights, n, R.default_opts(W, H))[0]
+        if (W, H) in first:
+            assert np.array_equal(img, first[(W, H)])
+        else:
+            first[(W, H)] = img
+            fresh = R.Scene(R.assets.mesh_path("dragon_vis.ply"))
+            fresh.bvh_create()
+            assert np.array_equal(img, fresh.render(9, cam, lights, n, R.default_opts(W, H))[0])
