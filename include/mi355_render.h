@@ -165,7 +165,7 @@ int mi355_render(mi355_ctx *, int mode, const mi355_camera *, const mi355_light 
  * MI355_MAX_IN_FLIGHT frames are in flight, each on its own stream with its own framebuffer; their kernels and their
  * transfers to the host overlap.  The frame is complete in out_xrgb when mi355_render_wait(ticket) returns, and is the
  * frame mi355_render produces.  No collect_stats, no out_rgb_f32.  -45: every slot is busy (wait first) / unknown ticket. */
-#define MI355_MAX_IN_FLIGHT 3
+#define MI355_MAX_IN_FLIGHT 4
 int mi355_render_async(mi355_ctx *, int mode, const mi355_camera *, const mi355_light *lights, int n_lights,
                        const mi355_opts *, uint32_t *out_xrgb, int pitch_bytes, int *ticket);
 int mi355_render_wait(mi355_ctx *, int ticket, mi355_stats *stats);

@@ -29,6 +29,9 @@ HEADER = os.path.join(ROOT, "include", "mi355_render.h")
 MAX_LIGHTS = 4
 
 
+MAX_IN_FLIGHT = 4      # MI355_MAX_IN_FLIGHT (include/mi355_render.h)
+
+
 class Mi355Error(RuntimeError):
     pass
 

@@ -20,17 +20,17 @@ def measure(mesh, mode, n=120):
     t0 = time.perf_counter(); ks = 0.0
     for c in cams: ks += s.render_into(mode, *c, o, buf).kernel_ms
     out["sync_pageable_fps"] = round(n / (time.perf_counter() - t0), 1); out["kernel_ms"] = round(ks / n, 4)
-    bufs = [np.zeros((H, W), np.uint32) for _ in range(3)]
+    bufs = [np.zeros((H, W), np.uint32) for _ in range(4)]
     for b in bufs: s.host_register(b)
     for c in cams[:5]: s.render_into(mode, *c, o, bufs[0])
     t0 = time.perf_counter()
     for c in cams: s.render_into(mode, *c, o, bufs[0])
     out["sync_registered_fps"] = round(n / (time.perf_counter() - t0), 1)
-    for depth in (2, 3):
+    for depth in (2, 3, 4):
         t0 = time.perf_counter(); q = []
         for k, c in enumerate(cams):
             if len(q) == depth: s.render_wait(q.pop(0))
-            q.append(s.render_async(mode, *c, o, bufs[k % 3]))
+            q.append(s.render_async(mode, *c, o, bufs[k % 4]))
         for t in q: s.render_wait(t)
         out["pipelined_%d_registered_fps" % depth] = round(n / (time.perf_counter() - t0), 1)
     for b in bufs: s.host_unregister(b)

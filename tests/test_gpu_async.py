@@ -20,7 +20,7 @@ def test_pipelined_frames_equal_synchronous_frames(mode, mesh, registered):
         s.shadowmap_render(0, cams[0][1][0])
     o = R.default_opts(W, H)
     want = [s.render(mode, *c, o)[0] for c in cams]
-    bufs = [np.full((H, W + 8), 0xdeadbeef, np.uint32) for _ in range(3)]        # (pitch wider than the frame)
+    bufs = [np.full((H, W + 8), 0xdeadbeef, np.uint32) for _ in range(R.MAX_IN_FLIGHT)]        # (pitch wider than the frame)
     if registered:
         for b in bufs:
             s.host_register(b)
@@ -28,13 +28,13 @@ def test_pipelined_frames_equal_synchronous_frames(mode, mesh, registered):
         tickets = []
         got = []
         for k, c in enumerate(cams):
-            if len(tickets) == 3:
+            if len(tickets) == R.MAX_IN_FLIGHT:
                 t, slot = tickets.pop(0)
                 st = s.render_wait(t)
                 assert mode < 9 or st.normal_rays > 0
                 got.append(bufs[slot][:, :W].copy())
                 assert (bufs[slot][:, W:] == 0xdeadbeef).all()
-            slot = k % 3
+            slot = k % R.MAX_IN_FLIGHT
             tickets.append((s.render_async(mode, *c, o, bufs[slot]), slot))
         with pytest.raises(R.Mi355Error, match="in flight"):
             s.render_async(mode, *cams[0], o, np.zeros((H, W), np.uint32))
