@@ -205,6 +205,25 @@ int mi355_render_batch_device(mi355_ctx *, int mode, int n_frames, const mi355_c
                               int n_lights, const mi355_opts *, void *const *d_out_xrgb, int pitch_bytes,
                               void *const *d_out_rgb_f32, void *hip_stream);
 
+/* One frame on several GPUs from one host thread (north_star: frames shard across GPUs as independent screen tiles with
+ * a single RCCL gather over xGMI).  No reference counterpart (one process, shared-memory threads: SURVEY.md 2).  The
+ * scene is replicated, one context per device; a frame is cut into interleaved bands of 8 scanlines (band b -> device
+ * b mod N), every device renders its bands (mi355_opts::band_* above), devices 1..N-1 send them to device 0 in one
+ * grouped RCCL exchange and device 0 puts the rows in screen order.  The frame is the frame mi355_render produces.
+ * A device listed twice (or MI355_MGPU_TRANSPORT=copy) selects peer copies instead of RCCL: a one-GPU box can then play
+ * every rank of an N-GPU frame. */
+typedef struct mi355_mgpu mi355_mgpu;
+mi355_mgpu *mi355_mgpu_create(const mi355_scene_desc *desc, const int *devices, int n_devices);
+void mi355_mgpu_destroy(mi355_mgpu *);
+int mi355_mgpu_n_devices(const mi355_mgpu *);
+mi355_ctx *mi355_mgpu_context(mi355_mgpu *, int rank);          /* the rank's own context (e.g. mi355_build_bvh on rank 0) */
+const char *mi355_mgpu_transport(const mi355_mgpu *);           /* "rccl", "copy" or "none" (one device) */
+int mi355_mgpu_set_bvh(mi355_mgpu *, const void *nodes32B, uint32_t n_nodes, const int32_t *tri_idx, uint32_t n_idx);
+int mi355_mgpu_shadowmap_render(mi355_mgpu *, int slot, const mi355_light *light, int size, float *out_map);
+/* out_xrgb (host) or d_out (device 0) receives the assembled frame; synchronous.  stats: ray counts summed over the devices. */
+int mi355_mgpu_render(mi355_mgpu *, int mode, const mi355_camera *, const mi355_light *lights, int n_lights, const mi355_opts *,
+                      uint32_t *out_xrgb, int pitch_bytes, void *d_out, mi355_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -245,6 +245,13 @@ class Scene:
         self.desc = d
         self.nv, self.nt = int(d.n_vertices), int(d.n_triangles)
 
+    def set_devices(self, devices) -> None:
+        """mi355::Scene::_devices: every frame of the C++ render* API on these GPUs (a device listed twice plays two ranks)."""
+        arr = (C.c_int * len(devices))(*devices)
+        f = host().mi355h_set_devices
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
+        f(self._h, arr, len(devices))
+
     def close(self):
         if getattr(self, "_h", None):
             host().mi355h_scene_free(self._h)

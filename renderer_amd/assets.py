@@ -23,6 +23,7 @@ SHA256 = {
     "statue.ply": "ca4906aeaef5646f69612a41fbab21922cb7512162f571ef65e220dd27a3af9b",
     "dragon_vis.ply": "4d70bb53c2fe06df59d8d8c8087196446919ccc3324c9f286bfcdf0f181027fb",
     "legocar.3ds": "407311b55df3d390a3f66348d06966cd48fb8f249170ca122a83b1f0a65033b9",
+    "trainColor.tri": "00e51bd47174c5132a68963dd008d14af78e46f633f403cde52b8449d24485fa",      # the mesh of the reference's `make bench` (src/Makefile.am:25-26)
 }
 
 # Test fixtures (tests/golden/): what the REAL lib3ds hands the reference's loader for a .3ds asset, dumped by

@@ -560,6 +560,9 @@ extern "C" {
 
 int mi355_abi_version(void) { return MI355_ABI_VERSION; }
 
+// (for the library's other translation units: mgpu.hip)
+int mi355i_set_error(int code, const char *text) { g_err = text ? text : ""; return code; }
+
 const char *mi355_last_error(void) { return g_err.c_str(); }
 
 int mi355_init(int n_devices_requested, int *n_devices_out)
@@ -585,7 +588,7 @@ void mi355_default_opts(mi355_opts *o, int width, int height)
     o->reflect_rate = 0.375f; o->nudge = 1e-5f;                               // Raytracer.cc:68,59
     o->ambient = 96.f; o->diffuse = 128.f; o->specular = 192.f;               // Defines.h:30-32
     o->clip_z = 0.2f;                                                         // Rasterizers.cc:39
-    o->band_rows = 15; o->band_index = 0; o->band_count = 1; o->compact_rows = 0;
+    o->band_rows = 8; o->band_index = 0; o->band_count = 1; o->compact_rows = 0;     // (8 = one row of the kernels' 8x8 tiles)
 }
 
 mi355_ctx *mi355_scene_create(const mi355_scene_desc *d, int device)

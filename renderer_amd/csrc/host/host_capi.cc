@@ -75,6 +75,16 @@ int mi355h_set_device(void *h, int device)
     return 0;
 }
 
+// every frame on these devices (Scene::_devices); n <= 1: back to one device
+int mi355h_set_devices(void *h, const int *devices, int n)
+{
+    Handle *H = (Handle *)h;
+    H->scene.invalidateDevice();
+    H->scene._devices.assign(devices, devices + (n > 0 ? n : 0));
+    if (n == 1) { H->scene._device = devices[0]; H->scene._devices.clear(); }
+    return 0;
+}
+
 // BVH: build (always), or the reference's cache-or-build entry point
 int mi355h_bvh_create(void *h) { return guarded([&] { ((Handle *)h)->scene.CreateBVH(); }); }
 // where: 0 auto, 1 host builder, 2 device builder; *on_device (optional) tells which one ran

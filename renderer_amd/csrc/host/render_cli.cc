@@ -4,9 +4,16 @@
 // camera sequence, BVH build and shadow-map generation outside the timed region, fps =
 // frames / seconds spent inside Scene::render* -- on top of the C++ host API, i.e. on the GPU.
 // There is no window: -o PREFIX dumps frames as binary PPM instead of SDL_Flip.
+//   -r          report the frame rate every 5 seconds while running (renderer.cc:603-614)
+//   --bench     the reference's `make bench` (src/Makefile.am:25-26): five runs of `-b -n 500` (or -n N), then
+//               Average / Std dev / Median / Min / Max of their frame rates, as its perl one-liner prints them
+//   -g N        draw every frame on N GPUs (devices 0..N-1; -g 0,0 lists devices explicitly)
 #include "renderer_host.h"
 
+#include <algorithm>
 #include <chrono>
+#include <cmath>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -17,82 +24,125 @@ using namespace mi355;
 static void usage()
 {
     fprintf(stderr,
-            "Usage: render_cli [-b] [-n frames] [-m mode] [-w] [-W width] [-H height] [-d device] [-o ppm_prefix] FILE\n"
+            "Usage: render_cli [-b] [-r] [--bench] [-n frames] [-m mode] [-w] [-W width] [-H height] [-d device] [-g gpus] [-o ppm_prefix] FILE\n"
             "  -m <mode>  1 points, 2 points from triangles, 4 ambient, 5 Gouraud, 6 Phong,\n"
             "             7 Phong+shadow maps, 8 Phong+soft shadow maps, 9 raytracing, 0 raytracing+AA\n"
             "  -w         use two lights        -n N  frames (default 100)\n");
     exit(1);
 }
 
+// one `renderer -b -n frames` run; returns frames per second (time inside Scene::render* only, renderer.cc:584-585, 631-633)
+static double run(const char *fname, int mode, int frames, int W, int H, const std::vector<int> &devices, bool twoLights, bool periodic, const char *dump)
+{
+    Scene scene;
+    if (devices.size() > 1) scene._devices = devices;
+    else if (!devices.empty()) scene._device = devices[0];
+    Screen canvas(scene, W, H);
+    scene.load(fname);
+    printf("Vertexes: %zu Triangles: %zu\n", scene.numVertices(), scene.numTriangles());
+    if (mode >= 9) scene.UpdateBoundingVolumeHierarchy(fname);          // renderer.cc:254-258 (untimed)
+    const Vector3 lp = BenchmarkOrbit::lightPosition(), lp2 = BenchmarkOrbit::secondLightPosition();
+    Light light(lp._x, lp._y, lp._z), light2(lp2._x, lp2._y, lp2._z);
+    scene._lights.push_back(&light);
+    if (twoLights) scene._lights.push_back(&light2);
+    BenchmarkOrbit orbit;
+    Camera sony(orbit.eye, Vector3(orbit.eye._x + 1.0f, orbit.eye._y, orbit.eye._z));
+    for (Light *l : scene._lights) {                                    // renderer.cc:319-327 (untimed)
+        l->CalculatePositionInCameraSpace(sony);
+        l->RenderSceneIntoShadowBuffer(scene);
+        l->CalculateXformFromWorldToLightSpace();
+    }
+    double msSpentDrawing = 0, msAtLastReport = 0;
+    int framesAtLastReport = 0;
+    const auto tStart = std::chrono::steady_clock::now();
+    double lastReport = 0;
+    for (int f = 0; f < frames; f++) {
+        orbit.advance();
+        sony.set(orbit.eye, orbit.lookat);
+        if (mode >= 5) for (Light *l : scene._lights) l->CalculatePositionInCameraSpace(sony);
+        if (mode >= 7) for (Light *l : scene._lights) l->CalculateXformFromCameraToLightSpace(sony);
+        const auto t0 = std::chrono::steady_clock::now();
+        switch (mode) {
+        case 1: scene.renderPoints(sony, canvas, false); break;
+        case 2: scene.renderPoints(sony, canvas, true); break;
+        case 4: scene.renderAmbient(sony, canvas); break;
+        case 5: scene.renderGouraud(sony, canvas); break;
+        case 6: scene.renderPhong(sony, canvas); break;
+        case 7: scene.renderPhongAndShadowed(sony, canvas); break;
+        case 8: scene.renderPhongAndSoftShadowed(sony, canvas); break;
+        case 9: scene.renderRaytracer(sony, canvas, false); break;
+        default: scene.renderRaytracer(sony, canvas, true); break;
+        }
+        const auto t1 = std::chrono::steady_clock::now();
+        msSpentDrawing += std::chrono::duration<double, std::milli>(t1 - t0).count();
+        if (periodic) {                                                  // renderer.cc:603-614: every 5 seconds of wall time
+            const double wall = std::chrono::duration<double>(t1 - tStart).count();
+            if (wall - lastReport >= 5.0) {
+                printf("FPS: %g\n", (f + 1 - framesAtLastReport) / ((msSpentDrawing - msAtLastReport) / 1000.0));
+                fflush(stdout);
+                lastReport = wall; framesAtLastReport = f + 1; msAtLastReport = msSpentDrawing;
+            }
+        }
+        if (dump) {
+            char name[512];
+            snprintf(name, sizeof name, "%s_%04d.ppm", dump, f + 1);
+            if (FILE *fp = fopen(name, "wb")) {
+                fprintf(fp, "P6\n%d %d\n255\n", W, H);
+                for (uint32_t p : canvas._pixels) { unsigned char rgb[3] = {(unsigned char)(p >> 16), (unsigned char)(p >> 8), (unsigned char)p}; fwrite(rgb, 1, 3, fp); }
+                fclose(fp);
+            }
+        }
+    }
+    const double fps = msSpentDrawing > 0 ? frames / (msSpentDrawing / 1000.0) : 0.0;
+    if (msSpentDrawing > 0) printf("Rendering %d frames in %g seconds. (%g fps)\n", frames, msSpentDrawing / 1000.0, fps);
+    return fps;
+}
+
 int main(int argc, char **argv)
 {
-    int mode = 8, frames = 100, W = 800, H = 600, device = 0;      // defaults: renderer.cc:177-181, Defines.h:26-27
-    bool twoLights = false;
+    int mode = 8, frames = -1, W = 800, H = 600;                   // defaults: renderer.cc:177-181, Defines.h:26-27
+    std::vector<int> devices;
+    bool twoLights = false, periodic = false, bench = false;
     const char *dump = nullptr, *fname = nullptr;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
         auto next = [&]() -> const char * { if (i + 1 >= argc) usage(); return argv[++i]; };
         if (!strcmp(a, "-b")) continue;                            // always benchmarking: there is no UI
         else if (!strcmp(a, "-w")) twoLights = true;
+        else if (!strcmp(a, "-r")) periodic = true;
+        else if (!strcmp(a, "--bench")) bench = true;
         else if (!strcmp(a, "-n")) frames = atoi(next());
         else if (!strcmp(a, "-m")) { mode = atoi(next()); if (mode == 0) mode = 10; }
         else if (!strcmp(a, "-W")) W = atoi(next());
         else if (!strcmp(a, "-H")) H = atoi(next());
-        else if (!strcmp(a, "-d")) device = atoi(next());
+        else if (!strcmp(a, "-d")) devices.assign(1, atoi(next()));
+        else if (!strcmp(a, "-g")) {
+            const char *v = next();
+            devices.clear();
+            if (strchr(v, ',')) { for (const char *q = v; *q;) { devices.push_back(atoi(q)); q = strchr(q, ','); if (!q) break; q++; } }
+            else for (int d = 0; d < atoi(v); d++) devices.push_back(d);
+            if (devices.empty()) usage();
+        }
         else if (!strcmp(a, "-o")) dump = next();
         else if (a[0] == '-') usage();
         else fname = a;
     }
     if (!fname || mode < 1 || mode > 10 || mode == 3) usage();
+    if (frames < 0) frames = bench ? 500 : 100;
     try {
-        Scene scene;
-        scene._device = device;
-        Screen canvas(scene, W, H);
-        scene.load(fname);
-        printf("Vertexes: %zu Triangles: %zu\n", scene.numVertices(), scene.numTriangles());
-        if (mode >= 9) scene.UpdateBoundingVolumeHierarchy(fname);          // renderer.cc:254-258 (untimed)
-        const Vector3 lp = BenchmarkOrbit::lightPosition(), lp2 = BenchmarkOrbit::secondLightPosition();
-        Light light(lp._x, lp._y, lp._z), light2(lp2._x, lp2._y, lp2._z);
-        scene._lights.push_back(&light);
-        if (twoLights) scene._lights.push_back(&light2);
-        BenchmarkOrbit orbit;
-        Camera sony(orbit.eye, Vector3(orbit.eye._x + 1.0f, orbit.eye._y, orbit.eye._z));
-        for (Light *l : scene._lights) {                                    // renderer.cc:319-327 (untimed)
-            l->CalculatePositionInCameraSpace(sony);
-            l->RenderSceneIntoShadowBuffer(scene);
-            l->CalculateXformFromWorldToLightSpace();
-        }
-        double msSpentDrawing = 0;
-        for (int f = 0; f < frames; f++) {
-            orbit.advance();
-            sony.set(orbit.eye, orbit.lookat);
-            if (mode >= 5) for (Light *l : scene._lights) l->CalculatePositionInCameraSpace(sony);
-            if (mode >= 7) for (Light *l : scene._lights) l->CalculateXformFromCameraToLightSpace(sony);
-            const auto t0 = std::chrono::steady_clock::now();
-            switch (mode) {
-            case 1: scene.renderPoints(sony, canvas, false); break;
-            case 2: scene.renderPoints(sony, canvas, true); break;
-            case 4: scene.renderAmbient(sony, canvas); break;
-            case 5: scene.renderGouraud(sony, canvas); break;
-            case 6: scene.renderPhong(sony, canvas); break;
-            case 7: scene.renderPhongAndShadowed(sony, canvas); break;
-            case 8: scene.renderPhongAndSoftShadowed(sony, canvas); break;
-            case 9: scene.renderRaytracer(sony, canvas, false); break;
-            default: scene.renderRaytracer(sony, canvas, true); break;
-            }
-            msSpentDrawing += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            if (dump) {
-                char name[512];
-                snprintf(name, sizeof name, "%s_%04d.ppm", dump, f + 1);
-                if (FILE *fp = fopen(name, "wb")) {
-                    fprintf(fp, "P6\n%d %d\n255\n", W, H);
-                    for (uint32_t p : canvas._pixels) { unsigned char rgb[3] = {(unsigned char)(p >> 16), (unsigned char)(p >> 8), (unsigned char)p}; fwrite(rgb, 1, 3, fp); }
-                    fclose(fp);
-                }
-            }
-        }
-        if (msSpentDrawing > 0)
-            printf("Rendering %d frames in %g seconds. (%g fps)\n", frames, msSpentDrawing / 1000.0, frames / (msSpentDrawing / 1000.0));
+        if (!bench) { run(fname, mode, frames, W, H, devices, twoLights, periodic, dump); return 0; }
+        // src/Makefile.am:25-26: five runs, then the statistics of their frame rates
+        std::vector<double> fps;
+        for (int i = 0; i < 5; i++) fps.push_back(run(fname, mode, frames, W, H, devices, twoLights, periodic, nullptr));
+        // (the perl of src/Makefile.am:26: sample variance, the middle element of the sorted rates, "%15s: %f")
+        double total = 0, totalSq = 0;
+        for (double v : fps) { printf("%g\n", v); total += v; totalSq += v * v; }
+        const double n = (double)fps.size(), variance = (totalSq - total * total / n) / (n - 1);
+        std::vector<double> sorted = fps; std::sort(sorted.begin(), sorted.end());
+        size_t len = sorted.size(); if (len % 2) len++;
+        const char *names[5] = {"Average value", "Std deviation", "Median", "Min", "Max"};
+        const double vals[5] = {total / n, std::sqrt(variance > 0 ? variance : 0), sorted[len / 2 - 1], sorted.front(), sorted.back()};
+        for (int i = 0; i < 5; i++) printf("%15s: %f\n", names[i], vals[i]);
     } catch (const std::string &s) {
         fprintf(stderr, "%s\n", s.c_str());
         return 1;

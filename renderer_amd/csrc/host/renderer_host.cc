@@ -121,7 +121,10 @@ void Light::RenderSceneIntoShadowBuffer(const Scene &scene, bool fetchToHost)
     const int size = scene._opts.shadowmap_size;
     if (fetchToHost) _shadowBuffer.resize((size_t)size * size);
     const mi355_light l = abi();
-    if (mi355_shadowmap_render(scene.context(), slot, &l, size, fetchToHost ? _shadowBuffer.data() : nullptr) != 0)
+    if (mi355_mgpu *m = scene.multi()) {
+        if (mi355_mgpu_shadowmap_render(m, slot, &l, size, fetchToHost ? _shadowBuffer.data() : nullptr) != 0)
+            raise(std::string("mi355_mgpu_shadowmap_render: ") + mi355_last_error());
+    } else if (mi355_shadowmap_render(scene.context(), slot, &l, size, fetchToHost ? _shadowBuffer.data() : nullptr) != 0)
         raise(std::string("mi355_shadowmap_render: ") + mi355_last_error());
 }
 
@@ -143,7 +146,9 @@ Scene::~Scene() { invalidateDevice(); }
 
 void Scene::invalidateDevice()
 {
-    if (_ctx) mi355_scene_destroy(_ctx);
+    if (_mgpu) mi355_mgpu_destroy(_mgpu);          // (owns its contexts, _ctx among them)
+    else if (_ctx) mi355_scene_destroy(_ctx);
+    _mgpu = nullptr;
     _ctx = nullptr;
     _bvhOnDevice = false;
 }
@@ -681,7 +686,7 @@ void Scene::CreateBVH(BvhBuilderChoice where)
                 _pCFBVH.swap(nodes);
                 _triIndexList.swap(tris);
                 _bvhMaxDepth = depth;
-                _bvhOnDevice = true;                                         // mi355_build_bvh installed it already
+                _bvhOnDevice = _mgpu == nullptr;                             // mi355_build_bvh installed it already (on that one device)
                 _bvhBuiltOnDevice = true;
                 return;
             }
@@ -751,16 +756,30 @@ mi355_ctx *Scene::context() const
 {
     if (!_ctx) {
         const mi355_scene_desc d = desc();
-        _ctx = mi355_scene_create(&d, _device);
-        if (!_ctx) raise(std::string("mi355_scene_create: ") + mi355_last_error());
+        if (_devices.size() > 1) {
+            _mgpu = mi355_mgpu_create(&d, _devices.data(), (int)_devices.size());
+            if (!_mgpu) raise(std::string("mi355_mgpu_create: ") + mi355_last_error());
+            _ctx = mi355_mgpu_context(_mgpu, 0);
+        } else {
+            _ctx = mi355_scene_create(&d, _devices.empty() ? _device : _devices[0]);
+            if (!_ctx) raise(std::string("mi355_scene_create: ") + mi355_last_error());
+        }
         _bvhOnDevice = false;
     }
     if (!_bvhOnDevice && !_pCFBVH.empty()) {
-        if (mi355_scene_set_bvh(_ctx, _pCFBVH.data(), (uint32_t)_pCFBVH.size(), _triIndexList.data(), (uint32_t)_triIndexList.size()) != 0)
-            raise(std::string("mi355_scene_set_bvh: ") + mi355_last_error());
+        // (with several devices: all of them, also after a build on the first one)
+        const int r = _mgpu ? mi355_mgpu_set_bvh(_mgpu, _pCFBVH.data(), (uint32_t)_pCFBVH.size(), _triIndexList.data(), (uint32_t)_triIndexList.size())
+                            : mi355_scene_set_bvh(_ctx, _pCFBVH.data(), (uint32_t)_pCFBVH.size(), _triIndexList.data(), (uint32_t)_triIndexList.size());
+        if (r != 0) raise(std::string("mi355_scene_set_bvh: ") + mi355_last_error());
         _bvhOnDevice = true;
     }
     return _ctx;
+}
+
+mi355_mgpu *Scene::multi() const
+{
+    context();
+    return _mgpu;
 }
 
 void Scene::renderMode(int mode, const Camera &eye, Screen &canvas)
@@ -772,6 +791,15 @@ void Scene::renderMode(int mode, const Camera &eye, Screen &canvas)
     mi355_light lights[MI355_MAX_LIGHTS];
     const int n = (int)std::min<size_t>(_lights.size(), MI355_MAX_LIGHTS);
     for (int i = 0; i < n; i++) lights[i] = _lights[i]->abi();
+    if (mi355_mgpu *m = multi()) {
+        for (int attempt = 0;; attempt++) {
+            const int r = mi355_mgpu_render(m, mode, &cam, lights, n, &o, canvas._pixels.data(), canvas._pitch, nullptr, &_lastStats);
+            if (r == -44 && attempt < 8) continue;                           // a rasterizer buffer has grown on some device: draw again
+            if (r != 0) raise(std::string("mi355_mgpu_render: ") + mi355_last_error());
+            break;
+        }
+        return;
+    }
     if (mi355_render(context(), mode, &cam, lights, n, &o, canvas._pixels.data(), canvas._pitch, nullptr, &_lastStats) != 0)
         raise(std::string("mi355_render: ") + mi355_last_error());
 }

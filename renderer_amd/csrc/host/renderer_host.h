@@ -111,6 +111,9 @@ struct Scene {                                         // Scene.h:32-86
 
     mi355_opts _opts;                                  // reference compile-time knobs, run-time here
     int _device = 0;
+    // More than one entry: every frame is drawn by all of these devices (interleaved 8-scanline bands, assembled on the
+    // first one: mi355_mgpu_*).  Set before the first frame; a device listed twice plays two ranks (tests on one GPU).
+    std::vector<int> _devices;
     mi355_stats _lastStats;
 
     Scene();
@@ -141,10 +144,12 @@ struct Scene {                                         // Scene.h:32-86
     // device plumbing
     mi355_scene_desc desc() const;
     mi355_ctx *context() const;                        // uploads on first use; throws std::string on failure
+    mi355_mgpu *multi() const;                         // the multi-GPU set when _devices has more than one entry, else NULL
     void invalidateDevice();
 
 private:
     mutable mi355_ctx *_ctx = nullptr;
+    mutable mi355_mgpu *_mgpu = nullptr;
     mutable bool _bvhOnDevice = false;
     void finishLoad();
     void renderMode(int mode, const Camera &, Screen &);
