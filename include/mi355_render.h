@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 1
+#define MI355_ABI_VERSION 2
 
 /* RenderMode, renderer.cc:68-79 */
 enum {
@@ -94,6 +94,11 @@ typedef struct {
      *            | 16, 32 reserved
      * [6], [7] reserved */
     int32_t tune[8];
+    /* Compile-time extras of the reference, off by default like there: */
+    int32_t mlaa;            /* configure --enable-mlaa && !$NOMLAA: the morphological anti-aliasing post filter (MLAA.cc) on
+                              * the finished frame of ANY mode, as Screen::ShowScreen applies it (Screen.h:132-135): over
+                              * pitch/4 x height words, which must be multiples of 4 and 8 (MLAA.cc:395-396); whole frames only */
+    int32_t reserved[7];     /* 0 */
 } mi355_opts;
 
 /* Counters.  Ray counts are always filled for raytrace modes; the rest only
@@ -191,6 +196,10 @@ int mi355_render_device(mi355_ctx *, int mode, const mi355_camera *, const mi355
                         const mi355_opts *, void *d_out_xrgb, int pitch_bytes, void *d_out_rgb_f32,
                         void *hip_stream);
 int mi355_fetch_stats(mi355_ctx *, mi355_stats *stats);
+
+/* The MLAA post filter alone (MLAA.cc:374-714: MLAA(pixels, NULL, pitch / 4, height)) on a frame in device memory, enqueued
+ * on hip_stream; what opts.mlaa does after a render.  pitch_bytes / 4 must be a multiple of 4, height of 8. */
+int mi355_mlaa_device(mi355_ctx *, void *d_xrgb, int pitch_bytes, int height, void *hip_stream);
 
 /* Several raytraced frames in ONE launch: the body of the reference's benchmark loop (renderer.cc:481-520: frame k of
  * the auto-spin orbit, k = 0..N-1, same scene, same size) for n_frames consecutive cameras.  A 1080p frame lasts as long

@@ -1329,3 +1329,219 @@ void orc_lighting(const orc_light *lights, int n_lights, const float *const *sha
 }
 
 } /* extern "C" */
+
+/* ---------- MLAA post filter (MLAA.cc:64-714, the call of Screen.h:132-135: in place, whole frame, one thread) ---------- */
+/* The reference's code is SSE; this is its scalar meaning, quirks included:
+ *  - flags: bit 31 of a pixel = it differs "significantly" (some byte by >= 16) from the pixel BELOW, bit 30 = from the
+ *    pixel to its RIGHT (MLAA.cc:48-57, 447-507); the last row / column gets no flag;
+ *  - blocks of 8 rows (then of 8 columns): "even blocks first, then odd ones", with the job arithmetic of MLAA.cc:560-585,
+ *    which for an odd number of blocks skips the last even block;
+ *  - findSeparationLine (MLAA.cc:122-172): the horizontal scan reads flags four aligned pixels at a time and can find
+ *    its next "line" in the first four pixels of the NEXT row. */
+namespace {
+
+static inline int ml_sum(uint32_t c) { return (int)((c >> 16) & 0xff) + (int)((c >> 8) & 0xff) + (int)(c & 0xff); }
+static inline uint32_t ml_mix2(float w1, uint32_t c1, float w2, uint32_t c2)
+{
+    unsigned char r1 = (c1 >> 16) & 0xff, g1 = (c1 >> 8) & 0xff, b1 = c1 & 0xff;
+    unsigned char r2 = (c2 >> 16) & 0xff, g2 = (c2 >> 8) & 0xff, b2 = c2 & 0xff;
+    r1 = (unsigned char)cvtt(r1 * w1 + r2 * w2);
+    g1 = (unsigned char)cvtt(g1 * w1 + g2 * w2);
+    b1 = (unsigned char)cvtt(b1 * w1 + b2 * w2);
+    return ((uint32_t)r1 << 16) | ((uint32_t)g1 << 8) | b1;
+}
+static inline bool ml_sig(uint32_t a, uint32_t b)
+{
+    for (int k = 0; k < 4; k++) {
+        const int x = (a >> (8 * k)) & 0xff, y = (b >> (8 * k)) & 0xff;
+        if (((x > y ? x - y : y - x) & 0xf0) != 0) return true;
+    }
+    return false;
+}
+
+struct Mlaa {
+    uint32_t *fbi; std::vector<uint32_t> fb0; int resX, resY;
+
+    int find(int &x0, int &x1, uint32_t fc, int xstart, int xend, int stepx)
+    {
+        if (xstart >= xend) return 0;
+        x0 = -1;
+        if (stepx > 1) {
+            for (;;) {
+                if (fb0[xstart] & fc) { x0 = xstart; break; }
+                xstart += stepx;
+                if (xstart > xend) return 0;
+            }
+        } else {
+            bool found = false;
+            while (xstart & 3) {
+                if (fb0[xstart] & (1u << 31)) { x0 = xstart; found = true; break; }
+                xstart++;
+            }
+            while (!found) {
+                int k = -1;
+                for (int i = 0; i < 4; i++) if (fb0[xstart + i] & (1u << 31)) { k = i; break; }
+                if (k >= 0) { xstart += k; x0 = xstart; break; }
+                xstart += 4;
+                if (xstart >= xend) return 0;
+            }
+        }
+        int len = 1;
+        xstart += stepx;
+        while (xstart <= xend && (fb0[xstart] & fc)) { len++; xstart += stepx; }
+        x1 = xstart - stepx;
+        return len;
+    }
+    float split(int l, int icb, int icm, int ipb, int ipm)
+    {
+        const int cc = ml_sum(fb0[icb]), cu = ml_sum(fb0[icm]), pc = ml_sum(fb0[ipb]), pu = ml_sum(fb0[ipm]);
+        return float(l * (pc - cu) + (cc - cu) - (pc - pu)) / (l * ((cc - cu) + (pc - pu)) + (cc - cu) - (pc - pu));
+    }
+    void upper(int &s0, int &s1, float &h0, float &h1, uint32_t fc, int x0, int x1, int len, int stepx, int befor, int after, int sz)
+    {
+        s0 = s1 = -1;
+        int nsteps = 0, xi = x0, t0 = -1, t1 = -1;
+        const uint32_t fo = fc ^ ((1u << 31) | (1u << 30));
+        do {
+            if ((fb0[xi] & fo) && (fb0[xi + befor] & fc)) {
+                h0 = split(len - nsteps, xi + stepx, xi + stepx + after, xi + befor, xi);
+                if (0 < h0 && h0 < 1) { s0 = xi + stepx; break; }
+            }
+            if ((fb0[xi] & fo) && t0 == -1) t0 = xi;
+            xi += stepx; nsteps++;
+        } while (xi < x1);
+        if (s0 == -1 && t0 != -1) { h0 = 0.5f; s0 = t0 + stepx; }
+        if (x1 + stepx >= sz) { if (fb0[x1] & fo) t1 = x1; x1 -= stepx; }
+        xi = x1;
+        do {
+            if ((fb0[xi] & fo) && (fb0[xi + stepx + befor] & fc)) {
+                h1 = split(nsteps, xi + stepx, xi + stepx + befor, xi + after, xi);
+                if (0 < h1 && h1 < 1) { s1 = xi; break; }
+            }
+            if ((fb0[xi] & fo) && t1 == -1) t1 = xi;
+            xi -= stepx; nsteps++;
+        } while (xi > x0);
+        if (s1 == -1 && t1 != -1) { h1 = 0.5f; s1 = t1; }
+    }
+    void lower(int &s0, int &s1, float &h0, float &h1, uint32_t fc, int x0, int x1, int len, int stepx, int after, int sz)
+    {
+        s0 = s1 = -1;
+        int nsteps = 0, xi = x0, t0 = -1, t1 = -1;
+        const uint32_t fo = fc ^ ((1u << 31) | (1u << 30));
+        do {
+            const int xia = xi + after;
+            if ((fb0[xia] & fo) && (fb0[xia] & fc)) {
+                if (xia + after < sz) h0 = split(len - nsteps, xia + stepx, xi + stepx, xia + after, xia);
+                else h0 = 0.5f;
+                if (0 < h0 && h0 < 1) { s0 = xi + stepx; break; }
+            }
+            if ((fb0[xia] & fo) && t0 == -1) t0 = xi;
+            xi += stepx; nsteps++;
+        } while (xi < x1);
+        if (s0 == -1 && t0 != -1) { h0 = 0.5f; s0 = t0 + stepx; }
+        if (x1 + stepx >= sz) { if (fb0[x1] & fo) t1 = x1; x1 -= stepx; }
+        xi = x1;
+        do {
+            const int xia = xi + after;
+            if ((fb0[xia] & fo) && (fb0[xia + stepx] & fo)) {
+                if (xia + after < sz) h1 = split(nsteps, xia + stepx, xia + after + stepx, xi, xia);
+                else h1 = 0.5f;
+                if (0 < h1 && h1 < 1) { s1 = xi; break; }
+            }
+            if ((fb0[xia] & fo) && t1 == -1) t1 = xi;
+            xi -= stepx; nsteps++;
+        } while (xi > x0);
+        if (s1 == -1 && t1 != -1) { h1 = 0.5f; s1 = t1; }
+    }
+    void blend(int x0, int x1, float h0, float h1, int stepx, int other, bool ushape)
+    {
+        float dh0 = 2 * (1 - h0) * stepx / (x1 - x0 + stepx);
+        float dh1 = 2 * (1 - h1) * stepx / (x1 - x0 + stepx);
+        int shift = other < 0 ? -other : 0;
+        x0 += shift; x1 += shift;
+        const int middle = (x0 + x1) / 2;
+        float area = h0 + 0.5f * dh0;
+        if (h0 == 0) { x0 += 1 + (x1 - x0) / stepx; area = dh1; }
+        else {
+            do {
+                fbi[x0] = ml_mix2(area, fbi[x0], 1 - area, fbi[x0 + other]);
+                area += dh0; x0 += stepx;
+            } while (x0 < middle);
+            if (x0 == middle) {
+                fbi[x0] = ml_mix2((1 - dh0 / 8), fbi[x0], dh0 / 8, fbi[x0 + other]);
+                if (!ushape) fbi[x0 + other] = ml_mix2(dh1 / 8, fbi[x0], (1 - dh1 / 8), fbi[x0 + other]);
+                x0 += stepx; area = dh1;
+            } else area = 0.5f * dh1;
+        }
+        if (h1 == 0) return;
+        if (ushape) { area = 1 - area; dh1 = -dh1; }
+        shift = ushape ? 0 : other;
+        do {
+            fbi[x0 + shift] = ml_mix2(area, fbi[x0], 1 - area, fbi[x0 + other]);
+            area += dh1; x0 += stepx;
+        } while (x0 <= x1);
+    }
+    void scan_block(bool vertical, int block)
+    {
+        const int rows_per_job = 8;
+        uint32_t fc; int resx, resy, stepy, stepx;
+        if (!vertical) { fc = 1u << 31; resx = resX; resy = resY; stepy = resX; stepx = 1; }
+        else { fc = 1u << 30; resx = resY; resy = resX; stepy = 1; stepx = resX; }
+        int yfrst = block * rows_per_job * stepy, ylast = yfrst + rows_per_job * stepy;
+        if (ylast >= resy * stepy) ylast = resy * stepy - stepy;
+        int befor = yfrst ? -stepy : 0;
+        const int after = stepy, sz = resX * resY;
+        for (int yc = yfrst; yc < ylast; yc += stepy, befor = -stepy) {
+            int x0, x1, len;
+            const int xend = yc + (resx - 1) * stepx;
+            int xstart = yc;
+            while ((len = find(x0, x1, fc, xstart, xend, stepx))) {
+                if (len == 1) {
+                    if (x0 + after >= sz) { xstart = x1 + stepx; continue; }   /* (the quirk's line in the LAST row: the reference writes beyond its frame) */
+                    const float weightc = 7.0f / 8;
+                    fbi[x0] = ml_mix2(weightc, fbi[x0], 1 - weightc, fbi[x0 + after]);
+                    fbi[x0 + after] = ml_mix2(1 - weightc, fbi[x0], weightc, fbi[x0 + after]);
+                } else {
+                    if (x0 == yc) { x0 += stepx; len--; }
+                    int ui0, ui1, li0, li1; float uh0 = 0, uh1 = 0, lh0 = 0, lh1 = 0;
+                    upper(ui0, ui1, uh0, uh1, fc, x0 - stepx, x1, len, stepx, befor, after, sz);
+                    lower(li0, li1, lh0, lh1, fc, x0 - stepx, x1, len, stepx, after, sz);
+                    bool done = false;
+                    if (ui0 != -1 && li1 != -1 && ui0 < li1) { blend(ui0, li1, uh0, lh1, stepx, after, false); done = true; }
+                    if (li0 != -1 && ui1 != -1 && li0 < ui1) { blend(li0, ui1, lh0, uh1, stepx, befor, false); done = true; }
+                    if (!done) {
+                        if (ui0 != -1 && ui1 != -1 && ui0 < ui1) blend(ui0, ui1, uh0, uh1, stepx, after, true);
+                        if (li0 != -1 && li1 != -1 && li0 < li1) blend(li0, li1, lh0, lh1, stepx, befor, true);
+                    }
+                }
+                xstart = x1 + stepx;
+            }
+        }
+    }
+};
+
+} // namespace
+
+extern "C" int orc_mlaa(uint32_t *pixels, int resX, int resY)
+{
+    if (resX < 8 || resY < 8 || (resX & 3) || (resY & 7)) return -1;      /* the reference's loops assume this (MLAA.cc:395-396) */
+    Mlaa m; m.fbi = pixels; m.resX = resX; m.resY = resY;
+    m.fb0.assign((size_t)resX * resY, 0u);
+    for (int y = 0; y < resY; y++)
+        for (int x = 0; x < resX; x++) {
+            const uint32_t c = pixels[(size_t)y * resX + x];
+            uint32_t f = c;
+            if (y + 1 < resY && ml_sig(c, pixels[(size_t)(y + 1) * resX + x])) f |= 1u << 31;
+            if (x + 1 < resX && ml_sig(c, pixels[(size_t)y * resX + x + 1])) f |= 1u << 30;
+            m.fb0[(size_t)y * resX + x] = f;
+        }
+    for (int vertical = 0; vertical < 2; vertical++) {
+        const int res = vertical ? resX : resY;
+        const int scanjobs = res / 8 + ((res % 8) ? 1 : 0);
+        for (int j = 0; j < scanjobs; j++) {                                  /* MLAA.cc:560-585 */
+            const int block = j < scanjobs / 2 ? 2 * j : 2 * (j - scanjobs / 2) + 1;
+            m.scan_block(vertical != 0, block);
+        }
+    }
+    return 0;
+}

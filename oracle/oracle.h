@@ -116,6 +116,10 @@ int orc_render(const orc_scene *, int mode, const orc_camera *, const orc_light 
 void orc_lighting(const orc_light *lights, int n_lights, const float *const *shadow_maps, const orc_opts *o,
                   int shadow_mode, int n, const float *pts10, float *rgb);
 
+/* MLAA post filter (MLAA.cc:374-714, called in place on the whole 32-bpp frame, Screen.h:132-135); width % 4 == 0,
+ * height % 8 == 0 like the reference's loops assume, else -1 */
+int orc_mlaa(uint32_t *pixels, int width, int height);
+
 #ifdef __cplusplus
 }
 #endif

@@ -227,6 +227,14 @@ def lighting(lights, n_lights: int, opts: Opts, shadow_mode: int, points, shadow
     return out
 
 
+def mlaa(pixels: np.ndarray) -> np.ndarray:
+    """MLAA(fbi, NULL, width, height) of the reference on a copy of `pixels` (uint32 [H, W])."""
+    out = np.ascontiguousarray(pixels, np.uint32).copy()
+    if lib().orc_mlaa(C.c_void_p(out.ctypes.data), C.c_int(out.shape[1]), C.c_int(out.shape[0])) != 0:
+        raise RuntimeError("orc_mlaa: frame size %dx%d is not one the reference's MLAA handles" % (out.shape[1], out.shape[0]))
+    return out
+
+
 def rgb_bytes(xrgb: np.ndarray) -> bytes:
     """Raw R,G,B bytes (row-major, top row first) -- the layout SURVEY.md 8(c) hashes."""
     a = np.ascontiguousarray(xrgb)

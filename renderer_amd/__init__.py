@@ -53,7 +53,7 @@ class Opts(C.Structure):
                 ("ambient", C.c_float), ("diffuse", C.c_float), ("specular", C.c_float),
                 ("clip_z", C.c_float), ("band_rows", C.c_int32), ("band_index", C.c_int32),
                 ("band_count", C.c_int32), ("compact_rows", C.c_int32), ("collect_stats", C.c_int32),
-                ("tune", C.c_int32 * 8)]
+                ("tune", C.c_int32 * 8), ("mlaa", C.c_int32), ("reserved", C.c_int32 * 7)]
 
 
 class Stats(C.Structure):

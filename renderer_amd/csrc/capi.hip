@@ -28,6 +28,7 @@ extern "C" hipError_t mi355i_bvh_launch_level(const void *cur, uint32_t n_cur, v
                                               uint32_t *tree_count, const float4 *prim, const uint32_t *list_cur, uint32_t *list_next,
                                               int depth, int many_planes, uint32_t *bad, hipStream_t st);
 extern "C" hipError_t mi355i_launch_points(const DevScene *, const FrameParams *, int as_triangles, hipStream_t);
+extern "C" hipError_t mi355i_launch_mlaa(uint32_t *d_pixels, uint32_t *d_scratch, int resX, int resY, hipStream_t st);
 struct RasterScratch;
 extern "C" hipError_t mi355i_launch_raster(const DevScene *, const FrameParams *, int mode, RasterScratch *,
                                            hipStream_t);
@@ -127,6 +128,7 @@ struct mi355_ctx {
     DevBuf ctrl;            // [0] (16 B, unused) | counters[CS_COUNT] | at MI_CTRL_DISPENSER_OFF: the raytrace pixel
                             // dispenser (MI_DISPENSERS counters, MI_DISPENSER_STRIDE words apart) -- one memset per frame
     DevBuf fb, fbf;         // internal framebuffer for the host-output path
+    DevBuf mlaa;            // MLAA's "input" copy of the frame (colours + separation flags)
     DevBuf cam_table;       // batched launches: FrameCam[MI355_MAX_BATCH]
     DevBuf bvh_prim, bvh_list[2], bvh_lvl[2], bvh_tree, bvh_cnt;   // mi355_build_bvh work buffers (kept for rebuilds)
     PinBuf pin_walk, pin_edge, pin_shade, pin_tree, pin_list, pin_ctl;   // host staging of the BVH streams and the builder
@@ -141,7 +143,7 @@ struct mi355_ctx {
     struct AsyncSlot {
         hipStream_t st = nullptr;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        DevBuf ctrl, fb;
+        DevBuf ctrl, fb, mlaa;
         PinBuf pin;
         RasterScratch *rs = nullptr;
         bool busy = false;
@@ -284,6 +286,12 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.prof_ordered = (flags & 8) ? 1 : 0;
     P.blocks_per_cu = t[4] > 0 ? t[4] : 0;
     P.rs_threads = t[3];
+    P.mlaa = o->mlaa ? 1 : 0;
+    if (P.mlaa) {
+        if (o->band_count > 1) return fail(-20, "mlaa works on whole frames: no band sharding (mi355_mgpu_render filters the assembled frame)");
+        if ((P.pitch_words & 3) || (o->height & 7) || P.pitch_words < 8 || o->height < 8)
+            return fail(-20, "mlaa: pitch / 4 = %d must be a multiple of 4 and the height %d of 8 (MLAA.cc:395-396)", P.pitch_words, o->height);
+    }
     P.exact_box = (flags & 1) ? 1 : 0;
     if (!c->boxes_tame) P.exact_box = 1;     // box coordinates outside the filtered test's validated range
     P.wave_prof = nullptr;
@@ -500,7 +508,8 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
     return 0;
 }
 
-int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipStream_t st, void *ctrl = nullptr, RasterScratch *rs = nullptr)
+int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipStream_t st, void *ctrl = nullptr, RasterScratch *rs = nullptr,
+                  DevBuf *mlaa_scratch = nullptr, uint32_t *const *frame_outs = nullptr)
 {
     if (!ctrl) ctrl = c->ctrl.p;
     if (!rs) rs = c->rscratch;
@@ -551,6 +560,16 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipSt
         return fail(-42, "unknown render mode %d", mode);
     }
     if (e != hipSuccess) return fail(-43, "kernel launch failed: %s", hipGetErrorString(e));
+    if (P.mlaa) {
+        DevBuf &scratch = mlaa_scratch ? *mlaa_scratch : c->mlaa;
+        HIP_TRY(scratch.ensure((size_t)P.pitch_words * P.H * 4), -31);
+        const int nf = (P.n_frames > 1 && P.cams) ? P.n_frames : 1;
+        for (int f = 0; f < nf; f++) {
+            uint32_t *px = nf > 1 ? frame_outs[f] : P.out;
+            if ((e = mi355i_launch_mlaa(px, (uint32_t *)scratch.p, P.pitch_words, P.H, st)) != hipSuccess)
+                return fail(-43, "MLAA launch failed: %s", hipGetErrorString(e));
+        }
+    }
     return 0;
 }
 
@@ -664,7 +683,7 @@ void mi355_scene_destroy(mi355_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->walk, &c->tri_edge, &c->tri_shade, &c->rs_tri, &c->rs_col, &c->rs_idx,
-                      &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->cam_table, &c->wave_prof, &c->bvh_prim, &c->bvh_list[0], &c->bvh_list[1],
+                      &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->mlaa, &c->cam_table, &c->wave_prof, &c->bvh_prim, &c->bvh_list[0], &c->bvh_list[1],
                       &c->bvh_lvl[0], &c->bvh_lvl[1], &c->bvh_tree, &c->bvh_cnt})
         b->release();
     for (PinBuf *b : {&c->pin_walk, &c->pin_edge, &c->pin_shade, &c->pin_tree, &c->pin_list, &c->pin_ctl}) b->release();
@@ -672,7 +691,7 @@ void mi355_scene_destroy(mi355_ctx *c)
     for (auto &o : c->orders) o.buf.release();
     for (auto &a : c->slot) {
         if (a.st) (void)hipStreamSynchronize(a.st);
-        a.ctrl.release(); a.fb.release(); a.pin.release();
+        a.ctrl.release(); a.fb.release(); a.mlaa.release(); a.pin.release();
         if (a.rs) mi355i_raster_scratch_destroy(a.rs);
         if (a.ev0) (void)hipEventDestroy(a.ev0);
         if (a.ev1) (void)hipEventDestroy(a.ev1);
@@ -893,6 +912,12 @@ int mi355_render_batch_device(mi355_ctx *c, int mode, int n_frames, const mi355_
             if (int r = fill_params(c, mode, &cams[f], lights + (size_t)f * n_lights, n_lights, o, d_out[f], pitch_bytes, nullptr, frames[f])) return r;
         hipError_t e = mi355i_launch_raster_batch(&c->dev, frames.data(), n_frames, mode, c->rscratch, user);
         if (e != hipSuccess) return fail(-43, "kernel launch failed: %s", hipGetErrorString(e));
+        if (frames[0].mlaa) {
+            HIP_TRY(c->mlaa.ensure((size_t)frames[0].pitch_words * frames[0].H * 4), -31);
+            for (int f = 0; f < n_frames; f++)
+                if ((e = mi355i_launch_mlaa((uint32_t *)d_out[f], (uint32_t *)c->mlaa.p, frames[0].pitch_words, frames[0].H, user)) != hipSuccess)
+                    return fail(-43, "MLAA launch failed: %s", hipGetErrorString(e));
+        }
         c->last_stats = false;
         return 0;
     }
@@ -921,7 +946,20 @@ int mi355_render_batch_device(mi355_ctx *c, int mode, int n_frames, const mi355_
     HIP_TRY(hipMemcpyAsync(c->cam_table.p, tab, sizeof(FrameCam) * (size_t)n_frames, hipMemcpyHostToDevice, st), -31);
     P.cams = (const FrameCam *)c->cam_table.p;
     P.n_frames = n_frames;
-    return enqueue_frame(c, mode, P, 0, st);
+    return enqueue_frame(c, mode, P, 0, st, nullptr, nullptr, nullptr, (uint32_t *const *)d_out);
+}
+
+int mi355_mlaa_device(mi355_ctx *c, void *d_xrgb, int pitch_bytes, int height, void *hip_stream)
+{
+    if (!c || !d_xrgb) return fail(-3, "mi355_mlaa_device: null argument");
+    const int pw = pitch_bytes / 4;
+    if (pitch_bytes <= 0 || (pitch_bytes & 3) || (pw & 3) || (height & 7) || pw < 8 || height < 8)
+        return fail(-20, "mlaa: pitch / 4 = %d must be a multiple of 4 and the height %d of 8 (MLAA.cc:395-396)", pw, height);
+    if (int r = select_device(c)) return r;
+    HIP_TRY(c->mlaa.ensure((size_t)pw * height * 4), -31);
+    const hipError_t e = mi355i_launch_mlaa((uint32_t *)d_xrgb, (uint32_t *)c->mlaa.p, pw, height, (hipStream_t)hip_stream);
+    if (e != hipSuccess) return fail(-43, "MLAA launch failed: %s", hipGetErrorString(e));
+    return 0;
 }
 
 int mi355_fetch_stats(mi355_ctx *c, mi355_stats *s)
@@ -1128,7 +1166,7 @@ int mi355_render_async(mi355_ctx *c, int mode, const mi355_camera *cam, const mi
     FrameParams P;
     if (int r = fill_params(c, mode, cam, lights, n_lights, o, a->fb.p, W * 4, nullptr, P, a->ctrl.p)) return r;
     HIP_TRY(hipEventRecord(a->ev0, a->st), -40);
-    if (int r = enqueue_frame(c, mode, P, 0, a->st, a->ctrl.p, a->rs)) return r;
+    if (int r = enqueue_frame(c, mode, P, 0, a->st, a->ctrl.p, a->rs, &a->mlaa)) return r;
     HIP_TRY(hipEventRecord(a->ev1, a->st), -40);
     a->staged = !host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4);
     if (a->staged) {
@@ -1160,7 +1198,7 @@ int mi355_render_wait(mi355_ctx *c, int ticket, mi355_stats *stats)
             if (!mi355i_raster_grow(a->rs)) break;
             FrameParams P;
             if (int r = fill_params(c, a->mode, &a->cam, a->lights, a->n_lights, &a->opts, a->fb.p, a->opts.width * 4, nullptr, P, a->ctrl.p)) return r;
-            if (int r = enqueue_frame(c, a->mode, P, 0, a->st, a->ctrl.p, a->rs)) return r;
+            if (int r = enqueue_frame(c, a->mode, P, 0, a->st, a->ctrl.p, a->rs, &a->mlaa)) return r;
             HIP_TRY(hipStreamSynchronize(a->st), -40);
             HIP_TRY(hipMemcpy(h, (char *)a->ctrl.p + 16, sizeof h, hipMemcpyDeviceToHost), -31);
             if (!h[CS_OVERFLOW]) break;

@@ -123,6 +123,7 @@ struct FrameParams {
     const uint32_t *tile_order; // dispenser index -> 8x8 tile id (heavy tiles first), or NULL = row-major
     int32_t blocks_per_cu;     // 0 = occupancy query
     int32_t rs_threads;        // rasterizer: threads per tile block (0 = default)
+    int32_t mlaa;              // MLAA post filter on the finished frame
 };
 
 enum CounterSlot {

@@ -196,8 +196,10 @@ int mi355_mgpu_render(mi355_mgpu *m, int mode, const mi355_camera *cam, const mi
     if (W <= 0 || H <= 0 || W > 16384 || H > 16384) return mfail(-20, "bad frame size %dx%d", W, H);
     if (pitch_bytes < W * 4 || (pitch_bytes & 3)) return mfail(-21, "bad pitch %d for width %d", pitch_bytes, W);
     if (int e = geometry(m, W, H)) return e;
+    if (o->mlaa && (((d_out ? pitch_bytes / 4 : W) & 3) || (H & 7))) return mfail(-20, "mlaa: the frame's pitch / 4 must be a multiple of 4 and its height of 8");
     for (int r = 0; r < m->n; r++) {
         mi355_opts ro = *o;
+        ro.mlaa = 0;                                 // (the filter runs on the ASSEMBLED frame, below)
         ro.band_rows = MGPU_BAND_ROWS; ro.band_index = r; ro.band_count = m->n; ro.compact_rows = 1;
         if (m->n == 1) { ro.band_count = 1; ro.compact_rows = 0; }
         if (m->rows[r] == 0) continue;
@@ -231,6 +233,8 @@ int mi355_mgpu_render(mi355_mgpu *m, int mode, const mi355_camera *cam, const mi
     const int dpitch = d_out ? pitch_bytes / 4 : W;
     hipLaunchKernelGGL(k_deinterleave, dim3(2048), dim3(256), 0, m->st[0], m->gathered, m->src, dst, W, H, dpitch);
     MG_HIP(hipGetLastError(), -43);
+    if (o->mlaa)
+        if (int e = mi355_mlaa_device(m->ctx[0], dst, dpitch * 4, H, m->st[0])) return e;
     if (!d_out) MG_HIP(hipMemcpy2DAsync(out_xrgb, (size_t)pitch_bytes, m->frame, (size_t)W * 4, (size_t)W * 4, (size_t)H, hipMemcpyDeviceToHost, m->st[0]), -31);
     for (int r = m->n - 1; r >= 0; r--) {                // (rank 0 last: its stream carries the assembly)
         MG_HIP(hipSetDevice(m->dev[r]), -10);

@@ -41,13 +41,13 @@ def test_abi_exports_every_declared_symbol():
     L = R.lib()
     for n in names:
         assert hasattr(L, n), "libmi355render.so does not export %s" % n
-    assert L.mi355_abi_version() == 1
+    assert L.mi355_abi_version() == 2
 
 
 def test_struct_sizes_match_header():
     # sizeof() as the C compiler sees them (computed from the header's field lists)
     assert C.sizeof(R.Camera) == 48 and C.sizeof(R.Light) == 96
-    assert C.sizeof(R.Opts) == 26 * 4
+    assert C.sizeof(R.Opts) == 34 * 4
     assert C.sizeof(R.Stats) == 11 * 8 + 8
     assert C.sizeof(R.SceneDesc) == 8 + 11 * 8
 

@@ -156,3 +156,34 @@ def test_bvh_builder_equals_the_reference_on_small_soups(oracle, tmp_path):
         assert np.array_equal(rn, nodes) and np.array_equal(ri, idx), "soup %d (%d triangles)" % (it, len(verts) // 3)
         done += 1
     assert done >= 40
+
+
+def test_mlaa_equals_the_reference(oracle, oracle_scene):
+    """f4: the oracle's scalar restatement of MLAA.cc (SSE in the reference) against MLAA.cc itself, compiled by
+    oracle/refcore: rendered frames and noise (which exercises every quirk of its aligned four-pixel scans)."""
+    s = oracle_scene("chessboard.tri")
+    cam, lights, n = oracle.benchmark_frame(5)
+    for (W, H) in ((800, 600), (1920, 1080), (64, 48), (8, 8), (12, 8)):
+        img, _, _ = s.render(6, cam, lights, n, oracle.default_opts(W, H))
+        ref = RC.mlaa(img)
+        assert np.array_equal(oracle.mlaa(img), ref), "%dx%d" % (W, H)
+        assert W < 64 or (ref != img).sum() > 100
+    rng = np.random.default_rng(3)
+    for it in range(60):
+        W, H = int(rng.integers(2, 40)) * 4, int(rng.integers(1, 20)) * 8
+        kind = it % 4
+        if kind == 0:
+            img = rng.integers(0, 1 << 24, (H, W), dtype=np.uint32)
+        elif kind == 1:
+            img = (rng.integers(0, 3, (H, W)) * 0x404040).astype(np.uint32)
+        elif kind == 2:
+            img = np.zeros((H, W), np.uint32)
+            for _ in range(6):
+                x0, y0 = int(rng.integers(0, W)), int(rng.integers(0, H))
+                img[y0:y0 + int(rng.integers(1, H)), x0:x0 + int(rng.integers(1, W))] = int(rng.integers(0, 1 << 24))
+        else:
+            yy, xx = np.mgrid[0:H, 0:W]
+            img = (((xx * int(rng.integers(1, 5)) + yy * int(rng.integers(1, 5))) // int(rng.integers(3, 17))) % 2 * 0xffffff).astype(np.uint32)
+        assert np.array_equal(oracle.mlaa(img), RC.mlaa(img)), "case %d (%dx%d)" % (it, W, H)
+    with pytest.raises(RuntimeError):
+        oracle.mlaa(np.zeros((10, 16), np.uint32))
