@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(1024) k_rs_scan(const RsGrid g, const RsBuffer
     }
 }
 
-#define RS_SCAN_LDS 2048          // frames with at most this many bins (1080p: 511, 4K: 2041): every block of k_rs_fill scans the counts itself
+#define RS_SCAN_LDS 2048          // frames with at most this many bins (1080p: 2041): every block of k_rs_fill scans the counts itself
 
 // The tiles of a frame, those whose bins hold entries first: k_rs_tile starts with them and knows the others to be
 // background without reading anything.  One block; off = the frame's bin offsets; tot = 4 words of LDS.
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
     }
     uint32_t n_rec = B.band_top[f];
     if (n_rec > B.band_cap) n_rec = B.band_cap;
-    const uint32_t n_items = n_rec * 24u;
+    const uint32_t n_items = n_rec * 3u;
     // (the blocks that filled bins are late already: the others take the band items when there are enough of them)
     const uint32_t fill_blocks = (n_tris + blockDim.x - 1) / blockDim.x;
     uint32_t first_block = 0, n_blocks = gridDim.x;

@@ -10,7 +10,7 @@
 // (bits of 1/z << 32 | ~triangle) and the frame is cut into RS_TW x RS_TH pixel tiles whose keys live in LDS:
 //
 //   rs_setup  1 thread / triangle   cull, transform, near reject, project, Filler<>  -> 112-byte record, tile box;
-//                                   counts the triangle into the COARSE bins (64 x 64 pixels) its box touches
+//                                   counts the triangle into the COARSE bins (32 x 32 pixels) its box touches
 //   rs_fill   1 thread / triangle   scan of the (few) coarse counts, (triangle, box) entries into the coarse bins
 //   rs_tile   1 block / tile        bin : the tile's coarse bin is filtered by box into an LDS list -- the fine binning
 //                                         never leaves the CU;
@@ -35,7 +35,7 @@
 #define RS_TW 16              // tile width  (pixels)
 #define RS_TH 16              // tile height (pixels)
 #define RS_TPIX (RS_TW * RS_TH)
-#define RS_CB 4               // a coarse bin covers RS_CB x RS_CB tiles
+#define RS_CB 2               // a coarse bin covers RS_CB x RS_CB tiles
 #define RS_COARSE_MAX 64      // largest coarse box binned bin by bin; beyond: the global bin
 #define RS_REC4 7             // float4 per triangle record
 #define RS_MAX_THREADS 512    // largest block k_rs_tile is built for (threads per tile: a launch parameter, FrameParams::chunk)
@@ -511,16 +511,17 @@ MI_HD void rs_set_band_base(const RsBuffers &B, uint32_t n_tris, uint32_t frame,
     ((uint32_t *)(B.box + slot))[3] = base;
 }
 
-// one interpolant of one edge of one band record: item p = (record * 3 + edge) * 8 + interpolant
+// one edge of one band record: item p = record * 3 + edge; all eight interpolants (they share the edge's geometry)
 MI_HD void rs_band_item(const RsBuffers &B, uint32_t n_tris, uint32_t frame, uint32_t p, int height)
 {
-    const uint32_t r = p / 24u;
-    const int e = (int)(p / 8u % 3u), c = (int)(p % 8u);
+    const uint32_t r = p / 3u;
+    const int e = (int)(p % 3u);
     if (r >= B.band_cap) return;                                  // (the frame reports the overflow)
     const uint2 own = B.band_owner[(size_t)frame * B.band_cap + r];
     const size_t slot = (size_t)frame * n_tris + own.x;
-    const float *rec = (const float *)(B.rec + slot * RS_REC4);
-    const int iy[3] = {(int)ff_f2u(rec[24]), (int)ff_f2u(rec[25]), (int)ff_f2u(rec[26])};
+    const float4 *rec4 = B.rec + slot * RS_REC4;
+    const float4 r6 = rec4[6];
+    const int iy[3] = {(int)ff_f2u(r6.x), (int)ff_f2u(r6.y), (int)ff_f2u(r6.z)};
     const int ia = rs_edge_a(e), ib = rs_edge_b(e);
     const RsEdgeRange R = rs_edge_range(iy[ia], iy[ib], height);
     if (R.horiz || R.first > R.last) return;
@@ -528,13 +529,23 @@ MI_HD void rs_band_item(const RsBuffers &B, uint32_t n_tris, uint32_t frame, uin
     const int rb = R.first > Y0 ? R.first : Y0;
     const int re = R.last < Y0 + RS_BH - 1 ? R.last : Y0 + RS_BH - 1;
     if (rb > re) return;
-    const float a = rec[8 * (R.sw ? ib : ia) + c], b = rec[8 * (R.sw ? ia : ib) + c];
-    const float d = (b - a) / (float)(R.y2 - R.y1);
-    float x = a;
-    if (R.y1 < 0) x += d * (float)-R.y1;
-    float *out = (float *)(B.band + ((size_t)frame * B.band_cap + r) * RS_BAND4 + e * 4) + 2 * c;
-    out[0] = ff_add(x, d, rb - R.first);
-    out[1] = d;
+    const int pa = R.sw ? ib : ia, pb = R.sw ? ia : ib;
+    const float4 a0 = rec4[2 * pa], a1 = rec4[2 * pa + 1], b0 = rec4[2 * pb], b1 = rec4[2 * pb + 1];
+    const float va[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, vb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    const float dy = (float)(R.y2 - R.y1);
+    const int k = rb - R.first;
+    float w[16];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const float d = (vb[c] - va[c]) / dy;
+        float x = va[c];
+        if (R.y1 < 0) x += d * (float)-R.y1;
+        w[2 * c] = ff_add(x, d, k);
+        w[2 * c + 1] = d;
+    }
+    float4 *out = B.band + ((size_t)frame * B.band_cap + r) * RS_BAND4 + e * 4;
+#pragma unroll
+    for (int q = 0; q < 4; q++) out[q] = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
 }
 
 // ---- rs_tile ------------------------------------------------------------------------------------------------------

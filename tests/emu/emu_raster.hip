@@ -88,7 +88,7 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
         }
     for (int f = 0; f < n_frames; f++) {                       // k_rs_fill, second half: the band records
         const uint32_t n_rec = B.band_top[f] < B.band_cap ? B.band_top[f] : B.band_cap;
-        for (uint32_t p = 0; p < n_rec * 24u; p++) rs_band_item(B, S.n_tris, (uint32_t)f, p, F[f].H);
+        for (uint32_t p = 0; p < n_rec * 3u; p++) rs_band_item(B, S.n_tris, (uint32_t)f, p, F[f].H);
     }
     static RsTileLds lds;                                      // the block's LDS
     for (int f = 0; f < n_frames; f++)                         // k_rs_tile, one block per tile
