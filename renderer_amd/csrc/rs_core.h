@@ -36,7 +36,7 @@
 #define RS_TH 16              // tile height (pixels)
 #define RS_TPIX (RS_TW * RS_TH)
 #define RS_CB 2               // a coarse bin covers RS_CB x RS_CB tiles
-#define RS_COARSE_MAX 64      // largest coarse box binned bin by bin; beyond: the global bin
+#define RS_COARSE_MAX 512     // largest coarse box binned bin by bin (up to 512 x 1024 pixels); beyond: the global bin
 #define RS_REC4 7             // float4 per triangle record
 #define RS_MAX_THREADS 512    // largest block k_rs_tile is built for (threads per tile: a launch parameter, FrameParams::chunk)
 #define RS_LIST_CAP 1024      // bin entries filtered per pass of a tile (LDS list of accepted triangles)
