@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(1024) k_rs_scan(const RsGrid g, const RsBuffer
     }
 }
 
-#define RS_SCAN_LDS 2048          // frames with at most this many bins (1080p: 2041): every block of k_rs_fill scans the counts itself
+#define RS_SCAN_LDS 2048          // frames with at most this many bins (1080p: 511, 4K: 2041): every block of k_rs_fill scans the counts itself
 
 // The tiles of a frame, those whose bins hold entries first: k_rs_tile starts with them and knows the others to be
 // background without reading anything.  One block; off = the frame's bin offsets; tot = 4 words of LDS.

@@ -10,7 +10,7 @@
 // (bits of 1/z << 32 | ~triangle) and the frame is cut into RS_TW x RS_TH pixel tiles whose keys live in LDS:
 //
 //   rs_setup  1 thread / triangle   cull, transform, near reject, project, Filler<>  -> 112-byte record, tile box;
-//                                   counts the triangle into the COARSE bins (32 x 32 pixels) its box touches
+//                                   counts the triangle into the COARSE bins (64 x 64 pixels) its box touches
 //   rs_fill   1 thread / triangle   scan of the (few) coarse counts, (triangle, box) entries into the coarse bins
 //   rs_tile   1 block / tile        bin : the tile's coarse bin is filtered by box into an LDS list -- the fine binning
 //                                         never leaves the CU;
@@ -35,8 +35,8 @@
 #define RS_TW 16              // tile width  (pixels)
 #define RS_TH 16              // tile height (pixels)
 #define RS_TPIX (RS_TW * RS_TH)
-#define RS_CB 2               // a coarse bin covers RS_CB x RS_CB tiles
-#define RS_COARSE_MAX 512     // largest coarse box binned bin by bin (up to 512 x 1024 pixels); beyond: the global bin
+#define RS_CB 4               // a coarse bin covers RS_CB x RS_CB tiles
+#define RS_COARSE_MAX 64      // largest coarse box binned bin by bin; beyond: the global bin
 #define RS_REC4 7             // float4 per triangle record
 #define RS_MAX_THREADS 512    // largest block k_rs_tile is built for (threads per tile: a launch parameter, FrameParams::chunk)
 #define RS_LIST_CAP 1024      // bin entries filtered per pass of a tile (LDS list of accepted triangles)
