@@ -302,9 +302,33 @@ MI_DEV void tile_order(const RsGrid &g, const RsBuffers &B, uint32_t f, const ui
     if (tid == 0) order[0] = n_active;
 }
 
-// Bin entries and band records.  LDS_SCAN: the bin offsets are the block's own exclusive scan of the frame's counts
-// (block 0 also stores them for k_rs_tile); otherwise they come from k_rs_scan.  Then every thread of the grid takes
-// band items (one interpolant of one edge of one record each) until they are done.
+// exclusive scan of frame f's bin counts into LDS (soff[n_bins + 1]) by a 256-thread block; tot: 4 words of LDS
+MI_DEV uint32_t block_scan_counts(const RsGrid &g, const RsBuffers &B, uint32_t f, uint32_t *soff, uint32_t *tot)
+{
+    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t n = (uint32_t)g.n_bins, per = (n + 255u) / 256u;      // <= 8 consecutive counts per thread
+    const uint32_t *cnt = B.count + (size_t)f * n;
+    const uint32_t b = (uint32_t)tid * per < n ? (uint32_t)tid * per : n, e = b + per < n ? b + per : n;
+    uint32_t c[(RS_SCAN_LDS + 255) / 256], s = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < (RS_SCAN_LDS + 255) / 256; i++) { c[i] = b + i < e ? cnt[b + i] : 0u; s += c[i]; }
+    uint32_t incl = s;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) tot[wid] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int w = 0; w < 4; w++) { const uint32_t v = tot[w]; if (w < wid) before += v; total += v; }
+    uint32_t run = before + incl - s;
+#pragma unroll
+    for (uint32_t i = 0; i < (RS_SCAN_LDS + 255) / 256; i++) if (b + i < e) { soff[b + i] = run; run += c[i]; }
+    if (tid == 0) soff[n] = total;
+    __syncthreads();
+    return total;
+}
+
+// Bin entries and band records.  LDS_SCAN: the bin offsets are the block's own exclusive scan of the frame's counts;
+// otherwise they come from k_rs_scan.  The blocks beyond the triangles take the band items (one edge of one record each)
+// and the background; the last of them also stores the offsets and the tile order for k_rs_tile.
 template <bool LDS_SCAN>
 __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers B, uint32_t n_tris, const FrameParams P, const FrameParams *batch,
                                                  unsigned long long *counters)
@@ -315,61 +339,48 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
     __shared__ uint32_t soff[LDS_SCAN ? RS_SCAN_LDS + 1 : 1];
     __shared__ uint32_t stot[4];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (blockIdx.x * blockDim.x < n_tris) {
+    const int tid = (int)threadIdx.x;
+    const uint32_t fill_blocks = (n_tris + blockDim.x - 1) / blockDim.x;
+    const bool spare = gridDim.x >= 2u * fill_blocks;                 // blocks beyond the triangles exist and take the rest
+    const uint32_t order_block = spare ? gridDim.x - 1u : 0u;         // who publishes offsets and tile order
+    if (blockIdx.x < fill_blocks || blockIdx.x == order_block) {
         const uint32_t *off = B.offset + (size_t)f * (g.n_bins + 1);
         if (LDS_SCAN) {
-            const uint32_t n = (uint32_t)g.n_bins, per = (n + 255u) / 256u;      // <= 8 consecutive counts per thread
-            const uint32_t *cnt = B.count + (size_t)f * n;
-            const uint32_t b = (uint32_t)tid * per < n ? (uint32_t)tid * per : n, e = b + per < n ? b + per : n;
-            uint32_t c[(RS_SCAN_LDS + 255) / 256], s = 0;
-#pragma unroll
-            for (uint32_t i = 0; i < (RS_SCAN_LDS + 255) / 256; i++) { c[i] = b + i < e ? cnt[b + i] : 0u; s += c[i]; }
-            uint32_t incl = s;
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += v; }
-            if (lane == 63) stot[wid] = incl;
-            __syncthreads();
-            uint32_t before = 0, total = 0;
-            for (int w = 0; w < 4; w++) { const uint32_t v = stot[w]; if (w < wid) before += v; total += v; }
-            uint32_t run = before + incl - s;
-#pragma unroll
-            for (uint32_t i = 0; i < (RS_SCAN_LDS + 255) / 256; i++) if (b + i < e) { soff[b + i] = run; run += c[i]; }
-            if (tid == 0) soff[n] = total;
-            __syncthreads();
-            if (blockIdx.x == 0) {
-                uint32_t *goff = B.offset + (size_t)f * (n + 1);
-                for (uint32_t i = (uint32_t)tid; i <= n; i += 256u) goff[i] = soff[i];
+            const uint32_t total = block_scan_counts(g, B, f, soff, stot);
+            if (blockIdx.x == order_block) {
+                uint32_t *goff = B.offset + (size_t)f * ((size_t)g.n_bins + 1);
+                for (uint32_t i = (uint32_t)tid; i <= (uint32_t)g.n_bins; i += 256u) goff[i] = soff[i];
                 if (tid == 0 && total > B.bins_cap && counters) atomicAdd(&counters[CS_OVERFLOW], (unsigned long long)(total - B.bins_cap));
             }
             off = soff;
         }
-        if (blockIdx.x == 0) tile_order(g, B, f, off, stot);      // (off: this block's scan, or k_rs_scan's)
-        uint4 box = make_uint4(0xffffffffu, 0u, 0u, 0u);
-        if (t < n_tris) box = B.box[(size_t)f * n_tris + t];
-        const uint32_t total = block_pairs_begin(bp, box, box.x == 0xffffffffu ? 0 : rs_bin_count(box));
-        uint32_t *cur = B.cursor + (size_t)f * g.n_bins;
-        uint4 *bins = B.bins + (size_t)f * B.bins_cap;
-        for (uint32_t base = 0; base < total; base += 256u) {
-            const uint32_t p = base + (uint32_t)tid;
-            const bool act = p < total;
-            int owner = 0, k = 0;
-            if (act) block_pair(bp, p, owner, k);
-            const uint4 pb = bp.box[owner];
-            const int bin = act ? rs_bin_at(g, pb, k) : -1;
-            const uint32_t pos = wave_bin_add<true>(cur, bin, act);
-            if (act) {
-                const uint32_t at = off[bin] + pos;
-                if (at < B.bins_cap) bins[at] = make_uint4(blockIdx.x * blockDim.x + (uint32_t)owner, pb.x, pb.z, pb.w);   // (else: the overflow has been reported)
+        if (blockIdx.x == order_block) tile_order(g, B, f, off, stot);      // (off: this block's scan, or k_rs_scan's)
+        if (blockIdx.x < fill_blocks) {
+            uint4 box = make_uint4(0xffffffffu, 0u, 0u, 0u);
+            if (t < n_tris) box = B.box[(size_t)f * n_tris + t];
+            const uint32_t total = block_pairs_begin(bp, box, box.x == 0xffffffffu ? 0 : rs_bin_count(box));
+            uint32_t *cur = B.cursor + (size_t)f * g.n_bins;
+            uint4 *bins = B.bins + (size_t)f * B.bins_cap;
+            for (uint32_t base = 0; base < total; base += 256u) {
+                const uint32_t p = base + (uint32_t)tid;
+                const bool act = p < total;
+                int owner = 0, k = 0;
+                if (act) block_pair(bp, p, owner, k);
+                const uint4 pb = bp.box[owner];
+                const int bin = act ? rs_bin_at(g, pb, k) : -1;
+                const uint32_t pos = wave_bin_add<true>(cur, bin, act);
+                if (act) {
+                    const uint32_t at = off[bin] + pos;
+                    if (at < B.bins_cap) bins[at] = make_uint4(blockIdx.x * blockDim.x + (uint32_t)owner, pb.x, pb.z, pb.w);   // (else: the overflow has been reported)
+                }
             }
         }
     }
     uint32_t n_rec = B.band_top[f];
     if (n_rec > B.band_cap) n_rec = B.band_cap;
     const uint32_t n_items = n_rec * 3u;
-    // (the blocks that filled bins are late already: the others take the band items when there are enough of them)
-    const uint32_t fill_blocks = (n_tris + blockDim.x - 1) / blockDim.x;
     uint32_t first_block = 0, n_blocks = gridDim.x;
-    if (gridDim.x >= 2u * fill_blocks) { first_block = fill_blocks; n_blocks = gridDim.x - fill_blocks; }
+    if (spare) { first_block = fill_blocks; n_blocks = gridDim.x - fill_blocks; }
     if (blockIdx.x < first_block) return;
     {   // this block's share of the background (Screen::ClearScreen): the tile kernel only visits tiles that hold triangles
         const unsigned long long total = (unsigned long long)F.out_rows * (unsigned long long)F.W;
