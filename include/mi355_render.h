@@ -98,7 +98,17 @@ typedef struct {
     int32_t mlaa;            /* configure --enable-mlaa && !$NOMLAA: the morphological anti-aliasing post filter (MLAA.cc) on
                               * the finished frame of ANY mode, as Screen::ShowScreen applies it (Screen.h:132-135): over
                               * pitch/4 x height words, which must be multiples of 4 and 8 (MLAA.cc:395-396); whole frames only */
-    int32_t reserved[7];     /* 0 */
+    int32_t use_refractions; /* -DREFRACTIONS (Raytracer.cc:72, 526-551): every hit also spawns a refracted ray traced
+                              * without backface culling; the ray tree becomes binary (1 + 2 + 4 rays at depth 3) */
+    float refract_rate;      /* REFRACTIONS_RATE 0.58 */
+    int32_t ambient_occlusion; /* -DAMBIENT_OCCLUSION (Raytracer.cc:76, 386-417): the ambient term of every hit from
+                              * ao_samples random rays of length ao_range instead of the model's per-vertex coefficients.
+                              * The reference draws from rand() (no defined order under OpenMP); this path draws from a
+                              * counter-based generator keyed by pixel, sample and ray-tree node, so frames are
+                              * reproducible and independent of scheduling */
+    int32_t ao_samples;      /* AMBIENT_SAMPLES 32 */
+    float ao_range;          /* AMBIENT_RANGE 0.15f */
+    int32_t reserved[2];     /* 0 */
 } mi355_opts;
 
 /* Counters.  Ray counts are always filled for raytrace modes; the rest only

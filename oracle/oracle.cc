@@ -490,7 +490,20 @@ struct RtCtx {
     const orc_light *lights;
     int nLights;
     orc_stats st;
+    int px, py, sample;   /* ray-cast ambient occlusion, generator 2: the pixel sample being traced */
 };
+
+/* lowbias32-style integer mixer; the device path (k_raytrace.hip) draws the same numbers */
+static inline uint32_t ao_mix(uint32_t v)
+{
+    v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+    return v;
+}
+extern "C" uint32_t orc_ao_random(int x, int y, int sample, uint32_t path, uint32_t index)
+{
+    const uint32_t key = ao_mix(ao_mix(((uint32_t)y << 16) ^ (uint32_t)x) + (uint32_t)sample * 0x9e3779b9u) ^ (path * 0x85ebca6bu);
+    return ao_mix(key + index * 0x9e3779b9u) >> 1;
+}
 
 /* Raytracer.cc:99-151 */
 static inline bool ray_box(const V3 &o, const V3 &d, const Node32 &box)
@@ -517,7 +530,7 @@ static inline bool ray_box(const V3 &o, const V3 &d, const Node32 &box)
 /* Raytracer.cc:183-308.  shadow: pointHit holds the light position on entry. */
 template <bool shadow>
 static bool bvh_intersect(RtCtx &c, const V3 &origin, const V3 &ray, int avoidSelf, int &bestTri,
-                          V3 &pointHit, float &kAB, float &kBC, float &kCA)
+                          V3 &pointHit, float &kAB, float &kBC, float &kCA, const bool doCulling = true)
 {
     const orc_scene &s = *c.s;
     const float nudge = c.o->nudge;
@@ -546,7 +559,7 @@ static bool bvh_intersect(RtCtx &c, const V3 &origin, const V3 &ray, int avoidSe
                 const Tri &t = s.tris[ti];
                 c.st.tri_tests++;
                 if (avoidSelf == ti) continue;
-                if (!t.twoSided) {       /* doCulling is always true in the default build */
+                if (doCulling && !t.twoSided) {       /* :247; false only below a refraction ray */
                     V3 fromTriToOrigin = sub(origin, t.center);
                     if (dot(fromTriToOrigin, t.normal) < 0) continue;
                 }
@@ -577,9 +590,9 @@ static bool bvh_intersect(RtCtx &c, const V3 &origin, const V3 &ray, int avoidSe
     return false;
 }
 
-/* Raytracer.cc:315-553 (default build: USE_PHONG_NORMAL, USE_SHADOWS, REFLECTIONS,
- * no REFRACTIONS, no ray-cast AMBIENT_OCCLUSION) */
-static Px raytrace(RtCtx &c, V3 origin, V3 ray, int avoidSelf, int depth)
+/* Raytracer.cc:315-553: USE_PHONG_NORMAL, USE_SHADOWS; REFLECTIONS / REFRACTIONS / AMBIENT_OCCLUSION by option.
+ * doCulling is the template parameter of Raytrace<>: true for camera and reflection rays, false below a refraction. */
+static Px raytrace(RtCtx &c, V3 origin, V3 ray, int avoidSelf, int depth, const bool doCulling = true, const uint32_t path = 1)
 {
     const orc_scene &s = *c.s;
     const orc_opts &o = *c.o;
@@ -587,7 +600,7 @@ static Px raytrace(RtCtx &c, V3 origin, V3 ray, int avoidSelf, int depth)
     int best = -1;
     V3 hit;
     float kAB = 0.f, kBC = 0.f, kCA = 0.f;
-    if (!bvh_intersect<false>(c, origin, ray, avoidSelf, best, hit, kAB, kBC, kCA))
+    if (!bvh_intersect<false>(c, origin, ray, avoidSelf, best, hit, kAB, kBC, kCA, doCulling))
         return Px(0.f, 0.f, 0.f);
     c.st.shaded_hits++;
     avoidSelf = best;
@@ -601,9 +614,37 @@ static Px raytrace(RtCtx &c, V3 origin, V3 ray, int avoidSelf, int depth)
     float CAx = kCA * distance(vC.p, vA.p);
     V3 nA = mul(vA.n, BCx / area), nB = mul(vB.n, CAx / area), nC = mul(vC.n, ABx / area);
     V3 phongNormal = normalized(add(add(nA, nB), nC));                   /* (A+B)+C, :380 */
-    float aoc = vA.ao * BCx / area + vB.ao * CAx / area + vC.ao * ABx / area;   /* :429-432 */
-    float ambientFactor = (float)((o.ambient * aoc / 255.0) / 255.0);            /* :435 */
-    px_scale(color, ambientFactor);
+    if (o.ambient_occlusion) {
+        /* :386-417: AMBIENT_SAMPLES random rays in the hemisphere around the normal, each a shadow-type query
+         * (always culled) towards the point AMBIENT_RANGE away */
+        int i = 0;
+        uint32_t draw = 0;
+        float totalLight = 0.f, maxLight = 0.f;
+        const int half = RAND_MAX / 2;
+        auto next = [&]() -> int {
+            return o.ambient_occlusion == 1 ? rand() : (int)orc_ao_random(c.px, c.py, c.sample, path, draw++);
+        };
+        while (i < o.ao_samples) {
+            V3 ambientRay = phongNormal;
+            ambientRay.x += float(next() - half) / half;
+            ambientRay.y += float(next() - half) / half;
+            ambientRay.z += float(next() - half) / half;
+            float cosangle = dot(ambientRay, phongNormal);
+            if (cosangle < 0.f) continue;
+            i++;
+            maxLight += cosangle;
+            ambientRay = normalized(ambientRay);
+            V3 temp = add(hit, mul(ambientRay, o.ao_range));
+            int dummy; float k0 = 0, k1 = 0, k2 = 0;
+            if (!bvh_intersect<true>(c, hit, ambientRay, avoidSelf, dummy, temp, k0, k1, k2, true))
+                totalLight += cosangle;
+        }
+        px_scale(color, (float)((o.ambient / 255.0) * (totalLight / maxLight)));       /* :417 */
+    } else {
+        float aoc = vA.ao * BCx / area + vB.ao * CAx / area + vC.ao * ABx / area;   /* :429-432 */
+        float ambientFactor = (float)((o.ambient * aoc / 255.0) / 255.0);            /* :435 */
+        px_scale(color, ambientFactor);
+    }
 
     for (int i = 0; i < c.nLights; i++) {
         const V3 light(c.lights[i].pos[0], c.lights[i].pos[1], c.lights[i].pos[2]);
@@ -613,7 +654,7 @@ static Px raytrace(RtCtx &c, V3 origin, V3 ray, int avoidSelf, int depth)
             float distSq = lengthsq(pointToLight);
             V3 shadowRay = divs(pointToLight, sqrtf(distSq));
             int dummy; V3 lp = light; float k0 = 0, k1 = 0, k2 = 0;
-            if (bvh_intersect<true>(c, hit, shadowRay, avoidSelf, dummy, lp, k0, k1, k2))
+            if (bvh_intersect<true>(c, hit, shadowRay, avoidSelf, dummy, lp, k0, k1, k2, doCulling))   /* :458 */
                 continue;
         }
         pointToLight = normalized(pointToLight);
@@ -634,12 +675,30 @@ static Px raytrace(RtCtx &c, V3 origin, V3 ray, int avoidSelf, int depth)
         }
         px_acc(color, dColor);
     }
-    if (!o.use_reflections) return color;   /* `return color;` -- no clamping operator+ without REFLECTIONS */
-    float c1 = -dot(ray, phongNormal);
-    V3 refl = normalized(add(ray, mul(phongNormal, 2.0f * c1)));
-    Px child = raytrace(c, hit, refl, avoidSelf, depth + 1);
-    const float rate = o.reflect_rate;
-    return px_add_clamped(color, Px(rate * child.r, rate * child.g, rate * child.b));  /* :538-551 */
+    if (!o.use_reflections && !o.use_refractions) return color;   /* `return color;` -- no clamping operator+ */
+    float c1 = -dot(ray, phongNormal);                                          /* :507-511 */
+    V3 refl, refr;
+    if (o.use_reflections) refl = normalized(add(ray, mul(phongNormal, 2.0f * c1)));
+    if (o.use_refractions) {                                                     /* :526-535 */
+        float n1 = 1.f + float(depth & 1);
+        float n2 = 2.f + float(depth & 1);
+        float n = n1 / n2;
+        float c2 = sqrtf(1.f - n * n * (1.f - c1 * c1));
+        refr = normalized(add(mul(ray, n), mul(phongNormal, n * c1 - c2)));
+    }
+    /* :537-551: color + reflected * rate + refracted * rate, every + the clamping Pixel::operator+ */
+    Px sum = color;
+    if (o.use_reflections) {
+        Px child = raytrace(c, hit, refl, avoidSelf, depth + 1, true, 2 * path);
+        const float rate = o.reflect_rate;
+        sum = px_add_clamped(sum, Px(rate * child.r, rate * child.g, rate * child.b));
+    }
+    if (o.use_refractions) {
+        Px child = raytrace(c, hit, refr, avoidSelf, depth + 1, false, 2 * path + 1);
+        const float rate = o.refract_rate;
+        sum = px_add_clamped(sum, Px(rate * child.r, rate * child.g, rate * child.b));
+    }
+    return sum;
 }
 
 static inline bool row_selected(const orc_opts &o, int y)
@@ -658,6 +717,7 @@ static void render_raytrace(const orc_scene &s, const orc_camera &cam, const orc
     const V3 eye(cam.eye[0], cam.eye[1], cam.eye[2]);
     const bool aa = o.antialias != 0;
     int threads = o.threads > 1 ? o.threads : 1;
+    if (o.ambient_occlusion == 1) { threads = 1; srand(1); }     /* the rand() sequence of a fresh single-thread process */
     (void)threads;
 #ifdef _OPENMP
 #pragma omp parallel num_threads(threads)
@@ -687,6 +747,7 @@ static void render_raytrace(const orc_scene &s, const orc_camera &cam, const orc
                     rw = add(rw, mul(mv.r2, rc.y));
                     rw = add(rw, mul(mv.r3, rc.z));
                     rw = normalized(rw);
+                    c.px = x; c.py = y; c.sample = traced;
                     px_acc(fin, raytrace(c, eye, rw, -1, 0));
                 }
                 if (aa) { fin.b = fin.b / 4.f; fin.g = fin.g / 4.f; fin.r = fin.r / 4.f; }
@@ -1049,6 +1110,7 @@ void orc_default_opts(orc_opts *o, int width, int height)
     o->reflect_rate = 0.375f; o->nudge = 1e-5f;
     o->ambient = 96.f; o->diffuse = 128.f; o->specular = 192.f; o->clip_z = 0.2f;
     o->band_rows = 0; o->band_index = 0; o->band_count = 1; o->threads = 1;
+    o->use_refractions = 0; o->refract_rate = 0.58f; o->ambient_occlusion = 0; o->ao_samples = 32; o->ao_range = 0.15f;
 }
 
 orc_scene *orc_scene_load(const char *path, char *err, int errlen)

@@ -60,7 +60,21 @@ typedef struct {
      * render only rows y with ((y / band_rows) % band_count) == band_index.  */
     int32_t band_rows, band_index, band_count;
     int32_t threads;           /* OpenMP threads for raytrace modes (<=1: serial) */
+    /* compile-time options of Raytracer.cc the default build leaves off (Raytracer.cc:70-80) */
+    int32_t use_refractions;   /* REFRACTIONS                                        */
+    float refract_rate;        /* REFRACTIONS_RATE 0.58                              */
+    int32_t ambient_occlusion; /* AMBIENT_OCCLUSION: 0 off (per-vertex coefficients);
+                                * 1 the C library's rand() sequence, reseeded with 1 per call: what the
+                                *   reference binary draws when it traces the same rays in the same order
+                                *   on one thread (forces threads = 1);
+                                * 2 the counter-based generator of the device path (orc_ao_random)   */
+    int32_t ao_samples;        /* AMBIENT_SAMPLES 32                                 */
+    float ao_range;            /* AMBIENT_RANGE 0.15f                                */
 } orc_opts;
+
+/* Generator of ambient_occlusion == 2: draw number `index` of the hit that is node `path` of the ray tree (root 1,
+ * reflection child 2p, refraction child 2p+1) of sample `sample` of screen pixel (x, y); value in [0, RAND_MAX]. */
+uint32_t orc_ao_random(int x, int y, int sample, uint32_t path, uint32_t index);
 
 /* Counters of SURVEY.md 8(d); a KAT against the reference's probe */
 typedef struct {

@@ -31,7 +31,9 @@ class Opts(C.Structure):
                 ("shadowmap_size", C.c_int32), ("reflect_rate", C.c_float), ("nudge", C.c_float),
                 ("ambient", C.c_float), ("diffuse", C.c_float), ("specular", C.c_float),
                 ("clip_z", C.c_float), ("band_rows", C.c_int32), ("band_index", C.c_int32),
-                ("band_count", C.c_int32), ("threads", C.c_int32)]
+                ("band_count", C.c_int32), ("threads", C.c_int32),
+                ("use_refractions", C.c_int32), ("refract_rate", C.c_float), ("ambient_occlusion", C.c_int32),
+                ("ao_samples", C.c_int32), ("ao_range", C.c_float)]
 
 
 class Stats(C.Structure):

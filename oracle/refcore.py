@@ -29,13 +29,13 @@ def available() -> bool:
     return os.path.exists(BINARY)
 
 
-def _run(cmd: str, blobs, out_dtype, timeout=1800):
+def _run(cmd: str, blobs, out_dtype, timeout=1800, variant=""):
     with tempfile.TemporaryDirectory() as d:
         fin, fout = os.path.join(d, "in"), os.path.join(d, "out")
         with open(fin, "wb") as f:
             for b in blobs:
                 f.write(b if isinstance(b, (bytes, bytearray)) else np.ascontiguousarray(b).tobytes())
-        subprocess.run([BINARY, cmd, fin, fout], check=True, timeout=timeout, stdout=subprocess.DEVNULL)
+        subprocess.run([BINARY + variant, cmd, fin, fout], check=True, timeout=timeout, stdout=subprocess.DEVNULL)
         return np.fromfile(fout, dtype=out_dtype)
 
 
@@ -85,13 +85,16 @@ def primary_rays(cam, W, H, SD, xs=None, ys=None, sub=None):
     return np.concatenate([o, d], axis=-1).reshape(-1, 6).astype(f)
 
 
-def raytrace(osc, cam, lights, n_lights, rays, max_depth=3):
+def raytrace(osc, cam, lights, n_lights, rays, max_depth=3, variant=""):
     """Raytrace<true>(origin, dir, NULL, 3 - max_depth) of the reference for every ray -> (n, 3) r,g,b floats.
-    (MAX_RAY_DEPTH is a #define of 3 in Raytracer.cc:56; starting the recursion at depth 3 - k leaves k levels.)"""
+    (MAX_RAY_DEPTH is a #define of 3 in Raytracer.cc:56; starting the recursion at depth 3 - k leaves k levels.)
+    variant "_refr": the build with -DREFRACTIONS (its two refractive indices alternate with the parity of the depth,
+    so only max_depth 3 and 1 start on the parity a camera ray has); "_ao": -DAMBIENT_OCCLUSION, rand() from a fresh
+    process, rays traced in the order given."""
     lp = np.array([list(lights[i].pos) for i in range(n_lights)], np.float32).reshape(-1)
     blobs = scene_blobs(osc) + bvh_blobs(osc) + [_u32(n_lights), lp, np.array(list(cam.eye), np.float32),
                                                  np.array(list(cam.mv), np.float32), _i32(3 - max_depth), _u32(len(rays)), rays]
-    return _run("raytrace", blobs, np.float32).reshape(-1, 3)
+    return _run("raytrace", blobs, np.float32, variant=variant).reshape(-1, 3)
 
 
 def shadowmap(osc, light_pos):

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -53,7 +54,9 @@ class Opts(C.Structure):
                 ("ambient", C.c_float), ("diffuse", C.c_float), ("specular", C.c_float),
                 ("clip_z", C.c_float), ("band_rows", C.c_int32), ("band_index", C.c_int32),
                 ("band_count", C.c_int32), ("compact_rows", C.c_int32), ("collect_stats", C.c_int32),
-                ("tune", C.c_int32 * 8), ("mlaa", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("tune", C.c_int32 * 8), ("mlaa", C.c_int32),
+                ("use_refractions", C.c_int32), ("refract_rate", C.c_float), ("ambient_occlusion", C.c_int32),
+                ("ao_samples", C.c_int32), ("ao_range", C.c_float), ("reserved", C.c_int32 * 2)]
 
 
 class Stats(C.Structure):
@@ -96,6 +99,15 @@ def lib():
         if not os.path.exists(RENDER_SO):
             raise Mi355Error("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(the HIP extension is required, there is no CPU path)" % RENDER_SO)
+        # A PyTorch-ROCm wheel carries its own copies of the HIP runtime and RCCL.  If this library (linked against
+        # /opt/rocm) is loaded first and torch later, the process holds two runtimes and aborts at exit ("double free",
+        # seen on the MI355X boxes); with torch first the loader hands this library the copies already in the process.
+        # torch is what the callers here use for device buffers and streams anyway, so it goes first when it exists.
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(RENDER_SO, mode=C.RTLD_GLOBAL)
         L.mi355_abi_version.restype = C.c_int
         L.mi355_init.argtypes = [C.c_int, C.POINTER(C.c_int)]

@@ -19,9 +19,9 @@
 #include <vector>
 
 // kernel launchers (defined next to their kernels)
-extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth);
-extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int ordered, int waves, int batch, int n_blocks,
-                                             hipStream_t);
+extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext);
+extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int ordered, int waves, int batch, int ext,
+                                             int n_blocks, hipStream_t);
 extern "C" hipError_t mi355i_bvh_launch_prims(const float4 *rs_vert, const uint4 *rs_idx, uint32_t T, float4 *prim, uint32_t *list,
                                               uint32_t *bad, hipStream_t st);
 extern "C" hipError_t mi355i_bvh_launch_level(const void *cur, uint32_t n_cur, void *next, uint32_t *next_count, void *tree,
@@ -195,6 +195,8 @@ int validate_opts(const mi355_opts &o, int mode)
     if (o.band_count > 1 && (o.band_rows <= 0 || o.band_index < 0 || o.band_index >= o.band_count))
         return fail(-20, "bad band sharding rows=%d index=%d count=%d", o.band_rows, o.band_index, o.band_count);
     if (o.shadowmap_size <= 0 || o.shadowmap_size > 16384) return fail(-20, "bad shadowmap_size %d", o.shadowmap_size);
+    if (mode >= MI355_MODE_RAYTRACE && o.ambient_occlusion && (o.ao_samples < 1 || o.ao_samples > 4096 || !(o.ao_range > 0.f)))
+        return fail(-20, "ambient occlusion: ao_samples %d outside 1..4096 or ao_range %g not positive", o.ao_samples, (double)o.ao_range);
     return 0;
 }
 
@@ -258,6 +260,8 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     }
     P.W = o->width; P.H = o->height; P.SD = o->screen_dist;
     P.max_depth = o->max_ray_depth; P.use_shadows = o->use_shadows; P.use_refl = o->use_reflections;
+    P.use_refr = o->use_refractions ? 1 : 0; P.refr_rate = o->refract_rate;
+    P.ao = o->ambient_occlusion ? 1 : 0; P.ao_samples = o->ao_samples; P.ao_range = o->ao_range;
     P.aa = mode == MI355_MODE_RAYTRACE_ANTIALIAS;
     P.sm_size = o->shadowmap_size;
     P.refl_rate = o->reflect_rate; P.nudge = o->nudge;
@@ -534,16 +538,18 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipSt
         // +10-18 %, four another +6 %); a single 1080p frame is bound by its slowest tiles and runs fastest with two
         // (measured, profiles/).  A build is only used if that many blocks of it fit a CU (registers, LDS stack).
         const int batch = (P.n_frames > 1 && P.cams) ? 1 : 0;
+        const int ext = (P.use_refr || P.ao) ? 1 : 0;         // the build with refractions and ray-cast ambient occlusion
+        if (ext && (stats || batch)) return fail(-41, "refractions / ray-cast ambient occlusion: single frames without collect_stats only");
         if (batch && !(ordered && !stats)) return fail(-41, "batched frames need the ordered walk (checked tree, no collect_stats, no reference-order flag)");
         const long long work_tiles = (((long long)P.W + 7) / 8) * (((long long)P.n_rows + 7) / 8) * (P.aa ? 4 : 1) * P.n_frames;
         int waves = 2;
-        if (ordered && !stats) {
+        if (ordered && !stats && !ext) {
             for (int w = 4; w >= 3; w--) {
                 const bool wanted = P.blocks_per_cu == 0 ? work_tiles >= 20ll * w * c->n_cus * 4 : P.blocks_per_cu >= w;
-                if (wanted && mi355i_raytrace_blocks_per_cu(0, P.exact_box, 1, w, batch, (int)c->dev.stack_depth) >= w) { waves = w; break; }
+                if (wanted && mi355i_raytrace_blocks_per_cu(0, P.exact_box, 1, w, batch, (int)c->dev.stack_depth, 0) >= w) { waves = w; break; }
             }
         }
-        int per_cu = mi355i_raytrace_blocks_per_cu(stats, P.exact_box, ordered, waves, batch, (int)c->dev.stack_depth);
+        int per_cu = mi355i_raytrace_blocks_per_cu(stats, P.exact_box, ordered, waves, batch, (int)c->dev.stack_depth, ext);
         if (per_cu > waves) per_cu = waves;
         if (P.blocks_per_cu > 0 && P.blocks_per_cu < per_cu) per_cu = P.blocks_per_cu;
         int n_blocks = per_cu * c->n_cus;
@@ -551,7 +557,7 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipSt
         if (n_blocks > lanes_needed) n_blocks = (int)(lanes_needed > 0 ? lanes_needed : 1);
         c->last_blocks = n_blocks;
         if (P.wave_prof) HIP_TRY(hipMemsetAsync(c->wave_prof.p, 0, (size_t)n_blocks * 4 * 16 * 8, st), -40);
-        e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, waves, batch, n_blocks, st);
+        e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, waves, batch, ext, n_blocks, st);
         break;
     }
     case MI355_MODE_LINES:
@@ -603,6 +609,8 @@ void mi355_default_opts(mi355_opts *o, int width, int height)
     memset(o, 0, sizeof *o);
     o->width = width; o->height = height; o->screen_dist = 2 * height;       // Defines.h:26-28
     o->max_ray_depth = 3; o->use_shadows = 1; o->use_reflections = 1;         // Raytracer.cc:56,63,67
+    o->use_refractions = 0; o->refract_rate = 0.58f;                          // Raytracer.cc:72-73
+    o->ambient_occlusion = 0; o->ao_samples = 32; o->ao_range = 0.15f;        // Raytracer.cc:76-80
     o->shadowmap_size = 1024;                                                 // Defines.h:25
     o->reflect_rate = 0.375f; o->nudge = 1e-5f;                               // Raytracer.cc:68,59
     o->ambient = 96.f; o->diffuse = 128.f; o->specular = 192.f;               // Defines.h:30-32
@@ -926,6 +934,11 @@ int mi355_render_batch_device(mi355_ctx *c, int mode, int n_frames, const mi355_
     if (o->collect_stats) return fail(-21, "batched frames cannot collect the traversal counters");
     for (int f = 0; f < n_frames; f++) if (!d_out[f]) return fail(-3, "mi355_render_batch_device: frame %d has no output buffer", f);
     if (n_frames == 1) return mi355_render_device(c, mode, cams, lights, n_lights, o, d_out[0], pitch_bytes, d_outf ? d_outf[0] : nullptr, hip_stream);
+    if (o->use_refractions || o->ambient_occlusion) {       // (these builds render single frames)
+        for (int f = 0; f < n_frames; f++)
+            if (int r = mi355_render_device(c, mode, &cams[f], lights + (size_t)f * n_lights, n_lights, o, d_out[f], pitch_bytes, d_outf ? d_outf[f] : nullptr, hip_stream)) return r;
+        return 0;
+    }
     if (int r = validate_opts(*o, mode)) return r;
     if (int r = select_device(c)) return r;
     FrameParams P;

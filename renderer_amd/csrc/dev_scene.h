@@ -123,6 +123,11 @@ struct FrameParams {
     const uint32_t *tile_order; // dispenser index -> 8x8 tile id (heavy tiles first), or NULL = row-major
     int32_t blocks_per_cu;     // 0 = occupancy query
     int32_t rs_threads;        // rasterizer: threads per tile block (0 = default)
+    // the raytracer's compile-time extras (Raytracer.cc:70-80)
+    int32_t use_refr;          // REFRACTIONS
+    float refr_rate;           // REFRACTIONS_RATE
+    int32_t ao, ao_samples;    // AMBIENT_OCCLUSION, AMBIENT_SAMPLES
+    float ao_range;            // AMBIENT_RANGE
     int32_t mlaa;              // MLAA post filter on the finished frame
 };
 

@@ -76,6 +76,13 @@ struct Lane {
     f3 lp;                 // current light position
     int li;                // light being processed
     float cr, cg, cb;      // colour being accumulated for this depth
+    // EXT builds only (refractions, ray-cast ambient occlusion); constants in the others
+    uint32_t nocull;       // MI_TWOSIDED_BIT while the ray is traced without backface culling (Raytrace<false>), else 0
+    uint32_t path;         // node of the ray tree the current ray leads to: root 1, reflection child 2p, refraction child 2p + 1
+    uint32_t pendmask;     // bit d: the hit at depth d has a refracted ray waiting in LDS
+    int ao_i;              // ambient-occlusion sample in flight (-1: not sampling)
+    uint32_t ao_draw;      // random numbers drawn for this hit so far
+    float ao_total, ao_max, ao_cos;
 };
 
 // RayIntersectsBox, Raytracer.cc:99-151, exactly: IEEE divisions, the reference's comparisons.
@@ -314,6 +321,15 @@ MI_DEV void shade_begin(const FrameParams &P, const DevScene &S, Lane &L)
     L.li = 0;
 }
 
+// integer mixer of the ambient-occlusion sampler: draw `i` of the hit that is node `path` of sample `s` of pixel (x, y) is
+// mix(key + i * 0x9e3779b9) >> 1 with key = mix(mix(y << 16 ^ x) + s * 0x9e3779b9) ^ path * 0x85ebca6b -- a value in
+// [0, RAND_MAX] in place of the reference's rand() (Raytracer.cc:393-395), which has no defined order across threads
+MI_DEV uint32_t ao_mix(uint32_t v)
+{
+    v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Walk records (DevScene::walk, two float4 each; dev_scene.h):
 //     inner node    : a = (bmin, hit link)      b = (bmax, miss link)
@@ -358,7 +374,7 @@ MI_DEV bool tri_plane_test(const Lane &L, float nudge, uint32_t link, int j, con
 {
     if (j == L.avoid) return false;
     const f3 n = mk3(a.x, a.y, a.z);
-    if ((link & MI_TWOSIDED_BIT) == 0u) {                    // !_twoSided
+    if (((link | L.nocull) & MI_TWOSIDED_BIT) == 0u) {       // doCulling && !_twoSided
         const f3 fto = sub3(L.o, mk3(b.x, b.y, b.z));
         if (dot3(fto, n) < 0.f) return false;
     }
@@ -410,12 +426,17 @@ MI_DEV bool tri_edge_test(Lane &L)
 // the 128-register build spills ~100 bytes of transition state per lane and still wins by 6 %).
 // BATCH = the launch renders P.n_frames frames (tile slot s belongs to frame s % n_frames: every frame's heavy centre
 // tiles are handed out first); the waves then never run dry while one frame's slowest tiles finish.
-template <bool STATS, bool EXACT_BOX, bool ORDERED, int WAVES, bool BATCH>
+// EXT = the build that also knows the reference's two compile-time extras (Raytracer.cc:70-80): refractions -- every
+// hit spawns a second, unculled child ray, so the chain of depth levels becomes a binary tree walked depth first with
+// the waiting refracted rays parked in LDS -- and ray-cast ambient occlusion (AMBIENT_SAMPLES shadow-type rays per hit).
+template <bool STATS, bool EXACT_BOX, bool ORDERED, int WAVES, bool BATCH, bool EXT = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 k_raytrace(const DevScene S, const FrameParams P)
 {
     // LDS: per-lane colour columns of the ray tree's depth levels
     __shared__ float lds_col[MI_MAX_DEPTH * 3 * 256];
+    // LDS (EXT): the refracted ray waiting at each depth level: hit point, direction, triangle to avoid
+    __shared__ float lds_refr[EXT ? MI_MAX_DEPTH * 7 * 256 : 1];
     // LDS (ordered walk only, sized at launch): per-lane stack of postponed children, one row per level
     extern __shared__ uint32_t lds_stack[];
     Lane L;
@@ -436,6 +457,7 @@ k_raytrace(const DevScene S, const FrameParams P)
     L.tame = false; L.pend = false; L.pj = -1;
     L.limit = 0.f; L.delta = 0.f; L.dmax = 0.f; L.sp = 0; L.top = MI_END_LINK;
     L.pe1 = L.pe2 = L.pe3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; L.ao_draw = 0u; L.ao_total = L.ao_max = L.ao_cos = 0.f;
 
     unsigned n_normal = 0, n_shadow = 0;
     unsigned n_pops = 0, n_ihits = 0, n_tris = 0, n_plane = 0, n_shaded = 0;
@@ -514,6 +536,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                                     L.fr = L.fg = L.fb = 0.f;
                                     L.samples_left = P.aa ? 3 : 0;
                                     primary_ray<BATCH>(P, S, L, L.samples_left);
+                                    if constexpr (EXT) { L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; }
                                     begin_walk<ORDERED>(S, L, R, R2);
                                     n_normal++;
                                     alive = true;
@@ -544,19 +567,91 @@ k_raytrace(const DevScene S, const FrameParams P)
             if (STATS) { it_trans++; ln_trans += __popcll(mX); }
             bool finish = false;     // ray tree complete -> fold
             bool lights = false;     // continue with light loop
+            // EXT: value of the finished ray tree; the child that just returned `up_v` to the hit at depth `up_d`
+            float ar = 0.f, ag = 0.f, ab = 0.f;
+            bool up = false, ao_next = false;
+            int up_d = 0; uint32_t up_which = 0u;
+            f3 up_v = mk3(0.f, 0.f, 0.f);
             if (ray_done) {
                 if (L.mode == MODE_CLOSEST) {
-                    if (L.btri < 0) finish = true;                  // Raytracer.cc:327-331
-                    else {
+                    if (L.btri < 0) {                               // Raytracer.cc:327-331
+                        if (EXT && L.depth > 0) { up = true; up_d = L.depth - 1; up_which = L.path & 1u; L.path >>= 1; }
+                        else finish = true;
+                    } else {
                         if (STATS) n_shaded++;
                         shade_begin(P, S, L);
                         lights = true;
+                        if constexpr (EXT) {
+                            if (P.use_refr && L.depth + 1 < P.max_depth) {
+                                // Raytracer.cc:526-535: the two "materials" alternate with the parity of the depth
+                                const float c1 = -dot3(L.d, L.pn);
+                                const float n1 = 1.f + (float)(L.depth & 1), n2 = 2.f + (float)(L.depth & 1);
+                                const float n = n1 / n2;
+                                const float c2 = __builtin_sqrtf(1.f - n * n * (1.f - c1 * c1));
+                                const f3 rd = norm3(add3(mul3(L.d, n), mul3(L.pn, n * c1 - c2)));
+                                float *q = lds_refr + L.depth * 7 * 256 + threadIdx.x;
+                                q[0] = L.hit.x; q[256] = L.hit.y; q[512] = L.hit.z;
+                                q[768] = rd.x; q[1024] = rd.y; q[1280] = rd.z;
+                                q[1536] = __int_as_float(L.btri);
+                                L.pendmask |= 1u << L.depth;
+                            }
+                            if (P.ao) {                             // Raytracer.cc:386-417 replaces the ambient term
+                                lights = false; ao_next = true;
+                                L.ao_i = 0; L.ao_draw = 0u; L.ao_total = 0.f; L.ao_max = 0.f;
+                            }
+                        }
                     }
+                } else if (EXT && L.ao_i >= 0) {
+                    if (!L.shadow_hit) L.ao_total += L.ao_cos;      // Raytracer.cc:409-412
+                    L.ao_i++;
+                    ao_next = true;
                 } else {
                     if (!L.shadow_hit) add_light<BATCH>(P, S, L);   // Raytracer.cc:458-466
                     L.li++;
                     lights = true;
                 }
+            }
+            if constexpr (EXT) {
+                if (ao_next) {
+                    if (L.ao_i < P.ao_samples) {
+                        // the next random direction in the hemisphere around the normal (rejection, Raytracer.cc:391-398)
+                        const uint32_t key = ao_mix(ao_mix(((uint32_t)L.py << 16) ^ (uint32_t)L.px) + (uint32_t)L.samples_left * 0x9e3779b9u) ^
+                                             (L.path * 0x85ebca6bu);
+                        const int half = 0x7fffffff / 2;
+                        f3 v; float cosangle;
+                        for (;;) {
+                            v = L.pn;
+                            v.x += (float)((int)(ao_mix(key + (L.ao_draw + 0u) * 0x9e3779b9u) >> 1) - half) / (float)half;
+                            v.y += (float)((int)(ao_mix(key + (L.ao_draw + 1u) * 0x9e3779b9u) >> 1) - half) / (float)half;
+                            v.z += (float)((int)(ao_mix(key + (L.ao_draw + 2u) * 0x9e3779b9u) >> 1) - half) / (float)half;
+                            L.ao_draw += 3u;
+                            cosangle = dot3(v, L.pn);
+                            if (!(cosangle < 0.f)) break;
+                        }
+                        L.ao_cos = cosangle;
+                        L.ao_max += cosangle;
+                        v = norm3(v);
+                        L.lp = add3(L.hit, mul3(v, P.ao_range));
+                        L.o = L.hit; L.d = v;
+                        set_ray_aux(L, S.scene_mag);
+                        L.best = distsq3(L.o, L.lp);
+                        L.limit = 2.f * __builtin_sqrtf(L.best) * 1.001f + L.delta;
+                        L.mode = MODE_SHADOW;
+                        L.shadow_hit = false;
+                        L.nocull = 0u;                              // BVH_IntersectTriangles<true,true>
+                        begin_walk<ORDERED>(S, L, R, R2);
+                        L.avoid = L.btri;
+                        n_shadow++;
+                    } else {
+                        const float4 sh4 = S.tri_shade[(size_t)L.btri * 5 + 4];
+                        const float f = (float)(((double)P.ambient / 255.0) * (double)(L.ao_total / L.ao_max));   // :417
+                        L.cr = f * sh4.x; L.cg = f * sh4.y; L.cb = f * sh4.z;
+                        L.ao_i = -1;
+                        lights = true;
+                    }
+                }
+                // the light loop's shadow rays inherit the culling of the ray that found the hit (Raytracer.cc:458)
+                if (lights) L.nocull = (L.path != 1u && (L.path & 1u)) ? (uint32_t)MI_TWOSIDED_BIT : 0u;
             }
             if (lights) {
                 bool launched = false;
@@ -587,6 +682,17 @@ k_raytrace(const DevScene S, const FrameParams P)
                 if (!launched) {
                     // all lights done for this hit: store the level colour, bounce or finish
                     set_c(lds_col, (int)threadIdx.x, L.depth, L.cr, L.cg, L.cb);
+                    if constexpr (EXT) {
+                        if (P.use_refl && L.depth + 1 < P.max_depth) {
+                            L.o = L.hit; L.d = L.refl; L.avoid = L.btri;
+                            set_ray_aux(L, S.scene_mag);
+                            L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
+                            L.nocull = 0u;                          // Raytrace<true>
+                            L.path = 2u * L.path; L.depth++;
+                            begin_walk<ORDERED>(S, L, R, R2);
+                            n_normal++;
+                        } else { up = true; up_d = L.depth; up_which = 0u; }     // "the reflected ray returned black"
+                    } else {
                     L.depth++;
                     if (P.use_refl && L.depth < P.max_depth) {
                         L.o = L.hit; L.d = L.refl; L.avoid = L.btri;
@@ -595,17 +701,49 @@ k_raytrace(const DevScene S, const FrameParams P)
                         begin_walk<ORDERED>(S, L, R, R2);
                         n_normal++;
                     } else finish = true;
+                    }
+                }
+            }
+            if constexpr (EXT) {
+                // Raytracer.cc:537-551 bottom up: value = (colour + reflected * rate) + refracted * rate, each + the clamping
+                // Pixel::operator+ (Types.h:137-142); L.path is the node at depth up_d while this loop runs
+                while (up) {
+                    float *a = lds_col + up_d * 3 * 256 + threadIdx.x;
+                    bool complete = true;
+                    if (up_which == 0u) {
+                        if (P.use_refl) { a[0] = addclamp(a[0], P.refl_rate * up_v.x); a[256] = addclamp(a[256], P.refl_rate * up_v.y); a[512] = addclamp(a[512], P.refl_rate * up_v.z); }
+                        if (L.pendmask & (1u << up_d)) {
+                            L.pendmask &= ~(1u << up_d);
+                            const float *q = lds_refr + up_d * 7 * 256 + threadIdx.x;
+                            L.o = mk3(q[0], q[256], q[512]); L.d = mk3(q[768], q[1024], q[1280]);
+                            L.avoid = __float_as_int(q[1536]);
+                            set_ray_aux(L, S.scene_mag);
+                            L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
+                            L.nocull = (uint32_t)MI_TWOSIDED_BIT;   // Raytrace<false>
+                            L.path = 2u * L.path + 1u; L.depth = up_d + 1;
+                            begin_walk<ORDERED>(S, L, R, R2);
+                            n_normal++;
+                            complete = false; up = false;
+                        } else if (P.use_refr) { a[0] = addclamp(a[0], 0.f); a[256] = addclamp(a[256], 0.f); a[512] = addclamp(a[512], 0.f); }   // too deep: black * rate
+                    } else { a[0] = addclamp(a[0], P.refr_rate * up_v.x); a[256] = addclamp(a[256], P.refr_rate * up_v.y); a[512] = addclamp(a[512], P.refr_rate * up_v.z); }
+                    if (complete) {
+                        up_v = mk3(a[0], a[256], a[512]);
+                        if (up_d == 0) { ar = up_v.x; ag = up_v.y; ab = up_v.z; finish = true; up = false; }
+                        else { up_which = L.path & 1u; L.path >>= 1; up_d--; }
+                    }
                 }
             }
             if (finish) {
                 // fold c[depth-1] ... c[0] (Raytracer.cc:538-551 with Types.h:137-142)
-                float ar = 0.f, ag = 0.f, ab = 0.f;
+                if constexpr (!EXT) {
                 if (P.use_refl) { const f3 a = fold_levels(lds_col, L.depth, P.refl_rate); ar = a.x; ag = a.y; ab = a.z; }
                 else if (L.depth > 0) { ar = lds_col[threadIdx.x]; ag = lds_col[256 + threadIdx.x]; ab = lds_col[512 + threadIdx.x]; }
+                }
                 L.fb += ab; L.fg += ag; L.fr += ar;              // finalColor += ...
                 if (L.samples_left > 0) {
                     L.samples_left--;
                     primary_ray<BATCH>(P, S, L, L.samples_left);
+                    if constexpr (EXT) { L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; }
                     begin_walk<ORDERED>(S, L, R, R2);
                     n_normal++;
                 } else {
@@ -740,7 +878,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                 const int j = (int)(((tcur & MI_INDEX_MASK) - S.tri_base) >> 1);
                 const f3 n = mk3(ta.x, ta.y, ta.z);
                 const f3 fto = sub3(L.o, mk3(tb.x, tb.y, tb.z));
-                const bool facing = (tcur & MI_TWOSIDED_BIT) != 0u || !(dot3(fto, n) < 0.f);
+                const bool facing = ((tcur | L.nocull) & MI_TWOSIDED_BIT) != 0u || !(dot3(fto, n) < 0.f);
                 const float k = dot3(n, L.d);
                 const float sp = (tb.w - dot3(n, L.o)) / k;
                 const bool cand = tri && j != L.avoid && facing && !(k == 0.0f) && !(sp <= 0.0f) && !(sp <= P.nudge);
@@ -802,7 +940,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     const int j = (int)(((tcur & MI_INDEX_MASK) - S.tri_base) >> 1);
                     const f3 n = mk3(ta.x, ta.y, ta.z);
                     const f3 fto = sub3(L.o, mk3(tb.x, tb.y, tb.z));
-                    const bool facing = (tcur & MI_TWOSIDED_BIT) != 0u || !(dot3(fto, n) < 0.f);
+                    const bool facing = ((tcur | L.nocull) & MI_TWOSIDED_BIT) != 0u || !(dot3(fto, n) < 0.f);
                     const float k = dot3(n, L.d);
                     const float sp = (tb.w - dot3(n, L.o)) / k;
                     const bool cand = tri && j != L.avoid && facing && !(k == 0.0f) && !(sp <= 0.0f) && !(sp <= P.nudge);
@@ -945,8 +1083,12 @@ template <bool EXACT, bool BATCH> rt_kernel ordered_kernel(int waves)
     if (waves == 3) return k_raytrace<false, EXACT, true, 3, BATCH>;
     return k_raytrace<false, EXACT, true, 2, BATCH>;
 }
-rt_kernel pick_kernel(int stats, int exact, int ordered, int waves, int batch)
+rt_kernel pick_kernel(int stats, int exact, int ordered, int waves, int batch, int ext)
 {
+    if (ext) {      // refractions / ray-cast ambient occlusion: single frames, no counters, two waves per SIMD
+        if (ordered) return exact ? k_raytrace<false, true, true, 2, false, true> : k_raytrace<false, false, true, 2, false, true>;
+        return exact ? k_raytrace<false, true, false, 2, false, true> : k_raytrace<false, false, false, 2, false, true>;
+    }
     if (ordered && !stats) {
         if (batch) return exact ? ordered_kernel<true, true>(waves) : ordered_kernel<false, true>(waves);
         return exact ? ordered_kernel<true, false>(waves) : ordered_kernel<false, false>(waves);
@@ -962,15 +1104,15 @@ size_t stack_bytes(int ordered, int stack_depth) { return ordered ? (size_t)stac
 extern "C" int mi355i_raytrace_can_batch(int stats, int ordered) { return ordered && !stats; }
 
 // blocks per CU the (stats, exact, ordered, waves, batch) variant can hold
-extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth)
+extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext)
 {
-    static int cache[2][2][2][3][2][MI_MAX_STACK + 1];        // 0 = not asked yet
+    static int cache[2][2][2][2][3][2][MI_MAX_STACK + 1];        // 0 = not asked yet
     if (stack_depth < 0 || stack_depth > MI_MAX_STACK) stack_depth = MI_MAX_STACK;
     const int w = waves >= 4 ? 2 : (waves == 3 ? 1 : 0);
-    int &slot = cache[stats ? 1 : 0][exact ? 1 : 0][ordered ? 1 : 0][w][batch ? 1 : 0][ordered ? stack_depth : 0];
+    int &slot = cache[ext ? 1 : 0][stats ? 1 : 0][exact ? 1 : 0][ordered ? 1 : 0][w][batch ? 1 : 0][ordered ? stack_depth : 0];
     if (!slot) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_kernel(stats, exact, ordered, waves, batch), 256, stack_bytes(ordered, stack_depth)) != hipSuccess || nb < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_kernel(stats, exact, ordered, waves, batch, ext), 256, stack_bytes(ordered, stack_depth)) != hipSuccess || nb < 1)
             nb = 2;
         slot = nb > 8 ? 8 : nb;
     }
@@ -978,8 +1120,8 @@ extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, 
 }
 
 extern "C" hipError_t mi355i_launch_raytrace(const DevScene *S, const FrameParams *P, int stats, int exact, int ordered, int waves,
-                                             int batch, int n_blocks, hipStream_t st)
+                                             int batch, int ext, int n_blocks, hipStream_t st)
 {
-    hipLaunchKernelGGL(pick_kernel(stats, exact, ordered, waves, batch), dim3(n_blocks), dim3(256), stack_bytes(ordered, (int)S->stack_depth), st, *S, *P);
+    hipLaunchKernelGGL(pick_kernel(stats, exact, ordered, waves, batch, ext), dim3(n_blocks), dim3(256), stack_bytes(ordered, (int)S->stack_depth), st, *S, *P);
     return hipGetLastError();
 }

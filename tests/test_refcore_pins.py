@@ -187,3 +187,42 @@ def test_mlaa_equals_the_reference(oracle, oracle_scene):
         assert np.array_equal(oracle.mlaa(img), RC.mlaa(img)), "case %d (%dx%d)" % (it, W, H)
     with pytest.raises(RuntimeError):
         oracle.mlaa(np.zeros((10, 16), np.uint32))
+
+
+@pytest.mark.parametrize("mesh,w,h,depth,frame,two", [
+    ("chessboard.tri", 480, 270, 3, 0, True),
+    ("dragon_vis.ply", 480, 270, 3, 40, False),
+    ("statue.ply", 320, 180, 1, 90, False),
+], ids=["chessboard_2lights", "dragon", "statue_depth1"])
+def test_refractions_equal_the_reference_built_with_them(oracle, oracle_scene, mesh, w, h, depth, frame, two):
+    """-DREFRACTIONS (Raytracer.cc:72, 526-551): every hit also spawns an unculled refracted ray; the binary tree of
+    rays, the alternating indices and the two clamping additions, float for float."""
+    s = oracle_scene(mesh, bvh=True)
+    cam, lights, n = oracle.benchmark_frame(frame, two)
+    o = oracle.default_opts(w, h, max_ray_depth=depth, threads=os.cpu_count() or 1, use_refractions=1)
+    _, imgf, _ = s.render(9, cam, lights, n, o, want_f32=True)
+    ref = RC.raytrace(s, cam, lights, n, RC.primary_rays(cam, w, h, 2 * h), depth, variant="_refr").reshape(h, w, 3)
+    plain = RC.raytrace(s, cam, lights, n, RC.primary_rays(cam, w, h, 2 * h), depth).reshape(h, w, 3)
+    assert _same(ref, imgf)
+    if depth > 1:
+        assert (ref != plain).any(axis=-1).sum() > w * h // 100       # (the option does change the picture)
+
+
+@pytest.mark.parametrize("mesh,w,h,frame", [("chessboard.tri", 160, 90, 0), ("dragon_vis.ply", 128, 72, 40)])
+def test_raycast_ambient_occlusion_equals_the_reference_on_its_rand_sequence(oracle, oracle_scene, mesh, w, h, frame):
+    """-DAMBIENT_OCCLUSION (Raytracer.cc:386-417) draws from rand(): one thread tracing the same rays in the same order
+    as the reference binary (a fresh process: seed 1) reproduces its floats."""
+    s = oracle_scene(mesh, bvh=True)
+    cam, lights, n = oracle.benchmark_frame(frame)
+    o = oracle.default_opts(w, h, threads=1, ambient_occlusion=1)
+    _, imgf, _ = s.render(9, cam, lights, n, o, want_f32=True)
+    ref = RC.raytrace(s, cam, lights, n, RC.primary_rays(cam, w, h, 2 * h), 3, variant="_ao").reshape(h, w, 3)
+    assert (imgf.sum(-1) > 0).sum() > w * h // 50
+    assert _same(ref, imgf)
+    # the device's counter-based generator gives the same picture up to sampling noise
+    o2 = oracle.default_opts(w, h, threads=os.cpu_count() or 1, ambient_occlusion=2)
+    _, img2, _ = s.render(9, cam, lights, n, o2, want_f32=True)
+    lit = imgf.sum(-1) > 0
+    assert np.array_equal(lit, img2.sum(-1) > 0)
+    a, b = np.minimum(imgf, 255.0)[lit].mean(), np.minimum(img2, 255.0)[lit].mean()
+    assert abs(a - b) < 0.01 * max(a, b), (a, b)
