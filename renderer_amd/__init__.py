@@ -343,6 +343,21 @@ class Scene:
         _check(f(self.context(), out), "mi355i_scene_info")
         return tuple(int(x) for x in out)
 
+    def traversal_state(self):
+        """(scalars[32] uint32, walk, edge, shade) as installed in the device context -- the meaningful part of each stream."""
+        f = lib().mi355i_fetch_traversal
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        sc = np.zeros(32, np.uint32)
+        _check(f(self.context(), 0, sc.ctypes.data, sc.nbytes), "mi355i_fetch_traversal")
+        tri_base, T = int(sc[17]), self.nt
+        n4 = tri_base + 2 * T + 4 * (tri_base // 2)
+        out = [sc]
+        for which, n in ((1, n4 * 4), (2, T * 12), (3, T * 20)):
+            a = np.zeros(n, np.uint32)
+            _check(f(self.context(), which, a.ctypes.data, a.nbytes), "mi355i_fetch_traversal")
+            out.append(a)
+        return tuple(out)
+
     def build_bvh_device(self):
         """mi355_build_bvh: the reference's tree built on the GPU.  Returns (nodes[n,8] uint32, tri_idx[T] int32, max depth)
         and installs the tree in the device context (the host-side Scene keeps whatever tree it had)."""

@@ -5,6 +5,7 @@
 #include "../../include/mi355_render.h"
 #include "dev_math.h"
 #include "dev_scene.h"
+#include "bvh_build.h"
 
 #include <hip/hip_runtime.h>
 
@@ -22,11 +23,6 @@
 extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext);
 extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int ordered, int waves, int batch, int ext,
                                              int n_blocks, hipStream_t);
-extern "C" hipError_t mi355i_bvh_launch_prims(const float4 *rs_vert, const uint4 *rs_idx, uint32_t T, float4 *prim, uint32_t *list,
-                                              uint32_t *bad, hipStream_t st);
-extern "C" hipError_t mi355i_bvh_launch_level(const void *cur, uint32_t n_cur, void *next, uint32_t *next_count, void *tree,
-                                              uint32_t *tree_count, const float4 *prim, const uint32_t *list_cur, uint32_t *list_next,
-                                              int depth, int many_planes, uint32_t *bad, hipStream_t st);
 extern "C" hipError_t mi355i_launch_points(const DevScene *, const FrameParams *, int as_triangles, hipStream_t);
 extern "C" hipError_t mi355i_launch_mlaa(uint32_t *d_pixels, uint32_t *d_scratch, int resX, int resY, hipStream_t st);
 struct RasterScratch;
@@ -131,6 +127,8 @@ struct mi355_ctx {
     DevBuf mlaa;            // MLAA's "input" copy of the frame (colours + separation flags)
     DevBuf cam_table;       // batched launches: FrameCam[MI355_MAX_BATCH]
     DevBuf bvh_prim, bvh_list[2], bvh_lvl[2], bvh_tree, bvh_cnt;   // mi355_build_bvh work buffers (kept for rebuilds)
+    DevBuf bvh_big[2], bvh_task[2], bvh_gthr[2], bvh_gbin, bvh_tcnt, bvh_choff, bvh_num[5], bvh_out, bvh_in_td, bvh_in_te;
+    bool bvh_inputs_ready = false;
     PinBuf pin_walk, pin_edge, pin_shade, pin_tree, pin_list, pin_ctl;   // host staging of the BVH streams and the builder
     DevBuf wave_prof;       // per-wave phase profile of counting launches (debug)
     int last_blocks = 0;
@@ -692,7 +690,9 @@ void mi355_scene_destroy(mi355_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->walk, &c->tri_edge, &c->tri_shade, &c->rs_tri, &c->rs_col, &c->rs_idx,
                       &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->mlaa, &c->cam_table, &c->wave_prof, &c->bvh_prim, &c->bvh_list[0], &c->bvh_list[1],
-                      &c->bvh_lvl[0], &c->bvh_lvl[1], &c->bvh_tree, &c->bvh_cnt})
+                      &c->bvh_lvl[0], &c->bvh_lvl[1], &c->bvh_tree, &c->bvh_cnt, &c->bvh_big[0], &c->bvh_big[1], &c->bvh_task[0], &c->bvh_task[1],
+                      &c->bvh_gthr[0], &c->bvh_gthr[1], &c->bvh_gbin, &c->bvh_tcnt, &c->bvh_choff, &c->bvh_num[0], &c->bvh_num[1], &c->bvh_num[2],
+                      &c->bvh_num[3], &c->bvh_num[4], &c->bvh_out, &c->bvh_in_td, &c->bvh_in_te})
         b->release();
     for (PinBuf *b : {&c->pin_walk, &c->pin_edge, &c->pin_shade, &c->pin_tree, &c->pin_list, &c->pin_ctl}) b->release();
     for (auto &m : c->smap) m.release();
@@ -737,119 +737,111 @@ int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_
     if (int r = select_device(c)) return r;
     const uint32_t T = c->nT;
     if (T == 0) return fail(-50, "mi355_build_bvh: scene has no triangles");
-    static const bool trace = getenv("MI355_BVH_TRACE") != nullptr;
-    double t_mark = t_start;
-    auto mark = [&](const char *what) { if (trace) { const double t = clk(); fprintf(stderr, "[bvh] %-28s %.3f ms\n", what, t - t_mark); t_mark = t; } };
+    if ((size_t)5 * T + 16 >= (size_t)MI_VROOT_LINK) return fail(-30, "BVH too large");
     HIP_TRY(hipStreamSynchronize(c->stream), -40);
-    mark("stream sync");
-    struct LevelNode { uint32_t first, count, tree, pad; float bb[6]; float pad2[2]; };
-    struct TreeNode { float bb[6]; uint32_t a, b; };
-    static_assert(sizeof(LevelNode) == 48 && sizeof(TreeNode) == 32, "layouts shared with k_bvh.hip");
-    DevBuf &prim = c->bvh_prim, *list = c->bvh_list, *lvl = c->bvh_lvl, &tree = c->bvh_tree, &cnt = c->bvh_cnt;
-    const size_t max_level_nodes = (size_t)T / 2 + 4;
-    HIP_TRY(prim.ensure((size_t)T * 3 * sizeof(float4)), -31);
-    for (int i = 0; i < 2; i++) { HIP_TRY(list[i].ensure((size_t)T * 4), -31); HIP_TRY(lvl[i].ensure(max_level_nodes * sizeof(LevelNode)), -31); }
-    HIP_TRY(tree.ensure(((size_t)2 * T + 4) * sizeof(TreeNode)), -31);
-    HIP_TRY(cnt.ensure(16), -31);
-    uint32_t *d_cnt = (uint32_t *)cnt.p;      // [0] nodes of the next level, [1] tree nodes, [2] error bits
-    // every small transfer of the build goes through one page-locked block on the context's stream
-    struct Ctl { uint32_t init[4]; LevelNode root; uint32_t flags, n_tree, pad[2]; uint32_t reset[4]; uint32_t h[4]; };
-    HIP_TRY(c->pin_ctl.ensure(sizeof(Ctl)), -31);
-    HIP_TRY(c->pin_tree.ensure(((size_t)2 * T + 4) * sizeof(TreeNode)), -31);
+    static_assert(sizeof(BvLevelNode) == 48 && sizeof(BvTreeNode) == 32, "layouts shared with k_bvh.hip");
+    // ---- buffers (kept for rebuilds) ----
+    const size_t max_level_nodes = (size_t)T / 2 + 4, max_tree = (size_t)2 * T + 4;
+    const uint32_t max_big = T / BV_CH + 2u, max_task = 2u * (T / BV_CH) + 4u;
+    HIP_TRY(c->bvh_prim.ensure((size_t)T * 3 * sizeof(float4)), -31);
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(c->bvh_list[i].ensure((size_t)T * 4), -31);
+        HIP_TRY(c->bvh_lvl[i].ensure(max_level_nodes * sizeof(BvLevelNode)), -31);
+        HIP_TRY(c->bvh_big[i].ensure((size_t)max_big * sizeof(BvBig)), -31);
+        HIP_TRY(c->bvh_task[i].ensure((size_t)max_task * sizeof(BvTask)), -31);
+    }
+    HIP_TRY(c->bvh_tree.ensure(max_tree * sizeof(BvTreeNode)), -31);
+    HIP_TRY(c->bvh_cnt.ensure(sizeof(BvCtl)), -31);
+    HIP_TRY(c->bvh_choff.ensure((size_t)max_task * 4), -31);
+    for (int i = 0; i < 5; i++) HIP_TRY(c->bvh_num[i].ensure(max_tree * 4), -31);
+    HIP_TRY(c->bvh_out.ensure(max_tree * 32), -31);
+    // the finished streams go straight into the buffers the kernels read (dev_scene.h)
+    const size_t walk_bytes = ((size_t)5 * T + 16) * sizeof(float4);
+    HIP_TRY(c->walk.ensure(walk_bytes), -31);
+    HIP_TRY(c->tri_edge.ensure((size_t)T * 3 * sizeof(float4) + 16), -31);
+    HIP_TRY(c->tri_shade.ensure((size_t)T * 5 * sizeof(float4) + 16), -31);
+    if (!c->bvh_inputs_ready) {
+        // the per-triangle plane data in input order (once per scene)
+        HIP_TRY(c->bvh_in_td.ensure((size_t)T * 16), -31);
+        HIP_TRY(c->bvh_in_te.ensure((size_t)T * 36), -31);
+        HIP_TRY(hipMemcpy(c->bvh_in_td.p, c->td.data(), (size_t)T * 16, hipMemcpyHostToDevice), -31);
+        HIP_TRY(hipMemcpy(c->bvh_in_te.p, c->te.data(), (size_t)T * 36, hipMemcpyHostToDevice), -31);
+        c->bvh_inputs_ready = true;
+    }
+    HIP_TRY(c->pin_ctl.ensure(sizeof(BvCtl)), -31);
+    HIP_TRY(c->pin_tree.ensure(max_tree * 32), -31);
     HIP_TRY(c->pin_list.ensure((size_t)T * 4), -31);
-    Ctl *ctl = (Ctl *)c->pin_ctl.p;
-    ctl->init[0] = 0u; ctl->init[1] = 1u; ctl->init[2] = 0u; ctl->init[3] = 0u;
-    mark("buffers");
-    HIP_TRY(hipMemcpyAsync(d_cnt, ctl->init, sizeof ctl->init, hipMemcpyHostToDevice, c->stream), -31);
-    mark("counter upload");
-    hipError_t e = mi355i_bvh_launch_prims((const float4 *)c->rs_vert.p, (const uint4 *)c->rs_idx.p, T, (float4 *)prim.p,
-                                           (uint32_t *)list[0].p, d_cnt + 2, c->stream);
-    if (e != hipSuccess) return fail(-43, "BVH work-item launch failed: %s", hipGetErrorString(e));
-    // the root gets the global box, accumulated over the triangles in index order (BVH.cc:331-368)
-    LevelNode root{};
-    root.first = 0; root.count = T; root.tree = 0;
-    {
-        float gb[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, gt[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-        for (uint32_t t = 0; t < T; t++) {
-            float b[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, tp[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-            for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) { const float q = c->vpos[3 * (size_t)c->tidx[3 * (size_t)t + k] + a]; b[a] = (q < b[a]) ? q : b[a]; }
-            for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) { const float q = c->vpos[3 * (size_t)c->tidx[3 * (size_t)t + k] + a]; tp[a] = (tp[a] < q) ? q : tp[a]; }
-            for (int a = 0; a < 3; a++) { gb[a] = (b[a] < gb[a]) ? b[a] : gb[a]; gt[a] = (gt[a] < tp[a]) ? tp[a] : gt[a]; }
-        }
-        for (int a = 0; a < 3; a++) { root.bb[a] = gb[a]; root.bb[3 + a] = gt[a]; }
-    }
-    mark("prims launch + global box");
-    ctl->root = root;
-    HIP_TRY(hipMemcpyAsync(lvl[0].p, &ctl->root, sizeof root, hipMemcpyHostToDevice, c->stream), -31);
-    HIP_TRY(hipMemcpyAsync(&ctl->flags, d_cnt + 2, 4, hipMemcpyDeviceToHost, c->stream), -31);
-    HIP_TRY(hipStreamSynchronize(c->stream), -40);
-    mark("root upload");
-    if (ctl->flags & 1u) return fail(-50, "mi355_build_bvh: non-finite vertex coordinates (use the host builder)");
+    BvCtl *ctl = (BvCtl *)c->pin_ctl.p;
     const double t_setup = clk();
-    uint32_t tree_before = 1;          // tree nodes allocated so far (the root)
-    uint32_t n_cur = 1;
-    int cur = 0, depth = 0;
-    while (n_cur) {
-        if (depth >= 64) return fail(-51, "BVH deeper than 64 levels");
-        if (n_cur > max_level_nodes) return fail(-51, "BVH level %d has %u nodes", depth, n_cur);
-        const double t_l0 = clk();
-        uint32_t h[3];
-        for (int many = 0; many < 2; many++) {
-            // a node with more candidate planes than the fast build holds: redo the level with the large one
-            ctl->reset[0] = 0u; ctl->reset[1] = tree_before; ctl->reset[2] = 0u;
-            HIP_TRY(hipMemcpyAsync(d_cnt, ctl->reset, 12, hipMemcpyHostToDevice, c->stream), -31);
-            e = mi355i_bvh_launch_level(lvl[cur].p, n_cur, lvl[1 - cur].p, d_cnt, tree.p, d_cnt + 1, (const float4 *)prim.p,
-                                        (const uint32_t *)list[cur].p, (uint32_t *)list[1 - cur].p, depth, many, d_cnt + 2, c->stream);
-            if (e != hipSuccess) return fail(-43, "BVH level launch failed: %s", hipGetErrorString(e));
-            HIP_TRY(hipMemcpyAsync(ctl->h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream), -31);
+    double t_levels = t_setup;
+    for (uint32_t planes = 1100u; ; planes = 2200u) {
+        // (a node with more candidate planes than the fast build holds: the whole build again with the large one)
+        HIP_TRY(c->bvh_gbin.ensure((size_t)max_big * 3 * 7 * (planes + 1) * 4), -31);
+        HIP_TRY(c->bvh_tcnt.ensure((size_t)max_task * 3 * (planes + 1) * 4), -31);
+        for (int i = 0; i < 2; i++) HIP_TRY(c->bvh_gthr[i].ensure((size_t)max_big * 3 * planes * 4), -31);
+        BvWork W{};
+        W.rs_vert = (const float4 *)c->rs_vert.p; W.rs_tri = (const float4 *)c->rs_tri.p; W.rs_col = (const float4 *)c->rs_col.p;
+        W.rs_idx = (const uint4 *)c->rs_idx.p; W.in_td = (const float4 *)c->bvh_in_td.p; W.in_te = (const float *)c->bvh_in_te.p;
+        W.T = T; W.max_planes = planes;
+        W.prim = (float4 *)c->bvh_prim.p; W.tree = (BvTreeNode *)c->bvh_tree.p; W.ctl = (BvCtl *)c->bvh_cnt.p;
+        for (int i = 0; i < 2; i++) {
+            W.list[i] = (uint32_t *)c->bvh_list[i].p; W.lvl[i] = (BvLevelNode *)c->bvh_lvl[i].p;
+            W.big[i] = (BvBig *)c->bvh_big[i].p; W.task[i] = (BvTask *)c->bvh_task[i].p; W.gthr[i] = (float *)c->bvh_gthr[i].p;
+        }
+        W.gbin = (uint32_t *)c->bvh_gbin.p; W.tcnt = (uint32_t *)c->bvh_tcnt.p; W.chunk_off = (uint32_t *)c->bvh_choff.p;
+        W.max_big = max_big; W.max_task = max_task;
+        W.sub = (uint32_t *)c->bvh_num[0].p; W.subi = (uint32_t *)c->bvh_num[1].p; W.pre = (uint32_t *)c->bvh_num[2].p;
+        W.irank = (uint32_t *)c->bvh_num[3].p; W.esc = (uint32_t *)c->bvh_num[4].p;
+        W.out_nodes = c->bvh_out.p; W.walk = (float4 *)c->walk.p; W.tri_edge = (float4 *)c->tri_edge.p; W.tri_shade = (float4 *)c->tri_shade.p;
+        HIP_TRY(hipMemsetAsync(c->walk.p, 0, walk_bytes, c->stream), -40);
+        hipError_t e = mi355i_bvh_build_begin(&W, c->stream);
+        if (e != hipSuccess) return fail(-43, "BVH build launch failed: %s", hipGetErrorString(e));
+        // Levels are enqueued in batches without reading anything back; the flatten / emit kernels behind a batch do
+        // nothing until the level loop has run dry, so one look at the control block per batch is all the host does.
+        int depth = 0;
+        for (int batch = BV_FIRST_BATCH; ; batch = 8) {
+            if ((e = mi355i_bvh_build_levels(&W, depth, batch, c->stream)) != hipSuccess) return fail(-43, "BVH level launch failed: %s", hipGetErrorString(e));
+            depth += batch;
+            if ((e = mi355i_bvh_build_finish(&W, c->stream)) != hipSuccess) return fail(-43, "BVH flatten launch failed: %s", hipGetErrorString(e));
+            HIP_TRY(hipMemcpyAsync(ctl, c->bvh_cnt.p, sizeof(BvCtl), hipMemcpyDeviceToHost, c->stream), -31);
             HIP_TRY(hipStreamSynchronize(c->stream), -40);
-            h[0] = ctl->h[0]; h[1] = ctl->h[1]; h[2] = ctl->h[2];
-            if (!(h[2] & 2u)) break;
+            if (ctl->levels || ctl->bad || depth >= BV_MAX_LEVELS) break;
         }
-        if (h[2] & 6u) return fail(-50, "mi355_build_bvh: more than 2200 candidate planes on an axis (use the host builder)");
-        tree_before = h[1];
-        g_bvh_level_ms[depth] = clk() - t_l0; g_bvh_level_nodes[depth] = n_cur; g_bvh_levels = depth + 1;
-        n_cur = h[0];
-        cur = 1 - cur;
-        depth++;
+        if (ctl->bad & 1u) return fail(-50, "mi355_build_bvh: non-finite vertex coordinates (use the host builder)");
+        if ((ctl->bad & 2u) && planes == 1100u) continue;
+        if (ctl->bad & 2u) return fail(-50, "mi355_build_bvh: more than 2200 candidate planes on an axis (use the host builder)");
+        if (ctl->bad) return fail(-51, "BVH build failed (internal error bits %#x)", ctl->bad);
+        if (!ctl->levels) return fail(-51, "BVH deeper than %d levels", BV_MAX_LEVELS);
+        break;
     }
-    const double t_levels = clk();
-    const uint32_t n_tree = tree_before;          // tree nodes allocated when the last level finished
-    if ((size_t)n_tree > (size_t)2 * T + 4) return fail(-51, "BVH build produced %u tree nodes for %u triangles", n_tree, T);
-    const TreeNode *tn = (const TreeNode *)c->pin_tree.p;
-    HIP_TRY(hipMemcpyAsync(c->pin_tree.p, tree.p, (size_t)n_tree * sizeof(TreeNode), hipMemcpyDeviceToHost, c->stream), -31);
-    HIP_TRY(hipMemcpyAsync(c->pin_list.p, list[cur].p, (size_t)T * 4, hipMemcpyDeviceToHost, c->stream), -31);
+    t_levels = clk();
+    const uint32_t n_out = ctl->n_nodes;
+    if (n_out == 0 || (size_t)n_out > max_tree || n_out != ctl->n_tree) return fail(-51, "BVH build produced %u nodes (%u allocated) for %u triangles", n_out, ctl->n_tree, T);
+    HIP_TRY(hipMemcpyAsync(c->pin_tree.p, c->bvh_out.p, (size_t)n_out * 32, hipMemcpyDeviceToHost, c->stream), -31);
+    HIP_TRY(hipMemcpyAsync(c->pin_list.p, c->bvh_list[0].p, (size_t)T * 4, hipMemcpyDeviceToHost, c->stream), -31);
     HIP_TRY(hipStreamSynchronize(c->stream), -40);
+    memcpy(nodes32B, c->pin_tree.p, (size_t)n_out * 32);
     memcpy(tri_idx, c->pin_list.p, (size_t)T * 4);
-    // flatten (Raytracer.cc:651-682): pre-order, idxLeft = own index + 1, leaves keep their list segment
-    struct RefNode { float bottom[3], top[3]; uint32_t a, b; };
-    RefNode *out = (RefNode *)nodes32B;
-    uint32_t n_out = 0;
-    int deepest = 0;
-    struct Item { uint32_t t; uint32_t parent; int side, depth; };
-    std::vector<Item> st;
-    st.push_back({0u, 0xffffffffu, 0, 0});
-    while (!st.empty()) {
-        const Item it = st.back(); st.pop_back();
-        if (it.t >= n_tree) return fail(-51, "BVH build produced a dangling child index");
-        const uint32_t me = n_out++;
-        if (it.depth > deepest) deepest = it.depth;
-        const TreeNode &s = tn[it.t];
-        for (int k = 0; k < 3; k++) { out[me].bottom[k] = s.bb[k]; out[me].top[k] = s.bb[3 + k]; }
-        if (it.parent != 0xffffffffu) { if (it.side == 0) out[it.parent].a = me; else out[it.parent].b = me; }
-        if (s.a & 0x80000000u) { out[me].a = s.a; out[me].b = s.b; }
-        else {
-            out[me].a = out[me].b = 0;
-            st.push_back({s.b, me, 1, it.depth + 1});       // right is visited after the whole left subtree
-            st.push_back({s.a, me, 0, it.depth + 1});
-        }
-    }
     *n_nodes = n_out;
-    if (max_depth) *max_depth = deepest;
-    const double t_flat = clk();
-    const int r = build_bvh_streams(c, nodes32B, n_out, tri_idx, T);
-    g_bvh_ms[0] = t_setup - t_start; g_bvh_ms[1] = t_levels - t_setup; g_bvh_ms[2] = t_flat - t_levels; g_bvh_ms[3] = clk() - t_flat;
-    return r;
+    if (max_depth) *max_depth = (int32_t)ctl->levels - 1;
+    const double t_down = clk();
+    // install: the streams are already where the kernels read them
+    c->boxes_tame = ctl->tame != 0u;
+    c->dev.ordered_ok = (ctl->tame && ctl->bounded && ctl->inner_levels + 1u <= (uint32_t)MI_MAX_STACK) ? 1u : 0u;
+    c->dev.stack_depth = ctl->inner_levels + 1u;
+    c->dev.scene_mag = ctl->mag;
+    c->dev.walk = (const float4 *)c->walk.p;
+    c->dev.tri_edge = (const float4 *)c->tri_edge.p;
+    c->dev.tri_shade = (const float4 *)c->tri_shade.p;
+    c->dev.root_link = ctl->root_link;
+    c->dev.root_a = ctl->root_a; c->dev.root_b = ctl->root_b;
+    c->dev.vroot_a = ctl->vroot_a; c->dev.vroot_b = ctl->vroot_b;
+    c->dev.tri_base = 2u * ctl->n_inner;
+    c->dev.n_nodes = n_out;
+    c->has_bvh = true;
+    g_bvh_levels = 0;
+    g_bvh_ms[0] = t_setup - t_start; g_bvh_ms[1] = t_levels - t_setup; g_bvh_ms[2] = t_down - t_levels; g_bvh_ms[3] = clk() - t_down;
+    return 0;
 }
 
 int mi355_shadowmap_set(mi355_ctx *c, int slot, const float *map, int size)
@@ -1054,6 +1046,28 @@ int mi355i_scene_info(mi355_ctx *c, uint32_t *out4)
     out4[1] = c->dev.stack_depth;
     out4[2] = c->dev.n_nodes;
     out4[3] = c->boxes_tame ? 1u : 0u;
+    return 0;
+}
+
+// debug / tests: the installed traversal state.  which = 0: the DevScene scalars (as 32 words: root_a, root_b, vroot_a, vroot_b, root_link,
+// tri_base, ordered_ok, stack_depth, scene_mag, n_nodes); 1, 2, 3: the first `bytes` bytes of the walk / edge / shading streams.
+int mi355i_fetch_traversal(mi355_ctx *c, int which, void *out, size_t bytes)
+{
+    if (!c || !out) return fail(-3, "mi355i_fetch_traversal: null argument");
+    if (!c->has_bvh) return fail(-41, "no BVH installed");
+    if (int r = select_device(c)) return r;
+    if (which == 0) {
+        uint32_t w[32] = {0};
+        memcpy(w, &c->dev.root_a, 16); memcpy(w + 4, &c->dev.root_b, 16); memcpy(w + 8, &c->dev.vroot_a, 16); memcpy(w + 12, &c->dev.vroot_b, 16);
+        w[16] = c->dev.root_link; w[17] = c->dev.tri_base; w[18] = c->dev.ordered_ok; w[19] = c->dev.stack_depth;
+        memcpy(w + 20, &c->dev.scene_mag, 4); w[21] = c->dev.n_nodes; w[22] = c->boxes_tame ? 1u : 0u;
+        memcpy(out, w, bytes < sizeof w ? bytes : sizeof w);
+        return 0;
+    }
+    const DevBuf *b = which == 1 ? &c->walk : (which == 2 ? &c->tri_edge : (which == 3 ? &c->tri_shade : nullptr));
+    if (!b || bytes > b->bytes) return fail(-3, "mi355i_fetch_traversal: stream %d holds %zu bytes, %zu asked", which, b ? b->bytes : (size_t)0, bytes);
+    HIP_TRY(hipDeviceSynchronize(), -40);
+    HIP_TRY(hipMemcpy(out, b->p, bytes, hipMemcpyDeviceToHost), -31);
     return 0;
 }
 

@@ -105,6 +105,14 @@ CASES = {
     "flat_in_z_500 (one axis below the 1e-4 extent)": lambda rng: (lambda vf: (vf[0] * np.array([1, 1, 0.0]), vf[1]))(soup(rng, 500)),
     "duplicates_300 (identical triangles cannot be separated)": lambda rng: (lambda vf: (np.tile(vf[0], (10, 1)), np.arange(900).reshape(300, 3)))(soup(rng, 30)),
     "long_thin_1000": lambda rng: (lambda vf: (vf[0] * np.array([40.0, 1, 0.2]), vf[1]))(soup(rng, 1000)),
+    # more than 4096 triangles in a node: the first levels are split by many workgroups (k_big_bin / _eval / _scatter)
+    "random_20000": lambda rng: soup(rng, 20000),
+    "snapped_grid_30000 (chunked nodes with equal centroids)": lambda rng: soup(rng, 30000, snap=0.0625),
+    "exactly_4096": lambda rng: soup(rng, 4096),
+    "chunk_plus_one_4097": lambda rng: soup(rng, 4097),
+    "two_chunks_8192": lambda rng: soup(rng, 8192),
+    "duplicates_9000 (a chunked node that cannot be split)": lambda rng: (lambda vf: (np.tile(vf[0], (3000, 1)), np.arange(27000).reshape(9000, 3)))(soup(rng, 3)),
+    "flat_in_z_12000": lambda rng: (lambda vf: (vf[0] * np.array([1, 1, 0.0]), vf[1]))(soup(rng, 12000)),
 }
 
 
@@ -135,6 +143,41 @@ def test_gpu_builder_keeps_the_sign_of_zero_the_reference_keeps(tmp_path):
     boxes = dn[:, :6]
     assert ((boxes == 0x80000000).any() or (boxes == 0).any()), "the case is meant to produce zero box coordinates"
     assert_same_tree(d, h, p)
+
+
+def test_signed_zeros_in_chunked_nodes(tmp_path):
+    """the same with nodes large enough to be split by several workgroups: the first zero in list order may sit in any chunk"""
+    rng = np.random.default_rng(11)
+    n = 15000
+    base = rng.choice(np.array([-1.0, -0.5, -0.25, -0.0, 0.0, 0.25, 0.5, 1.0]), (n, 3, 3))
+    base += rng.choice(np.array([0.0, -0.0]), (n, 3, 3))
+    verts = np.concatenate([base.reshape(-1, 3), [[-1, -1, -1], [1, 1, 1], [1, -1, 1]]])
+    faces = np.concatenate([np.arange(3 * n).reshape(n, 3), [[3 * n, 3 * n + 1, 3 * n + 2]]])
+    p = str(tmp_path / "z.ply")
+    write_ply(p, verts, faces)
+    d, h = both_builders(p)
+    assert_same_tree(d, h, p)
+
+
+@pytest.mark.parametrize("mesh", MESHES + ["synthetic"])
+def test_device_made_traversal_streams_equal_the_host_made_ones(mesh, tmp_path):
+    """mi355_build_bvh numbers the nodes and writes the walk / wide / edge / shading records with kernels; mi355_scene_set_bvh
+    makes them on the host from the node array (the path of a `.bvh` cache or a foreign tree).  Same bytes, same scalars."""
+    if mesh == "synthetic":
+        verts, faces = soup(np.random.default_rng(5), 6000)
+        path = str(tmp_path / "m.ply")
+        write_ply(path, verts, faces)
+    else:
+        path = R.assets.mesh_path(mesh)
+    s = R.Scene(path)
+    nodes, idx, _ = s.build_bvh_device()
+    dev = s.traversal_state()
+    s.set_bvh_arrays(nodes, idx)
+    host = s.traversal_state()
+    for name, a, b in zip(("scalars", "walk", "edge", "shade"), dev, host):
+        assert a.shape == b.shape, name
+        bad = np.flatnonzero(a != b)
+        assert bad.size == 0, "%s: %d words differ, first at %d: %#x vs %#x" % (name, bad.size, bad[0], a[bad[0]], b[bad[0]])
 
 
 def test_frames_after_a_device_build_match_the_pins():
