@@ -29,7 +29,7 @@ struct BvTask { uint32_t big, chunk; };
 
 // device-resident control block of one build; the host reads it back when the launches have drained
 struct BvCtl {
-    uint32_t n_level[2], n_big[2], n_task[2];     // per level parity
+    uint32_t n_level[BV_MAX_LEVELS + 2], n_big[BV_MAX_LEVELS + 2], n_task[BV_MAX_LEVELS + 2];   // per tree level
     uint32_t n_tree, bad;                         // bad: 1 non-finite vertex, 2 more candidate planes than the build holds
     uint32_t levels;                              // levels of the finished tree (0 while building)
     uint32_t n_inner, n_nodes, inner_levels;
@@ -37,7 +37,6 @@ struct BvCtl {
     uint32_t root_link;
     float4 root_a, root_b, vroot_a, vroot_b;
     uint32_t rkey[6], rzero[6];                   // root box: ordered keys of min / max, triangle index of the first zero
-    uint32_t level_start[BV_MAX_LEVELS + 2];      // tree index of the first node of each level
 };
 
 struct BvWork {
@@ -58,4 +57,4 @@ struct BvWork {
 
 extern "C" hipError_t mi355i_bvh_build_begin(const BvWork *w, hipStream_t st);
 extern "C" hipError_t mi355i_bvh_build_levels(const BvWork *w, int first_depth, int n_levels, hipStream_t st);
-extern "C" hipError_t mi355i_bvh_build_finish(const BvWork *w, hipStream_t st);
+extern "C" hipError_t mi355i_bvh_build_finish(const BvWork *w, int levels_launched, hipStream_t st);

@@ -802,7 +802,7 @@ int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_
         for (int batch = BV_FIRST_BATCH; ; batch = 8) {
             if ((e = mi355i_bvh_build_levels(&W, depth, batch, c->stream)) != hipSuccess) return fail(-43, "BVH level launch failed: %s", hipGetErrorString(e));
             depth += batch;
-            if ((e = mi355i_bvh_build_finish(&W, c->stream)) != hipSuccess) return fail(-43, "BVH flatten launch failed: %s", hipGetErrorString(e));
+            if ((e = mi355i_bvh_build_finish(&W, depth, c->stream)) != hipSuccess) return fail(-43, "BVH flatten launch failed: %s", hipGetErrorString(e));
             HIP_TRY(hipMemcpyAsync(ctl, c->bvh_cnt.p, sizeof(BvCtl), hipMemcpyDeviceToHost, c->stream), -31);
             HIP_TRY(hipStreamSynchronize(c->stream), -40);
             if (ctl->levels || ctl->bad || depth >= BV_MAX_LEVELS) break;

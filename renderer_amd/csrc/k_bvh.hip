@@ -27,12 +27,13 @@
 #include "bvh_build.h"
 #include "dev_math.h"
 #include "dev_scene.h"
+#include "ff_add.h"
 
 #include <cfloat>
 
 namespace {
 
-enum { BV_SMALL = 96, BV_THREADS = 256 };
+enum { BV_SMALL = 96, BV_SMALL_DEPTH = 5, BV_THREADS = 256 };
 // Candidate planes per axis: nominally 1024/(depth+1), but `testSplit += step` rounds, and on a thin axis (extent just
 // above the 1e-4 cut) the step is about one ulp of the coordinate, so up to ~2x as many.  The kernels are built for
 // 1100 (two workgroups per CU) and for 2200 planes; the host redoes a build with the larger ones when a node needs it.
@@ -55,10 +56,9 @@ k_bvh_init(BvWork W, size_t n_bin_words)
     const size_t i0 = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (i0 == 0) {
         BvCtl &c = *W.ctl;
-        c.n_level[0] = c.n_level[1] = c.n_big[0] = c.n_big[1] = c.n_task[0] = c.n_task[1] = 0u;
+        for (int k = 0; k < BV_MAX_LEVELS + 2; k++) c.n_level[k] = c.n_big[k] = c.n_task[k] = 0u;
         c.n_tree = 0u; c.bad = 0u; c.levels = 0u; c.n_inner = c.n_nodes = c.inner_levels = 0u; c.tame = 1u; c.mag = 0.f;
         for (int k = 0; k < 6; k++) { c.rkey[k] = k < 3 ? BV_KEY_HI : BV_KEY_LO; c.rzero[k] = 0xffffffffu; }
-        for (int k = 0; k < BV_MAX_LEVELS + 2; k++) c.level_start[k] = 0u;
     }
     // bins: per (node, axis) 7 rows of max_planes + 1 words: counts, min x y z, max x y z
     const size_t row = (size_t)W.max_planes + 1u;
@@ -118,13 +118,23 @@ k_bvh_prims(BvWork W)
     }
 }
 
-// planes of one axis of a node's box at `depth` (BVH.cc:142-154): count, and the planes themselves into thr[]
+// what one lane of a wavefront writes to LDS and another reads is ordered by this
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Planes of one axis of a node's box at `depth` (BVH.cc:142-154): the reference's serial float accumulation, run by one
+// thread per axis (three at once) into LDS.  Returns the count.
 __device__ int bv_planes(const float start, const float stop, const int depth, float *thr, const int max_planes, uint32_t *bad)
 {
     if ((double)__builtin_fabsf(stop - start) < 1e-4) return 0;           // BVH.cc:142 (float promoted to double)
     const float step = (stop - start) / (1024.f / ((float)depth + 1.f));   // BVH.cc:148
+    const float lim = stop - step;
     int C = 0;
-    for (float testSplit = start + step; testSplit < stop - step; testSplit += step) {   // BVH.cc:154
+    for (float testSplit = start + step; testSplit < lim; testSplit += step) {   // BVH.cc:154
         if (C >= max_planes) { atomicOr(bad, 2u); break; }
         thr[C++] = testSplit;
     }
@@ -133,20 +143,29 @@ __device__ int bv_planes(const float start, const float stop, const int depth, f
 
 // A new node of level `depth` (index `node` of that level's array) with more than BV_CH triangles: give it a slot in the
 // level's table of big nodes, its chunk tasks and its candidate planes.  Called by one whole wavefront (tid = lane).
-__device__ void bv_register_big(const BvWork &W, const int depth, const uint32_t node, const float *bb, const uint32_t count, const int tid)
+__device__ void bv_register_big(const BvWork &W, const int depth, const uint32_t node, const float *bb, const uint32_t count, const int tid,
+                                float *lds_planes /* [3][max_planes] */, int *lds_C /* [3] */)
 {
     const int p = depth & 1;
     const uint32_t n_chunks = (count + BV_CH - 1u) / BV_CH;
     uint32_t slot = 0, task0 = 0;
     if (tid == 0) {
-        slot = atomicAdd(&W.ctl->n_big[p], 1u);
-        task0 = atomicAdd(&W.ctl->n_task[p], n_chunks);
+        slot = atomicAdd(&W.ctl->n_big[depth], 1u);
+        task0 = atomicAdd(&W.ctl->n_task[depth], n_chunks);
     }
     slot = (uint32_t)__shfl((int)slot, 0); task0 = (uint32_t)__shfl((int)task0, 0);
     if (slot >= W.max_big || task0 + n_chunks > W.max_task) { if (tid == 0) atomicOr(&W.ctl->bad, 8u); return; }
     BvBig *B = &W.big[p][slot];
-    if (tid < 3)
-        B->C[tid] = bv_planes(bb[tid], bb[3 + tid], depth, W.gthr[p] + ((size_t)slot * 3 + tid) * W.max_planes, (int)W.max_planes, &W.ctl->bad);
+    if (tid < 3) {
+        lds_C[tid] = bv_planes(bb[tid], bb[3 + tid], depth, lds_planes + (size_t)tid * W.max_planes, (int)W.max_planes, &W.ctl->bad);
+        B->C[tid] = lds_C[tid];
+    }
+    wave_sync();
+    for (int a = 0; a < 3; a++) {
+        float *g = W.gthr[p] + ((size_t)slot * 3 + a) * W.max_planes;
+        for (int k = tid; k < lds_C[a]; k += 64) g[k] = lds_planes[(size_t)a * W.max_planes + k];
+    }
+    wave_sync();
     if (tid == 0) {
         B->node = node; B->task0 = task0; B->n_chunks = n_chunks; B->kind = 0u; B->done = 0u;
         for (int k = 0; k < 12; k++) B->czero[k] = 0xffffffffu;
@@ -159,6 +178,8 @@ k_bvh_root(BvWork W)
 {
     const int tid = (int)threadIdx.x;
     __shared__ float bb[6];
+    __shared__ float planes[3 * 2200];
+    __shared__ int planes_C[3];
     BvCtl &c = *W.ctl;
     if (tid < 6) {
         float v = bv_dec(c.rkey[tid]);
@@ -177,9 +198,9 @@ k_bvh_root(BvWork W)
         r.first = 0; r.count = W.T; r.tree = 0; r.pad = 0; r.pad2[0] = r.pad2[1] = 0.f;
         for (int k = 0; k < 6; k++) r.bb[k] = bb[k];
         W.lvl[0][0] = r;
-        c.n_level[0] = 1u; c.n_tree = 1u; c.level_start[0] = 0u; c.level_start[1] = 1u;
+        c.n_level[0] = 1u; c.n_tree = 1u;
     }
-    if (W.T > (uint32_t)BV_CH && BV_BIG_LEVELS > 0) bv_register_big(W, 0, 0u, bb, W.T, tid);
+    if (W.T > (uint32_t)BV_CH && BV_BIG_LEVELS > 0) bv_register_big(W, 0, 0u, bb, W.T, tid, planes, planes_C);
 }
 
 // ---- workgroup-wide inclusive scan of a[0..n) in LDS, forward or backward ---------------------------------
@@ -227,7 +248,8 @@ struct OpMax { __device__ uint32_t operator()(uint32_t x, uint32_t y) const { re
 // LDS of the sweep of one node
 template <int MAXP>
 struct BvSweep {
-    float thr[MAXP];
+    float thr[3][MAXP];                                // the three axes' planes
+    int C3[3];
     uint32_t cnt[MAXP + 1];
     uint32_t lmin[3][MAXP + 1], lmax[3][MAXP + 1];     // bins, then inclusive prefix
     uint32_t rmin[3][MAXP + 1], rmax[3][MAXP + 1];     // inclusive suffix
@@ -261,7 +283,7 @@ __device__ void bv_take_best(BvSweep<MAXP> &S, const int axis, float my_cost, in
     }
     if (tid == 0 && S.red_k[0] >= 0 && S.red_cost[0] < S.best_cost) {
         const int k = S.red_k[0];
-        S.best_cost = S.red_cost[0]; S.best_axis = axis; S.best_k = k; S.best_split = S.thr[k]; S.best_nl = S.red_nl[0];
+        S.best_cost = S.red_cost[0]; S.best_axis = axis; S.best_k = k; S.best_split = S.thr[axis][k]; S.best_nl = S.red_nl[0];
         if (with_keys)
             for (int a = 0; a < 3; a++) {
                 S.best_key[a] = S.lmin[a][k]; S.best_key[3 + a] = S.lmax[a][k];
@@ -320,7 +342,7 @@ __device__ __forceinline__ int bv_bin(const float *thr, const int C, const float
 __device__ uint32_t bv_emit_children(const BvWork &W, const int depth, const BvLevelNode &N, const uint32_t nL, const float *bb12)
 {
     const int p = depth & 1;
-    const uint32_t slot = atomicAdd(&W.ctl->n_level[1 - p], 2u);
+    const uint32_t slot = atomicAdd(&W.ctl->n_level[depth + 1], 2u);
     const uint32_t tslot = atomicAdd(&W.ctl->n_tree, 2u);
     for (int s = 0; s < 2; s++) {
         BvLevelNode ch;
@@ -347,10 +369,9 @@ k_bvh_level(const BvWork W, const int depth)
     __shared__ uint32_t ckey[12];            // child boxes: left min xyz, left max xyz, right min xyz, right max xyz (keys)
     __shared__ uint32_t czero[12];           // list position of the first zero among the values equal to the extreme
     __shared__ uint32_t wave_left[BV_THREADS / 64];
-    __shared__ float sm_prim[BV_SMALL][9];   // small nodes: bottom, top, centre of the node's triangles
 
     const int p = depth & 1;
-    const uint32_t n_cur = W.ctl->n_level[p];
+    const uint32_t n_cur = W.ctl->n_level[depth];
     const BvLevelNode *cur = W.lvl[p];
     const float4 *prim = W.prim;
     const uint32_t *list_cur = W.list[p];
@@ -362,6 +383,7 @@ k_bvh_level(const BvWork W, const int depth)
         const BvLevelNode N = cur[node];
         const uint32_t n = N.count, first = N.first;
         if (n > (uint32_t)BV_CH && depth < BV_BIG_LEVELS) continue;      // split by chunks (k_big_*)
+        if (n <= (uint32_t)BV_SMALL && depth >= BV_SMALL_DEPTH) continue;   // one wavefront each (k_bvh_small)
 
         auto make_leaf = [&]() {
             for (uint32_t i = (uint32_t)tid; i < n; i += BV_THREADS) list_next[first + i] = list_cur[first + i];
@@ -379,53 +401,15 @@ k_bvh_level(const BvWork W, const int depth)
             S.best_cost = (float)n * (side1 * side2 + side2 * side3 + side3 * side1);   // BVH.cc:113-117
             S.best_axis = -1; S.best_k = 0; S.best_split = FLT_MAX; S.best_nl = 0;
         }
-        const bool small = n <= (uint32_t)BV_SMALL;
-        if (small)
-            for (uint32_t i = (uint32_t)tid; i < n; i += BV_THREADS) {
-                const uint32_t t = list_cur[first + i];
-                const float4 b = prim[(size_t)t * 3], tp = prim[(size_t)t * 3 + 1], c2 = prim[(size_t)t * 3 + 2];
-                sm_prim[i][0] = b.x; sm_prim[i][1] = b.y; sm_prim[i][2] = b.z;
-                sm_prim[i][3] = tp.x; sm_prim[i][4] = tp.y; sm_prim[i][5] = tp.z;
-                sm_prim[i][6] = b.w; sm_prim[i][7] = tp.w; sm_prim[i][8] = c2.x;
-            }
         __syncthreads();
 
+        if (tid < 3) S.C3[tid] = bv_planes(N.bb[tid], N.bb[3 + tid], depth, S.thr[tid], MAXP, &W.ctl->bad);
+        __syncthreads();
         for (int axis = 0; axis < 3; axis++) {
-            if (tid == 0) S.C = bv_planes(N.bb[axis], N.bb[3 + axis], depth, S.thr, MAXP, &W.ctl->bad);
-            __syncthreads();
-            const int C = S.C;
-            if (C == 0) { __syncthreads(); continue; }
-            if (small) {
-                // few triangles: every thread owns candidate planes and walks the node's triangles itself, as the
-                // reference does (BVH.cc:160-206) -- no bins, no scans
-                float my_cost = FLT_MAX;
-                int my_k = -1;
-                uint32_t my_nl = 0;
-                for (int k = tid; k < C; k += BV_THREADS) {
-                    const float plane = S.thr[k];
-                    float lb[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lt[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-                    float rb[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, rt[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-                    int countLeft = 0;
-                    for (uint32_t i = 0; i < n; i++) {
-                        const bool left = sm_prim[i][6 + axis] < plane;
-                        countLeft += left ? 1 : 0;
-                        for (int a = 0; a < 3; a++) {
-                            const float b = sm_prim[i][a], t = sm_prim[i][3 + a];
-                            if (left) { lb[a] = b < lb[a] ? b : lb[a]; lt[a] = lt[a] < t ? t : lt[a]; }
-                            else { rb[a] = b < rb[a] ? b : rb[a]; rt[a] = rt[a] < t ? t : rt[a]; }
-                        }
-                    }
-                    const int countRight = (int)n - countLeft;
-                    if (countLeft <= 1 || countRight <= 1) continue;
-                    const float l1 = lt[0] - lb[0], l2 = lt[1] - lb[1], l3 = lt[2] - lb[2];
-                    const float r1 = rt[0] - rb[0], r2 = rt[1] - rb[1], r3 = rt[2] - rb[2];
-                    const float surfaceLeft = l1 * l2 + l2 * l3 + l3 * l1;
-                    const float surfaceRight = r1 * r2 + r2 * r3 + r3 * r1;
-                    const float cost = surfaceLeft * (float)countLeft + surfaceRight * (float)countRight;
-                    if (cost < my_cost) { my_cost = cost; my_k = k; my_nl = (uint32_t)countLeft; }
-                }
-                bv_take_best(S, axis, my_cost, my_k, my_nl, false);
-            } else {
+            const int C = S.C3[axis];
+            if (C == 0) continue;
+            if (tid == 0) S.C = C;
+            {
                 for (int i = tid; i <= C; i += BV_THREADS) {
                     S.cnt[i] = 0u;
                     for (int a = 0; a < 3; a++) { S.lmin[a][i] = BV_KEY_HI; S.lmax[a][i] = BV_KEY_LO; }
@@ -433,7 +417,7 @@ k_bvh_level(const BvWork W, const int depth)
                 __syncthreads();
                 for (uint32_t i = (uint32_t)tid; i < n; i += BV_THREADS) {
                     const uint32_t t = list_cur[first + i];
-                    const int lo = bv_bin(S.thr, C, prim_center(prim, t, axis));
+                    const int lo = bv_bin(S.thr[axis], C, prim_center(prim, t, axis));
                     const float4 b = prim[(size_t)t * 3], tp = prim[(size_t)t * 3 + 1];
                     atomicAdd(&S.cnt[lo], 1u);
                     atomicMin(&S.lmin[0][lo], bv_enc(b.x)); atomicMin(&S.lmin[1][lo], bv_enc(b.y)); atomicMin(&S.lmin[2][lo], bv_enc(b.z));
@@ -497,6 +481,137 @@ k_bvh_level(const BvWork W, const int depth)
     }
 }
 
+// ---- nodes of at most BV_SMALL triangles, from level BV_SMALL_DEPTH on (where an axis has at most 1024/6 planes, twice
+//      that with the rounding of thin axes: MAXP here is 352, or 704 in the large build): one wavefront each, four per workgroup
+// Every lane owns candidate planes and walks the node's triangles itself, as the reference does (BVH.cc:160-206) -- no
+// bins, no scans, no workgroup barriers.  (What one lane writes to LDS and another reads is ordered by wave_sync().)
+template <int MAXP>
+__global__ void __launch_bounds__(BV_THREADS)
+k_bvh_small(const BvWork W, const int depth)
+{
+    __shared__ float s_thr[BV_THREADS / 64][3][MAXP];
+    __shared__ int s_C[BV_THREADS / 64][4];
+    __shared__ float s_prim[BV_THREADS / 64][BV_SMALL][9];   // bottom, top, centre of the node's triangles
+    __shared__ uint32_t s_ckey[BV_THREADS / 64][12], s_czero[BV_THREADS / 64][12];
+    const int p = depth & 1;
+    const uint32_t n_cur = W.ctl->n_level[depth];
+    const BvLevelNode *cur = W.lvl[p];
+    const float4 *prim = W.prim;
+    const uint32_t *list_cur = W.list[p];
+    uint32_t *list_next = W.list[1 - p];
+    const int lane = (int)(threadIdx.x & 63u), wid = (int)(threadIdx.x >> 6);
+    float (*thr3)[MAXP] = s_thr[wid];
+    int *C3 = s_C[wid];
+    float (*sm)[9] = s_prim[wid];
+    uint32_t *ckey = s_ckey[wid], *czero = s_czero[wid];
+    const uint32_t n_waves = gridDim.x * (BV_THREADS / 64);
+
+    for (uint32_t node = blockIdx.x * (BV_THREADS / 64) + (uint32_t)wid; node < n_cur; node += n_waves) {
+        const BvLevelNode N = cur[node];
+        const uint32_t n = N.count, first = N.first;
+        if (n > (uint32_t)BV_SMALL) continue;
+        wave_sync();
+        int best_axis = -1;
+        float best_cost = 0.f, best_split = FLT_MAX;
+        uint32_t best_nl = 0;
+        if (n >= 4u) {                                                    // BVH.cc:99
+            const float side1 = N.bb[3] - N.bb[0], side2 = N.bb[4] - N.bb[1], side3 = N.bb[5] - N.bb[2];
+            best_cost = (float)n * (side1 * side2 + side2 * side3 + side3 * side1);   // BVH.cc:113-117
+            for (uint32_t i = (uint32_t)lane; i < n; i += 64u) {
+                const uint32_t t = list_cur[first + i];
+                const float4 b = prim[(size_t)t * 3], tp = prim[(size_t)t * 3 + 1], c2 = prim[(size_t)t * 3 + 2];
+                sm[i][0] = b.x; sm[i][1] = b.y; sm[i][2] = b.z;
+                sm[i][3] = tp.x; sm[i][4] = tp.y; sm[i][5] = tp.z;
+                sm[i][6] = b.w; sm[i][7] = tp.w; sm[i][8] = c2.x;
+            }
+            if (lane < 3) C3[lane] = bv_planes(N.bb[lane], N.bb[3 + lane], depth, thr3[lane], MAXP, &W.ctl->bad);
+            wave_sync();
+            for (int axis = 0; axis < 3; axis++) {
+                const int C = C3[axis];
+                const float *thr = thr3[axis];
+                if (C == 0) continue;
+                float my_cost = FLT_MAX;
+                int my_k = 0x7fffffff;
+                uint32_t my_nl = 0;
+                for (int k = lane; k < C; k += 64) {
+                    const float plane = thr[k];
+                    float lb[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lt[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+                    float rb[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, rt[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+                    int countLeft = 0;
+                    for (uint32_t i = 0; i < n; i++) {
+                        const bool left = sm[i][6 + axis] < plane;
+                        countLeft += left ? 1 : 0;
+                        for (int a = 0; a < 3; a++) {
+                            const float b = sm[i][a], t = sm[i][3 + a];
+                            if (left) { lb[a] = b < lb[a] ? b : lb[a]; lt[a] = lt[a] < t ? t : lt[a]; }
+                            else { rb[a] = b < rb[a] ? b : rb[a]; rt[a] = rt[a] < t ? t : rt[a]; }
+                        }
+                    }
+                    const int countRight = (int)n - countLeft;
+                    if (countLeft <= 1 || countRight <= 1) continue;
+                    const float l1 = lt[0] - lb[0], l2 = lt[1] - lb[1], l3 = lt[2] - lb[2];
+                    const float r1 = rt[0] - rb[0], r2 = rt[1] - rb[1], r3 = rt[2] - rb[2];
+                    const float surfaceLeft = l1 * l2 + l2 * l3 + l3 * l1;
+                    const float surfaceRight = r1 * r2 + r2 * r3 + r3 * r1;
+                    const float cost = surfaceLeft * (float)countLeft + surfaceRight * (float)countRight;
+                    if (cost < my_cost) { my_cost = cost; my_k = k; my_nl = (uint32_t)countLeft; }   // increasing k: the first minimum stays
+                }
+                // smallest cost of the wavefront, ties to the lowest plane; then strict against the earlier axes
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float oc = __shfl_xor(my_cost, off);
+                    const int ok = __shfl_xor(my_k, off);
+                    const uint32_t onl = (uint32_t)__shfl_xor((int)my_nl, off);
+                    const bool have = my_k != 0x7fffffff, ohave = ok != 0x7fffffff;
+                    if (ohave && (!have || oc < my_cost || (oc == my_cost && ok < my_k))) { my_cost = oc; my_k = ok; my_nl = onl; }
+                }
+                if (my_k != 0x7fffffff && my_cost < best_cost) { best_cost = my_cost; best_axis = axis; best_split = thr[my_k]; best_nl = my_nl; }
+            }
+        }
+        if (best_axis < 0) {                                              // BVH.cc:99, 211-216: a leaf
+            for (uint32_t i = (uint32_t)lane; i < n; i += 64u) list_next[first + i] = list_cur[first + i];
+            if (lane == 0) {
+                BvTreeNode t;
+                for (int k = 0; k < 6; k++) t.bb[k] = N.bb[k];
+                t.a = 0x80000000u | n; t.b = first;
+                W.tree[N.tree] = t;
+            }
+            continue;
+        }
+        // ---- stable partition (BVH.cc:219-254) + child boxes accumulated "in list order" ----
+        if (lane < 12) { ckey[lane] = (lane % 6) < 3 ? BV_KEY_HI : BV_KEY_LO; czero[lane] = 0xffffffffu; }
+        wave_sync();
+        uint32_t done_left = 0;
+        for (uint32_t base = 0; base < n; base += 64u) {
+            const uint32_t i = base + (uint32_t)lane;
+            const bool valid = i < n;
+            uint32_t t = 0; bool isLeft = false;
+            if (valid) { t = list_cur[first + i]; isLeft = sm[i][6 + best_axis] < best_split; }
+            const unsigned long long m = __ballot(valid && isLeft);
+            const uint32_t lrank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (valid) {
+                const uint32_t pos = isLeft ? done_left + lrank : best_nl + (base - done_left) + ((uint32_t)lane - lrank);
+                list_next[first + pos] = t;
+                const int o = isLeft ? 0 : 6;
+                for (int k = 0; k < 3; k++) { atomicMin(&ckey[o + k], bv_enc(sm[i][k])); atomicMax(&ckey[o + 3 + k], bv_enc(sm[i][3 + k])); }
+                // a zero coordinate: remember the first one in list order (its sign is the one the reference keeps)
+                for (int k = 0; k < 6; k++) if (sm[i][k] == 0.f) atomicMin(&czero[o + k], i);
+            }
+            done_left += (uint32_t)__popcll(m);
+        }
+        wave_sync();
+        if (lane == 0) {
+            float bb12[12];
+            for (int k = 0; k < 12; k++) {
+                float v = bv_dec(ckey[k]);
+                // std::min / std::max keep the first of equal values: take the sign of the first zero of this side
+                if (v == 0.f && czero[k] != 0xffffffffu) v = sm[czero[k]][k % 6];
+                bb12[k] = v;
+            }
+            bv_emit_children(W, depth, N, best_nl, bb12);
+        }
+    }
+}
+
 // ---- big nodes, step 1: one chunk of a node per workgroup into the node's global bins -------------------------
 template <int MAXP>
 __global__ void __launch_bounds__(BV_THREADS)
@@ -506,7 +621,7 @@ k_big_bin(const BvWork W, const int depth)
     __shared__ uint32_t cnt[MAXP + 1], lmin[3][MAXP + 1], lmax[3][MAXP + 1];
     __shared__ uint32_t scan_tmp[BV_THREADS / 64];
     const int p = depth & 1, tid = (int)threadIdx.x;
-    const uint32_t n_task = W.ctl->n_task[p];
+    const uint32_t n_task = W.ctl->n_task[depth];
     const size_t row = (size_t)MAXP + 1u;
     for (uint32_t task = blockIdx.x; task < n_task; task += gridDim.x) {
         const BvTask tk = W.task[p][task];
@@ -561,7 +676,7 @@ k_big_eval(const BvWork W, const int depth)
     __shared__ uint32_t carry, s_child;
     __shared__ float bb12[12];
     const int p = depth & 1, tid = (int)threadIdx.x;
-    const uint32_t n_big = W.ctl->n_big[p];
+    const uint32_t n_big = W.ctl->n_big[depth];
     const size_t row = (size_t)MAXP + 1u;
     for (uint32_t bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
         __syncthreads();
@@ -579,7 +694,7 @@ k_big_eval(const BvWork W, const int depth)
             __syncthreads();
             if (tid == 0) S.C = C;
             const float *gt = W.gthr[p] + ((size_t)bi * 3 + axis) * MAXP;
-            for (int i = tid; i < C; i += BV_THREADS) S.thr[i] = gt[i];
+            for (int i = tid; i < C; i += BV_THREADS) S.thr[axis][i] = gt[i];
             uint32_t *g = W.gbin + ((size_t)bi * 3 + axis) * 7u * row;
             for (int i = tid; i <= C; i += BV_THREADS) {
                 S.cnt[i] = g[i]; g[i] = 0u;
@@ -628,8 +743,9 @@ k_big_eval(const BvWork W, const int depth)
         // children that are split by chunks themselves: slots, tasks, planes (one wavefront, lanes 0-2 each)
         if (depth + 1 < BV_BIG_LEVELS && tid < 64) {
             const uint32_t cl = S.best_nl, cr = n - S.best_nl;
-            if (cl > (uint32_t)BV_CH) bv_register_big(W, depth + 1, s_child, bb12, cl, tid);
-            if (cr > (uint32_t)BV_CH) bv_register_big(W, depth + 1, s_child + 1u, bb12 + 6, cr, tid);
+            // (the sweep is over: its plane array is free for the children's planes)
+            if (cl > (uint32_t)BV_CH) bv_register_big(W, depth + 1, s_child, bb12, cl, tid, &S.thr[0][0], S.C3);
+            if (cr > (uint32_t)BV_CH) bv_register_big(W, depth + 1, s_child + 1u, bb12 + 6, cr, tid, &S.thr[0][0], S.C3);
         }
     }
 }
@@ -641,7 +757,7 @@ k_big_scatter(const BvWork W, const int depth)
     __shared__ uint32_t wave_left[BV_THREADS / 64];
     __shared__ uint32_t s_last;
     const int p = depth & 1, tid = (int)threadIdx.x;
-    const uint32_t n_task = W.ctl->n_task[p];
+    const uint32_t n_task = W.ctl->n_task[depth];
     const uint32_t *list_cur = W.list[p];
     uint32_t *list_next = W.list[1 - p];
     for (uint32_t task = blockIdx.x; task < n_task; task += gridDim.x) {
@@ -701,45 +817,60 @@ k_big_scatter(const BvWork W, const int depth)
     }
 }
 
-// ---- between two levels ------------------------------------------------------------------------------
-__global__ void k_bvh_advance(const BvWork W, const int depth)
-{
-    BvCtl &c = *W.ctl;
-    const int p = depth & 1;
-    if (depth + 2 < BV_MAX_LEVELS + 2) c.level_start[depth + 2] = c.n_tree;
-    c.n_level[p] = 0u; c.n_big[p] = 0u; c.n_task[p] = 0u;
-    if (c.n_level[1 - p] == 0u && c.levels == 0u) c.levels = (uint32_t)depth + 1u;
-}
-
 // ---- pre-order numbering (Raytracer.cc:651-682): subtree sizes bottom up, indices and links top down -----------
 __device__ __forceinline__ bool bv_tame(const float x) { const float a = __builtin_fabsf(x); return a == 0.f || (a >= 1e-30f && a <= 1e17f); }
 
 __global__ void __launch_bounds__(1024)
-k_bvh_flatten(const BvWork W)
+k_bvh_flatten(const BvWork W, const int launched)
 {
-    __shared__ uint32_t s_tame, s_bounded;
-    __shared__ uint32_t s_mag;
+    __shared__ uint32_t s_tame, s_bounded, s_mag;
+    __shared__ uint32_t level_start[BV_MAX_LEVELS + 2];     // tree index of the first node of each level
+    __shared__ int s_levels;
     BvCtl &c = *W.ctl;
     const int tid = (int)threadIdx.x;
-    const int levels = (int)c.levels;
-    if (levels == 0) return;                      // the level loop has not finished (the host launches more levels first)
-    const BvTreeNode *tree = W.tree;
-    if (tid == 0) { s_tame = 1u; s_bounded = 1u; s_mag = 0u; }
+    if (tid == 0) {
+        // children are allocated level by level, so a level's nodes are consecutive tree indices
+        int levels = 0;
+        uint32_t at = 0;
+        while (levels < launched && levels <= BV_MAX_LEVELS && c.n_level[levels] != 0u) { level_start[levels] = at; at += c.n_level[levels]; levels++; }
+        level_start[levels] = at;
+        // (finished = the first level that was not launched yet is empty)
+        s_levels = (levels <= BV_MAX_LEVELS && c.n_level[levels] == 0u) ? levels : 0;
+        s_tame = 1u; s_bounded = 1u; s_mag = 0u;
+    }
     __syncthreads();
+    const int levels = s_levels;
+    if (levels == 0) return;                      // the level loop has not run dry yet (the host launches more levels first)
+    const BvTreeNode *tree = W.tree;
     uint32_t tame = 1u, bounded = 1u;
     float mag = 0.f;
+    enum { U = 4 };                               // nodes per thread in flight: the loads of a level are independent
     for (int d = levels - 1; d >= 0; d--) {
-        const uint32_t i0 = c.level_start[d], i1 = c.level_start[d + 1];
-        for (uint32_t i = i0 + (uint32_t)tid; i < i1; i += 1024u) {
-            const BvTreeNode n = tree[i];
-            const bool leaf = (n.a & 0x80000000u) != 0u;
-            W.sub[i] = leaf ? 1u : 1u + W.sub[n.a] + W.sub[n.b];
-            W.subi[i] = leaf ? 0u : 1u + W.subi[n.a] + W.subi[n.b];
-            for (int k = 0; k < 6; k++) {
-                const float a = __builtin_fabsf(n.bb[k]);
-                if (!leaf && !bv_tame(n.bb[k])) tame = 0u;
-                if (!(a <= 1e17f)) bounded = 0u;
-                mag = a > mag ? a : mag;
+        const uint32_t i0 = level_start[d], i1 = level_start[d + 1];
+        for (uint32_t ib = i0 + (uint32_t)tid; ib < i1; ib += 1024u * U) {
+            BvTreeNode n[U];
+            uint32_t sa[U], sb[U], ia[U], jb[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) { const uint32_t i = ib + 1024u * u; if (i < i1) n[u] = tree[i]; else { n[u].a = 0x80000000u; n[u].b = 0u; for (int k = 0; k < 6; k++) n[u].bb[k] = 0.f; } }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const bool leaf = (n[u].a & 0x80000000u) != 0u;
+                sa[u] = leaf ? 0u : W.sub[n[u].a]; sb[u] = leaf ? 0u : W.sub[n[u].b];
+                ia[u] = leaf ? 0u : W.subi[n[u].a]; jb[u] = leaf ? 0u : W.subi[n[u].b];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t i = ib + 1024u * u;
+                if (i >= i1) continue;
+                const bool leaf = (n[u].a & 0x80000000u) != 0u;
+                W.sub[i] = 1u + sa[u] + sb[u];
+                W.subi[i] = leaf ? 0u : 1u + ia[u] + jb[u];
+                for (int k = 0; k < 6; k++) {
+                    const float a = __builtin_fabsf(n[u].bb[k]);
+                    if (!leaf && !bv_tame(n[u].bb[k])) tame = 0u;
+                    if (!(a <= 1e17f)) bounded = 0u;
+                    mag = a > mag ? a : mag;
+                }
             }
         }
         __syncthreads();
@@ -750,14 +881,24 @@ k_bvh_flatten(const BvWork W)
     if (tid == 0) { W.pre[0] = 0u; W.irank[0] = 0u; W.esc[0] = MI_END_LINK; }
     __syncthreads();
     for (int d = 0; d + 1 < levels; d++) {
-        const uint32_t i0 = c.level_start[d], i1 = c.level_start[d + 1];
-        for (uint32_t i = i0 + (uint32_t)tid; i < i1; i += 1024u) {
-            const BvTreeNode n = tree[i];
-            if (n.a & 0x80000000u) continue;
-            const uint32_t pr = W.pre[i], ir = W.irank[i];
-            W.pre[n.a] = pr + 1u; W.pre[n.b] = pr + 1u + W.sub[n.a];
-            W.irank[n.a] = ir + 1u; W.irank[n.b] = ir + 1u + W.subi[n.a];
-            W.esc[n.a] = n.b; W.esc[n.b] = W.esc[i];
+        const uint32_t i0 = level_start[d], i1 = level_start[d + 1];
+        for (uint32_t ib = i0 + (uint32_t)tid; ib < i1; ib += 1024u * U) {
+            uint32_t na[U], nb[U], pr[U], ir[U], es[U], sa[U], ia[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t i = ib + 1024u * u;
+                na[u] = 0x80000000u; nb[u] = 0u;
+                if (i < i1) { na[u] = tree[i].a; nb[u] = tree[i].b; pr[u] = W.pre[i]; ir[u] = W.irank[i]; es[u] = W.esc[i]; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) if (!(na[u] & 0x80000000u)) { sa[u] = W.sub[na[u]]; ia[u] = W.subi[na[u]]; }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (na[u] & 0x80000000u) continue;
+                W.pre[na[u]] = pr[u] + 1u; W.pre[nb[u]] = pr[u] + 1u + sa[u];
+                W.irank[na[u]] = ir[u] + 1u; W.irank[nb[u]] = ir[u] + 1u + ia[u];
+                W.esc[na[u]] = nb[u]; W.esc[nb[u]] = es[u];
+            }
         }
         __syncthreads();
     }
@@ -765,6 +906,7 @@ k_bvh_flatten(const BvWork W)
         c.n_nodes = W.sub[0]; c.n_inner = W.subi[0];
         c.inner_levels = (uint32_t)(levels - 1);
         c.tame = s_tame; c.bounded = s_bounded; c.mag = __uint_as_float(s_mag);
+        c.levels = (uint32_t)levels;
     }
 }
 
@@ -898,16 +1040,20 @@ extern "C" hipError_t mi355i_bvh_build_levels(const BvWork *w, int first_depth, 
             }
             hipLaunchKernelGGL(k_big_scatter, dim3(g_task), dim3(BV_THREADS), 0, st, *w, depth);
         }
-        if (many) hipLaunchKernelGGL((k_bvh_level<2200>), dim3(1024), dim3(BV_THREADS), 0, st, *w, depth);
-        else hipLaunchKernelGGL((k_bvh_level<1100>), dim3(1024), dim3(BV_THREADS), 0, st, *w, depth);
-        hipLaunchKernelGGL(k_bvh_advance, dim3(1), dim3(1), 0, st, *w, depth);
+        if (many) {
+            hipLaunchKernelGGL((k_bvh_level<2200>), dim3(1024), dim3(BV_THREADS), 0, st, *w, depth);
+            if (depth >= BV_SMALL_DEPTH) hipLaunchKernelGGL((k_bvh_small<704>), dim3(1024), dim3(BV_THREADS), 0, st, *w, depth);
+        } else {
+            hipLaunchKernelGGL((k_bvh_level<1100>), dim3(1024), dim3(BV_THREADS), 0, st, *w, depth);
+            if (depth >= BV_SMALL_DEPTH) hipLaunchKernelGGL((k_bvh_small<352>), dim3(1024), dim3(BV_THREADS), 0, st, *w, depth);
+        }
     }
     return hipGetLastError();
 }
 
-extern "C" hipError_t mi355i_bvh_build_finish(const BvWork *w, hipStream_t st)
+extern "C" hipError_t mi355i_bvh_build_finish(const BvWork *w, int levels_launched, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_bvh_flatten, dim3(1), dim3(1024), 0, st, *w);
+    hipLaunchKernelGGL(k_bvh_flatten, dim3(1), dim3(1024), 0, st, *w, levels_launched);
     hipLaunchKernelGGL(k_bvh_emit_nodes, dim3(512), dim3(256), 0, st, *w);
     hipLaunchKernelGGL(k_bvh_emit_tris, dim3((w->T + 255u) / 256u), dim3(256), 0, st, *w);
     return hipGetLastError();

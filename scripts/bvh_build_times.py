@@ -8,4 +8,4 @@ for mesh in ("dragon_vis.ply", "statue.ply", "chessboard.tri", "legocar.3ds"):
     for rep in range(6):
         t0 = time.perf_counter(); s.build_bvh_device(); wall = (time.perf_counter() - t0) * 1e3
         tm = (C.c_double * 4)(); R.lib().mi355i_bvh_last_times(tm)
-        print("%-16s rep %d: wall %.2f ms = setup %.2f + levels %.2f + download/flatten %.2f + install %.2f" % (mesh, rep, wall, tm[0], tm[1], tm[2], tm[3]), flush=True)
+        print("%-16s rep %d: wall %.2f ms = setup %.2f + kernels %.2f + tree to caller %.2f + install %.2f" % (mesh, rep, wall, tm[0], tm[1], tm[2], tm[3]), flush=True)

@@ -14,10 +14,7 @@ for mesh in ("dragon_vis.ply", "statue.ply", "chessboard.tri"):
     t0 = time.perf_counter(); g = s.build_bvh_device(); t_gpu = time.perf_counter() - t0
     import ctypes as C
     tm = (C.c_double * 4)(); R.lib().mi355i_bvh_last_times(tm)
-    print("   GPU builder: setup %.2f ms, %d level launches %.2f ms, download + flatten %.2f ms, install in the context %.2f ms" % (tm[0], g[2] + 1, tm[1], tm[2], tm[3]))
-    lm = (C.c_double * 64)(); ln = (C.c_uint32 * 64)()
-    nl = R.lib().mi355i_bvh_level_times(lm, ln)
-    print("   per level (nodes: ms): " + "  ".join("%d: %.2f" % (ln[i], lm[i]) for i in range(nl)))
+    print("   GPU builder: setup %.2f ms, kernels of %d levels + flatten + streams %.2f ms, tree to the caller %.2f ms, install in the context %.2f ms" % (tm[0], g[2] + 1, tm[1], tm[2], tm[3]))
     same_nodes = g[0].shape == nodes.shape and bool((g[0] == nodes).all())
     same_idx = bool((g[1] == idx).all())
     blob = np.array([nodes.shape[0], idx.shape[0]], np.uint32).tobytes() + g[0].tobytes() + g[1].tobytes()
