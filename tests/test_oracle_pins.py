@@ -1,10 +1,13 @@
-"""Pin the CPU oracle against outputs of the REAL reference.
+"""Pin the CPU oracle against outputs of the reference recorded by the survey.
 
-The reference cannot be rebuilt here (it needs SDL 1.2 headers the image lacks and
-stand-ins are not allowed), so the pins are the frame hashes, counters, camera
-probes and .bvh statistics the survey recorded from the strict single-thread
-reference build.  If these pass, the restatement is bit-identical to the reference
-on every BASELINE.json config's first benchmark frame.
+*** SURVEY PROVENANCE ***  The whole reference program cannot be rebuilt here (it needs SDL 1.2 development files the image
+lacks, and stand-ins are not allowed), so THESE pins are the frame hashes, counters, camera probes and .bvh statistics the
+survey recorded from its own strict single-thread build -- nobody can regenerate them in this container.
+scripts/make_reference_pins.sh is the recipe for a machine that has SDL 1.2 (and widens the set to frames f0/f50/f100/f150,
+modes 1/4/5/7/10 and full .bvh hashes).  What the image CAN build from the reference's own sources is pinned separately and
+bit for bit by tests/test_refcore_pins.py (oracle/_ref/refcore: Raytrace<>, shadow maps, camera / light bases,
+LightingEquation<>, the scalar BVH builder, MLAA, and the -DREFRACTIONS / -DAMBIENT_OCCLUSION builds).
+If the tests below pass, the restatement reproduces the survey's numbers on every BASELINE.json config's first benchmark frame.
 """
 import hashlib
 import json
