@@ -1101,6 +1101,23 @@ static M3 lookat_basis(const V3 &forwardUnnormalised)
 
 extern "C" {
 
+void orc_trace_hits(const orc_scene *s, int n, const float *rays6, int32_t *tri, float *hit3)
+{
+    orc_opts o;
+    orc_default_opts(&o, 16, 16);
+    RtCtx c; c.s = s; c.o = &o; c.lights = nullptr; c.nLights = 0;
+    memset(&c.st, 0, sizeof c.st);
+    for (int i = 0; i < n; i++) {
+        const float *r = rays6 + 6 * (size_t)i;
+        int best = -1;
+        V3 hit(0.f, 0.f, 0.f);
+        float k1 = 0.f, k2 = 0.f, k3 = 0.f;
+        bvh_intersect<false>(c, V3(r[0], r[1], r[2]), V3(r[3], r[4], r[5]), -1, best, hit, k1, k2, k3, true);
+        tri[i] = best;
+        hit3[3 * (size_t)i] = hit.x; hit3[3 * (size_t)i + 1] = hit.y; hit3[3 * (size_t)i + 2] = hit.z;
+    }
+}
+
 void orc_default_opts(orc_opts *o, int width, int height)
 {
     memset(o, 0, sizeof *o);

@@ -125,6 +125,10 @@ int orc_render(const orc_scene *, int mode, const orc_camera *, const orc_light 
                int n_lights, const float *const *shadow_maps, const orc_opts *,
                uint32_t *out_xrgb, int pitch_words, float *out_f32, orc_stats *stats);
 
+/* BVH_IntersectTriangles<false,true> (Raytracer.cc:183-308) for n rays (origin, direction): the triangle each ray hits first
+ * (index into the scene's triangles, -1 = none) and the hit point.  For tests that need hits, not pixels. */
+void orc_trace_hits(const orc_scene *, int n, const float *rays6, int32_t *tri, float *hit3);
+
 /* LightingEquation<mode>::ComputePixel (LightingEq.h:45-170) on caller-supplied points, rows of
  * (inCameraSpace[3], normal[3], material r,g,b, ao) -> r,g,b; shadow_mode 0 none, 1 shadow maps, 2 soft */
 void orc_lighting(const orc_light *lights, int n_lights, const float *const *shadow_maps, const orc_opts *o,

@@ -200,6 +200,17 @@ class Scene:
         lib().orc_shadowmap_render(self._h, C.byref(light), size, m.ctypes.data)
         return m
 
+    def trace_hits(self, rays):
+        """orc_trace_hits: rays (n, 6) float32 -> (triangle index or -1 [n], hit point [n, 3])"""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        tri = np.zeros(len(rays), np.int32)
+        hit = np.zeros((len(rays), 3), np.float32)
+        f = lib().orc_trace_hits
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        f.restype = None
+        f(self._h, len(rays), rays.ctypes.data, tri.ctypes.data, hit.ctypes.data)
+        return tri, hit
+
     def render(self, mode: int, cam: Camera, lights, n_lights: int, opts: Opts, shadow_maps=None,
                want_f32: bool = False):
         W, H = opts.width, opts.height

@@ -1049,6 +1049,27 @@ int mi355i_scene_info(mi355_ctx *c, uint32_t *out4)
     return 0;
 }
 
+// tests: what a lane of the ordered walk computes for (ray, box) pairs (k_raytrace.hip k_cull_probe); out4 = n_pairs * 4 floats
+extern "C" hipError_t mi355i_launch_cull_probe(const float *rays6, const uint32_t *pair_ray, const float *pair_box6, uint32_t n_pairs, float scene_mag,
+                                               float *out4, hipStream_t st);
+int mi355i_cull_probe(mi355_ctx *c, const float *rays6, uint32_t n_rays, const uint32_t *pair_ray, const float *pair_box6, uint32_t n_pairs, float *out4)
+{
+    if (!c || !rays6 || !pair_ray || !pair_box6 || !out4) return fail(-3, "mi355i_cull_probe: null argument");
+    if (!c->has_bvh) return fail(-41, "no BVH installed");
+    if (int r = select_device(c)) return r;
+    DevBuf d_r, d_p, d_b, d_o;
+    auto done = [&](int rc) { d_r.release(); d_p.release(); d_b.release(); d_o.release(); return rc; };
+    if (d_r.ensure((size_t)n_rays * 24 + 16) != hipSuccess || d_p.ensure((size_t)n_pairs * 4 + 16) != hipSuccess ||
+        d_b.ensure((size_t)n_pairs * 24 + 16) != hipSuccess || d_o.ensure((size_t)n_pairs * 16 + 16) != hipSuccess) return done(fail(-31, "mi355i_cull_probe: out of device memory"));
+    if (hipMemcpy(d_r.p, rays6, (size_t)n_rays * 24, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_p.p, pair_ray, (size_t)n_pairs * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_b.p, pair_box6, (size_t)n_pairs * 24, hipMemcpyHostToDevice) != hipSuccess) return done(fail(-31, "mi355i_cull_probe: upload failed"));
+    if (mi355i_launch_cull_probe((const float *)d_r.p, (const uint32_t *)d_p.p, (const float *)d_b.p, n_pairs, c->dev.scene_mag, (float *)d_o.p, c->stream) != hipSuccess)
+        return done(fail(-43, "mi355i_cull_probe: launch failed"));
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out4, d_o.p, (size_t)n_pairs * 16, hipMemcpyDeviceToHost) != hipSuccess)
+        return done(fail(-40, "mi355i_cull_probe: kernel failed"));
+    return done(0);
+}
+
 // debug / tests: the installed traversal state.  which = 0: the DevScene scalars (as 32 words: root_a, root_b, vroot_a, vroot_b, root_link,
 // tri_base, ordered_ok, stack_depth, scene_mag, n_nodes); 1, 2, 3: the first `bytes` bytes of the walk / edge / shading streams.
 int mi355i_fetch_traversal(mi355_ctx *c, int which, void *out, size_t bytes)

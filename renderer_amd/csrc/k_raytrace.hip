@@ -1073,6 +1073,33 @@ k_raytrace(const DevScene S, const FrameParams P)
 #undef MI_PHASE
 }
 
+// ---- test probe: the ordered walk's box bounds for (ray, box) pairs, exactly as a lane computes them -----------
+// out[4 * i] = near_g (lower bound of the entry into the box grown by the slack), far_g, dmax (the slack in ray parameter),
+// flag bits (1 sure, 2 pass, 4 tame ray) as a float
+namespace {
+__global__ void __launch_bounds__(256)
+k_cull_probe(const float *rays6, const uint32_t *pair_ray, const float *pair_box6, uint32_t n_pairs, float scene_mag, float *out4)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_pairs) return;
+    const float *r = rays6 + 6 * (size_t)pair_ray[i], *b = pair_box6 + 6 * (size_t)i;
+    Lane L;
+    L.o = mk3(r[0], r[1], r[2]); L.d = mk3(r[3], r[4], r[5]);
+    set_ray_aux(L, scene_mag);
+    bool sure;
+    float key, near_g, far_g;
+    const bool pass = ray_box_fast_ordered(L.o, L.inv, L.dmax, make_float4(b[0], b[3], b[1], b[4]), make_float4(b[2], b[5], 0.f, 0.f), sure, key, near_g, far_g);
+    out4[4 * (size_t)i] = near_g; out4[4 * (size_t)i + 1] = far_g; out4[4 * (size_t)i + 2] = L.dmax;
+    out4[4 * (size_t)i + 3] = (float)((sure ? 1 : 0) | (pass ? 2 : 0) | (L.tame ? 4 : 0));
+}
+} // namespace
+extern "C" hipError_t mi355i_launch_cull_probe(const float *rays6, const uint32_t *pair_ray, const float *pair_box6, uint32_t n_pairs, float scene_mag,
+                                               float *out4, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_cull_probe, dim3((n_pairs + 255u) / 256u), dim3(256), 0, st, rays6, pair_ray, pair_box6, n_pairs, scene_mag, out4);
+    return hipGetLastError();
+}
+
 // ---- launch helper (called from capi.hip) ------------------------------------------------
 namespace {
 typedef void (*rt_kernel)(const DevScene, const FrameParams);

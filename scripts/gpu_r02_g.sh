@@ -1,3 +1,3 @@
 mkdir -p gpurun_out
-(timeout 300 python scripts/rt_lane_util.py 2>&1 | tail -12) > gpurun_out/r02g_lanes.log
-cat gpurun_out/r02g_lanes.log
+(timeout 600 python -m pytest tests/test_gpu_cull_margin.py -q -s 2>&1 | grep -E "pairs|passed|failed|Error") > gpurun_out/r02g_margin.log
+cat gpurun_out/r02g_margin.log
