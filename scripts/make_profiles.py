@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""Distil the rocprofv3 output of scripts/gpu_round1_full.sh (under gpurun_out/) into the tracked files in profiles/.
+"""Distil the rocprofv3 output of scripts/gpu_round2_full.sh (under gpurun_out/) into the tracked files in profiles/.
 
-    python scripts/make_profiles.py [round-tag, default r01]
+    python scripts/make_profiles.py [round-tag, default r02]
 """
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
-KERNEL = "k_raytrace<false, false, true, 4, true>"   # the bench kernel: ordered walk, batched launch, four waves per SIMD
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+KERNEL = "k_raytrace<false, false, true, 4, true, false>"   # the bench kernel: ordered walk, batched launch, four waves per SIMD
 
 
 def newest(pattern):
@@ -15,12 +15,12 @@ def newest(pattern):
     return files[-1] if files else None
 
 
-def per_launch(kind):
+def per_launch(kind, kernel=KERNEL):
     f = newest("gpurun_out/%s/**/*counter_collection.csv" % kind)
     acc = collections.defaultdict(lambda: [0.0, 0])
     if f:
         for row in csv.DictReader(open(f)):
-            if KERNEL in row["Kernel_Name"]:
+            if kernel in row["Kernel_Name"]:
                 a = acc[row["Counter_Name"]]
                 a[0] += float(row["Counter_Value"]); a[1] += 1
     return {k: v[0] / v[1] for k, v in acc.items()}, {k: v[1] for k, v in acc.items()}
@@ -39,7 +39,20 @@ def main():
     traffic = None
     if fetch_kb is not None and write_kb is not None:
         traffic = 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0
+    # the rasterizer's three tiled kernels (mode 6, chessboard 1080p, single-frame launches)
+    raster = {}
+    for kern in ("k_rs_setup", "k_rs_fill", "k_rs_tile"):
+        r, rn = {}, {}
+        for kind in ("prof_rs_fetch", "prof_rs_write", "prof_rs_sq", "prof_rs_valu"):
+            v, n = per_launch(kind, kern)
+            r.update(v); rn.update(n)
+        if r:
+            f_kb, w_kb = r.get("FETCH_SIZE"), r.get("WRITE_SIZE")
+            raster[kern] = {"pmc_per_launch": r, "launches": max(rn.values()),
+                            "hbm_bytes_per_launch": (2.0 * f_kb * 1024.0 + w_kb * 1024.0) if f_kb is not None and w_kb is not None else None}
     json.dump({
+        "round": TAG,
+        "raster_kernels": raster,
         "kernel": KERNEL,
         "workload": "dragon_vis.ply mode 9 1920x1080, bench.py --steps 20 --warmup 2 under rocprofv3 --pmc (one pass per counter group)",
         "FETCH_SIZE_KB_per_launch_raw": fetch_kb, "WRITE_SIZE_KB_per_launch_raw": write_kb,
@@ -47,7 +60,8 @@ def main():
         "k_raytrace_hbm_bytes_per_launch": traffic,
         "pmc_per_launch": pmc, "launches": launches,
     }, open(os.path.join(out, "traffic.json"), "w"), indent=1)
-    for src, dst in (("gpurun_out/bench_full.log", "%s_bench_n1.jsonl" % TAG), ("gpurun_out/pytest_full.log", "%s_pytest_gpu.log" % TAG)):
+    for src, dst in (("gpurun_out/bench_full.log", "%s_bench_n1.jsonl" % TAG), ("gpurun_out/pytest_full.log", "%s_pytest_gpu.log" % TAG),
+                     ("gpurun_out/misc_full.log", "%s_side_measurements.log" % TAG)):
         p = os.path.join(ROOT, src)
         if os.path.exists(p):
             lines = [l for l in open(p).read().splitlines() if l.strip()]
