@@ -8,6 +8,8 @@
 //   --bench     the reference's `make bench` (src/Makefile.am:25-26): five runs of `-b -n 500` (or -n N), then
 //               Average / Std dev / Median / Min / Max of their frame rates, as its perl one-liner prints them
 //   -g N        draw every frame on N GPUs (devices 0..N-1; -g 0,0 lists devices explicitly)
+//   -p N        keep N frames in flight (2..4, Scene::renderAsync): frame k is copied out while frame k+1 renders; the
+//               reported rate is then frames / wall time of the loop (there is no "time inside render" to add up)
 #include "renderer_host.h"
 
 #include <algorithm>
@@ -24,15 +26,27 @@ using namespace mi355;
 static void usage()
 {
     fprintf(stderr,
-            "Usage: render_cli [-b] [-r] [--bench] [-n frames] [-m mode] [-w] [-W width] [-H height] [-d device] [-g gpus] [-o ppm_prefix] FILE\n"
+            "Usage: render_cli [-b] [-r] [--bench] [-n frames] [-m mode] [-w] [-W width] [-H height] [-d device] [-g gpus] [-p in_flight] [-o ppm_prefix] FILE\n"
             "  -m <mode>  1 points, 2 points from triangles, 4 ambient, 5 Gouraud, 6 Phong,\n"
             "             7 Phong+shadow maps, 8 Phong+soft shadow maps, 9 raytracing, 0 raytracing+AA\n"
             "  -w         use two lights        -n N  frames (default 100)\n");
     exit(1);
 }
 
+static void write_ppm(const char *prefix, int frame, const Screen &canvas)
+{
+    char name[512];
+    snprintf(name, sizeof name, "%s_%04d.ppm", prefix, frame);
+    if (FILE *fp = fopen(name, "wb")) {
+        fprintf(fp, "P6\n%d %d\n255\n", canvas._width, canvas._height);
+        for (uint32_t p : canvas._pixels) { unsigned char rgb[3] = {(unsigned char)(p >> 16), (unsigned char)(p >> 8), (unsigned char)p}; fwrite(rgb, 1, 3, fp); }
+        fclose(fp);
+    }
+}
+
 // one `renderer -b -n frames` run; returns frames per second (time inside Scene::render* only, renderer.cc:584-585, 631-633)
-static double run(const char *fname, int mode, int frames, int W, int H, const std::vector<int> &devices, bool twoLights, bool periodic, const char *dump)
+static double run(const char *fname, int mode, int frames, int W, int H, const std::vector<int> &devices, bool twoLights, bool periodic, const char *dump,
+                  int inFlight = 1)
 {
     Scene scene;
     if (devices.size() > 1) scene._devices = devices;
@@ -51,6 +65,42 @@ static double run(const char *fname, int mode, int frames, int W, int H, const s
         l->CalculatePositionInCameraSpace(sony);
         l->RenderSceneIntoShadowBuffer(scene);
         l->CalculateXformFromWorldToLightSpace();
+    }
+    if (inFlight > 1) {
+        // pipelined presentation: a ring of canvases, frame f waits for frame f - inFlight + 1 before it is shown
+        std::vector<std::unique_ptr<Screen>> ring;
+        for (int i = 0; i < inFlight; i++) {
+            ring.emplace_back(new Screen(scene, W, H));
+            mi355_host_register(scene.context(), ring.back()->_pixels.data(), ring.back()->_pixels.size() * 4);     // direct DMA into the canvas
+        }
+        std::vector<int> ticket((size_t)inFlight, -1), frameOf((size_t)inFlight, 0);
+        const int m = mode == 2 ? MI355_MODE_POINTS_FROM_TRIANGLES : mode;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int f = 0; f < frames + inFlight - 1; f++) {
+            const int slot = f % inFlight;
+            if (f >= inFlight - 1) {                                       // oldest pending frame: wait, present
+                const int old = (f + 1) % inFlight;
+                if (ticket[old] >= 0) {
+                    scene.renderWait(ticket[old]); ring[old]->ShowScreen(mode >= 9, true); ticket[old] = -1;
+                    if (dump) write_ppm(dump, frameOf[old], *ring[old]);
+                }
+            }
+            if (f < frames) {
+                orbit.advance();
+                sony.set(orbit.eye, orbit.lookat);
+                if (mode >= 5) for (Light *l : scene._lights) l->CalculatePositionInCameraSpace(sony);
+                if (mode >= 7) for (Light *l : scene._lights) l->CalculateXformFromCameraToLightSpace(sony);
+                ticket[slot] = scene.renderAsync(m, sony, *ring[slot]);
+                frameOf[slot] = f + 1;
+            }
+        }
+        for (int i = 0; i < inFlight; i++)
+            if (ticket[i] >= 0) { scene.renderWait(ticket[i]); ring[i]->ShowScreen(mode >= 9, true); if (dump) write_ppm(dump, frameOf[i], *ring[i]); }
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        for (auto &c : ring) mi355_host_unregister(scene.context(), c->_pixels.data());
+        const double fps = frames / sec;
+        printf("Rendering %d frames in %g seconds. (%g fps, %d in flight)\n", frames, sec, fps, inFlight);
+        return fps;
     }
     double msSpentDrawing = 0, msAtLastReport = 0;
     int framesAtLastReport = 0;
@@ -83,15 +133,7 @@ static double run(const char *fname, int mode, int frames, int W, int H, const s
                 lastReport = wall; framesAtLastReport = f + 1; msAtLastReport = msSpentDrawing;
             }
         }
-        if (dump) {
-            char name[512];
-            snprintf(name, sizeof name, "%s_%04d.ppm", dump, f + 1);
-            if (FILE *fp = fopen(name, "wb")) {
-                fprintf(fp, "P6\n%d %d\n255\n", W, H);
-                for (uint32_t p : canvas._pixels) { unsigned char rgb[3] = {(unsigned char)(p >> 16), (unsigned char)(p >> 8), (unsigned char)p}; fwrite(rgb, 1, 3, fp); }
-                fclose(fp);
-            }
-        }
+        if (dump) write_ppm(dump, f + 1, canvas);
     }
     const double fps = msSpentDrawing > 0 ? frames / (msSpentDrawing / 1000.0) : 0.0;
     if (msSpentDrawing > 0) printf("Rendering %d frames in %g seconds. (%g fps)\n", frames, msSpentDrawing / 1000.0, fps);
@@ -103,6 +145,7 @@ int main(int argc, char **argv)
     int mode = 8, frames = -1, W = 800, H = 600;                   // defaults: renderer.cc:177-181, Defines.h:26-27
     std::vector<int> devices;
     bool twoLights = false, periodic = false, bench = false;
+    int inFlight = 1;
     const char *dump = nullptr, *fname = nullptr;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
@@ -123,6 +166,7 @@ int main(int argc, char **argv)
             else for (int d = 0; d < atoi(v); d++) devices.push_back(d);
             if (devices.empty()) usage();
         }
+        else if (!strcmp(a, "-p")) { inFlight = atoi(next()); if (inFlight < 1 || inFlight > MI355_MAX_IN_FLIGHT) usage(); }
         else if (!strcmp(a, "-o")) dump = next();
         else if (a[0] == '-') usage();
         else fname = a;
@@ -130,10 +174,10 @@ int main(int argc, char **argv)
     if (!fname || mode < 1 || mode > 10 || mode == 3) usage();
     if (frames < 0) frames = bench ? 500 : 100;
     try {
-        if (!bench) { run(fname, mode, frames, W, H, devices, twoLights, periodic, dump); return 0; }
+        if (!bench) { run(fname, mode, frames, W, H, devices, twoLights, periodic, dump, inFlight); return 0; }
         // src/Makefile.am:25-26: five runs, then the statistics of their frame rates
         std::vector<double> fps;
-        for (int i = 0; i < 5; i++) fps.push_back(run(fname, mode, frames, W, H, devices, twoLights, periodic, nullptr));
+        for (int i = 0; i < 5; i++) fps.push_back(run(fname, mode, frames, W, H, devices, twoLights, periodic, nullptr, inFlight));
         // (the perl of src/Makefile.am:26: sample variance, the middle element of the sorted rates, "%15s: %f")
         double total = 0, totalSq = 0;
         for (double v : fps) { printf("%g\n", v); total += v; totalSq += v * v; }

@@ -804,6 +804,28 @@ void Scene::renderMode(int mode, const Camera &eye, Screen &canvas)
         raise(std::string("mi355_render: ") + mi355_last_error());
 }
 
+int Scene::renderAsync(int mode, const Camera &eye, Screen &canvas)
+{
+    if (multi()) raise("renderAsync: frames in flight are a single-device feature (mi355_render_async)");
+    if (mode >= MI355_MODE_RAYTRACE && _pCFBVH.empty()) raise("renderAsync: call UpdateBoundingVolumeHierarchy(filename) first");
+    mi355_opts o = _opts;
+    o.width = canvas._width; o.height = canvas._height;
+    o.screen_dist = canvas._height * 2;
+    const mi355_camera cam = eye.abi();
+    mi355_light lights[MI355_MAX_LIGHTS];
+    const int n = (int)std::min<size_t>(_lights.size(), MI355_MAX_LIGHTS);
+    for (int i = 0; i < n; i++) lights[i] = _lights[i]->abi();
+    int ticket = -1;
+    if (mi355_render_async(context(), mode, &cam, lights, n, &o, canvas._pixels.data(), canvas._pitch, &ticket) != 0)
+        raise(std::string("mi355_render_async: ") + mi355_last_error());
+    return ticket;
+}
+
+void Scene::renderWait(int ticket)
+{
+    if (mi355_render_wait(context(), ticket, &_lastStats) != 0) raise(std::string("mi355_render_wait: ") + mi355_last_error());
+}
+
 void Scene::renderPoints(const Camera &eye, Screen &canvas, bool asTriangles)
 {
     renderMode(asTriangles ? MI355_MODE_POINTS_FROM_TRIANGLES : MI355_MODE_POINTS, eye, canvas);

@@ -141,6 +141,13 @@ struct Scene {                                         // Scene.h:32-86
     void renderPhongAndSoftShadowed(const Camera &, Screen &);
     bool renderRaytracer(Camera &, Screen &, bool antiAlias = false);       // Scene.h:85
 
+    // The same frames, pipelined (no reference counterpart: its loop is synchronous).  renderAsync enqueues the frame of any
+    // RenderMode into `canvas` and returns a ticket; up to MI355_MAX_IN_FLIGHT frames may be pending, each into its own
+    // Screen; renderWait blocks until that frame is in canvas._pixels (then call canvas.ShowScreen()).  A front-end that
+    // alternates two or more canvases overlaps the copy-out of frame k with the rendering of frame k+1.
+    int renderAsync(int mode, const Camera &, Screen &canvas);
+    void renderWait(int ticket);
+
     // device plumbing
     mi355_scene_desc desc() const;
     mi355_ctx *context() const;                        // uploads on first use; throws std::string on failure

@@ -449,6 +449,20 @@ def test_render_cli_runs():
     assert "Rendering 5 frames in" in out.stdout and "fps" in out.stdout
 
 
+@pytest.mark.parametrize("mode,mesh", [(9, "dragon_vis.ply"), (8, "chessboard.tri")])
+def test_render_cli_pipelined_frames_are_the_synchronous_frames(mode, mesh, tmp_path):
+    """render_cli -p 3 (mi355::Scene::renderAsync / renderWait, three canvases in flight) writes the frames of the plain loop"""
+    import subprocess
+    for tag, extra in (("sync", []), ("pipe", ["-p", "3"])):
+        out = subprocess.run([R.RENDER_CLI, "-b", "-n", "7", "-m", str(mode), "-W", "640", "-H", "360", "-o", str(tmp_path / tag)] + extra +
+                             [R.assets.mesh_path(mesh)], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+    assert "3 in flight" in out.stdout
+    for f in range(1, 8):
+        a, b = (tmp_path / ("sync_%04d.ppm" % f)).read_bytes(), (tmp_path / ("pipe_%04d.ppm" % f)).read_bytes()
+        assert len(a) == 640 * 360 * 3 + 15 and a == b, "frame %d" % f
+
+
 def test_errors_are_reported_not_swallowed(gpu_scene):
     hs = R.Scene(R.assets.mesh_path("chessboard.tri"))
     cam, lights, n = R.benchmark_frame(0)
