@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(256) k_rs_setup(const DevScene S, const FrameP
     const FrameParams &F = batch ? batch[f] : P;
     if (blockIdx.x == 0) {                                // rs_fill's cursors and rs_tile's dispenser start at zero
         for (uint32_t i = threadIdx.x; i < (uint32_t)g.n_bins; i += blockDim.x) B.cursor[(size_t)f * g.n_bins + i] = 0u;
-        if (f == 0 && threadIdx.x == 0) B.band_top[gridDim.y] = 0u;
+        if (f == 0 && threadIdx.x < RS_DISPENSERS) B.band_top[gridDim.y + threadIdx.x] = 0u;
     }
     uint4 box = make_uint4(0xffffffffu, 0u, 0u, 0u);
     if (t < S.n_tris) box = rs_setup_thread<MODE>(S, F, B, f, t);
@@ -422,7 +422,13 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) k_rs_tile(const DevScene S, co
     for (uint32_t w = blockIdx.x; w < total_items;) {
         const uint32_t f = w % (uint32_t)n_frames, slot = w / (uint32_t)n_frames;
         const uint32_t *order = B.order + (size_t)f * ((size_t)g.n_tiles + 1);
-        if (tid == 0) next_w = gridDim.x + atomicAdd(&B.band_top[n_frames], 1u);     // (arrives while this tile is worked on)
+        // The next item: none when every item is some block's first one (a single frame).  Else from one of RS_DISPENSERS
+        // counters (counter c hands out items grid + c, grid + c + RS_DISPENSERS, ...): atomics on ONE address come back
+        // ~10 ns apart, and a wave's later loads queue behind its atomic -- a single counter cost 10 us of a 1080p frame.
+        if (tid == 0) {
+            const uint32_t nd = gridDim.x < RS_DISPENSERS ? 1u : (uint32_t)RS_DISPENSERS, c = blockIdx.x % nd;
+            next_w = total_items <= gridDim.x ? total_items : gridDim.x + c + nd * atomicAdd(&B.band_top[n_frames + c], 1u);
+        }
         if (slot >= order[0]) { __syncthreads(); const uint32_t nw = next_w; __syncthreads(); w = nw; continue; }
         const uint32_t tile = order[1 + slot];
         const int tx = (int)(tile % (uint32_t)g.tiles_x), ty = (int)(tile / (uint32_t)g.tiles_x);
@@ -623,7 +629,7 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
     // cut short) starts from a cleared array
     if (s->count_bins != g.n_bins || s->count_frames != n_frames) {
         if ((e = hipMemsetAsync(s->B.count, 0, words * 4, st)) != hipSuccess) return e;
-        if (s->B.band_top && (e = hipMemsetAsync(s->B.band_top, 0, ((size_t)s->band_frames + 1) * 4, st)) != hipSuccess) return e;
+        if (s->B.band_top && (e = hipMemsetAsync(s->B.band_top, 0, ((size_t)s->band_frames + RS_DISPENSERS) * 4, st)) != hipSuccess) return e;
         s->count_bins = g.n_bins; s->count_frames = n_frames;
     }
     // Bin entries per frame (16 bytes each): three per triangle cover meshes of small triangles (chessboard, dragon:
@@ -656,8 +662,8 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
     if (n_frames != s->band_frames || !s->B.band_top) {
         if (s->B.band_top) (void)hipFree(s->B.band_top);
         s->B.band_top = nullptr; s->band_frames = 0;
-        if ((e = hipMalloc((void **)&s->B.band_top, ((size_t)n_frames + 1) * 4)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(s->B.band_top, 0, ((size_t)n_frames + 1) * 4, st)) != hipSuccess) return e;
+        if ((e = hipMalloc((void **)&s->B.band_top, ((size_t)n_frames + RS_DISPENSERS) * 4)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(s->B.band_top, 0, ((size_t)n_frames + RS_DISPENSERS) * 4, st)) != hipSuccess) return e;
         s->band_frames = n_frames;
     }
     return hipSuccess;

@@ -35,6 +35,7 @@
 #define RS_TW 16              // tile width  (pixels)
 #define RS_TH 16              // tile height (pixels)
 #define RS_TPIX (RS_TW * RS_TH)
+#define RS_DISPENSERS 16      // counters the tile kernel's blocks draw further tiles from
 #define RS_CB 4               // a coarse bin covers RS_CB x RS_CB tiles
 #define RS_COARSE_MAX 64      // largest coarse box binned bin by bin; beyond: the global bin
 #define RS_REC4 7             // float4 per triangle record
@@ -94,7 +95,7 @@ struct RsBuffers {
     uint32_t bins_cap;             // per frame
     float4 *band;                  // [frames][band_cap][RS_BAND4]  edge walkers of a triangle at the first scanline of a tile row
     uint32_t band_cap;             // per frame
-    uint32_t *band_top;            // [frames + 1]           band records handed out (rs_setup; zeroed again by rs_tile); the last
+    uint32_t *band_top;            // [frames + RS_DISPENSERS]           band records handed out (rs_setup; zeroed again by rs_tile); the last
                                    //                        word: k_rs_tile's tile dispenser (zeroed by rs_setup)
     uint2 *band_owner;             // [frames][band_cap]     (triangle, band = scanline / RS_BH) of each band record
     uint32_t *order;               // [frames][n_tiles + 1]  [0] = number of tiles with bin entries, then those tiles, then the others (rs_fill)
