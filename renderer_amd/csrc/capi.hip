@@ -517,7 +517,9 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipSt
     if (!rs) rs = c->rscratch;
     // raytrace frames also reset the pixel dispenser behind the counters (same memset)
     const bool rt = mode == MI355_MODE_RAYTRACE || mode == MI355_MODE_RAYTRACE_ANTIALIAS;
-    HIP_TRY(hipMemsetAsync(ctrl, 0, rt ? MI_CTRL_BYTES : 16 + sizeof(unsigned long long) * CS_COUNT, st), -40);
+    // (a raster frame that does not count zeroes its control block in its first kernel: one launch less per frame, ~4.7 us)
+    const bool raster_self_clear = mode >= MI355_MODE_AMBIENT && mode <= MI355_MODE_PHONG_SOFTSHADOWMAPS && !stats && !P.cams;
+    if (!raster_self_clear) HIP_TRY(hipMemsetAsync(ctrl, 0, rt ? MI_CTRL_BYTES : 16 + sizeof(unsigned long long) * CS_COUNT, st), -40);
     if (stats)   // the two "min" time stamps start at all-ones
         HIP_TRY(hipMemsetAsync((char *)ctrl + 16 + sizeof(unsigned long long) * CS_TIME0, 0xff, 2 * sizeof(unsigned long long), st), -40);
     c->last_stats = stats != 0;

@@ -212,6 +212,10 @@ __global__ void __launch_bounds__(256) k_rs_setup(const DevScene S, const FrameP
     if (blockIdx.x == 0) {                                // rs_fill's cursors and rs_tile's dispenser start at zero
         for (uint32_t i = threadIdx.x; i < (uint32_t)g.n_bins; i += blockDim.x) B.cursor[(size_t)f * g.n_bins + i] = 0u;
         if (f == 0 && threadIdx.x < RS_DISPENSERS) B.band_top[gridDim.y + threadIdx.x] = 0u;
+        // the frame's control block (header + counters) starts at zero: nothing in this kernel touches it, the later kernels
+        // of the frame report overflows there.  (Counting frames are zeroed by the host before the launch: they count here.)
+        if (f == 0 && P.counters && !P.raster_stats && !batch)
+            for (uint32_t i = threadIdx.x; i < (16u + 8u * CS_COUNT) / 4u; i += blockDim.x) ((uint32_t *)((char *)P.counters - 16))[i] = 0u;
     }
     uint4 box = make_uint4(0xffffffffu, 0u, 0u, 0u);
     if (t < S.n_tris) box = rs_setup_thread<MODE>(S, F, B, f, t);
@@ -229,8 +233,7 @@ __global__ void __launch_bounds__(256) k_rs_setup(const DevScene S, const FrameP
     __syncthreads();                                      // (bp is reused)
     const uint32_t n_bands = block_pairs_begin(bp, box, rs_band_count(box));
     if (threadIdx.x == 0) {
-        band_base = n_bands ? atomicAdd(&B.band_top[f], n_bands) : 0u;
-        if (n_bands && band_base + n_bands > B.band_cap && P.counters) atomicAdd(&P.counters[CS_OVERFLOW], 1ull);
+        band_base = n_bands ? atomicAdd(&B.band_top[f], n_bands) : 0u;     // (more than band_cap: k_rs_fill reports it)
     }
     __syncthreads();
     if (box.x != 0xffffffffu) rs_set_band_base(B, S.n_tris, f, t, band_base + bp.pre[threadIdx.x]);
@@ -377,7 +380,10 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
         }
     }
     uint32_t n_rec = B.band_top[f];
-    if (n_rec > B.band_cap) n_rec = B.band_cap;
+    if (n_rec > B.band_cap) {
+        if (blockIdx.x == order_block && tid == 0 && counters) atomicAdd(&counters[CS_OVERFLOW], 1ull);
+        n_rec = B.band_cap;
+    }
     const uint32_t n_items = n_rec * 3u;
     uint32_t first_block = 0, n_blocks = gridDim.x;
     if (spare) { first_block = fill_blocks; n_blocks = gridDim.x - fill_blocks; }
