@@ -280,8 +280,11 @@ def main():
                 "frac": round(total_abytes / K / (kernel_ms * 1e-3) / 1e9 / max(world, 1) / HBM_PEAK_GBS, 5),
                 "traffic": None,
                 "frac_means": "reference-work rate: the REFERENCE algorithm's bytes (SURVEY 8d) over this kernel's time -- not HBM "
-                              "utilisation (the scene is cache resident) and saturated near 1; the bound that binds is `issue_bound`",
-                "kernel": "k_raytrace<STATS=false, EXACT_BOX=false, ORDERED=true, WAVES=2|3|4 by launch size, BATCH=frames>1> (ordered walk)",
+                              "utilisation (the scene is cache resident).  It can exceed 1: the ordered walk and the tile culling do not "
+                              "perform all of the reference's node pops and triangle tests, so the reference's work gets done faster "
+                              "than HBM could stream its bytes; the bound that binds is `issue_bound`",
+                "kernel": "k_raytrace<STATS=false, EXACT_BOX=false, ORDERED=true, WAVES=2|3|4 by launch size, BATCH=frames>1> (ordered walk), "
+                          "preceded by k_tile_select (tiles no camera ray can hit anything in are set to black, ~1 % of the launch)",
                 "kernel_ms": round(kernel_ms, 5),
                 "algorithmic_bytes_per_launch": round(total_abytes / K / max(world, 1), 1),
                 "frames_per_launch": B_local,
@@ -289,7 +292,8 @@ def main():
                         "achieved = SURVEY 8(d) algorithmic bytes per launch (the REFERENCE algorithm's node pops / "
                         "triangle tests / hits, counted by the reference-order kernel variant on the same frames) / "
                         "HIP-event time per launch on the launch stream (rank 0). The timed kernel walks the tree near "
-                        "child first with distance culling (identical pixels, fewer visits); the scene (~8 MB) is "
+                        "child first with distance culling and skips 8x8 tiles outside the projected boxes of the tree's top "
+                        "(identical pixels, fewer visits); the scene (~8 MB) is "
                         "L2/MALL resident so real HBM traffic is far lower -- see profiles/ and DESIGN.md 4.1",
             },
         }

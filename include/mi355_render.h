@@ -91,7 +91,9 @@ typedef struct {
      *            passed the checks of mi355_scene_set_bvh; counting frames always use the reference's
      *            order so that the counters below mean what they mean in the reference)
      *            | 8 (debug) counting frames profile the ordered walk: counters then describe that walk
-     *            | 16, 32 reserved
+     *            | 16 hand out every 8x8 tile of a raytraced frame (default: tiles whose camera rays cannot reach any of the
+     *            boxes at the top of the tree are not traced at all; they are black either way)
+     *            | 32 reserved
      * [6], [7] reserved */
     int32_t tune[8];
     /* Compile-time extras of the reference, off by default like there: */

@@ -20,6 +20,8 @@
 #include <vector>
 
 // kernel launchers (defined next to their kernels)
+extern "C" hipError_t mi355i_launch_tile_select(const FrameParams *P, const float4 *boxes, int n_boxes, const uint32_t *order, uint32_t *sel, uint32_t *cnt,
+                                                hipStream_t st);
 extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext);
 extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int ordered, int waves, int batch, int ext,
                                              int n_blocks, hipStream_t);
@@ -129,6 +131,8 @@ struct mi355_ctx {
     DevBuf bvh_prim, bvh_list[2], bvh_lvl[2], bvh_tree, bvh_cnt;   // mi355_build_bvh work buffers (kept for rebuilds)
     DevBuf bvh_big[2], bvh_task[2], bvh_gthr[2], bvh_gbin, bvh_tcnt, bvh_choff, bvh_num[5], bvh_out, bvh_in_td, bvh_in_te;
     bool bvh_inputs_ready = false;
+    DevBuf cull_boxes, tile_sel;     // boxes of the tree's top (tile culling of raytraced frames) and the culled tile lists of the frame in flight
+    int n_cull_boxes = 0;
     PinBuf pin_walk, pin_edge, pin_shade, pin_tree, pin_list, pin_ctl;   // host staging of the BVH streams and the builder
     DevBuf wave_prof;       // per-wave phase profile of counting launches (debug)
     int last_blocks = 0;
@@ -141,7 +145,7 @@ struct mi355_ctx {
     struct AsyncSlot {
         hipStream_t st = nullptr;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        DevBuf ctrl, fb, mlaa;
+        DevBuf ctrl, fb, mlaa, sel;
         PinBuf pin;
         RasterScratch *rs = nullptr;
         bool busy = false;
@@ -286,6 +290,8 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.chunk = t[2] > 0 ? t[2] : 64;
     P.ref_order = (flags & 4) ? 1 : 0;
     P.prof_ordered = (flags & 8) ? 1 : 0;
+    P.no_cull = (flags & 16) ? 1 : 0;
+    P.tile_sel = nullptr; P.tile_cnt = nullptr;
     P.blocks_per_cu = t[4] > 0 ? t[4] : 0;
     P.rs_threads = t[3];
     P.mlaa = o->mlaa ? 1 : 0;
@@ -309,6 +315,7 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
 
 // Thread the reference's flat BVH (pre-order CacheFriendlyBVHNode[], BVH.h:52-65) with hit/miss
 // links and build the leaf-ordered triangle streams.
+int upload_cull_boxes(mi355_ctx *c, const void *nodes32B, uint32_t nN);
 int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int32_t *triIdx, uint32_t nI)
 {
     struct RefNode { float bottom[3], top[3]; uint32_t a, b; };
@@ -507,12 +514,42 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
     }
     c->dev.n_nodes = nN;
     c->has_bvh = true;
+    return upload_cull_boxes(c, nodes32B, nN);
+}
+
+// The boxes raytraced frames are culled against (k_tile_select): start from the root and keep replacing the inner node of the
+// largest surface by its two children, up to MI_CULL_BOXES boxes.  Together they hold every triangle of a checked tree.
+int upload_cull_boxes(mi355_ctx *c, const void *nodes32B, uint32_t nN)
+{
+    struct RefNode { float bottom[3], top[3]; uint32_t a, b; };
+    const RefNode *rn = (const RefNode *)nodes32B;
+    c->n_cull_boxes = 0;
+    if (!c->dev.ordered_ok || nN == 0) return 0;          // (an unchecked tree's boxes need not bound its triangles)
+    std::vector<uint32_t> set{0u};
+    auto area = [&](uint32_t i) { const float x = rn[i].top[0] - rn[i].bottom[0], y = rn[i].top[1] - rn[i].bottom[1], z = rn[i].top[2] - rn[i].bottom[2]; return x * y + y * z + z * x; };
+    while (set.size() < (size_t)MI_CULL_BOXES) {
+        int best = -1;
+        for (size_t k = 0; k < set.size(); k++)
+            if (!(rn[set[k]].a & 0x80000000u) && (best < 0 || area(set[k]) > area(set[(size_t)best]))) best = (int)k;
+        if (best < 0) break;
+        const uint32_t n = set[(size_t)best];
+        set[(size_t)best] = rn[n].a; set.push_back(rn[n].b);
+    }
+    std::vector<float4> b(set.size() * 2);
+    for (size_t k = 0; k < set.size(); k++) {
+        const RefNode &n = rn[set[k]];
+        b[2 * k] = make_float4(n.bottom[0], n.bottom[1], n.bottom[2], 0.f);
+        b[2 * k + 1] = make_float4(n.top[0], n.top[1], n.top[2], 0.f);
+    }
+    HIP_TRY(c->cull_boxes.upload(b), -31);
+    c->n_cull_boxes = (int)set.size();
     return 0;
 }
 
-int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipStream_t st, void *ctrl = nullptr, RasterScratch *rs = nullptr,
-                  DevBuf *mlaa_scratch = nullptr, uint32_t *const *frame_outs = nullptr)
+int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hipStream_t st, void *ctrl = nullptr, RasterScratch *rs = nullptr,
+                  DevBuf *mlaa_scratch = nullptr, uint32_t *const *frame_outs = nullptr, DevBuf *sel = nullptr)
 {
+    FrameParams P = P_in;
     if (!ctrl) ctrl = c->ctrl.p;
     if (!rs) rs = c->rscratch;
     // raytrace frames also reset the pixel dispenser behind the counters (same memset)
@@ -557,6 +594,18 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P, int stats, hipSt
         if (n_blocks > lanes_needed) n_blocks = (int)(lanes_needed > 0 ? lanes_needed : 1);
         c->last_blocks = n_blocks;
         if (P.wave_prof) HIP_TRY(hipMemsetAsync(c->wave_prof.p, 0, (size_t)n_blocks * 4 * 16 * 8, st), -40);
+        // Tiles no camera ray can hit anything in are not handed out at all (they are most of the frame: a tile costs a
+        // dispenser round trip, 64 primary rays and a shading phase even when it is background).  Not for counting frames
+        // (they count the reference's rays), bands (tile rows are band rows there) and trees that failed the checks.
+        const long long n_tiles = (((long long)P.W + 7) / 8) * (((long long)P.n_rows + 7) / 8);
+        if (ordered && !stats && P.band_count <= 1 && c->n_cull_boxes > 0 && !P.no_cull && n_tiles <= MI_CULL_MAX_TILES) {
+            DevBuf *buf = sel ? sel : &c->tile_sel;
+            HIP_TRY(buf->ensure(512 + (size_t)P.n_frames * (size_t)n_tiles * 4), -31);
+            P.tile_cnt = (const uint32_t *)buf->p;
+            P.tile_sel = (const uint32_t *)((char *)buf->p + 512);
+            if ((e = mi355i_launch_tile_select(&P, (const float4 *)c->cull_boxes.p, c->n_cull_boxes, P.tile_order, (uint32_t *)((char *)buf->p + 512),
+                                               (uint32_t *)buf->p, st)) != hipSuccess) return fail(-43, "tile culling launch failed: %s", hipGetErrorString(e));
+        }
         e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, waves, batch, ext, n_blocks, st);
         break;
     }
@@ -694,14 +743,14 @@ void mi355_scene_destroy(mi355_ctx *c)
                       &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->mlaa, &c->cam_table, &c->wave_prof, &c->bvh_prim, &c->bvh_list[0], &c->bvh_list[1],
                       &c->bvh_lvl[0], &c->bvh_lvl[1], &c->bvh_tree, &c->bvh_cnt, &c->bvh_big[0], &c->bvh_big[1], &c->bvh_task[0], &c->bvh_task[1],
                       &c->bvh_gthr[0], &c->bvh_gthr[1], &c->bvh_gbin, &c->bvh_tcnt, &c->bvh_choff, &c->bvh_num[0], &c->bvh_num[1], &c->bvh_num[2],
-                      &c->bvh_num[3], &c->bvh_num[4], &c->bvh_out, &c->bvh_in_td, &c->bvh_in_te})
+                      &c->bvh_num[3], &c->bvh_num[4], &c->bvh_out, &c->bvh_in_td, &c->bvh_in_te, &c->cull_boxes, &c->tile_sel})
         b->release();
     for (PinBuf *b : {&c->pin_walk, &c->pin_edge, &c->pin_shade, &c->pin_tree, &c->pin_list, &c->pin_ctl}) b->release();
     for (auto &m : c->smap) m.release();
     for (auto &o : c->orders) o.buf.release();
     for (auto &a : c->slot) {
         if (a.st) (void)hipStreamSynchronize(a.st);
-        a.ctrl.release(); a.fb.release(); a.mlaa.release(); a.pin.release();
+        a.ctrl.release(); a.fb.release(); a.mlaa.release(); a.sel.release(); a.pin.release();
         if (a.rs) mi355i_raster_scratch_destroy(a.rs);
         if (a.ev0) (void)hipEventDestroy(a.ev0);
         if (a.ev1) (void)hipEventDestroy(a.ev1);
@@ -841,6 +890,7 @@ int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_
     c->dev.tri_base = 2u * ctl->n_inner;
     c->dev.n_nodes = n_out;
     c->has_bvh = true;
+    if (int r = upload_cull_boxes(c, nodes32B, n_out)) return r;
     g_bvh_levels = 0;
     g_bvh_ms[0] = t_setup - t_start; g_bvh_ms[1] = t_levels - t_setup; g_bvh_ms[2] = t_down - t_levels; g_bvh_ms[3] = clk() - t_down;
     return 0;
@@ -1216,7 +1266,7 @@ int mi355_render_async(mi355_ctx *c, int mode, const mi355_camera *cam, const mi
     FrameParams P;
     if (int r = fill_params(c, mode, cam, lights, n_lights, o, a->fb.p, W * 4, nullptr, P, a->ctrl.p)) return r;
     HIP_TRY(hipEventRecord(a->ev0, a->st), -40);
-    if (int r = enqueue_frame(c, mode, P, 0, a->st, a->ctrl.p, a->rs, &a->mlaa)) return r;
+    if (int r = enqueue_frame(c, mode, P, 0, a->st, a->ctrl.p, a->rs, &a->mlaa, nullptr, &a->sel)) return r;
     HIP_TRY(hipEventRecord(a->ev1, a->st), -40);
     a->staged = !host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4);
     if (a->staged) {
@@ -1248,7 +1298,7 @@ int mi355_render_wait(mi355_ctx *c, int ticket, mi355_stats *stats)
             if (!mi355i_raster_grow(a->rs)) break;
             FrameParams P;
             if (int r = fill_params(c, a->mode, &a->cam, a->lights, a->n_lights, &a->opts, a->fb.p, a->opts.width * 4, nullptr, P, a->ctrl.p)) return r;
-            if (int r = enqueue_frame(c, a->mode, P, 0, a->st, a->ctrl.p, a->rs, &a->mlaa)) return r;
+            if (int r = enqueue_frame(c, a->mode, P, 0, a->st, a->ctrl.p, a->rs, &a->mlaa, nullptr, &a->sel)) return r;
             HIP_TRY(hipStreamSynchronize(a->st), -40);
             HIP_TRY(hipMemcpy(h, (char *)a->ctrl.p + 16, sizeof h, hipMemcpyDeviceToHost), -31);
             if (!h[CS_OVERFLOW]) break;

@@ -36,6 +36,8 @@
 
 #define MI_MAX_LIGHTS 4
 #define MI_MAX_DEPTH 4
+#define MI_CULL_BOXES 128           // boxes of the tree's top the tiles of a frame are culled against
+#define MI_CULL_MAX_TILES (1 << 19) // frames with more 8x8 tiles are not culled (the tile mask lives in LDS)
 
 // Walk records, two float4 each (a link is the float4 index of a record plus the flag bits above, or
 // MI_END_LINK):
@@ -117,10 +119,15 @@ struct FrameParams {
     int32_t exact_box;         // always use the exact six-division box test
     int32_t ref_order;         // walk in the reference's fixed left-first order even when the ordered walk is available
     int32_t prof_ordered;      // counting frames profile the ordered walk instead of reproducing the reference's counters
+    int32_t no_cull;           // hand out every tile of the frame (tune flag 16)
     unsigned long long *wave_prof; // counting builds: 16 words of phase profile per wave (debug), or NULL
     const FrameCam *cams;      // batched launch: per-frame cameras / lights / outputs (device memory), else NULL
     int32_t n_frames;          // frames rendered by this launch (1 unless batched)
     const uint32_t *tile_order; // dispenser index -> 8x8 tile id (heavy tiles first), or NULL = row-major
+    // Raytrace frames whose tiles were culled against the scene's boxes (k_tile_select): frame f hands out
+    // tile_sel[f * n_tiles + i] for i < tile_cnt[f] (the tile order restricted to tiles a ray can hit something in; the other
+    // tiles are already black), else NULL.
+    const uint32_t *tile_sel, *tile_cnt;
     int32_t blocks_per_cu;     // 0 = occupancy query
     int32_t rs_threads;        // rasterizer: threads per tile block (0 = default)
     // the raytracer's compile-time extras (Raytracer.cc:70-80)

@@ -475,7 +475,13 @@ k_raytrace(const DevScene S, const FrameParams P)
     const int tiles_x = (P.W + 7) >> 3;
     const int tiles_y = (P.n_rows + 7) >> 3;
     const uint32_t n_tiles = (uint32_t)tiles_x * (uint32_t)tiles_y;
-    const uint32_t n_slots_all = BATCH ? n_tiles * (uint32_t)P.n_frames : n_tiles;     // (tile, frame) pairs to hand out
+    // tiles per frame the dispenser hands out: all, or (culled frames) the longest of the frames' lists
+    uint32_t n_tiles_out = n_tiles;
+    if (P.tile_cnt) {
+        n_tiles_out = 0u;
+        for (int f = 0; f < (BATCH ? P.n_frames : 1); f++) { const uint32_t k = P.tile_cnt[f]; n_tiles_out = k > n_tiles_out ? k : n_tiles_out; }
+    }
+    const uint32_t n_slots_all = BATCH ? n_tiles_out * (uint32_t)P.n_frames : n_tiles_out;     // (tile, frame) pairs to hand out
 
     for (;;) {
         // ---------------- refill: hand new pixels to idle lanes --------------------------
@@ -526,10 +532,15 @@ k_raytrace(const DevScene S, const FrameParams P)
                                 const uint32_t sub = idx & 63u;
                                 int fid = 0;
                                 if (BATCH) { fid = (int)(tslot % (uint32_t)P.n_frames); tslot /= (uint32_t)P.n_frames; }
-                                const uint32_t tile = P.tile_order ? P.tile_order[tslot] : tslot;
+                                uint32_t tile;
+                                bool have = true;
+                                if (P.tile_cnt) {
+                                    have = tslot < P.tile_cnt[fid];          // (a frame with a shorter list than the longest)
+                                    tile = have ? P.tile_sel[(size_t)fid * n_tiles + tslot] : 0u;
+                                } else tile = P.tile_order ? P.tile_order[tslot] : tslot;
                                 const int tx = (int)(tile % (uint32_t)tiles_x), ty = (int)(tile / (uint32_t)tiles_x);
                                 const int x = (tx << 3) + (int)(sub & 7u), r = (ty << 3) + (int)(sub >> 3);
-                                if (x < P.W && r < P.n_rows) {   // ragged right / bottom edge
+                                if (have && x < P.W && r < P.n_rows) {   // ragged right / bottom edge
                                     L.px = x; L.fid = fid;
                                     L.py = band_row_to_y(r, P.band_rows, P.band_index, P.band_count);
                                     L.orow = P.compact ? r : L.py;
@@ -1071,6 +1082,141 @@ k_raytrace(const DevScene S, const FrameParams P)
         }
     }
 #undef MI_PHASE
+}
+
+// ---- tile culling ---------------------------------------------------------------------------------------------
+// A camera ray hits a triangle only if it passes through every box above the triangle, in particular through one of the
+// <= MI_CULL_BOXES boxes of the tree's top that capi.hip picked (together they hold every triangle).  The pixels whose rays
+// can pass through a box lie in the bounding rectangle of the box's eight projected corners (pinhole camera,
+// Raytracer.cc:563-593: pixel (x, y) looks through the camera-space point ((H/2 - y)/SD, (x - W/2)/SD, 1)), widened by two
+// pixels against rounding and the quarter-pixel offsets of the antialiased mode; a box with a corner at or behind the
+// camera plane counts as covering the screen.  Per frame: mark the 8x8-pixel tiles the rectangles touch (bit mask in LDS),
+// write the tile order restricted to marked tiles to sel[] and its length to cnt[] -- that is what k_raytrace hands out
+// -- and set the pixels of the other tiles to the reference's result for a ray that hits nothing: black.
+namespace {
+__global__ void __launch_bounds__(1024)
+k_tile_select(const FrameParams P, const float4 *boxes, int n_boxes, const uint32_t *order, uint32_t *sel, uint32_t *cnt)
+{
+    extern __shared__ uint32_t mask[];               // one bit per tile
+    __shared__ int s_rect[MI_CULL_BOXES][4];
+    __shared__ uint32_t s_wave[16];
+    const int f = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tiles_x = (P.W + 7) >> 3, tiles_y = (P.n_rows + 7) >> 3;
+    const uint32_t n_tiles = (uint32_t)tiles_x * (uint32_t)tiles_y, n_words = (n_tiles + 31u) >> 5;
+    const bool batch = P.cams != nullptr;
+    for (uint32_t i = (uint32_t)tid; i < n_words; i += 1024u) mask[i] = 0u;
+    if (tid < n_boxes) {
+        const f3 eye = batch ? cam_eye<true>(P, f) : cam_eye<false>(P, f);
+        const f3 r1 = batch ? cam_row<true>(P, f, 0) : cam_row<false>(P, f, 0), r2 = batch ? cam_row<true>(P, f, 1) : cam_row<false>(P, f, 1),
+                 r3 = batch ? cam_row<true>(P, f, 2) : cam_row<false>(P, f, 2);
+        const float4 lo = boxes[2 * tid], hi = boxes[2 * tid + 1];
+        float x0 = FLT_MAX, x1 = -FLT_MAX, y0 = FLT_MAX, y1 = -FLT_MAX;
+        bool whole = false;
+        for (int k = 0; k < 8; k++) {
+            const f3 p = sub3(mk3((k & 1) ? hi.x : lo.x, (k & 2) ? hi.y : lo.y, (k & 4) ? hi.z : lo.z), eye);
+            const float cx = dot3(r1, p), cy = dot3(r2, p), cz = dot3(r3, p);
+            if (!(cz > 1e-3f * len3(p))) { whole = true; continue; }        // at / behind the camera plane (or not a number)
+            const float sx = (float)(P.W / 2) + (float)P.SD * cy / cz, sy = (float)(P.H / 2) - (float)P.SD * cx / cz;
+            if (!(__builtin_fabsf(sx) < 1e9f) || !(__builtin_fabsf(sy) < 1e9f)) { whole = true; continue; }
+            x0 = sx < x0 ? sx : x0; x1 = sx > x1 ? sx : x1; y0 = sy < y0 ? sy : y0; y1 = sy > y1 ? sy : y1;
+        }
+        int tx0 = 0, ty0 = 0, tx1 = tiles_x - 1, ty1 = tiles_y - 1;
+        if (!whole) {
+            const float fx0 = __builtin_floorf(x0) - 2.f, fx1 = __builtin_ceilf(x1) + 2.f, fy0 = __builtin_floorf(y0) - 2.f, fy1 = __builtin_ceilf(y1) + 2.f;
+            if (fx1 < 0.f || fy1 < 0.f || fx0 > (float)(P.W - 1) || fy0 > (float)(P.n_rows - 1)) { tx0 = 1; tx1 = 0; }      // off screen
+            else {
+                tx0 = (int)(fx0 < 0.f ? 0.f : fx0) >> 3; ty0 = (int)(fy0 < 0.f ? 0.f : fy0) >> 3;
+                tx1 = (int)(fx1 > (float)(P.W - 1) ? (float)(P.W - 1) : fx1) >> 3; ty1 = (int)(fy1 > (float)(P.n_rows - 1) ? (float)(P.n_rows - 1) : fy1) >> 3;
+            }
+        }
+        s_rect[tid][0] = tx0; s_rect[tid][1] = ty0; s_rect[tid][2] = tx1; s_rect[tid][3] = ty1;
+    }
+    __syncthreads();
+    // mark: eight threads per box, a tile row of its rectangle each
+    {
+        const int b = tid >> 3;
+        int tx0 = 1, ty0 = 0, tx1 = 0, ty1 = -1;
+        if (b < n_boxes) { tx0 = s_rect[b][0]; ty0 = s_rect[b][1]; tx1 = s_rect[b][2]; ty1 = s_rect[b][3]; }
+        if (tx0 > tx1) ty1 = ty0 - 1;
+        for (int ty = ty0 + (tid & 7); ty <= ty1; ty += 8) {
+            const uint32_t a = (uint32_t)ty * (uint32_t)tiles_x + (uint32_t)tx0, e = (uint32_t)ty * (uint32_t)tiles_x + (uint32_t)tx1;
+            for (uint32_t w = a >> 5; w <= e >> 5; w++) {
+                const uint32_t lo_bit = w == (a >> 5) ? (a & 31u) : 0u, hi_bit = w == (e >> 5) ? (e & 31u) : 31u;
+                atomicOr(&mask[w], (0xffffffffu >> (31u - hi_bit)) & (0xffffffffu << lo_bit));
+            }
+        }
+    }
+    __syncthreads();
+    if (blockIdx.y == 0) {
+        // the tile order restricted to marked tiles, order kept.  In pieces of 32768 entries: a wave owns 2048 contiguous
+        // entries of the piece, loads them at once (32 independent loads per lane: one memory latency, not 32), counts its
+        // marked tiles, and writes them behind those of the waves before it.
+        uint32_t done = 0;
+        for (uint32_t p0 = 0; p0 < n_tiles; p0 += 32768u) {
+            const uint32_t i_begin = p0 + (uint32_t)wid * 2048u;
+            uint32_t tl[32];
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                const uint32_t i = i_begin + (uint32_t)j * 64u + (uint32_t)lane;
+                tl[j] = i < n_tiles ? (order ? order[i] : i) : 0xffffffffu;
+            }
+            unsigned long long m[32];
+            uint32_t mine = 0;
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                const uint32_t t = tl[j];
+                m[j] = __ballot(t != 0xffffffffu && ((mask[t >> 5] >> (t & 31u)) & 1u));
+                mine += (uint32_t)__popcll(m[j]);
+            }
+            __syncthreads();                                  // (s_wave of the piece before has been read)
+            if (lane == 0) s_wave[wid] = mine;
+            __syncthreads();
+            uint32_t at = done, all = 0;
+            for (int w = 0; w < 16; w++) { if (w < wid) at += s_wave[w]; all += s_wave[w]; }
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                if ((m[j] >> lane) & 1ull) sel[(size_t)f * n_tiles + at + (uint32_t)__popcll(m[j] & ((1ull << lane) - 1ull))] = tl[j];
+                at += (uint32_t)__popcll(m[j]);
+            }
+            done += all;
+        }
+        if (tid == 0) cnt[f] = done;
+        // the camera rays of the other tiles are accounted for: the reference traces one per pixel sample (Raytracer.cc:570-597)
+        unsigned long long px = 0;
+        for (uint32_t t = (uint32_t)tid; t < n_tiles; t += 1024u) {
+            if ((mask[t >> 5] >> (t & 31u)) & 1u) continue;
+            const int w = P.W - (int)(t % (uint32_t)tiles_x) * 8, h = P.n_rows - (int)(t / (uint32_t)tiles_x) * 8;
+            px += (unsigned long long)((w < 8 ? w : 8) * (h < 8 ? h : 8));
+        }
+        for (int off = 32; off > 0; off >>= 1) px += __shfl_xor(px, off);
+        if (lane == 0 && px && P.counters) atomicAdd(&P.counters[CS_NORMAL_RAYS], px * (P.aa ? 4ull : 1ull));
+    }
+    // the other tiles are black: a wave per pixel row, four pixels per lane and step (whole cache lines per wave)
+    uint32_t *const out = batch ? P.cams[f].out : P.out;
+    float *const outf = batch ? P.cams[f].outf : P.outf;
+    const bool vec = (P.pitch_words & 3) == 0 && (((size_t)out) & 15u) == 0;
+    for (int r = (int)(blockIdx.y * 16u) + wid; r < P.n_rows; r += (int)(gridDim.y * 16u)) {
+        const uint32_t trow = (uint32_t)(r >> 3) * (uint32_t)tiles_x;
+        uint32_t *const orow = out + (size_t)r * P.pitch_words;
+        for (int x = lane * 4; x < P.W; x += 256) {
+            const uint32_t t = trow + (uint32_t)(x >> 3);             // (four pixels from a multiple of four: one tile)
+            if ((mask[t >> 5] >> (t & 31u)) & 1u) continue;
+            if (vec && x + 3 < P.W) *(uint4 *)(orow + x) = make_uint4(0u, 0u, 0u, 0u);
+            else for (int k = 0; k < 4 && x + k < P.W; k++) orow[x + k] = 0u;
+            if (outf) {
+                float *q = outf + ((size_t)r * P.W + x) * 3;
+                for (int k = 0; k < 12 && x + k / 3 < P.W; k++) q[k] = 0.f;
+            }
+        }
+    }
+}
+} // namespace
+extern "C" hipError_t mi355i_launch_tile_select(const FrameParams *P, const float4 *boxes, int n_boxes, const uint32_t *order, uint32_t *sel, uint32_t *cnt,
+                                                hipStream_t st)
+{
+    const uint32_t n_tiles = (uint32_t)((P->W + 7) >> 3) * (uint32_t)((P->n_rows + 7) >> 3);
+    hipLaunchKernelGGL(k_tile_select, dim3((unsigned)P->n_frames, P->n_frames >= 8 ? 32 : 64), dim3(1024), ((n_tiles + 31u) >> 5) * 4u, st, *P, boxes, n_boxes, order, sel, cnt);
+    return hipGetLastError();
 }
 
 // ---- test probe: the ordered walk's box bounds for (ray, box) pairs, exactly as a lane computes them -----------
