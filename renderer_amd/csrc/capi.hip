@@ -596,9 +596,9 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
         if (P.wave_prof) HIP_TRY(hipMemsetAsync(c->wave_prof.p, 0, (size_t)n_blocks * 4 * 16 * 8, st), -40);
         // Tiles no camera ray can hit anything in are not handed out at all (they are most of the frame: a tile costs a
         // dispenser round trip, 64 primary rays and a shading phase even when it is background).  Not for counting frames
-        // (they count the reference's rays), bands (tile rows are band rows there) and trees that failed the checks.
+        // (they count the reference's rays), bands that cut through tile rows, and trees that failed the checks.
         const long long n_tiles = (((long long)P.W + 7) / 8) * (((long long)P.n_rows + 7) / 8);
-        if (ordered && !stats && P.band_count <= 1 && c->n_cull_boxes > 0 && !P.no_cull && n_tiles <= MI_CULL_MAX_TILES) {
+        if (ordered && !stats && (P.band_count <= 1 || (P.band_rows > 0 && P.band_rows % 8 == 0)) && c->n_cull_boxes > 0 && !P.no_cull && n_tiles <= MI_CULL_MAX_TILES) {
             DevBuf *buf = sel ? sel : &c->tile_sel;
             HIP_TRY(buf->ensure(512 + (size_t)P.n_frames * (size_t)n_tiles * 4), -31);
             P.tile_cnt = (const uint32_t *)buf->p;

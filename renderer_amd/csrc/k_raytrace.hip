@@ -1120,13 +1120,14 @@ k_tile_select(const FrameParams P, const float4 *boxes, int n_boxes, const uint3
             if (!(__builtin_fabsf(sx) < 1e9f) || !(__builtin_fabsf(sy) < 1e9f)) { whole = true; continue; }
             x0 = sx < x0 ? sx : x0; x1 = sx > x1 ? sx : x1; y0 = sy < y0 ? sy : y0; y1 = sy > y1 ? sy : y1;
         }
-        int tx0 = 0, ty0 = 0, tx1 = tiles_x - 1, ty1 = tiles_y - 1;
+        // (rows of the rectangle are SCREEN tile rows; with band sharding the mask is over the rank's own, compact rows)
+        int tx0 = 0, ty0 = 0, tx1 = tiles_x - 1, ty1 = (P.H - 1) >> 3;
         if (!whole) {
             const float fx0 = __builtin_floorf(x0) - 2.f, fx1 = __builtin_ceilf(x1) + 2.f, fy0 = __builtin_floorf(y0) - 2.f, fy1 = __builtin_ceilf(y1) + 2.f;
-            if (fx1 < 0.f || fy1 < 0.f || fx0 > (float)(P.W - 1) || fy0 > (float)(P.n_rows - 1)) { tx0 = 1; tx1 = 0; }      // off screen
+            if (fx1 < 0.f || fy1 < 0.f || fx0 > (float)(P.W - 1) || fy0 > (float)(P.H - 1)) { tx0 = 1; tx1 = 0; }      // off screen
             else {
                 tx0 = (int)(fx0 < 0.f ? 0.f : fx0) >> 3; ty0 = (int)(fy0 < 0.f ? 0.f : fy0) >> 3;
-                tx1 = (int)(fx1 > (float)(P.W - 1) ? (float)(P.W - 1) : fx1) >> 3; ty1 = (int)(fy1 > (float)(P.n_rows - 1) ? (float)(P.n_rows - 1) : fy1) >> 3;
+                tx1 = (int)(fx1 > (float)(P.W - 1) ? (float)(P.W - 1) : fx1) >> 3; ty1 = (int)(fy1 > (float)(P.H - 1) ? (float)(P.H - 1) : fy1) >> 3;
             }
         }
         s_rect[tid][0] = tx0; s_rect[tid][1] = ty0; s_rect[tid][2] = tx1; s_rect[tid][3] = ty1;
@@ -1138,7 +1139,14 @@ k_tile_select(const FrameParams P, const float4 *boxes, int n_boxes, const uint3
         int tx0 = 1, ty0 = 0, tx1 = 0, ty1 = -1;
         if (b < n_boxes) { tx0 = s_rect[b][0]; ty0 = s_rect[b][1]; tx1 = s_rect[b][2]; ty1 = s_rect[b][3]; }
         if (tx0 > tx1) ty1 = ty0 - 1;
-        for (int ty = ty0 + (tid & 7); ty <= ty1; ty += 8) {
+        for (int sty = ty0 + (tid & 7); sty <= ty1; sty += 8) {
+            int ty = sty;
+            if (P.band_count > 1) {           // (band_rows is a multiple of 8 here: a tile row lies in one band)
+                const int band = (sty * 8) / P.band_rows;
+                if (band % P.band_count != P.band_index) continue;
+                ty = ((band / P.band_count) * P.band_rows + (sty * 8 - band * P.band_rows)) >> 3;
+            }
+            if (ty >= tiles_y) continue;
             const uint32_t a = (uint32_t)ty * (uint32_t)tiles_x + (uint32_t)tx0, e = (uint32_t)ty * (uint32_t)tiles_x + (uint32_t)tx1;
             for (uint32_t w = a >> 5; w <= e >> 5; w++) {
                 const uint32_t lo_bit = w == (a >> 5) ? (a & 31u) : 0u, hi_bit = w == (e >> 5) ? (e & 31u) : 31u;
@@ -1197,14 +1205,15 @@ k_tile_select(const FrameParams P, const float4 *boxes, int n_boxes, const uint3
     const bool vec = (P.pitch_words & 3) == 0 && (((size_t)out) & 15u) == 0;
     for (int r = (int)(blockIdx.y * 16u) + wid; r < P.n_rows; r += (int)(gridDim.y * 16u)) {
         const uint32_t trow = (uint32_t)(r >> 3) * (uint32_t)tiles_x;
-        uint32_t *const orow = out + (size_t)r * P.pitch_words;
+        const int out_r = P.compact ? r : band_row_to_y(r, P.band_rows, P.band_index, P.band_count);
+        uint32_t *const orow = out + (size_t)out_r * P.pitch_words;
         for (int x = lane * 4; x < P.W; x += 256) {
             const uint32_t t = trow + (uint32_t)(x >> 3);             // (four pixels from a multiple of four: one tile)
             if ((mask[t >> 5] >> (t & 31u)) & 1u) continue;
             if (vec && x + 3 < P.W) *(uint4 *)(orow + x) = make_uint4(0u, 0u, 0u, 0u);
             else for (int k = 0; k < 4 && x + k < P.W; k++) orow[x + k] = 0u;
             if (outf) {
-                float *q = outf + ((size_t)r * P.W + x) * 3;
+                float *q = outf + ((size_t)out_r * P.W + x) * 3;
                 for (int k = 0; k < 12 && x + k / 3 < P.W; k++) q[k] = 0.f;
             }
         }

@@ -93,3 +93,21 @@ def test_culled_batches_and_stale_buffers(scenes):
     for j, k in enumerate(ks):
         ref = s.render(9, cams[j], ls[j], 1, R.default_opts(W, H, tune=R.tune(nocull=1)))[0]
         assert np.array_equal(got[j], ref), "frame %d of the batch" % k
+
+
+@pytest.mark.parametrize("compact", [0, 1])
+@pytest.mark.parametrize("band_rows,count", [(8, 2), (8, 3), (16, 4), (24, 5), (8, 8)])
+def test_culled_bands_equal_unculled_bands(scenes, band_rows, count, compact):
+    """band sharding (the multi-GPU layout): the tile mask is over the rank's own rows"""
+    s = scenes("dragon_vis.ply")
+    W, H = 640, 360
+    cam, lights, n = R.benchmark_frame(25)
+    whole = s.render(9, cam, lights, n, R.default_opts(W, H, tune=R.tune(nocull=1)))[0]
+    for b in range(count):
+        kw = dict(band_rows=band_rows, band_index=b, band_count=count, compact_rows=compact)
+        a = s.render(9, cam, lights, n, R.default_opts(W, H, **kw), want_f32=True)
+        rows = [y for y in range(H) if (y // band_rows) % count == b]
+        got = a[0] if compact else a[0][rows]
+        assert np.array_equal(got, whole[rows]), "band %d of %d" % (b, count)
+        c = s.render(9, cam, lights, n, R.default_opts(W, H, tune=R.tune(nocull=1), **kw), want_f32=True)
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1].view(np.uint32), c[1].view(np.uint32))
