@@ -37,6 +37,8 @@ extern "C" hipError_t mi355i_launch_shadowmap(const DevScene *, const float *lig
 extern "C" RasterScratch *mi355i_raster_scratch_create(void);
 extern "C" void mi355i_raster_scratch_destroy(RasterScratch *);
 extern "C" uint32_t mi355i_raster_overflow(RasterScratch *);
+extern "C" hipError_t mi355i_launch_raster_pipelined(const DevScene *S, const FrameParams *P, int mode, RasterScratch *s, hipStream_t st,
+                                                     hipStream_t pre, hipEvent_t fill_done, hipEvent_t tile_done);
 extern "C" int mi355i_raster_grow(RasterScratch *);
 
 namespace {
@@ -131,6 +133,13 @@ struct mi355_ctx {
     DevBuf bvh_prim, bvh_list[2], bvh_lvl[2], bvh_tree, bvh_cnt;   // mi355_build_bvh work buffers (kept for rebuilds)
     DevBuf bvh_big[2], bvh_task[2], bvh_gthr[2], bvh_gbin, bvh_tcnt, bvh_choff, bvh_num[5], bvh_out, bvh_in_td, bvh_in_te;
     bool bvh_inputs_ready = false;
+    // raster frames of the device entry points are pipelined: two scratch sets take turns, setup + fill of a frame run on
+    // `pre` beside the tile kernel of the frame before (enqueue_frame)
+    RasterScratch *rs_pipe[2] = {nullptr, nullptr};
+    hipStream_t pre = nullptr;
+    hipEvent_t ev_fill[2] = {nullptr, nullptr}, ev_tile[2] = {nullptr, nullptr};
+    bool ev_tile_set[2] = {false, false};
+    int pipe_turn = 0;
     DevBuf cull_boxes, tile_sel;     // boxes of the tree's top (tile culling of raytraced frames) and the culled tile lists of the frame in flight
     int n_cull_boxes = 0;
     PinBuf pin_walk, pin_edge, pin_shade, pin_tree, pin_list, pin_ctl;   // host staging of the BVH streams and the builder
@@ -291,6 +300,7 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.ref_order = (flags & 4) ? 1 : 0;
     P.prof_ordered = (flags & 8) ? 1 : 0;
     P.no_cull = (flags & 16) ? 1 : 0;
+    P.no_pipe = (flags & 32) ? 1 : 0;
     P.tile_sel = nullptr; P.tile_cnt = nullptr;
     P.blocks_per_cu = t[4] > 0 ? t[4] : 0;
     P.rs_threads = t[3];
@@ -566,6 +576,18 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
     case MI355_MODE_POINTS_FROM_TRIANGLES: e = mi355i_launch_points(&c->dev, &P, 1, st); break;
     case MI355_MODE_AMBIENT: case MI355_MODE_GOURAUD: case MI355_MODE_PHONG:
     case MI355_MODE_PHONG_SHADOWMAPS: case MI355_MODE_PHONG_SOFTSHADOWMAPS:
+        if (raster_self_clear && rs == c->rscratch && c->pre && !P.no_pipe) {
+            // pipelined: this frame's setup + fill on `pre` while `st` still runs the previous frame's tile kernel; the events
+            // ride on the kernels' own completion signals (no marker packets between the tile kernels of `st`)
+            const int k = c->pipe_turn; c->pipe_turn ^= 1;
+            if (c->ev_tile_set[k]) HIP_TRY(hipStreamWaitEvent(c->pre, c->ev_tile[k], 0), -40);     // the set's last user is done
+            e = mi355i_launch_raster_pipelined(&c->dev, &P, mode, c->rs_pipe[k], st, c->pre, c->ev_fill[k], c->ev_tile[k]);
+            if (e == hipSuccess) c->ev_tile_set[k] = true;
+            break;
+        }
+        // (a frame outside the pipeline -- counting frames -- first lets the pipelined frames on other streams finish with
+        //  the scratch it is about to use)
+        if (rs == c->rscratch) for (int k = 0; k < 2; k++) if (c->ev_tile_set[k]) HIP_TRY(hipStreamWaitEvent(st, c->ev_tile[k], 0), -40);
         e = mi355i_launch_raster(&c->dev, &P, mode, rs, st);
         break;
     case MI355_MODE_RAYTRACE: case MI355_MODE_RAYTRACE_ANTIALIAS: {
@@ -726,6 +748,16 @@ mi355_ctx *mi355_scene_create(const mi355_scene_desc *d, int device)
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     c->rscratch = mi355i_raster_scratch_create();
+    // the raster pipeline of the device entry points: the context's scratch set and a second one, a stream for the
+    // setup / fill kernels, events ordering the two streams (if any of this fails the frames simply are not pipelined)
+    c->rs_pipe[0] = c->rscratch; c->rs_pipe[1] = mi355i_raster_scratch_create();
+    if (c->rs_pipe[1] && hipStreamCreateWithFlags(&c->pre, hipStreamNonBlocking) == hipSuccess) {
+        bool ok = true;
+        for (int k = 0; k < 2; k++)
+            ok = ok && hipEventCreateWithFlags(&c->ev_fill[k], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&c->ev_tile[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { (void)hipStreamDestroy(c->pre); c->pre = nullptr; }
+    } else c->pre = nullptr;
     c->dev.rs_tri = (const float4 *)c->rs_tri.p;
     c->dev.rs_col = (const float4 *)c->rs_col.p;
     c->dev.rs_idx = (const uint4 *)c->rs_idx.p;
@@ -758,6 +790,9 @@ void mi355_scene_destroy(mi355_ctx *c)
     }
     for (auto &h : c->host_reg) if (h.p) (void)hipHostUnregister(h.p);
     if (c->rscratch) mi355i_raster_scratch_destroy(c->rscratch);
+    if (c->rs_pipe[1]) mi355i_raster_scratch_destroy(c->rs_pipe[1]);
+    for (int k = 0; k < 2; k++) { if (c->ev_fill[k]) (void)hipEventDestroy(c->ev_fill[k]); if (c->ev_tile[k]) (void)hipEventDestroy(c->ev_tile[k]); }
+    if (c->pre) (void)hipStreamDestroy(c->pre);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -962,6 +997,7 @@ int mi355_render_batch_device(mi355_ctx *c, int mode, int n_frames, const mi355_
         std::vector<FrameParams> frames((size_t)n_frames);
         for (int f = 0; f < n_frames; f++)
             if (int r = fill_params(c, mode, &cams[f], lights + (size_t)f * n_lights, n_lights, o, d_out[f], pitch_bytes, nullptr, frames[f])) return r;
+        for (int k = 0; k < 2; k++) if (c->ev_tile_set[k]) HIP_TRY(hipStreamWaitEvent(user, c->ev_tile[k], 0), -40);   // (pipelined single frames still using the scratch)
         hipError_t e = mi355i_launch_raster_batch(&c->dev, frames.data(), n_frames, mode, c->rscratch, user);
         if (e != hipSuccess) return fail(-43, "kernel launch failed: %s", hipGetErrorString(e));
         if (frames[0].mlaa) {
@@ -1032,7 +1068,9 @@ int mi355_fetch_stats(mi355_ctx *c, mi355_stats *s)
     s->tris_drawn = h[CS_TRIS_DRAWN]; s->spans = h[CS_SPANS]; s->ztests = h[CS_ZTESTS]; s->plots = h[CS_PLOTS];
     if (h[CS_OVERFLOW]) {
         // the frame is incomplete; the next one gets span buffers twice as large (mi355_render retries by itself)
-        const int grown = mi355i_raster_grow(c->rscratch);
+        HIP_TRY(hipMemset((char *)c->ctrl.p + 16 + sizeof(unsigned long long) * CS_OVERFLOW, 0, sizeof(unsigned long long)), -31);
+        int grown = mi355i_raster_grow(c->rscratch);
+        for (int k = 0; k < 2; k++) if (c->rs_pipe[k] && c->rs_pipe[k] != c->rscratch) grown |= mi355i_raster_grow(c->rs_pipe[k]);
         return fail(-44, "rasterizer triangle bins overflowed (%llu entries dropped)%s", h[CS_OVERFLOW],
                     grown ? "; the buffers grow for the next frame" : "");
     }
@@ -1296,6 +1334,7 @@ int mi355_render_wait(mi355_ctx *c, int ticket, mi355_stats *stats)
         // the rasterizer's bins were too small for this frame: this slot's grow, and the frame is drawn again (synchronously)
         for (int attempt = 0; attempt < 8; attempt++) {
             if (!mi355i_raster_grow(a->rs)) break;
+            HIP_TRY(hipMemset((char *)a->ctrl.p + 16 + sizeof(unsigned long long) * CS_OVERFLOW, 0, sizeof(unsigned long long)), -31);
             FrameParams P;
             if (int r = fill_params(c, a->mode, &a->cam, a->lights, a->n_lights, &a->opts, a->fb.p, a->opts.width * 4, nullptr, P, a->ctrl.p)) return r;
             if (int r = enqueue_frame(c, a->mode, P, 0, a->st, a->ctrl.p, a->rs, &a->mlaa, nullptr, &a->sel)) return r;

@@ -120,6 +120,7 @@ struct FrameParams {
     int32_t ref_order;         // walk in the reference's fixed left-first order even when the ordered walk is available
     int32_t prof_ordered;      // counting frames profile the ordered walk instead of reproducing the reference's counters
     int32_t no_cull;           // hand out every tile of the frame (tune flag 16)
+    int32_t no_pipe;           // raster frames: setup, fill and tile kernels on the caller's stream (tune flag 32)
     unsigned long long *wave_prof; // counting builds: 16 words of phase profile per wave (debug), or NULL
     const FrameCam *cams;      // batched launch: per-frame cameras / lights / outputs (device memory), else NULL
     int32_t n_frames;          // frames rendered by this launch (1 unless batched)

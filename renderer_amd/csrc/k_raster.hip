@@ -8,6 +8,7 @@
 // independent): one lane per triangle walks its edges, one lane per row its span, 32-bit atomicMax on an
 // order-preserving float key.
 #include "rs_core.h"
+#include <hip/hip_ext.h>
 #include <cstring>
 
 struct RowRec {            // shadow map: one span row (40 B)
@@ -214,8 +215,11 @@ __global__ void __launch_bounds__(256) k_rs_setup(const DevScene S, const FrameP
         if (f == 0 && threadIdx.x < RS_DISPENSERS) B.band_top[gridDim.y + threadIdx.x] = 0u;
         // the frame's control block (header + counters) starts at zero: nothing in this kernel touches it, the later kernels
         // of the frame report overflows there.  (Counting frames are zeroed by the host before the launch: they count here.)
+        // (not the overflow counter: the frame before may have reported into it and the host not yet looked -- mi355_fetch_stats
+        //  resets it when it reports it)
         if (f == 0 && P.counters && !P.raster_stats && !batch)
-            for (uint32_t i = threadIdx.x; i < (16u + 8u * CS_COUNT) / 4u; i += blockDim.x) ((uint32_t *)((char *)P.counters - 16))[i] = 0u;
+            for (uint32_t i = threadIdx.x; i < (16u + 8u * CS_COUNT) / 4u; i += blockDim.x)
+                if (i != 4u + 2u * CS_OVERFLOW && i != 5u + 2u * CS_OVERFLOW) ((uint32_t *)((char *)P.counters - 16))[i] = 0u;
     }
     uint4 box = make_uint4(0xffffffffu, 0u, 0u, 0u);
     if (t < S.n_tris) box = rs_setup_thread<MODE>(S, F, B, f, t);
@@ -334,7 +338,7 @@ MI_DEV uint32_t block_scan_counts(const RsGrid &g, const RsBuffers &B, uint32_t 
 // and the background; the last of them also stores the offsets and the tile order for k_rs_tile.
 template <bool LDS_SCAN>
 __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers B, uint32_t n_tris, const FrameParams P, const FrameParams *batch,
-                                                 unsigned long long *counters)
+                                                 unsigned long long *counters, const int clear)
 {
     const FrameParams &F = batch ? batch[blockIdx.y] : P;
     const int height = F.H;
@@ -388,7 +392,7 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
     uint32_t first_block = 0, n_blocks = gridDim.x;
     if (spare) { first_block = fill_blocks; n_blocks = gridDim.x - fill_blocks; }
     if (blockIdx.x < first_block) return;
-    {   // this block's share of the background (Screen::ClearScreen): the tile kernel only visits tiles that hold triangles
+    if (clear) {   // this block's share of the background (Screen::ClearScreen): the tile kernel only visits tiles that hold triangles
         const unsigned long long total = (unsigned long long)F.out_rows * (unsigned long long)F.W;
         const unsigned long long per = ((total + n_blocks - 1) / n_blocks + 3ull) & ~3ull;
         rs_clear_out(F, per * (blockIdx.x - first_block), per, tid, (int)blockDim.x);
@@ -404,7 +408,7 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
 
 template <int MODE>
 __global__ void __launch_bounds__(RS_MAX_THREADS) k_rs_tile(const DevScene S, const FrameParams P, const FrameParams *batch, int n_frames,
-                                                        const RsGrid g, const RsBuffers B)
+                                                        const RsGrid g, const RsBuffers B, const int clear_rows)
 {
     __shared__ RsTileLds lds;
     const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
@@ -477,7 +481,7 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) k_rs_tile(const DevScene S, co
             __syncthreads();
             RS_PROF_MARK(5);
             rs_tile_shade<MODE>(S, F, tx, ty, lds, tid, nt, plots);
-        }
+        } else if (clear_rows) rs_tile_blank(F, tx, ty, tid, nt);     // (nobody else clears a tile whose bin holds entries)
         const uint32_t nw = next_w;                           // (written by thread 0 at the top of this tile, barriers ago)
         __syncthreads();                                      // (the next tile clears the keys and draws the next item)
         w = nw;
@@ -487,6 +491,32 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) k_rs_tile(const DevScene S, co
             acc[7] += dt; acc[8]++;
             const unsigned long long packed = (dt << 32) | ((unsigned long long)(total > 0xffffu ? 0xffffu : total) << 16) | (unsigned long long)(lds.n_runs & 0xffffu);
             if (packed > acc[9]) acc[9] = packed;             // the longest tile with its bin entries and runs
+        }
+    }
+    if (clear_rows) {
+        // Pipelined single frames (mi355i_launch_raster_pipelined): the background (Screen::ClearScreen) is written here, by the
+        // blocks without a tile of their own, a wave per output row and 16 bytes per lane; the 16x16 tiles that hold triangles
+        // are written in full by their blocks.  (The fill kernel of this frame ran beside the previous frame's tile kernel: it
+        // must not touch the output.)
+        const uint32_t *off = B.offset;
+        const bool global_any = off[g.n_coarse + 1] != off[g.n_coarse];
+        const uint32_t first = total_items + 64u <= gridDim.x ? total_items : 0u, nb = gridDim.x - first;
+        if (!global_any && blockIdx.x >= first) {
+            const uint32_t wpb = (uint32_t)nt >> 6, n_waves = nb * wpb;
+            const int lane = tid & 63;
+            const bool vec = (P.pitch_words & 3) == 0 && (((size_t)P.out) & 15u) == 0;
+            for (uint32_t o = (blockIdx.x - first) * wpb + ((uint32_t)tid >> 6); o < (uint32_t)P.out_rows; o += n_waves) {
+                const int y = P.compact ? band_row_to_y((int)o, P.band_rows, P.band_index, P.band_count) : (int)o;
+                const bool owned = rs_out_row(P, y) >= 0;
+                const uint32_t *crow = off + (y / (RS_TH * RS_CB)) * g.cx;
+                uint32_t *orow = P.out + (size_t)o * P.pitch_words;
+                for (int x = lane * 4; x < P.W; x += 256) {
+                    const int cb = x / (RS_TW * RS_CB);
+                    if (owned && crow[cb + 1] != crow[cb]) continue;           // a tile with triangles: its block writes it
+                    if (vec && x + 3 < P.W) *(uint4 *)(orow + x) = make_uint4(0u, 0u, 0u, 0u);
+                    else for (int k = 0; k < 4 && x + k < P.W; k++) orow[x + k] = 0u;
+                }
+            }
         }
     }
     if (prof) {
@@ -675,10 +705,15 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
     return hipSuccess;
 }
 
+// pre / fill_done: pipelined single frames -- setup and fill go to the stream `pre` (beside the previous frame's tile kernel on
+// `st`), the tile kernel waits for them on `st` and also writes the background (the fill kernel must not touch the output then)
 template <int MODE>
 static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const FrameParams *d_batch, int n_frames, RasterScratch *s,
-                                hipStream_t st)
+                                hipStream_t st, hipStream_t pre = nullptr, hipEvent_t fill_done = nullptr, hipEvent_t tile_done = nullptr)
 {
+    const bool piped = pre != nullptr && fill_done != nullptr && n_frames == 1;
+    hipStream_t st_tile = st;
+    if (piped) st = pre;
     const RsGrid g = rs_grid(P->W, P->H);
     hipError_t e = tiled_ensure(s, g, S->n_tris, n_frames, st);
     if (e != hipSuccess) return e;
@@ -687,10 +722,17 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     hipLaunchKernelGGL((k_rs_setup<MODE>), per_tri, dim3(256), 0, st, *S, *P, d_batch, g, s->B);
     // (the fill kernel's grid also has to carry the band items: at least four blocks per CU)
     const dim3 fill_grid(per_tri.x > 1024u ? per_tri.x : 1024u, n_frames);
-    if (g.n_bins <= RS_SCAN_LDS) hipLaunchKernelGGL(k_rs_fill<true>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters);
+    if (piped && g.n_bins <= RS_SCAN_LDS)       // (fill_done is this kernel's own completion signal)
+        hipExtLaunchKernelGGL(k_rs_fill<true>, fill_grid, dim3(256), 0, st, nullptr, fill_done, 0, g, s->B, S->n_tris, *P, d_batch, P->counters, 0);
+    else if (g.n_bins <= RS_SCAN_LDS) hipLaunchKernelGGL(k_rs_fill<true>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters, piped ? 0 : 1);
     else {
         hipLaunchKernelGGL(k_rs_scan, dim3(n_frames), dim3(1024), 0, st, g, s->B, P->counters);
-        hipLaunchKernelGGL(k_rs_fill<false>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters);
+        hipLaunchKernelGGL(k_rs_fill<false>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters, piped ? 0 : 1);
+    }
+    if (piped) {
+        if (g.n_bins > RS_SCAN_LDS && (e = hipEventRecord(fill_done, pre)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(st_tile, fill_done, 0)) != hipSuccess) return e;
+        st = st_tile;
     }
     // Tiles that hold triangles are handed out by a dispenser (a fixed assignment to resident blocks balances unequal
     // tiles badly: measured); 2048 blocks = eight per CU cover a 1080p frame's ~1100 such tiles with one tile per block.
@@ -698,21 +740,32 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     if (blocks > 2048) blocks = 2048;
     // threads per tile: mi355_opts::tune[3] (64..512, whole waves), default 256
     const int nt = P->rs_threads >= 64 && P->rs_threads <= RS_MAX_THREADS && (P->rs_threads & 63) == 0 ? P->rs_threads : 256;
-    hipLaunchKernelGGL((k_rs_tile<MODE>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B);
+    if (piped) hipExtLaunchKernelGGL((k_rs_tile<MODE>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, nullptr, tile_done, 0, *S, *P, d_batch, n_frames, g, s->B, 1);
+    else hipLaunchKernelGGL((k_rs_tile<MODE>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B, 0);
     return hipGetLastError();
 }
 
 static hipError_t raster_dispatch(const DevScene *S, const FrameParams *P, const FrameParams *d_batch, int n_frames, int mode,
-                                  RasterScratch *s, hipStream_t st)
+                                  RasterScratch *s, hipStream_t st, hipStream_t pre = nullptr, hipEvent_t fill_done = nullptr,
+                                  hipEvent_t tile_done = nullptr)
 {
     switch (mode) {
-    case M_AMBIENT: return raster_frames<M_AMBIENT>(S, P, d_batch, n_frames, s, st);
-    case M_GOURAUD: return raster_frames<M_GOURAUD>(S, P, d_batch, n_frames, s, st);
-    case M_PHONG: return raster_frames<M_PHONG>(S, P, d_batch, n_frames, s, st);
-    case M_PHONG_SH: return raster_frames<M_PHONG_SH>(S, P, d_batch, n_frames, s, st);
-    case M_PHONG_SOFT: return raster_frames<M_PHONG_SOFT>(S, P, d_batch, n_frames, s, st);
+    case M_AMBIENT: return raster_frames<M_AMBIENT>(S, P, d_batch, n_frames, s, st, pre, fill_done, tile_done);
+    case M_GOURAUD: return raster_frames<M_GOURAUD>(S, P, d_batch, n_frames, s, st, pre, fill_done, tile_done);
+    case M_PHONG: return raster_frames<M_PHONG>(S, P, d_batch, n_frames, s, st, pre, fill_done, tile_done);
+    case M_PHONG_SH: return raster_frames<M_PHONG_SH>(S, P, d_batch, n_frames, s, st, pre, fill_done, tile_done);
+    case M_PHONG_SOFT: return raster_frames<M_PHONG_SOFT>(S, P, d_batch, n_frames, s, st, pre, fill_done, tile_done);
     }
     return hipErrorInvalidValue;
+}
+
+// One frame whose setup and fill kernels run on `pre` -- beside whatever `st` is still doing, normally the previous frame's
+// tile kernel -- and whose tile kernel follows on `st` (it waits for fill_done).  The scratch set must not be in use by a
+// frame whose tile kernel has not finished: the caller alternates two sets and orders them with events (capi.hip).
+extern "C" hipError_t mi355i_launch_raster_pipelined(const DevScene *S, const FrameParams *P, int mode, RasterScratch *s, hipStream_t st,
+                                                     hipStream_t pre, hipEvent_t fill_done, hipEvent_t tile_done)
+{
+    return raster_dispatch(S, P, nullptr, 1, mode, s, st, pre, fill_done, tile_done);
 }
 
 extern "C" hipError_t mi355i_launch_raster(const DevScene *S, const FrameParams *P, int mode, RasterScratch *s, hipStream_t st)
