@@ -589,6 +589,8 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
         //  the scratch it is about to use)
         if (rs == c->rscratch) for (int k = 0; k < 2; k++) if (c->ev_tile_set[k]) HIP_TRY(hipStreamWaitEvent(st, c->ev_tile[k], 0), -40);
         e = mi355i_launch_raster(&c->dev, &P, mode, rs, st);
+        // (... and the next pipelined frame that takes this scratch set waits for this one)
+        if (e == hipSuccess && rs == c->rscratch && c->pre) { HIP_TRY(hipEventRecord(c->ev_tile[0], st), -40); c->ev_tile_set[0] = true; }
         break;
     case MI355_MODE_RAYTRACE: case MI355_MODE_RAYTRACE_ANTIALIAS: {
         if (!c->has_bvh) return fail(-41, "raytrace modes need mi355_scene_set_bvh first");
@@ -1000,6 +1002,7 @@ int mi355_render_batch_device(mi355_ctx *c, int mode, int n_frames, const mi355_
         for (int k = 0; k < 2; k++) if (c->ev_tile_set[k]) HIP_TRY(hipStreamWaitEvent(user, c->ev_tile[k], 0), -40);   // (pipelined single frames still using the scratch)
         hipError_t e = mi355i_launch_raster_batch(&c->dev, frames.data(), n_frames, mode, c->rscratch, user);
         if (e != hipSuccess) return fail(-43, "kernel launch failed: %s", hipGetErrorString(e));
+        if (c->pre) { HIP_TRY(hipEventRecord(c->ev_tile[0], user), -40); c->ev_tile_set[0] = true; }
         if (frames[0].mlaa) {
             HIP_TRY(c->mlaa.ensure((size_t)frames[0].pitch_words * frames[0].H * 4), -31);
             for (int f = 0; f < n_frames; f++)
