@@ -33,7 +33,8 @@ extern "C" {
 enum {
     MI355_MODE_POINTS = 1,                /* Scene::renderPoints(asTriangles=false)  Rasterizers.cc:56-76  */
     MI355_MODE_POINTS_FROM_TRIANGLES = 2, /* Scene::renderPoints(asTriangles=true)   Rasterizers.cc:77-109 */
-    MI355_MODE_LINES = 3,                 /* Scene::renderWireframe -- NOT on the hot path, returns error  */
+    MI355_MODE_LINES = 3,                 /* Scene::renderWireframe (Wu anti-aliased lines blended in triangle order; synchronises the stream;
+                                           * frames up to 4095 x 4095 / 2^23 pixels, scenes up to 349525 triangles)               */
     MI355_MODE_AMBIENT = 4,               /* Scene::renderAmbient               Rasterizers.cc:360-363 */
     MI355_MODE_GOURAUD = 5,               /* Scene::renderGouraud               Rasterizers.cc:365-368 */
     MI355_MODE_PHONG = 6,                 /* Scene::renderPhong                 Rasterizers.cc:370-373 */

@@ -1082,6 +1082,223 @@ static void render_points(const orc_scene &s, const orc_camera &cam, const orc_o
     }
 }
 
+/* ---------- wireframe (Rasterizers.cc:117-187) and the Wu lines it draws (Wu.cc, a copy of SDL_gfx) --------------
+ * PARITY UNPINNED: Wu.cc calls SDL_MapRGBA of the SDL library for every pixel, so it cannot be compiled into oracle/_ref
+ * (refcore), and the survey recorded no mode-3 frame.  This is a restatement of the code as read: surface format XRGB8888
+ * (Rmask 0xff0000, Gmask 0xff00, Bmask 0xff, Amask 0), clip rectangle = the whole surface, the reference's single-thread
+ * triangle order (its OpenMP loop races on the blending). */
+struct WuSurf { uint32_t *px; int pitch, W, H; };
+
+/* _putPixelAlpha, 32 bpp, DEFAULT_ALPHA_PIXEL_ROUTINE (Wu.cc:47-177): `color` is in surface format */
+static inline void wu_put_pixel_alpha(WuSurf &s, int16_t x, int16_t y, uint32_t color, uint8_t alpha)
+{
+    if (!(x >= 0 && x <= s.W - 1 && y >= 0 && y <= s.H - 1)) return;
+    uint32_t *pixel = s.px + (size_t)y * s.pitch + x;
+    if (alpha == 255) { *pixel = color; return; }
+    const uint32_t dc = *pixel;
+    const uint32_t Rmask = 0xff0000u, Gmask = 0xff00u, Bmask = 0xffu;
+    const uint32_t R = ((dc & Rmask) + (((((color & Rmask) - (dc & Rmask)) >> 16) * alpha >> 8) << 16)) & Rmask;
+    const uint32_t G = ((dc & Gmask) + (((((color & Gmask) - (dc & Gmask)) >> 8) * alpha >> 8) << 8)) & Gmask;
+    const uint32_t B = ((dc & Bmask) + (((((color & Bmask) - (dc & Bmask)) >> 0) * alpha >> 8) << 0)) & Bmask;
+    *pixel = R | G | B;                                       /* Amask == 0: A = 0 */
+}
+/* SDL_MapRGBA for this format: (r << 16) | (g << 8) | b, alpha dropped */
+static inline uint32_t wu_map(uint32_t rgba) { return (((rgba >> 24) & 0xffu) << 16) | (((rgba >> 16) & 0xffu) << 8) | ((rgba >> 8) & 0xffu); }
+/* pixelColor / pixelColorNolock (Wu.cc:258-310): color = 0xRRGGBBAA */
+static inline void wu_pixel(WuSurf &s, int16_t x, int16_t y, uint32_t color) { wu_put_pixel_alpha(s, x, y, wu_map(color), (uint8_t)(color & 0xffu)); }
+/* pixelColorWeightNolock (Wu.cc:620-634) */
+static inline void wu_pixel_weight(WuSurf &s, int16_t x, int16_t y, uint32_t color, uint32_t weight)
+{
+    uint32_t a = color & 0xffu;
+    a = (a * weight) >> 8;
+    wu_pixel(s, x, y, (color & 0xffffff00u) | a);
+}
+/* _filledRectAlpha, 32 bpp (Wu.cc:328-553): the same blend, rows then columns; an alpha of 255 never reaches it */
+static void wu_rect_alpha(WuSurf &s, int16_t x1, int16_t y1, int16_t x2, int16_t y2, uint32_t rgba)
+{
+    const uint32_t color = wu_map(rgba), alpha = rgba & 0xffu;
+    for (int y = y1; y <= y2; y++)
+        for (int x = x1; x <= x2; x++) {
+            uint32_t *pixel = s.px + (size_t)y * s.pitch + x;
+            const uint32_t Rmask = 0xff0000u, Gmask = 0xff00u, Bmask = 0xffu;
+            const uint32_t R = ((*pixel & Rmask) + (((((color & Rmask) - (*pixel & Rmask)) >> 16) * alpha >> 8) << 16)) & Rmask;
+            const uint32_t G = ((*pixel & Gmask) + (((((color & Gmask) - (*pixel & Gmask)) >> 8) * alpha >> 8) << 8)) & Gmask;
+            const uint32_t B = ((*pixel & Bmask) + (((((color & Bmask) - (*pixel & Bmask)) >> 0) * alpha >> 8) << 0)) & Bmask;
+            *pixel = R | G | B;
+        }
+}
+/* hlineColor (Wu.cc:649-785) */
+static void wu_hline(WuSurf &s, int16_t x1, int16_t x2, int16_t y, uint32_t color)
+{
+    if (x1 > x2) { const int16_t t = x1; x1 = x2; x2 = t; }
+    const int16_t left = 0, right = (int16_t)(s.W - 1), top = 0, bottom = (int16_t)(s.H - 1);
+    if (x2 < left || x1 > right) return;
+    if (y < top || y > bottom) return;
+    if (x1 < left) x1 = left;
+    if (x2 > right) x2 = right;
+    const int dx = x2 - x1;
+    if ((color & 255u) == 255u) { for (int x = x1; x <= x1 + dx; x++) s.px[(size_t)y * s.pitch + x] = wu_map(color); }
+    else wu_rect_alpha(s, x1, y, (int16_t)(x1 + dx), y, color);
+}
+/* vlineColor (Wu.cc:799-940) */
+static void wu_vline(WuSurf &s, int16_t x, int16_t y1, int16_t y2, uint32_t color)
+{
+    if (y1 > y2) { const int16_t t = y1; y1 = y2; y2 = t; }
+    const int16_t left = 0, right = (int16_t)(s.W - 1), top = 0, bottom = (int16_t)(s.H - 1);
+    if (x < left || x > right) return;
+    if (y2 < top || y1 > bottom) return;
+    if (y1 < top) y1 = top;
+    if (y2 > bottom) y2 = bottom;
+    const int16_t h = (int16_t)(y2 - y1);
+    if ((color & 255u) == 255u) { for (int y = y1; y <= y1 + h; y++) s.px[(size_t)y * s.pitch + x] = wu_map(color); }
+    else wu_rect_alpha(s, x, y1, x, (int16_t)(y1 + h), color);
+}
+/* _clipEncode / _clipLine (Wu.cc:964-1051): Cohen-Sutherland with a float slope and truncating casts to Sint16 */
+static inline int wu_clip_code(int16_t x, int16_t y, int16_t left, int16_t top, int16_t right, int16_t bottom)
+{
+    int code = 0;
+    if (x < left) code |= 1; else if (x > right) code |= 2;
+    if (y < top) code |= 8; else if (y > bottom) code |= 4;
+    return code;
+}
+static inline int16_t wu_s16(float f) { return (int16_t)cvtt(f); }      /* (Sint16) of a float on x86-64: cvttss2si, low 16 bits */
+static bool wu_clip_line(const WuSurf &s, int16_t &x1, int16_t &y1, int16_t &x2, int16_t &y2)
+{
+    const int16_t left = 0, right = (int16_t)(s.W - 1), top = 0, bottom = (int16_t)(s.H - 1);
+    for (;;) {
+        int code1 = wu_clip_code(x1, y1, left, top, right, bottom);
+        const int code2 = wu_clip_code(x2, y2, left, top, right, bottom);
+        if (!(code1 | code2)) return true;
+        if (code1 & code2) return false;
+        if (!code1) {
+            int16_t t = x2; x2 = x1; x1 = t;
+            t = y2; y2 = y1; y1 = t;
+            code1 = code2;
+        }
+        float m;
+        if (x2 != x1) m = (y2 - y1) / (float)(x2 - x1); else m = 1.0f;
+        if (code1 & 1) { y1 = (int16_t)(y1 + wu_s16((left - x1) * m)); x1 = left; }
+        else if (code1 & 2) { y1 = (int16_t)(y1 + wu_s16((right - x1) * m)); x1 = right; }
+        else if (code1 & 4) { if (x2 != x1) x1 = (int16_t)(x1 + wu_s16((bottom - y1) / m)); y1 = bottom; }
+        else if (code1 & 8) { if (x2 != x1) x1 = (int16_t)(x1 + wu_s16((top - y1) / m)); y1 = top; }
+    }
+}
+/* lineColor (Wu.cc:1075-1262), the blended branch (alpha != 255): clip, special cases, Bresenham with pixelColorNolock */
+static void wu_line(WuSurf &s, int16_t x1, int16_t y1, int16_t x2, int16_t y2, uint32_t color)
+{
+    if (!wu_clip_line(s, x1, y1, x2, y2)) return;
+    if (x1 == x2) {
+        if (y1 < y2) wu_vline(s, x1, y1, y2, color);
+        else if (y1 > y2) wu_vline(s, x1, y2, y1, color);
+        else wu_pixel(s, x1, y1, color);
+        return;
+    }
+    if (y1 == y2) {
+        if (x1 < x2) { wu_hline(s, x1, x2, y1, color); return; }
+        else if (x1 > x2) { wu_hline(s, x2, x1, y1, color); return; }
+    }
+    const int dx = x2 - x1, dy = y2 - y1;
+    const int sx = dx >= 0 ? 1 : -1, sy = dy >= 0 ? 1 : -1;
+    const int ax = (dx < 0 ? -dx : dx) << 1, ay = (dy < 0 ? -dy : dy) << 1;
+    int x = x1, y = y1;
+    if (ax > ay) {
+        int d = ay - (ax >> 1);
+        while (x != x2) {
+            wu_pixel(s, (int16_t)x, (int16_t)y, color);
+            if (d > 0 || (d == 0 && sx == 1)) { y += sy; d -= ax; }
+            x += sx; d += ay;
+        }
+    } else {
+        int d = ax - (ay >> 1);
+        while (y != y2) {
+            wu_pixel(s, (int16_t)x, (int16_t)y, color);
+            if (d > 0 || (d == 0 && sy == 1)) { x += sx; d -= ay; }
+            y += sy; d += ax;
+        }
+    }
+    wu_pixel(s, (int16_t)x, (int16_t)y, color);
+}
+/* _aalineColor with draw_endpoint = 1 = my_aalineColor (Wu.cc:1282-1512) */
+static void wu_aaline(WuSurf &s, int16_t x1, int16_t y1, int16_t x2, int16_t y2, uint32_t color)
+{
+    if (!wu_clip_line(s, x1, y1, x2, y2)) return;
+    int32_t xx0 = x1, yy0 = y1, xx1 = x2, yy1 = y2;
+    if (yy0 > yy1) { int32_t t = yy0; yy0 = yy1; yy1 = t; t = xx0; xx0 = xx1; xx1 = t; }
+    int dx = xx1 - xx0, dy = yy1 - yy0;
+    if (dx == 0) { wu_vline(s, x1, y1, y2, color); return; }
+    if (dy == 0) { wu_hline(s, x1, x2, y1, color); return; }
+    if (dx == dy) { wu_line(s, x1, y1, x2, y2, color); return; }
+    int xdir;
+    if (dx >= 0) xdir = 1; else { xdir = -1; dx = -dx; }
+    uint32_t erracc = 0;
+    const uint32_t intshift = 32 - 8;
+    wu_pixel(s, x1, y1, color);                              /* the initial pixel in the foreground colour: (x1, y1) as clipped, not (xx0, yy0) */
+    if (dy > dx) {
+        const uint32_t erradj = ((uint32_t)((dx << 16) / dy)) << 16;
+        int x0pxdir = xx0 + xdir;
+        while (--dy) {
+            const uint32_t erracctmp = erracc;
+            erracc += erradj;
+            if (erracc <= erracctmp) { xx0 = x0pxdir; x0pxdir += xdir; }
+            yy0++;
+            const uint32_t wgt = (erracc >> intshift) & 255u;
+            wu_pixel_weight(s, (int16_t)xx0, (int16_t)yy0, color, 255u - wgt);
+            wu_pixel_weight(s, (int16_t)x0pxdir, (int16_t)yy0, color, wgt);
+        }
+    } else {
+        const uint32_t erradj = ((uint32_t)((dy << 16) / dx)) << 16;
+        int y0p1 = yy0 + 1;
+        while (--dx) {
+            const uint32_t erracctmp = erracc;
+            erracc += erradj;
+            if (erracc <= erracctmp) { yy0 = y0p1; y0p1++; }
+            xx0 += xdir;
+            const uint32_t wgt = (erracc >> intshift) & 255u;
+            wu_pixel_weight(s, (int16_t)xx0, (int16_t)yy0, color, 255u - wgt);
+            wu_pixel_weight(s, (int16_t)xx0, (int16_t)y0p1, color, wgt);
+        }
+    }
+    wu_pixel(s, x2, y2, color);                              /* draw_endpoint */
+}
+
+/* Scene::renderWireframe (Rasterizers.cc:117-187), triangles in index order */
+static void render_wireframe(const orc_scene &s, const orc_camera &cam, const orc_opts &o, uint32_t *out, int pitch, orc_stats &st)
+{
+    for (int y = 0; y < o.height; y++) for (int x = 0; x < o.width; x++) out[(size_t)y * pitch + x] = 0;
+    WuSurf surf{out, pitch, o.width, o.height};
+    const uint32_t greyPixel = (200u << 16) | (200u << 8) | 200u;       /* SDL_MapRGB(format, 200,200,200) -- which the line code reads as 0xRRGGBBAA */
+    const M3 mv = m3_from(cam.mv);
+    const V3 eye(cam.eye[0], cam.eye[1], cam.eye[2]);
+    for (const Tri &t : s.tris) {
+        V3 triToEye = sub(eye, t.center);
+        if (dot(triToEye, t.normal) < 0) continue;
+        st.tris_drawn++;
+        const V3 A = transform(s.verts[t.a].p, eye, mv), B = transform(s.verts[t.b].p, eye, mv), C = transform(s.verts[t.c].p, eye, mv);
+        const bool agood = A.z > o.clip_z, bgood = B.z > o.clip_z, cgood = C.z > o.clip_z;
+#define ORC_SCREENSPACE(P, xx, yy) const int xx = cvtt(o.width / 2 + o.screen_dist * P.y / P.z), yy = cvtt(o.height / 2 - o.screen_dist * P.x / P.z)
+        if (agood) {
+            ORC_SCREENSPACE(A, ax, ay);
+            if (bgood) {
+                ORC_SCREENSPACE(B, bx, by);
+                wu_aaline(surf, (int16_t)ax, (int16_t)ay, (int16_t)bx, (int16_t)by, greyPixel);
+                if (cgood) {
+                    ORC_SCREENSPACE(C, cx, cy);
+                    wu_aaline(surf, (int16_t)ax, (int16_t)ay, (int16_t)cx, (int16_t)cy, greyPixel);
+                    wu_aaline(surf, (int16_t)bx, (int16_t)by, (int16_t)cx, (int16_t)cy, greyPixel);
+                }
+            } else if (cgood) {
+                ORC_SCREENSPACE(C, cx, cy);
+                wu_aaline(surf, (int16_t)ax, (int16_t)ay, (int16_t)cx, (int16_t)cy, greyPixel);
+            }
+        } else if (bgood && cgood) {
+            ORC_SCREENSPACE(B, bx, by);
+            ORC_SCREENSPACE(C, cx, cy);
+            wu_aaline(surf, (int16_t)bx, (int16_t)by, (int16_t)cx, (int16_t)cy, greyPixel);
+        }
+#undef ORC_SCREENSPACE
+    }
+}
+
 /* ---------- light / camera bases ------------------------------------------ */
 
 /* Camera.cc:24-42 and Light.cc:173-216 share this look-at construction (zenith = +Z) */
@@ -1116,6 +1333,13 @@ void orc_trace_hits(const orc_scene *s, int n, const float *rays6, int32_t *tri,
         tri[i] = best;
         hit3[3 * (size_t)i] = hit.x; hit3[3 * (size_t)i + 1] = hit.y; hit3[3 * (size_t)i + 2] = hit.z;
     }
+}
+
+void orc_wu_lines(uint32_t *pixels, int width, int height, int pitch_words, int n, const int16_t *xyxy)
+{
+    WuSurf surf{pixels, pitch_words, width, height};
+    const uint32_t greyPixel = (200u << 16) | (200u << 8) | 200u;
+    for (int i = 0; i < n; i++) wu_aaline(surf, xyxy[4 * i], xyxy[4 * i + 1], xyxy[4 * i + 2], xyxy[4 * i + 3], greyPixel);
 }
 
 void orc_default_opts(orc_opts *o, int width, int height)
@@ -1370,6 +1594,7 @@ int orc_render(const orc_scene *s, int mode, const orc_camera *cam, const orc_li
     switch (mode) {
     case 1: render_points(*s, *cam, *o, false, out, pitch, local); break;
     case 2: render_points(*s, *cam, *o, true, out, pitch, local); break;
+    case 3: render_wireframe(*s, *cam, *o, out, pitch, local); break;
     case 4: render_raster<5, FAmbient>(*s, *cam, L, *o, out, pitch, local); break;
     case 5: render_raster<5, FGouraud>(*s, *cam, L, *o, out, pitch, local); break;
     case 6: render_raster<8, FPhong>(*s, *cam, L, *o, out, pitch, local); break;

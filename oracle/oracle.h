@@ -118,7 +118,7 @@ void orc_benchmark_frame(int k, int second_light, orc_camera *cam, orc_light *li
 void orc_shadowmap_render(const orc_scene *, const orc_light *, int size, float *map);
 
 /* Scene::render* (Rasterizers.cc, Raytracer.cc:791-868).  mode = reference RenderMode 1..10
- * (3 = wireframe unsupported -> returns -1).  out_xrgb: height*pitch_words uint32
+ * (3 = wireframe: restated from Wu.cc as read, PARITY UNPINNED -- see oracle.cc).  out_xrgb: height*pitch_words uint32
  * (r<<16|g<<8|b); out_f32 (optional): width*height*3 pre-quantisation r,g,b floats
  * (raytrace modes only).  shadow_maps: n_lights pointers (modes 7/8). */
 int orc_render(const orc_scene *, int mode, const orc_camera *, const orc_light *lights,
@@ -128,6 +128,10 @@ int orc_render(const orc_scene *, int mode, const orc_camera *, const orc_light 
 /* BVH_IntersectTriangles<false,true> (Raytracer.cc:183-308) for n rays (origin, direction): the triangle each ray hits first
  * (index into the scene's triangles, -1 = none) and the hit point.  For tests that need hits, not pixels. */
 void orc_trace_hits(const orc_scene *, int n, const float *rays6, int32_t *tri, float *hit3);
+
+/* my_aalineColor(surface, x1, y1, x2, y2, greyPixel) (Wu.cc:1509, as Rasterizers.cc:166-183 calls it) for n lines in order,
+ * blended into `pixels` (for tests of the wireframe's line generator) */
+void orc_wu_lines(uint32_t *pixels, int width, int height, int pitch_words, int n, const int16_t *xyxy);
 
 /* LightingEquation<mode>::ComputePixel (LightingEq.h:45-170) on caller-supplied points, rows of
  * (inCameraSpace[3], normal[3], material r,g,b, ao) -> r,g,b; shadow_mode 0 none, 1 shadow maps, 2 soft */

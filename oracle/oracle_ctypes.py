@@ -99,6 +99,16 @@ def default_opts(width: int, height: int, **kw) -> Opts:
     return o
 
 
+def wu_lines(pixels: np.ndarray, xyxy) -> np.ndarray:
+    """orc_wu_lines: draw the lines (n x 4 int16: x1, y1, x2, y2) over `pixels` (H x W uint32, modified in place)"""
+    xyxy = np.ascontiguousarray(xyxy, np.int16).reshape(-1, 4)
+    f = lib().orc_wu_lines
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    f.restype = None
+    f(pixels.ctypes.data, pixels.shape[1], pixels.shape[0], pixels.strides[0] // 4, len(xyxy), xyxy.ctypes.data)
+    return pixels
+
+
 def benchmark_frame(k: int, second_light: bool = False):
     """Camera + lights of frame k of the reference's `renderer -b` orbit."""
     cam = Camera()

@@ -37,6 +37,11 @@ extern "C" hipError_t mi355i_launch_shadowmap(const DevScene *, const float *lig
 extern "C" RasterScratch *mi355i_raster_scratch_create(void);
 extern "C" void mi355i_raster_scratch_destroy(RasterScratch *);
 extern "C" uint32_t mi355i_raster_overflow(RasterScratch *);
+struct WireScratch;
+extern "C" WireScratch *mi355i_wire_scratch_create(void);
+extern "C" void mi355i_wire_scratch_destroy(WireScratch *);
+extern "C" int mi355i_wireframe_fits(int W, int H, uint32_t n_tris);
+extern "C" hipError_t mi355i_launch_wireframe(const DevScene *S, const FrameParams *P, WireScratch *w, hipStream_t st);
 extern "C" hipError_t mi355i_launch_raster_pipelined(const DevScene *S, const FrameParams *P, int mode, RasterScratch *s, hipStream_t st,
                                                      hipStream_t pre, hipEvent_t fill_done, hipEvent_t tile_done);
 extern "C" int mi355i_raster_grow(RasterScratch *);
@@ -149,6 +154,7 @@ struct mi355_ctx {
     DevBuf smap[MI355_MAX_LIGHTS];
     int smap_size[MI355_MAX_LIGHTS] = {0, 0, 0, 0};
     RasterScratch *rscratch = nullptr;
+    WireScratch *wscratch = nullptr;     // mode 3 (created with its first frame)
     // pipelined frames (mi355_render_async / _wait): each slot is a stream with its own control block (counters, pixel
     // dispenser), framebuffer, page-locked staging and rasterizer scratch
     struct AsyncSlot {
@@ -634,7 +640,13 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
         break;
     }
     case MI355_MODE_LINES:
-        return fail(-42, "mode 3 (wireframe, Scene::renderWireframe) is outside the accelerated hot path");
+        // Scene::renderWireframe (Rasterizers.cc:117-187).  Synchronises the stream once inside (k_wire.hip).
+        if (!mi355i_wireframe_fits(P.W, P.H, c->dev.n_tris))
+            return fail(-42, "mode 3 (wireframe): frames up to 4095 x 4095 with at most 2^23 pixels and scenes up to 349525 triangles");
+        HIP_TRY(hipDeviceSynchronize(), -40);          // (one set of key buffers per context: no two wireframe frames in flight)
+        if (!c->wscratch) c->wscratch = mi355i_wire_scratch_create();
+        e = mi355i_launch_wireframe(&c->dev, &P, c->wscratch, st);
+        break;
     default:
         return fail(-42, "unknown render mode %d", mode);
     }
@@ -792,6 +804,7 @@ void mi355_scene_destroy(mi355_ctx *c)
     }
     for (auto &h : c->host_reg) if (h.p) (void)hipHostUnregister(h.p);
     if (c->rscratch) mi355i_raster_scratch_destroy(c->rscratch);
+    if (c->wscratch) mi355i_wire_scratch_destroy(c->wscratch);
     if (c->rs_pipe[1]) mi355i_raster_scratch_destroy(c->rs_pipe[1]);
     for (int k = 0; k < 2; k++) { if (c->ev_fill[k]) (void)hipEventDestroy(c->ev_fill[k]); if (c->ev_tile[k]) (void)hipEventDestroy(c->ev_tile[k]); }
     if (c->pre) (void)hipStreamDestroy(c->pre);

@@ -27,7 +27,7 @@ static void usage()
 {
     fprintf(stderr,
             "Usage: render_cli [-b] [-r] [--bench] [-n frames] [-m mode] [-w] [-W width] [-H height] [-d device] [-g gpus] [-p in_flight] [-o ppm_prefix] FILE\n"
-            "  -m <mode>  1 points, 2 points from triangles, 4 ambient, 5 Gouraud, 6 Phong,\n"
+            "  -m <mode>  1 points, 2 points from triangles, 3 wireframe, 4 ambient, 5 Gouraud, 6 Phong,\n"
             "             7 Phong+shadow maps, 8 Phong+soft shadow maps, 9 raytracing, 0 raytracing+AA\n"
             "  -w         use two lights        -n N  frames (default 100)\n");
     exit(1);
@@ -115,6 +115,7 @@ static double run(const char *fname, int mode, int frames, int W, int H, const s
         switch (mode) {
         case 1: scene.renderPoints(sony, canvas, false); break;
         case 2: scene.renderPoints(sony, canvas, true); break;
+        case 3: scene.renderWireframe(sony, canvas); break;
         case 4: scene.renderAmbient(sony, canvas); break;
         case 5: scene.renderGouraud(sony, canvas); break;
         case 6: scene.renderPhong(sony, canvas); break;
@@ -171,7 +172,7 @@ int main(int argc, char **argv)
         else if (a[0] == '-') usage();
         else fname = a;
     }
-    if (!fname || mode < 1 || mode > 10 || mode == 3) usage();
+    if (!fname || mode < 1 || mode > 10) usage();
     if (frames < 0) frames = bench ? 500 : 100;
     try {
         if (!bench) { run(fname, mode, frames, W, H, devices, twoLights, periodic, dump, inFlight); return 0; }

@@ -831,6 +831,7 @@ void Scene::renderPoints(const Camera &eye, Screen &canvas, bool asTriangles)
     renderMode(asTriangles ? MI355_MODE_POINTS_FROM_TRIANGLES : MI355_MODE_POINTS, eye, canvas);
     canvas.ShowScreen();
 }
+void Scene::renderWireframe(const Camera &eye, Screen &canvas) { renderMode(MI355_MODE_LINES, eye, canvas); canvas.ShowScreen(); }
 void Scene::renderAmbient(const Camera &eye, Screen &canvas) { renderMode(MI355_MODE_AMBIENT, eye, canvas); canvas.ShowScreen(); }
 void Scene::renderGouraud(const Camera &eye, Screen &canvas) { renderMode(MI355_MODE_GOURAUD, eye, canvas); canvas.ShowScreen(); }
 void Scene::renderPhong(const Camera &eye, Screen &canvas) { renderMode(MI355_MODE_PHONG, eye, canvas); canvas.ShowScreen(); }

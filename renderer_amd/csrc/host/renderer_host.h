@@ -134,6 +134,7 @@ struct Scene {                                         // Scene.h:32-86
     void UpdateBoundingVolumeHierarchy(const char *filename, bool forceRecalc = false);   // Raytracer.cc:720-789
 
     void renderPoints(const Camera &, Screen &, bool asTriangles = true);   // Scene.h:76
+    void renderWireframe(const Camera &, Screen &);                         // Scene.h:77
     void renderAmbient(const Camera &, Screen &);
     void renderGouraud(const Camera &, Screen &);
     void renderPhong(const Camera &, Screen &);

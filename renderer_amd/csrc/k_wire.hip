@@ -1,0 +1,166 @@
+// k_wire.hip -- mode 3, the wireframe (Scene::renderWireframe, Rasterizers.cc:117-187; lines: Wu.cc) on the GPU.
+//
+// The reference blends every line over whatever the earlier lines left in the frame, so a pixel's value depends on the ORDER
+// of the lines through it.  Here the order is made explicit: every line is expanded into its pixel operations (wf_core.h),
+// each a 64-bit key   pixel << 41 | line << 21 | position in the line << 8 | alpha;   the keys are sorted (rocPRIM radix
+// sort, whole keys: a bit range starting above bit 0 came back unsorted from this rocPRIM) and one thread per pixel replays its alphas in order over black.  Lines are numbered 3 * triangle +
+// {AB, AC, BC}: the reference's single-thread drawing order.
+//   k_wf_count  : thread per (triangle, line): back-face test, transform, projection, clip; counts the line's operations
+//   scan        : rocprim::exclusive_scan of the counts
+//   k_wf_emit   : the same walk again, writing keys at the line's offset
+//   sort        : rocprim::radix_sort_keys
+//   k_wf_apply  : thread per key; the first key of a pixel replays the pixel's run
+// Limits (the key's fields): width, height <= 4095, width * height <= 2^23, triangles <= 349 525.
+#include "dev_scene.h"
+#include "wf_core.h"
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+namespace {
+
+enum { WF_PIXEL_SHIFT = 41, WF_LINE_SHIFT = 21, WF_POS_SHIFT = 8 };
+
+MI_DEV f3 wf_to_camera(const FrameParams &P, f3 p) { return mulright(P.mv, sub3(p, mk3(P.eye[0], P.eye[1], P.eye[2]))); }   // Transform, Algebra.h:38-42
+
+// line `slot` of triangle t, or false (culled, behind the clip plane)
+MI_DEV bool wf_line_of(const DevScene &S, const FrameParams &P, uint32_t t, int slot, int16_t &x1, int16_t &y1, int16_t &x2, int16_t &y2)
+{
+    const float4 c = S.rs_tri[(size_t)t * 2], n = S.rs_tri[(size_t)t * 2 + 1];
+    const f3 triToEye = sub3(mk3(P.eye[0], P.eye[1], P.eye[2]), mk3(c.x, c.y, c.z));
+    if (dot3(triToEye, mk3(n.x, n.y, n.z)) < 0.f) return false;             // Rasterizers.cc:133-140 (no _twoSided test)
+    const uint4 id = S.rs_idx[t];
+    const float4 a4 = S.rs_vert[(size_t)id.x * 2], b4 = S.rs_vert[(size_t)id.y * 2], c4 = S.rs_vert[(size_t)id.z * 2];
+    const f3 A = wf_to_camera(P, mk3(a4.x, a4.y, a4.z)), B = wf_to_camera(P, mk3(b4.x, b4.y, b4.z)), C = wf_to_camera(P, mk3(c4.x, c4.y, c4.z));
+    return wf_triangle_line(P.W, P.H, P.SD, P.clip_z, A, B, C, slot, x1, y1, x2, y2);
+}
+
+struct WfCount {
+    int W, H; uint32_t n;
+    MI_DEV void operator()(int x, int y, uint32_t) { if (x >= 0 && x < W && y >= 0 && y < H) n++; }
+};
+struct WfEmit {
+    int W, H; uint64_t *keys; uint64_t line; uint32_t pos;
+    MI_DEV void operator()(int x, int y, uint32_t alpha)
+    {
+        if (!(x >= 0 && x < W && y >= 0 && y < H)) return;
+        keys[pos] = ((uint64_t)((uint32_t)y * (uint32_t)W + (uint32_t)x) << WF_PIXEL_SHIFT) | (line << WF_LINE_SHIFT) | ((uint64_t)pos_in_line() << WF_POS_SHIFT) | (uint64_t)alpha;
+        pos++;
+    }
+    uint32_t first;
+    MI_DEV uint32_t pos_in_line() const { return pos - first; }
+};
+
+__global__ void __launch_bounds__(256) k_wf_count(const DevScene S, const FrameParams P, uint32_t *counts)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= S.n_tris * 3u) return;
+    int16_t x1, y1, x2, y2;
+    WfCount c{P.W, P.H, 0u};
+    if (wf_line_of(S, P, i / 3u, (int)(i % 3u), x1, y1, x2, y2)) wf_aaline(P.W, P.H, x1, y1, x2, y2, c);
+    counts[i] = c.n;
+}
+
+__global__ void __launch_bounds__(256) k_wf_emit(const DevScene S, const FrameParams P, const uint32_t *offsets, uint64_t *keys)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= S.n_tris * 3u) return;
+    int16_t x1, y1, x2, y2;
+    if (!wf_line_of(S, P, i / 3u, (int)(i % 3u), x1, y1, x2, y2)) return;
+    WfEmit e{P.W, P.H, keys, (uint64_t)i, offsets[i], offsets[i]};
+    wf_aaline(P.W, P.H, x1, y1, x2, y2, e);
+}
+
+// y -> output row, or -1 when the row belongs to another GPU's band
+MI_DEV int wf_out_row(const FrameParams &P, int y)
+{
+    if (P.band_count <= 1 || P.band_rows <= 0) return y;
+    const int b = y / P.band_rows;
+    if (b % P.band_count != P.band_index) return -1;
+    return P.compact ? (b / P.band_count) * P.band_rows + (y - b * P.band_rows) : y;
+}
+
+__global__ void __launch_bounds__(256) k_wf_apply(const FrameParams P, const uint64_t *keys, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pixel = (uint32_t)(keys[i] >> WF_PIXEL_SHIFT);
+    if (i > 0 && (uint32_t)(keys[i - 1] >> WF_PIXEL_SHIFT) == pixel) return;          // not the first operation of its pixel
+    uint32_t v = 0u;                                                                  // Screen::ClearScreen
+    for (uint32_t j = i; j < n && (uint32_t)(keys[j] >> WF_PIXEL_SHIFT) == pixel; j++) v = wf_blend(v, (uint32_t)(keys[j] & 0xffu));
+    const int y = (int)(pixel / (uint32_t)P.W), x = (int)(pixel % (uint32_t)P.W);
+    const int r = wf_out_row(P, y);
+    if (r >= 0) P.out[(size_t)r * P.pitch_words + x] = v;
+}
+
+} // namespace
+
+struct WireScratch {
+    uint32_t *counts = nullptr, *offsets = nullptr; size_t lines_cap = 0;
+    uint64_t *keys[2] = {nullptr, nullptr}; size_t keys_cap = 0;
+    void *temp = nullptr; size_t temp_cap = 0;
+};
+
+extern "C" WireScratch *mi355i_wire_scratch_create(void) { return new WireScratch(); }
+extern "C" void mi355i_wire_scratch_destroy(WireScratch *w)
+{
+    if (!w) return;
+    for (void *p : {(void *)w->counts, (void *)w->offsets, (void *)w->keys[0], (void *)w->keys[1], w->temp}) if (p) (void)hipFree(p);
+    delete w;
+}
+
+// can this frame / scene be drawn?  (the fields of the sort key)
+extern "C" int mi355i_wireframe_fits(int W, int H, uint32_t n_tris)
+{
+    return W <= 4095 && H <= 4095 && (long long)W * H <= (1ll << 23) && (unsigned long long)n_tris * 3ull < (1ull << 20);
+}
+
+// One frame.  Synchronises `st` once (the number of pixel operations sizes the key buffers).
+extern "C" hipError_t mi355i_launch_wireframe(const DevScene *S, const FrameParams *P, WireScratch *w, hipStream_t st)
+{
+    hipError_t e = hipMemset2DAsync(P->out, (size_t)P->pitch_words * 4, 0, (size_t)P->W * 4, (size_t)P->out_rows, st);
+    if (e != hipSuccess) return e;
+    const size_t n_lines = (size_t)S->n_tris * 3;
+    if (n_lines == 0) return hipSuccess;
+    if (n_lines + 1 > w->lines_cap) {
+        if (w->counts) (void)hipFree(w->counts);
+        if (w->offsets) (void)hipFree(w->offsets);
+        w->counts = w->offsets = nullptr; w->lines_cap = 0;
+        if ((e = hipMalloc((void **)&w->counts, (n_lines + 1) * 4)) != hipSuccess) return e;
+        if ((e = hipMalloc((void **)&w->offsets, (n_lines + 1) * 4)) != hipSuccess) return e;
+        w->lines_cap = n_lines + 1;
+    }
+    auto temp_for = [&](size_t bytes) -> hipError_t {
+        if (bytes <= w->temp_cap) return hipSuccess;
+        if (w->temp) (void)hipFree(w->temp);
+        w->temp = nullptr; w->temp_cap = 0;
+        const hipError_t r = hipMalloc(&w->temp, bytes);
+        if (r == hipSuccess) w->temp_cap = bytes;
+        return r;
+    };
+    const unsigned nb = (unsigned)((n_lines + 255) / 256);
+    hipLaunchKernelGGL(k_wf_count, dim3(nb), dim3(256), 0, st, *S, *P, w->counts);
+    if ((e = hipMemsetAsync(w->counts + n_lines, 0, 4, st)) != hipSuccess) return e;      // (the scan's last output = the total)
+    size_t tb = 0;
+    if ((e = rocprim::exclusive_scan(nullptr, tb, w->counts, w->offsets, 0u, n_lines + 1, rocprim::plus<uint32_t>(), st)) != hipSuccess) return e;
+    if ((e = temp_for(tb)) != hipSuccess) return e;
+    if ((e = rocprim::exclusive_scan(w->temp, tb, w->counts, w->offsets, 0u, n_lines + 1, rocprim::plus<uint32_t>(), st)) != hipSuccess) return e;
+    uint32_t n_ops = 0;
+    if ((e = hipMemcpyAsync(&n_ops, w->offsets + n_lines, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    if (n_ops == 0) return hipSuccess;
+    if (n_ops > w->keys_cap) {
+        for (int k = 0; k < 2; k++) { if (w->keys[k]) (void)hipFree(w->keys[k]); w->keys[k] = nullptr; }
+        w->keys_cap = 0;
+        const size_t cap = (size_t)n_ops + n_ops / 4 + 1024;
+        for (int k = 0; k < 2; k++) if ((e = hipMalloc((void **)&w->keys[k], cap * 8)) != hipSuccess) return e;
+        w->keys_cap = cap;
+    }
+    hipLaunchKernelGGL(k_wf_emit, dim3(nb), dim3(256), 0, st, *S, *P, w->offsets, w->keys[0]);
+    tb = 0;
+    if ((e = rocprim::radix_sort_keys(nullptr, tb, w->keys[0], w->keys[1], (size_t)n_ops, 0u, 64u, st)) != hipSuccess) return e;
+    if ((e = temp_for(tb)) != hipSuccess) return e;
+    if ((e = rocprim::radix_sort_keys(w->temp, tb, w->keys[0], w->keys[1], (size_t)n_ops, 0u, 64u, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_wf_apply, dim3((n_ops + 255u) / 256u), dim3(256), 0, st, *P, w->keys[1], n_ops);
+    return hipGetLastError();
+}

@@ -470,7 +470,9 @@ def test_errors_are_reported_not_swallowed(gpu_scene):
         hs.render(9, cam, lights, n, R.default_opts(64, 48))
     with pytest.raises(R.Mi355Error, match="shadow map"):
         hs.render(8, cam, lights, n, R.default_opts(64, 48))
+    with pytest.raises(R.Mi355Error, match="unknown render mode"):
+        hs.render(11, cam, lights, n, R.default_opts(64, 48))
     with pytest.raises(R.Mi355Error, match="wireframe"):
-        hs.render(3, cam, lights, n, R.default_opts(64, 48))
+        hs.render(3, cam, lights, n, R.default_opts(4096, 16))         # beyond the sort key's fields
     with pytest.raises(R.Mi355Error):
         hs.render(6, cam, lights, n, R.default_opts(0, 48))
