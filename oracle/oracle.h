@@ -15,6 +15,9 @@
  * rasterizer's span walk and plotters, the builder on big meshes): the SHA-256 frame
  * pins, counters, camera probes and BVH statistics that SURVEY.md 8(c)/8(d) recorded
  * from the reference -- survey provenance, see tests/test_oracle_pins.py.
+ * (3) PARITY UNPINNED for mode 3 alone: the wireframe's lines (Wu.cc, SDL_gfx's code) call SDL_MapRGBA of the SDL library
+ * per pixel, so they cannot be built into refcore, and the survey recorded no frame of that mode; orc_render(mode 3) and
+ * orc_wu_lines restate the code as read.
  * The vendored lib3ds is built too (oracle/ref3ds): it pins the product's .3ds reader
  * and made the .r3ds dump this oracle loads for .3ds models.
  */
