@@ -596,12 +596,19 @@ MI_HD void rs_tile_filter(const RsBuffers &B, uint32_t frame, int tx, int ty, co
     uint32_t end = first + RS_LIST_CAP;
     if (end > n) end = n;
     const uint4 *bins = B.bins + (size_t)frame * B.bins_cap;
-    for (uint32_t e = first + (uint32_t)tid; e < end; e += (uint32_t)nt) {
-        const uint4 b = bins[L.pos(e)];
-        const int tx0 = (int)(b.y & 0xffffu), tx1 = (int)(b.y >> 16), ty0 = (int)(b.z & 0xffffu) / RS_TH, ty1 = (int)(b.z >> 16) / RS_TH;
-        if (tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1) {
-            uint32_t *li = lds.list[RS_ATOMIC_ADD_U32(&lds.n_list, 1u)];
-            li[0] = b.x; li[1] = b.z; li[2] = b.w;
+    // (four entries per thread in flight: the heaviest tiles read ~1700 entries, one memory round trip per step otherwise)
+    for (uint32_t e0 = first + (uint32_t)tid; e0 < end; e0 += 4u * (uint32_t)nt) {
+        uint4 b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t e = e0 + (uint32_t)u * (uint32_t)nt; if (e < end) b[u] = bins[L.pos(e)]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (e0 + (uint32_t)u * (uint32_t)nt >= end) break;
+            const int tx0 = (int)(b[u].y & 0xffffu), tx1 = (int)(b[u].y >> 16), ty0 = (int)(b[u].z & 0xffffu) / RS_TH, ty1 = (int)(b[u].z >> 16) / RS_TH;
+            if (tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1) {
+                uint32_t *li = lds.list[RS_ATOMIC_ADD_U32(&lds.n_list, 1u)];
+                li[0] = b[u].x; li[1] = b[u].z; li[2] = b[u].w;
+            }
         }
     }
 }
@@ -627,7 +634,42 @@ MI_HD const float4 *rs_band_of(const RsBuffers &B, uint32_t frame, int miny, uin
     return B.band + ((size_t)frame * B.band_cap + idx) * RS_BAND4;
 }
 
-// phase 2b: one work item = one scanline of one triangle: Screen.h:244-290 restricted to the tile's columns, depth only
+// phase 2b: one work item = one scanline of one triangle: Screen.h:244-290 restricted to the tile's columns, depth only.
+// What an item reads from memory -- the triangle's three scanline numbers and, per edge, the walker's x and 1/z with their
+// steps on the band's first scanline -- is fetched one item AHEAD: the heaviest tiles give a thread ~20 items, and a
+// dependent memory round trip per item was most of the phase.
+struct RsDepthItem {
+    uint32_t tri; int row; bool skip;
+    int iy[3];
+    float bw[3][4];            // per edge: x, dx, 1/z, d(1/z) of the band record
+    const float *rec;
+};
+
+// rs_row_from_band<1> on the prefetched words of a band record
+MI_HD uint32_t rs_row_from_item(const RsDepthItem &it, int zi, int height, int y, float (&l)[2], float (&r)[2])
+{
+    const int Y0 = (y / RS_BH) * RS_BH;
+    uint32_t cnt = 0;
+    l[0] = l[1] = r[0] = r[1] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        const int ia = rs_edge_a(e), ib = rs_edge_b(e);
+        const RsEdgeRange R = rs_edge_range(it.iy[ia], it.iy[ib], height);
+        if (y < R.first || y > R.last) continue;
+        if (R.horiz) {
+            const float pa[2] = {it.rec[8 * ia], it.rec[8 * ia + zi]}, pb[2] = {it.rec[8 * ib], it.rec[8 * ib + zi]};
+            scan_add_n<1>(l, r, cnt, pa); scan_add_n<1>(l, r, cnt, pb);
+            continue;
+        }
+        const int rb = R.first > Y0 ? R.first : Y0;
+        float v[2] = {it.bw[e][0], it.bw[e][2]};
+        const float d[2] = {it.bw[e][1], it.bw[e][3]};
+        for (int j = y - rb; j > 0; j--) { v[0] += d[0]; v[1] += d[1]; }
+        scan_add_n<1>(l, r, cnt, v);
+    }
+    return cnt;
+}
+
 template <int MODE>
 MI_HD void rs_tile_depth(const FrameParams &P, const RsBuffers &B, uint32_t n_tris, uint32_t frame, int tx, int ty, uint32_t chunk, int parity,
                          RsTileLds &lds, int tid, int nt, unsigned long long &ztests)
@@ -636,32 +678,51 @@ MI_HD void rs_tile_depth(const FrameParams &P, const RsBuffers &B, uint32_t n_tr
     const int W = P.W, H = P.H;
     const int X0 = tx * RS_TW, X1 = (X0 + RS_TW < W ? X0 + RS_TW : W) - 1;
     const uint32_t n = lds.n_items[parity];
-    for (uint32_t it = (uint32_t)tid; it < n; it += (uint32_t)nt) {
-        const uint32_t item = lds.items[it];
+    auto fetch = [&](uint32_t i, RsDepthItem &q) {
+        const uint32_t item = lds.items[i];
         const uint32_t *li = lds.list[chunk + (item >> 4)];
-        const int row = (int)(item & 15u), y = ty * RS_TH + row;
-        if (rs_out_row(P, y) < 0) continue;              // another GPU's band
-        const uint32_t tri = li[0];
-        const float *rec = (const float *)(B.rec + ((size_t)frame * n_tris + tri) * RS_REC4);
-        const int iy[3] = {(int)ff_f2u(rec[24]), (int)ff_f2u(rec[25]), (int)ff_f2u(rec[26])};
-        float l[2], r[2];
-        const uint32_t cnt = rs_row_from_band<1>(iy, rs_band_of(B, frame, (int)(li[1] & 0xffffu), li[2], y), rec, ZI, 1, H, y, l, r);
-        if (!cnt) continue;
-        RsSpan s;
-        if (!rs_span(l[0], r[0], cnt, W, s)) continue;
-        int xa = s.x1 > X0 ? s.x1 : X0, xb = s.x1 + s.steps < X1 ? s.x1 + s.steps : X1;
-        if (xa > xb) continue;
-        const unsigned long long trikey = (unsigned long long)(0xffffffffu - tri);
-        unsigned long long *krow = lds.keys + row * RS_TW - X0;
-        float d = 0.f, z = l[1];
-        if (!s.single) z = rs_span_value(s, l[1], r[1], xa - s.x1, d);
-        for (int x = xa;; x++) {
-            ztests++;
-            if (z > 0.f)                                 // only 1/z > 0 can beat the cleared Z-buffer (Screen.h:209)
-                RS_ATOMIC_MAX_U64(&krow[x], ((unsigned long long)ff_f2u(z) << 32) | trikey);
-            if (x == xb) break;
-            z += d;
+        q.row = (int)(item & 15u);
+        const int y = ty * RS_TH + q.row;
+        q.skip = rs_out_row(P, y) < 0;                  // another GPU's band
+        q.tri = li[0];
+        q.rec = (const float *)(B.rec + ((size_t)frame * n_tris + q.tri) * RS_REC4);
+        const float *band = (const float *)rs_band_of(B, frame, (int)(li[1] & 0xffffu), li[2], y);
+        q.iy[0] = (int)ff_f2u(q.rec[24]); q.iy[1] = (int)ff_f2u(q.rec[25]); q.iy[2] = (int)ff_f2u(q.rec[26]);
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            const float *be = band + e * 16;
+            q.bw[e][0] = be[0]; q.bw[e][1] = be[1]; q.bw[e][2] = be[2 * ZI]; q.bw[e][3] = be[2 * ZI + 1];
         }
+    };
+    RsDepthItem cur, nxt;
+    uint32_t it = (uint32_t)tid;
+    if (it < n) fetch(it, cur);
+    for (; it < n; it += (uint32_t)nt) {
+        const bool more = it + (uint32_t)nt < n;
+        if (more) fetch(it + (uint32_t)nt, nxt);
+        do {
+            if (cur.skip) break;
+            const int row = cur.row, y = ty * RS_TH + row;
+            float l[2], r[2];
+            const uint32_t cnt = rs_row_from_item(cur, ZI, H, y, l, r);
+            if (!cnt) break;
+            RsSpan s;
+            if (!rs_span(l[0], r[0], cnt, W, s)) break;
+            int xa = s.x1 > X0 ? s.x1 : X0, xb = s.x1 + s.steps < X1 ? s.x1 + s.steps : X1;
+            if (xa > xb) break;
+            const unsigned long long trikey = (unsigned long long)(0xffffffffu - cur.tri);
+            unsigned long long *krow = lds.keys + row * RS_TW - X0;
+            float d = 0.f, z = l[1];
+            if (!s.single) z = rs_span_value(s, l[1], r[1], xa - s.x1, d);
+            for (int x = xa;; x++) {
+                ztests++;
+                if (z > 0.f)                                 // only 1/z > 0 can beat the cleared Z-buffer (Screen.h:209)
+                    RS_ATOMIC_MAX_U64(&krow[x], ((unsigned long long)ff_f2u(z) << 32) | trikey);
+                if (x == xb) break;
+                z += d;
+            }
+        } while (0);
+        if (more) cur = nxt;
     }
 }
 
