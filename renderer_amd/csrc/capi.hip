@@ -138,12 +138,14 @@ struct mi355_ctx {
     DevBuf bvh_prim, bvh_list[2], bvh_lvl[2], bvh_tree, bvh_cnt;   // mi355_build_bvh work buffers (kept for rebuilds)
     DevBuf bvh_big[2], bvh_task[2], bvh_gthr[2], bvh_gbin, bvh_tcnt, bvh_choff, bvh_num[5], bvh_out, bvh_in_td, bvh_in_te;
     bool bvh_inputs_ready = false;
-    // raster frames of the device entry points are pipelined: two scratch sets take turns, setup + fill of a frame run on
+    // raster frames of the device entry points are pipelined: three scratch sets take turns, setup + fill of a frame run on
     // `pre` beside the tile kernel of the frame before (enqueue_frame)
-    RasterScratch *rs_pipe[2] = {nullptr, nullptr};
+    enum { PIPE_SETS = 3 };          // (two sets tie a frame's setup to the end of the tile kernel two frames back: measured, the
+                                     //  setup / fill stream then is the critical path; with three it runs a frame ahead)
+    RasterScratch *rs_pipe[PIPE_SETS] = {nullptr, nullptr, nullptr};
     hipStream_t pre = nullptr;
-    hipEvent_t ev_fill[2] = {nullptr, nullptr}, ev_tile[2] = {nullptr, nullptr};
-    bool ev_tile_set[2] = {false, false};
+    hipEvent_t ev_fill[PIPE_SETS] = {nullptr, nullptr, nullptr}, ev_tile[PIPE_SETS] = {nullptr, nullptr, nullptr};
+    bool ev_tile_set[PIPE_SETS] = {false, false, false};
     int pipe_turn = 0;
     DevBuf cull_boxes, tile_sel;     // boxes of the tree's top (tile culling of raytraced frames) and the culled tile lists of the frame in flight
     int n_cull_boxes = 0;
@@ -585,7 +587,7 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
         if (raster_self_clear && rs == c->rscratch && c->pre && !P.no_pipe) {
             // pipelined: this frame's setup + fill on `pre` while `st` still runs the previous frame's tile kernel; the events
             // ride on the kernels' own completion signals (no marker packets between the tile kernels of `st`)
-            const int k = c->pipe_turn; c->pipe_turn ^= 1;
+            const int k = c->pipe_turn; c->pipe_turn = (c->pipe_turn + 1) % mi355_ctx::PIPE_SETS;
             if (c->ev_tile_set[k]) HIP_TRY(hipStreamWaitEvent(c->pre, c->ev_tile[k], 0), -40);     // the set's last user is done
             e = mi355i_launch_raster_pipelined(&c->dev, &P, mode, c->rs_pipe[k], st, c->pre, c->ev_fill[k], c->ev_tile[k]);
             if (e == hipSuccess) c->ev_tile_set[k] = true;
@@ -593,7 +595,7 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
         }
         // (a frame outside the pipeline -- counting frames -- first lets the pipelined frames on other streams finish with
         //  the scratch it is about to use)
-        if (rs == c->rscratch) for (int k = 0; k < 2; k++) if (c->ev_tile_set[k]) HIP_TRY(hipStreamWaitEvent(st, c->ev_tile[k], 0), -40);
+        if (rs == c->rscratch) for (int k = 0; k < mi355_ctx::PIPE_SETS; k++) if (c->ev_tile_set[k]) HIP_TRY(hipStreamWaitEvent(st, c->ev_tile[k], 0), -40);
         e = mi355i_launch_raster(&c->dev, &P, mode, rs, st);
         // (... and the next pipelined frame that takes this scratch set waits for this one)
         if (e == hipSuccess && rs == c->rscratch && c->pre) { HIP_TRY(hipEventRecord(c->ev_tile[0], st), -40); c->ev_tile_set[0] = true; }
@@ -764,10 +766,11 @@ mi355_ctx *mi355_scene_create(const mi355_scene_desc *d, int device)
     c->rscratch = mi355i_raster_scratch_create();
     // the raster pipeline of the device entry points: the context's scratch set and a second one, a stream for the
     // setup / fill kernels, events ordering the two streams (if any of this fails the frames simply are not pipelined)
-    c->rs_pipe[0] = c->rscratch; c->rs_pipe[1] = mi355i_raster_scratch_create();
-    if (c->rs_pipe[1] && hipStreamCreateWithFlags(&c->pre, hipStreamNonBlocking) == hipSuccess) {
+    c->rs_pipe[0] = c->rscratch;
+    for (int k = 1; k < mi355_ctx::PIPE_SETS; k++) c->rs_pipe[k] = mi355i_raster_scratch_create();
+    if (c->rs_pipe[1] && c->rs_pipe[2] && hipStreamCreateWithFlags(&c->pre, hipStreamNonBlocking) == hipSuccess) {
         bool ok = true;
-        for (int k = 0; k < 2; k++)
+        for (int k = 0; k < mi355_ctx::PIPE_SETS; k++)
             ok = ok && hipEventCreateWithFlags(&c->ev_fill[k], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&c->ev_tile[k], hipEventDisableTiming) == hipSuccess;
         if (!ok) { (void)hipStreamDestroy(c->pre); c->pre = nullptr; }
@@ -805,8 +808,8 @@ void mi355_scene_destroy(mi355_ctx *c)
     for (auto &h : c->host_reg) if (h.p) (void)hipHostUnregister(h.p);
     if (c->rscratch) mi355i_raster_scratch_destroy(c->rscratch);
     if (c->wscratch) mi355i_wire_scratch_destroy(c->wscratch);
-    if (c->rs_pipe[1]) mi355i_raster_scratch_destroy(c->rs_pipe[1]);
-    for (int k = 0; k < 2; k++) { if (c->ev_fill[k]) (void)hipEventDestroy(c->ev_fill[k]); if (c->ev_tile[k]) (void)hipEventDestroy(c->ev_tile[k]); }
+    for (int k = 1; k < mi355_ctx::PIPE_SETS; k++) if (c->rs_pipe[k]) mi355i_raster_scratch_destroy(c->rs_pipe[k]);
+    for (int k = 0; k < mi355_ctx::PIPE_SETS; k++) { if (c->ev_fill[k]) (void)hipEventDestroy(c->ev_fill[k]); if (c->ev_tile[k]) (void)hipEventDestroy(c->ev_tile[k]); }
     if (c->pre) (void)hipStreamDestroy(c->pre);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1012,7 +1015,7 @@ int mi355_render_batch_device(mi355_ctx *c, int mode, int n_frames, const mi355_
         std::vector<FrameParams> frames((size_t)n_frames);
         for (int f = 0; f < n_frames; f++)
             if (int r = fill_params(c, mode, &cams[f], lights + (size_t)f * n_lights, n_lights, o, d_out[f], pitch_bytes, nullptr, frames[f])) return r;
-        for (int k = 0; k < 2; k++) if (c->ev_tile_set[k]) HIP_TRY(hipStreamWaitEvent(user, c->ev_tile[k], 0), -40);   // (pipelined single frames still using the scratch)
+        for (int k = 0; k < mi355_ctx::PIPE_SETS; k++) if (c->ev_tile_set[k]) HIP_TRY(hipStreamWaitEvent(user, c->ev_tile[k], 0), -40);   // (pipelined single frames still using the scratch)
         hipError_t e = mi355i_launch_raster_batch(&c->dev, frames.data(), n_frames, mode, c->rscratch, user);
         if (e != hipSuccess) return fail(-43, "kernel launch failed: %s", hipGetErrorString(e));
         if (c->pre) { HIP_TRY(hipEventRecord(c->ev_tile[0], user), -40); c->ev_tile_set[0] = true; }
@@ -1086,7 +1089,7 @@ int mi355_fetch_stats(mi355_ctx *c, mi355_stats *s)
         // the frame is incomplete; the next one gets span buffers twice as large (mi355_render retries by itself)
         HIP_TRY(hipMemset((char *)c->ctrl.p + 16 + sizeof(unsigned long long) * CS_OVERFLOW, 0, sizeof(unsigned long long)), -31);
         int grown = mi355i_raster_grow(c->rscratch);
-        for (int k = 0; k < 2; k++) if (c->rs_pipe[k] && c->rs_pipe[k] != c->rscratch) grown |= mi355i_raster_grow(c->rs_pipe[k]);
+        for (int k = 0; k < mi355_ctx::PIPE_SETS; k++) if (c->rs_pipe[k] && c->rs_pipe[k] != c->rscratch) grown |= mi355i_raster_grow(c->rs_pipe[k]);
         return fail(-44, "rasterizer triangle bins overflowed (%llu entries dropped)%s", h[CS_OVERFLOW],
                     grown ? "; the buffers grow for the next frame" : "");
     }
