@@ -33,7 +33,7 @@ def test_bad_options_are_refused(scene, kw):
     assert not out.any()
 
 
-@pytest.mark.parametrize("mode", [0, 3, 11, -1, 100])
+@pytest.mark.parametrize("mode", [0, 11, -1, 100])
 def test_unknown_or_unsupported_modes_are_refused(scene, mode):
     cam, lights, n = R.benchmark_frame(0)
     with pytest.raises(R.Mi355Error):
