@@ -94,8 +94,11 @@ typedef struct {
      *            | 8 (debug) counting frames profile the ordered walk: counters then describe that walk
      *            | 16 hand out every 8x8 tile of a raytraced frame (default: tiles whose camera rays cannot reach any of the
      *            boxes at the top of the tree are not traced at all; they are black either way)
-     *            | 32 raster frames of the device entry points: all three kernels on the caller's stream (default: setup and fill
-     *            of a frame run on an internal stream beside the previous frame's tile kernel)
+     *            | 32 raster frames of the device entry points: all three kernels on the caller's stream (default: consecutive
+     *            frames overlap -- each runs on one of three internal streams into a buffer of the library's, and the caller's
+     *            stream copies it to the caller's frame buffer, which holds the frame in stream order as always)
+     *            | 64 the round-2 pipeline instead: setup and fill of a frame on an internal stream beside the previous frame's
+     *            tile kernel, the tile kernels in order on the caller's stream
      * [6], [7] reserved */
     int32_t tune[8];
     /* Compile-time extras of the reference, off by default like there: */

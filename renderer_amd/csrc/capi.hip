@@ -44,6 +44,7 @@ extern "C" int mi355i_wireframe_fits(int W, int H, uint32_t n_tris);
 extern "C" hipError_t mi355i_launch_wireframe(const DevScene *S, const FrameParams *P, WireScratch *w, hipStream_t st);
 extern "C" hipError_t mi355i_launch_raster_pipelined(const DevScene *S, const FrameParams *P, int mode, RasterScratch *s, hipStream_t st,
                                                      hipStream_t pre, hipEvent_t fill_done, hipEvent_t tile_done);
+extern "C" hipError_t mi355i_launch_frame_copy(uint32_t *dst, const uint32_t *src, int W, int rows, int pitch_words, hipStream_t st, hipEvent_t done);
 extern "C" int mi355i_raster_grow(RasterScratch *);
 
 namespace {
@@ -140,13 +141,34 @@ struct mi355_ctx {
     bool bvh_inputs_ready = false;
     // raster frames of the device entry points are pipelined: three scratch sets take turns, setup + fill of a frame run on
     // `pre` beside the tile kernel of the frame before (enqueue_frame)
-    enum { PIPE_SETS = 3 };          // (two sets tie a frame's setup to the end of the tile kernel two frames back: measured, the
+    enum { PIPE_SETS = 4 };          // (two sets tie a frame's setup to the end of the tile kernel two frames back: measured, the
                                      //  setup / fill stream then is the critical path; with three it runs a frame ahead)
-    RasterScratch *rs_pipe[PIPE_SETS] = {nullptr, nullptr, nullptr};
+    RasterScratch *rs_pipe[PIPE_SETS] = {};
+    int n_pipe = 3;                  // sets in use (the ordered pipeline: at most three)
     hipStream_t pre = nullptr;
-    hipEvent_t ev_fill[PIPE_SETS] = {nullptr, nullptr, nullptr}, ev_tile[PIPE_SETS] = {nullptr, nullptr, nullptr};
-    bool ev_tile_set[PIPE_SETS] = {false, false, false};
+    hipEvent_t ev_fill[PIPE_SETS] = {}, ev_tile[PIPE_SETS] = {};
+    bool ev_tile_set[PIPE_SETS] = {};
     int pipe_turn = 0;
+    // ... or, the default, whole frames overlap: set k's three kernels run on its own stream into the set's own frame
+    // buffer, and the caller's stream only copies that buffer to the caller's (the tile kernels of consecutive frames then
+    // do not wait for each other: a dependency that crosses streams costs ~10 us on this stack, a fifth of a frame)
+    // The frames' streams are picked from PIPE_CANDS candidates so that no two of them, and none and the caller's stream,
+    // share a hardware queue: the runtime spreads all streams of the process over four queues, and streams that share one
+    // run in submission order -- a frame stream behind the caller's stream sits behind that stream's waits (measured: 16 k
+    // fps with one such stream among three, 26 k with none).  Which streams share is not something the runtime tells:
+    // probe_queues() measures it (a 200 us spin kernel on one stream, empty kernels on the others, device time stamps).
+    enum { PIPE_CANDS = 8 };
+    hipStream_t cand_st[PIPE_CANDS] = {};
+    int cand_class[PIPE_CANDS] = {}, n_class = -1;      // candidates with the same class share a queue (-1: not probed yet)
+    hipEvent_t ev_probe[PIPE_CANDS + 1] = {};
+    struct PipeChoice { hipStream_t caller; int n; int cand[PIPE_SETS]; };
+    std::vector<PipeChoice> pipe_choice;                // per caller's stream: the candidates that carry its frames
+    hipStream_t pipe_st[PIPE_SETS] = {};                // the stream set k's last frame ran on
+    // (two frame buffers per set: the set's next frame does not wait for the copy of its last one)
+    hipEvent_t ev_copy[2 * PIPE_SETS] = {};
+    bool ev_copy_set[2 * PIPE_SETS] = {}, ev_tile_ext[PIPE_SETS] = {};
+    int fb_turn[PIPE_SETS] = {};
+    DevBuf pipe_fb[2 * PIPE_SETS];
     DevBuf cull_boxes, tile_sel;     // boxes of the tree's top (tile culling of raytraced frames) and the culled tile lists of the frame in flight
     int n_cull_boxes = 0;
     PinBuf pin_walk, pin_edge, pin_shade, pin_tree, pin_list, pin_ctl;   // host staging of the BVH streams and the builder
@@ -308,7 +330,7 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.ref_order = (flags & 4) ? 1 : 0;
     P.prof_ordered = (flags & 8) ? 1 : 0;
     P.no_cull = (flags & 16) ? 1 : 0;
-    P.no_pipe = (flags & 32) ? 1 : 0;
+    P.no_pipe = (flags & 32) ? 1 : (flags & 64) ? 2 : 0;
     P.tile_sel = nullptr; P.tile_cnt = nullptr;
     P.blocks_per_cu = t[4] > 0 ? t[4] : 0;
     P.rs_threads = t[3];
@@ -564,6 +586,76 @@ int upload_cull_boxes(mi355_ctx *c, const void *nodes32B, uint32_t nN)
     return 0;
 }
 
+// ---- which streams share a hardware queue (see mi355_ctx::cand_st) -------------------------------------------------
+__global__ void k_probe_spin(unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    for (int i = 0; i < (1 << 16) && wall_clock64() - t0 < ticks; i++) __builtin_amdgcn_s_sleep(16);      // (bounded either way)
+}
+__global__ void k_probe_touch() {}
+
+// `a` spins for 200 us; every stream of `others` gets an empty kernel.  shared[j] = that kernel ended after the spin did,
+// i.e. others[j] runs behind `a`: same hardware queue.  (Device time stamps: the host's scheduling does not enter.)
+static bool probe_queues(mi355_ctx *c, hipStream_t a, const hipStream_t *others, int n, bool *shared)
+{
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
+    hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, a, (unsigned long long)khz / 5ull);              // 200 us
+    if (hipEventRecord(c->ev_probe[mi355_ctx::PIPE_CANDS], a) != hipSuccess) return false;
+    for (int j = 0; j < n; j++) {
+        hipLaunchKernelGGL(k_probe_touch, dim3(1), dim3(64), 0, others[j]);
+        if (hipEventRecord(c->ev_probe[j], others[j]) != hipSuccess) return false;
+    }
+    if (hipEventSynchronize(c->ev_probe[mi355_ctx::PIPE_CANDS]) != hipSuccess) return false;
+    for (int j = 0; j < n; j++) {
+        float ms = 0.f;
+        if (hipEventSynchronize(c->ev_probe[j]) != hipSuccess || hipEventElapsedTime(&ms, c->ev_probe[mi355_ctx::PIPE_CANDS], c->ev_probe[j]) != hipSuccess) return false;
+        shared[j] = ms > -0.1f;           // (not shared: it ended ~190 us BEFORE the spin did)
+    }
+    return hipGetLastError() == hipSuccess;
+}
+
+// The frame streams for raster frames the caller enqueues on `st`: one candidate of every queue class but st's own (at most
+// PIPE_SETS).  Probed once per context (the classes) and once per caller's stream; nullptr = probing failed, fewer than
+// two = the ordered pipeline is used instead.
+static const mi355_ctx::PipeChoice *pipe_streams_for(mi355_ctx *c, hipStream_t st)
+{
+    for (const auto &pc : c->pipe_choice) if (pc.caller == st) return &pc;
+    const int N = mi355_ctx::PIPE_CANDS;
+    // (frames of another caller's stream may still be running on the candidates: the probe must find them idle)
+    for (int i = 0; i < N; i++) if (hipStreamSynchronize(c->cand_st[i]) != hipSuccess) return nullptr;
+    if (c->n_class < 0) {
+        int n_class = 0;
+        for (int i = 0; i < N; i++) c->cand_class[i] = -1;
+        for (int i = 0; i < N; i++) {
+            if (c->cand_class[i] >= 0) continue;
+            c->cand_class[i] = n_class;
+            hipStream_t others[N]; int idx[N], n = 0; bool shared[N];
+            for (int j = i + 1; j < N; j++) if (c->cand_class[j] < 0) { others[n] = c->cand_st[j]; idx[n++] = j; }
+            if (n > 0 && !probe_queues(c, c->cand_st[i], others, n, shared)) return nullptr;
+            for (int j = 0; j < n; j++) if (shared[j]) c->cand_class[idx[j]] = n_class;
+            n_class++;
+        }
+        c->n_class = n_class;
+    }
+    hipStream_t reps[N]; int rep_class[N], n = 0; bool shared[N];
+    for (int cl = 0; cl < c->n_class; cl++)
+        for (int i = 0; i < N; i++) if (c->cand_class[i] == cl) { reps[n] = c->cand_st[i]; rep_class[n++] = i; break; }
+    if (!probe_queues(c, st, reps, n, shared)) return nullptr;
+    mi355_ctx::PipeChoice pc; pc.caller = st; pc.n = 0;
+    for (int j = 0; j < n && pc.n < (int)mi355_ctx::PIPE_SETS; j++) if (!shared[j]) pc.cand[pc.n++] = rep_class[j];
+    if (getenv("MI355_PIPE_DEBUG")) {
+        fprintf(stderr, "mi355: stream %p: queue classes of the frame streams", (void *)st);
+        for (int i = 0; i < N; i++) fprintf(stderr, " %d", c->cand_class[i]);
+        fprintf(stderr, "; chosen");
+        for (int k = 0; k < pc.n; k++) fprintf(stderr, " %d", pc.cand[k]);
+        fprintf(stderr, "\n");
+    }
+    if (c->pipe_choice.size() >= 16) c->pipe_choice.erase(c->pipe_choice.begin());
+    c->pipe_choice.push_back(pc);
+    return &c->pipe_choice.back();
+}
+
 int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hipStream_t st, void *ctrl = nullptr, RasterScratch *rs = nullptr,
                   DevBuf *mlaa_scratch = nullptr, uint32_t *const *frame_outs = nullptr, DevBuf *sel = nullptr)
 {
@@ -583,14 +675,38 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
     case MI355_MODE_POINTS: e = mi355i_launch_points(&c->dev, &P, 0, st); break;
     case MI355_MODE_POINTS_FROM_TRIANGLES: e = mi355i_launch_points(&c->dev, &P, 1, st); break;
     case MI355_MODE_AMBIENT: case MI355_MODE_GOURAUD: case MI355_MODE_PHONG:
-    case MI355_MODE_PHONG_SHADOWMAPS: case MI355_MODE_PHONG_SOFTSHADOWMAPS:
-        if (raster_self_clear && rs == c->rscratch && c->pre && !P.no_pipe) {
+    case MI355_MODE_PHONG_SHADOWMAPS: case MI355_MODE_PHONG_SOFTSHADOWMAPS: {
+        const mi355_ctx::PipeChoice *pc = nullptr;
+        if (raster_self_clear && rs == c->rscratch && c->pre && !P.no_pipe && c->cand_st[0] && P.out_rows > 0) pc = pipe_streams_for(c, st);
+        if (pc && pc->n >= 2) {
+            // overlapped: the whole frame on one of the frame streams, into a frame buffer of the library's; `st` waits for the
+            // tile kernel and copies the frame to the caller's buffer
+            const int k = c->pipe_turn % pc->n; c->pipe_turn = (k + 1) % pc->n;
+            hipStream_t ps = c->cand_st[pc->cand[k]];
+            const int b = 2 * k + c->fb_turn[k]; c->fb_turn[k] ^= 1;
+            HIP_TRY(c->pipe_fb[b].ensure((size_t)P.pitch_words * (size_t)P.out_rows * 4), -31);
+            // (the scratch set's last frame ran on another stream: a frame of another caller's stream, of the ordered pipeline,
+            //  a counting frame, a batch)
+            if (c->ev_tile_set[k] && (c->ev_tile_ext[k] || c->pipe_st[k] != ps)) HIP_TRY(hipStreamWaitEvent(ps, c->ev_tile[k], 0), -40);
+            c->pipe_st[k] = ps;
+            if (c->ev_copy_set[b]) HIP_TRY(hipStreamWaitEvent(ps, c->ev_copy[b], 0), -40);                        // the frame buffer has been copied out
+            FrameParams Q = P;
+            Q.out = (uint32_t *)c->pipe_fb[b].p;
+            e = mi355i_launch_raster_pipelined(&c->dev, &Q, mode, c->rs_pipe[k], ps, ps, nullptr, c->ev_tile[k]);
+            if (e != hipSuccess) break;
+            c->ev_tile_set[k] = true; c->ev_tile_ext[k] = false;
+            HIP_TRY(hipStreamWaitEvent(st, c->ev_tile[k], 0), -40);
+            e = mi355i_launch_frame_copy(P.out, Q.out, P.W, P.out_rows, P.pitch_words, st, c->ev_copy[b]);
+            if (e == hipSuccess) c->ev_copy_set[b] = true;
+            break;
+        }
+        if (raster_self_clear && rs == c->rscratch && c->pre && P.no_pipe != 1) {
             // pipelined: this frame's setup + fill on `pre` while `st` still runs the previous frame's tile kernel; the events
             // ride on the kernels' own completion signals (no marker packets between the tile kernels of `st`)
-            const int k = c->pipe_turn; c->pipe_turn = (c->pipe_turn + 1) % mi355_ctx::PIPE_SETS;
+            const int k = c->pipe_turn % c->n_pipe; c->pipe_turn = (k + 1) % c->n_pipe;
             if (c->ev_tile_set[k]) HIP_TRY(hipStreamWaitEvent(c->pre, c->ev_tile[k], 0), -40);     // the set's last user is done
             e = mi355i_launch_raster_pipelined(&c->dev, &P, mode, c->rs_pipe[k], st, c->pre, c->ev_fill[k], c->ev_tile[k]);
-            if (e == hipSuccess) c->ev_tile_set[k] = true;
+            if (e == hipSuccess) { c->ev_tile_set[k] = true; c->ev_tile_ext[k] = true; }
             break;
         }
         // (a frame outside the pipeline -- counting frames -- first lets the pipelined frames on other streams finish with
@@ -598,8 +714,9 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
         if (rs == c->rscratch) for (int k = 0; k < mi355_ctx::PIPE_SETS; k++) if (c->ev_tile_set[k]) HIP_TRY(hipStreamWaitEvent(st, c->ev_tile[k], 0), -40);
         e = mi355i_launch_raster(&c->dev, &P, mode, rs, st);
         // (... and the next pipelined frame that takes this scratch set waits for this one)
-        if (e == hipSuccess && rs == c->rscratch && c->pre) { HIP_TRY(hipEventRecord(c->ev_tile[0], st), -40); c->ev_tile_set[0] = true; }
+        if (e == hipSuccess && rs == c->rscratch && c->pre) { HIP_TRY(hipEventRecord(c->ev_tile[0], st), -40); c->ev_tile_set[0] = true; c->ev_tile_ext[0] = true; }
         break;
+    }
     case MI355_MODE_RAYTRACE: case MI355_MODE_RAYTRACE_ANTIALIAS: {
         if (!c->has_bvh) return fail(-41, "raytrace modes need mi355_scene_set_bvh first");
         const int ordered = ((!stats || P.prof_ordered) && !P.ref_order && c->dev.ordered_ok) ? 1 : 0;
@@ -768,13 +885,23 @@ mi355_ctx *mi355_scene_create(const mi355_scene_desc *d, int device)
     // setup / fill kernels, events ordering the two streams (if any of this fails the frames simply are not pipelined)
     c->rs_pipe[0] = c->rscratch;
     for (int k = 1; k < mi355_ctx::PIPE_SETS; k++) c->rs_pipe[k] = mi355i_raster_scratch_create();
-    if (c->rs_pipe[1] && c->rs_pipe[2] && hipStreamCreateWithFlags(&c->pre, hipStreamNonBlocking) == hipSuccess) {
+    if (c->rs_pipe[1] && c->rs_pipe[2] && c->rs_pipe[3] && hipStreamCreateWithFlags(&c->pre, hipStreamNonBlocking) == hipSuccess) {
         bool ok = true;
         for (int k = 0; k < mi355_ctx::PIPE_SETS; k++)
             ok = ok && hipEventCreateWithFlags(&c->ev_fill[k], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&c->ev_tile[k], hipEventDisableTiming) == hipSuccess;
         if (!ok) { (void)hipStreamDestroy(c->pre); c->pre = nullptr; }
     } else c->pre = nullptr;
+    if (c->pre) {
+        // the frames' own streams have a priority of their own: the runtime hands out hardware queues per priority, and a
+        // frame stream that shares a queue with the caller's stream would sit behind that stream's waits (measured: every
+        // third frame stalled for a whole frame time)
+        bool ok = true;
+        for (int k = 0; k < mi355_ctx::PIPE_CANDS; k++) ok = ok && hipStreamCreateWithFlags(&c->cand_st[k], hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; k < 2 * mi355_ctx::PIPE_SETS; k++) ok = ok && hipEventCreateWithFlags(&c->ev_copy[k], hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k <= mi355_ctx::PIPE_CANDS; k++) ok = ok && hipEventCreate(&c->ev_probe[k]) == hipSuccess;
+        if (!ok) for (int k = 0; k < mi355_ctx::PIPE_CANDS; k++) { if (c->cand_st[k]) (void)hipStreamDestroy(c->cand_st[k]); c->cand_st[k] = nullptr; }
+    }
     c->dev.rs_tri = (const float4 *)c->rs_tri.p;
     c->dev.rs_col = (const float4 *)c->rs_col.p;
     c->dev.rs_idx = (const uint4 *)c->rs_idx.p;
@@ -792,7 +919,7 @@ void mi355_scene_destroy(mi355_ctx *c)
                       &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->mlaa, &c->cam_table, &c->wave_prof, &c->bvh_prim, &c->bvh_list[0], &c->bvh_list[1],
                       &c->bvh_lvl[0], &c->bvh_lvl[1], &c->bvh_tree, &c->bvh_cnt, &c->bvh_big[0], &c->bvh_big[1], &c->bvh_task[0], &c->bvh_task[1],
                       &c->bvh_gthr[0], &c->bvh_gthr[1], &c->bvh_gbin, &c->bvh_tcnt, &c->bvh_choff, &c->bvh_num[0], &c->bvh_num[1], &c->bvh_num[2],
-                      &c->bvh_num[3], &c->bvh_num[4], &c->bvh_out, &c->bvh_in_td, &c->bvh_in_te, &c->cull_boxes, &c->tile_sel})
+                      &c->bvh_num[3], &c->bvh_num[4], &c->bvh_out, &c->bvh_in_td, &c->bvh_in_te, &c->cull_boxes, &c->tile_sel, &c->pipe_fb[0], &c->pipe_fb[1], &c->pipe_fb[2], &c->pipe_fb[3], &c->pipe_fb[4], &c->pipe_fb[5], &c->pipe_fb[6], &c->pipe_fb[7]})
         b->release();
     for (PinBuf *b : {&c->pin_walk, &c->pin_edge, &c->pin_shade, &c->pin_tree, &c->pin_list, &c->pin_ctl}) b->release();
     for (auto &m : c->smap) m.release();
@@ -811,6 +938,9 @@ void mi355_scene_destroy(mi355_ctx *c)
     for (int k = 1; k < mi355_ctx::PIPE_SETS; k++) if (c->rs_pipe[k]) mi355i_raster_scratch_destroy(c->rs_pipe[k]);
     for (int k = 0; k < mi355_ctx::PIPE_SETS; k++) { if (c->ev_fill[k]) (void)hipEventDestroy(c->ev_fill[k]); if (c->ev_tile[k]) (void)hipEventDestroy(c->ev_tile[k]); }
     if (c->pre) (void)hipStreamDestroy(c->pre);
+    for (int k = 0; k < mi355_ctx::PIPE_CANDS; k++) if (c->cand_st[k]) { (void)hipStreamSynchronize(c->cand_st[k]); (void)hipStreamDestroy(c->cand_st[k]); }
+    for (int k = 0; k < 2 * mi355_ctx::PIPE_SETS; k++) if (c->ev_copy[k]) (void)hipEventDestroy(c->ev_copy[k]);
+    for (int k = 0; k <= mi355_ctx::PIPE_CANDS; k++) if (c->ev_probe[k]) (void)hipEventDestroy(c->ev_probe[k]);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1018,7 +1148,7 @@ int mi355_render_batch_device(mi355_ctx *c, int mode, int n_frames, const mi355_
         for (int k = 0; k < mi355_ctx::PIPE_SETS; k++) if (c->ev_tile_set[k]) HIP_TRY(hipStreamWaitEvent(user, c->ev_tile[k], 0), -40);   // (pipelined single frames still using the scratch)
         hipError_t e = mi355i_launch_raster_batch(&c->dev, frames.data(), n_frames, mode, c->rscratch, user);
         if (e != hipSuccess) return fail(-43, "kernel launch failed: %s", hipGetErrorString(e));
-        if (c->pre) { HIP_TRY(hipEventRecord(c->ev_tile[0], user), -40); c->ev_tile_set[0] = true; }
+        if (c->pre) { HIP_TRY(hipEventRecord(c->ev_tile[0], user), -40); c->ev_tile_set[0] = true; c->ev_tile_ext[0] = true; }
         if (frames[0].mlaa) {
             HIP_TRY(c->mlaa.ensure((size_t)frames[0].pitch_words * frames[0].H * 4), -31);
             for (int f = 0; f < n_frames; f++)

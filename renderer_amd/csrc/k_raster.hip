@@ -711,6 +711,9 @@ template <int MODE>
 static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const FrameParams *d_batch, int n_frames, RasterScratch *s,
                                 hipStream_t st, hipStream_t pre = nullptr, hipEvent_t fill_done = nullptr, hipEvent_t tile_done = nullptr)
 {
+    // piped: setup + fill on `pre`, the tile kernel on `st` behind fill_done.  whole: the frame's own stream carries all
+    // three kernels (pre == st, no fill_done); the tile kernel clears the background and signals tile_done as in a piped frame.
+    const bool whole = pre != nullptr && fill_done == nullptr && tile_done != nullptr && n_frames == 1;
     const bool piped = pre != nullptr && fill_done != nullptr && n_frames == 1;
     hipStream_t st_tile = st;
     if (piped) st = pre;
@@ -724,10 +727,10 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     const dim3 fill_grid(per_tri.x > 1024u ? per_tri.x : 1024u, n_frames);
     if (piped && g.n_bins <= RS_SCAN_LDS)       // (fill_done is this kernel's own completion signal)
         hipExtLaunchKernelGGL(k_rs_fill<true>, fill_grid, dim3(256), 0, st, nullptr, fill_done, 0, g, s->B, S->n_tris, *P, d_batch, P->counters, 0);
-    else if (g.n_bins <= RS_SCAN_LDS) hipLaunchKernelGGL(k_rs_fill<true>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters, piped ? 0 : 1);
+    else if (g.n_bins <= RS_SCAN_LDS) hipLaunchKernelGGL(k_rs_fill<true>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters, piped || whole ? 0 : 1);
     else {
         hipLaunchKernelGGL(k_rs_scan, dim3(n_frames), dim3(1024), 0, st, g, s->B, P->counters);
-        hipLaunchKernelGGL(k_rs_fill<false>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters, piped ? 0 : 1);
+        hipLaunchKernelGGL(k_rs_fill<false>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters, piped || whole ? 0 : 1);
     }
     if (piped) {
         if (g.n_bins > RS_SCAN_LDS && (e = hipEventRecord(fill_done, pre)) != hipSuccess) return e;
@@ -740,7 +743,7 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     if (blocks > 2048) blocks = 2048;
     // threads per tile: mi355_opts::tune[3] (64..512, whole waves), default 256
     const int nt = P->rs_threads >= 64 && P->rs_threads <= RS_MAX_THREADS && (P->rs_threads & 63) == 0 ? P->rs_threads : 256;
-    if (piped) hipExtLaunchKernelGGL((k_rs_tile<MODE>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, nullptr, tile_done, 0, *S, *P, d_batch, n_frames, g, s->B, 1);
+    if (piped || whole) hipExtLaunchKernelGGL((k_rs_tile<MODE>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, nullptr, tile_done, 0, *S, *P, d_batch, n_frames, g, s->B, 1);
     else hipLaunchKernelGGL((k_rs_tile<MODE>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B, 0);
     return hipGetLastError();
 }
@@ -766,6 +769,42 @@ extern "C" hipError_t mi355i_launch_raster_pipelined(const DevScene *S, const Fr
                                                      hipStream_t pre, hipEvent_t fill_done, hipEvent_t tile_done)
 {
     return raster_dispatch(S, P, nullptr, 1, mode, s, st, pre, fill_done, tile_done);
+}
+
+// The finished frame of an overlapped raster frame (capi.hip) from the library's buffer to the caller's: `rows` rows of W
+// words, both buffers with the caller's pitch (the caller's padding words are not touched).  A wave per row piece, 16 bytes
+// per lane where the pitch allows.
+__global__ void __launch_bounds__(256) k_frame_copy(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, const int W, const int rows,
+                                                    const int pitch_words)
+{
+    const bool vec = (pitch_words & 3) == 0 && ((((size_t)dst) | ((size_t)src)) & 15u) == 0;
+    if (vec && W == pitch_words) {                        // one flat run
+        const size_t n4 = (size_t)rows * (size_t)W / 4u;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+            ((uint4 *)dst)[i] = ((const uint4 *)src)[i];
+        return;
+    }
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t o = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); o < (uint32_t)rows; o += n_waves) {
+        const uint32_t *srow = src + (size_t)o * (size_t)pitch_words;
+        uint32_t *drow = dst + (size_t)o * (size_t)pitch_words;
+        for (int x = lane * 4; x < W; x += 256) {
+            if (vec && x + 3 < W) *(uint4 *)(drow + x) = *(const uint4 *)(srow + x);
+            else for (int k = 0; k < 4 && x + k < W; k++) drow[x + k] = srow[x + k];
+        }
+    }
+}
+
+extern "C" hipError_t mi355i_launch_frame_copy(uint32_t *dst, const uint32_t *src, int W, int rows, int pitch_words, hipStream_t st, hipEvent_t done)
+{
+    if (W <= 0 || rows <= 0) return hipSuccess;
+    const size_t words = (size_t)rows * (size_t)W;
+    unsigned blocks = (unsigned)((words / 4u + 255u) / 256u);
+    if (blocks > 2048u) blocks = 2048u;
+    if (blocks < 1u) blocks = 1u;
+    hipExtLaunchKernelGGL(k_frame_copy, dim3(blocks), dim3(256), 0, st, nullptr, done, 0, dst, (const uint32_t *)src, W, rows, pitch_words);
+    return hipGetLastError();
 }
 
 extern "C" hipError_t mi355i_launch_raster(const DevScene *S, const FrameParams *P, int mode, RasterScratch *s, hipStream_t st)

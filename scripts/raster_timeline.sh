@@ -7,7 +7,7 @@ python - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/tl/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-rows = [r for r in rows if "k_rs_" in r["Kernel_Name"]][-18:]
+rows = [r for r in rows if "k_rs_" in r["Kernel_Name"] or "k_frame_copy" in r["Kernel_Name"]][-24:]
 t0 = int(rows[0]["Start_Timestamp"])
 for r in rows:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
