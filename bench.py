@@ -353,9 +353,9 @@ def main():
                     ms = g0.elapsed_time(g1) / n_f
                     raster[name] = {"bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_frame": int(nbytes),
-                                    "gpu_ms_per_frame": round(ms, 5), "kernels": "k_rs_setup + k_rs_fill + k_rs_tile (one frame = three launches, consecutive frames "
-                                    "overlap: setup + fill of a frame run beside the tile kernel of the frame before; HIP events on the "
-                                    "launch stream around %d frames)" % n_f,
+                                    "gpu_ms_per_frame": round(ms, 5), "kernels": "k_rs_setup + k_rs_fill + k_rs_tile + k_frame_copy (consecutive frames overlap: "
+                                    "each runs on one of three internal streams into a buffer of the library's, the launch stream copies it "
+                                    "out; HIP events on the launch stream around %d frames)" % n_f,
                                     "ztests": int(cst.ztests), "shaded_pixels": int(cst.plots)}
             result["roofline_raster"] = raster
             # the same raster frames eight at a time (mi355_render_batch_device: side by side on internal streams)
