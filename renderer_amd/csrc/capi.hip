@@ -169,6 +169,10 @@ struct mi355_ctx {
     bool ev_copy_set[2 * PIPE_SETS] = {}, ev_tile_ext[PIPE_SETS] = {};
     int fb_turn[PIPE_SETS] = {};
     DevBuf pipe_fb[2 * PIPE_SETS];
+    // raytraced frames overlap the same way; a frame in flight has its own control block (counters, pixel dispenser) and
+    // list of culled tiles.  last_ctrl: the control block of the most recent frame (what mi355_fetch_stats reads).
+    DevBuf pipe_ctrl[PIPE_SETS], pipe_sel[PIPE_SETS];
+    void *last_ctrl = nullptr;
     DevBuf cull_boxes, tile_sel;     // boxes of the tree's top (tile culling of raytraced frames) and the culled tile lists of the frame in flight
     int n_cull_boxes = 0;
     PinBuf pin_walk, pin_edge, pin_shade, pin_tree, pin_list, pin_ctl;   // host staging of the BVH streams and the builder
@@ -660,10 +664,50 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
                   DevBuf *mlaa_scratch = nullptr, uint32_t *const *frame_outs = nullptr, DevBuf *sel = nullptr)
 {
     FrameParams P = P_in;
-    if (!ctrl) ctrl = c->ctrl.p;
+    const bool own_ctrl = ctrl != nullptr;
+    if (!ctrl) { ctrl = c->ctrl.p; c->last_ctrl = ctrl; }
     if (!rs) rs = c->rscratch;
     // raytrace frames also reset the pixel dispenser behind the counters (same memset)
     const bool rt = mode == MI355_MODE_RAYTRACE || mode == MI355_MODE_RAYTRACE_ANTIALIAS;
+    // Raytraced frames of the device entry points overlap like the raster frames below: a single 1080p frame ends on the
+    // dependent chain of its most expensive tile (0.72 ms, most of the GPU idle; 0.24 ms per frame when eight share a
+    // launch), so consecutive frames run on the frame streams, each with a control block and a tile list of its own, into
+    // a buffer of the library's that the caller's stream copies out.  Not for counting frames, batches, float output,
+    // bands in place (their other rows are not this frame's to write) and the debug profiles.
+    if (rt && !own_ctrl && !sel && !stats && !P.cams && !P.no_pipe && !P.outf && !P.wave_prof && c->has_bvh && c->cand_st[0] && P.out_rows > 0 &&
+        (P.band_count <= 1 || P.compact)) {
+        const mi355_ctx::PipeChoice *pc = pipe_streams_for(c, st);
+        if (pc && pc->n >= 2) {
+            const int k = c->pipe_turn % pc->n; c->pipe_turn = (k + 1) % pc->n;
+            hipStream_t ps = c->cand_st[pc->cand[k]];
+            const int b = 2 * k + c->fb_turn[k]; c->fb_turn[k] ^= 1;
+            HIP_TRY(c->pipe_fb[b].ensure((size_t)P.pitch_words * (size_t)P.out_rows * 4), -31);
+            HIP_TRY(c->pipe_ctrl[k].ensure(MI_CTRL_BYTES), -31);
+            if (c->ev_tile_set[k] && (c->ev_tile_ext[k] || c->pipe_st[k] != ps)) HIP_TRY(hipStreamWaitEvent(ps, c->ev_tile[k], 0), -40);
+            c->pipe_st[k] = ps;
+            if (c->ev_copy_set[b]) HIP_TRY(hipStreamWaitEvent(ps, c->ev_copy[b], 0), -40);
+            FrameParams Q = P;
+            Q.out = (uint32_t *)c->pipe_fb[b].p;
+            Q.mlaa = 0;                                   // (the filter runs on the caller's buffer, below)
+            Q.work_counter = (uint32_t *)((char *)c->pipe_ctrl[k].p + MI_CTRL_DISPENSER_OFF);
+            Q.counters = (unsigned long long *)((char *)c->pipe_ctrl[k].p + 16);
+            if (int r = enqueue_frame(c, mode, Q, 0, ps, c->pipe_ctrl[k].p, nullptr, nullptr, nullptr, &c->pipe_sel[k])) return r;
+            HIP_TRY(hipEventRecord(c->ev_tile[k], ps), -40);
+            c->ev_tile_set[k] = true; c->ev_tile_ext[k] = false;
+            HIP_TRY(hipStreamWaitEvent(st, c->ev_tile[k], 0), -40);
+            hipError_t ce = mi355i_launch_frame_copy(P.out, Q.out, P.W, P.out_rows, P.pitch_words, st, c->ev_copy[b]);
+            if (ce != hipSuccess) return fail(-43, "kernel launch failed: %s", hipGetErrorString(ce));
+            c->ev_copy_set[b] = true;
+            c->last_ctrl = c->pipe_ctrl[k].p;
+            c->last_stats = false;
+            if (P.mlaa) {
+                HIP_TRY(c->mlaa.ensure((size_t)P.pitch_words * P.H * 4), -31);
+                hipError_t me = mi355i_launch_mlaa(P.out, (uint32_t *)c->mlaa.p, P.pitch_words, P.H, st);
+                if (me != hipSuccess) return fail(-43, "MLAA launch failed: %s", hipGetErrorString(me));
+            }
+            return 0;
+        }
+    }
     // (a raster frame that does not count zeroes its control block in its first kernel: one launch less per frame, ~4.7 us)
     const bool raster_self_clear = mode >= MI355_MODE_AMBIENT && mode <= MI355_MODE_PHONG_SOFTSHADOWMAPS && !stats && !P.cams;
     if (!raster_self_clear) HIP_TRY(hipMemsetAsync(ctrl, 0, rt ? MI_CTRL_BYTES : 16 + sizeof(unsigned long long) * CS_COUNT, st), -40);
@@ -919,7 +963,8 @@ void mi355_scene_destroy(mi355_ctx *c)
                       &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->mlaa, &c->cam_table, &c->wave_prof, &c->bvh_prim, &c->bvh_list[0], &c->bvh_list[1],
                       &c->bvh_lvl[0], &c->bvh_lvl[1], &c->bvh_tree, &c->bvh_cnt, &c->bvh_big[0], &c->bvh_big[1], &c->bvh_task[0], &c->bvh_task[1],
                       &c->bvh_gthr[0], &c->bvh_gthr[1], &c->bvh_gbin, &c->bvh_tcnt, &c->bvh_choff, &c->bvh_num[0], &c->bvh_num[1], &c->bvh_num[2],
-                      &c->bvh_num[3], &c->bvh_num[4], &c->bvh_out, &c->bvh_in_td, &c->bvh_in_te, &c->cull_boxes, &c->tile_sel, &c->pipe_fb[0], &c->pipe_fb[1], &c->pipe_fb[2], &c->pipe_fb[3], &c->pipe_fb[4], &c->pipe_fb[5], &c->pipe_fb[6], &c->pipe_fb[7]})
+                      &c->bvh_num[3], &c->bvh_num[4], &c->bvh_out, &c->bvh_in_td, &c->bvh_in_te, &c->cull_boxes, &c->tile_sel, &c->pipe_fb[0], &c->pipe_fb[1], &c->pipe_fb[2], &c->pipe_fb[3], &c->pipe_fb[4], &c->pipe_fb[5], &c->pipe_fb[6], &c->pipe_fb[7], &c->pipe_ctrl[0], &c->pipe_ctrl[1], &c->pipe_ctrl[2], &c->pipe_ctrl[3],
+                      &c->pipe_sel[0], &c->pipe_sel[1], &c->pipe_sel[2], &c->pipe_sel[3]})
         b->release();
     for (PinBuf *b : {&c->pin_walk, &c->pin_edge, &c->pin_shade, &c->pin_tree, &c->pin_list, &c->pin_ctl}) b->release();
     for (auto &m : c->smap) m.release();
@@ -1209,7 +1254,7 @@ int mi355_fetch_stats(mi355_ctx *c, mi355_stats *s)
     if (!c || !s) return fail(-3, "mi355_fetch_stats: null argument");
     if (int r = select_device(c)) return r;
     unsigned long long h[CS_COUNT];
-    HIP_TRY(hipMemcpy(h, (char *)c->ctrl.p + 16, sizeof h, hipMemcpyDeviceToHost), -31);
+    HIP_TRY(hipMemcpy(h, (char *)(c->last_ctrl ? c->last_ctrl : c->ctrl.p) + 16, sizeof h, hipMemcpyDeviceToHost), -31);
     memset(s, 0, sizeof *s);
     s->normal_rays = h[CS_NORMAL_RAYS]; s->shadow_rays = h[CS_SHADOW_RAYS];
     s->node_pops = h[CS_NODE_POPS]; s->inner_box_hits = h[CS_INNER_HITS]; s->tri_tests = h[CS_TRI_TESTS];
@@ -1396,6 +1441,7 @@ int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_li
     if (int r = fill_params(c, mode, cam, lights, n_lights, o, c->fb.p, W * 4, wantf ? c->fbf.p : nullptr, P)) return r;
     mi355_stats tmp;
     mi355_stats *st = stats ? stats : &tmp;
+    P.no_pipe = 1;          // (a synchronous frame has nothing to overlap with: its kernels follow each other on the context's stream)
     for (int attempt = 0;; attempt++) {
         HIP_TRY(hipEventRecord(c->ev0, c->stream), -40);
         if (int r = enqueue_frame(c, mode, P, o->collect_stats, c->stream)) return r;
