@@ -1,3 +1,2 @@
 mkdir -p gpurun_out
-MI355_PIPE_DEBUG=1 timeout 200 python scripts/raytrace_frame_by_frame.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/rt_fbf.txt
-timeout 600 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_full.log 2>&1; tail -5 gpurun_out/pytest_full.log
+timeout 600 python -m pytest tests/test_gpu_frame_overlap.py tests/test_gpu_raster_pipeline.py -x -q > gpurun_out/overlap_tests.log 2>&1; grep -v amdgpu.ids gpurun_out/overlap_tests.log | tail -30
