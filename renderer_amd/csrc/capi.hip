@@ -186,7 +186,8 @@ struct mi355_ctx {
     // pipelined frames (mi355_render_async / _wait): each slot is a stream with its own control block (counters, pixel
     // dispenser), framebuffer, page-locked staging and rasterizer scratch
     struct AsyncSlot {
-        hipStream_t st = nullptr;
+        hipStream_t st = nullptr;     // one of cand_st (slot i: a stream of queue class i, so that no two slots share a hardware queue), or its own
+        bool st_owned = false;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         DevBuf ctrl, fb, mlaa, sel;
         PinBuf pin;
@@ -619,6 +620,29 @@ static bool probe_queues(mi355_ctx *c, hipStream_t a, const hipStream_t *others,
     return hipGetLastError() == hipSuccess;
 }
 
+// The queue classes of the candidate streams (once per context).
+static bool probe_classes(mi355_ctx *c)
+{
+    const int N = mi355_ctx::PIPE_CANDS;
+    if (!c->cand_st[0]) return false;
+    // (frames may still be running on the candidates: the probe must find them idle)
+    for (int i = 0; i < N; i++) if (hipStreamSynchronize(c->cand_st[i]) != hipSuccess) return false;
+    if (c->n_class >= 0) return true;
+    int n_class = 0;
+    for (int i = 0; i < N; i++) c->cand_class[i] = -1;
+    for (int i = 0; i < N; i++) {
+        if (c->cand_class[i] >= 0) continue;
+        c->cand_class[i] = n_class;
+        hipStream_t others[N]; int idx[N], n = 0; bool shared[N];
+        for (int j = i + 1; j < N; j++) if (c->cand_class[j] < 0) { others[n] = c->cand_st[j]; idx[n++] = j; }
+        if (n > 0 && !probe_queues(c, c->cand_st[i], others, n, shared)) { for (int j = 0; j < N; j++) c->cand_class[j] = -1; return false; }
+        for (int j = 0; j < n; j++) if (shared[j]) c->cand_class[idx[j]] = n_class;
+        n_class++;
+    }
+    c->n_class = n_class;
+    return true;
+}
+
 // The frame streams for raster frames the caller enqueues on `st`: one candidate of every queue class but st's own (at most
 // PIPE_SETS).  Probed once per context (the classes) and once per caller's stream; nullptr = probing failed, fewer than
 // two = the ordered pipeline is used instead.
@@ -626,22 +650,7 @@ static const mi355_ctx::PipeChoice *pipe_streams_for(mi355_ctx *c, hipStream_t s
 {
     for (const auto &pc : c->pipe_choice) if (pc.caller == st) return &pc;
     const int N = mi355_ctx::PIPE_CANDS;
-    // (frames of another caller's stream may still be running on the candidates: the probe must find them idle)
-    for (int i = 0; i < N; i++) if (hipStreamSynchronize(c->cand_st[i]) != hipSuccess) return nullptr;
-    if (c->n_class < 0) {
-        int n_class = 0;
-        for (int i = 0; i < N; i++) c->cand_class[i] = -1;
-        for (int i = 0; i < N; i++) {
-            if (c->cand_class[i] >= 0) continue;
-            c->cand_class[i] = n_class;
-            hipStream_t others[N]; int idx[N], n = 0; bool shared[N];
-            for (int j = i + 1; j < N; j++) if (c->cand_class[j] < 0) { others[n] = c->cand_st[j]; idx[n++] = j; }
-            if (n > 0 && !probe_queues(c, c->cand_st[i], others, n, shared)) return nullptr;
-            for (int j = 0; j < n; j++) if (shared[j]) c->cand_class[idx[j]] = n_class;
-            n_class++;
-        }
-        c->n_class = n_class;
-    }
+    if (!probe_classes(c)) return nullptr;
     hipStream_t reps[N]; int rep_class[N], n = 0; bool shared[N];
     for (int cl = 0; cl < c->n_class; cl++)
         for (int i = 0; i < N; i++) if (c->cand_class[i] == cl) { reps[n] = c->cand_st[i]; rep_class[n++] = i; break; }
@@ -975,7 +984,7 @@ void mi355_scene_destroy(mi355_ctx *c)
         if (a.rs) mi355i_raster_scratch_destroy(a.rs);
         if (a.ev0) (void)hipEventDestroy(a.ev0);
         if (a.ev1) (void)hipEventDestroy(a.ev1);
-        if (a.st) (void)hipStreamDestroy(a.st);
+        if (a.st && a.st_owned) (void)hipStreamDestroy(a.st);
     }
     for (auto &h : c->host_reg) if (h.p) (void)hipHostUnregister(h.p);
     if (c->rscratch) mi355i_raster_scratch_destroy(c->rscratch);
@@ -1486,7 +1495,11 @@ int mi355_render_async(mi355_ctx *c, int mode, const mi355_camera *cam, const mi
     const int W = o->width;
     const int rows = (o->band_count > 1 && o->compact_rows) ? count_rows(*o) : o->height;
     if (!a->st) {
-        HIP_TRY(hipStreamCreateWithFlags(&a->st, hipStreamNonBlocking), -11);
+        // (slot i on a candidate stream of queue class i: frames in flight then never queue up behind one another)
+        const int si = (int)(a - c->slot);
+        if (probe_classes(c) && c->n_class >= 2)
+            for (int i = 0; i < (int)mi355_ctx::PIPE_CANDS && !a->st; i++) if (c->cand_class[i] == si % c->n_class) a->st = c->cand_st[i];
+        if (!a->st) { HIP_TRY(hipStreamCreateWithFlags(&a->st, hipStreamNonBlocking), -11); a->st_owned = true; }
         HIP_TRY(hipEventCreate(&a->ev0), -11);
         HIP_TRY(hipEventCreate(&a->ev1), -11);
         HIP_TRY(a->ctrl.ensure(MI_CTRL_BYTES), -31);
