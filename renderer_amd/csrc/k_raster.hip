@@ -796,6 +796,44 @@ __global__ void __launch_bounds__(256) k_frame_copy(uint32_t *__restrict__ dst, 
     }
 }
 
+// ... and the frames of a batch (capi.hip: overlapped batches of raytraced frames): frame f = blockIdx.y, src frames back to back
+struct CopyDst { uint32_t *p[64]; };
+__global__ void __launch_bounds__(256) k_frames_copy(const CopyDst dst, const uint32_t *__restrict__ src, const int W, const int rows, const int pitch_words)
+{
+    uint32_t *d = dst.p[blockIdx.y];
+    const uint32_t *sf = src + (size_t)blockIdx.y * (size_t)rows * (size_t)pitch_words;
+    const bool vec = (pitch_words & 3) == 0 && ((((size_t)d) | ((size_t)sf)) & 15u) == 0;
+    if (vec && W == pitch_words) {
+        const size_t n4 = (size_t)rows * (size_t)W / 4u;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) ((uint4 *)d)[i] = ((const uint4 *)sf)[i];
+        return;
+    }
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t o = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); o < (uint32_t)rows; o += n_waves) {
+        const uint32_t *srow = sf + (size_t)o * (size_t)pitch_words;
+        uint32_t *drow = d + (size_t)o * (size_t)pitch_words;
+        for (int x = lane * 4; x < W; x += 256) {
+            if (vec && x + 3 < W) *(uint4 *)(drow + x) = *(const uint4 *)(srow + x);
+            else for (int k = 0; k < 4 && x + k < W; k++) drow[x + k] = srow[x + k];
+        }
+    }
+}
+
+extern "C" hipError_t mi355i_launch_frames_copy(void *const *dst, int n_frames, const uint32_t *src, int W, int rows, int pitch_words, hipStream_t st, hipEvent_t done)
+{
+    if (W <= 0 || rows <= 0 || n_frames <= 0) return hipSuccess;
+    if (n_frames > 64) return hipErrorInvalidValue;
+    CopyDst d;
+    for (int f = 0; f < 64; f++) d.p[f] = (uint32_t *)dst[f < n_frames ? f : 0];
+    const size_t words = (size_t)rows * (size_t)W;
+    unsigned blocks = (unsigned)((words / 4u + 255u) / 256u);
+    if (blocks > 1024u) blocks = 1024u;
+    if (blocks < 1u) blocks = 1u;
+    hipExtLaunchKernelGGL(k_frames_copy, dim3(blocks, (unsigned)n_frames), dim3(256), 0, st, nullptr, done, 0, d, src, W, rows, pitch_words);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t mi355i_launch_frame_copy(uint32_t *dst, const uint32_t *src, int W, int rows, int pitch_words, hipStream_t st, hipEvent_t done)
 {
     if (W <= 0 || rows <= 0) return hipSuccess;

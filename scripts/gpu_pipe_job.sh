@@ -1,7 +1,7 @@
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_async.py tests/test_gpu_threads.py tests/test_gpu_lifecycle.py -x -q > gpurun_out/async_tests.log 2>&1; grep -v amdgpu.ids gpurun_out/async_tests.log | tail -5
-timeout 300 python bench.py 2>/dev/null | tail -1 > gpurun_out/bench_try.json; python - <<'PY'
-import json
-d = json.loads(open("gpurun_out/bench_try.json").read())
-print(d["value"], d["ms_per_step"]); print(d["seam"]); print(d["other_workloads"]); print({k: (v["frac"], v["gpu_ms_per_frame"]) for k, v in d["roofline_raster"].items()})
-PY
+for t in '{}' '{"bpc":5}' '{"bpc":5,"nopipe":1}'; do
+  timeout 200 python bench.py --no-extra --no-cpu-baseline --tune "$t" 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['config']['tune'], 'Mrays/s', d['value'], 'ms/step', d['ms_per_step'], 'iso kernel_ms', r.get('kernel_ms'), 'frac', r.get('frac'), 'period', r.get('timed_region_ms_per_launch'))"
+done | tee gpurun_out/waves5.txt
+timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -k "tuning_knobs" 2>&1 | tail -2

@@ -107,3 +107,31 @@ def test_frames_of_two_streams_and_a_new_tree_in_between(scene):
     got = bufs.cpu().numpy().view(np.uint32)
     for k in range(10):
         assert np.array_equal(got[k], host_frame(scene, 9, 21 * k, W, H)[0]), "frame %d" % k
+
+
+def test_consecutive_batches_into_the_same_buffers(scene):
+    """batches overlap too: the caller's buffers hold batch i after call i in stream order, although batch i + 1 is already running"""
+    W, H, NB = 384, 216, 3
+    stream = torch.cuda.current_stream()
+    bufs = torch.zeros((NB, H, W), dtype=torch.int32, device="cuda")
+    keep, rays = [], []
+    for i in range(7):
+        ks = [5 * (NB * i + j) for j in range(NB)]
+        cs = [R.benchmark_frame(k) for k in ks]
+        mode = 10 if i == 3 else 9
+        scene.render_batch_device(mode, [c[0] for c in cs], [c[1] for c in cs], 1, R.default_opts(W, H), [bufs[j].data_ptr() for j in range(NB)], W * 4, None, stream.cuda_stream)
+        keep.append((bufs.clone(), mode, ks))
+        if i == 4:           # a single frame between two batches
+            cam, lights, n = R.benchmark_frame(3)
+            scene.render_device(9, cam, lights, n, R.default_opts(W, H), bufs[1].data_ptr(), W * 4, 0, stream.cuda_stream)
+            keep.append((bufs[1:2].clone(), 9, [3]))
+    torch.cuda.synchronize()
+    last = scene.fetch_stats()
+    total = 0
+    for got, mode, ks in keep:
+        total = 0
+        for j, k in enumerate(ks):
+            ref, st = host_frame(scene, mode, k, W, H)
+            total += st.normal_rays + st.shadow_rays
+            assert np.array_equal(got[j].cpu().numpy().view(np.uint32), ref), "mode %d frame %d" % (mode, k)
+    assert last.normal_rays + last.shadow_rays == total        # the counters are those of the last call
