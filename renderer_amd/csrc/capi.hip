@@ -337,6 +337,13 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.prof_ordered = (flags & 8) ? 1 : 0;
     P.no_cull = (flags & 16) ? 1 : 0;
     P.no_pipe = (flags & 32) ? 1 : (flags & 64) ? 2 : 0;
+    // A profiler collecting hardware counters runs one kernel at a time (rocprofv3 --pmc): frames that wait for each other
+    // across streams gain nothing there and were seen to stall for minutes.  MI355_NO_OVERLAP=1 asks for the same.
+    static const int no_overlap = [] {
+        auto on = [](const char *v) { return v && *v && strcmp(v, "0") && strcmp(v, "false") && strcmp(v, "False") && strcmp(v, "OFF") && strcmp(v, "off"); };
+        return (on(getenv("MI355_NO_OVERLAP")) || on(getenv("ROCPROF_COUNTER_COLLECTION")) || getenv("ROCPROF_COUNTERS") || getenv("ROCPROF_COUNTER_GROUPS")) ? 1 : 0;
+    }();
+    if (no_overlap) P.no_pipe = 1;
     P.tile_sel = nullptr; P.tile_cnt = nullptr;
     P.blocks_per_cu = t[4] > 0 ? t[4] : 0;
     P.rs_threads = t[3];

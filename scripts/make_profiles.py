@@ -31,6 +31,9 @@ def main():
     ks = newest("gpurun_out/prof_stats/**/*kernel_stats.csv")
     if ks:
         shutil.copy(ks, os.path.join(out, "%s_kernel_stats.csv" % TAG))
+    ko = newest("gpurun_out/prof_stats_overlapped/**/*kernel_stats.csv")
+    if ko:
+        shutil.copy(ko, os.path.join(out, "%s_kernel_stats_overlapped.csv" % TAG))
     pmc, launches = {}, {}
     for kind in ("prof_fetch", "prof_write", "prof_sq", "prof_cache", "prof_valu1", "prof_valu2"):
         v, n = per_launch(kind)
@@ -66,6 +69,10 @@ def main():
         if os.path.exists(p):
             lines = [l for l in open(p).read().splitlines() if l.strip()]
             open(os.path.join(out, dst), "w").write("\n".join(lines[-1:] if dst.endswith("jsonl") else lines) + "\n")
+    mo = os.path.join(ROOT, "gpurun_out/misc_overlap.log")
+    if os.path.exists(mo):          # (scripts/gpu_round2_final.sh: the frame-by-frame measurements after the overlap work)
+        with open(os.path.join(out, "%s_side_measurements.log" % TAG), "a") as f:
+            f.write("".join(l for l in open(mo) if l.strip()))
     print("traffic bytes/launch:", traffic, "| launches:", launches)
     if ks:
         for i, row in enumerate(csv.DictReader(open(ks))):
