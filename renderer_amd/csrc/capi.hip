@@ -1311,6 +1311,9 @@ int mi355_fetch_stats(mi355_ctx *c, mi355_stats *s)
     if (int r = select_device(c)) return r;
     unsigned long long h[CS_COUNT];
     HIP_TRY(hipMemcpy(h, (char *)(c->last_ctrl ? c->last_ctrl : c->ctrl.p) + 16, sizeof h, hipMemcpyDeviceToHost), -31);
+    // (the rasterizer reports a bin overflow in the context's own block, whichever block the last call counted in)
+    if (c->last_ctrl && c->last_ctrl != c->ctrl.p)
+        HIP_TRY(hipMemcpy(&h[CS_OVERFLOW], (char *)c->ctrl.p + 16 + sizeof(unsigned long long) * CS_OVERFLOW, sizeof(unsigned long long), hipMemcpyDeviceToHost), -31);
     memset(s, 0, sizeof *s);
     s->normal_rays = h[CS_NORMAL_RAYS]; s->shadow_rays = h[CS_SHADOW_RAYS];
     s->node_pops = h[CS_NODE_POPS]; s->inner_box_hits = h[CS_INNER_HITS]; s->tri_tests = h[CS_TRI_TESTS];
