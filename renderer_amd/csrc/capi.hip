@@ -706,6 +706,9 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
             FrameParams Q = P;
             Q.out = (uint32_t *)c->pipe_fb[b].p;
             Q.mlaa = 0;                                   // (the filter runs on the caller's buffer, below)
+            // (frames that share the GPU are a throughput problem: the four-wave build, which loses on a frame alone, wins
+            //  here -- 1080p frame by frame 2640 -> 3170 fps, measured)
+            if (Q.blocks_per_cu == 0) Q.blocks_per_cu = 4;
             Q.work_counter = (uint32_t *)((char *)c->pipe_ctrl[k].p + MI_CTRL_DISPENSER_OFF);
             Q.counters = (unsigned long long *)((char *)c->pipe_ctrl[k].p + 16);
             if (int r = enqueue_frame(c, mode, Q, 0, ps, c->pipe_ctrl[k].p, nullptr, nullptr, nullptr, &c->pipe_sel[k])) return r;

@@ -31,6 +31,10 @@ def main():
     ks = newest("gpurun_out/prof_stats/**/*kernel_stats.csv")
     if ks:
         shutil.copy(ks, os.path.join(out, "%s_kernel_stats.csv" % TAG))
+    for kind in ("raster", "raster_overlapped"):      # (scripts/gpu_round2_final.sh: the rasterizer's kernels, mode 6, one frame per call)
+        kr = newest("gpurun_out/prof_stats_%s/**/*kernel_stats.csv" % kind)
+        if kr:
+            shutil.copy(kr, os.path.join(out, "%s_kernel_stats_%s.csv" % (TAG, kind)))
     ko = newest("gpurun_out/prof_stats_overlapped/**/*kernel_stats.csv")
     if ko:
         shutil.copy(ko, os.path.join(out, "%s_kernel_stats_overlapped.csv" % TAG))

@@ -12,7 +12,7 @@ dev = torch.device("cuda", 0); stream = torch.cuda.current_stream(dev)
 buf = torch.zeros((H, W), dtype=torch.int32, device=dev)
 cams = [R.benchmark_frame(k) for k in range(200)]
 for mode in (9, 10):
-    for label, t in (("overlapped", {}), ("one_stream", dict(nopipe=1))):
+    for label, t in (("overlapped", {}), ("overlapped bpc3", dict(bpc=3)), ("overlapped bpc4", dict(bpc=4)), ("one_stream", dict(nopipe=1))):
         o = R.default_opts(W, H, tune=R.tune(**t))
         best = 0.0
         for rep in range(3):
@@ -22,4 +22,4 @@ for mode in (9, 10):
             t1 = time.perf_counter(); torch.cuda.synchronize(dev)
             best = max(best, 200 / (time.perf_counter() - t0))
         st = s.fetch_stats()
-        print("mode %d %-11s %.1f fps (host enqueue %.1f us per frame; last frame %d + %d rays)" % (mode, label, best, (t1 - t0) / 200 * 1e6, st.normal_rays, st.shadow_rays))
+        print("mode %d %-16s %.1f fps (host enqueue %.1f us per frame; last frame %d + %d rays)" % (mode, label, best, (t1 - t0) / 200 * 1e6, st.normal_rays, st.shadow_rays))
