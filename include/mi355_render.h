@@ -208,7 +208,11 @@ int mi355_host_unregister(mi355_ctx *, void *p);
  * and makes the next frame's buffers twice as large -- a caller of the device entry points checks it once per scene /
  * camera regime, or sizes for the worst case by drawing the frame through mi355_render first (which retries by itself).
  * Frames of ONE context must not run concurrently on different streams (they share the context's control block and
- * rasterizer scratch): use one stream per context, mi355_render_batch_device, or mi355_render_async. */
+ * rasterizer scratch): use one stream per context, mi355_render_batch_device, or mi355_render_async.
+ * Consecutive calls overlap inside the library: the frame is drawn on an internal stream into a buffer of the library's and
+ * `hip_stream` copies it to d_out_xrgb, which holds it in stream order as for any asynchronous call (tune flag 32: everything
+ * on hip_stream itself).  The first call on a stream takes a few milliseconds longer (the library measures which of its
+ * streams share a hardware queue with it).  -47: hip_stream is capturing -- the calls cannot be captured into a HIP graph. */
 int mi355_render_device(mi355_ctx *, int mode, const mi355_camera *, const mi355_light *lights, int n_lights,
                         const mi355_opts *, void *d_out_xrgb, int pitch_bytes, void *d_out_rgb_f32,
                         void *hip_stream);

@@ -682,6 +682,14 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
 {
     FrameParams P = P_in;
     const bool own_ctrl = ctrl != nullptr;
+    {
+        // The calls cannot be captured into a HIP graph: they size buffers, order themselves against earlier frames with events
+        // recorded outside the capture, and the overlapped paths synchronise when they probe the streams.  (Tried: a captured
+        // frame on the caller's stream alone replays a wrong picture.)  Refused rather than drawn wrong.
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs != hipStreamCaptureStatusNone) return fail(-47, "the render calls cannot be captured into a HIP graph (stream %p is capturing)", (void *)st);
+    }
     if (!ctrl) { ctrl = c->ctrl.p; c->last_ctrl = ctrl; }
     if (!rs) rs = c->rscratch;
     // raytrace frames also reset the pixel dispenser behind the counters (same memset)
@@ -1253,6 +1261,11 @@ int mi355_render_batch_device(mi355_ctx *c, int mode, int n_frames, const mi355_
     // next batch fills when it runs on another stream.  The batch renders into a buffer of the library's; the caller's
     // stream copies the frames out in one launch.
     const size_t frame_words = (size_t)P.pitch_words * (size_t)P.out_rows;
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs != hipStreamCaptureStatusNone) return fail(-47, "the render calls cannot be captured into a HIP graph (stream %p is capturing)", (void *)st);
+    }
     if (!d_outf && !P.mlaa && !P.no_pipe && !P.wave_prof && c->has_bvh && c->cand_st[0] && P.out_rows > 0 && (P.band_count <= 1 || P.compact) &&
         frame_words * 4 * (size_t)n_frames <= ((size_t)1 << 30) && n_frames <= 64) {
         const mi355_ctx::PipeChoice *pc = pipe_streams_for(c, st);

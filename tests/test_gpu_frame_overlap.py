@@ -135,3 +135,4 @@ def test_consecutive_batches_into_the_same_buffers(scene):
             total += st.normal_rays + st.shadow_rays
             assert np.array_equal(got[j].cpu().numpy().view(np.uint32), ref), "mode %d frame %d" % (mode, k)
     assert last.normal_rays + last.shadow_rays == total        # the counters are those of the last call
+
