@@ -677,6 +677,33 @@ static const mi355_ctx::PipeChoice *pipe_streams_for(mi355_ctx *c, hipStream_t s
     return &c->pipe_choice.back();
 }
 
+// One call in flight: resource set k (rasterizer scratch / control block, tile list, camera table), frame stream
+// ps, frame buffer fb = pipe_fb[b].  lease_begin orders ps behind the set's last call, if that ran elsewhere (a call of another
+// caller's stream, of the ordered pipeline, a counting frame, a batch), and behind the copy that last read the buffer;
+// lease_done makes the caller's stream wait for the call's last kernel (`recorded`: that kernel carries ev_tile[k] itself).
+struct FrameLease { int k, b; hipStream_t ps; uint32_t *fb; };
+
+static int lease_begin(mi355_ctx *c, const mi355_ctx::PipeChoice *pc, size_t fb_bytes, FrameLease &L)
+{
+    L.k = c->pipe_turn % pc->n; c->pipe_turn = (L.k + 1) % pc->n;
+    L.ps = c->cand_st[pc->cand[L.k]];
+    L.b = 2 * L.k + c->fb_turn[L.k]; c->fb_turn[L.k] ^= 1;
+    HIP_TRY(c->pipe_fb[L.b].ensure(fb_bytes), -31);
+    L.fb = (uint32_t *)c->pipe_fb[L.b].p;
+    if (c->ev_tile_set[L.k] && (c->ev_tile_ext[L.k] || c->pipe_st[L.k] != L.ps)) HIP_TRY(hipStreamWaitEvent(L.ps, c->ev_tile[L.k], 0), -40);
+    c->pipe_st[L.k] = L.ps;
+    if (c->ev_copy_set[L.b]) HIP_TRY(hipStreamWaitEvent(L.ps, c->ev_copy[L.b], 0), -40);
+    return 0;
+}
+
+static int lease_done(mi355_ctx *c, const FrameLease &L, hipStream_t st, bool recorded)
+{
+    if (!recorded) HIP_TRY(hipEventRecord(c->ev_tile[L.k], L.ps), -40);
+    c->ev_tile_set[L.k] = true; c->ev_tile_ext[L.k] = false;
+    HIP_TRY(hipStreamWaitEvent(st, c->ev_tile[L.k], 0), -40);
+    return 0;
+}
+
 int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hipStream_t st, void *ctrl = nullptr, RasterScratch *rs = nullptr,
                   DevBuf *mlaa_scratch = nullptr, uint32_t *const *frame_outs = nullptr, DevBuf *sel = nullptr)
 {
@@ -703,29 +730,23 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
         (P.band_count <= 1 || P.compact)) {
         const mi355_ctx::PipeChoice *pc = pipe_streams_for(c, st);
         if (pc && pc->n >= 2) {
-            const int k = c->pipe_turn % pc->n; c->pipe_turn = (k + 1) % pc->n;
-            hipStream_t ps = c->cand_st[pc->cand[k]];
-            const int b = 2 * k + c->fb_turn[k]; c->fb_turn[k] ^= 1;
-            HIP_TRY(c->pipe_fb[b].ensure((size_t)P.pitch_words * (size_t)P.out_rows * 4), -31);
+            FrameLease fl;
+            if (int r = lease_begin(c, pc, (size_t)P.pitch_words * (size_t)P.out_rows * 4, fl)) return r;
+            const int k = fl.k;
             HIP_TRY(c->pipe_ctrl[k].ensure(MI_CTRL_BYTES), -31);
-            if (c->ev_tile_set[k] && (c->ev_tile_ext[k] || c->pipe_st[k] != ps)) HIP_TRY(hipStreamWaitEvent(ps, c->ev_tile[k], 0), -40);
-            c->pipe_st[k] = ps;
-            if (c->ev_copy_set[b]) HIP_TRY(hipStreamWaitEvent(ps, c->ev_copy[b], 0), -40);
             FrameParams Q = P;
-            Q.out = (uint32_t *)c->pipe_fb[b].p;
+            Q.out = fl.fb;
             Q.mlaa = 0;                                   // (the filter runs on the caller's buffer, below)
             // (frames that share the GPU are a throughput problem: the four-wave build, which loses on a frame alone, wins
             //  here -- 1080p frame by frame 2640 -> 3170 fps, measured)
             if (Q.blocks_per_cu == 0) Q.blocks_per_cu = 4;
             Q.work_counter = (uint32_t *)((char *)c->pipe_ctrl[k].p + MI_CTRL_DISPENSER_OFF);
             Q.counters = (unsigned long long *)((char *)c->pipe_ctrl[k].p + 16);
-            if (int r = enqueue_frame(c, mode, Q, 0, ps, c->pipe_ctrl[k].p, nullptr, nullptr, nullptr, &c->pipe_sel[k])) return r;
-            HIP_TRY(hipEventRecord(c->ev_tile[k], ps), -40);
-            c->ev_tile_set[k] = true; c->ev_tile_ext[k] = false;
-            HIP_TRY(hipStreamWaitEvent(st, c->ev_tile[k], 0), -40);
-            hipError_t ce = mi355i_launch_frame_copy(P.out, Q.out, P.W, P.out_rows, P.pitch_words, st, c->ev_copy[b]);
+            if (int r = enqueue_frame(c, mode, Q, 0, fl.ps, c->pipe_ctrl[k].p, nullptr, nullptr, nullptr, &c->pipe_sel[k])) return r;
+            if (int r = lease_done(c, fl, st, false)) return r;
+            hipError_t ce = mi355i_launch_frame_copy(P.out, Q.out, P.W, P.out_rows, P.pitch_words, st, c->ev_copy[fl.b]);
             if (ce != hipSuccess) return fail(-43, "kernel launch failed: %s", hipGetErrorString(ce));
-            c->ev_copy_set[b] = true;
+            c->ev_copy_set[fl.b] = true;
             c->last_ctrl = c->pipe_ctrl[k].p;
             c->last_stats = false;
             if (P.mlaa) {
@@ -753,23 +774,15 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
         if (pc && pc->n >= 2) {
             // overlapped: the whole frame on one of the frame streams, into a frame buffer of the library's; `st` waits for the
             // tile kernel and copies the frame to the caller's buffer
-            const int k = c->pipe_turn % pc->n; c->pipe_turn = (k + 1) % pc->n;
-            hipStream_t ps = c->cand_st[pc->cand[k]];
-            const int b = 2 * k + c->fb_turn[k]; c->fb_turn[k] ^= 1;
-            HIP_TRY(c->pipe_fb[b].ensure((size_t)P.pitch_words * (size_t)P.out_rows * 4), -31);
-            // (the scratch set's last frame ran on another stream: a frame of another caller's stream, of the ordered pipeline,
-            //  a counting frame, a batch)
-            if (c->ev_tile_set[k] && (c->ev_tile_ext[k] || c->pipe_st[k] != ps)) HIP_TRY(hipStreamWaitEvent(ps, c->ev_tile[k], 0), -40);
-            c->pipe_st[k] = ps;
-            if (c->ev_copy_set[b]) HIP_TRY(hipStreamWaitEvent(ps, c->ev_copy[b], 0), -40);                        // the frame buffer has been copied out
+            FrameLease fl;
+            if (int r = lease_begin(c, pc, (size_t)P.pitch_words * (size_t)P.out_rows * 4, fl)) return r;
             FrameParams Q = P;
-            Q.out = (uint32_t *)c->pipe_fb[b].p;
-            e = mi355i_launch_raster_pipelined(&c->dev, &Q, mode, c->rs_pipe[k], ps, ps, nullptr, c->ev_tile[k]);
+            Q.out = fl.fb;
+            e = mi355i_launch_raster_pipelined(&c->dev, &Q, mode, c->rs_pipe[fl.k], fl.ps, fl.ps, nullptr, c->ev_tile[fl.k]);
             if (e != hipSuccess) break;
-            c->ev_tile_set[k] = true; c->ev_tile_ext[k] = false;
-            HIP_TRY(hipStreamWaitEvent(st, c->ev_tile[k], 0), -40);
-            e = mi355i_launch_frame_copy(P.out, Q.out, P.W, P.out_rows, P.pitch_words, st, c->ev_copy[b]);
-            if (e == hipSuccess) c->ev_copy_set[b] = true;
+            if (int r = lease_done(c, fl, st, true)) return r;       // (ev_tile is the tile kernel's own completion signal)
+            e = mi355i_launch_frame_copy(P.out, Q.out, P.W, P.out_rows, P.pitch_words, st, c->ev_copy[fl.b]);
+            if (e == hipSuccess) c->ev_copy_set[fl.b] = true;
             break;
         }
         if (raster_self_clear && rs == c->rscratch && c->pre && P.no_pipe != 1) {
@@ -1270,30 +1283,24 @@ int mi355_render_batch_device(mi355_ctx *c, int mode, int n_frames, const mi355_
         frame_words * 4 * (size_t)n_frames <= ((size_t)1 << 30) && n_frames <= 64) {
         const mi355_ctx::PipeChoice *pc = pipe_streams_for(c, st);
         if (pc && pc->n >= 2) {
-            const int k = c->pipe_turn % pc->n; c->pipe_turn = (k + 1) % pc->n;
-            hipStream_t ps = c->cand_st[pc->cand[k]];
-            const int b = 2 * k + c->fb_turn[k]; c->fb_turn[k] ^= 1;
-            HIP_TRY(c->pipe_fb[b].ensure(frame_words * 4 * (size_t)n_frames), -31);
+            FrameLease fl;
+            if (int r = lease_begin(c, pc, frame_words * 4 * (size_t)n_frames, fl)) return r;
+            const int k = fl.k;
             HIP_TRY(c->pipe_ctrl[k].ensure(MI_CTRL_BYTES), -31);
             HIP_TRY(c->pipe_cam[k].ensure(sizeof tab), -31);
-            if (c->ev_tile_set[k] && (c->ev_tile_ext[k] || c->pipe_st[k] != ps)) HIP_TRY(hipStreamWaitEvent(ps, c->ev_tile[k], 0), -40);
-            c->pipe_st[k] = ps;
-            if (c->ev_copy_set[b]) HIP_TRY(hipStreamWaitEvent(ps, c->ev_copy[b], 0), -40);
-            for (int f = 0; f < n_frames; f++) tab[f].out = (uint32_t *)c->pipe_fb[b].p + (size_t)f * frame_words;
-            HIP_TRY(hipMemcpyAsync(c->pipe_cam[k].p, tab, sizeof(FrameCam) * (size_t)n_frames, hipMemcpyHostToDevice, ps), -31);
+            for (int f = 0; f < n_frames; f++) tab[f].out = fl.fb + (size_t)f * frame_words;
+            HIP_TRY(hipMemcpyAsync(c->pipe_cam[k].p, tab, sizeof(FrameCam) * (size_t)n_frames, hipMemcpyHostToDevice, fl.ps), -31);
             FrameParams Q = P;
             Q.cams = (const FrameCam *)c->pipe_cam[k].p;
             Q.n_frames = n_frames;
-            Q.out = (uint32_t *)c->pipe_fb[b].p;
+            Q.out = fl.fb;
             Q.work_counter = (uint32_t *)((char *)c->pipe_ctrl[k].p + MI_CTRL_DISPENSER_OFF);
             Q.counters = (unsigned long long *)((char *)c->pipe_ctrl[k].p + 16);
-            if (int r = enqueue_frame(c, mode, Q, 0, ps, c->pipe_ctrl[k].p, nullptr, nullptr, nullptr, &c->pipe_sel[k])) return r;
-            HIP_TRY(hipEventRecord(c->ev_tile[k], ps), -40);
-            c->ev_tile_set[k] = true; c->ev_tile_ext[k] = false;
-            HIP_TRY(hipStreamWaitEvent(st, c->ev_tile[k], 0), -40);
-            hipError_t ce = mi355i_launch_frames_copy(d_out, n_frames, (const uint32_t *)c->pipe_fb[b].p, P.W, P.out_rows, P.pitch_words, st, c->ev_copy[b]);
+            if (int r = enqueue_frame(c, mode, Q, 0, fl.ps, c->pipe_ctrl[k].p, nullptr, nullptr, nullptr, &c->pipe_sel[k])) return r;
+            if (int r = lease_done(c, fl, st, false)) return r;
+            hipError_t ce = mi355i_launch_frames_copy(d_out, n_frames, fl.fb, P.W, P.out_rows, P.pitch_words, st, c->ev_copy[fl.b]);
             if (ce != hipSuccess) return fail(-43, "kernel launch failed: %s", hipGetErrorString(ce));
-            c->ev_copy_set[b] = true;
+            c->ev_copy_set[fl.b] = true;
             c->last_ctrl = c->pipe_ctrl[k].p;
             c->last_stats = false;
             return 0;
