@@ -77,6 +77,11 @@ def main():
     if os.path.exists(mo):          # (scripts/gpu_round2_final.sh: the frame-by-frame measurements after the overlap work)
         with open(os.path.join(out, "%s_side_measurements.log" % TAG), "a") as f:
             f.write("".join(l for l in open(mo) if l.strip()))
+            for extra, title in (("gpurun_out/rt_fbf_bpc.txt", "scripts/raytrace_frame_by_frame.py: waves per SIMD of overlapped single frames (tune bpc)"),
+                                 ("gpurun_out/rt_fbf_final.txt", "scripts/raytrace_frame_by_frame.py after overlapped single frames took the four-wave build")):
+                q = os.path.join(ROOT, extra)
+                if os.path.exists(q):
+                    f.write("== %s\n" % title + "".join(l for l in open(q) if l.strip()))
     print("traffic bytes/launch:", traffic, "| launches:", launches)
     if ks:
         for i, row in enumerate(csv.DictReader(open(ks))):
