@@ -636,6 +636,9 @@ static bool probe_classes(mi355_ctx *c)
     // (frames may still be running on the candidates: the probe must find them idle)
     for (int i = 0; i < N; i++) if (hipStreamSynchronize(c->cand_st[i]) != hipSuccess) return false;
     if (c->n_class >= 0) return true;
+    // (a stream's first kernel may take milliseconds -- the runtime binds it to a hardware queue then: not inside a probe)
+    for (int i = 0; i < N; i++) hipLaunchKernelGGL(k_probe_touch, dim3(1), dim3(64), 0, c->cand_st[i]);
+    for (int i = 0; i < N; i++) if (hipStreamSynchronize(c->cand_st[i]) != hipSuccess) return false;
     int n_class = 0;
     for (int i = 0; i < N; i++) c->cand_class[i] = -1;
     for (int i = 0; i < N; i++) {
