@@ -140,19 +140,21 @@ struct mi355_ctx {
     DevBuf bvh_prim, bvh_list[2], bvh_lvl[2], bvh_tree, bvh_cnt;   // mi355_build_bvh work buffers (kept for rebuilds)
     DevBuf bvh_big[2], bvh_task[2], bvh_gthr[2], bvh_gbin, bvh_tcnt, bvh_choff, bvh_num[5], bvh_out, bvh_in_td, bvh_in_te;
     bool bvh_inputs_ready = false;
-    // raster frames of the device entry points are pipelined: three scratch sets take turns, setup + fill of a frame run on
-    // `pre` beside the tile kernel of the frame before (enqueue_frame)
-    enum { PIPE_SETS = 4 };          // (two sets tie a frame's setup to the end of the tile kernel two frames back: measured, the
-                                     //  setup / fill stream then is the critical path; with three it runs a frame ahead)
+    // Calls of the device entry points overlap inside the library (enqueue_frame): a frame -- all its kernels --
+    // runs on one of up to PIPE_SETS internal streams with resource set k (rasterizer scratch rs_pipe[k]; control block, tile
+    // list and camera table pipe_ctrl / pipe_sel / pipe_cam[k]) into a frame buffer of the library's, and the caller's stream only
+    // copies that buffer out: the kernels of consecutive frames do not wait for each other (a dependency that crosses streams
+    // costs ~10 us on this stack, a fifth of a raster frame).  ev_tile[k] = the last kernel of set k's last call.
+    // The ordered pipeline (tune flag 64; the fallback when fewer than two usable frame streams are found) keeps the tile
+    // kernels on the caller's stream and runs setup + fill of a frame on `pre` beside the tile kernel of the frame before,
+    // n_pipe = 3 sets taking turns (with two, a frame's setup waits for the tile kernel two frames back: measured slower).
+    enum { PIPE_SETS = 4 };
     RasterScratch *rs_pipe[PIPE_SETS] = {};
-    int n_pipe = 3;                  // sets in use (the ordered pipeline: at most three)
+    int n_pipe = 3;
     hipStream_t pre = nullptr;
     hipEvent_t ev_fill[PIPE_SETS] = {}, ev_tile[PIPE_SETS] = {};
     bool ev_tile_set[PIPE_SETS] = {};
     int pipe_turn = 0;
-    // ... or, the default, whole frames overlap: set k's three kernels run on its own stream into the set's own frame
-    // buffer, and the caller's stream only copies that buffer to the caller's (the tile kernels of consecutive frames then
-    // do not wait for each other: a dependency that crosses streams costs ~10 us on this stack, a fifth of a frame)
     // The frames' streams are picked from PIPE_CANDS candidates so that no two of them, and none and the caller's stream,
     // share a hardware queue: the runtime spreads all streams of the process over four queues, and streams that share one
     // run in submission order -- a frame stream behind the caller's stream sits behind that stream's waits (measured: 16 k
@@ -170,8 +172,8 @@ struct mi355_ctx {
     bool ev_copy_set[2 * PIPE_SETS] = {}, ev_tile_ext[PIPE_SETS] = {};
     int fb_turn[PIPE_SETS] = {};
     DevBuf pipe_fb[2 * PIPE_SETS];
-    // raytraced frames overlap the same way; a frame in flight has its own control block (counters, pixel dispenser) and
-    // list of culled tiles.  last_ctrl: the control block of the most recent frame (what mi355_fetch_stats reads).
+    // (raytraced frames and batches: control block = counters + pixel dispenser)  last_ctrl: the control block of the most
+    // recent call, what mi355_fetch_stats reads.
     DevBuf pipe_ctrl[PIPE_SETS], pipe_sel[PIPE_SETS], pipe_cam[PIPE_SETS];
     void *last_ctrl = nullptr;
     DevBuf cull_boxes, tile_sel;     // boxes of the tree's top (tile culling of raytraced frames) and the culled tile lists of the frame in flight
