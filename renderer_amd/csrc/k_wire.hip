@@ -5,9 +5,13 @@
 // each a 64-bit key   pixel << 41 | line << 21 | position in the line << 8 | alpha;   the keys are sorted (rocPRIM radix
 // sort, whole keys: a bit range starting above bit 0 came back unsorted from this rocPRIM) and one thread per pixel replays its alphas in order over black.  Lines are numbered 3 * triangle +
 // {AB, AC, BC}: the reference's single-thread drawing order.
-//   k_wf_count  : thread per (triangle, line): back-face test, transform, projection, clip; counts the line's operations
+//   k_wf_plan   : thread per (triangle, line): back-face test, transform, projection, clip; the clipped ends and the number of
+//                 pixel operations the line code makes (wf_plan: known from the ends, nothing is walked)
 //   scan        : rocprim::exclusive_scan of the counts
-//   k_wf_emit   : the same walk again, writing keys at the line's offset
+//   k_wf_emit   : thread per OPERATION: its line by binary search in the offsets, the operation from the table form of the
+//                 line (wf_op: the Wu accumulator after k steps is k * erradj); operations outside the surface get the key ~0
+//                 (round 2's first version walked every line twice with a thread per line: 0.5 of its 0.8 ms per frame went
+//                 into the few long lines of the chessboard)
 //   sort        : rocprim::radix_sort_keys
 //   k_wf_apply  : thread per key; the first key of a pixel replays the pixel's run
 // Limits (the key's fields): width, height <= 4095, width * height <= 2^23, triangles <= 349 525.
@@ -35,40 +39,36 @@ MI_DEV bool wf_line_of(const DevScene &S, const FrameParams &P, uint32_t t, int 
     return wf_triangle_line(P.W, P.H, P.SD, P.clip_z, A, B, C, slot, x1, y1, x2, y2);
 }
 
-struct WfCount {
-    int W, H; uint32_t n;
-    MI_DEV void operator()(int x, int y, uint32_t) { if (x >= 0 && x < W && y >= 0 && y < H) n++; }
-};
-struct WfEmit {
-    int W, H; uint64_t *keys; uint64_t line; uint32_t pos;
-    MI_DEV void operator()(int x, int y, uint32_t alpha)
-    {
-        if (!(x >= 0 && x < W && y >= 0 && y < H)) return;
-        keys[pos] = ((uint64_t)((uint32_t)y * (uint32_t)W + (uint32_t)x) << WF_PIXEL_SHIFT) | (line << WF_LINE_SHIFT) | ((uint64_t)pos_in_line() << WF_POS_SHIFT) | (uint64_t)alpha;
-        pos++;
-    }
-    uint32_t first;
-    MI_DEV uint32_t pos_in_line() const { return pos - first; }
-};
-
-__global__ void __launch_bounds__(256) k_wf_count(const DevScene S, const FrameParams P, uint32_t *counts)
+__global__ void __launch_bounds__(256) k_wf_plan(const DevScene S, const FrameParams P, uint2 *plan, uint32_t *counts)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= S.n_tris * 3u) return;
     int16_t x1, y1, x2, y2;
-    WfCount c{P.W, P.H, 0u};
-    if (wf_line_of(S, P, i / 3u, (int)(i % 3u), x1, y1, x2, y2)) wf_aaline(P.W, P.H, x1, y1, x2, y2, c);
-    counts[i] = c.n;
+    WfPlan p; p.x1 = p.y1 = p.x2 = p.y2 = 0; p.n = 0u;
+    if (wf_line_of(S, P, i / 3u, (int)(i % 3u), x1, y1, x2, y2)) p = wf_plan(P.W, P.H, x1, y1, x2, y2);
+    plan[i] = make_uint2(((uint32_t)(uint16_t)p.x1) | ((uint32_t)(uint16_t)p.y1 << 16), ((uint32_t)(uint16_t)p.x2) | ((uint32_t)(uint16_t)p.y2 << 16));
+    counts[i] = p.n;
 }
 
-__global__ void __launch_bounds__(256) k_wf_emit(const DevScene S, const FrameParams P, const uint32_t *offsets, uint64_t *keys)
+__global__ void __launch_bounds__(256) k_wf_emit(const FrameParams P, const uint2 *plan, const uint32_t *offsets, uint32_t n_lines, uint32_t n_ops,
+                                                 uint64_t *keys)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= S.n_tris * 3u) return;
-    int16_t x1, y1, x2, y2;
-    if (!wf_line_of(S, P, i / 3u, (int)(i % 3u), x1, y1, x2, y2)) return;
-    WfEmit e{P.W, P.H, keys, (uint64_t)i, offsets[i], offsets[i]};
-    wf_aaline(P.W, P.H, x1, y1, x2, y2, e);
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= n_ops) return;
+    // the line: the last one whose offset is <= g (lines that draw nothing share their successor's offset)
+    uint32_t lo = 0, hi = n_lines;
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (offsets[mid] <= g) lo = mid; else hi = mid; }
+    const uint2 e = plan[lo];
+    WfPlan p;
+    p.x1 = (int16_t)(uint16_t)(e.x & 0xffffu); p.y1 = (int16_t)(uint16_t)(e.x >> 16);
+    p.x2 = (int16_t)(uint16_t)(e.y & 0xffffu); p.y2 = (int16_t)(uint16_t)(e.y >> 16);
+    p.n = 0u;
+    const uint32_t i = g - offsets[lo];
+    int x, y; uint32_t alpha;
+    wf_op(p, i, x, y, alpha);
+    const bool inside = x >= 0 && x < P.W && y >= 0 && y < P.H;                     // (_putPixelAlpha drops the others)
+    keys[g] = inside ? ((uint64_t)((uint32_t)y * (uint32_t)P.W + (uint32_t)x) << WF_PIXEL_SHIFT) | ((uint64_t)lo << WF_LINE_SHIFT) | ((uint64_t)i << WF_POS_SHIFT) | (uint64_t)alpha
+                     : ~0ull;
 }
 
 // y -> output row, or -1 when the row belongs to another GPU's band
@@ -83,7 +83,7 @@ MI_DEV int wf_out_row(const FrameParams &P, int y)
 __global__ void __launch_bounds__(256) k_wf_apply(const FrameParams P, const uint64_t *keys, uint32_t n)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || keys[i] == ~0ull) return;                                            // (an operation outside the surface)
     const uint32_t pixel = (uint32_t)(keys[i] >> WF_PIXEL_SHIFT);
     if (i > 0 && (uint32_t)(keys[i - 1] >> WF_PIXEL_SHIFT) == pixel) return;          // not the first operation of its pixel
     uint32_t v = 0u;                                                                  // Screen::ClearScreen
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) k_wf_apply(const FrameParams P, const uin
 } // namespace
 
 struct WireScratch {
-    uint32_t *counts = nullptr, *offsets = nullptr; size_t lines_cap = 0;
+    uint32_t *counts = nullptr, *offsets = nullptr; uint2 *plan = nullptr; size_t lines_cap = 0;
     uint64_t *keys[2] = {nullptr, nullptr}; size_t keys_cap = 0;
     void *temp = nullptr; size_t temp_cap = 0;
 };
@@ -105,7 +105,7 @@ extern "C" WireScratch *mi355i_wire_scratch_create(void) { return new WireScratc
 extern "C" void mi355i_wire_scratch_destroy(WireScratch *w)
 {
     if (!w) return;
-    for (void *p : {(void *)w->counts, (void *)w->offsets, (void *)w->keys[0], (void *)w->keys[1], w->temp}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)w->counts, (void *)w->offsets, (void *)w->plan, (void *)w->keys[0], (void *)w->keys[1], w->temp}) if (p) (void)hipFree(p);
     delete w;
 }
 
@@ -125,9 +125,11 @@ extern "C" hipError_t mi355i_launch_wireframe(const DevScene *S, const FramePara
     if (n_lines + 1 > w->lines_cap) {
         if (w->counts) (void)hipFree(w->counts);
         if (w->offsets) (void)hipFree(w->offsets);
-        w->counts = w->offsets = nullptr; w->lines_cap = 0;
+        if (w->plan) (void)hipFree(w->plan);
+        w->counts = w->offsets = nullptr; w->plan = nullptr; w->lines_cap = 0;
         if ((e = hipMalloc((void **)&w->counts, (n_lines + 1) * 4)) != hipSuccess) return e;
         if ((e = hipMalloc((void **)&w->offsets, (n_lines + 1) * 4)) != hipSuccess) return e;
+        if ((e = hipMalloc((void **)&w->plan, (n_lines + 1) * 8)) != hipSuccess) return e;
         w->lines_cap = n_lines + 1;
     }
     auto temp_for = [&](size_t bytes) -> hipError_t {
@@ -139,7 +141,7 @@ extern "C" hipError_t mi355i_launch_wireframe(const DevScene *S, const FramePara
         return r;
     };
     const unsigned nb = (unsigned)((n_lines + 255) / 256);
-    hipLaunchKernelGGL(k_wf_count, dim3(nb), dim3(256), 0, st, *S, *P, w->counts);
+    hipLaunchKernelGGL(k_wf_plan, dim3(nb), dim3(256), 0, st, *S, *P, w->plan, w->counts);
     if ((e = hipMemsetAsync(w->counts + n_lines, 0, 4, st)) != hipSuccess) return e;      // (the scan's last output = the total)
     size_t tb = 0;
     if ((e = rocprim::exclusive_scan(nullptr, tb, w->counts, w->offsets, 0u, n_lines + 1, rocprim::plus<uint32_t>(), st)) != hipSuccess) return e;
@@ -156,7 +158,7 @@ extern "C" hipError_t mi355i_launch_wireframe(const DevScene *S, const FramePara
         for (int k = 0; k < 2; k++) if ((e = hipMalloc((void **)&w->keys[k], cap * 8)) != hipSuccess) return e;
         w->keys_cap = cap;
     }
-    hipLaunchKernelGGL(k_wf_emit, dim3(nb), dim3(256), 0, st, *S, *P, w->offsets, w->keys[0]);
+    hipLaunchKernelGGL(k_wf_emit, dim3((n_ops + 255u) / 256u), dim3(256), 0, st, *P, (const uint2 *)w->plan, (const uint32_t *)w->offsets, (uint32_t)n_lines, n_ops, w->keys[0]);
     tb = 0;
     if ((e = rocprim::radix_sort_keys(nullptr, tb, w->keys[0], w->keys[1], (size_t)n_ops, 0u, 64u, st)) != hipSuccess) return e;
     if ((e = temp_for(tb)) != hipSuccess) return e;

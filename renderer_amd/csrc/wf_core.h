@@ -139,6 +139,58 @@ MI_HD void wf_aaline(int W, int H, int16_t x1, int16_t y1, int16_t x2, int16_t y
     emit((int)x2, (int)y2, WF_ALPHA);                        // draw_endpoint
 }
 
+// The same line as a TABLE: wf_plan clips it and says how many emit calls wf_aaline makes for it (those outside the surface
+// included: the second pixel of a Wu pair may lie one past the edge), wf_op gives call i without walking the line -- the Wu
+// error accumulator after k steps is k * erradj mod 2^32, its carries number (k * e16) >> 16 with e16 = erradj >> 16 (a step
+// that lands on 0 counts as a carry in the reference's `erracc <= before`, and e16 = 65536 -- the anti-diagonal -- makes
+// every step one: both fall out of the same formula).  k_wire.hip expands lines with one thread per call; tests/emu checks
+// the table against the walk call by call.
+struct WfPlan { int16_t x1, y1, x2, y2; uint32_t n; };      // the clipped ends; n = 0: nothing is drawn
+
+MI_HD WfPlan wf_plan(int W, int H, int16_t x1, int16_t y1, int16_t x2, int16_t y2)
+{
+    WfPlan p; p.x1 = p.y1 = p.x2 = p.y2 = 0; p.n = 0u;
+    if (!wf_clip_line(W, H, x1, y1, x2, y2)) return p;
+    p.x1 = x1; p.y1 = y1; p.x2 = x2; p.y2 = y2;
+    int dx = (int)x2 - (int)x1, dy = (int)y2 - (int)y1;
+    if (dy < 0) { dx = -dx; dy = -dy; }                      // (as seen from the upper end)
+    const int adx = dx < 0 ? -dx : dx;
+    if (dx == 0) p.n = (uint32_t)dy + 1u;
+    else if (dy == 0) p.n = (uint32_t)adx + 1u;
+    else if (dx == dy) p.n = (uint32_t)dy + 1u;
+    else p.n = 2u * (uint32_t)(dy > adx ? dy : adx);
+    return p;
+}
+
+MI_HD void wf_op(const WfPlan &p, uint32_t i, int &x, int &y, uint32_t &alpha)
+{
+    const int x1 = p.x1, y1 = p.y1, x2 = p.x2, y2 = p.y2;
+    int xx0 = x1, yy0 = y1, xx1 = x2, yy1 = y2;
+    if (yy0 > yy1) { int t = yy0; yy0 = yy1; yy1 = t; t = xx0; xx0 = xx1; xx1 = t; }
+    int dx = xx1 - xx0, dy = yy1 - yy0;
+    alpha = WF_ALPHA;
+    if (dx == 0) { x = x1; y = yy0 + (int)i; return; }                                   // vlineColor, top to bottom
+    if (dy == 0) { x = (x1 < x2 ? x1 : x2) + (int)i; y = y1; return; }                   // hlineColor, left to right
+    if (dx == dy) { x = x1 + (x2 >= x1 ? (int)i : -(int)i); y = y1 + (y2 >= y1 ? (int)i : -(int)i); return; }   // lineColor from (x1, y1)
+    int xdir = 1;
+    if (dx < 0) { xdir = -1; dx = -dx; }
+    const uint32_t D = (uint32_t)(dy > dx ? dy : dx);
+    if (i == 0u) { x = x1; y = y1; return; }                                              // the initial pixel
+    if (i == 2u * D - 1u) { x = x2; y = y2; return; }                                     // draw_endpoint
+    const uint32_t k = (i + 1u) >> 1;                                                     // the loop's k-th pass draws calls 2k-1, 2k
+    const bool second = (i & 1u) == 0u;
+    const uint32_t e16 = dy > dx ? (uint32_t)((dx << 16) / dy) : (uint32_t)((dy << 16) / dx);
+    const uint32_t prod = k * e16, carries = prod >> 16, wgt = (prod >> 8) & 255u;
+    alpha = second ? (WF_ALPHA * wgt) >> 8 : (WF_ALPHA * (255u - wgt)) >> 8;
+    if (dy > dx) {
+        x = (int)wf_s16(xx0 + xdir * (int)carries + (second ? xdir : 0));
+        y = (int)wf_s16(yy0 + (int)k);
+    } else {
+        x = (int)wf_s16(xx0 + xdir * (int)k);
+        y = (int)wf_s16(yy0 + (int)carries + (second ? 1 : 0));
+    }
+}
+
 // The three lines of a triangle in the reference's drawing order: slot 0 = AB, 1 = AC, 2 = BC (Rasterizers.cc:147-183).
 // false = this slot draws nothing.  A, B, C: the corners in camera space.
 MI_HD bool wf_triangle_line(int W, int H, int SD, float clip_z, f3 A, f3 B, f3 C, int slot, int16_t &x1, int16_t &y1, int16_t &x2, int16_t &y2)

@@ -20,10 +20,20 @@ def emu():
     L.emu_wire_lines.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.emu_wire_lines.restype = None
 
-    def draw(pixels, xyxy):
+    L.emu_wire_lines_table.argtypes = L.emu_wire_lines.argtypes
+    L.emu_wire_lines_table.restype = None
+    L.emu_wire_check_table.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.emu_wire_check_table.restype = C.c_int
+
+    def draw(pixels, xyxy, table=False):
         xyxy = np.ascontiguousarray(xyxy, np.int16).reshape(-1, 4)
-        L.emu_wire_lines(pixels.ctypes.data, pixels.shape[1], pixels.shape[0], pixels.strides[0] // 4, len(xyxy), xyxy.ctypes.data)
+        (L.emu_wire_lines_table if table else L.emu_wire_lines)(pixels.ctypes.data, pixels.shape[1], pixels.shape[0], pixels.strides[0] // 4, len(xyxy), xyxy.ctypes.data)
         return pixels
+
+    def check_table(W, H, xyxy):
+        xyxy = np.ascontiguousarray(xyxy, np.int16).reshape(-1, 4)
+        return L.emu_wire_check_table(W, H, len(xyxy), xyxy.ctypes.data)
+    draw.check_table = check_table
     return draw
 
 
@@ -68,3 +78,29 @@ def test_one_line_at_a_time(oracle, emu):
             a = oracle.wu_lines(np.zeros((H, W), np.uint32), l)
             b = emu(np.zeros((H, W), np.uint32), l)
             assert np.array_equal(a, b), "line %s (%s)" % (l.tolist(), kind)
+
+
+@pytest.mark.parametrize("kind", ["inside", "around", "wild", "axis"])
+@pytest.mark.parametrize("W,H", [(64, 48), (333, 187), (1920, 1080), (4095, 2048), (17, 9), (1, 1)])
+def test_the_table_form_is_the_walk_call_by_call(oracle, emu, kind, W, H):
+    """k_wire.hip expands a line with one thread per emit call (wf_plan / wf_op): every call of the walk, the ones that fall
+    outside the surface included, is the table's entry of the same index -- and the frame drawn through the table is the
+    oracle's"""
+    rng = np.random.default_rng(hash(("table", kind, W, H)) & 0xffff)
+    xyxy = lines(rng, 6000 if W < 500 else 2500, W, H, kind).astype(np.int16)
+    bad = emu.check_table(W, H, xyxy)
+    assert bad < 0, "line %d: %s" % (bad, xyxy[bad].tolist())
+    if W * H <= 1920 * 1080:
+        a = oracle.wu_lines(np.zeros((H, W), np.uint32), xyxy)
+        b = emu(np.zeros((H, W), np.uint32), xyxy, table=True)
+        assert np.array_equal(a, b)
+
+
+def test_the_table_on_every_short_line(emu):
+    """all lines between points of a small grid that reaches past the surface on every side: every slope, both directions,
+    every clip case"""
+    W, H = 13, 11
+    pts = [(x, y) for x in range(-4, W + 4) for y in range(-4, H + 4)]
+    xyxy = np.array([(a[0], a[1], b[0], b[1]) for a in pts for b in pts], np.int16)
+    bad = emu.check_table(W, H, xyxy)
+    assert bad < 0, "line %s" % xyxy[bad].tolist()
