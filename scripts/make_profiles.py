@@ -79,7 +79,7 @@ def main():
             f.write("".join(l for l in open(mo) if l.strip()))
             for extra, title in (("gpurun_out/rt_fbf_bpc.txt", "scripts/raytrace_frame_by_frame.py: waves per SIMD of overlapped single frames (tune bpc)"),
                                  ("gpurun_out/rt_fbf_final.txt", "scripts/raytrace_frame_by_frame.py after overlapped single frames took the four-wave build"),
-                                 ("gpurun_out/wire_fps.txt", "wireframe (mode 3) chessboard 1080p after the thread-per-operation rewrite (1229.9 fps in the bench line, taken before)")):
+                                 ("gpurun_out/wire_fps.txt", "wireframe (mode 3) chessboard 1080p after the thread-per-operation rewrite (1229.9 fps before)")):
                 q = os.path.join(ROOT, extra)
                 if os.path.exists(q):
                     f.write("== %s\n" % title + "".join(l for l in open(q) if l.strip()))
