@@ -2,19 +2,19 @@
 //
 // The reference blends every line over whatever the earlier lines left in the frame, so a pixel's value depends on the ORDER
 // of the lines through it.  Here the order is made explicit: every line is expanded into its pixel operations (wf_core.h),
-// each a 64-bit key   pixel << 41 | line << 21 | position in the line << 8 | alpha;   the keys are sorted (rocPRIM radix
-// sort, whole keys: a bit range starting above bit 0 came back unsorted from this rocPRIM) and one thread per pixel replays its alphas in order over black.  Lines are numbered 3 * triangle +
-// {AB, AC, BC}: the reference's single-thread drawing order.
+// written in drawing order -- line by line, lines numbered 3 * triangle + {AB, AC, BC} (the reference's single-thread order),
+// each line's operations in the order it makes them -- as (pixel, alpha) pairs; a STABLE sort by pixel (rocPRIM radix sort,
+// 24 key bits) keeps that order inside every pixel, and one thread per pixel replays its alphas over black.
 //   k_wf_plan   : thread per (triangle, line): back-face test, transform, projection, clip; the clipped ends and the number of
 //                 pixel operations the line code makes (wf_plan: known from the ends, nothing is walked)
 //   scan        : rocprim::exclusive_scan of the counts
 //   k_wf_emit   : thread per OPERATION: its line by binary search in the offsets, the operation from the table form of the
-//                 line (wf_op: the Wu accumulator after k steps is k * erradj); operations outside the surface get the key ~0
+//                 line (wf_op: the Wu accumulator after k steps is k * erradj); operations outside the surface get pixel 2^23
 //                 (round 2's first version walked every line twice with a thread per line: 0.5 of its 0.8 ms per frame went
 //                 into the few long lines of the chessboard)
-//   sort        : rocprim::radix_sort_keys
-//   k_wf_apply  : thread per key; the first key of a pixel replays the pixel's run
-// Limits (the key's fields): width, height <= 4095, width * height <= 2^23, triangles <= 349 525.
+//   sort        : rocprim::radix_sort_pairs (the first version sorted 64-bit keys pixel | line | position | alpha: 8 passes for 3)
+//   k_wf_apply  : thread per pair; the first pair of a pixel replays the pixel's run
+// Limits: width, height <= 4095 (16-bit line coordinates), width * height <= 2^23 (the key), triangles <= 349 525.
 #include "dev_scene.h"
 #include "wf_core.h"
 
@@ -23,7 +23,7 @@
 
 namespace {
 
-enum { WF_PIXEL_SHIFT = 41, WF_LINE_SHIFT = 21, WF_POS_SHIFT = 8 };
+#define WF_NO_PIXEL (1u << 23)           // an operation outside the surface: behind every pixel in the sort, skipped by k_wf_apply
 
 MI_DEV f3 wf_to_camera(const FrameParams &P, f3 p) { return mulright(P.mv, sub3(p, mk3(P.eye[0], P.eye[1], P.eye[2]))); }   // Transform, Algebra.h:38-42
 
@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) k_wf_plan(const DevScene S, const FramePa
 }
 
 __global__ void __launch_bounds__(256) k_wf_emit(const FrameParams P, const uint2 *plan, const uint32_t *offsets, uint32_t n_lines, uint32_t n_ops,
-                                                 uint64_t *keys)
+                                                 uint32_t *pix, uint32_t *alphas)
 {
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     if (g >= n_ops) return;
@@ -67,8 +67,8 @@ __global__ void __launch_bounds__(256) k_wf_emit(const FrameParams P, const uint
     int x, y; uint32_t alpha;
     wf_op(p, i, x, y, alpha);
     const bool inside = x >= 0 && x < P.W && y >= 0 && y < P.H;                     // (_putPixelAlpha drops the others)
-    keys[g] = inside ? ((uint64_t)((uint32_t)y * (uint32_t)P.W + (uint32_t)x) << WF_PIXEL_SHIFT) | ((uint64_t)lo << WF_LINE_SHIFT) | ((uint64_t)i << WF_POS_SHIFT) | (uint64_t)alpha
-                     : ~0ull;
+    pix[g] = inside ? (uint32_t)y * (uint32_t)P.W + (uint32_t)x : WF_NO_PIXEL;
+    alphas[g] = alpha;
 }
 
 // y -> output row, or -1 when the row belongs to another GPU's band
@@ -80,14 +80,15 @@ MI_DEV int wf_out_row(const FrameParams &P, int y)
     return P.compact ? (b / P.band_count) * P.band_rows + (y - b * P.band_rows) : y;
 }
 
-__global__ void __launch_bounds__(256) k_wf_apply(const FrameParams P, const uint64_t *keys, uint32_t n)
+__global__ void __launch_bounds__(256) k_wf_apply(const FrameParams P, const uint32_t *pix, const uint32_t *alphas, uint32_t n)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n || keys[i] == ~0ull) return;                                            // (an operation outside the surface)
-    const uint32_t pixel = (uint32_t)(keys[i] >> WF_PIXEL_SHIFT);
-    if (i > 0 && (uint32_t)(keys[i - 1] >> WF_PIXEL_SHIFT) == pixel) return;          // not the first operation of its pixel
+    if (i >= n) return;
+    const uint32_t pixel = pix[i];
+    if (pixel >= WF_NO_PIXEL) return;                                                 // (an operation outside the surface)
+    if (i > 0 && pix[i - 1] == pixel) return;                                         // not the first operation of its pixel
     uint32_t v = 0u;                                                                  // Screen::ClearScreen
-    for (uint32_t j = i; j < n && (uint32_t)(keys[j] >> WF_PIXEL_SHIFT) == pixel; j++) v = wf_blend(v, (uint32_t)(keys[j] & 0xffu));
+    for (uint32_t j = i; j < n && pix[j] == pixel; j++) v = wf_blend(v, alphas[j]);
     const int y = (int)(pixel / (uint32_t)P.W), x = (int)(pixel % (uint32_t)P.W);
     const int r = wf_out_row(P, y);
     if (r >= 0) P.out[(size_t)r * P.pitch_words + x] = v;
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(256) k_wf_apply(const FrameParams P, const uin
 
 struct WireScratch {
     uint32_t *counts = nullptr, *offsets = nullptr; uint2 *plan = nullptr; size_t lines_cap = 0;
-    uint64_t *keys[2] = {nullptr, nullptr}; size_t keys_cap = 0;
+    uint32_t *pix[2] = {nullptr, nullptr}, *alphas[2] = {nullptr, nullptr}; size_t keys_cap = 0;
     void *temp = nullptr; size_t temp_cap = 0;
 };
 
@@ -105,7 +106,7 @@ extern "C" WireScratch *mi355i_wire_scratch_create(void) { return new WireScratc
 extern "C" void mi355i_wire_scratch_destroy(WireScratch *w)
 {
     if (!w) return;
-    for (void *p : {(void *)w->counts, (void *)w->offsets, (void *)w->plan, (void *)w->keys[0], (void *)w->keys[1], w->temp}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)w->counts, (void *)w->offsets, (void *)w->plan, (void *)w->pix[0], (void *)w->pix[1], (void *)w->alphas[0], (void *)w->alphas[1], w->temp}) if (p) (void)hipFree(p);
     delete w;
 }
 
@@ -152,17 +153,25 @@ extern "C" hipError_t mi355i_launch_wireframe(const DevScene *S, const FramePara
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
     if (n_ops == 0) return hipSuccess;
     if (n_ops > w->keys_cap) {
-        for (int k = 0; k < 2; k++) { if (w->keys[k]) (void)hipFree(w->keys[k]); w->keys[k] = nullptr; }
+        for (int k = 0; k < 2; k++) {
+            if (w->pix[k]) (void)hipFree(w->pix[k]);
+            if (w->alphas[k]) (void)hipFree(w->alphas[k]);
+            w->pix[k] = w->alphas[k] = nullptr;
+        }
         w->keys_cap = 0;
         const size_t cap = (size_t)n_ops + n_ops / 4 + 1024;
-        for (int k = 0; k < 2; k++) if ((e = hipMalloc((void **)&w->keys[k], cap * 8)) != hipSuccess) return e;
+        for (int k = 0; k < 2; k++) {
+            if ((e = hipMalloc((void **)&w->pix[k], cap * 4)) != hipSuccess) return e;
+            if ((e = hipMalloc((void **)&w->alphas[k], cap * 4)) != hipSuccess) return e;
+        }
         w->keys_cap = cap;
     }
-    hipLaunchKernelGGL(k_wf_emit, dim3((n_ops + 255u) / 256u), dim3(256), 0, st, *P, (const uint2 *)w->plan, (const uint32_t *)w->offsets, (uint32_t)n_lines, n_ops, w->keys[0]);
+    hipLaunchKernelGGL(k_wf_emit, dim3((n_ops + 255u) / 256u), dim3(256), 0, st, *P, (const uint2 *)w->plan, (const uint32_t *)w->offsets, (uint32_t)n_lines, n_ops, w->pix[0], w->alphas[0]);
     tb = 0;
-    if ((e = rocprim::radix_sort_keys(nullptr, tb, w->keys[0], w->keys[1], (size_t)n_ops, 0u, 64u, st)) != hipSuccess) return e;
+    // (stable: pairs of one pixel stay in drawing order.  Key bits 0..23: pixel indices and WF_NO_PIXEL)
+    if ((e = rocprim::radix_sort_pairs(nullptr, tb, w->pix[0], w->pix[1], w->alphas[0], w->alphas[1], (size_t)n_ops, 0u, 24u, st)) != hipSuccess) return e;
     if ((e = temp_for(tb)) != hipSuccess) return e;
-    if ((e = rocprim::radix_sort_keys(w->temp, tb, w->keys[0], w->keys[1], (size_t)n_ops, 0u, 64u, st)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_wf_apply, dim3((n_ops + 255u) / 256u), dim3(256), 0, st, *P, w->keys[1], n_ops);
+    if ((e = rocprim::radix_sort_pairs(w->temp, tb, w->pix[0], w->pix[1], w->alphas[0], w->alphas[1], (size_t)n_ops, 0u, 24u, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_wf_apply, dim3((n_ops + 255u) / 256u), dim3(256), 0, st, *P, (const uint32_t *)w->pix[1], (const uint32_t *)w->alphas[1], n_ops);
     return hipGetLastError();
 }
