@@ -762,9 +762,11 @@ static hipError_t raster_dispatch(const DevScene *S, const FrameParams *P, const
     return hipErrorInvalidValue;
 }
 
-// One frame whose setup and fill kernels run on `pre` -- beside whatever `st` is still doing, normally the previous frame's
-// tile kernel -- and whose tile kernel follows on `st` (it waits for fill_done).  The scratch set must not be in use by a
-// frame whose tile kernel has not finished: the caller alternates two sets and orders them with events (capi.hip).
+// One frame outside the caller's stream (capi.hip, enqueue_frame).  fill_done = NULL: the whole frame on `pre` (= st), the
+// overlapped frames of DESIGN.md 4.5.  Else the ordered pipeline: setup and fill on `pre` -- beside whatever `st` is still
+// doing, normally the previous frame's tile kernel -- and the tile kernel on `st` behind fill_done.  Either way the tile
+// kernel clears the background and carries tile_done; the scratch set must not be in use by a frame whose tile kernel has not
+// finished (the caller keeps several sets and orders them).
 extern "C" hipError_t mi355i_launch_raster_pipelined(const DevScene *S, const FrameParams *P, int mode, RasterScratch *s, hipStream_t st,
                                                      hipStream_t pre, hipEvent_t fill_done, hipEvent_t tile_done)
 {
