@@ -491,6 +491,10 @@ struct RtCtx {
     int nLights;
     orc_stats st;
     int px, py, sample;   /* ray-cast ambient occlusion, generator 2: the pixel sample being traced */
+    /* orc_chain_profile: per ray of the pixel, in the order the rays are cast, what a NEAR-FIRST walk of the tree with
+     * distance culling (the device's ordered walk, modelled) would cost: inner records visited | triangles tested << 16 */
+    uint32_t *chain = nullptr;
+    int chain_n = 0;
 };
 
 /* lowbias32-style integer mixer; the device path (k_raytrace.hip) draws the same numbers */
@@ -527,6 +531,76 @@ static inline bool ray_box(const V3 &o, const V3 &d, const Node32 &box)
     return true;
 }
 
+/* A model of the device's ordered walk (k_raytrace.hip), for orc_chain_profile only -- it does not decide any pixel: visit the
+ * nearer child first, postpone the other, skip children whose box the ray enters beyond the best hit so far (a shadow ray:
+ * beyond the light); a postponed child is entered when it comes up, whatever has been found meanwhile (its children are
+ * culled then).  Cost: one step per inner record visited, one per triangle of a leaf entered.  A shadow ray stops at its
+ * first blocker.  Double-precision slabs: a cost model, not a parity path. */
+template <bool shadow>
+static uint32_t ordered_walk_cost(const orc_scene &s, float nudge, const V3 &origin, const V3 &ray, int avoidSelf, const V3 &lightPos, bool doCulling)
+{
+    uint32_t inner = 0, tris = 0;
+    const double o[3] = {origin.x, origin.y, origin.z}, d[3] = {ray.x, ray.y, ray.z};
+    double best = shadow ? sqrt((double)distancesq(origin, lightPos)) : 1e300;
+    const float lightDistSq = shadow ? distancesq(origin, lightPos) : 0.f;
+    auto enter = [&](const Node32 &n, double &tn) -> bool {
+        double t0 = -1e300, t1 = 1e300;
+        for (int a = 0; a < 3; a++) {
+            if (d[a] == 0.0) { if (o[a] < n.bottom[a] || o[a] > n.top[a]) return false; continue; }
+            double ta = (n.bottom[a] - o[a]) / d[a], tb = (n.top[a] - o[a]) / d[a];
+            if (ta > tb) { const double t = ta; ta = tb; tb = t; }
+            if (ta > t0) t0 = ta;
+            if (tb < t1) t1 = tb;
+        }
+        if (t0 > t1 || t1 < 0.0) return false;
+        tn = t0;
+        return true;
+    };
+    unsigned stack[128];
+    int sp = 0;
+    double tn;
+    if (!enter(s.nodes[0], tn)) return 1u;
+    unsigned cur = 0;
+    for (;;) {
+        const Node32 &n = s.nodes[cur];
+        bool have_next = false;
+        if (!(n.a & 0x80000000u)) {
+            inner++;
+            double ta = 0, tb = 0;
+            bool ha = enter(s.nodes[n.a], ta) && !(ta > best), hb = enter(s.nodes[n.b], tb) && !(tb > best);
+            if (ha && hb) {
+                const bool a_first = ta <= tb;
+                cur = a_first ? n.a : n.b;
+                if (sp < 128) stack[sp++] = a_first ? n.b : n.a;
+                have_next = true;
+            } else if (ha) { cur = n.a; have_next = true; }
+            else if (hb) { cur = n.b; have_next = true; }
+        } else {
+            const unsigned start = n.b, cnt = n.a & 0x7fffffffu;
+            for (unsigned i = start; i < start + cnt; i++) {
+                tris++;
+                const int ti = s.triIdx[i];
+                const Tri &t = s.tris[ti];
+                if (avoidSelf == ti) continue;
+                if (doCulling && !t.twoSided && dot(sub(origin, t.center), t.normal) < 0) continue;
+                const float k = dot(t.normal, ray);
+                if (k == 0.0) continue;
+                const float sdist = (t.d - dot(t.normal, origin)) / k;
+                if (sdist <= 0.0 || sdist <= nudge) continue;
+                const V3 hit = add(mul(ray, sdist), origin);
+                if (dot(t.e1, hit) - t.d1 < 0.0 || dot(t.e2, hit) - t.d2 < 0.0 || dot(t.e3, hit) - t.d3 < 0.0) continue;
+                if (shadow) { if (distancesq(lightPos, hit) < lightDistSq) return inner | (tris << 16); }
+                else if ((double)sdist < best) best = sdist;
+            }
+        }
+        if (!have_next) {
+            if (!sp) break;
+            cur = stack[--sp];
+        }
+    }
+    return inner | (tris << 16);
+}
+
 /* Raytracer.cc:183-308.  shadow: pointHit holds the light position on entry. */
 template <bool shadow>
 static bool bvh_intersect(RtCtx &c, const V3 &origin, const V3 &ray, int avoidSelf, int &bestTri,
@@ -539,6 +613,7 @@ static bool bvh_intersect(RtCtx &c, const V3 &origin, const V3 &ray, int avoidSe
     const V3 lightPos = pointHit;
     if (shadow) { bestTriDist = distancesq(origin, lightPos); c.st.shadow_rays++; }
     else { bestTriDist = FLT_MAX; c.st.normal_rays++; }
+    if (c.chain && c.chain_n < 8) c.chain[c.chain_n++] = ordered_walk_cost<shadow>(s, nudge, origin, ray, avoidSelf, lightPos, doCulling);
     unsigned stack[64];
     int sp = 0;
     stack[sp++] = 0;
@@ -1332,6 +1407,39 @@ void orc_trace_hits(const orc_scene *s, int n, const float *rays6, int32_t *tri,
         bvh_intersect<false>(c, V3(r[0], r[1], r[2]), V3(r[3], r[4], r[5]), -1, best, hit, k1, k2, k3, true);
         tri[i] = best;
         hit3[3 * (size_t)i] = hit.x; hit3[3 * (size_t)i + 1] = hit.y; hit3[3 * (size_t)i + 2] = hit.z;
+    }
+}
+
+void orc_chain_profile(const orc_scene *s, const orc_camera *cam, const orc_light *lights, int n_lights, const orc_opts *oo, uint32_t *out8)
+{
+    const orc_opts &o = *oo;
+    const int W = o.width, H = o.height, SD = o.screen_dist;
+    const M3 mv = m3_from(cam->mv);
+    const V3 eye(cam->eye[0], cam->eye[1], cam->eye[2]);
+    int threads = o.threads > 1 ? o.threads : 1;
+    (void)threads;
+    memset(out8, 0, (size_t)W * H * 8 * sizeof(uint32_t));
+#ifdef _OPENMP
+#pragma omp parallel num_threads(threads)
+#endif
+    {
+        RtCtx c; c.s = s; c.o = &o; c.eye = eye; c.lights = lights; c.nLights = n_lights;
+        memset(&c.st, 0, sizeof c.st);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {                      /* the camera ray of render_raytrace, one sample */
+                const float lx = float((H / 2) - (float)y) / SD, ly = float((float)x - (W / 2)) / SD;
+                const V3 rc = normalized(V3(lx, ly, 1.0f));
+                V3 rw = mul(mv.r1, rc.x);
+                rw = add(rw, mul(mv.r2, rc.y));
+                rw = add(rw, mul(mv.r3, rc.z));
+                rw = normalized(rw);
+                c.px = x; c.py = y; c.sample = 0;
+                c.chain = out8 + ((size_t)y * W + x) * 8; c.chain_n = 0;
+                (void)raytrace(c, eye, rw, -1, 0);
+            }
     }
 }
 

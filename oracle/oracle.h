@@ -132,6 +132,11 @@ int orc_render(const orc_scene *, int mode, const orc_camera *, const orc_light 
  * (index into the scene's triangles, -1 = none) and the hit point.  For tests that need hits, not pixels. */
 void orc_trace_hits(const orc_scene *, int n, const float *rays6, int32_t *tri, float *hit3);
 
+/* Analysis only (scripts/chain_model.py): for every pixel of a raytraced frame, the rays cast for it in casting order (camera,
+ * shadow, reflection, shadow, ...; at most 8) with the cost a near-first walk with distance culling -- a MODEL of the device's
+ * ordered walk -- would have: inner records visited | triangles tested << 16.  out8: width * height * 8 words. */
+void orc_chain_profile(const orc_scene *, const orc_camera *, const orc_light *lights, int n_lights, const orc_opts *, uint32_t *out8);
+
 /* my_aalineColor(surface, x1, y1, x2, y2, greyPixel) (Wu.cc:1509, as Rasterizers.cc:166-183 calls it) for n lines in order,
  * blended into `pixels` (for tests of the wireframe's line generator) */
 void orc_wu_lines(uint32_t *pixels, int width, int height, int pitch_words, int n, const int16_t *xyxy);
