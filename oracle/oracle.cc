@@ -1410,6 +1410,14 @@ void orc_trace_hits(const orc_scene *s, int n, const float *rays6, int32_t *tri,
     }
 }
 
+int orc_ray_box(const float *origin3, const float *ray3, const float *bottom3, const float *top3)
+{
+    Node32 n;
+    for (int i = 0; i < 3; i++) { n.bottom[i] = bottom3[i]; n.top[i] = top3[i]; }
+    n.a = n.b = 0;
+    return ray_box(V3(origin3[0], origin3[1], origin3[2]), V3(ray3[0], ray3[1], ray3[2]), n) ? 1 : 0;
+}
+
 void orc_chain_profile(const orc_scene *s, const orc_camera *cam, const orc_light *lights, int n_lights, const orc_opts *oo, uint32_t *out8)
 {
     const orc_opts &o = *oo;

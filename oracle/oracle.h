@@ -132,6 +132,9 @@ int orc_render(const orc_scene *, int mode, const orc_camera *, const orc_light 
  * (index into the scene's triangles, -1 = none) and the hit point.  For tests that need hits, not pixels. */
 void orc_trace_hits(const orc_scene *, int n, const float *rays6, int32_t *tri, float *hit3);
 
+/* RayIntersectsBox (Raytracer.cc:99-151) on one ray and one box: 1 = the reference enters the node's children */
+int orc_ray_box(const float *origin3, const float *ray3, const float *bottom3, const float *top3);
+
 /* Analysis only (scripts/chain_model.py): for every pixel of a raytraced frame, the rays cast for it in casting order (camera,
  * shadow, reflection, shadow, ...; at most 8) with the cost a near-first walk with distance culling -- a MODEL of the device's
  * ordered walk -- would have: inner records visited | triangles tested << 16.  out8: width * height * 8 words. */

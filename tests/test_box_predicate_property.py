@@ -1,0 +1,73 @@
+"""A property of the reference's box test the four-wide tree of DESIGN.md 8 rests on (nothing in the product uses it yet):
+RayIntersectsBox (Raytracer.cc:99-151) is monotone in the box -- a ray that passes a box passes every box that contains it,
+in the reference's own float arithmetic, early returns and parallel-ray cases included.  A node's box is the exact union of
+its children's, so 'the grandchild's box passes' implies 'the child's box passes'."""
+import ctypes as C
+
+import numpy as np
+
+
+def test_a_ray_that_passes_a_box_passes_every_box_around_it(oracle):
+    L = oracle.lib()
+    L.orc_ray_box.argtypes = [C.c_void_p] * 4
+    L.orc_ray_box.restype = C.c_int
+    rng = np.random.default_rng(11)
+    n, passed = 60000, 0
+    for i in range(n):
+        kind = i % 4
+        lo = rng.uniform(-1, 1, 3).astype(np.float32)
+        hi = (lo + rng.uniform(0, 1, 3) * (1e-3 if kind == 3 else 1.0)).astype(np.float32)
+        # the outer box: grown by anything from nothing (shared faces, as between a node and its child) to a lot
+        grow_lo = (rng.uniform(0, 1, 3) * rng.integers(0, 2, 3)).astype(np.float32)
+        grow_hi = (rng.uniform(0, 1, 3) * rng.integers(0, 2, 3)).astype(np.float32)
+        olo, ohi = (lo - grow_lo).astype(np.float32), (hi + grow_hi).astype(np.float32)
+        o = rng.uniform(-3, 3, 3).astype(np.float32)
+        if kind == 1:      # aimed at the inner box: most rays pass, many of them grazing
+            target = (lo + (hi - lo) * rng.uniform(-0.05, 1.05, 3)).astype(np.float32)
+            d = target - o
+        else:
+            d = rng.normal(0, 1, 3).astype(np.float32)
+        if kind == 2:      # axis-parallel rays, origins on faces
+            z = rng.integers(0, 3)
+            d[z] = 0.0
+            if rng.integers(0, 2): o[z] = (lo[z], hi[z], olo[z], ohi[z])[rng.integers(0, 4)]
+        d = (d / max(float(np.linalg.norm(d)), 1e-20)).astype(np.float32)
+        args = lambda a, b: (o.ctypes.data, d.ctypes.data, a.ctypes.data, b.ctypes.data)
+        if L.orc_ray_box(*args(lo, hi)):
+            passed += 1
+            assert L.orc_ray_box(*args(olo, ohi)), "ray %s %s passes %s..%s but not %s..%s" % (o, d, lo, hi, olo, ohi)
+    assert passed > n // 10
+
+
+def test_on_a_real_tree_boxes_are_unions_and_the_predicate_follows(oracle):
+    import renderer_amd.assets as A
+    L = oracle.lib()
+    L.orc_ray_box.argtypes = [C.c_void_p] * 4
+    L.orc_ray_box.restype = C.c_int
+    s = oracle.Scene(A.mesh_path("statue.ply"))
+    s.bvh_build()
+    nodes, _ = s.bvh()
+    nodes = np.ascontiguousarray(nodes)
+    raw = nodes.view(np.uint8).reshape(len(nodes), 32)
+    box = raw[:, :24].copy().view(np.float32).reshape(-1, 6)          # bottom[3], top[3]
+    ab = raw[:, 24:].copy().view(np.uint32).reshape(-1, 2)
+    inner = np.nonzero((ab[:, 0] & 0x80000000) == 0)[0]
+    # (1) a node's box holds its children's; it is their exact union wherever both children are inner nodes or leaves alike
+    a, b = ab[inner, 0], ab[inner, 1]
+    assert (box[inner, :3] <= np.minimum(box[a, :3], box[b, :3])).all() and (box[inner, 3:] >= np.maximum(box[a, 3:], box[b, 3:])).all()
+    assert np.array_equal(box[inner, :3], np.minimum(box[a, :3], box[b, :3])) and np.array_equal(box[inner, 3:], np.maximum(box[a, 3:], box[b, 3:]))
+    # (2) the predicate on (ray, parent, child) samples: rays from outside towards points of the child's box
+    rng = np.random.default_rng(3)
+    passed = 0
+    for _ in range(30000):
+        p = int(inner[rng.integers(0, len(inner))])
+        c = int(ab[p, rng.integers(0, 2)])
+        o = rng.uniform(-2, 2, 3).astype(np.float32)
+        t = (box[c, :3] + (box[c, 3:] - box[c, :3]) * rng.uniform(-0.1, 1.1, 3)).astype(np.float32)
+        d = t - o
+        d = (d / max(float(np.linalg.norm(d)), 1e-20)).astype(np.float32)
+        lo_c, hi_c, lo_p, hi_p = (np.ascontiguousarray(v) for v in (box[c, :3], box[c, 3:], box[p, :3], box[p, 3:]))
+        if L.orc_ray_box(o.ctypes.data, d.ctypes.data, lo_c.ctypes.data, hi_c.ctypes.data):
+            passed += 1
+            assert L.orc_ray_box(o.ctypes.data, d.ctypes.data, lo_p.ctypes.data, hi_p.ctypes.data), "node %d child %d" % (p, c)
+    assert passed > 10000
