@@ -495,6 +495,8 @@ struct RtCtx {
      * distance culling (the device's ordered walk, modelled) would cost: inner records visited | triangles tested << 16 */
     uint32_t *chain = nullptr;
     int chain_n = 0;
+    bool chain_quad = false;      /* price the four-wide walk instead */
+    uint32_t chain_max_sp = 0;
 };
 
 /* lowbias32-style integer mixer; the device path (k_raytrace.hip) draws the same numbers */
@@ -536,8 +538,11 @@ static inline bool ray_box(const V3 &o, const V3 &d, const Node32 &box)
  * beyond the light); a postponed child is entered when it comes up, whatever has been found meanwhile (its children are
  * culled then).  Cost: one step per inner record visited, one per triangle of a leaf entered.  A shadow ray stops at its
  * first blocker.  Double-precision slabs: a cost model, not a parity path. */
+/* quad: a step looks at the node's grandchildren (a leaf child takes a slot of its own), nearest first, the others postponed:
+ * the four-wide tree of DESIGN.md 8, priced.  *max_sp: the deepest the stack of postponed slots got. */
 template <bool shadow>
-static uint32_t ordered_walk_cost(const orc_scene &s, float nudge, const V3 &origin, const V3 &ray, int avoidSelf, const V3 &lightPos, bool doCulling)
+static uint32_t ordered_walk_cost(const orc_scene &s, float nudge, const V3 &origin, const V3 &ray, int avoidSelf, const V3 &lightPos, bool doCulling,
+                                  bool quad = false, uint32_t *max_sp = nullptr)
 {
     uint32_t inner = 0, tris = 0;
     const double o[3] = {origin.x, origin.y, origin.z}, d[3] = {ray.x, ray.y, ray.z};
@@ -564,7 +569,22 @@ static uint32_t ordered_walk_cost(const orc_scene &s, float nudge, const V3 &ori
     for (;;) {
         const Node32 &n = s.nodes[cur];
         bool have_next = false;
-        if (!(n.a & 0x80000000u)) {
+        if (!(n.a & 0x80000000u) && quad) {
+            inner++;
+            unsigned slot[4]; double key[4]; int ns = 0;
+            for (unsigned child : {n.a, n.b}) {
+                const Node32 &cn = s.nodes[child];
+                if (cn.a & 0x80000000u) { double t; if (enter(cn, t) && !(t > best)) { slot[ns] = child; key[ns++] = t; } }
+                else for (unsigned g : {cn.a, cn.b}) { double t; if (enter(s.nodes[g], t) && !(t > best)) { slot[ns] = g; key[ns++] = t; } }
+            }
+            for (int i = 1; i < ns; i++)                        /* nearest first */
+                for (int j = i; j > 0 && key[j] < key[j - 1]; j--) { const double t = key[j]; key[j] = key[j - 1]; key[j - 1] = t; const unsigned u = slot[j]; slot[j] = slot[j - 1]; slot[j - 1] = u; }
+            if (ns) {
+                cur = slot[0]; have_next = true;
+                for (int i = ns - 1; i >= 1; i--) if (sp < 128) stack[sp++] = slot[i];
+                if (max_sp && (uint32_t)sp > *max_sp) *max_sp = (uint32_t)sp;
+            }
+        } else if (!(n.a & 0x80000000u)) {
             inner++;
             double ta = 0, tb = 0;
             bool ha = enter(s.nodes[n.a], ta) && !(ta > best), hb = enter(s.nodes[n.b], tb) && !(tb > best);
@@ -572,6 +592,7 @@ static uint32_t ordered_walk_cost(const orc_scene &s, float nudge, const V3 &ori
                 const bool a_first = ta <= tb;
                 cur = a_first ? n.a : n.b;
                 if (sp < 128) stack[sp++] = a_first ? n.b : n.a;
+                if (max_sp && (uint32_t)sp > *max_sp) *max_sp = (uint32_t)sp;
                 have_next = true;
             } else if (ha) { cur = n.a; have_next = true; }
             else if (hb) { cur = n.b; have_next = true; }
@@ -613,7 +634,7 @@ static bool bvh_intersect(RtCtx &c, const V3 &origin, const V3 &ray, int avoidSe
     const V3 lightPos = pointHit;
     if (shadow) { bestTriDist = distancesq(origin, lightPos); c.st.shadow_rays++; }
     else { bestTriDist = FLT_MAX; c.st.normal_rays++; }
-    if (c.chain && c.chain_n < 8) c.chain[c.chain_n++] = ordered_walk_cost<shadow>(s, nudge, origin, ray, avoidSelf, lightPos, doCulling);
+    if (c.chain && c.chain_n < 8) c.chain[c.chain_n++] = ordered_walk_cost<shadow>(s, nudge, origin, ray, avoidSelf, lightPos, doCulling, c.chain_quad, &c.chain_max_sp);
     unsigned stack[64];
     int sp = 0;
     stack[sp++] = 0;
@@ -1418,8 +1439,9 @@ int orc_ray_box(const float *origin3, const float *ray3, const float *bottom3, c
     return ray_box(V3(origin3[0], origin3[1], origin3[2]), V3(ray3[0], ray3[1], ray3[2]), n) ? 1 : 0;
 }
 
-void orc_chain_profile(const orc_scene *s, const orc_camera *cam, const orc_light *lights, int n_lights, const orc_opts *oo, uint32_t *out8)
+uint32_t orc_chain_profile(const orc_scene *s, const orc_camera *cam, const orc_light *lights, int n_lights, const orc_opts *oo, uint32_t *out8, int quad)
 {
+    uint32_t max_sp = 0;
     const orc_opts &o = *oo;
     const int W = o.width, H = o.height, SD = o.screen_dist;
     const M3 mv = m3_from(cam->mv);
@@ -1433,6 +1455,7 @@ void orc_chain_profile(const orc_scene *s, const orc_camera *cam, const orc_ligh
     {
         RtCtx c; c.s = s; c.o = &o; c.eye = eye; c.lights = lights; c.nLights = n_lights;
         memset(&c.st, 0, sizeof c.st);
+        c.chain_quad = quad != 0;
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 1)
 #endif
@@ -1448,7 +1471,12 @@ void orc_chain_profile(const orc_scene *s, const orc_camera *cam, const orc_ligh
                 c.chain = out8 + ((size_t)y * W + x) * 8; c.chain_n = 0;
                 (void)raytrace(c, eye, rw, -1, 0);
             }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        if (c.chain_max_sp > max_sp) max_sp = c.chain_max_sp;
     }
+    return max_sp;
 }
 
 void orc_wu_lines(uint32_t *pixels, int width, int height, int pitch_words, int n, const int16_t *xyxy)

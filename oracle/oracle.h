@@ -137,8 +137,9 @@ int orc_ray_box(const float *origin3, const float *ray3, const float *bottom3, c
 
 /* Analysis only (scripts/chain_model.py): for every pixel of a raytraced frame, the rays cast for it in casting order (camera,
  * shadow, reflection, shadow, ...; at most 8) with the cost a near-first walk with distance culling -- a MODEL of the device's
- * ordered walk -- would have: inner records visited | triangles tested << 16.  out8: width * height * 8 words. */
-void orc_chain_profile(const orc_scene *, const orc_camera *, const orc_light *lights, int n_lights, const orc_opts *, uint32_t *out8);
+ * ordered walk -- would have: inner records visited | triangles tested << 16.  out8: width * height * 8 words.  quad: price the four-wide walk (a
+ * step looks at a node's grandchildren).  Returns the deepest stack of postponed nodes any ray needed. */
+uint32_t orc_chain_profile(const orc_scene *, const orc_camera *, const orc_light *lights, int n_lights, const orc_opts *, uint32_t *out8, int quad);
 
 /* my_aalineColor(surface, x1, y1, x2, y2, greyPixel) (Wu.cc:1509, as Rasterizers.cc:166-183 calls it) for n lines in order,
  * blended into `pixels` (for tests of the wireframe's line generator) */
