@@ -1431,6 +1431,63 @@ void orc_trace_hits(const orc_scene *s, int n, const float *rays6, int32_t *tri,
     }
 }
 
+/* The reachability rule a four-wide record would use, as a checker of the rule only: at a node the reference has
+ * entered, a LEAF child is entered; an inner child's INNER children are entered iff their OWN box passes RayIntersectsBox (which
+ * implies the child's passes: the predicate is monotone in the box and a node's box is the union of its children's); an inner
+ * child's LEAF children are entered iff the child's box passes.  Candidates in any order: the nearest wins, the lowest position
+ * in the triangle list among equal distances (the reference's left-first order finds that one first).  Must name the triangle
+ * BVH_IntersectTriangles<false> names, for every ray. */
+void orc_trace_hits_fourwide(const orc_scene *sc, int n, const float *rays6, int32_t *tri, float *hit3)
+{
+    const orc_scene &s = *sc;
+    orc_opts o;
+    orc_default_opts(&o, 16, 16);
+    const float nudge = o.nudge;
+    for (int r = 0; r < n; r++) {
+        const float *q = rays6 + 6 * (size_t)r;
+        const V3 origin(q[0], q[1], q[2]), ray(q[3], q[4], q[5]);
+        int best = -1; unsigned bestPos = 0; float bestDist = FLT_MAX; V3 bestHit(0.f, 0.f, 0.f);
+        auto leaf = [&](const Node32 &n) {
+            const unsigned start = n.b, cnt = n.a & 0x7fffffffu;
+            for (unsigned i = start; i < start + cnt; i++) {
+                const int ti = s.triIdx[i];
+                const Tri &t = s.tris[ti];
+                if (!t.twoSided && dot(sub(origin, t.center), t.normal) < 0) continue;
+                const float k = dot(t.normal, ray);
+                if (k == 0.0) continue;
+                const float sdist = (t.d - dot(t.normal, origin)) / k;
+                if (sdist <= 0.0 || sdist <= nudge) continue;
+                const V3 hit = add(mul(ray, sdist), origin);
+                if (dot(t.e1, hit) - t.d1 < 0.0 || dot(t.e2, hit) - t.d2 < 0.0 || dot(t.e3, hit) - t.d3 < 0.0) continue;
+                const float hitZ = distancesq(origin, hit);
+                if (hitZ < bestDist || (hitZ == bestDist && best >= 0 && i < bestPos)) { bestDist = hitZ; best = ti; bestPos = i; bestHit = hit; }
+            }
+        };
+        std::vector<unsigned> stack;
+        const Node32 &root = s.nodes[0];
+        if (root.a & 0x80000000u) leaf(root);
+        else if (ray_box(origin, ray, root)) stack.push_back(0u);
+        while (!stack.empty()) {
+            const Node32 &n = s.nodes[stack.back()];             /* an inner node the reference has entered */
+            stack.pop_back();
+            for (unsigned child : {n.b, n.a}) {                  /* (any order) */
+                const Node32 &c = s.nodes[child];
+                if (c.a & 0x80000000u) { leaf(c); continue; }
+                bool child_passes = false, asked = false;
+                for (unsigned g : {c.a, c.b}) {
+                    const Node32 &gn = s.nodes[g];
+                    if (gn.a & 0x80000000u) {
+                        if (!asked) { child_passes = ray_box(origin, ray, c); asked = true; }
+                        if (child_passes) leaf(gn);
+                    } else if (ray_box(origin, ray, gn)) stack.push_back(g);
+                }
+            }
+        }
+        tri[r] = best;
+        hit3[3 * (size_t)r] = bestHit.x; hit3[3 * (size_t)r + 1] = bestHit.y; hit3[3 * (size_t)r + 2] = bestHit.z;
+    }
+}
+
 int orc_ray_box(const float *origin3, const float *ray3, const float *bottom3, const float *top3)
 {
     Node32 n;

@@ -132,6 +132,10 @@ int orc_render(const orc_scene *, int mode, const orc_camera *, const orc_light 
  * (index into the scene's triangles, -1 = none) and the hit point.  For tests that need hits, not pixels. */
 void orc_trace_hits(const orc_scene *, int n, const float *rays6, int32_t *tri, float *hit3);
 
+/* The same question answered through the reachability rule of a four-wide tree (oracle.cc): a checker of that
+ * rule -- it must name the triangle orc_trace_hits names for every ray.  Nothing in the product uses it. */
+void orc_trace_hits_fourwide(const orc_scene *, int n, const float *rays6, int32_t *tri, float *hit3);
+
 /* RayIntersectsBox (Raytracer.cc:99-151) on one ray and one box: 1 = the reference enters the node's children */
 int orc_ray_box(const float *origin3, const float *ray3, const float *bottom3, const float *top3);
 
