@@ -99,7 +99,12 @@ typedef struct {
      *            stream copies it to the caller's frame buffer, which holds the frame in stream order as always)
      *            | 64 the round-2 pipeline instead: setup and fill of a frame on an internal stream beside the previous frame's
      *            tile kernel, the tile kernels in order on the caller's stream
-     * [6], [7] reserved */
+     *            | 128 raytrace: the four-wide walk (128-byte records holding a node's leaf children and its inner children's
+     *            children; where the tree's boxes are exact unions of their children's) instead of the two-wide one
+     *            | 256 raytrace: no work sharing inside a wave (default: lanes without a ray of their own walk postponed
+     *            subtrees of other lanes' shadow rays -- a shadow ray's verdict is an OR over the triangles its walk reaches)
+     * [6] raytrace: idle lanes of a wave before subtrees are handed over (default 8)
+     * [7] reserved */
     int32_t tune[8];
     /* Compile-time extras of the reference, off by default like there: */
     int32_t mlaa;            /* configure --enable-mlaa && !$NOMLAA: the morphological anti-aliasing post filter (MLAA.cc) on

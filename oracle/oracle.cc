@@ -495,7 +495,7 @@ struct RtCtx {
      * distance culling (the device's ordered walk, modelled) would cost: inner records visited | triangles tested << 16 */
     uint32_t *chain = nullptr;
     int chain_n = 0;
-    bool chain_quad = false;      /* price the four-wide walk instead */
+    int chain_quad = 0;        /* price the four-wide walk instead */
     uint32_t chain_max_sp = 0;
 };
 
@@ -542,8 +542,9 @@ static inline bool ray_box(const V3 &o, const V3 &d, const Node32 &box)
  * the four-wide tree of DESIGN.md 8, priced.  *max_sp: the deepest the stack of postponed slots got. */
 template <bool shadow>
 static uint32_t ordered_walk_cost(const orc_scene &s, float nudge, const V3 &origin, const V3 &ray, int avoidSelf, const V3 &lightPos, bool doCulling,
-                                  bool quad = false, uint32_t *max_sp = nullptr)
+                                  int quad_kind = 0, uint32_t *max_sp = nullptr)
 {
+    const bool quad = quad_kind != 0;
     uint32_t inner = 0, tris = 0;
     const double o[3] = {origin.x, origin.y, origin.z}, d[3] = {ray.x, ray.y, ray.z};
     double best = shadow ? sqrt((double)distancesq(origin, lightPos)) : 1e300;
@@ -575,7 +576,15 @@ static uint32_t ordered_walk_cost(const orc_scene &s, float nudge, const V3 &ori
             for (unsigned child : {n.a, n.b}) {
                 const Node32 &cn = s.nodes[child];
                 if (cn.a & 0x80000000u) { double t; if (enter(cn, t) && !(t > best)) { slot[ns] = child; key[ns++] = t; } }
-                else for (unsigned g : {cn.a, cn.b}) { double t; if (enter(s.nodes[g], t) && !(t > best)) { slot[ns] = g; key[ns++] = t; } }
+                else if (quad_kind == 2 && ((s.nodes[cn.a].a | s.nodes[cn.b].a) & 0x80000000u)) {
+                    /* variant 2: a child with a leaf below it is a slot by itself (every rule stays local to a slot) */
+                    double t; if (enter(cn, t) && !(t > best)) { slot[ns] = child; key[ns++] = t; }
+                } else for (unsigned g : {cn.a, cn.b}) {
+                    double t;
+                    /* variant 3: a leaf grandchild is entered iff its PARENT's box is (the reference's rule, kept local by storing that box) */
+                    const Node32 &gb = (quad_kind == 3 && (s.nodes[g].a & 0x80000000u)) ? cn : s.nodes[g];
+                    if (enter(gb, t) && !(t > best)) { slot[ns] = g; key[ns++] = t; }
+                }
             }
             for (int i = 1; i < ns; i++)                        /* nearest first */
                 for (int j = i; j > 0 && key[j] < key[j - 1]; j--) { const double t = key[j]; key[j] = key[j - 1]; key[j - 1] = t; const unsigned u = slot[j]; slot[j] = slot[j - 1]; slot[j - 1] = u; }
@@ -1512,7 +1521,7 @@ uint32_t orc_chain_profile(const orc_scene *s, const orc_camera *cam, const orc_
     {
         RtCtx c; c.s = s; c.o = &o; c.eye = eye; c.lights = lights; c.nLights = n_lights;
         memset(&c.st, 0, sizeof c.st);
-        c.chain_quad = quad != 0;
+        c.chain_quad = quad;
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 1)
 #endif

@@ -227,7 +227,7 @@ class Scene:
         f = lib().orc_chain_profile
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         f.restype = C.c_uint32
-        sp = f(self._h, C.byref(cam), lights, n_lights, C.byref(opts), out.ctypes.data, 1 if quad else 0)
+        sp = f(self._h, C.byref(cam), lights, n_lights, C.byref(opts), out.ctypes.data, int(quad))
         return out, int(sp)
 
     def render(self, mode: int, cam: Camera, lights, n_lights: int, opts: Opts, shadow_maps=None,

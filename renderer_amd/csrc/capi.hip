@@ -22,9 +22,9 @@
 // kernel launchers (defined next to their kernels)
 extern "C" hipError_t mi355i_launch_tile_select(const FrameParams *P, const float4 *boxes, int n_boxes, const uint32_t *order, uint32_t *sel, uint32_t *cnt,
                                                 hipStream_t st);
-extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext);
+extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext, int quad);
 extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int ordered, int waves, int batch, int ext,
-                                             int n_blocks, hipStream_t);
+                                             int quad, int stack_depth, int n_blocks, hipStream_t);
 extern "C" hipError_t mi355i_launch_points(const DevScene *, const FrameParams *, int as_triangles, hipStream_t);
 extern "C" hipError_t mi355i_launch_mlaa(uint32_t *d_pixels, uint32_t *d_scratch, int resX, int resY, hipStream_t st);
 struct RasterScratch;
@@ -339,6 +339,10 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.prof_ordered = (flags & 8) ? 1 : 0;
     P.no_cull = (flags & 16) ? 1 : 0;
     P.no_pipe = (flags & 32) ? 1 : (flags & 64) ? 2 : 0;
+    P.quad = (flags & 128) ? 1 : 0;
+    // work sharing inside a wave (k_raytrace.hip): on by default with 8 idle lanes as the threshold; tune[6] sets the threshold,
+    // flag 256 turns it off; it needs the wave in lockstep (xmin 64)
+    P.steal_min = ((flags & 256) || P.xmin < 64) ? 0 : (t[6] > 0 ? (t[6] > 64 ? 64 : t[6]) : 8);
     // A profiler collecting hardware counters runs one kernel at a time (rocprofv3 --pmc): frames that wait for each other
     // across streams gain nothing there and were seen to stall for minutes.  MI355_NO_OVERLAP=1 asks for the same.
     static const int no_overlap = [] {
@@ -371,6 +375,17 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
 // Thread the reference's flat BVH (pre-order CacheFriendlyBVHNode[], BVH.h:52-65) with hit/miss
 // links and build the leaf-ordered triangle streams.
 int upload_cull_boxes(mi355_ctx *c, const void *nodes32B, uint32_t nN);
+// Stack rows of the four-wide walk for a tree with `inner_levels` levels of inner nodes: a step postpones up to three slots
+// and descends two levels (a leaf child's slot is a leaf: nothing is postponed below it), plus one row of slack.
+uint32_t quad_stack_rows(uint32_t inner_levels) { return 3u * ((inner_levels + 1u) / 2u) + 1u; }
+// a tree is being replaced: frames of the device entry points run on internal streams and may still read the old streams, and a
+// failed build must not leave the context describing a tree whose buffers are half written
+int begin_tree_update(mi355_ctx *c)
+{
+    HIP_TRY(hipDeviceSynchronize(), -40);
+    c->has_bvh = false; c->n_cull_boxes = 0; c->dev.ordered_ok = 0u; c->dev.quad_ok = 0u;
+    return 0;
+}
 int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int32_t *triIdx, uint32_t nI)
 {
     struct RefNode { float bottom[3], top[3]; uint32_t a, b; };
@@ -416,13 +431,14 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
         return tri_link(((size_t)off[i] - tri_base) / 2, true);
     };
     const size_t wide_base = n4;                      // wide records of the ordered walk: 4 float4 per inner node
-    const size_t n4_all = n4 + 4 * n_inner;
+    const size_t quad_base = (n4 + 4 * n_inner + 7) & ~(size_t)7;     // quad records of the four-wide walk: 8 float4 per inner node
+    const size_t n4_all = quad_base + 8 * n_inner;
     if (n4_all + 8 >= (size_t)MI_VROOT_LINK) return fail(-30, "BVH too large");
     HIP_TRY(c->pin_walk.ensure((n4_all + 4) * sizeof(float4)), -31);
     float4 *walk = (float4 *)c->pin_walk.p;
     memset(walk, 0, (n4_all + 4) * sizeof(float4));
     std::vector<uint32_t> order; order.reserve(nN);   // the reference's visiting order
-    bool list_in_visit_order = true;
+    bool list_in_visit_order = true, exact_unions = true;
     uint32_t list_end = 0;
     int inner_levels = 0;
     std::vector<uint8_t> visited(nN, 0);
@@ -454,6 +470,29 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
             w[1] = make_float4(ca.bottom[2], ca.top[2], u2f(wlink(n.a)), u2f(wlink(n.b)));
             w[2] = make_float4(cb.bottom[0], cb.top[0], cb.bottom[1], cb.top[1]);
             w[3] = make_float4(cb.bottom[2], cb.top[2], 0.f, 0.f);
+            // quad record (dev_scene.h): a leaf child is a slot; an inner child contributes its two children, own boxes
+            float4 *q = &walk[quad_base + 4 * (size_t)off[it.node]];
+            for (int k = 0; k < 2; k++) {
+                const uint32_t x = k ? n.b : n.a;
+                if (is_leaf(x)) {
+                    q[4 * k] = make_float4(rn[x].bottom[0], rn[x].top[0], rn[x].bottom[1], rn[x].top[1]);
+                    q[4 * k + 1] = make_float4(rn[x].bottom[2], rn[x].top[2], u2f(link(x)), 0.f);
+                    q[4 * k + 3] = make_float4(0.f, 0.f, u2f(MI_END_LINK), 0.f);
+                } else {
+                    if (rn[x].a >= nN || rn[x].b >= nN) return fail(-30, "BVH child index out of range at node %u", x);
+                    for (int g = 0; g < 2; g++) {
+                        const uint32_t y = g ? rn[x].b : rn[x].a;
+                        const uint32_t l = is_leaf(y) ? link(y) : (uint32_t)(quad_base + 4 * (size_t)off[y]);
+                        q[4 * k + 2 * g] = make_float4(rn[y].bottom[0], rn[y].top[0], rn[y].bottom[1], rn[y].top[1]);
+                        q[4 * k + 2 * g + 1] = make_float4(rn[y].bottom[2], rn[y].top[2], u2f(l), 0.f);
+                    }
+                }
+            }
+            // the four-wide walk derives a child's box from its children's: the node's box must be their exact union
+            for (int k = 0; k < 3; k++) {
+                const float lo = ca.bottom[k] < cb.bottom[k] ? ca.bottom[k] : cb.bottom[k], hi = ca.top[k] > cb.top[k] ? ca.top[k] : cb.top[k];
+                if (!(lo == n.bottom[k] && hi == n.top[k])) exact_unions = false;
+            }
         } else {
             const uint32_t cnt = n.a & 0x7fffffffu, first = n.b;
             if (cnt) { if (first < list_end) list_in_visit_order = false; list_end = first + cnt; }
@@ -519,6 +558,9 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
     c->dev.ordered_ok = (tame && bounded && list_in_visit_order && inner_levels + 1 <= MI_MAX_STACK) ? 1u : 0u;
     c->dev.stack_depth = (uint32_t)(inner_levels + 1);
     c->dev.scene_mag = mag;
+    c->dev.qstack_depth = quad_stack_rows((uint32_t)inner_levels);
+    c->dev.quad_ok = (c->dev.ordered_ok && exact_unions && c->dev.qstack_depth <= (uint32_t)MI_MAX_QSTACK) ? 1u : 0u;
+    c->dev.quad_base = (uint32_t)quad_base;
 
     const uint32_t T = c->nT;
     // (+ zeroed edge records behind the dummy blocks of empty leaves: a NaN ray can pass their plane test)
@@ -566,6 +608,8 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
         const uint32_t wroot = is_leaf(0) ? link(0) : (uint32_t)(wide_base + 2 * (size_t)off[0]);
         c->dev.vroot_a = make_float4(rn[0].bottom[0], rn[0].top[0], rn[0].bottom[1], rn[0].top[1]);
         c->dev.vroot_b = make_float4(rn[0].bottom[2], rn[0].top[2], u2f(wroot), u2f(MI_END_LINK));
+        c->dev.qvroot_a = c->dev.vroot_a;
+        c->dev.qvroot_b = make_float4(rn[0].bottom[2], rn[0].top[2], u2f(is_leaf(0) ? link(0) : (uint32_t)quad_base), 0.f);
     }
     c->dev.n_nodes = nN;
     c->has_bvh = true;
@@ -818,14 +862,18 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
         if (ext && (stats || batch)) return fail(-41, "refractions / ray-cast ambient occlusion: single frames without collect_stats only");
         if (batch && !(ordered && !stats)) return fail(-41, "batched frames need the ordered walk (checked tree, no collect_stats, no reference-order flag)");
         const long long work_tiles = (((long long)P.W + 7) / 8) * (((long long)P.n_rows + 7) / 8) * (P.aa ? 4 : 1) * P.n_frames;
+        // the four-wide walk (dev_scene.h) on request (tune flag 128) where the tree allows it: it visits 0.57 of the inner records
+        // but a step costs 635 instructions against 377 (scripts/isa_loop_stats.py), and the kernel is bound by instruction issue
+        const int quad = (ordered && !ext && c->dev.quad_ok && P.quad) ? 1 : 0;
+        const int stack_rows = quad ? (int)c->dev.qstack_depth : (int)c->dev.stack_depth;
         int waves = 2;
         if (ordered && !stats && !ext) {
             for (int w = 4; w >= 3; w--) {
                 const bool wanted = P.blocks_per_cu == 0 ? work_tiles >= 20ll * w * c->n_cus * 4 : P.blocks_per_cu >= w;
-                if (wanted && mi355i_raytrace_blocks_per_cu(0, P.exact_box, 1, w, batch, (int)c->dev.stack_depth, 0) >= w) { waves = w; break; }
+                if (wanted && mi355i_raytrace_blocks_per_cu(0, P.exact_box, 1, w, batch, stack_rows, 0, quad) >= w) { waves = w; break; }
             }
         }
-        int per_cu = mi355i_raytrace_blocks_per_cu(stats, P.exact_box, ordered, waves, batch, (int)c->dev.stack_depth, ext);
+        int per_cu = mi355i_raytrace_blocks_per_cu(stats, P.exact_box, ordered, waves, batch, stack_rows, ext, quad);
         if (per_cu > waves) per_cu = waves;
         if (P.blocks_per_cu > 0 && P.blocks_per_cu < per_cu) per_cu = P.blocks_per_cu;
         int n_blocks = per_cu * c->n_cus;
@@ -845,7 +893,7 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
             if ((e = mi355i_launch_tile_select(&P, (const float4 *)c->cull_boxes.p, c->n_cull_boxes, P.tile_order, (uint32_t *)((char *)buf->p + 512),
                                                (uint32_t *)buf->p, st)) != hipSuccess) return fail(-43, "tile culling launch failed: %s", hipGetErrorString(e));
         }
-        e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, waves, batch, ext, n_blocks, st);
+        e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, waves, batch, ext, quad, stack_rows, n_blocks, st);
         break;
     }
     case MI355_MODE_LINES:
@@ -1043,7 +1091,7 @@ int mi355_scene_set_bvh(mi355_ctx *c, const void *nodes32B, uint32_t n_nodes, co
 {
     if (!c || !nodes32B || !tri_idx) return fail(-3, "mi355_scene_set_bvh: null argument");
     if (int r = select_device(c)) return r;
-    HIP_TRY(hipStreamSynchronize(c->stream), -40);
+    if (int r = begin_tree_update(c)) return r;
     return build_bvh_streams(c, nodes32B, n_nodes, tri_idx, n_idx);
 }
 
@@ -1063,8 +1111,8 @@ int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_
     if (int r = select_device(c)) return r;
     const uint32_t T = c->nT;
     if (T == 0) return fail(-50, "mi355_build_bvh: scene has no triangles");
-    if ((size_t)5 * T + 16 >= (size_t)MI_VROOT_LINK) return fail(-30, "BVH too large");
-    HIP_TRY(hipStreamSynchronize(c->stream), -40);
+    if ((size_t)9 * T + 32 >= (size_t)MI_VROOT_LINK) return fail(-30, "BVH too large");
+    if (int r = begin_tree_update(c)) return r;
     static_assert(sizeof(BvLevelNode) == 48 && sizeof(BvTreeNode) == 32, "layouts shared with k_bvh.hip");
     // ---- buffers (kept for rebuilds) ----
     const size_t max_level_nodes = (size_t)T / 2 + 4, max_tree = (size_t)2 * T + 4;
@@ -1082,7 +1130,7 @@ int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_
     for (int i = 0; i < 5; i++) HIP_TRY(c->bvh_num[i].ensure(max_tree * 4), -31);
     HIP_TRY(c->bvh_out.ensure(max_tree * 32), -31);
     // the finished streams go straight into the buffers the kernels read (dev_scene.h)
-    const size_t walk_bytes = ((size_t)5 * T + 16) * sizeof(float4);
+    const size_t walk_bytes = ((size_t)9 * T + 32) * sizeof(float4);      // (2 + 4 + 8 float4 per inner node, 2 per triangle)
     HIP_TRY(c->walk.ensure(walk_bytes), -31);
     HIP_TRY(c->tri_edge.ensure((size_t)T * 3 * sizeof(float4) + 16), -31);
     HIP_TRY(c->tri_shade.ensure((size_t)T * 5 * sizeof(float4) + 16), -31);
@@ -1156,6 +1204,10 @@ int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_
     c->dev.ordered_ok = (ctl->tame && ctl->bounded && ctl->inner_levels + 1u <= (uint32_t)MI_MAX_STACK) ? 1u : 0u;
     c->dev.stack_depth = ctl->inner_levels + 1u;
     c->dev.scene_mag = ctl->mag;
+    c->dev.qstack_depth = quad_stack_rows(ctl->inner_levels);
+    c->dev.quad_ok = (c->dev.ordered_ok && ctl->qunion && c->dev.qstack_depth <= (uint32_t)MI_MAX_QSTACK) ? 1u : 0u;
+    c->dev.quad_base = ctl->quad_base;
+    c->dev.qvroot_a = ctl->qvroot_a; c->dev.qvroot_b = ctl->qvroot_b;
     c->dev.walk = (const float4 *)c->walk.p;
     c->dev.tri_edge = (const float4 *)c->tri_edge.p;
     c->dev.tri_shade = (const float4 *)c->tri_shade.p;
@@ -1453,6 +1505,7 @@ int mi355i_fetch_traversal(mi355_ctx *c, int which, void *out, size_t bytes)
         memcpy(w, &c->dev.root_a, 16); memcpy(w + 4, &c->dev.root_b, 16); memcpy(w + 8, &c->dev.vroot_a, 16); memcpy(w + 12, &c->dev.vroot_b, 16);
         w[16] = c->dev.root_link; w[17] = c->dev.tri_base; w[18] = c->dev.ordered_ok; w[19] = c->dev.stack_depth;
         memcpy(w + 20, &c->dev.scene_mag, 4); w[21] = c->dev.n_nodes; w[22] = c->boxes_tame ? 1u : 0u;
+        w[23] = c->dev.quad_base; w[24] = c->dev.quad_ok; w[25] = c->dev.qstack_depth; memcpy(w + 26, &c->dev.qvroot_b, 16);
         memcpy(out, w, bytes < sizeof w ? bytes : sizeof w);
         return 0;
     }

@@ -59,8 +59,10 @@ struct Lane {
     float limit;           // ordered walk: a box whose entry lies beyond this cannot change the result
     float delta;           // ordered walk: slack for a hit point lying just outside its triangle's box
     float dmax;            // ordered walk: delta * max |inv| -- how far (in ray parameter) growing a box by delta can move its faces
-    int sp;                // ordered walk: postponed children of this lane (the newest in `top`, the rest in LDS)
+    int sp;                // ordered walk: postponed children of this lane (the newest in `top`, the rest in LDS rows base .. sp - 2)
     uint32_t top;
+    int base;              // work sharing: rows below this one were handed to other lanes (0 otherwise)
+    int owner;             // work sharing: thread of the block whose shadow ray this lane walks a part of (its own id otherwise)
     int btri;              // closest triangle so far (leaf order), -1 = none
     f3 hit;
     float k1, k2, k3;      // kAB, kBC, kCA
@@ -278,6 +280,8 @@ MI_DEV f3 fold_levels(const float *lds, int depth, float rate)
 template <bool BATCH>
 MI_DEV void add_light(const FrameParams &P, const DevScene &S, Lane &L)
 {
+    // (L.lp may hold another lane's light by now: a lane whose shadow ray has ended walks parts of other lanes' shadow rays)
+    L.lp = cam_light<BATCH>(P, L.fid, L.li);
     f3 ptl = norm3(sub3(L.lp, L.hit));
     float intensity = dot3(L.pn, ptl);
     if (!(intensity < 0.f)) {
@@ -345,11 +349,17 @@ MI_DEV void rec_fetch(const DevScene &S, uint32_t link, Rec &r)
 
 // every walk starts at the root, whose record is a kernel argument
 // (ordered walk: at the virtual record above the root, both of whose boxes are the root's)
-template <bool ORDERED>
-MI_DEV void begin_walk(const DevScene &S, Lane &L, Rec &R, Rec &R2)
+template <bool ORDERED, bool QUAD = false>
+MI_DEV void begin_walk(const DevScene &S, Lane &L, Rec &R, Rec &R2, Rec &R3, Rec &R4)
 {
-    if (ORDERED) {
-        L.cur = MI_VROOT_LINK; L.sp = 0; L.top = MI_END_LINK;
+    if (QUAD) {
+        // the virtual quad record above the root: slot 0 = the root, the other slots empty
+        L.cur = MI_QROOT_LINK; L.sp = 0; L.base = 0; L.top = MI_END_LINK;
+        R.a = S.qvroot_a; R.b = S.qvroot_b;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f), e = make_float4(0.f, 0.f, __uint_as_float(MI_END_LINK), 0.f);
+        R2.a = z; R2.b = e; R3.a = z; R3.b = e; R4.a = z; R4.b = e;
+    } else if (ORDERED) {
+        L.cur = MI_VROOT_LINK; L.sp = 0; L.base = 0; L.top = MI_END_LINK;
         R.a = S.vroot_a; R.b = S.vroot_b; R2.a = S.vroot_a; R2.b = S.vroot_b;
     } else {
         L.cur = S.root_link;
@@ -419,6 +429,41 @@ MI_DEV bool tri_edge_test(Lane &L)
     return false;
 }
 
+// ---- four-wide walk: the rare exact decisions of a step (dev_scene.h; one lane's view) -----------------------------
+// need: bit i (0..3) = slot i is an inner slot whose filtered test is not sure (or the ray is not tame): RayIntersectsBox on
+// its own box; bit 4 / 5 = a leaf grandchild of the left / right side needs the verdict of its parent, whose box is the
+// union of the side's two slot boxes.  Returns the verdicts at the same bit positions.
+MI_DEV uint32_t quad_exact(const f3 o, const f3 d, uint32_t need, const Rec &R, const Rec &R2, const Rec &R3, const Rec &R4)
+{
+    uint32_t res = 0u;
+    while (need) {
+        const uint32_t b = (uint32_t)__builtin_ctz(need);
+        need &= need - 1u;
+        const bool right = b == 2u || b == 3u || b == 5u;
+        const float4 xa = right ? R3.a : R.a, xb = right ? R3.b : R.b, ya = right ? R4.a : R2.a, yb = right ? R4.b : R2.b;
+        const bool second = b == 1u || b == 3u, both = b >= 4u;
+        // own box of the side's first / second slot, or the union of the two (min of the mins, max of the maxes)
+        float4 lo = second ? make_float4(ya.x, ya.z, yb.x, 0.f) : make_float4(xa.x, xa.z, xb.x, 0.f);
+        float4 hi = second ? make_float4(ya.y, ya.w, yb.y, 0.f) : make_float4(xa.y, xa.w, xb.y, 0.f);
+        if (both) {
+            lo = make_float4(__builtin_fminf(xa.x, ya.x), __builtin_fminf(xa.z, ya.z), __builtin_fminf(xb.x, yb.x), 0.f);
+            hi = make_float4(__builtin_fmaxf(xa.y, ya.y), __builtin_fmaxf(xa.w, ya.w), __builtin_fmaxf(xb.y, yb.y), 0.f);
+        }
+        if (ray_box_exact(o, d, lo, hi)) res |= 1u << b;
+    }
+    return res;
+}
+
+// median of three (v_med3_u32)
+MI_DEV uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) { return max(min(a, b), min(max(a, b), c)); }
+
+// select one of four words by a two-bit index
+MI_DEV uint32_t pick4(uint32_t i, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    const uint32_t x = (i & 1u) ? b : a, y = (i & 1u) ? d : c;
+    return (i & 2u) ? y : x;
+}
+
 } // namespace
 
 // WAVES = wavefronts per SIMD the register allocation aims at: 2 for the latency of a single 1080p frame (deferred edge
@@ -429,7 +474,9 @@ MI_DEV bool tri_edge_test(Lane &L)
 // EXT = the build that also knows the reference's two compile-time extras (Raytracer.cc:70-80): refractions -- every
 // hit spawns a second, unculled child ray, so the chain of depth levels becomes a binary tree walked depth first with
 // the waiting refracted rays parked in LDS -- and ray-cast ambient occlusion (AMBIENT_SAMPLES shadow-type rays per hit).
-template <bool STATS, bool EXACT_BOX, bool ORDERED, int WAVES, bool BATCH, bool EXT = false>
+// QUAD = the four-wide walk (dev_scene.h): a step tests the four slots of a 128-byte quad record -- the node's leaf children
+// and its inner children's children -- enters the nearest, postpones the others: 0.56 of the binary walk's inner steps.
+template <bool STATS, bool EXACT_BOX, bool ORDERED, int WAVES, bool BATCH, bool EXT = false, bool QUAD = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 k_raytrace(const DevScene S, const FrameParams P)
 {
@@ -439,13 +486,22 @@ k_raytrace(const DevScene S, const FrameParams P)
     __shared__ float lds_refr[EXT ? MI_MAX_DEPTH * 7 * 256 : 1];
     // LDS (ordered walk only, sized at launch): per-lane stack of postponed children, one row per level
     extern __shared__ uint32_t lds_stack[];
+    // Work sharing inside a wave (production builds): a shadow ray's verdict is an OR over the triangles its walk reaches, so any
+    // part of that walk can be done by any lane.  Lanes without a ray of their own take the oldest postponed subtree of a lane
+    // that still walks a shadow ray; a blocker found by anyone is reported in the owner's word of an LDS row.  Two more rows
+    // behind the stack's: the verdict words, and a per-wave table (rank among the givers -> lane).
+    constexpr bool STEAL = ORDERED && !STATS && !EXT && !QUAD;
+    const bool steal_on = STEAL && P.steal_min > 0;
+    uint32_t *const sflag = lds_stack + (QUAD ? S.qstack_depth : S.stack_depth) * 256u;
+    uint32_t *const stab = sflag + 256u + (threadIdx.x & ~63u);
     Lane L;
     bool alive = false;         // lane owns a pixel
     bool want_pixel = true;     // lane needs a (new) pixel
     bool exhausted = false;     // dispenser ran dry (wave-uniform)
     Rec R;                      // record of the node this lane visits next
     Rec R2;                     // ordered walk: second half of a wide record (the right child's box)
-    R.a = R.b = R2.a = R2.b = make_float4(0.f, 0.f, 0.f, 0.f);
+    Rec R3, R4;                 // four-wide walk: R, R2, R3, R4 = the four slots of a quad record
+    R.a = R.b = R2.a = R2.b = R3.a = R3.b = R4.a = R4.b = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t pool_next = 0, pool_end = 0;   // wave-local pixel pool (wave-uniform): local indices of share pool_share
     uint32_t pool_share = 0;
     uint32_t share = blockIdx.x % MI_DISPENSERS;   // the share this wave draws from (consecutive blocks sit on different XCDs)
@@ -455,11 +511,11 @@ k_raytrace(const DevScene S, const FrameParams P)
     L.shadow_hit = false; L.li = 0; L.cr = L.cg = L.cb = 0.f; L.k1 = L.k2 = L.k3 = 0.f;
     L.o = L.d = L.hit = L.pn = L.refl = L.lp = L.inv = L.ph = mk3(0.f, 0.f, 0.f);
     L.tame = false; L.pend = false; L.pj = -1;
-    L.limit = 0.f; L.delta = 0.f; L.dmax = 0.f; L.sp = 0; L.top = MI_END_LINK;
+    L.limit = 0.f; L.delta = 0.f; L.dmax = 0.f; L.sp = 0; L.top = MI_END_LINK; L.base = 0; L.owner = (int)threadIdx.x;
     L.pe1 = L.pe2 = L.pe3 = make_float4(0.f, 0.f, 0.f, 0.f);
     L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; L.ao_draw = 0u; L.ao_total = L.ao_max = L.ao_cos = 0.f;
 
-    unsigned n_normal = 0, n_shadow = 0;
+    unsigned n_normal = 0, n_shadow = 0, n_steal = 0;
     unsigned n_pops = 0, n_ihits = 0, n_tris = 0, n_plane = 0, n_shaded = 0;
     // phase profile (STATS builds only; wave-uniform): cycles and lane occupancy per phase
     unsigned long long pc_refill = 0, pc_trans = 0, pc_a = 0, pc_b = 0, pc_total = 0, pc_wait = 0;
@@ -548,7 +604,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                                     L.samples_left = P.aa ? 3 : 0;
                                     primary_ray<BATCH>(P, S, L, L.samples_left);
                                     if constexpr (EXT) { L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; }
-                                    begin_walk<ORDERED>(S, L, R, R2);
+                                    begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
                                     n_normal++;
                                     alive = true;
                                     want_pixel = false;
@@ -564,13 +620,16 @@ k_raytrace(const DevScene S, const FrameParams P)
         // a lane's ray is complete when its walk has ended and no candidate is left to judge
         const bool ray_done = alive && L.cur == MI_END_LINK && !L.pend;
         const unsigned long long mX = __ballot(ray_done);
-        const unsigned long long mT = __ballot(alive && !ray_done);
+        // (lanes still walking: their own ray, or -- work sharing -- a part of another lane's)
+        const unsigned long long mT = __ballot((alive && !ray_done) || L.cur != MI_END_LINK);
         if (!mX && !mT) {
             if (!__ballot(want_pixel)) break;
             continue;
         }
         const bool drain = exhausted && pool_next == pool_end;
-        const int xmin_now = drain ? 1 : P.xmin;          // nothing left to batch with once the dispenser is dry
+        // nothing left to batch with once the dispenser is dry (with work sharing the wave stays in lockstep: a lane whose
+        // shadow ray is helped by others must not look at the verdict before they are done)
+        const int xmin_now = (drain && !steal_on) ? 1 : P.xmin;
 
         if (mX && (__popcll(mX) >= xmin_now || !mT)) {
             // ---------------- transitions ------------------------------------------------
@@ -617,7 +676,9 @@ k_raytrace(const DevScene S, const FrameParams P)
                     L.ao_i++;
                     ao_next = true;
                 } else {
-                    if (!L.shadow_hit) add_light<BATCH>(P, S, L);   // Raytracer.cc:458-466
+                    bool blocked = L.shadow_hit;
+                    if constexpr (STEAL) blocked = sflag[threadIdx.x] != 0u;
+                    if (!blocked) add_light<BATCH>(P, S, L);        // Raytracer.cc:458-466
                     L.li++;
                     lights = true;
                 }
@@ -650,7 +711,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         L.mode = MODE_SHADOW;
                         L.shadow_hit = false;
                         L.nocull = 0u;                              // BVH_IntersectTriangles<true,true>
-                        begin_walk<ORDERED>(S, L, R, R2);
+                        begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
                         L.avoid = L.btri;
                         n_shadow++;
                     } else {
@@ -681,7 +742,8 @@ k_raytrace(const DevScene S, const FrameParams P)
                         L.limit = 2.f * __builtin_sqrtf(L.best) * 1.001f + L.delta;
                         L.mode = MODE_SHADOW;
                         L.shadow_hit = false;
-                        begin_walk<ORDERED>(S, L, R, R2);
+                        if constexpr (STEAL) { sflag[threadIdx.x] = 0u; L.owner = (int)threadIdx.x; }
+                        begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
                         L.avoid = L.btri;                       // avoidSelf = the triangle just hit (Raytracer.cc:335)
                         n_shadow++;
                         launched = true;
@@ -700,7 +762,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                             L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
                             L.nocull = 0u;                          // Raytrace<true>
                             L.path = 2u * L.path; L.depth++;
-                            begin_walk<ORDERED>(S, L, R, R2);
+                            begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
                             n_normal++;
                         } else { up = true; up_d = L.depth; up_which = 0u; }     // "the reflected ray returned black"
                     } else {
@@ -709,7 +771,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         L.o = L.hit; L.d = L.refl; L.avoid = L.btri;
                         set_ray_aux(L, S.scene_mag);
                         L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
-                        begin_walk<ORDERED>(S, L, R, R2);
+                        begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
                         n_normal++;
                     } else finish = true;
                     }
@@ -732,7 +794,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                             L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
                             L.nocull = (uint32_t)MI_TWOSIDED_BIT;   // Raytrace<false>
                             L.path = 2u * L.path + 1u; L.depth = up_d + 1;
-                            begin_walk<ORDERED>(S, L, R, R2);
+                            begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
                             n_normal++;
                             complete = false; up = false;
                         } else if (P.use_refr) { a[0] = addclamp(a[0], 0.f); a[256] = addclamp(a[256], 0.f); a[512] = addclamp(a[512], 0.f); }   // too deep: black * rate
@@ -755,7 +817,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     L.samples_left--;
                     primary_ray<BATCH>(P, S, L, L.samples_left);
                     if constexpr (EXT) { L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; }
-                    begin_walk<ORDERED>(S, L, R, R2);
+                    begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
                     n_normal++;
                 } else {
                     float r = L.fr, g = L.fg, b = L.fb;
@@ -791,6 +853,50 @@ k_raytrace(const DevScene S, const FrameParams P)
         uint32_t *const stk = lds_stack + threadIdx.x;
         for (;;) {
             if (STATS) it_loops++;
+            if constexpr (STEAL) {
+            if (steal_on) {
+                // takers: lanes with nothing to walk whose ray registers are dead (no pixel, or a shadow ray that has ended: a
+                // closest-hit ray's direction is still needed for shading); givers: lanes on a shadow ray with a postponed node
+                const bool taker = L.cur == MI_END_LINK && !L.pend && (!alive || L.mode == MODE_SHADOW);
+                const bool giver = L.cur != MI_END_LINK && L.mode == MODE_SHADOW && L.sp > L.base;
+                const unsigned long long mTk = __ballot(taker), mGv = __ballot(giver);
+                if (mGv && __popcll(mTk) >= P.steal_min) {
+                    const int lane = (int)(threadIdx.x & 63u);
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    const int gr = __popcll(mGv & below), tr = __popcll(mTk & below);
+                    const int nG = __popcll(mGv), nT = __popcll(mTk);
+                    if (giver) stab[gr] = (uint32_t)lane;
+                    // a giver hands over the OLDEST node it has postponed (the bottom of its stack): the largest subtree it owes
+                    const bool deep = L.sp - L.base >= 2;
+                    uint32_t give = L.top;
+                    if (giver && deep) give = stk[L.base * 256];
+                    const bool takes = taker && tr < nG, robbed = giver && gr < nT;
+                    const int v = takes ? (int)stab[tr] : lane;
+                    const float ox = __shfl(L.o.x, v), oy = __shfl(L.o.y, v), oz = __shfl(L.o.z, v);
+                    const float dx = __shfl(L.d.x, v), dy = __shfl(L.d.y, v), dz = __shfl(L.d.z, v);
+                    const float ix = __shfl(L.inv.x, v), iy = __shfl(L.inv.y, v), iz = __shfl(L.inv.z, v);
+                    const float lx = __shfl(L.lp.x, v), ly = __shfl(L.lp.y, v), lz = __shfl(L.lp.z, v);
+                    const float vdmax = __shfl(L.dmax, v), vlimit = __shfl(L.limit, v), vbest = __shfl(L.best, v);
+                    const int vavoid = __shfl(L.avoid, v), vowner = __shfl(L.owner, v), vtame = __shfl(L.tame ? 1 : 0, v);
+                    const uint32_t vgive = (uint32_t)__shfl((int)give, v);
+                    if (takes) {
+                        L.o = mk3(ox, oy, oz); L.d = mk3(dx, dy, dz); L.inv = mk3(ix, iy, iz); L.lp = mk3(lx, ly, lz);
+                        L.dmax = vdmax; L.limit = vlimit; L.best = vbest; L.avoid = vavoid; L.owner = vowner; L.tame = vtame != 0;
+                        L.mode = MODE_SHADOW; L.sp = 0; L.base = 0; L.top = MI_END_LINK;
+                        L.cur = vgive;
+                        const float4 *p = S.walk + (size_t)(vgive & MI_INDEX_MASK);
+                        R.a = p[0]; R.b = p[1];
+                        if ((vgive & MI_LEAF_BIT) == 0) { R2.a = p[2]; R2.b = p[3]; }
+                        n_steal++;
+                    }
+                    if (robbed) {
+                        if (deep) L.base++;
+                        else { L.sp = L.base; L.top = MI_END_LINK; }
+                    }
+                }
+            }
+            }
+            const int sbase = STEAL ? L.base : 0;
             // (a lane without a ray has L.cur == END and no pending candidate, so `alive` need not be looked at here)
             const bool walking = L.cur != MI_END_LINK;
             const bool inner = walking && (L.cur & MI_LEAF_BIT) == 0;
@@ -802,6 +908,86 @@ k_raytrace(const DevScene S, const FrameParams P)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 MI_PHASE(pc_wait);
             }
+            // 1q. quad records: the four slots' box tests, the nearest entered slot next, the others postponed
+            if constexpr (QUAD) {
+            if (mI) {
+                if (STATS) { it_a++; ln_a += __popcll(mI); }
+                if (inner) {
+                    const uint32_t l0 = __float_as_uint(R.b.z), l1 = __float_as_uint(R2.b.z), l2 = __float_as_uint(R3.b.z), l3 = __float_as_uint(R4.b.z);
+                    // (MI_END_LINK has no leaf bit: an empty slot is neither a leaf nor, below, an inner slot)
+                    const bool e0 = l0 == MI_END_LINK, e1 = l1 == MI_END_LINK, e2 = l2 == MI_END_LINK, e3 = l3 == MI_END_LINK;
+                    const bool f0 = (l0 & MI_LEAF_BIT) != 0u, f1 = (l1 & MI_LEAF_BIT) != 0u, f2 = (l2 & MI_LEAF_BIT) != 0u, f3_ = (l3 & MI_LEAF_BIT) != 0u;
+                    // a leaf slot whose side has a second slot is a GRANDCHILD: entered iff its parent's box passes
+                    const bool g0 = f0 && !e1, g1 = f1, g2 = f2 && !e3, g3 = f3_;
+                    bool h0, h1, h2, h3;
+                    float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f;
+                    if (EXACT_BOX) {
+                        uint32_t need = (!f0 && !e0 ? 1u : 0u) | (!f1 && !e1 ? 2u : 0u) | (!f2 && !e2 ? 4u : 0u) | (!f3_ && !e3 ? 8u : 0u) |
+                                        ((g0 || g1) ? 16u : 0u) | ((g2 || g3) ? 32u : 0u);
+                        const uint32_t r = quad_exact(L.o, L.d, need, R, R2, R3, R4);
+                        h0 = f0 ? (!g0 || (r & 16u)) : (r & 1u) != 0u; h1 = f1 ? (r & 16u) != 0u : (r & 2u) != 0u;
+                        h2 = f2 ? (!g2 || (r & 32u)) : (r & 4u) != 0u; h3 = f3_ ? (r & 32u) != 0u : (r & 8u) != 0u;
+                    } else {
+                        bool s0, s1, s2, s3;
+                        float n0, n1, n2, n3, t0, t1, t2, t3;
+                        const bool p0 = ray_box_fast_ordered(L.o, L.inv, L.dmax, R.a, R.b, s0, k0, n0, t0);
+                        const bool p1 = ray_box_fast_ordered(L.o, L.inv, L.dmax, R2.a, R2.b, s1, k1, n1, t1);
+                        const bool p2 = ray_box_fast_ordered(L.o, L.inv, L.dmax, R3.a, R3.b, s2, k2, n2, t2);
+                        const bool p3 = ray_box_fast_ordered(L.o, L.inv, L.dmax, R4.a, R4.b, s3, k3, n3, t3);
+                        // the ray may reach something in the slot: it does not surely miss the grown box, and enters it before
+                        // the best hit so far (every slot); a leaf needs no more than that of its own box
+                        const bool tame = L.tame;
+                        const bool m0 = !tame || (!(n0 > t0) && !(t0 < 0.f) && !(n0 > L.limit)), m1 = !tame || (!(n1 > t1) && !(t1 < 0.f) && !(n1 > L.limit));
+                        const bool m2 = !tame || (!(n2 > t2) && !(t2 < 0.f) && !(n2 > L.limit)), m3 = !tame || (!(n3 > t3) && !(t3 < 0.f) && !(n3 > L.limit));
+                        // a side's parent box surely passes when one of its slot boxes does (the predicate is monotone in the box)
+                        const bool kl = tame && ((p0 && s0) || (p1 && s1)), kr = tame && ((p2 && s2) || (p3 && s3));
+                        uint32_t need = 0u;
+                        if (!f0 && !e0 && m0 && !(tame && s0)) need |= 1u;
+                        if (!f1 && !e1 && m1 && !(tame && s1)) need |= 2u;
+                        if (!f2 && !e2 && m2 && !(tame && s2)) need |= 4u;
+                        if (!f3_ && !e3 && m3 && !(tame && s3)) need |= 8u;
+                        if (((g0 && m0) || (g1 && m1)) && !kl) need |= 16u;
+                        if (((g2 && m2) || (g3 && m3)) && !kr) need |= 32u;
+                        uint32_t r = 0u;
+                        if (__builtin_expect(need != 0u, 0)) {
+                            if (STATS) n_slow++;
+                            r = quad_exact(L.o, L.d, need, R, R2, R3, R4);
+                        }
+                        const bool cl = kl || (r & 16u) != 0u, cr = kr || (r & 32u) != 0u;
+                        h0 = m0 && (f0 ? (!g0 || cl) : ((need & 1u) ? (r & 1u) != 0u : p0));
+                        h1 = m1 && (f1 ? cl : ((need & 2u) ? (r & 2u) != 0u : p1));
+                        h2 = m2 && (f2 ? (!g2 || cr) : ((need & 4u) ? (r & 4u) != 0u : p2));
+                        h3 = m3 && (f3_ ? cr : ((need & 8u) ? (r & 8u) != 0u : p3));
+                    }
+                    h0 = h0 && !e0; h1 = h1 && !e1; h2 = h2 && !e2; h3 = h3 && !e3;
+                    if (STATS) { n_pops += (e0 ? 0u : 1u) + (e1 ? 0u : 1u) + (e2 ? 0u : 1u) + (e3 ? 0u : 1u); n_ihits += (h0 ? 1u : 0u) + (h1 ? 1u : 0u) + (h2 ? 1u : 0u) + (h3 ? 1u : 0u); }
+                    // order: entry bounds clamped at 0 order like their bits; the slot number rides in the two lowest bits, so
+                    // the four keys are distinct and ANY bit patterns sort to a permutation (the order is advisory, the set is not)
+                    const uint32_t q0 = h0 ? ((__float_as_uint(__builtin_fmaxf(k0, 0.f)) & ~3u) | 0u) : 0xfffffffcu;
+                    const uint32_t q1 = h1 ? ((__float_as_uint(__builtin_fmaxf(k1, 0.f)) & ~3u) | 1u) : 0xfffffffdu;
+                    const uint32_t q2 = h2 ? ((__float_as_uint(__builtin_fmaxf(k2, 0.f)) & ~3u) | 2u) : 0xfffffffeu;
+                    const uint32_t q3 = h3 ? ((__float_as_uint(__builtin_fmaxf(k3, 0.f)) & ~3u) | 3u) : 0xffffffffu;
+                    const uint32_t lo3 = min(min(q0, q1), q2), hi3 = max(max(q0, q1), q2), mid3 = umed3(q0, q1, q2);
+                    const uint32_t s_0 = min(lo3, q3), s_1 = umed3(lo3, mid3, q3), s_2 = umed3(mid3, hi3, q3), s_3 = max(hi3, q3);
+                    const uint32_t NONE = 0xfffffffcu;
+                    if (s_0 < NONE) next = pick4(s_0, l0, l1, l2, l3);
+                    if (s_1 < NONE) {
+                        // postpone the others, the farthest first: entry #(sp-1) leaves the register for its row, then #sp .., the
+                        // second nearest stays in the register
+                        if (L.sp > 0) stk[(L.sp - 1) * 256] = L.top;
+                        L.top = pick4(s_1, l0, l1, l2, l3);
+                        if (s_2 < NONE) {
+                            const bool four = s_3 < NONE;
+                            stk[(L.sp + (four ? 1 : 0)) * 256] = pick4(s_2, l0, l1, l2, l3);
+                            if (four) { stk[L.sp * 256] = pick4(s_3, l0, l1, l2, l3); L.sp++; }
+                            L.sp++;
+                        }
+                        L.sp++;
+                    }
+                }
+                MI_PHASE(pc_a);
+            }
+            } else {
             // 1. wide nodes: both children's box tests (Raytracer.cc:222-230 for each)
             if (mI) {
                 if (STATS) { it_a++; ln_a += __popcll(mI); }
@@ -842,13 +1028,14 @@ k_raytrace(const DevScene S, const FrameParams P)
                     if (hL && hR) {
                         const bool left_first = kL <= kR;
                         next = left_first ? linkL : linkR;
-                        if (L.sp > 0) stk[(L.sp - 1) * 256] = L.top;
+                        if (L.sp > sbase) stk[(L.sp - 1) * 256] = L.top;
                         L.top = left_first ? linkR : linkL;
                         L.sp++;
                     } else if (hL) next = linkL;
                     else if (hR) next = linkR;
                 }
                 MI_PHASE(pc_a);
+            }
             }
             // 2. triangle blocks: the chain continues while the next link stays inside the leaf; keep the block
             //    for the plane test below (R is about to be overwritten)
@@ -866,17 +1053,20 @@ k_raytrace(const DevScene S, const FrameParams P)
             }
             // 3. nothing to enter: resume at the most recently postponed child (the one below it comes up from
             //    LDS; it is not needed before this lane's next push or pop); then request the next record
-            if (walking && next == MI_END_LINK && L.sp > 0) {
+            if (walking && next == MI_END_LINK && L.sp > sbase) {
                 next = L.top;
                 L.sp--;
-                if (L.sp > 0) L.top = stk[(L.sp - 1) * 256];
+                if (L.sp > sbase) L.top = stk[(L.sp - 1) * 256];
             }
             if (walking) {
                 L.cur = next;
                 if (next != MI_END_LINK) {
                     const float4 *p = S.walk + (size_t)(next & MI_INDEX_MASK);
                     R.a = p[0]; R.b = p[1];
-                    if ((next & MI_LEAF_BIT) == 0) { R2.a = p[2]; R2.b = p[3]; }
+                    if ((next & MI_LEAF_BIT) == 0) {
+                        R2.a = p[2]; R2.b = p[3];
+                        if constexpr (QUAD) { R3.a = p[4]; R3.b = p[5]; R4.a = p[6]; R4.b = p[7]; }
+                    }
                 }
             }
             if constexpr (WAVES >= 3) {
@@ -911,7 +1101,8 @@ k_raytrace(const DevScene S, const FrameParams P)
                     const float dz = distsq3(from, hit);
                     const bool nearer = dz < L.best;
                     if (inside && shadow && nearer) {                // a blocked shadow ray stops (Raytracer.cc:284)
-                        L.shadow_hit = true; L.cur = MI_END_LINK; L.sp = 0;
+                        if constexpr (STEAL) { sflag[L.owner] = 1u; L.sp = L.base; } else { L.shadow_hit = true; L.sp = 0; }
+                        L.cur = MI_END_LINK;
                     }
                     // candidates arrive in any order: lowest list position wins among equal distances
                     if (inside && !shadow && (nearer || (dz == L.best && j < L.btri))) {
@@ -938,7 +1129,8 @@ k_raytrace(const DevScene S, const FrameParams P)
                     const float dz = distsq3(from, hit);
                     const bool nearer = dz < L.best;
                     if (inside && shadow && nearer) {                // a blocked shadow ray stops (Raytracer.cc:284)
-                        L.shadow_hit = true; L.cur = MI_END_LINK; L.sp = 0;
+                        if constexpr (STEAL) { sflag[L.owner] = 1u; L.sp = L.base; } else { L.shadow_hit = true; L.sp = 0; }
+                        L.cur = MI_END_LINK;
                     }
                     // candidates arrive in any order: lowest list position wins among equal distances
                     if (inside && !shadow && (nearer || (dz == L.best && L.pj < L.btri))) {
@@ -1057,6 +1249,10 @@ k_raytrace(const DevScene S, const FrameParams P)
         const unsigned long long a = wsum(n_normal), b = wsum(n_shadow);
         const bool lead = (threadIdx.x & 63u) == 0;
         if (lead) { atomicAdd(&P.counters[CS_NORMAL_RAYS], a); atomicAdd(&P.counters[CS_SHADOW_RAYS], b); }
+        if constexpr (STEAL) {      // (debug: subtrees handed from lane to lane, in a word the counting builds use for their profile)
+            const unsigned long long ns = wsum(n_steal);
+            if (lead && ns) atomicAdd(&P.counters[CS_PROF0 + 12], ns);
+        }
         if (STATS) {
             const unsigned long long c = wsum(n_pops), d = wsum(n_ihits), e = wsum(n_tris), f = wsum(n_plane),
                                      g = wsum(n_shaded), sl = wsum(n_slow);
@@ -1259,51 +1455,56 @@ extern "C" hipError_t mi355i_launch_cull_probe(const float *rays6, const uint32_
 namespace {
 typedef void (*rt_kernel)(const DevScene, const FrameParams);
 // waves = wavefronts per SIMD the build is allocated for (2, 3 or 4; counting and reference-order builds: 2)
-template <bool EXACT, bool BATCH> rt_kernel ordered_kernel(int waves)
+template <bool EXACT, bool BATCH, bool QUAD> rt_kernel ordered_kernel(int waves)
 {
-    if (waves >= 4) return k_raytrace<false, EXACT, true, 4, BATCH>;
-    if (waves == 3) return k_raytrace<false, EXACT, true, 3, BATCH>;
-    return k_raytrace<false, EXACT, true, 2, BATCH>;
+    if (waves >= 4) return k_raytrace<false, EXACT, true, 4, BATCH, false, QUAD>;
+    if (waves == 3) return k_raytrace<false, EXACT, true, 3, BATCH, false, QUAD>;
+    return k_raytrace<false, EXACT, true, 2, BATCH, false, QUAD>;
 }
-rt_kernel pick_kernel(int stats, int exact, int ordered, int waves, int batch, int ext)
+template <bool QUAD> rt_kernel ordered_kernel_q(int exact, int waves, int batch)
+{
+    if (batch) return exact ? ordered_kernel<true, true, QUAD>(waves) : ordered_kernel<false, true, QUAD>(waves);
+    return exact ? ordered_kernel<true, false, QUAD>(waves) : ordered_kernel<false, false, QUAD>(waves);
+}
+rt_kernel pick_kernel(int stats, int exact, int ordered, int waves, int batch, int ext, int quad)
 {
     if (ext) {      // refractions / ray-cast ambient occlusion: single frames, no counters, two waves per SIMD
         if (ordered) return exact ? k_raytrace<false, true, true, 2, false, true> : k_raytrace<false, false, true, 2, false, true>;
         return exact ? k_raytrace<false, true, false, 2, false, true> : k_raytrace<false, false, false, 2, false, true>;
     }
-    if (ordered && !stats) {
-        if (batch) return exact ? ordered_kernel<true, true>(waves) : ordered_kernel<false, true>(waves);
-        return exact ? ordered_kernel<true, false>(waves) : ordered_kernel<false, false>(waves);
-    }
+    if (ordered && !stats) return quad ? ordered_kernel_q<true>(exact, waves, batch) : ordered_kernel_q<false>(exact, waves, batch);
+    if (ordered && quad) return exact ? k_raytrace<true, true, true, 2, false, false, true> : k_raytrace<true, false, true, 2, false, false, true>;
     if (ordered) return exact ? k_raytrace<true, true, true, 2, false> : k_raytrace<true, false, true, 2, false>;
     if (stats) return exact ? k_raytrace<true, true, false, 2, false> : k_raytrace<true, false, false, 2, false>;
     return exact ? k_raytrace<false, true, false, 2, false> : k_raytrace<false, false, false, 2, false>;
 }
-size_t stack_bytes(int ordered, int stack_depth) { return ordered ? (size_t)stack_depth * 256u * sizeof(uint32_t) : 0u; }
+// (two rows behind the stack's: the shadow verdict words and the givers' table of the work sharing)
+size_t stack_bytes(int ordered, int stack_depth) { return ordered ? (size_t)(stack_depth + 2) * 256u * sizeof(uint32_t) : 0u; }
 } // namespace
 
 // can this build render several frames per launch?  (the ordered, non-counting kernels only)
 extern "C" int mi355i_raytrace_can_batch(int stats, int ordered) { return ordered && !stats; }
 
-// blocks per CU the (stats, exact, ordered, waves, batch) variant can hold
-extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext)
+// blocks per CU the (stats, exact, ordered, waves, batch, quad) variant can hold with `stack_depth` rows of LDS stack
+extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext, int quad)
 {
-    static int cache[2][2][2][2][3][2][MI_MAX_STACK + 1];        // 0 = not asked yet
-    if (stack_depth < 0 || stack_depth > MI_MAX_STACK) stack_depth = MI_MAX_STACK;
+    static int cache[2][2][2][2][2][3][2][MI_MAX_QSTACK + 1];        // 0 = not asked yet
+    if (stack_depth < 0 || stack_depth > MI_MAX_QSTACK) stack_depth = MI_MAX_QSTACK;
     const int w = waves >= 4 ? 2 : (waves == 3 ? 1 : 0);
-    int &slot = cache[ext ? 1 : 0][stats ? 1 : 0][exact ? 1 : 0][ordered ? 1 : 0][w][batch ? 1 : 0][ordered ? stack_depth : 0];
+    int &slot = cache[quad ? 1 : 0][ext ? 1 : 0][stats ? 1 : 0][exact ? 1 : 0][ordered ? 1 : 0][w][batch ? 1 : 0][ordered ? stack_depth : 0];
     if (!slot) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_kernel(stats, exact, ordered, waves, batch, ext), 256, stack_bytes(ordered, stack_depth)) != hipSuccess || nb < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_kernel(stats, exact, ordered, waves, batch, ext, quad), 256, stack_bytes(ordered, stack_depth)) != hipSuccess || nb < 1)
             nb = 2;
         slot = nb > 8 ? 8 : nb;
     }
     return slot;
 }
 
+// stack_depth = rows of the per-lane LDS stack (DevScene::stack_depth, or qstack_depth for the four-wide walk)
 extern "C" hipError_t mi355i_launch_raytrace(const DevScene *S, const FrameParams *P, int stats, int exact, int ordered, int waves,
-                                             int batch, int ext, int n_blocks, hipStream_t st)
+                                             int batch, int ext, int quad, int stack_depth, int n_blocks, hipStream_t st)
 {
-    hipLaunchKernelGGL(pick_kernel(stats, exact, ordered, waves, batch, ext), dim3(n_blocks), dim3(256), stack_bytes(ordered, (int)S->stack_depth), st, *S, *P);
+    hipLaunchKernelGGL(pick_kernel(stats, exact, ordered, waves, batch, ext, quad), dim3(n_blocks), dim3(256), stack_bytes(ordered, stack_depth), st, *S, *P);
     return hipGetLastError();
 }
