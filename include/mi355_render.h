@@ -258,6 +258,16 @@ int mi355_mgpu_shadowmap_render(mi355_mgpu *, int slot, const mi355_light *light
 /* out_xrgb (host) or d_out (device 0) receives the assembled frame; synchronous.  stats: ray counts summed over the devices. */
 int mi355_mgpu_render(mi355_mgpu *, int mode, const mi355_camera *, const mi355_light *lights, int n_lights, const mi355_opts *,
                       uint32_t *out_xrgb, int pitch_bytes, void *d_out, mi355_stats *stats);
+/* A STEP of n_frames frames (1 .. MI355_MAX_BATCH; `lights` holds n_lights per frame, frame-major): every device renders its
+ * bands of all of them with one batched launch, ONE grouped exchange carries them to device 0, which assembles frame f into
+ * d_out[f] (device 0 memory, rows pitch_bytes apart).  Asynchronous -- the call returns once the work is enqueued, nothing is
+ * synchronised and no counter is fetched; two steps are in flight: a device renders step k + 1 while its bands of step k
+ * travel and are assembled (render and transfer streams of their own, buffers alternate).  -45: two steps already in flight. */
+int mi355_mgpu_render_batch(mi355_mgpu *, int mode, int n_frames, const mi355_camera *cams, const mi355_light *lights, int n_lights,
+                            const mi355_opts *, void *const *d_out, int pitch_bytes, int *ticket);
+/* The frames of that step are complete when this returns.  stats (optional): ray counts summed over devices and frames.
+ * Raster modes: -44 if a device's bin / band buffers were too small for a frame of the step (they have grown: draw it again). */
+int mi355_mgpu_wait(mi355_mgpu *, int ticket, mi355_stats *stats);
 
 #ifdef __cplusplus
 }

@@ -195,7 +195,7 @@ struct mi355_ctx {
         DevBuf ctrl, fb, mlaa, sel;
         PinBuf pin;
         RasterScratch *rs = nullptr;
-        bool busy = false;
+        bool busy = false, ready = false;   // ready: stream, events, control block and scratch all exist
         int ticket = 0, mode = 0, n_lights = 0, pitch_bytes = 0;
         uint32_t *user = nullptr;
         bool staged = false;          // the frame lands in `pin` and is copied to `user` by mi355_render_wait
@@ -1619,24 +1619,29 @@ int mi355_render_async(mi355_ctx *c, int mode, const mi355_camera *cam, const mi
     if (int r = validate_opts(*o, mode)) return r;
     if (n_lights < 0 || n_lights > MI355_MAX_LIGHTS) return fail(-21, "n_lights %d outside 0..%d", n_lights, MI355_MAX_LIGHTS);
     if (o->collect_stats) return fail(-21, "pipelined frames cannot collect the counters");
+    // (the staged path copies row by row with the caller's pitch: checked here, fill_params below only sees the internal one)
+    if (pitch_bytes < o->width * 4 || (pitch_bytes & 3)) return fail(-21, "bad pitch %d for width %d", pitch_bytes, o->width);
     if (int r = select_device(c)) return r;
     mi355_ctx::AsyncSlot *a = nullptr;
     for (auto &s : c->slot) if (!s.busy) { a = &s; break; }
     if (!a) return fail(-45, "%d frames are in flight: call mi355_render_wait first", MI355_MAX_IN_FLIGHT);
     const int W = o->width;
     const int rows = (o->band_count > 1 && o->compact_rows) ? count_rows(*o) : o->height;
-    if (!a->st) {
+    if (!a->ready) {
         // (slot i on a candidate stream of queue class i: frames in flight then never queue up behind one another)
+        // Every piece is created if it is missing and the slot counts as usable only once all of them exist: a call that fails
+        // half way leaves a slot the next call completes instead of one that looks initialised.
         const int si = (int)(a - c->slot);
-        if (probe_classes(c) && c->n_class >= 2)
+        if (!a->st && probe_classes(c) && c->n_class >= 2)
             for (int i = 0; i < (int)mi355_ctx::PIPE_CANDS && !a->st; i++) if (c->cand_class[i] == si % c->n_class) a->st = c->cand_st[i];
         if (!a->st) { HIP_TRY(hipStreamCreateWithFlags(&a->st, hipStreamNonBlocking), -11); a->st_owned = true; }
-        HIP_TRY(hipEventCreate(&a->ev0), -11);
-        HIP_TRY(hipEventCreate(&a->ev1), -11);
+        if (!a->ev0) HIP_TRY(hipEventCreate(&a->ev0), -11);
+        if (!a->ev1) HIP_TRY(hipEventCreate(&a->ev1), -11);
         HIP_TRY(a->ctrl.ensure(MI_CTRL_BYTES), -31);
         HIP_TRY(hipMemsetAsync(a->ctrl.p, 0, MI_CTRL_BYTES, a->st), -40);
-        a->rs = mi355i_raster_scratch_create();
+        if (!a->rs) a->rs = mi355i_raster_scratch_create();
         if (!a->rs) return fail(-11, "out of memory");
+        a->ready = true;
     }
     HIP_TRY(a->fb.ensure((size_t)W * o->height * 4), -31);
     if (o->band_count > 1) HIP_TRY(hipMemsetAsync(a->fb.p, 0, (size_t)W * o->height * 4, a->st), -40);

@@ -515,7 +515,7 @@ k_raytrace(const DevScene S, const FrameParams P)
     L.pe1 = L.pe2 = L.pe3 = make_float4(0.f, 0.f, 0.f, 0.f);
     L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; L.ao_draw = 0u; L.ao_total = L.ao_max = L.ao_cos = 0.f;
 
-    unsigned n_normal = 0, n_shadow = 0, n_steal = 0;
+    unsigned n_normal = 0, n_shadow = 0, n_steal = 0, n_event = 0;
     unsigned n_pops = 0, n_ihits = 0, n_tris = 0, n_plane = 0, n_shaded = 0;
     // phase profile (STATS builds only; wave-uniform): cycles and lane occupancy per phase
     unsigned long long pc_refill = 0, pc_trans = 0, pc_a = 0, pc_b = 0, pc_total = 0, pc_wait = 0;
@@ -851,10 +851,17 @@ k_raytrace(const DevScene S, const FrameParams P)
         // A step decides where to go next and requests that record at once; the candidate of the previous step
         // is judged and this step's triangle is plane-tested while the request is in flight.
         uint32_t *const stk = lds_stack + threadIdx.x;
+        // (work sharing: only while some lane of the wave walks a shadow ray -- a burst of camera or reflected rays pays nothing;
+        //  `lent` = a subtree has changed lanes in this burst: only then can somebody else end a lane's ray)
+        const bool share_now = STEAL && steal_on && __ballot(L.cur != MI_END_LINK && L.mode == MODE_SHADOW) != 0ull;
+        bool lent = false;
         for (;;) {
             if (STATS) it_loops++;
+            uint32_t blocked_word = 0u;
             if constexpr (STEAL) {
-            if (steal_on) {
+            if (share_now) {
+                // (the verdict word of the ray this lane walks a part of: requested here, looked at when the step is done)
+                if (lent) blocked_word = sflag[L.owner];
                 // takers: lanes with nothing to walk whose ray registers are dead (no pixel, or a shadow ray that has ended: a
                 // closest-hit ray's direction is still needed for shading); givers: lanes on a shadow ray with a postponed node
                 const bool taker = L.cur == MI_END_LINK && !L.pend && (!alive || L.mode == MODE_SHADOW);
@@ -862,6 +869,8 @@ k_raytrace(const DevScene S, const FrameParams P)
                 const unsigned long long mTk = __ballot(taker), mGv = __ballot(giver);
                 if (mGv && __popcll(mTk) >= P.steal_min) {
                     const int lane = (int)(threadIdx.x & 63u);
+                    n_event++;
+                    lent = true;
                     const unsigned long long below = (1ull << lane) - 1ull;
                     const int gr = __popcll(mGv & below), tr = __popcll(mTk & below);
                     const int nG = __popcll(mGv), nT = __popcll(mTk);
@@ -888,6 +897,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         R.a = p[0]; R.b = p[1];
                         if ((vgive & MI_LEAF_BIT) == 0) { R2.a = p[2]; R2.b = p[3]; }
                         n_steal++;
+                        blocked_word = 0u;               // (the word read above was the one of the ray this lane walked before)
                     }
                     if (robbed) {
                         if (deep) L.base++;
@@ -1156,6 +1166,10 @@ k_raytrace(const DevScene S, const FrameParams P)
                 MI_PHASE(pc_b);
             }
             }
+            if constexpr (STEAL) {
+                // a blocker found by anyone ends the ray for everyone who walks a part of it
+                if (blocked_word != 0u && L.mode == MODE_SHADOW) { L.cur = MI_END_LINK; L.sp = L.base; L.pend = false; }
+            }
             const unsigned long long mBusy = __ballot(L.cur != MI_END_LINK || L.pend);
             if (!mBusy) break;
             if (xmin_now < 64 && __popcll(__ballot(alive && L.cur == MI_END_LINK && !L.pend)) >= xmin_now) break;
@@ -1251,7 +1265,7 @@ k_raytrace(const DevScene S, const FrameParams P)
         if (lead) { atomicAdd(&P.counters[CS_NORMAL_RAYS], a); atomicAdd(&P.counters[CS_SHADOW_RAYS], b); }
         if constexpr (STEAL) {      // (debug: subtrees handed from lane to lane, in a word the counting builds use for their profile)
             const unsigned long long ns = wsum(n_steal);
-            if (lead && ns) atomicAdd(&P.counters[CS_PROF0 + 12], ns);
+            if (lead && ns) { atomicAdd(&P.counters[CS_PROF0 + 12], ns); atomicAdd(&P.counters[CS_PROF0 + 11], (unsigned long long)n_event); }
         }
         if (STATS) {
             const unsigned long long c = wsum(n_pops), d = wsum(n_ihits), e = wsum(n_tris), f = wsum(n_plane),

@@ -19,15 +19,18 @@ B = 8
 bufs = [torch.zeros((H, W), dtype=torch.int32, device=dev) for _ in range(B)]
 variants = [("default", {}), ("noshare", dict(noshare=1)), ("sharemin1", dict(sharemin=1)), ("sharemin4", dict(sharemin=4)), ("sharemin16", dict(sharemin=16)),
             ("sharemin32", dict(sharemin=32)), ("bpc3", dict(bpc=3)), ("bpc3 noshare", dict(bpc=3, noshare=1)), ("bpc2", dict(bpc=2)),
-            ("quad", dict(quad=1)), ("quad bpc3", dict(quad=1, bpc=3)), ("quad bpc2", dict(quad=1, bpc=2))]
+            ("quad", dict(quad=1)), ("quad bpc3", dict(quad=1, bpc=3)), ("quad bpc2", dict(quad=1, bpc=2)),
+            # bounds, not variants (other pictures): what is left when shadow rays / reflected rays cost nothing
+            ("noshadows", dict(_opts=dict(use_shadows=0))), ("noshadows noshare", dict(noshare=1, _opts=dict(use_shadows=0))), ("norefl", dict(_opts=dict(use_reflections=0)))]
 sel = os.environ.get("RT_VARIANTS")
 if sel: variants = [v for v in variants if v[0] in sel.split(",")]
 def prof12():
     out = (C.c_ulonglong * 20)()
     R.lib().mi355i_fetch_profile.argtypes = [C.c_void_p, C.c_void_p]
-    return int(out[12]) if R.lib().mi355i_fetch_profile(s.context(), out) == 0 else -1
+    return (int(out[12]), int(out[11])) if R.lib().mi355i_fetch_profile(s.context(), out) == 0 else (-1, -1)
 for label, t in variants:
-    o = R.default_opts(W, H, max_ray_depth=depth, tune=R.tune(**t))
+    t = dict(t); extra = t.pop("_opts", {})
+    o = R.default_opts(W, H, max_ray_depth=depth, tune=R.tune(**t), **extra)
     def step(i):
         ks = [(i * B + j) % 200 for j in range(B)]
         s.render_batch_device(9, [cams[k][0] for k in ks], [cams[k][1] for k in ks], 1, o, [b.data_ptr() for b in bufs], W * 4, None, stream.cuda_stream)
@@ -46,4 +49,4 @@ for label, t in variants:
         ms.append(st.kernel_ms)
     ms = np.array(ms[20:])
     print(json.dumps({"variant": label, "batch8_fps": round(best, 1), "single_ms_mean": round(float(ms.mean()), 4), "single_ms_min": round(float(ms.min()), 4),
-                      "steals_last_frame": prof12()}), flush=True)
+                      "steals_events_last_frame": prof12()}), flush=True)

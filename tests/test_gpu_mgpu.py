@@ -66,6 +66,102 @@ def test_mgpu_c_entry_points():
             L.mi355_mgpu_destroy(m)
 
 
+def _mgpu_api():
+    L = R.lib()
+    L.mi355_mgpu_create.restype = C.c_void_p
+    L.mi355_mgpu_create.argtypes = [C.POINTER(R.SceneDesc), C.POINTER(C.c_int), C.c_int]
+    L.mi355_mgpu_destroy.argtypes = [C.c_void_p]
+    L.mi355_mgpu_set_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    L.mi355_mgpu_shadowmap_render.argtypes = [C.c_void_p, C.c_int, C.POINTER(R.Light), C.c_int, C.c_void_p]
+    L.mi355_mgpu_render_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(R.Camera), C.POINTER(R.Light), C.c_int, C.POINTER(R.Opts),
+                                          C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]
+    L.mi355_mgpu_wait.argtypes = [C.c_void_p, C.c_int, C.POINTER(R.Stats)]
+    return L
+
+
+@pytest.mark.parametrize("mode,mesh,ranks,frames", [(9, "dragon_vis.ply", 4, 4), (9, "dragon_vis.ply", 3, 1), (6, "chessboard.tri", 2, 3), (8, "chessboard.tri", 8, 2)])
+def test_mgpu_steps_in_flight_equal_single_device_frames(mode, mesh, ranks, frames):
+    """mi355_mgpu_render_batch / _wait: steps of several frames, two in flight (the third call has to wait for the first),
+    every frame the frame one device renders; ray counts of a step summed over ranks and frames."""
+    torch = pytest.importorskip("torch")
+    L = _mgpu_api()
+    W, H = 642, 363
+    s = R.Scene(R.assets.mesh_path(mesh))
+    if mode >= 9:
+        s.bvh_create()
+    m = L.mi355_mgpu_create(C.byref(s.desc), (C.c_int * ranks)(*([0] * ranks)), ranks)
+    assert m, L.mi355_last_error()
+    try:
+        if mode >= 9:
+            nodes, idx = s.bvh_arrays()
+            assert L.mi355_mgpu_set_bvh(m, nodes.ctypes.data, nodes.shape[0], idx.ctypes.data, idx.shape[0]) == 0
+        o = R.default_opts(W, H)
+        steps = 3
+        bufs = [[torch.zeros((H, W), dtype=torch.int32, device="cuda:0") for _ in range(frames)] for _ in range(steps)]
+        tickets, want, rays = [], [], []
+        for k in range(steps):
+            fs = [k * frames + j for j in range(frames)]
+            cams = (R.Camera * frames)(*[R.benchmark_frame(f)[0] for f in fs])
+            lights = (R.Light * frames)(*[R.benchmark_frame(f)[1][0] for f in fs])
+            if mode in (7, 8):           # (one light position for the whole orbit: its map is drawn once)
+                s.shadowmap_render(0, lights[0])
+                assert L.mi355_mgpu_shadowmap_render(m, 0, C.byref(lights[0]), 1024, None) == 0, L.mi355_last_error()
+            outs = (C.c_void_p * frames)(*[b.data_ptr() for b in bufs[k]])
+            t = C.c_int(0)
+            if k >= 2:
+                assert L.mi355_mgpu_render_batch(m, mode, frames, cams, lights, 1, C.byref(o), outs, W * 4, C.byref(t)) == -45
+                st = R.Stats()
+                assert L.mi355_mgpu_wait(m, tickets[k - 2], C.byref(st)) == 0, L.mi355_last_error()
+                rays.append((st.normal_rays, st.shadow_rays))
+            assert L.mi355_mgpu_render_batch(m, mode, frames, cams, lights, 1, C.byref(o), outs, W * 4, C.byref(t)) == 0, L.mi355_last_error()
+            tickets.append(t.value)
+            fr = [s.render(mode, R.benchmark_frame(f)[0], R.benchmark_frame(f)[1], 1, o) for f in fs]
+            want.append([x[0] for x in fr])
+            if k == 0:
+                rays_want = (sum(x[2].normal_rays for x in fr), sum(x[2].shadow_rays for x in fr))
+        for k in range(1, steps):
+            assert L.mi355_mgpu_wait(m, tickets[k], None) == 0, L.mi355_last_error()
+        assert L.mi355_mgpu_wait(m, tickets[0], None) == -45          # (waited for already)
+        for k in range(steps):
+            for j in range(frames):
+                assert np.array_equal(bufs[k][j].cpu().numpy().view(np.uint32), want[k][j]), (k, j)
+        if mode >= 9:
+            assert rays[0] == rays_want
+    finally:
+        L.mi355_mgpu_destroy(m)
+
+
+def test_config5_frame_on_eight_virtual_ranks(oracle):
+    """BASELINE config 5's frame -- dragon, 3840x2160, depth 3 -- cut over eight ranks (one GPU plays them all), assembled on
+    rank 0, against the oracle's frame."""
+    torch = pytest.importorskip("torch")
+    L = _mgpu_api()
+    W, H = 3840, 2160
+    s = R.Scene(R.assets.mesh_path("dragon_vis.ply"))
+    s.bvh_create()
+    nodes, idx = s.bvh_arrays()
+    m = L.mi355_mgpu_create(C.byref(s.desc), (C.c_int * 8)(*([0] * 8)), 8)
+    assert m, L.mi355_last_error()
+    try:
+        assert L.mi355_mgpu_set_bvh(m, nodes.ctypes.data, nodes.shape[0], idx.ctypes.data, idx.shape[0]) == 0
+        cam, lights, n = R.benchmark_frame(0)
+        o = R.default_opts(W, H)
+        buf = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
+        outs = (C.c_void_p * 1)(buf.data_ptr())
+        t, st = C.c_int(0), R.Stats()
+        assert L.mi355_mgpu_render_batch(m, 9, 1, C.byref(cam), lights, n, C.byref(o), outs, W * 4, C.byref(t)) == 0, L.mi355_last_error()
+        assert L.mi355_mgpu_wait(m, t.value, C.byref(st)) == 0, L.mi355_last_error()
+    finally:
+        L.mi355_mgpu_destroy(m)
+    osc = oracle.Scene(R.assets.mesh_path("dragon_vis.ply"))
+    osc.bvh_build()
+    ocam, olights, on = oracle.benchmark_frame(0)
+    import os
+    ref, _, ost = osc.render(9, ocam, olights, on, oracle.default_opts(W, H, threads=os.cpu_count() or 1))
+    assert np.array_equal(buf.cpu().numpy().view(np.uint32), ref)
+    assert (st.normal_rays, st.shadow_rays) == (ost.normal_rays, ost.shadow_rays) == (9410297, 1163742)      # SURVEY 8(d), cfg 5
+
+
 def test_render_cli_on_two_ranks_and_bench_statistics(tmp_path):
     import os
     cli = os.path.join(os.path.dirname(R.RENDER_SO), "render_cli")

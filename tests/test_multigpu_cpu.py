@@ -28,13 +28,16 @@ def test_assemble_numpy_roundtrip():
     assert np.array_equal(multigpu.assemble_numpy(parts, H, multigpu.BAND_ROWS), full)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_gloo_band_gather(tmp_path, world):
+    """(world 8: the layout of BASELINE config 5 -- eight ranks, a frame of 2 x 8 x 8 + 5 scanlines so that the ranks own
+    different numbers of rows and the last band is short)"""
     out = tmp_path / "result.txt"
     port = 29500 + (os.getpid() % 2000) + world
+    size = ["320", "180", "3"] if world < 8 else ["256", "133", "2"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(os.path.dirname(__file__), "_gloo_band_worker.py"), str(out), "320", "180", "3"]
+           os.path.join(os.path.dirname(__file__), "_gloo_band_worker.py"), str(out)] + size
     env = dict(os.environ, OMP_NUM_THREADS="2")
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
