@@ -28,11 +28,61 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+L2_PEAK_GBS = 34500.0       # aggregate L2 bandwidth of the eight XCDs, same guide ("L2 (per XCD)")
+# vector-ALU issue peak: 256 CUs x 4 SIMDs x 16 lanes, one lane-operation per lane and clock, at the 2.4 GHz the guide quotes
+VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+BENCH_KERNEL = "k_raytrace<false, false, true, 4, true"        # the batched four-wave build the headline launches use
 
 
 def algorithmic_bytes(st, width, rows):
-    """B = 32*N_pop + 36*N_tri + 48*N_plane + 96*N_hit + 4*W*H per raytraced frame."""
+    """B = 32*N_pop + 36*N_tri + 48*N_plane + 96*N_hit + 4*W*H per raytraced frame, with the REFERENCE
+    algorithm's counts (the counting build walks the tree in the reference's order)."""
     return 32 * st["node_pops"] + 36 * st["tri_tests"] + 48 * st["plane_pass"] + 96 * st["shaded_hits"] + 4 * width * rows
+
+
+def own_bytes(st, width, rows):
+    """The same sum for the walk the timed kernel does (counting build of the ORDERED walk, tune flag 8): 64 bytes per wide
+    record fetched (both children's boxes; the counters hold two box tests per record and one for the virtual record above the
+    root, which rides in the kernel arguments: one per ray), 32 per triangle block, 48 per edge record, 80 per shaded hit, 4 per
+    pixel written."""
+    rays = st["normal_rays"] + st["shadow_rays"]
+    wide = max(0, st["node_pops"] - rays) // 2
+    return 64 * wide + 32 * st["tri_tests"] + 48 * st["plane_pass"] + 80 * st["shaded_hits"] + 4 * width * rows
+
+
+def pmc_in_run(py_args, seconds=90):
+    """Hardware counters of the bench kernel, measured NOW: this script again as a child under `rocprofv3 --pmc` (one pass per
+    counter group: FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md), a handful of the same launches, averages
+    per launch of BENCH_KERNEL.  None when rocprofv3 is missing or a pass fails (the line then says so)."""
+    import collections, csv, glob, shutil, signal, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not found"
+    groups = [["VALUBusy", "VALUUtilization", "SALUBusy"], ["FETCH_SIZE"], ["WRITE_SIZE"],
+              ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"]]
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    t_all = time.perf_counter()
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        for gi, g in enumerate(groups):
+            out = os.path.join(td, "p%d" % gi)
+            cmd = [exe, "--kernel-trace", "--pmc"] + g + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--pmc-child"] + py_args
+            try:
+                p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+                try:
+                    p.wait(timeout=seconds)
+                except subprocess.TimeoutExpired:
+                    os.killpg(p.pid, signal.SIGKILL)
+                    return None, "counter pass %s timed out" % "+".join(g)
+            except Exception as e:
+                return None, "counter pass failed: %s" % e
+            n = 0
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if BENCH_KERNEL in row["Kernel_Name"]:
+                        a = acc[row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1; n += 1
+            if n == 0:
+                return None, "counter pass %s produced no rows for the bench kernel" % "+".join(g)
+    return {k: v[0] / v[1] for k, v in acc.items()}, "%d launches per counter, %.0f s" % (min(v[1] for v in acc.values()), time.perf_counter() - t_all)
 
 
 def main():
@@ -56,6 +106,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (rasterizer) workloads")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the secondary weak-scaling run at 1080p")
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect the hardware counters of the bench kernel in this run")
+    ap.add_argument("--pmc-child", action="store_true", help="(internal) a few launches of the bench workload and nothing else: run under rocprofv3 --pmc")
+    ap.add_argument("--repeats", type=int, default=4, help="re-run the timed region this many more times for the spread (N = 1)")
     args = ap.parse_args()
 
     import numpy as np
@@ -126,12 +179,25 @@ def main():
                                       [buf[j].data_ptr() for j in range(B_local)], W * 4, None, stream.cuda_stream)
         gather.gather(slot)
 
+    if args.pmc_child:
+        # launches one after the other, as the roofline's kernel_ms times them (the library does not overlap calls while a profiler
+        # collects counters anyway)
+        for k in range(12):
+            enqueue(k, opts(), k & 1)
+            torch.cuda.synchronize(dev)
+        return
+
     # ---- untimed pre-pass: per-frame ray counts and algorithmic bytes from the counting kernel variant (which walks
     #      the tree in the reference's order: these ARE the reference algorithm's counts), once per orbit camera used
     o_stats = opts(collect_stats=1)
+    t_own = dict(json.loads(args.tune)); t_own["profordered"] = 1
+    o_own = R.default_opts(W, H, tune=t_own, collect_stats=1)
+    if world > 1 and not by_frames:
+        o_own.band_rows, o_own.band_index, o_own.band_count, o_own.compact_rows = multigpu.BAND_ROWS, rank, world, 1
     used = sorted({f for k in range(K) for f in frames_of_step(k)})
     rays_f = np.zeros(N_CAMS, np.float64)
     abytes_f = np.zeros(N_CAMS, np.float64)
+    obytes_f = np.zeros(N_CAMS, np.float64)      # the ordered walk's own bytes (raytrace modes)
     scratch = torch.zeros((gather.max_rows, W), dtype=torch.int32, device=dev)
     for f in used:
         cam, lights, n = cams[f]
@@ -140,6 +206,10 @@ def main():
         st = scene.fetch_stats().as_dict()
         rays_f[f] = st["normal_rays"] + st["shadow_rays"]
         abytes_f[f] = algorithmic_bytes(st, W, my_rows)
+        if args.mode >= 9:
+            scene.render_device(args.mode, cam, lights, n, o_own, scratch.data_ptr(), W * 4, 0, stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            obytes_f[f] = own_bytes(scene.fetch_stats().as_dict(), W, my_rows)
     my_rays = sum(rays_f[f] for k in range(K) for f in frames_of_step(k))
     my_abytes = sum(abytes_f[f] for k in range(K) for f in frames_of_step(k))
     if world > 1:
@@ -177,6 +247,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
 
+    # ---- the same K-step region a few more times (N = 1): the spread of ms_per_step; `value` stays the first region's
+    repeats = None
+    if world == 1 and args.repeats > 0:
+        rs = [dt * 1e3 / K]
+        for _ in range(args.repeats):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for k in range(K):
+                enqueue(k, o_run, k & 1)
+            gather.drain()
+            torch.cuda.synchronize(dev)
+            rs.append((time.perf_counter() - t1) * 1e3 / K)
+        rs_sorted = sorted(rs)
+        repeats = {"n": len(rs), "min": round(rs_sorted[0], 5), "median": round(rs_sorted[len(rs) // 2], 5), "max": round(rs_sorted[-1], 5),
+                   "note": "ms_per_step of the timed region and of %d re-runs of the same %d steps; `value` and `ms_per_step` are the first region's" % (args.repeats, K)}
+
     # ---- the kernel by itself: consecutive launches of the timed region overlap inside the library (each on an internal
     #      stream; the tail of one launch -- a few waves finishing their tiles -- runs beside the head of the next), so no
     #      stream event brackets ONE of them.  The roofline's duration is therefore taken from the same launches one after
@@ -211,6 +297,7 @@ def main():
         torch.cuda.synchronize(dev)
         iso_ms = i0.elapsed_time(i1) / n_iso
         iso_abytes = sum(abytes_f[f] for k in range(n_iso) for f in frames_of_step(k)) / n_iso       # (this rank's launches)
+        iso_obytes = sum(obytes_f[f] for k in range(n_iso) for f in frames_of_step(k)) / n_iso
 
     # sanity: the last assembled frame is a real picture
     if rank == 0:
@@ -309,58 +396,78 @@ def main():
                        "frames_per_step": B, "frames": K * B,
                        "rays_per_frame": round(total_rays / (K * B), 1), "tune": json.loads(args.tune)},
             "frames_per_sec": round(K * B / dt, 3),
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(abytes_launch / (kernel_ms * 1e-3) / 1e9, 3),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(abytes_launch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "traffic": None,
-                "frac_means": "reference-work rate: the REFERENCE algorithm's bytes (SURVEY 8d) over this kernel's time -- not HBM "
-                              "utilisation (the scene is cache resident).  It can exceed 1: the ordered walk and the tile culling do not "
-                              "perform all of the reference's node pops and triangle tests, so the reference's work gets done faster "
-                              "than HBM could stream its bytes; the bound that binds is `issue_bound`",
-                "kernel": "k_raytrace<STATS=false, EXACT_BOX=false, ORDERED=true, WAVES=2|3|4 by launch size, BATCH=frames>1> (ordered walk), "
-                          "preceded by k_tile_select (tiles no camera ray can hit anything in are set to black, ~1 % of the launch)",
+            "roofline": None,
+        }
+        if repeats:
+            result["repeats"] = repeats
+        # ---- roofline of the traversal kernel.  No dense contraction -> no MFMA; the scene is cache resident -> HBM does not
+        #      bind either.  What binds is vector-ALU issue, so `frac` is the fraction of the chip's vector lanes
+        #      doing useful work = VALUBusy x VALUUtilization, from counters collected in THIS run where rocprofv3 is present.
+        ks = kernel_ms * 1e-3
+        own_launch = iso_obytes if (iso_ms and args.mode >= 9) else None
+        pmc, pmc_note, pmc_src = None, "not collected (N > 1, --no-pmc or a raster mode)", None
+        if world == 1 and args.mode >= 9 and not args.no_pmc:
+            child = ["--frames-per-step", str(B), "--mesh", args.mesh, "--mode", str(args.mode), "--tune", args.tune, "--width", str(W), "--height", str(H)]
+            pmc, pmc_note = pmc_in_run(child)
+            pmc_src = "this run: rocprofv3 --pmc passes of the same launches (%s)" % pmc_note if pmc else None
+        if pmc is None and world == 1:
+            tfile = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tfile):
+                try:
+                    tj = json.load(open(tfile))
+                    pmc = tj.get("pmc_per_launch")
+                    pmc_src = "STALE: profiles/traffic.json (committed passes of %s, another build of the kernel), because: %s" % (tj.get("round", "an earlier round"), pmc_note)
+                except Exception:
+                    pmc = None
+        roof = {"kernel": "k_raytrace<STATS=false, EXACT_BOX=false, ORDERED=true, WAVES=2|3|4 by launch size, BATCH=frames>1> (ordered walk, work shared "
+                          "inside a wave), preceded by k_tile_select (tiles no camera ray can hit anything in are set to black, ~1 % of the launch)",
                 "kernel_ms": round(kernel_ms, 5),
                 "kernel_ms_means": "one launch by itself: %d launches of the same steps one after the other on the launch stream (tune flag 32), "
                                    "HIP events around them" % (n_iso if iso_ms else K),
                 "timed_region_ms_per_launch": round(period_ms, 5),
                 "timed_region_note": "in the timed region consecutive launches overlap inside the library (internal streams, frames copied out "
                                      "on the launch stream): a launch every timed_region_ms_per_launch, each taking longer than kernel_ms",
-                "algorithmic_bytes_per_launch": round(abytes_launch, 1),
                 "frames_per_launch": B_local,
-                "note": "one launch = one GPU's share of a step = %d frames of the orbit (mi355_render_batch_device). " % B_local +
-                        "achieved = SURVEY 8(d) algorithmic bytes per launch (the REFERENCE algorithm's node pops / "
-                        "triangle tests / hits, counted by the reference-order kernel variant on the same frames) / "
-                        "HIP-event time per launch on the launch stream (rank 0; see kernel_ms_means). The timed kernel walks the tree near "
-                        "child first with distance culling and skips 8x8 tiles outside the projected boxes of the tree's top "
-                        "(identical pixels, fewer visits); the scene (~8 MB) is "
-                        "L2/MALL resident so real HBM traffic is far lower -- see profiles/ and DESIGN.md 4.1",
-            },
-        }
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if world == 1 and os.path.exists(tfile):
-            try:
-                result["roofline"]["traffic"] = json.load(open(tfile)).get("k_raytrace_hbm_bytes_per_launch")
-                tj = json.load(open(tfile))
-                pmc = tj.get("pmc_per_launch", {})
-                result["roofline"]["traffic_source"] = "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " + tj.get("round", "an earlier round") + \
-                                                       " (committed; NOT measured in this run), per launch of 8 frames"
-                if "VALUBusy" in pmc:
-                    # what actually bounds the kernel: vector-ALU issue.  Fraction of the chip's vector lanes doing useful work =
-                    # busy fraction of the VALUs x fraction of the lanes active per instruction.
-                    vb, vu = pmc["VALUBusy"] / 100.0, pmc.get("VALUUtilization", 0.0) / 100.0
-                    result["roofline"]["issue_bound"] = {
-                        "frac": round(vb * vu, 3), "valu_busy_pct": round(pmc["VALUBusy"], 1),
-                        "valu_active_lanes_pct": round(pmc.get("VALUUtilization", 0.0), 1), "salu_busy_pct": round(pmc.get("SALUBusy", 0.0), 1),
-                        "valu_wave_instructions_per_launch": pmc.get("SQ_INSTS_VALU"), "salu_wave_instructions_per_launch": pmc.get("SQ_INSTS_SALU"),
-                        "source": "profiles/traffic.json (counters of the committed rocprofv3 passes, not this run)"}
-                if result["roofline"]["traffic"]:
-                    # measured HBM rate of the traversal kernel (PMC bytes of profiles/traffic.json over this run's kernel time)
-                    result["roofline"]["measured_hbm_GBs"] = round(result["roofline"]["traffic"] / (kernel_ms * 1e-3) / 1e9, 2)
-            except Exception:
-                pass
+                "traffic": None}
+        if pmc and "VALUBusy" in pmc:
+            vb, vu = pmc["VALUBusy"] / 100.0, pmc.get("VALUUtilization", 0.0) / 100.0
+            roof.update({"bound": "valu-issue",
+                         "bound_note": "the contract's two bounds do not bind this kernel: there is no dense contraction (no MFMA) and the scene is cache "
+                                       "resident (measured HBM traffic: see `hbm`); the vector ALUs' issue slots do.  achieved = lane-operations per second "
+                                       "that do useful work = VALUBusy x VALUUtilization x peak; peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz",
+                         "achieved": round(vb * vu * VALU_PEAK_TLANEOPS, 3), "peak": round(VALU_PEAK_TLANEOPS, 3), "unit": "Tlane-op/s", "frac": round(vb * vu, 4),
+                         "counters": {"source": pmc_src, "valu_busy_pct": round(pmc["VALUBusy"], 2), "valu_active_lanes_pct": round(pmc.get("VALUUtilization", 0.0), 2),
+                                      "salu_busy_pct": round(pmc.get("SALUBusy", 0.0), 2),
+                                      "valu_wave_instructions_per_launch": pmc.get("SQ_INSTS_VALU"), "salu_wave_instructions_per_launch": pmc.get("SQ_INSTS_SALU")}})
+        else:
+            roof.update({"bound": "hbm", "achieved": round((own_launch or abytes_launch) / ks / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round((own_launch or abytes_launch) / ks / 1e9 / HBM_PEAK_GBS, 5),
+                         "bound_note": "no hardware counters available (%s): the kernel's own algorithmic bytes over its time against the HBM peak" % pmc_note})
+        hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        if own_launch:
+            hbm.update({"own_bytes_per_launch": round(own_launch, 1), "achieved": round(own_launch / ks / 1e9, 3), "frac_own": round(own_launch / ks / 1e9 / HBM_PEAK_GBS, 5),
+                        "own_bytes_mean": "the ordered walk's OWN algorithmic bytes: 64 B per wide record fetched, 32 per triangle block, 48 per edge record, 80 per "
+                                          "shaded hit, 4 per pixel -- counted on the same frames by the counting build of that walk (tune flag 8; without tile "
+                                          "culling and work sharing, which change the schedule, not the records a ray needs)"})
+        if pmc and pmc.get("FETCH_SIZE") is not None and pmc.get("WRITE_SIZE") is not None:
+            traffic = 2.0 * pmc["FETCH_SIZE"] * 1024.0 + pmc["WRITE_SIZE"] * 1024.0
+            roof["traffic"] = round(traffic, 1)
+            hbm.update({"measured_bytes_per_launch": round(traffic, 1), "measured_GBs": round(traffic / ks / 1e9, 2), "measured_frac": round(traffic / ks / 1e9 / HBM_PEAK_GBS, 5),
+                        "measured_read_bytes": round(2.0 * pmc["FETCH_SIZE"] * 1024.0, 1), "measured_write_bytes": round(pmc["WRITE_SIZE"] * 1024.0, 1),
+                        "measured_note": "FETCH_SIZE x 2 (the guide's gfx950 correction for 16-byte-per-lane loads) + WRITE_SIZE, KB -> bytes, separate passes; " + (pmc_src or "")})
+        roof["hbm"] = hbm
+        if pmc and pmc.get("TCP_TCC_READ_REQ_sum") is not None:
+            l2b = pmc["TCP_TCC_READ_REQ_sum"] * 128.0
+            roof["l2"] = {"read_requests_per_launch": round(pmc["TCP_TCC_READ_REQ_sum"], 1), "bytes_per_launch": round(l2b, 1), "GBs": round(l2b / ks / 1e9, 2),
+                          "peak": L2_PEAK_GBS, "frac": round(l2b / ks / 1e9 / L2_PEAK_GBS, 5),
+                          "hit_rate": round(pmc["TCC_HIT_sum"] / max(1.0, pmc["TCC_HIT_sum"] + pmc.get("TCC_MISS_sum", 0.0)), 4) if pmc.get("TCC_HIT_sum") is not None else None,
+                          "note": "L1 -> L2 read requests (TCP_TCC_READ_REQ_sum) x 128-byte lines: an upper bound of the bytes the L2s deliver"}
+        roof["reference_work_rate"] = {
+            "bytes_per_launch": round(abytes_launch, 1), "GBs": round(abytes_launch / ks / 1e9, 3), "x_hbm_peak": round(abytes_launch / ks / 1e9 / HBM_PEAK_GBS, 4),
+            "means": "SURVEY 8(d): the REFERENCE algorithm's bytes (its node pops / triangle tests / hits on the same frames, counted by the reference-order "
+                     "build) over this kernel's time.  A work rate, not a bandwidth and not a roofline fraction: the timed kernel reaches the same pixels with "
+                     "fewer visits (near child first, distance culling, tile culling), so it can exceed the HBM peak"}
+        result["roofline"] = roof
 
     if rank == 0 and mg is not None:
         result["multi_gpu"] = mg
@@ -440,7 +547,8 @@ def main():
                     kms += scene.render_into(args.mode, cams[k][0], cams[k][1], cams[k][2], o1, hb[0]).kernel_ms
                 seam["sync_host_fps"] = round(100 / (time.perf_counter() - t1), 1)
                 seam["single_frame_kernel_ms"] = round(kms / 100, 4)
-                seam["single_frame_roofline_frac"] = round(float(np.mean([abytes_f[k] for k in range(100) if abytes_f[k] > 0] or [0])) / (kms / 100 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                seam["single_frame_own_bytes_frac_of_hbm_peak"] = round(float(np.mean([obytes_f[k] for k in range(100) if obytes_f[k] > 0] or [0])) / (kms / 100 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                seam["single_frame_reference_work_x_hbm_peak"] = round(float(np.mean([abytes_f[k] for k in range(100) if abytes_f[k] > 0] or [0])) / (kms / 100 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                 for b in hb:
                     scene.host_register(b)
                 try:
@@ -468,6 +576,41 @@ def main():
                                 % R.MAX_IN_FLIGHT)
                 result["seam"] = seam
                 extra["frame_by_frame_Mrays_per_s"] = round(float(sum(rays_f[k] for k in range(200) if rays_f[k] > 0)) / max(1, sum(1 for k in range(200) if rays_f[k] > 0)) * 200 / dt1 / 1e6, 1)
+            # the other raytrace configurations of BASELINE.json on ONE GPU: configs[2] (statue, primary + shadow rays = depth 1) and
+            # configs[4]'s frame size (dragon 3840x2160): 8 frames per launch like the headline, and the kernel time of one frame
+            if args.mode >= 9:
+                def rt_workload(mesh, w, h, depth):
+                    sc = scene if mesh == args.mesh else R.Scene(R.assets.mesh_path(mesh), device=local_rank)
+                    if sc is not scene:
+                        sc.bvh_update()
+                    ow = R.default_opts(w, h, max_ray_depth=depth, tune=json.loads(args.tune))
+                    oc = R.default_opts(w, h, max_ray_depth=depth, collect_stats=1)
+                    bufs = [torch.zeros((h, w), dtype=torch.int32, device=dev) for _ in range(8)]
+                    n_cam = 40
+                    rays = []
+                    for f in range(n_cam):
+                        sc.render_device(9, cams[f][0], cams[f][1], cams[f][2], oc, bufs[0].data_ptr(), w * 4, 0, stream.cuda_stream)
+                        torch.cuda.synchronize(dev)
+                        st = sc.fetch_stats()
+                        rays.append(st.normal_rays + st.shadow_rays)
+                    def step(i):
+                        fs = [(8 * i + j) % n_cam for j in range(8)]
+                        sc.render_batch_device(9, [cams[f][0] for f in fs], [cams[f][1] for f in fs], cams[fs[0]][2], ow, [b.data_ptr() for b in bufs], w * 4, None, stream.cuda_stream)
+                    for i in range(5):
+                        step(i)
+                    torch.cuda.synchronize(dev)
+                    n_s = 25
+                    t1 = time.perf_counter()
+                    for i in range(n_s):
+                        step(i)
+                    torch.cuda.synchronize(dev)
+                    d = time.perf_counter() - t1
+                    kms = [sc.render(9, cams[f][0], cams[f][1], cams[f][2], ow)[2].kernel_ms for f in range(0, n_cam, 4)]
+                    return {"Mrays_per_s": round(sum(rays) / n_cam * 8 * n_s / d / 1e6, 1), "frames_per_sec": round(8 * n_s / d, 1), "frames_per_launch": 8,
+                            "rays_per_frame": round(sum(rays) / n_cam, 1), "single_frame_kernel_ms": round(float(np.mean(kms)), 4),
+                            "workload": "%s, mode 9, max_ray_depth %d, %dx%d, orbit frames f0..f%d" % (mesh, depth, w, h, n_cam - 1)}
+                extra["statue_depth1_1080p"] = rt_workload("statue.ply", 1920, 1080, 1)
+                extra["dragon_4k"] = rt_workload("dragon_vis.ply", 3840, 2160, 3)
             # BVH build of the benchmark mesh: GPU level kernels + download + flatten, host builder beside it
             import ctypes as C
             bs = R.Scene(R.assets.mesh_path(args.mesh), device=local_rank)

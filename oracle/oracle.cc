@@ -1019,6 +1019,10 @@ struct RasterTarget {
     uint32_t *pix;
     std::vector<float> z;
     orc_stats *st;
+    /* orc_raster_winners: per pixel, what the last Z-pass handed to Plot<> (oracle/refcore/refraster.cc records the same) */
+    int cur_tri = -1;
+    int32_t *win_tri = nullptr, *win_passes = nullptr;
+    float *win_fat = nullptr;          /* 8 floats per pixel */
 };
 
 enum FillMode { FAmbient = 4, FGouraud = 5, FPhong = 6, FPhongShadow = 7, FPhongSoft = 8 };
@@ -1041,6 +1045,11 @@ static inline void plot(RasterTarget &rt, const LightCtx &L, int y, int x, const
     }
     rt.pix[(size_t)y * rt.pitch + x] = out;
     rt.st->plots++;
+    if (rt.win_tri) {
+        const size_t i = (size_t)y * rt.W + x;
+        rt.win_tri[i] = rt.cur_tri; rt.win_passes[i]++;
+        for (int k = 0; k < N; k++) rt.win_fat[8 * i + k] = v.v[k];
+    }
 }
 
 template <int N, int MODE, bool checkX>
@@ -1096,11 +1105,12 @@ static void rasterize_triangle(RasterTarget &rt, const LightCtx &L, int ay, int 
 
 template <int N, int MODE>
 static void render_raster(const orc_scene &s, const orc_camera &cam, const LightCtx &L, const orc_opts &o,
-                          uint32_t *out, int pitch, orc_stats &stats)
+                          uint32_t *out, int pitch, orc_stats &stats, int32_t *win_tri = nullptr, int32_t *win_passes = nullptr, float *win_fat = nullptr)
 {
     const int W = o.width, H = o.height, SD = o.screen_dist;
     const float clip = o.clip_z;
     RasterTarget rt; rt.W = W; rt.H = H; rt.pitch = pitch; rt.pix = out; rt.st = &stats;
+    rt.win_tri = win_tri; rt.win_passes = win_passes; rt.win_fat = win_fat;
     rt.z.assign((size_t)W * H, 0.0f);                                     /* ClearZbuffer */
     for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) out[(size_t)y * pitch + x] = 0;
     std::vector<unsigned> lines(H);
@@ -1150,6 +1160,7 @@ static void render_raster(const orc_scene &s, const orc_camera &cam, const Light
                 f[k].v[5] = nrm.x; f[k].v[6] = nrm.y; f[k].v[7] = nrm.z;
             }
         }
+        rt.cur_tri = (int)j;
         rasterize_triangle<N, MODE>(rt, L, iy[0], iy[1], iy[2], f[0], f[1], f[2], t.colorf, lines.data(),
                                     left.data(), right.data());
     }
@@ -1820,6 +1831,29 @@ int orc_render(const orc_scene *s, int mode, const orc_camera *cam, const orc_li
     default: return -1;
     }
     if (stats) *stats = local;
+    return 0;
+}
+
+/* Raster modes 4..8, and per pixel what the LAST Z-pass handed to Screen::Plot<>: the triangle (-1: none), the number of
+ * Z-passes, and the interpolated fat point (Ambient / Gouraud: projx, 1/z, b, g, r; Phong*: projx, x/z, y/z, 1/z, ao, normal) in
+ * eight floats.  Exists so that tests can hold the span walk, the Z-test and the fillers to the reference's own code with
+ * recording plotters (oracle/refcore/refraster.cc). */
+int orc_raster_winners(const orc_scene *s, int mode, const orc_camera *cam, const orc_light *lights, int n_lights,
+                       const float *const *shadow_maps, const orc_opts *o, uint32_t *out, int32_t *win_tri, int32_t *win_passes, float *win_fat8)
+{
+    orc_stats local; memset(&local, 0, sizeof local);
+    LightCtx L; L.lights = lights; L.nLights = n_lights; L.maps = shadow_maps; L.o = o;
+    const size_t n = (size_t)o->width * o->height;
+    for (size_t i = 0; i < n; i++) { win_tri[i] = -1; win_passes[i] = 0; }
+    memset(win_fat8, 0, n * 8 * sizeof(float));
+    switch (mode) {
+    case 4: render_raster<5, FAmbient>(*s, *cam, L, *o, out, o->width, local, win_tri, win_passes, win_fat8); break;
+    case 5: render_raster<5, FGouraud>(*s, *cam, L, *o, out, o->width, local, win_tri, win_passes, win_fat8); break;
+    case 6: render_raster<8, FPhong>(*s, *cam, L, *o, out, o->width, local, win_tri, win_passes, win_fat8); break;
+    case 7: if (!shadow_maps) return -2; render_raster<8, FPhongShadow>(*s, *cam, L, *o, out, o->width, local, win_tri, win_passes, win_fat8); break;
+    case 8: if (!shadow_maps) return -2; render_raster<8, FPhongSoft>(*s, *cam, L, *o, out, o->width, local, win_tri, win_passes, win_fat8); break;
+    default: return -1;
+    }
     return 0;
 }
 

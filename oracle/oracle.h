@@ -151,6 +151,8 @@ void orc_wu_lines(uint32_t *pixels, int width, int height, int pitch_words, int 
 
 /* LightingEquation<mode>::ComputePixel (LightingEq.h:45-170) on caller-supplied points, rows of
  * (inCameraSpace[3], normal[3], material r,g,b, ao) -> r,g,b; shadow_mode 0 none, 1 shadow maps, 2 soft */
+int orc_raster_winners(const orc_scene *, int mode, const orc_camera *, const orc_light *lights, int n_lights,
+                       const float *const *shadow_maps, const orc_opts *, uint32_t *out, int32_t *win_tri, int32_t *win_passes, float *win_fat8);
 void orc_lighting(const orc_light *lights, int n_lights, const float *const *shadow_maps, const orc_opts *o,
                   int shadow_mode, int n, const float *pts10, float *rgb);
 

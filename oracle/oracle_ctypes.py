@@ -247,6 +247,26 @@ class Scene:
         return out, outf, st
 
 
+def raster_winners(scene, mode: int, cam: Camera, lights, n_lights: int, opts: Opts, shadow_maps=None):
+    """orc_raster_winners: (frame, winning triangle per pixel or -1, Z-passes per pixel, the fat point Plot<> received [H, W, 8])."""
+    W, H = opts.width, opts.height
+    out = np.zeros((H, W), np.uint32)
+    tri = np.zeros((H, W), np.int32)
+    passes = np.zeros((H, W), np.int32)
+    fat = np.zeros((H, W, 8), np.float32)
+    maps_arg = None
+    if shadow_maps is not None:
+        arr = (C.c_void_p * len(shadow_maps))(*[m.ctypes.data for m in shadow_maps])
+        maps_arg = C.cast(arr, C.c_void_p)
+    f = lib().orc_raster_winners
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    f.restype = C.c_int
+    rc = f(scene._h, mode, C.byref(cam), lights, n_lights, maps_arg, C.byref(opts), out.ctypes.data, tri.ctypes.data, passes.ctypes.data, fat.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("orc_raster_winners failed (%d)" % rc)
+    return out, tri, passes, fat
+
+
 def lighting(lights, n_lights: int, opts: Opts, shadow_mode: int, points, shadow_maps=None) -> np.ndarray:
     """LightingEquation<mode>::ComputePixel for rows (inCameraSpace[3], normal[3], material r,g,b, ao)."""
     pts = np.ascontiguousarray(points, np.float32)

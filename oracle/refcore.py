@@ -15,6 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 BINARY = os.path.join(_HERE, "_ref", "refcore")
+RASTER_BINARY = os.path.join(_HERE, "_ref", "refraster")
 REFERENCE_SRC = "/root/reference/src"
 
 
@@ -126,3 +127,26 @@ def bvh(osc):
     out = _run("bvh", scene_blobs(osc), np.uint32)
     n, ni = int(out[0]), int(out[1])
     return out[2:2 + 8 * n].reshape(n, 8).copy(), out[2 + 8 * n:2 + 8 * n + ni].astype(np.int32)
+
+
+def raster_available() -> bool:
+    return os.path.exists(RASTER_BINARY)
+
+
+def raster_winners(osc, mode, eye, lookat, light_positions, timeout=1800):
+    """The reference's OWN rasterizer (oracle/refcore/refraster.cc: RasterizeScene<T>::DrawTriangles, Filler<>, ScanConverter,
+    Screen::RasterizeTriangle, the Z-buffer) with recording plotters, at its compile-time 800 x 600: returns
+    (W, H, camera matrix[9], winning triangle per pixel or -1 [H, W], Z-passes per pixel [H, W], fat point of the last pass [H, W, 8])."""
+    lp = np.asarray(light_positions, np.float32).reshape(-1)
+    blobs = scene_blobs(osc) + [_u32(len(lp) // 3), lp, np.array(list(eye) + list(lookat), np.float32)]
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in"), os.path.join(d, "out")
+        with open(fin, "wb") as f:
+            for b in blobs:
+                f.write(b if isinstance(b, (bytes, bytearray)) else np.ascontiguousarray(b).tobytes())
+        subprocess.run([RASTER_BINARY, str(mode), fin, fout], check=True, timeout=timeout, stdout=subprocess.DEVNULL)
+        raw = np.fromfile(fout, dtype=np.uint32)
+    W, H = int(raw[0]), int(raw[1])
+    mv = raw[2:11].view(np.float32).copy()
+    px = raw[11:].reshape(H, W, 10)
+    return W, H, mv, px[..., 0].view(np.int32).copy(), px[..., 1].view(np.int32).copy(), px[..., 2:].view(np.float32).copy()

@@ -1410,6 +1410,10 @@ int mi355_fetch_stats(mi355_ctx *c, mi355_stats *s)
     return 0;
 }
 
+// Not part of the public ABI (mgpu.hip): device address of the ray counters (normal rays, shadow rays: two 64-bit words) of the
+// context's most recent call -- valid, in stream order, behind that call on the stream it was given
+void *mi355i_last_ray_counters(mi355_ctx *c) { return c ? (char *)(c->last_ctrl ? c->last_ctrl : c->ctrl.p) + 16 : nullptr; }
+
 // Not part of the public ABI: known-answer test of the device's float arithmetic (tests/test_gpu_parity.py).  Every
 // pixel of every mode rests on these operations rounding exactly like the strict x86-64 build of the reference:
 // out[0..8][i] = a/b, sqrt(a), a*b+c (two roundings: no contraction), a+b, a*b, cvtt_i32(a), myfloor(a), u8cast(a),

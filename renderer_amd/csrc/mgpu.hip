@@ -28,6 +28,7 @@
 #define MGPU_SETS 2                 // steps in flight: step k + 1 is rendered while step k is on the wire and being assembled
 
 extern "C" int mi355i_set_error(int code, const char *text);     // capi.hip: sets mi355_last_error() of this thread
+extern "C" void *mi355i_last_ray_counters(mi355_ctx *c);          // capi.hip: device address of the last call's two ray counters
 
 namespace {
 
@@ -70,6 +71,7 @@ struct mi355_mgpu {
     uint32_t *gathered[MGPU_SETS] = {};            // device 0: [n][cap_frames * max_rows][W]
     std::vector<hipEvent_t> rendered[MGPU_SETS];   // rank r's frames of the step are rendered (on st[r])
     std::vector<hipEvent_t> sent[MGPU_SETS];       // ... and have left part[b][r] (on cs[r] / cs[0])
+    std::vector<unsigned long long *> rays[MGPU_SETS];    // rank r's ray counters of the step (two words on its device, copied behind the launch)
     hipEvent_t assembled[MGPU_SETS] = {};          // the step's frames are in their destinations (on cs[0])
     bool sent_set[MGPU_SETS] = {}, asm_set[MGPU_SETS] = {};
     int ticket_of[MGPU_SETS] = {}, mode_of[MGPU_SETS] = {};
@@ -155,7 +157,7 @@ mi355_mgpu *mi355_mgpu_create(const mi355_scene_desc *desc, const int *devices, 
     m->n = n_devices;
     m->dev.assign(devices, devices + n_devices);
     m->ctx.assign(n_devices, nullptr); m->st.assign(n_devices, nullptr); m->cs.assign(n_devices, nullptr);
-    for (int b = 0; b < MGPU_SETS; b++) { m->part[b].assign(n_devices, nullptr); m->rendered[b].assign(n_devices, nullptr); m->sent[b].assign(n_devices, nullptr); }
+    for (int b = 0; b < MGPU_SETS; b++) { m->part[b].assign(n_devices, nullptr); m->rendered[b].assign(n_devices, nullptr); m->sent[b].assign(n_devices, nullptr); m->rays[b].assign(n_devices, nullptr); }
     bool distinct = true;
     for (int i = 0; i < n_devices; i++) for (int j = 0; j < i; j++) if (devices[i] == devices[j]) distinct = false;
     const char *tr = getenv("MI355_MGPU_TRANSPORT");
@@ -167,6 +169,7 @@ mi355_mgpu *mi355_mgpu_create(const mi355_scene_desc *desc, const int *devices, 
                   hipStreamCreateWithFlags(&m->cs[r], hipStreamNonBlocking) == hipSuccess;
         for (int b = 0; b < MGPU_SETS && ok; b++)
             ok = hipEventCreateWithFlags(&m->rendered[b][r], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&m->sent[b][r], hipEventDisableTiming) == hipSuccess &&
+                 hipMalloc((void **)&m->rays[b][r], 16) == hipSuccess &&
                  (r > 0 || hipEventCreateWithFlags(&m->assembled[b], hipEventDisableTiming) == hipSuccess);
         if (!ok) {
             mfail(-11, "mi355_mgpu_create: stream / event creation failed on device %d", devices[r]);
@@ -198,6 +201,7 @@ void mi355_mgpu_destroy(mi355_mgpu *m)
             if (r > 0 && m->part[b][r]) (void)hipFree(m->part[b][r]);
             if (m->rendered[b][r]) (void)hipEventDestroy(m->rendered[b][r]);
             if (m->sent[b][r]) (void)hipEventDestroy(m->sent[b][r]);
+            if (m->rays[b][r]) (void)hipFree(m->rays[b][r]);
         }
         if (m->st[r]) (void)hipStreamDestroy(m->st[r]);
         if (m->cs[r]) (void)hipStreamDestroy(m->cs[r]);
@@ -276,6 +280,9 @@ int mi355_mgpu_render_batch(mi355_mgpu *m, int mode, int n_frames, const mi355_c
         const int e = n_frames == 1 ? mi355_render_device(m->ctx[r], mode, cams, lights, n_lights, &ro, outs[0], W * 4, nullptr, m->st[r])
                                     : mi355_render_batch_device(m->ctx[r], mode, n_frames, cams, lights, n_lights, &ro, outs, W * 4, nullptr, m->st[r]);
         if (e) { drain(m); return e; }
+        // (the step's ray counters, kept apart: the context's block is the next call's by the time somebody asks)
+        if (mode >= MI355_MODE_RAYTRACE) he = hipMemcpyAsync(m->rays[b][r], mi355i_last_ray_counters(m->ctx[r]), 16, hipMemcpyDeviceToDevice, m->st[r]);
+        if (he != hipSuccess) { drain(m); return mfail(-31, "copy of the ray counters: %s", hipGetErrorString(he)); }
         if ((he = hipEventRecord(m->rendered[b][r], m->st[r])) != hipSuccess) { drain(m); return mfail(-40, "hipEventRecord: %s", hipGetErrorString(he)); }
     }
     // ---- one exchange for the whole step: rank r -> rank 0, each pair on its own link ----
@@ -337,9 +344,8 @@ int mi355_mgpu_render_batch(mi355_mgpu *m, int mode, int n_frames, const mi355_c
     return 0;
 }
 
-// The frames of step `ticket` are complete in their buffers when this returns.  stats (optional): ray counts of the step summed
-// over the devices -- asking for them waits for every device's render stream (the counters are read from each context's last
-// call).  Raster modes: -44 when a device's bin or band buffers were too small for a frame of the step; they have grown by
+// The frames of step `ticket` are complete in their buffers when this returns.  stats (optional): ray counts of THAT step summed
+// over the devices and frames (each device copies its counters aside behind the step's launch).  Raster modes: -44 when a device's bin or band buffers were too small for a frame of the step; they have grown by
 // then and the step has to be drawn again.
 int mi355_mgpu_wait(mi355_mgpu *m, int ticket, mi355_stats *stats)
 {
@@ -353,20 +359,28 @@ int mi355_mgpu_wait(mi355_mgpu *m, int ticket, mi355_stats *stats)
     if (he != hipSuccess) { drain(m); return mfail(-40, "hipEventSynchronize: %s", hipGetErrorString(he)); }
     const bool raster = m->mode_of[b] >= MI355_MODE_AMBIENT && m->mode_of[b] <= MI355_MODE_PHONG_SOFTSHADOWMAPS;
     if (stats) memset(stats, 0, sizeof *stats);
-    if (stats || raster) {
+    if (stats && !raster && m->mode_of[b] >= MI355_MODE_RAYTRACE)
+        for (int r = 0; r < m->n; r++) {
+            if (!m->rows[r]) continue;
+            unsigned long long two[2] = {0, 0};
+            (void)hipSetDevice(m->dev[r]);
+            // (behind the step's launch on the rank's render stream, which the assembly waited for)
+            if (hipEventSynchronize(m->rendered[b][r]) != hipSuccess || hipMemcpy(two, m->rays[b][r], 16, hipMemcpyDeviceToHost) != hipSuccess) { drain(m); return mfail(-31, "reading rank %d's ray counters failed", r); }
+            stats->normal_rays += two[0]; stats->shadow_rays += two[1];
+        }
+    if (raster) {
         int rc = 0;
         for (int r = 0; r < m->n; r++) {
             if (!m->rows[r]) continue;
             (void)hipSetDevice(m->dev[r]);
-            (void)hipStreamSynchronize(m->st[r]);        // (mi355_fetch_stats reads the control block of the context's LAST call)
+            (void)hipStreamSynchronize(m->st[r]);
             mi355_stats s;
-            const int e = mi355_fetch_stats(m->ctx[r], &s);
+            const int e = mi355_fetch_stats(m->ctx[r], &s);      // (the overflow word is sticky in the context's block until it is read)
             if (e && !rc) rc = e;                        // (-44: that rank's rasterizer buffers have grown: draw again; look at every rank)
-            if (stats) { stats->normal_rays += s.normal_rays; stats->shadow_rays += s.shadow_rays; }
         }
-        (void)hipSetDevice(m->dev[0]);
-        if (rc) { drain(m); return rc; }
+        if (rc) { (void)hipSetDevice(m->dev[0]); drain(m); return rc; }
     }
+    (void)hipSetDevice(m->dev[0]);
     return 0;
 }
 

@@ -10,9 +10,12 @@ and through the oracle's restatement and demands bit-identical floats:
   b4,b8  ScanConverter + Light::RenderSceneIntoShadowBuffer            three meshes x two lights
   b7     LightingEquation<NoShadows|ShadowMapping|SoftShadowMapping>   200 k points
   b9     Camera::UpdateMV, the three Light:: bases                     the whole benchmark orbit
+  b2-b5  RasterizeScene<T>::DrawTriangles, Filler<T> x 5, ScanConverter in the screen's edge order, Screen::RasterizeTriangle
+         and the Z-buffer (oracle/_ref/refraster: Rasterizers.cc itself, with plotters that record)      3 meshes x 4 cameras x 5 types
 
 What the reference cannot run without SDL (Scene::load's Triangle constructor, the BVH builder's progress report, the
-rasterizer's Plot<>, SDL_MapRGB's byte packing) stays pinned by the survey's hashes only (tests/test_oracle_pins.py).
+body of the rasterizer's Plot<> -- a cast per channel, or un-projection + normalisation in front of the pinned ComputePixel --
+and SDL_MapRGB's byte packing) stays pinned by the survey's hashes only (tests/test_oracle_pins.py).
 On a box without the reference tree the prebuilt binary is used; without either the tests skip.
 """
 import os
@@ -226,3 +229,41 @@ def test_raycast_ambient_occlusion_equals_the_reference_on_its_rand_sequence(ora
     assert np.array_equal(lit, img2.sum(-1) > 0)
     a, b = np.minimum(imgf, 255.0)[lit].mean(), np.minimum(img2, 255.0)[lit].mean()
     assert abs(a - b) < 0.01 * max(a, b), (a, b)
+
+
+# ---- the rasterizer itself: rows b2 - b5 against the reference's own code (oracle/refcore/refraster.cc) -------------------
+_RASTER_CAMERAS = {
+    # (eye, lookat): the benchmark orbit's first camera; one from above and behind; one INSIDE the model's box looking along it
+    # (triangles cut by the near distance, spans clipped at both screen edges, edges that start above the screen); one far away
+    "orbit0": ([4.799934387207031, -0.02513263002038002, 0.0], [0.0, 0.0, 0.0]),
+    "above": ([-2.1, 1.7, 3.3], [0.2, -0.1, 0.0]),
+    "inside": ([0.35, 0.1, 0.22], [-1.0, 0.4, -0.1]),
+    "far": ([31.0, -17.0, 9.0], [0.0, 0.0, 0.0]),
+}
+
+
+@pytest.mark.parametrize("mesh", ["chessboard.tri", "dragon_vis.ply", "legocar.3ds"])
+@pytest.mark.parametrize("mode", [4, 5, 6, 7, 8])
+def test_rasterizer_equals_the_reference_up_to_the_plotter(oracle, oracle_scene, mesh, mode):
+    """RasterizeScene<T>::DrawTriangles + Filler<T> + ScanConverter + Screen::RasterizeTriangle of the REFERENCE, compiled here,
+    with plotters that record what they are given: for every pixel of an 800 x 600 frame the oracle must name the same winning
+    triangle, count the same number of Z-passes and hand its plotter the same interpolated fat point, bit for bit -- for all five
+    fat-point types (two lights: Gouraud lights its vertices with both)."""
+    if not RC.raster_available():
+        pytest.skip("oracle/_ref/refraster not built")
+    s = oracle_scene(mesh)
+    lp = [[3.4, 3.4, 4.8], [-2.5, 1.0, 3.0]]
+    seen_lit = seen_multi = 0
+    for name, (eye, look) in _RASTER_CAMERAS.items():
+        W, H, mv, tri, passes, fat = RC.raster_winners(s, mode, eye, look, lp)
+        cam = oracle.camera(np.array(eye, np.float32), np.array(look, np.float32))
+        assert np.array_equal(_bits(mv), _bits(list(cam.mv))), name
+        lights = (oracle.Light * 2)(*[oracle.light(np.array(p, np.float32), cam) for p in lp])
+        maps = [s.shadowmap(lights[i]) for i in range(2)] if mode in (7, 8) else None
+        _, otri, opasses, ofat = oracle.raster_winners(s, mode, cam, lights, 2, oracle.default_opts(W, H), shadow_maps=maps)
+        assert np.array_equal(tri, otri), "%s: %d pixels won by another triangle" % (name, int((tri != otri).sum()))
+        assert np.array_equal(passes, opasses), "%s: Z-pass counts differ at %d pixels" % (name, int((passes != opasses).sum()))
+        bad = (_bits(fat) != _bits(ofat)) & ~(np.isnan(fat) & np.isnan(ofat))
+        assert not bad.any(), "%s: %d fat-point words differ" % (name, int(bad.sum()))
+        seen_lit += int((tri >= 0).sum()); seen_multi += int((passes > 1).sum())
+    assert seen_lit > 50000 and seen_multi > 2000        # (pictures, with overdraw)
