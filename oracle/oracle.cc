@@ -1556,6 +1556,157 @@ uint32_t orc_chain_profile(const orc_scene *s, const orc_camera *cam, const orc_
     return max_sp;
 }
 
+/* The interactive frame loop of renderer.cc:243-642 (with Keyboard.cc:30-119 and the scanline polls of Raytracer.cc:840-864), as a
+ * function from a key script to the sequence of frames it draws: one row of 24 floats per drawn frame -- pass of the loop, mode,
+ * eye, lookat, first light, camera matrix, dAngle, autoRotate, completed.  Nothing is rendered: this is the state machine that
+ * decides WHAT is rendered.  The script's grammar is renderer_amd/csrc/host/frontend.h's ("poll N", "down / up / tap KEY"; used
+ * up = the window is closed); every drawn frame takes frame_ms of the loop's clock.  Returns the number of frames. */
+int orc_frontend_trace(const char *script, int mode, int two_lights, int brakes, int height, long frame_ms, float *out24, int max_frames)
+{
+    (void)two_lights;      /* (the second light never moves and does not enter the redraw test, renderer.cc:511-514) */
+    /* ---- the script as the list of what successive polls find: 0 nothing, +k key k down, -k key k up ---- */
+    static const char *const names[] = {"", "up", "down", "left", "right", "a", "z", "w", "q", "s", "d", "f", "e", "r", "h", "esc", "pgdn", "pgup",
+                                        "0", "1", "2", "3", "4", "5", "6", "7", "8", "9"};
+    enum { K_UP = 1, K_DOWN, K_LEFT, K_RIGHT, K_A, K_Z, K_W, K_Q, K_S, K_D, K_F, K_E, K_R, K_H, K_ESC, K_PGDN, K_PGUP, K_0, K_N = K_0 + 10 };
+    std::vector<int> ev;
+    for (const char *p = script; *p;) {
+        const char *eol = strchr(p, '\n'); if (!eol) eol = p + strlen(p);
+        std::string line(p, eol); p = *eol ? eol + 1 : eol;
+        const size_t hash = line.find('#'); if (hash != std::string::npos) line.erase(hash);
+        char verb[16] = "", arg[32] = "";
+        if (sscanf(line.c_str(), "%15s %31s", verb, arg) < 1) continue;
+        if (!strcmp(verb, "poll")) { ev.insert(ev.end(), (size_t)atol(arg), 0); continue; }
+        int key = 0;
+        for (int k = 1; k < K_N; k++) if (!strcmp(arg, names[k])) key = k;
+        if (!strcmp(arg, "escape")) key = K_ESC;
+        if (!strcmp(arg, "pagedown")) key = K_PGDN;
+        if (!strcmp(arg, "pageup")) key = K_PGUP;
+        if (!key) return -1;
+        if (strcmp(verb, "up")) ev.push_back(key);
+        if (strcmp(verb, "down")) ev.push_back(-key);
+    }
+    size_t at = 0;
+    bool is[K_N] = {false}, quit = false;
+    auto poll = [&] { if (at >= ev.size()) { quit = true; return; } const int e = ev[at++]; if (e > 0) is[e] = true; else if (e < 0) is[-e] = false; };
+    auto digit = [&] { for (int k = 0; k < 10; k++) if (is[K_0 + k]) return true; return false; };
+    auto d2r = [](double x) { return (float)(x * M_PI / 180.0); };
+    /* ---- renderer.cc:246-336 ---- */
+    const float maxi = 1.2f, LDF = 4.0f;
+    bool autoRotate = true;
+    float angle1 = 0.0f, angle2 = (float)(0.0f * M_PI / 180.f), angle3 = (float)(45.0f * M_PI / 180.f);
+    V3 light(LDF * maxi * cosf(angle3), LDF * maxi * sinf(angle3), LDF * maxi);
+    V3 eye(maxi * 4.0f, 0.0f, 0.0f);
+    V3 lookat(eye.x + 1.0f * cosf(angle2) * cosf(angle1), eye.y + 1.0f * cosf(angle2) * sinf(angle1), eye.z + 1.0f * sinf(angle2));
+    unsigned framesDrawn = 0; long msSpentDrawing = 0;
+    float dAngle = d2r(0.3f);
+    poll();
+    bool dirty = true, forceRedraw = false;
+    V3 oldEye(1e10f, 1e10f, 1e10f), oldLook(1e10f, 1e10f, 1e10f), oldLight(1e10f, 1e10f, 1e10f);
+    auto differs = [](const V3 &a, const V3 &b) { return a.x != b.x || a.y != b.y || a.z != b.z; };
+    int n = 0;
+    unsigned long long pass = 0;
+    while (!is[K_ESC] && !quit) {
+        pass++;
+        if (is[K_H]) {                                                     /* :342-351, 141-163 */
+            while (is[K_H] && !quit) poll();
+            poll();
+            while (!is[K_H] && !is[K_ESC] && !quit) poll();
+            while ((is[K_H] || is[K_ESC]) && !quit) poll();
+            msSpentDrawing = 0; framesDrawn = 0; forceRedraw = true;
+            continue;
+        }
+        if (is[K_LEFT]) angle1 -= dAngle;
+        if (is[K_RIGHT]) angle1 += dAngle;
+        if (is[K_UP]) angle2 = fmin_std(angle2 + dAngle, d2r(89.0f));
+        if (is[K_DOWN]) angle2 = fmax_std(angle2 - dAngle, d2r(-89.0f));
+        if (is[K_A] || is[K_Z]) {
+            V3 v = sub(lookat, eye);
+            v = mul(v, autoRotate ? 0.05f : 0.05f * maxi);
+            eye = is[K_A] ? add(eye, v) : sub(eye, v);
+        }
+        if (is[K_S] || is[K_F] || is[K_E] || is[K_D]) {
+            const V3 fwd = normalized(sub(lookat, eye));
+            V3 right = normalized(cross(fwd, V3(0.f, 0.f, 1.f)));
+            V3 up = normalized(cross(right, fwd));
+            if (is[K_S]) { right = mul(right, 0.05f * maxi); eye = sub(eye, right); }
+            if (is[K_F]) { right = mul(right, 0.05f * maxi); eye = add(eye, right); }
+            if (is[K_D]) { up = mul(up, 0.05f * maxi); eye = sub(eye, up); }
+            if (is[K_E]) { up = mul(up, 0.05f * maxi); eye = add(eye, up); }
+        }
+        if (is[K_R]) {
+            while (is[K_R] && !quit) poll();
+            autoRotate = !autoRotate;
+            if (!autoRotate) {
+                const V3 e = normalized(eye);
+                angle2 = asinf(-e.z);
+                angle1 = (eye.y < 0) ? acosf(e.x / cosf(angle2)) : -acosf(e.x / cosf(angle2));
+            } else { angle1 = -angle1; angle2 = -angle2; }
+        }
+        if (is[K_W] || is[K_Q]) {
+            if (is[K_W]) angle3 += 4 * dAngle; else angle3 -= 4 * dAngle;
+            light.x = LDF * maxi * cosf(angle3);
+            light.y = LDF * maxi * sinf(angle3);
+            dirty = !(mode == 7 || mode == 8);
+        }
+        bool newMode = false;
+        if (digit()) {
+            for (int k = 1; k <= 9; k++) if (is[K_0 + k]) mode = k;
+            if (is[K_0]) mode = 10;
+            while (digit() && !quit) poll();
+            newMode = true;
+        }
+        if (is[K_PGDN] || is[K_PGUP]) {
+            const bool up = is[K_PGUP];
+            while ((is[K_PGDN] || is[K_PGUP]) && !quit) poll();
+            if (!up) mode = mode == 1 ? 10 : mode - 1; else mode = mode == 10 ? 1 : mode + 1;
+            newMode = true;
+        }
+        if (newMode) {
+            if (dirty && (mode == 7 || mode == 8)) dirty = false;
+            dAngle = d2r(0.3f);
+            msSpentDrawing = 0; framesDrawn = 0; forceRedraw = true;
+            continue;
+        }
+        if (!autoRotate) {
+            lookat.x = eye.x - 1.0f * cosf(angle2) * cosf(angle1);
+            lookat.y = eye.y + 1.0f * cosf(angle2) * sinf(angle1);
+            lookat.z = eye.z + 1.0f * sinf(angle2);
+        } else {
+            angle1 -= dAngle;
+            lookat = V3(0.f, 0.f, 0.f);
+            const float distance = sqrtf(eye.x * eye.x + eye.y * eye.y + eye.z * eye.z);
+            eye.x = distance * cosf(angle2) * cosf(angle1);
+            eye.y = distance * cosf(angle2) * sinf(angle1);
+            eye.z = distance * sinf(angle2);
+        }
+        if (differs(oldLight, light) || differs(oldEye, eye) || differs(oldLook, lookat) || forceRedraw) {
+            oldLight = light; oldEye = eye; oldLook = lookat; forceRedraw = false;
+            bool completed = true, back = false;
+            if (mode >= 9 && brakes) {                                     /* Raytracer.cc:812-866 + renderer.cc:553-573 */
+                for (int y = 0; y < height && completed; y++) {
+                    poll();
+                    if (is[K_ESC] || quit) { while (is[K_ESC] && !quit) poll(); completed = false; }
+                }
+                if (completed) { while (!is[K_ESC] && !quit) poll(); while (is[K_ESC] && !quit) poll(); }
+                back = true;
+            }
+            if (n < max_frames) {
+                float *r = out24 + 24 * (size_t)n;
+                const M3 mv = lookat_basis(sub(lookat, eye));
+                r[0] = (float)pass; r[1] = (float)mode; r[2] = eye.x; r[3] = eye.y; r[4] = eye.z; r[5] = lookat.x; r[6] = lookat.y; r[7] = lookat.z;
+                r[8] = light.x; r[9] = light.y; r[10] = light.z; m3_to(mv, r + 11); r[20] = dAngle; r[21] = autoRotate ? 1.f : 0.f; r[22] = completed ? 1.f : 0.f; r[23] = 0.f;
+            }
+            n++;
+            if (back) { mode = 8; msSpentDrawing = 0; framesDrawn = 0; forceRedraw = true; continue; }
+            framesDrawn++;
+            msSpentDrawing += frame_ms;
+        }
+        poll();
+        if (msSpentDrawing) dAngle += (d2r(9.0f / (framesDrawn / (msSpentDrawing / 1000.0f))) - dAngle) / 15.0f;
+    }
+    return n;
+}
+
 void orc_wu_lines(uint32_t *pixels, int width, int height, int pitch_words, int n, const int16_t *xyxy)
 {
     WuSurf surf{pixels, pitch_words, width, height};

@@ -153,6 +153,7 @@ void orc_wu_lines(uint32_t *pixels, int width, int height, int pitch_words, int 
  * (inCameraSpace[3], normal[3], material r,g,b, ao) -> r,g,b; shadow_mode 0 none, 1 shadow maps, 2 soft */
 int orc_raster_winners(const orc_scene *, int mode, const orc_camera *, const orc_light *lights, int n_lights,
                        const float *const *shadow_maps, const orc_opts *, uint32_t *out, int32_t *win_tri, int32_t *win_passes, float *win_fat8);
+int orc_frontend_trace(const char *script, int mode, int two_lights, int brakes, int height, long frame_ms, float *out24, int max_frames);
 void orc_lighting(const orc_light *lights, int n_lights, const float *const *shadow_maps, const orc_opts *o,
                   int shadow_mode, int n, const float *pts10, float *rgb);
 

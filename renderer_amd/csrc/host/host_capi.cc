@@ -4,6 +4,7 @@
 // exceptions (the reference's THROW(), Exceptions.h:28-33) into an error return.
 #include "renderer_host.h"
 #include "load_3ds.h"
+#include "frontend.h"
 
 #include <cstring>
 #include <memory>
@@ -195,6 +196,45 @@ int mi355h_render_frame(void *h, int mode, int width, int height, const float ey
         memcpy(out, canvas._pixels.data(), (size_t)width * height * 4);
         if (stats) *stats = s._lastStats;
     });
+}
+
+
+// Test hook: the interactive loop (frontend.h) driven by a key script, nothing rendered ("dry": the state machine alone) -- or,
+// with a scene handle, rendering every frame into a canvas of width x height.  One row of 24 floats per drawn frame: pass, mode,
+// eye, lookat, first light, camera matrix, dAngle, autoRotate, completed.  Every frame takes frame_ms of the loop's clock (< 0: the
+// measured time).  Returns the number of frames drawn (rows beyond max_frames are counted, not stored), < 0 on error.
+int mi355h_frontend_trace(void *scene_handle, const char *script, int mode, int two_lights, int brakes, int width, int height, long frame_ms,
+                          float *out24, int max_frames, uint32_t *last_frame_pixels)
+{
+    int n = 0;
+    const int rc = guarded([&] {
+        Scene dry;
+        Scene &scene = scene_handle ? ((Handle *)scene_handle)->scene : dry;
+        std::unique_ptr<Screen> canvas;
+        if (scene_handle) canvas.reset(new Screen(scene, width, height));
+        const size_t lights_before = scene._lights.size();
+        {
+            FrontEnd fe(scene, canvas.get(), mode, two_lights != 0, KeyScript(script));
+            fe.brakes = brakes != 0;
+            if (frame_ms >= 0) fe.frameMS = [frame_ms] { return frame_ms; };
+            fe.onFrame = [&](const FrontEnd::Frame &f) {
+                if (n < max_frames) {
+                    float *r = out24 + 24 * (size_t)n;
+                    r[0] = (float)f.pass; r[1] = (float)f.mode;
+                    r[2] = f.eye._x; r[3] = f.eye._y; r[4] = f.eye._z; r[5] = f.lookat._x; r[6] = f.lookat._y; r[7] = f.lookat._z;
+                    r[8] = f.light._x; r[9] = f.light._y; r[10] = f.light._z;
+                    const Vector3 *rows[3] = {&f.mv._row1, &f.mv._row2, &f.mv._row3};
+                    for (int k = 0; k < 3; k++) { r[11 + 3 * k] = rows[k]->_x; r[12 + 3 * k] = rows[k]->_y; r[13 + 3 * k] = rows[k]->_z; }
+                    r[20] = f.dAngle; r[21] = f.autoRotate ? 1.f : 0.f; r[22] = f.completed ? 1.f : 0.f; r[23] = 0.f;
+                }
+                n++;
+            };
+            fe.run();
+        }
+        scene._lights.resize(lights_before);            // (the front-end's lights are gone with it)
+        if (canvas && last_frame_pixels) memcpy(last_frame_pixels, canvas->_pixels.data(), canvas->_pixels.size() * 4);
+    });
+    return rc ? rc : n;
 }
 
 } // extern "C"

@@ -10,7 +10,15 @@
 //   -g N        draw every frame on N GPUs (devices 0..N-1; -g 0,0 lists devices explicitly)
 //   -p N        keep N frames in flight (2..4, Scene::renderAsync): frame k is copied out while frame k+1 renders; the
 //               reported rate is then frames / wall time of the loop (there is no "time inside render" to add up)
+//   --keys FILE the INTERACTIVE loop instead (renderer.cc:338-615 without -b: frontend.h), its keyboard fed from a script
+//               ("poll N", "down KEY", "up KEY", "tap KEY"; keys as on the reference's help screen: arrows, a z, s d f e, r, w q,
+//               0-9, pgup pgdn, h, esc); --frame-ms T gives every frame T ms on the loop's clock (default: the measured time),
+//               --no-brakes = configure --disable-brakes (raytraced modes are not frozen)
 #include "renderer_host.h"
+#include "frontend.h"
+
+#include <fstream>
+#include <sstream>
 
 #include <algorithm>
 #include <chrono>
@@ -141,9 +149,40 @@ static double run(const char *fname, int mode, int frames, int W, int H, const s
     return fps;
 }
 
+// the interactive loop on a key script; every drawn frame is shown (ShowScreen) and, with -o, dumped
+static int runKeys(const char *fname, const char *keysFile, int mode, int W, int H, const std::vector<int> &devices, bool twoLights, long frameMS, bool brakes, const char *dump)
+{
+    std::ifstream in(keysFile);
+    if (!in) throw std::string("cannot read key script ") + keysFile;
+    std::stringstream text; text << in.rdbuf();
+    Scene scene;
+    if (devices.size() > 1) scene._devices = devices;
+    else if (!devices.empty()) scene._device = devices[0];
+    Screen canvas(scene, W, H);
+    scene.load(fname);
+    printf("Vertexes: %zu Triangles: %zu\n", scene.numVertices(), scene.numTriangles());
+    scene.UpdateBoundingVolumeHierarchy(fname);        // (the reference builds it on the first raytraced frame, Raytracer.cc:797)
+    int shown = 0;
+    {
+        FrontEnd fe(scene, &canvas, mode, twoLights, KeyScript(text.str()));
+        fe.brakes = brakes;
+        if (frameMS >= 0) fe.frameMS = [frameMS] { return frameMS; };
+        fe.onFrame = [&](const FrontEnd::Frame &f) {
+            shown++;
+            if (dump) write_ppm(dump, shown, canvas);
+            printf("frame %d: pass %llu mode %d eye %.9g %.9g %.9g%s\n", shown, (unsigned long long)f.pass, f.mode, f.eye._x, f.eye._y, f.eye._z, f.completed ? "" : " (abandoned)");
+        };
+        fe.run();
+        printf("%d frames; %llu polls; last caption: %s\n", shown, (unsigned long long)fe.keys._polls, fe.caption.c_str());
+        scene._lights.clear();
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     int mode = 8, frames = -1, W = 800, H = 600;                   // defaults: renderer.cc:177-181, Defines.h:26-27
+    const char *keysFile = nullptr; long frameMS = -1; bool brakes = true;
     std::vector<int> devices;
     bool twoLights = false, periodic = false, bench = false;
     int inFlight = 1;
@@ -169,12 +208,16 @@ int main(int argc, char **argv)
         }
         else if (!strcmp(a, "-p")) { inFlight = atoi(next()); if (inFlight < 1 || inFlight > MI355_MAX_IN_FLIGHT) usage(); }
         else if (!strcmp(a, "-o")) dump = next();
+        else if (!strcmp(a, "--keys")) keysFile = next();
+        else if (!strcmp(a, "--frame-ms")) frameMS = atol(next());
+        else if (!strcmp(a, "--no-brakes")) brakes = false;
         else if (a[0] == '-') usage();
         else fname = a;
     }
     if (!fname || mode < 1 || mode > 10) usage();
     if (frames < 0) frames = bench ? 500 : 100;
     try {
+        if (keysFile) return runKeys(fname, keysFile, mode, W, H, devices, twoLights, frameMS, brakes, dump);
         if (!bench) { run(fname, mode, frames, W, H, devices, twoLights, periodic, dump, inFlight); return 0; }
         // src/Makefile.am:25-26: five runs, then the statistics of their frame rates
         std::vector<double> fps;
