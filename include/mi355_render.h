@@ -176,6 +176,11 @@ int mi355_build_bvh(mi355_ctx *, void *nodes32B, int32_t *tri_idx, uint32_t *n_n
 /* Light::RenderSceneIntoShadowBuffer (Light.h:61, Light.cc:218-244) for light slot `slot`;
  * out_map (optional) receives the size*size floats of Light::_shadowBuffer. */
 int mi355_shadowmap_render(mi355_ctx *, int slot, const mi355_light *light, int size, float *out_map);
+/* The same map for a light that MOVES between frames (renderer.cc:410-431), without stopping the frames: redrawn asynchronously in
+ * the order of the calls on hip_stream (frames enqueued before see the old map, frames enqueued after the new one); the light's
+ * world-to-light basis is computed from `pos` and returned in *light_out (pos, world_to_light; may be NULL).  Nothing is
+ * synchronised unless the slot has no map of that size yet. */
+int mi355_light_update(mi355_ctx *, int slot, const float pos[3], int size, mi355_light *light_out, void *hip_stream);
 /* Upload an externally computed Light::_shadowBuffer instead. */
 int mi355_shadowmap_set(mi355_ctx *, int slot, const float *map, int size);
 

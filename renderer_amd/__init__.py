@@ -383,6 +383,15 @@ class Scene:
                                             out.ctypes.data if fetch else None), "mi355_shadowmap_render")
         return out
 
+    def light_update(self, slot: int, pos, size: int = 1024, stream: int = 0) -> "Light":
+        """mi355_light_update: the slot's shadow map redrawn for a light at `pos`, asynchronously on `stream`; returns the light
+        with pos and world_to_light filled in (camera-space members: light() per frame)."""
+        l = Light()
+        f = lib().mi355_light_update
+        f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(Light), C.c_void_p]
+        _check(f(self.context(), slot, (C.c_float * 3)(*[float(x) for x in pos]), size, C.byref(l), C.c_void_p(stream)), "mi355_light_update")
+        return l
+
     def shadowmap_set(self, slot: int, m: np.ndarray):
         m = np.ascontiguousarray(m, np.float32)
         _check(lib().mi355_shadowmap_set(self.context(), slot, m.ctypes.data, m.shape[0]), "mi355_shadowmap_set")

@@ -184,6 +184,11 @@ struct mi355_ctx {
     bool boxes_tame = false; // every BVH box coordinate is 0 or within [1e-30, 1e17] in magnitude
     DevBuf smap[MI355_MAX_LIGHTS];
     int smap_size[MI355_MAX_LIGHTS] = {0, 0, 0, 0};
+    // mi355_light_update: a map redrawn in stream order.  ev_light = the redraw's last kernel; frames enqueued later wait for it
+    // on whatever stream they run, the redraw waits for the frames enqueued before it (ev_tile of every set in use).
+    hipEvent_t ev_light = nullptr;
+    bool ev_light_set = false;
+    RasterScratch *rs_light = nullptr;   // the redraw's own row buffer (frames in flight use the other sets)
     RasterScratch *rscratch = nullptr;
     WireScratch *wscratch = nullptr;     // mode 3 (created with its first frame)
     // pipelined frames (mi355_render_async / _wait): each slot is a stream with its own control block (counters, pixel
@@ -742,6 +747,7 @@ static int lease_begin(mi355_ctx *c, const mi355_ctx::PipeChoice *pc, size_t fb_
     if (c->ev_tile_set[L.k] && (c->ev_tile_ext[L.k] || c->pipe_st[L.k] != L.ps)) HIP_TRY(hipStreamWaitEvent(L.ps, c->ev_tile[L.k], 0), -40);
     c->pipe_st[L.k] = L.ps;
     if (c->ev_copy_set[L.b]) HIP_TRY(hipStreamWaitEvent(L.ps, c->ev_copy[L.b], 0), -40);
+    if (c->ev_light_set) HIP_TRY(hipStreamWaitEvent(L.ps, c->ev_light, 0), -40);        // (a shadow map redrawn by mi355_light_update)
     return 0;
 }
 
@@ -818,6 +824,8 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
     case MI355_MODE_POINTS_FROM_TRIANGLES: e = mi355i_launch_points(&c->dev, &P, 1, st); break;
     case MI355_MODE_AMBIENT: case MI355_MODE_GOURAUD: case MI355_MODE_PHONG:
     case MI355_MODE_PHONG_SHADOWMAPS: case MI355_MODE_PHONG_SOFTSHADOWMAPS: {
+        // (a shadow map being redrawn by mi355_light_update: the frame follows the redraw whatever stream it is on)
+        if (c->ev_light_set && (mode == MI355_MODE_PHONG_SHADOWMAPS || mode == MI355_MODE_PHONG_SOFTSHADOWMAPS)) HIP_TRY(hipStreamWaitEvent(st, c->ev_light, 0), -40);
         const mi355_ctx::PipeChoice *pc = nullptr;
         if (raster_self_clear && rs == c->rscratch && c->pre && !P.no_pipe && c->cand_st[0] && P.out_rows > 0) pc = pipe_streams_for(c, st);
         if (pc && pc->n >= 2) {
@@ -1073,6 +1081,8 @@ void mi355_scene_destroy(mi355_ctx *c)
         if (a.st && a.st_owned) (void)hipStreamDestroy(a.st);
     }
     for (auto &h : c->host_reg) if (h.p) (void)hipHostUnregister(h.p);
+    if (c->rs_light) mi355i_raster_scratch_destroy(c->rs_light);
+    if (c->ev_light) (void)hipEventDestroy(c->ev_light);
     if (c->rscratch) mi355i_raster_scratch_destroy(c->rscratch);
     if (c->wscratch) mi355i_wire_scratch_destroy(c->wscratch);
     for (int k = 1; k < mi355_ctx::PIPE_SETS; k++) if (c->rs_pipe[k]) mi355i_raster_scratch_destroy(c->rs_pipe[k]);
@@ -1259,6 +1269,55 @@ int mi355_shadowmap_render(mi355_ctx *c, int slot, const mi355_light *light, int
     return 0;
 }
 
+// Light::RenderSceneIntoShadowBuffer for a light that MOVES while frames are being drawn (renderer.cc:410-431: the W / Q keys):
+// the map of `slot` is redrawn for a light at `pos`, asynchronously and in the order of the calls on hip_stream -- frames enqueued
+// before see the old map, frames enqueued after see the new one -- without synchronising anything.  The light's world-to-light
+// basis (Light.cc:173-192: forward = towards the origin, right = forward x zenith, up = right x forward) is computed here from
+// the position and returned in *light_out (pos and world_to_light filled in; the camera-space members are the caller's, per
+// frame).  A row buffer that turns out too small is reported by the next mi355_fetch_stats (-44; it has grown by then).
+int mi355_light_update(mi355_ctx *c, int slot, const float pos[3], int size, mi355_light *light_out, void *hip_stream)
+{
+    if (!c || !pos) return fail(-3, "mi355_light_update: null argument");
+    if (slot < 0 || slot >= MI355_MAX_LIGHTS || size <= 0 || size > 16384) return fail(-3, "bad light slot %d / size %d", slot, size);
+    if (int r = select_device(c)) return r;
+    hipStream_t st = (hipStream_t)hip_stream;
+    mi355_light l;
+    memset(&l, 0, sizeof l);
+    {
+        // (the float operations of Light.cc:173-192 / Camera.cc:24-42, in their order)
+        V3h f = {-pos[0], -pos[1], -pos[2]};
+        const float fl = lenh(f);
+        f = {f.x / fl, f.y / fl, f.z / fl};
+        V3h right = crossh(f, V3h{0.f, 0.f, 1.f});
+        const float rl = lenh(right);
+        right = {right.x / rl, right.y / rl, right.z / rl};
+        V3h up = crossh(right, f);
+        const float ul = lenh(up);
+        up = {up.x / ul, up.y / ul, up.z / ul};
+        const float m[9] = {up.x, up.y, up.z, right.x, right.y, right.z, f.x, f.y, f.z};
+        memcpy(l.pos, pos, 12);
+        memcpy(l.world_to_light, m, 36);
+    }
+    if (light_out) { memcpy(light_out->pos, l.pos, 12); memcpy(light_out->world_to_light, l.world_to_light, 36); }
+    if (c->smap_size[slot] != size || !c->smap[slot].p) {
+        // a first map, or another size: nothing in flight may read the buffer that is replaced
+        HIP_TRY(hipDeviceSynchronize(), -40);
+        HIP_TRY(c->smap[slot].ensure((size_t)size * size * 4), -31);
+    }
+    if (!c->ev_light) HIP_TRY(hipEventCreateWithFlags(&c->ev_light, hipEventDisableTiming), -11);
+    if (!c->rs_light) c->rs_light = mi355i_raster_scratch_create();
+    if (!c->rs_light) return fail(-11, "out of memory");
+    // behind every frame enqueued so far, wherever it runs (the frames' own streams carry ev_tile; the caller's stream orders itself)
+    for (int k = 0; k < mi355_ctx::PIPE_SETS; k++) if (c->ev_tile_set[k]) HIP_TRY(hipStreamWaitEvent(st, c->ev_tile[k], 0), -40);
+    for (auto &a : c->slot) if (a.busy && a.ev1) HIP_TRY(hipStreamWaitEvent(st, a.ev1, 0), -40);      // (frames of mi355_render_async still in flight)
+    const hipError_t e = mi355i_launch_shadowmap(&c->dev, l.pos, l.world_to_light, size, (float *)c->smap[slot].p, c->rs_light, st);
+    if (e != hipSuccess) return fail(-43, "shadow map launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipEventRecord(c->ev_light, st), -40);
+    c->ev_light_set = true;
+    c->smap_size[slot] = size;
+    return 0;
+}
+
 int mi355_render_device(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_light *lights, int n_lights,
                         const mi355_opts *o, void *d_out, int pitch_bytes, void *d_outf, void *hip_stream)
 {
@@ -1394,6 +1453,14 @@ int mi355_fetch_stats(mi355_ctx *c, mi355_stats *s)
     // (the rasterizer reports a bin overflow in the context's own block, whichever block the last call counted in)
     if (c->last_ctrl && c->last_ctrl != c->ctrl.p)
         HIP_TRY(hipMemcpy(&h[CS_OVERFLOW], (char *)c->ctrl.p + 16 + sizeof(unsigned long long) * CS_OVERFLOW, sizeof(unsigned long long), hipMemcpyDeviceToHost), -31);
+    if (c->rs_light && c->ev_light_set) {
+        // (a map redrawn by mi355_light_update whose rows did not fit: the buffer doubles, the caller redraws the map)
+        const uint32_t dropped = mi355i_raster_overflow(c->rs_light);
+        if (dropped) {
+            const int grown = mi355i_raster_grow(c->rs_light);
+            return fail(-44, "mi355_light_update: the shadow map's row buffer overflowed (%u rows dropped)%s", dropped, grown ? "; it has grown: update the light again" : "");
+        }
+    }
     memset(s, 0, sizeof *s);
     s->normal_rays = h[CS_NORMAL_RAYS]; s->shadow_rays = h[CS_SHADOW_RAYS];
     s->node_pops = h[CS_NODE_POPS]; s->inner_box_hits = h[CS_INNER_HITS]; s->tri_tests = h[CS_TRI_TESTS];

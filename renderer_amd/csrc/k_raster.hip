@@ -9,6 +9,7 @@
 // order-preserving float key.
 #include "rs_core.h"
 #include <hip/hip_ext.h>
+#include <cstdlib>
 #include <cstring>
 
 struct RowRec {            // shadow map: one span row (40 B)
@@ -595,6 +596,158 @@ __global__ void __launch_bounds__(256) k_sm_spans(const ShadowParams Q, const Ro
     }
 }
 
+// ---- round 3: the same map from (triangle, row) items instead of one lane per triangle --------------------------------
+// k_sm_setup and k_sm_spans give a lane a whole triangle (all its rows, one after the other) and a whole row (all its pixels):
+// a mesh's few large triangles and long rows keep single lanes busy for hundreds of dependent steps while the GPU idles
+// (0.25 + 0.21 ms per light).  Here every row of every triangle is an item of its own: k_sm_count reserves the rows of a block's
+// triangles in one allocation and names each row's owner; k_sm_rows recomputes the owner's projected corners, brings the three
+// edge walkers to the item's row with ff_add -- the exact result of the reference's repeated `vtc += d12` (ScanConverter.h:
+// 112-116) without taking the steps -- and walks the row's span; spans of more than SM_LONG pixels are cut into 64 pieces by
+// the whole wave, each piece starting from ff_add of the span's first pixel.  Same plots, same values, same maximum.
+#define SM_LONG 48
+
+// the projected corners of triangle t (Light.cc:100-128): false = rejected (all above / below the map)
+MI_DEV bool sm_project(const DevScene &S, const ShadowParams &Q, uint32_t t, float (&f)[3][3], int (&iy)[3])
+{
+    const uint4 id = S.rs_idx[t];
+    const uint32_t vid[3] = {id.x, id.y, id.z};
+    const f3 light = mk3(Q.light[0], Q.light[1], Q.light[2]);
+    const int SM = Q.size;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float4 pv = S.rs_vert[(size_t)vid[k] * 2];
+        f3 x = mulright(Q.mv, sub3(mk3(pv.x, pv.y, pv.z), light));
+        x.x = (float)(SM / 2) + (float)(SM * 2) * x.x / x.z;
+        x.y = (float)(SM / 2) + (float)(SM * 2) * x.y / x.z;
+        x.z = 1.0f / x.z;
+        f[k][0] = x.x; f[k][1] = x.y; f[k][2] = x.z;
+    }
+    if (f[0][1] < 0.f && f[1][1] < 0.f && f[2][1] < 0.f) return false;
+    const float fS = (float)SM;
+    if (f[0][1] >= fS && f[1][1] >= fS && f[2][1] >= fS) return false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) iy[k] = cvtt_i32(f[k][1]);
+    return true;
+}
+
+// rows[i] = (triangle, row of the map) for every row a triangle touches; ctl[0] = rows used, ctl[1] = rows that did not fit
+__global__ void __launch_bounds__(256) k_sm_count(const DevScene S, const ShadowParams Q, uint2 *items, uint32_t items_cap, uint32_t *ctl)
+{
+    __shared__ BlockPairs bp;
+    __shared__ uint32_t s_base;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    int miny = 0, nrows = 0;
+    if (t < S.n_tris) {
+        float f[3][3]; int iy[3], maxy;
+        if (sm_project(S, Q, t, f, iy) && rs_tri_rows(iy, Q.size, miny, maxy)) nrows = maxy - miny + 1;
+    }
+    // (BlockPairs wants a box per thread: x = the triangle, y = its first row)
+    const uint32_t total = block_pairs_begin(bp, make_uint4(t, (uint32_t)miny, 0u, 0u), nrows);
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(&ctl[0], total) : 0u;
+    __syncthreads();
+    const uint32_t base = s_base;
+    for (uint32_t p0 = 0; p0 < total; p0 += 256u) {
+        const uint32_t p = p0 + threadIdx.x;
+        if (p >= total) break;
+        int owner = 0, k = 0;
+        block_pair(bp, p, owner, k);
+        if (base + p < items_cap) items[base + p] = make_uint2(bp.box[owner].x, bp.box[owner].y + (uint32_t)k);
+        else atomicAdd(&ctl[1], 1u);
+    }
+}
+
+// value of an edge walker (rs_edge_init) at row y: (y - y0) additions of d, taken at once
+MI_DEV void sm_edge_at(const RsEdge<3> &E, int y, float (&v)[3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++) v[i] = ff_add(E.v[i], E.d[i], y - E.y0);
+}
+
+__global__ void __launch_bounds__(256) k_sm_rows(const DevScene S, const ShadowParams Q, const uint2 *items, const uint32_t *ctl, uint32_t items_cap,
+                                                 uint32_t *smkeys)
+{
+    uint32_t n_items = ctl[0];
+    if (n_items > items_cap) n_items = items_cap;
+    const int SM = Q.size;
+    const int lane = (int)(threadIdx.x & 63u);
+    // (whole waves stay together: the long spans below are walked by all 64 lanes)
+    const uint32_t n_round = (n_items + 63u) & ~63u;
+    for (uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x; ri < n_round; ri += gridDim.x * blockDim.x) {
+        bool have = ri < n_items;
+        float l[3] = {0.f, 0.f, 0.f}, r[3] = {0.f, 0.f, 0.f};
+        uint32_t cnt = 0;
+        int y = 0;
+        if (have) {
+            const uint2 it = items[ri];
+            y = (int)it.y;
+            float f[3][3]; int iy[3];
+            have = sm_project(S, Q, it.x, f, iy);
+            if (have) {
+                RsEdge<3> e0, e1, e2;           // Light.cc:270-272: v1v2, v2v3, v1v3
+                rs_edge_init<3>(e0, iy[0], f[0], iy[1], f[1], SM);
+                rs_edge_init<3>(e1, iy[1], f[1], iy[2], f[2], SM);
+                rs_edge_init<3>(e2, iy[0], f[0], iy[2], f[2], SM);
+                const RsEdge<3> *es[3] = {&e0, &e1, &e2};
+                const float (*ea[3])[3] = {&f[0], &f[1], &f[0]}, (*eb[3])[3] = {&f[1], &f[2], &f[2]};
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const RsEdge<3> &E = *es[k];
+                    if (y < E.y0 || y > E.y1) continue;
+                    if (E.horiz) { scan_add<3>(l, r, cnt, *ea[k]); scan_add<3>(l, r, cnt, *eb[k]); continue; }
+                    float v[3];
+                    sm_edge_at(E, y, v);
+                    scan_add<3>(l, r, cnt, v);
+                }
+            }
+        }
+        uint32_t *row = smkeys + (size_t)y * SM;
+        auto plot_at = [&](uint32_t *rw, float x, float z) {               // PlotShadowPixel, Light.cc:253-259
+            const int idx = cvtt_i32(x);
+            if (idx >= 0 && idx < SM && z == z) atomicMax(&rw[idx], f2key(z));
+        };
+        float sx = l[0], sz = l[2], dx = 0.f, dz = 0.f;
+        int steps = -1;                                                    // pixels after the first one; -1: nothing to walk
+        if (have && cnt == 1) plot_at(row, l[0], l[2]);
+        else if (have) {                                                   // (cnt 2: a span; 0 cannot happen between a triangle's first and last row)
+            const int x1 = cvtt_i32(l[0]), x2 = cvtt_i32(r[0]);
+            const long long st = llabs((long long)x2 - (long long)x1);
+            if (!st) { plot_at(row, l[0], l[2]); plot_at(row, r[0], r[2]); }
+            else if (st <= (1ll << 24)) {                                  // (beyond: a degenerate projection, geometry at the light's plane)
+                steps = (int)st;
+                const float fsteps = (float)steps;
+                dx = (r[0] - sx) / fsteps; dz = (r[2] - sz) / fsteps;
+            }
+        }
+        // short spans: this lane walks its own; long ones: the wave takes them one after the other
+        const bool is_long = steps > SM_LONG && steps < (1 << 22);         // (ff_add's jump arithmetic is exact for chains below 2^22)
+        if (steps >= 0 && !is_long) {
+            plot_at(row, sx, sz);
+            for (int k = steps; k > 0; k--) { sx += dx; sz += dz; plot_at(row, sx, sz); }
+        }
+        unsigned long long todo = __ballot(is_long);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const float bx = __shfl(sx, src), bz = __shfl(sz, src), bdx = __shfl(dx, src), bdz = __shfl(dz, src);
+            const int bsteps = __shfl(steps, src), by = __shfl(y, src);
+            uint32_t *brow = smkeys + (size_t)by * SM;
+            // pixels 0 .. bsteps of the span (pixel j = j additions from the first), lane i takes [i * per, (i + 1) * per)
+            const int n_px = bsteps + 1, per = (n_px + 63) >> 6, j0 = lane * per;
+            if (j0 < n_px) {
+                float px = ff_add(bx, bdx, j0), pz = ff_add(bz, bdz, j0);
+                const int j1 = j0 + per < n_px ? j0 + per : n_px;
+                plot_at(brow, px, pz);
+                for (int j = j0 + 1; j < j1; j++) { px += bdx; pz += bdz; plot_at(brow, px, pz); }
+            }
+        }
+    }
+}
+
+// (Tried and measured, then removed -- profiles/r03_analysis.md: the same items sorted into bands of four map rows, a workgroup
+//  per band with the band's keys in LDS, no clear / resolve pass and no global atomic: 349 - 564 us per map against 84 - 333 us for
+//  the kernels above.  The items of a mesh sit in the few bands its silhouette covers; 2048 blocks over all items beat 256 unequal
+//  bands.)
+
 __global__ void __launch_bounds__(256) k_sm_resolve(const uint32_t *smkeys, float *map, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -916,11 +1069,20 @@ extern "C" hipError_t mi355i_launch_shadowmap(const DevScene *S, const float *li
     memcpy(Q.mv, w2l, 36);
     Q.size = size;
     if ((e = hipMemsetAsync(s->ctl, 0, 64, st)) != hipSuccess) return e;
+    static const bool legacy = [] { const char *v = getenv("MI355_SM_LEGACY"); return v && *v && strcmp(v, "0"); }();     // the round-1 kernels, for comparison
     // Light::ClearShadowBuffer: bytes 0xFE (Light.h:48-52) -> key of the float 0xFEFEFEFE
     hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, st, s->smkeys, ~0xFEFEFEFEu, n);
-    const int nbT = (int)((S->n_tris + 127) / 128);
-    hipLaunchKernelGGL(k_sm_setup, dim3(nbT > 0 ? nbT : 1), dim3(128), 0, st, *S, Q, s->rows, s->rows_cap, s->ctl);
-    hipLaunchKernelGGL(k_sm_spans, dim3(2048), dim3(256), 0, st, Q, s->rows, s->ctl, s->rows_cap, s->smkeys);
+    if (legacy) {     // the round-1 kernels: a lane per triangle, then a lane per row (kept for comparison)
+        const int nbT = (int)((S->n_tris + 127) / 128);
+        hipLaunchKernelGGL(k_sm_setup, dim3(nbT > 0 ? nbT : 1), dim3(128), 0, st, *S, Q, s->rows, s->rows_cap, s->ctl);
+        hipLaunchKernelGGL(k_sm_spans, dim3(2048), dim3(256), 0, st, Q, s->rows, s->ctl, s->rows_cap, s->smkeys);
+    } else {
+        // (the row buffer is the same allocation: 8-byte items in place of 40-byte records, five times as many fit)
+        const uint32_t items_cap = (uint32_t)(((size_t)s->rows_cap * sizeof(RowRec)) / sizeof(uint2) > 0xfffffff0ull ? 0xfffffff0ull : ((size_t)s->rows_cap * sizeof(RowRec)) / sizeof(uint2));
+        const int nbT = (int)((S->n_tris + 255) / 256);
+        hipLaunchKernelGGL(k_sm_count, dim3(nbT > 0 ? nbT : 1), dim3(256), 0, st, *S, Q, (uint2 *)s->rows, items_cap, s->ctl);
+        hipLaunchKernelGGL(k_sm_rows, dim3(2048), dim3(256), 0, st, *S, Q, (const uint2 *)s->rows, s->ctl, items_cap, s->smkeys);
+    }
     hipLaunchKernelGGL(k_sm_resolve, dim3(1024), dim3(256), 0, st, s->smkeys, d_map, n);
     return hipGetLastError();
 }

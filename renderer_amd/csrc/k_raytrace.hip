@@ -1027,10 +1027,10 @@ k_raytrace(const DevScene S, const FrameParams P)
                             hL = leafL || ray_box_exact(L.o, L.d, loL, hiL);
                             hR = leafR || ray_box_exact(L.o, L.d, loR, hiR);
                         } else {
-                            if (leafL) hL = !(nL > fL) && !(fL < 0.f);
-                            if (leafR) hR = !(nR > fR) && !(fR < 0.f);
-                            hL = hL && !(nL > L.limit);
-                            hR = hR && !(nR > L.limit);
+                            // (lane masks combined with & and |: a ?: on bools makes the compiler move them through registers)
+                            const bool gL = !(nL > fL) & !(fL < 0.f), gR = !(nR > fR) & !(fR < 0.f);
+                            hL = ((leafL & gL) | (!leafL & hL)) & !(nL > L.limit);
+                            hR = ((leafR & gR) | (!leafR & hR)) & !(nR > L.limit);
                         }
                     }
                     hR = hR && linkR != MI_END_LINK;                // the virtual record above the root has one child

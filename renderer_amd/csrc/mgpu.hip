@@ -102,7 +102,8 @@ static void drain(mi355_mgpu *m)
         if (m->cs[r]) (void)hipStreamSynchronize(m->cs[r]);
     }
     if (m->n) (void)hipSetDevice(m->dev[0]);
-    for (int b = 0; b < MGPU_SETS; b++) { m->busy[b] = false; m->sent_set[b] = m->asm_set[b] = false; }
+    // (steps in flight have finished by now but stay waited-for: their tickets remain valid)
+    for (int b = 0; b < MGPU_SETS; b++) m->sent_set[b] = m->asm_set[b] = false;
 }
 
 static int geometry(mi355_mgpu *m, int W, int H, int frames)

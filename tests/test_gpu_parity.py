@@ -480,3 +480,35 @@ def test_errors_are_reported_not_swallowed(gpu_scene):
         hs.render(3, cam, lights, n, R.default_opts(4096, 16))         # beyond the sort key's fields
     with pytest.raises(R.Mi355Error):
         hs.render(6, cam, lights, n, R.default_opts(0, 48))
+
+
+def test_light_rotation_redraws_the_map_in_stream_order(oracle, oracle_scene, gpu_scene):
+    """mi355_light_update (the W / Q keys of renderer.cc:410-431 without stopping the frames): six light positions, each followed
+    at once by soft-shadowed frames on the same stream -- no synchronisation in between; every frame must be the frame the
+    oracle draws with the map of ITS light (the redraw is ordered between the frames that come before and after it)."""
+    torch = pytest.importorskip("torch")
+    mesh, W, H = "chessboard.tri", 640, 360
+    hs, osc = gpu_scene(mesh), oracle_scene(mesh)
+    stream = torch.cuda.current_stream()
+    n_pos, per = 6, 3
+    bufs = [torch.zeros((H, W), dtype=torch.int32, device="cuda:0") for _ in range(n_pos * per)]
+    o = R.default_opts(W, H)
+    want = []
+    for i in range(n_pos):
+        a = np.float32(np.pi / 4 + 0.4 * i)
+        pos = [np.float32(4.8) * np.cos(a), np.float32(4.8) * np.sin(a), np.float32(4.8)]
+        gl = hs.light_update(0, pos, 1024, stream.cuda_stream)
+        for j in range(per):
+            cam, _, _ = R.benchmark_frame(7 * i + j)
+            l = R.light(pos, cam)
+            assert np.array_equal(np.array(list(gl.world_to_light), np.float32).view(np.uint32), np.array(list(l.world_to_light), np.float32).view(np.uint32))
+            lights = (R.Light * 2)(l)
+            hs.render_device(8, cam, lights, 1, o, bufs[i * per + j].data_ptr(), W * 4, 0, stream.cuda_stream)
+            ocam, _, _ = oracle.benchmark_frame(7 * i + j)
+            want.append((ocam, pos))
+    torch.cuda.synchronize()
+    hs.fetch_stats()                                   # (reports a row buffer that was too small)
+    for k, (ocam, pos) in enumerate(want):
+        ol = oracle.light(np.array(pos, np.float32), ocam)
+        ref = osc.render(8, ocam, (oracle.Light * 2)(ol), 1, oracle.default_opts(W, H), shadow_maps=[osc.shadowmap(ol)])[0]
+        assert np.array_equal(bufs[k].cpu().numpy().view(np.uint32), ref), k
