@@ -901,7 +901,11 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
             P.tile_cnt = (const uint32_t *)buf->p;
             P.tile_sel = (const uint32_t *)((char *)buf->p + 512);
             if ((e = mi355i_launch_tile_select(&P, (const float4 *)c->cull_boxes.p, c->n_cull_boxes, P.tile_order, (uint32_t *)((char *)buf->p + 512),
-                                               (uint32_t *)buf->p, st)) != hipSuccess) return fail(-43, "tile culling launch failed: %s", hipGetErrorString(e));
+                                               (uint32_t *)buf->p, st)) != hipSuccess) {
+                // (the selection could not be launched: the frame is traced without it -- every tile handed out, same pixels)
+                (void)hipGetLastError();
+                P.tile_cnt = nullptr; P.tile_sel = nullptr;
+            }
         }
         e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, waves, batch, ext, quad, stack_rows, n_blocks, st);
         break;

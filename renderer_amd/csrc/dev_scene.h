@@ -39,7 +39,7 @@
 #define MI_MAX_LIGHTS 4
 #define MI_MAX_DEPTH 4
 #define MI_CULL_BOXES 128           // boxes of the tree's top the tiles of a frame are culled against
-#define MI_CULL_MAX_TILES (1 << 19) // frames with more 8x8 tiles are not culled (the tile mask lives in LDS)
+#define MI_CULL_MAX_TILES (1 << 18) // frames with more 8x8 tiles are not culled (the tile mask lives in LDS: 32 KB here, beside 2 KB of static LDS -- inside the 64 KB a block gets without asking)
 
 // Walk records, two float4 each (a link is the float4 index of a record plus the flag bits above, or
 // MI_END_LINK):
