@@ -544,7 +544,8 @@ template <bool shadow>
 static uint32_t ordered_walk_cost(const orc_scene &s, float nudge, const V3 &origin, const V3 &ray, int avoidSelf, const V3 &lightPos, bool doCulling,
                                   int quad_kind = 0, uint32_t *max_sp = nullptr)
 {
-    const bool quad = quad_kind != 0;
+    /* kinds 4 / 5 (two-wide walk): a step tests two triangles of a leaf / the whole leaf (what a leaf-contiguous layout would cost) */
+    const bool quad = quad_kind != 0 && quad_kind < 4;
     uint32_t inner = 0, tris = 0;
     const double o[3] = {origin.x, origin.y, origin.z}, d[3] = {ray.x, ray.y, ray.z};
     double best = shadow ? sqrt((double)distancesq(origin, lightPos)) : 1e300;
@@ -608,7 +609,9 @@ static uint32_t ordered_walk_cost(const orc_scene &s, float nudge, const V3 &ori
         } else {
             const unsigned start = n.b, cnt = n.a & 0x7fffffffu;
             for (unsigned i = start; i < start + cnt; i++) {
-                tris++;
+                if (quad_kind == 4) tris += ((i - start) & 1u) ? 0u : 1u;
+                else if (quad_kind == 5) tris += i == start ? 1u : 0u;
+                else tris++;
                 const int ti = s.triIdx[i];
                 const Tri &t = s.tris[ti];
                 if (avoidSelf == ti) continue;

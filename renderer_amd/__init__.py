@@ -22,7 +22,8 @@ from . import assets  # noqa: F401
 _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_PKG)
 LIB_DIR = os.path.join(_PKG, "lib")
-RENDER_SO = os.path.join(LIB_DIR, "libmi355render.so")
+# (MI355_RENDER_SO: another build of the same library -- measurement scripts compare kernel variants that way)
+RENDER_SO = os.environ.get("MI355_RENDER_SO") or os.path.join(LIB_DIR, "libmi355render.so")
 HOST_SO = os.path.join(LIB_DIR, "libmi355host.so")
 RENDER_CLI = os.path.join(LIB_DIR, "render_cli")
 HEADER = os.path.join(ROOT, "include", "mi355_render.h")

@@ -1066,6 +1066,9 @@ void mi355_scene_destroy(mi355_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    // (nothing of this context may be in flight on any stream -- its own, the internal frame streams, a caller's -- while its
+    //  buffers go away)
+    (void)hipDeviceSynchronize();
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->walk, &c->tri_edge, &c->tri_shade, &c->rs_tri, &c->rs_col, &c->rs_idx,
                       &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->mlaa, &c->cam_table, &c->wave_prof, &c->bvh_prim, &c->bvh_list[0], &c->bvh_list[1],

@@ -57,15 +57,13 @@ struct Lane {
     int avoid;             // leaf-order index of the triangle to skip (avoidSelf), -1 = none
     float best;            // bestTriDist
     float limit;           // ordered walk: a box whose entry lies beyond this cannot change the result
-    float delta;           // ordered walk: slack for a hit point lying just outside its triangle's box
-    float dmax;            // ordered walk: delta * max |inv| -- how far (in ray parameter) growing a box by delta can move its faces
+    float dmax;            // ordered walk: ray_delta * max |inv| -- how far (in ray parameter) growing a box by the slack can move its faces
     int sp;                // ordered walk: postponed children of this lane (the newest in `top`, the rest in LDS rows base .. sp - 2)
     uint32_t top;
     int base;              // work sharing: rows below this one were handed to other lanes (0 otherwise)
     int owner;             // work sharing: thread of the block whose shadow ray this lane walks a part of (its own id otherwise)
     int btri;              // closest triangle so far (leaf order), -1 = none
-    f3 hit;
-    float k1, k2, k3;      // kAB, kBC, kCA
+    f3 hit;                // its hit point -- made by shade_begin from btri (the walk carries the triangle and the distance only)
     bool shadow_hit;
     // triangle that passed the plane test at the previous step; its edge record is in flight
     bool pend;
@@ -77,7 +75,6 @@ struct Lane {
     f3 refl;               // reflected direction
     f3 lp;                 // current light position
     int li;                // light being processed
-    float cr, cg, cb;      // colour being accumulated for this depth
     // EXT builds only (refractions, ray-cast ambient occlusion); constants in the others
     uint32_t nocull;       // MI_TWOSIDED_BIT while the ray is traced without backface culling (Raytrace<false>), else 0
     uint32_t path;         // node of the ray tree the current ray leads to: root 1, reflection child 2p, refraction child 2p + 1
@@ -198,16 +195,21 @@ MI_DEV bool ray_box_fast_ordered(const f3 o, const f3 inv, const float dmax, con
     return pass;
 }
 
+// ordered walk: the slack for a hit point lying just outside its triangle's box -- 1e-4 of the largest coordinate in play
+// (rounding moves a computed hit point by ~1e-6 of it).  A function of the ray's origin: recomputed where it is needed
+// (a closer hit, a new shadow ray) instead of held in a register through the walk.
+MI_DEV float ray_delta(const f3 o, float scene_mag)
+{
+    return 1e-4f * __builtin_fmaxf(__builtin_fmaxf(scene_mag, __builtin_fabsf(o.x)), __builtin_fmaxf(__builtin_fabsf(o.y), __builtin_fabsf(o.z)));
+}
+
 // per-ray constants of the filtered box test
 MI_DEV void set_ray_aux(Lane &L, float scene_mag)
 {
     L.inv = mk3(__builtin_amdgcn_rcpf(L.d.x), __builtin_amdgcn_rcpf(L.d.y), __builtin_amdgcn_rcpf(L.d.z));
     L.tame = ray_is_tame(L.o, L.d);
     L.pend = false;
-    // ordered walk: 1e-4 of the largest coordinate in play -- rounding moves a computed hit point by ~1e-6 of it
-    const float m = __builtin_fmaxf(__builtin_fmaxf(scene_mag, __builtin_fabsf(L.o.x)), __builtin_fmaxf(__builtin_fabsf(L.o.y), __builtin_fabsf(L.o.z)));
-    L.delta = 1e-4f * m;
-    L.dmax = L.delta * __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(L.inv.x), __builtin_fabsf(L.inv.y)), __builtin_fabsf(L.inv.z));
+    L.dmax = ray_delta(L.o, scene_mag) * __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(L.inv.x), __builtin_fabsf(L.inv.y)), __builtin_fabsf(L.inv.z));
 }
 
 // Camera, lights and output of the frame a lane works on: kernel arguments for a single frame, a small table in
@@ -278,7 +280,7 @@ MI_DEV f3 fold_levels(const float *lds, int depth, float rate)
 
 // Light i's diffuse + specular contribution at the current hit (Raytracer.cc:468-505)
 template <bool BATCH>
-MI_DEV void add_light(const FrameParams &P, const DevScene &S, Lane &L)
+MI_DEV void add_light(const FrameParams &P, const DevScene &S, Lane &L, float *lds_col)
 {
     // (L.lp may hold another lane's light by now: a lane whose shadow ray has ended walks parts of other lanes' shadow rays)
     L.lp = cam_light<BATCH>(P, L.fid, L.li);
@@ -297,13 +299,16 @@ MI_DEV void add_light(const FrameParams &P, const DevScene &S, Lane &L)
             float sp = (float)u8cast(P.specular * i2);
             dr += sp; dg += sp; db += sp;
         }
-        L.cr += dr; L.cg += dg; L.cb += db;                      // color += dColor
+        float *c = lds_col + L.depth * 3 * 256 + threadIdx.x;    // color += dColor (the level's colour lives in its LDS column)
+        c[0] += dr; c[256] += dg; c[512] += db;
     }
 }
 
+MI_DEV void load_edges(const float4 *e, float4 &e1, float4 &e2, float4 &e3);
+
 // Closest hit found: interpolate normal / AO, ambient term, reflection direction
 // (Raytracer.cc:333-381, 424-436, 509-521).
-MI_DEV void shade_begin(const FrameParams &P, const DevScene &S, Lane &L)
+MI_DEV void shade_begin(const FrameParams &P, const DevScene &S, Lane &L, float *lds_col)
 {
     const float4 *sh = S.tri_shade + (size_t)L.btri * 5;
     float4 s0 = sh[0];   // lenAB, lenBC, lenCA, area
@@ -311,7 +316,21 @@ MI_DEV void shade_begin(const FrameParams &P, const DevScene &S, Lane &L)
     float4 s2 = sh[2];   // nB.xyz, aoB
     float4 s3 = sh[3];   // nC.xyz, aoC
     float4 s4 = sh[4];   // colorf r,g,b
-    float ABx = L.k1 * s0.x, BCx = L.k2 * s0.y, CAx = L.k3 * s0.z;
+    // The hit point and the three edge values of the winning triangle: the walk kept the triangle and its distance only; the
+    // same float operations on the same inputs (Raytracer.cc:261-275: the ray, the triangle's plane and edge records) give the
+    // values the triangle test saw when it accepted the hit.
+    const float4 *tp = S.walk + (size_t)S.tri_base + (size_t)L.btri * 2;
+    const float4 ta = tp[0], tb = tp[1];
+    float4 e1, e2, e3;
+    load_edges(S.tri_edge + (size_t)L.btri * 3, e1, e2, e3);
+    const f3 tn = mk3(ta.x, ta.y, ta.z);
+    const float tk = dot3(tn, L.d);
+    const float ts = (tb.w - dot3(tn, L.o)) / tk;
+    L.hit = add3(mul3(L.d, ts), L.o);
+    const float k1 = dot3(mk3(e1.x, e1.y, e1.z), L.hit) - e1.w;
+    const float k2 = dot3(mk3(e2.x, e2.y, e2.z), L.hit) - e2.w;
+    const float k3 = dot3(mk3(e3.x, e3.y, e3.z), L.hit) - e3.w;
+    float ABx = k1 * s0.x, BCx = k2 * s0.y, CAx = k3 * s0.z;
     float area = s0.w;
     f3 nA = mul3(mk3(s1.x, s1.y, s1.z), BCx / area);
     f3 nB = mul3(mk3(s2.x, s2.y, s2.z), CAx / area);
@@ -319,7 +338,7 @@ MI_DEV void shade_begin(const FrameParams &P, const DevScene &S, Lane &L)
     L.pn = norm3(add3(add3(nA, nB), nC));
     float aoc = s1.w * BCx / area + s2.w * CAx / area + s3.w * ABx / area;
     float ambientFactor = (float)(((double)(P.ambient * aoc) / 255.0) / 255.0);
-    L.cr = ambientFactor * s4.x; L.cg = ambientFactor * s4.y; L.cb = ambientFactor * s4.z;
+    set_c(lds_col, (int)threadIdx.x, L.depth, ambientFactor * s4.x, ambientFactor * s4.y, ambientFactor * s4.z);
     float c1 = -dot3(L.d, L.pn);
     L.refl = norm3(add3(L.d, mul3(L.pn, 2.0f * c1)));
     L.li = 0;
@@ -410,7 +429,7 @@ MI_DEV void load_edges(const float4 *e, float4 &e1, float4 &e2, float4 &e3)
 // (ordered walk: candidates arrive in any order, so "first found wins among equal distances" becomes
 //  "lowest list position wins" -- the same triangle, list position being the reference's visiting rank)
 template <bool ORDERED>
-MI_DEV bool tri_edge_test(Lane &L)
+MI_DEV bool tri_edge_test(Lane &L, float scene_mag)
 {
     const f3 hit = L.ph;
     const float kt1 = dot3(mk3(L.pe1.x, L.pe1.y, L.pe1.z), hit) - L.pe1.w; if (kt1 < 0.0f) return false;
@@ -422,8 +441,8 @@ MI_DEV bool tri_edge_test(Lane &L)
         const float hitZ = distsq3(L.o, hit);
         const bool better = ORDERED ? (hitZ < L.best || (hitZ == L.best && L.pj < L.btri)) : (hitZ < L.best);
         if (better) {
-            L.best = hitZ; L.btri = L.pj; L.hit = hit; L.k1 = kt1; L.k2 = kt2; L.k3 = kt3;
-            if (ORDERED) L.limit = __builtin_sqrtf(hitZ) * 1.001f + L.delta;
+            L.best = hitZ; L.btri = L.pj;
+            if (ORDERED) L.limit = __builtin_sqrtf(hitZ) * 1.001f + ray_delta(L.o, scene_mag);
         }
     }
     return false;
@@ -494,6 +513,9 @@ k_raytrace(const DevScene S, const FrameParams P)
     const bool steal_on = STEAL && P.steal_min > 0;
     uint32_t *const sflag = lds_stack + (QUAD ? S.qstack_depth : S.stack_depth) * 256u;
     uint32_t *const stab = sflag + 256u + (threadIdx.x & ~63u);
+    // (work sharing: the light a lane's shadow ray aims at, three rows -- whoever walks a part of that ray looks it up when a
+    //  triangle lies across the ray, instead of carrying it through the walk)
+    float *const lds_lp = (float *)(sflag + 512u);
     Lane L;
     bool alive = false;         // lane owns a pixel
     bool want_pixel = true;     // lane needs a (new) pixel
@@ -508,10 +530,10 @@ k_raytrace(const DevScene S, const FrameParams P)
     uint32_t dry_shares = 0;
     L.cur = MI_END_LINK; L.mode = MODE_CLOSEST; L.btri = -1; L.depth = 0; L.samples_left = 0;
     L.fr = L.fg = L.fb = 0.f; L.px = L.py = L.orow = 0; L.fid = 0; L.avoid = -1; L.best = 0.f;
-    L.shadow_hit = false; L.li = 0; L.cr = L.cg = L.cb = 0.f; L.k1 = L.k2 = L.k3 = 0.f;
+    L.shadow_hit = false; L.li = 0;
     L.o = L.d = L.hit = L.pn = L.refl = L.lp = L.inv = L.ph = mk3(0.f, 0.f, 0.f);
     L.tame = false; L.pend = false; L.pj = -1;
-    L.limit = 0.f; L.delta = 0.f; L.dmax = 0.f; L.sp = 0; L.top = MI_END_LINK; L.base = 0; L.owner = (int)threadIdx.x;
+    L.limit = 0.f; L.dmax = 0.f; L.sp = 0; L.top = MI_END_LINK; L.base = 0; L.owner = (int)threadIdx.x;
     L.pe1 = L.pe2 = L.pe3 = make_float4(0.f, 0.f, 0.f, 0.f);
     L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; L.ao_draw = 0u; L.ao_total = L.ao_max = L.ao_cos = 0.f;
 
@@ -649,7 +671,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         else finish = true;
                     } else {
                         if (STATS) n_shaded++;
-                        shade_begin(P, S, L);
+                        shade_begin(P, S, L, lds_col);
                         lights = true;
                         if constexpr (EXT) {
                             if (P.use_refr && L.depth + 1 < P.max_depth) {
@@ -678,7 +700,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                 } else {
                     bool blocked = L.shadow_hit;
                     if constexpr (STEAL) blocked = sflag[threadIdx.x] != 0u;
-                    if (!blocked) add_light<BATCH>(P, S, L);        // Raytracer.cc:458-466
+                    if (!blocked) add_light<BATCH>(P, S, L, lds_col);        // Raytracer.cc:458-466
                     L.li++;
                     lights = true;
                 }
@@ -707,7 +729,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         L.o = L.hit; L.d = v;
                         set_ray_aux(L, S.scene_mag);
                         L.best = distsq3(L.o, L.lp);
-                        L.limit = 2.f * __builtin_sqrtf(L.best) * 1.001f + L.delta;
+                        L.limit = 2.f * __builtin_sqrtf(L.best) * 1.001f + ray_delta(L.o, S.scene_mag);
                         L.mode = MODE_SHADOW;
                         L.shadow_hit = false;
                         L.nocull = 0u;                              // BVH_IntersectTriangles<true,true>
@@ -717,7 +739,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     } else {
                         const float4 sh4 = S.tri_shade[(size_t)L.btri * 5 + 4];
                         const float f = (float)(((double)P.ambient / 255.0) * (double)(L.ao_total / L.ao_max));   // :417
-                        L.cr = f * sh4.x; L.cg = f * sh4.y; L.cb = f * sh4.z;
+                        set_c(lds_col, (int)threadIdx.x, L.depth, f * sh4.x, f * sh4.y, f * sh4.z);
                         L.ao_i = -1;
                         lights = true;
                     }
@@ -739,22 +761,24 @@ k_raytrace(const DevScene S, const FrameParams P)
                         L.best = distsq3(L.o, L.lp);            // Raytracer.cc:209
                         // a hit blocks when it is nearer to the light than the origin is, i.e. at a ray
                         // parameter below twice the light's distance
-                        L.limit = 2.f * __builtin_sqrtf(L.best) * 1.001f + L.delta;
+                        L.limit = 2.f * __builtin_sqrtf(L.best) * 1.001f + ray_delta(L.o, S.scene_mag);
                         L.mode = MODE_SHADOW;
                         L.shadow_hit = false;
-                        if constexpr (STEAL) { sflag[threadIdx.x] = 0u; L.owner = (int)threadIdx.x; }
+                        if constexpr (STEAL) {
+                            sflag[threadIdx.x] = 0u; L.owner = (int)threadIdx.x;
+                            lds_lp[threadIdx.x] = L.lp.x; lds_lp[256 + threadIdx.x] = L.lp.y; lds_lp[512 + threadIdx.x] = L.lp.z;
+                        }
                         begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
                         L.avoid = L.btri;                       // avoidSelf = the triangle just hit (Raytracer.cc:335)
                         n_shadow++;
                         launched = true;
                         break;
                     }
-                    add_light<BATCH>(P, S, L);
+                    add_light<BATCH>(P, S, L, lds_col);
                     L.li++;
                 }
                 if (!launched) {
-                    // all lights done for this hit: store the level colour, bounce or finish
-                    set_c(lds_col, (int)threadIdx.x, L.depth, L.cr, L.cg, L.cb);
+                    // all lights done for this hit (its colour is in the level's LDS column): bounce or finish
                     if constexpr (EXT) {
                         if (P.use_refl && L.depth + 1 < P.max_depth) {
                             L.o = L.hit; L.d = L.refl; L.avoid = L.btri;
@@ -827,9 +851,10 @@ k_raytrace(const DevScene S, const FrameParams P)
                     if (b > 255.0f) b = 255.0f;
                     uint32_t *const fout = BATCH ? P.cams[L.fid].out : P.out;
                     float *const foutf = BATCH ? P.cams[L.fid].outf : P.outf;
-                    fout[(size_t)L.orow * P.pitch_words + L.px] = pack_xrgb(r, g, b);
+                    const int orow = L.orow, ocol = L.px;
+                    fout[(size_t)orow * P.pitch_words + ocol] = pack_xrgb(r, g, b);
                     if (foutf) {
-                        float *q = foutf + ((size_t)L.orow * P.W + L.px) * 3;
+                        float *q = foutf + ((size_t)orow * P.W + ocol) * 3;
                         q[0] = r; q[1] = g; q[2] = b;
                     }
                     alive = false;
@@ -884,12 +909,11 @@ k_raytrace(const DevScene S, const FrameParams P)
                     const float ox = __shfl(L.o.x, v), oy = __shfl(L.o.y, v), oz = __shfl(L.o.z, v);
                     const float dx = __shfl(L.d.x, v), dy = __shfl(L.d.y, v), dz = __shfl(L.d.z, v);
                     const float ix = __shfl(L.inv.x, v), iy = __shfl(L.inv.y, v), iz = __shfl(L.inv.z, v);
-                    const float lx = __shfl(L.lp.x, v), ly = __shfl(L.lp.y, v), lz = __shfl(L.lp.z, v);
                     const float vdmax = __shfl(L.dmax, v), vlimit = __shfl(L.limit, v), vbest = __shfl(L.best, v);
                     const int vavoid = __shfl(L.avoid, v), vowner = __shfl(L.owner, v), vtame = __shfl(L.tame ? 1 : 0, v);
                     const uint32_t vgive = (uint32_t)__shfl((int)give, v);
                     if (takes) {
-                        L.o = mk3(ox, oy, oz); L.d = mk3(dx, dy, dz); L.inv = mk3(ix, iy, iz); L.lp = mk3(lx, ly, lz);
+                        L.o = mk3(ox, oy, oz); L.d = mk3(dx, dy, dz); L.inv = mk3(ix, iy, iz);
                         L.dmax = vdmax; L.limit = vlimit; L.best = vbest; L.avoid = vavoid; L.owner = vowner; L.tame = vtame != 0;
                         L.mode = MODE_SHADOW; L.sp = 0; L.base = 0; L.top = MI_END_LINK;
                         L.cur = vgive;
@@ -1107,7 +1131,14 @@ k_raytrace(const DevScene S, const FrameParams P)
                     const float kt2 = kt23.x, kt3 = kt23.y;
                     const bool inside = cand && !(kt1 < 0.0f) && !(kt2 < 0.0f) && !(kt3 < 0.0f);
                     const bool shadow = L.mode == MODE_SHADOW;
-                    const f3 from = shadow ? L.lp : L.o;
+                    f3 from = L.o;
+                    if constexpr (STEAL) {
+                        if (__ballot(inside && shadow)) {
+                            const int ow = shadow ? L.owner : (int)threadIdx.x;
+                            const f3 lp = mk3(lds_lp[ow], lds_lp[256 + ow], lds_lp[512 + ow]);
+                            if (shadow) from = lp;
+                        }
+                    } else if (shadow) from = L.lp;
                     const float dz = distsq3(from, hit);
                     const bool nearer = dz < L.best;
                     if (inside && shadow && nearer) {                // a blocked shadow ray stops (Raytracer.cc:284)
@@ -1116,8 +1147,8 @@ k_raytrace(const DevScene S, const FrameParams P)
                     }
                     // candidates arrive in any order: lowest list position wins among equal distances
                     if (inside && !shadow && (nearer || (dz == L.best && j < L.btri))) {
-                        L.best = dz; L.btri = j; L.hit = hit; L.k1 = kt1; L.k2 = kt2; L.k3 = kt3;
-                        L.limit = __builtin_sqrtf(dz) * 1.001f + L.delta;
+                        L.best = dz; L.btri = j;
+                        L.limit = __builtin_sqrtf(dz) * 1.001f + ray_delta(L.o, S.scene_mag);
                     }
                 }
                 MI_PHASE(pc_b);
@@ -1135,7 +1166,14 @@ k_raytrace(const DevScene S, const FrameParams P)
                     const float kt3 = dot3(mk3(L.pe3.x, L.pe3.y, L.pe3.z), hit) - L.pe3.w;
                     const bool inside = L.pend && !(kt1 < 0.0f) && !(kt2 < 0.0f) && !(kt3 < 0.0f);
                     const bool shadow = L.mode == MODE_SHADOW;
-                    const f3 from = shadow ? L.lp : L.o;
+                    f3 from = L.o;
+                    if constexpr (STEAL) {
+                        if (__ballot(inside && shadow)) {
+                            const int ow = shadow ? L.owner : (int)threadIdx.x;
+                            const f3 lp = mk3(lds_lp[ow], lds_lp[256 + ow], lds_lp[512 + ow]);
+                            if (shadow) from = lp;
+                        }
+                    } else if (shadow) from = L.lp;
                     const float dz = distsq3(from, hit);
                     const bool nearer = dz < L.best;
                     if (inside && shadow && nearer) {                // a blocked shadow ray stops (Raytracer.cc:284)
@@ -1144,8 +1182,8 @@ k_raytrace(const DevScene S, const FrameParams P)
                     }
                     // candidates arrive in any order: lowest list position wins among equal distances
                     if (inside && !shadow && (nearer || (dz == L.best && L.pj < L.btri))) {
-                        L.best = dz; L.btri = L.pj; L.hit = hit; L.k1 = kt1; L.k2 = kt2; L.k3 = kt3;
-                        L.limit = __builtin_sqrtf(dz) * 1.001f + L.delta;
+                        L.best = dz; L.btri = L.pj;
+                        L.limit = __builtin_sqrtf(dz) * 1.001f + ray_delta(L.o, S.scene_mag);
                     }
                     L.pend = false;
                 }
@@ -1217,7 +1255,7 @@ k_raytrace(const DevScene S, const FrameParams P)
             if (__ballot(L.pend)) {
                 if (L.pend) {
                     L.pend = false;
-                    stop = tri_edge_test<false>(L);                        // a blocked shadow ray stops (Raytracer.cc:284)
+                    stop = tri_edge_test<false>(L, S.scene_mag);                        // a blocked shadow ray stops (Raytracer.cc:284)
                 }
             }
             if (walking) {
@@ -1237,7 +1275,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     // counting builds judge at once so that a blocked shadow ray stops exactly where the
                     // reference does and the counters stay comparable
                     L.pend = false;
-                    if (tri_edge_test<false>(L)) L.cur = MI_END_LINK;
+                    if (tri_edge_test<false>(L, S.scene_mag)) L.cur = MI_END_LINK;
                 }
             }
             if (mL) MI_PHASE(pc_b);
@@ -1493,7 +1531,7 @@ rt_kernel pick_kernel(int stats, int exact, int ordered, int waves, int batch, i
     return exact ? k_raytrace<false, true, false, 2, false> : k_raytrace<false, false, false, 2, false>;
 }
 // (two rows behind the stack's: the shadow verdict words and the givers' table of the work sharing)
-size_t stack_bytes(int ordered, int stack_depth) { return ordered ? (size_t)(stack_depth + 2) * 256u * sizeof(uint32_t) : 0u; }
+size_t stack_bytes(int ordered, int stack_depth) { return ordered ? (size_t)(stack_depth + 5) * 256u * sizeof(uint32_t) : 0u; }   // (stack rows, verdict row, giver table, three light rows)
 } // namespace
 
 // can this build render several frames per launch?  (the ordered, non-counting kernels only)

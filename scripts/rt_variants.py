@@ -28,6 +28,8 @@ def prof12():
     out = (C.c_ulonglong * 20)()
     R.lib().mi355i_fetch_profile.argtypes = [C.c_void_p, C.c_void_p]
     return (int(out[12]), int(out[11])) if R.lib().mi355i_fetch_profile(s.context(), out) == 0 else (-1, -1)
+ref_px = {}
+T0 = time.perf_counter()
 for label, t in variants:
     t = dict(t); extra = t.pop("_opts", {})
     o = R.default_opts(W, H, max_ray_depth=depth, tune=R.tune(**t), **extra)
@@ -48,5 +50,8 @@ for label, t in variants:
         _, _, st = s.render(9, cam, lights, n, o)
         ms.append(st.kernel_ms)
     ms = np.array(ms[20:])
-    print(json.dumps({"variant": label, "batch8_fps": round(best, 1), "single_ms_mean": round(float(ms.mean()), 4), "single_ms_min": round(float(ms.min()), 4),
+    px, _, _ = s.render(9, *cams[0][:2], cams[0][2], o)
+    key = json.dumps(extra, sort_keys=True)
+    same = bool(np.array_equal(ref_px.setdefault(key, np.array(px)), np.array(px)))
+    print(json.dumps({"variant": label, "t": round(time.perf_counter() - T0, 1), "same_pixels": same, "batch8_fps": round(best, 1), "single_ms_mean": round(float(ms.mean()), 4), "single_ms_min": round(float(ms.min()), 4),
                       "steals_events_last_frame": prof12()}), flush=True)
