@@ -873,7 +873,9 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
         // the four-wide walk (dev_scene.h) on request (tune flag 128) where the tree allows it: it visits 0.57 of the inner records
         // but a step costs 635 instructions against 377 (scripts/isa_loop_stats.py), and the kernel is bound by instruction issue
         const int quad = (ordered && !ext && c->dev.quad_ok && P.quad) ? 1 : 0;
-        const int stack_rows = quad ? (int)c->dev.qstack_depth : (int)c->dev.stack_depth;
+        // (LDS rows the launch asks for: three colour rows per depth level, the tree's stack rows for the ordered walk, and a 4 spp
+        //  frame's three rows of pixel sums behind the kernel's own)
+        const int stack_rows = 3 * P.max_depth + (ordered ? (quad ? (int)c->dev.qstack_depth : (int)c->dev.stack_depth) + (P.aa ? 3 : 0) : 0);
         int waves = 2;
         if (ordered && !stats && !ext) {
             for (int w = 4; w >= 3; w--) {

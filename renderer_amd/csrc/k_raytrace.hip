@@ -499,12 +499,13 @@ template <bool STATS, bool EXACT_BOX, bool ORDERED, int WAVES, bool BATCH, bool 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 k_raytrace(const DevScene S, const FrameParams P)
 {
-    // LDS: per-lane colour columns of the ray tree's depth levels
-    __shared__ float lds_col[MI_MAX_DEPTH * 3 * 256];
+    // LDS, sized at launch (stack_bytes below): first the per-lane colour columns of the ray tree's depth levels, three rows each
+    extern __shared__ uint32_t lds_dyn[];
+    float *const lds_col = (float *)lds_dyn;
     // LDS (EXT): the refracted ray waiting at each depth level: hit point, direction, triangle to avoid
     __shared__ float lds_refr[EXT ? MI_MAX_DEPTH * 7 * 256 : 1];
-    // LDS (ordered walk only, sized at launch): per-lane stack of postponed children, one row per level
-    extern __shared__ uint32_t lds_stack[];
+    // then (ordered walk only) the per-lane stack of postponed children, one row per level
+    uint32_t *const lds_stack = lds_dyn + 3u * 256u * (uint32_t)P.max_depth;
     // Work sharing inside a wave (production builds): a shadow ray's verdict is an OR over the triangles its walk reaches, so any
     // part of that walk can be done by any lane.  Lanes without a ray of their own take the oldest postponed subtree of a lane
     // that still walks a shadow ray; a blocker found by anyone is reported in the owner's word of an LDS row.  Two more rows
@@ -516,6 +517,10 @@ k_raytrace(const DevScene S, const FrameParams P)
     // (work sharing: the light a lane's shadow ray aims at, three rows -- whoever walks a part of that ray looks it up when a
     //  triangle lies across the ray, instead of carrying it through the walk)
     float *const lds_lp = (float *)(sflag + 512u);
+    // (ordered builds: a hit's reflected direction waits in three rows while the hit's shadow rays are walked; a 4 spp frame
+    //  keeps its pixel sums in three more, which only such a launch allocates)
+    float *const lds_refl = (float *)(sflag + 5u * 256u) + threadIdx.x;
+    float *const lds_sum = lds_refl + 3 * 256;
     Lane L;
     bool alive = false;         // lane owns a pixel
     bool want_pixel = true;     // lane needs a (new) pixel
@@ -622,7 +627,8 @@ k_raytrace(const DevScene S, const FrameParams P)
                                     L.px = x; L.fid = fid;
                                     L.py = band_row_to_y(r, P.band_rows, P.band_index, P.band_count);
                                     L.orow = P.compact ? r : L.py;
-                                    L.fr = L.fg = L.fb = 0.f;
+                                    if constexpr (ORDERED) { if (P.aa) lds_sum[0] = lds_sum[256] = lds_sum[512] = 0.f; }
+                                    else L.fr = L.fg = L.fb = 0.f;
                                     L.samples_left = P.aa ? 3 : 0;
                                     primary_ray<BATCH>(P, S, L, L.samples_left);
                                     if constexpr (EXT) { L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; }
@@ -672,6 +678,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     } else {
                         if (STATS) n_shaded++;
                         shade_begin(P, S, L, lds_col);
+                        if constexpr (ORDERED) { lds_refl[0] = L.refl.x; lds_refl[256] = L.refl.y; lds_refl[512] = L.refl.z; }
                         lights = true;
                         if constexpr (EXT) {
                             if (P.use_refr && L.depth + 1 < P.max_depth) {
@@ -781,7 +788,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     // all lights done for this hit (its colour is in the level's LDS column): bounce or finish
                     if constexpr (EXT) {
                         if (P.use_refl && L.depth + 1 < P.max_depth) {
-                            L.o = L.hit; L.d = L.refl; L.avoid = L.btri;
+                            L.o = L.hit; L.d = ORDERED ? mk3(lds_refl[0], lds_refl[256], lds_refl[512]) : L.refl; L.avoid = L.btri;
                             set_ray_aux(L, S.scene_mag);
                             L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
                             L.nocull = 0u;                          // Raytrace<true>
@@ -792,7 +799,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     } else {
                     L.depth++;
                     if (P.use_refl && L.depth < P.max_depth) {
-                        L.o = L.hit; L.d = L.refl; L.avoid = L.btri;
+                        L.o = L.hit; L.d = ORDERED ? mk3(lds_refl[0], lds_refl[256], lds_refl[512]) : L.refl; L.avoid = L.btri;
                         set_ray_aux(L, S.scene_mag);
                         L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
                         begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
@@ -836,7 +843,12 @@ k_raytrace(const DevScene S, const FrameParams P)
                 if (P.use_refl) { const f3 a = fold_levels(lds_col, L.depth, P.refl_rate); ar = a.x; ag = a.y; ab = a.z; }
                 else if (L.depth > 0) { ar = lds_col[threadIdx.x]; ag = lds_col[256 + threadIdx.x]; ab = lds_col[512 + threadIdx.x]; }
                 }
-                L.fb += ab; L.fg += ag; L.fr += ar;              // finalColor += ...
+                // finalColor += ... (ordered builds: a one-sample pixel needs no sum of its own, 0 + its colour is the sum)
+                float sr, sg, sb;
+                if constexpr (ORDERED) {
+                    if (P.aa) { sb = lds_sum[512] + ab; sg = lds_sum[256] + ag; sr = lds_sum[0] + ar; lds_sum[0] = sr; lds_sum[256] = sg; lds_sum[512] = sb; }
+                    else { sb = 0.f + ab; sg = 0.f + ag; sr = 0.f + ar; }
+                } else { L.fb += ab; L.fg += ag; L.fr += ar; sr = L.fr; sg = L.fg; sb = L.fb; }
                 if (L.samples_left > 0) {
                     L.samples_left--;
                     primary_ray<BATCH>(P, S, L, L.samples_left);
@@ -844,7 +856,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
                     n_normal++;
                 } else {
-                    float r = L.fr, g = L.fg, b = L.fb;
+                    float r = sr, g = sg, b = sb;
                     if (P.aa) { b = b / 4.f; g = g / 4.f; r = r / 4.f; }
                     if (r > 255.0f) r = 255.0f;
                     if (g > 255.0f) g = 255.0f;
@@ -1531,19 +1543,23 @@ rt_kernel pick_kernel(int stats, int exact, int ordered, int waves, int batch, i
     return exact ? k_raytrace<false, true, false, 2, false> : k_raytrace<false, false, false, 2, false>;
 }
 // (two rows behind the stack's: the shadow verdict words and the givers' table of the work sharing)
-size_t stack_bytes(int ordered, int stack_depth) { return ordered ? (size_t)(stack_depth + 5) * 256u * sizeof(uint32_t) : 0u; }   // (stack rows, verdict row, giver table, three light rows)
+// (stack rows, verdict row, giver table, three light rows, three rows of reflected directions; 4 spp: three rows of pixel sums)
+// (`rows` as the launcher passes it: three per depth level of the ray tree, the tree's stack rows if the walk is ordered, three
+//  more for a 4 spp frame)
+size_t stack_bytes(int ordered, int rows) { return (size_t)(rows + (ordered ? 8 : 0)) * 256u * sizeof(uint32_t); }
 } // namespace
 
 // can this build render several frames per launch?  (the ordered, non-counting kernels only)
 extern "C" int mi355i_raytrace_can_batch(int stats, int ordered) { return ordered && !stats; }
 
-// blocks per CU the (stats, exact, ordered, waves, batch, quad) variant can hold with `stack_depth` rows of LDS stack
+// blocks per CU the (stats, exact, ordered, waves, batch, quad) variant can hold with `stack_depth` rows of LDS asked for by the launcher
 extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext, int quad)
 {
-    static int cache[2][2][2][2][2][3][2][MI_MAX_QSTACK + 1];        // 0 = not asked yet
-    if (stack_depth < 0 || stack_depth > MI_MAX_QSTACK) stack_depth = MI_MAX_QSTACK;
+    constexpr int MAX_ROWS = MI_MAX_QSTACK + 3 * MI_MAX_DEPTH + 3;
+    static int cache[2][2][2][2][2][3][2][MAX_ROWS + 1];        // 0 = not asked yet
+    if (stack_depth < 0 || stack_depth > MAX_ROWS) stack_depth = MAX_ROWS;
     const int w = waves >= 4 ? 2 : (waves == 3 ? 1 : 0);
-    int &slot = cache[quad ? 1 : 0][ext ? 1 : 0][stats ? 1 : 0][exact ? 1 : 0][ordered ? 1 : 0][w][batch ? 1 : 0][ordered ? stack_depth : 0];
+    int &slot = cache[quad ? 1 : 0][ext ? 1 : 0][stats ? 1 : 0][exact ? 1 : 0][ordered ? 1 : 0][w][batch ? 1 : 0][stack_depth];
     if (!slot) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_kernel(stats, exact, ordered, waves, batch, ext, quad), 256, stack_bytes(ordered, stack_depth)) != hipSuccess || nb < 1)
