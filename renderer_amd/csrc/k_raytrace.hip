@@ -230,9 +230,9 @@ template <bool BATCH> MI_DEV f3 cam_light(const FrameParams &P, int fid, int li)
     return mk3(P.light_pos[li][0], P.light_pos[li][1], P.light_pos[li][2]);
 }
 
-// Primary ray of pixel (px,py), sample index `traced` (Raytracer.cc:563-593)
+// Primary ray of pixel (px,py), sample index `traced` (Raytracer.cc:563-593): its direction
 template <bool BATCH>
-MI_DEV void primary_ray(const FrameParams &P, const DevScene &S, Lane &L, int traced)
+MI_DEV f3 primary_dir(const FrameParams &P, const Lane &L, int traced)
 {
     float xx = (float)L.px, yy = (float)L.py;
     if (P.aa) {
@@ -246,7 +246,13 @@ MI_DEV void primary_ray(const FrameParams &P, const DevScene &S, Lane &L, int tr
     f3 rw = mul3(r1, rc.x);
     rw = add3(rw, mul3(r2, rc.y));
     rw = add3(rw, mul3(r3, rc.z));
-    L.d = norm3(rw);
+    return norm3(rw);
+}
+
+template <bool BATCH>
+MI_DEV void primary_ray(const FrameParams &P, const DevScene &S, Lane &L, int traced)
+{
+    L.d = primary_dir<BATCH>(P, L, traced);
     L.o = cam_eye<BATCH>(P, L.fid);
     set_ray_aux(L, S.scene_mag);
     L.depth = 0;
@@ -358,6 +364,10 @@ MI_DEV uint32_t ao_mix(uint32_t v)
 //     inner node    : a = (bmin, hit link)      b = (bmax, miss link)
 //     triangle block: a = (normal, next link)   b = (centre, d)        at index tri_base + 2*j
 struct Rec { float4 a, b; };
+
+// result words of the work sharing (k_raytrace): nothing found yet / the word of a closest hit
+#define MI_RESULT_NONE 0x7f7fffffffffffffull          /* FLT_MAX, triangle -1 */
+MI_DEV unsigned long long result_key(float dist_sq, int tri) { return ((unsigned long long)__float_as_uint(dist_sq) << 32) | (uint32_t)tri; }
 
 MI_DEV void rec_fetch(const DevScene &S, uint32_t link, Rec &r)
 {
@@ -512,14 +522,20 @@ k_raytrace(const DevScene S, const FrameParams P)
     // behind the stack's: the verdict words, and a per-wave table (rank among the givers -> lane).
     constexpr bool STEAL = ORDERED && !STATS && !EXT && !QUAD;
     const bool steal_on = STEAL && P.steal_min > 0;
-    uint32_t *const sflag = lds_stack + (QUAD ? S.qstack_depth : S.stack_depth) * 256u;
-    uint32_t *const stab = sflag + 256u + (threadIdx.x & ~63u);
+    // Rows behind the stack's.  Two rows of 64-bit RESULT words, one per thread of the block: the state of the ray that thread
+    // owns, as everybody who walks a part of it sees it -- a closest-hit ray: distance^2 bits << 32 | triangle of the best hit so
+    // far (atomic min: the nearest hit, the lowest triangle among equals -- the rule of the walk itself), a shadow ray: 0 once a
+    // blocker has been found (the upper half; the lower half keeps the triangle the ray starts on, which the lane needs back
+    // after it has walked for others); both start at FLT_MAX in the upper half.
+    unsigned long long *const result = (unsigned long long *)(lds_stack + (QUAD ? S.qstack_depth : S.stack_depth) * 256u);
+    // one row: per wave, rank among the givers of a hand-over -> lane
+    uint32_t *const stab = (uint32_t *)(result + 256) + (threadIdx.x & ~63u);
     // (work sharing: the light a lane's shadow ray aims at, three rows -- whoever walks a part of that ray looks it up when a
     //  triangle lies across the ray, instead of carrying it through the walk)
-    float *const lds_lp = (float *)(sflag + 512u);
+    float *const lds_lp = (float *)(result + 256) + 256;
     // (ordered builds: a hit's reflected direction waits in three rows while the hit's shadow rays are walked; a 4 spp frame
     //  keeps its pixel sums in three more, which only such a launch allocates)
-    float *const lds_refl = (float *)(sflag + 5u * 256u) + threadIdx.x;
+    float *const lds_refl = lds_lp + 3 * 256 + threadIdx.x;
     float *const lds_sum = lds_refl + 3 * 256;
     Lane L;
     bool alive = false;         // lane owns a pixel
@@ -632,6 +648,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                                     L.samples_left = P.aa ? 3 : 0;
                                     primary_ray<BATCH>(P, S, L, L.samples_left);
                                     if constexpr (EXT) { L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; }
+                                    if constexpr (STEAL) { result[threadIdx.x] = MI_RESULT_NONE; L.owner = (int)threadIdx.x; }
                                     begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
                                     n_normal++;
                                     alive = true;
@@ -671,6 +688,10 @@ k_raytrace(const DevScene S, const FrameParams P)
             int up_d = 0; uint32_t up_which = 0u;
             f3 up_v = mk3(0.f, 0.f, 0.f);
             if (ray_done) {
+                if constexpr (STEAL) {
+                    // (the hit of a closest-hit ray is what all the lanes that walked parts of it have found together)
+                    if (L.mode == MODE_CLOSEST) { const unsigned long long w = result[threadIdx.x]; L.btri = (int)(uint32_t)w; L.best = __uint_as_float((uint32_t)(w >> 32)); }
+                }
                 if (L.mode == MODE_CLOSEST) {
                     if (L.btri < 0) {                               // Raytracer.cc:327-331
                         if (EXT && L.depth > 0) { up = true; up_d = L.depth - 1; up_which = L.path & 1u; L.path >>= 1; }
@@ -706,7 +727,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     ao_next = true;
                 } else {
                     bool blocked = L.shadow_hit;
-                    if constexpr (STEAL) blocked = sflag[threadIdx.x] != 0u;
+                    if constexpr (STEAL) blocked = (uint32_t)(result[threadIdx.x] >> 32) == 0u;
                     if (!blocked) add_light<BATCH>(P, S, L, lds_col);        // Raytracer.cc:458-466
                     L.li++;
                     lights = true;
@@ -772,7 +793,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         L.mode = MODE_SHADOW;
                         L.shadow_hit = false;
                         if constexpr (STEAL) {
-                            sflag[threadIdx.x] = 0u; L.owner = (int)threadIdx.x;
+                            result[threadIdx.x] = result_key(FLT_MAX, L.btri); L.owner = (int)threadIdx.x;
                             lds_lp[threadIdx.x] = L.lp.x; lds_lp[256 + threadIdx.x] = L.lp.y; lds_lp[512 + threadIdx.x] = L.lp.z;
                         }
                         begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
@@ -802,6 +823,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         L.o = L.hit; L.d = ORDERED ? mk3(lds_refl[0], lds_refl[256], lds_refl[512]) : L.refl; L.avoid = L.btri;
                         set_ray_aux(L, S.scene_mag);
                         L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
+                        if constexpr (STEAL) { result[threadIdx.x] = MI_RESULT_NONE; L.owner = (int)threadIdx.x; }
                         begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
                         n_normal++;
                     } else finish = true;
@@ -853,6 +875,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     L.samples_left--;
                     primary_ray<BATCH>(P, S, L, L.samples_left);
                     if constexpr (EXT) { L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; }
+                    if constexpr (STEAL) { result[threadIdx.x] = MI_RESULT_NONE; L.owner = (int)threadIdx.x; }
                     begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
                     n_normal++;
                 } else {
@@ -888,21 +911,23 @@ k_raytrace(const DevScene S, const FrameParams P)
         // A step decides where to go next and requests that record at once; the candidate of the previous step
         // is judged and this step's triangle is plane-tested while the request is in flight.
         uint32_t *const stk = lds_stack + threadIdx.x;
-        // (work sharing: only while some lane of the wave walks a shadow ray -- a burst of camera or reflected rays pays nothing;
-        //  `lent` = a subtree has changed lanes in this burst: only then can somebody else end a lane's ray)
-        const bool share_now = STEAL && steal_on && __ballot(L.cur != MI_END_LINK && L.mode == MODE_SHADOW) != 0ull;
-        bool lent = false;
+        // Work sharing: `lent` = a subtree has changed lanes in this burst -- only then can somebody else change the result of the ray
+        // a lane walks; `took` = this lane has walked for others in this burst: its own ray (ended before) is put back afterwards.
+        const bool share_now = STEAL && steal_on;
+        const bool own_closest = alive && L.mode == MODE_CLOSEST;
+        bool lent = false, took = false;
         for (;;) {
             if (STATS) it_loops++;
-            uint32_t blocked_word = 0u;
+            unsigned long long seen = MI_RESULT_NONE;
             if constexpr (STEAL) {
             if (share_now) {
-                // (the verdict word of the ray this lane walks a part of: requested here, looked at when the step is done)
-                if (lent) blocked_word = sflag[L.owner];
-                // takers: lanes with nothing to walk whose ray registers are dead (no pixel, or a shadow ray that has ended: a
-                // closest-hit ray's direction is still needed for shading); givers: lanes on a shadow ray with a postponed node
-                const bool taker = L.cur == MI_END_LINK && !L.pend && (!alive || L.mode == MODE_SHADOW);
-                const bool giver = L.cur != MI_END_LINK && L.mode == MODE_SHADOW && L.sp > L.base;
+                // (the result word of the ray this lane walks a part of: requested here, looked at when the step is done)
+                if (lent) seen = result[L.owner];
+                // takers: lanes with nothing to walk -- no pixel, or a ray that has ended: what it found is in its result word, and
+                // what shading needs of a closest-hit ray (origin, direction) is made again after the burst; givers: lanes with
+                // a postponed node
+                const bool taker = L.cur == MI_END_LINK && !L.pend;
+                const bool giver = L.cur != MI_END_LINK && L.sp > L.base;
                 const unsigned long long mTk = __ballot(taker), mGv = __ballot(giver);
                 if (mGv && __popcll(mTk) >= P.steal_min) {
                     const int lane = (int)(threadIdx.x & 63u);
@@ -923,17 +948,19 @@ k_raytrace(const DevScene S, const FrameParams P)
                     const float ix = __shfl(L.inv.x, v), iy = __shfl(L.inv.y, v), iz = __shfl(L.inv.z, v);
                     const float vdmax = __shfl(L.dmax, v), vlimit = __shfl(L.limit, v), vbest = __shfl(L.best, v);
                     const int vavoid = __shfl(L.avoid, v), vowner = __shfl(L.owner, v), vtame = __shfl(L.tame ? 1 : 0, v);
+                    const int vmode = __shfl(L.mode, v), vbtri = __shfl(L.btri, v);
                     const uint32_t vgive = (uint32_t)__shfl((int)give, v);
                     if (takes) {
                         L.o = mk3(ox, oy, oz); L.d = mk3(dx, dy, dz); L.inv = mk3(ix, iy, iz);
                         L.dmax = vdmax; L.limit = vlimit; L.best = vbest; L.avoid = vavoid; L.owner = vowner; L.tame = vtame != 0;
-                        L.mode = MODE_SHADOW; L.sp = 0; L.base = 0; L.top = MI_END_LINK;
+                        L.mode = vmode; L.btri = vbtri; L.sp = 0; L.base = 0; L.top = MI_END_LINK;
                         L.cur = vgive;
                         const float4 *p = S.walk + (size_t)(vgive & MI_INDEX_MASK);
                         R.a = p[0]; R.b = p[1];
                         if ((vgive & MI_LEAF_BIT) == 0) { R2.a = p[2]; R2.b = p[3]; }
                         n_steal++;
-                        blocked_word = 0u;               // (the word read above was the one of the ray this lane walked before)
+                        took = true;
+                        seen = MI_RESULT_NONE;           // (the word read above was the one of the ray this lane walked before)
                     }
                     if (robbed) {
                         if (deep) L.base++;
@@ -1154,13 +1181,14 @@ k_raytrace(const DevScene S, const FrameParams P)
                     const float dz = distsq3(from, hit);
                     const bool nearer = dz < L.best;
                     if (inside && shadow && nearer) {                // a blocked shadow ray stops (Raytracer.cc:284)
-                        if constexpr (STEAL) { sflag[L.owner] = 1u; L.sp = L.base; } else { L.shadow_hit = true; L.sp = 0; }
+                        if constexpr (STEAL) { ((uint32_t *)result)[2 * L.owner + 1] = 0u; L.sp = L.base; } else { L.shadow_hit = true; L.sp = 0; }
                         L.cur = MI_END_LINK;
                     }
                     // candidates arrive in any order: lowest list position wins among equal distances
                     if (inside && !shadow && (nearer || (dz == L.best && j < L.btri))) {
                         L.best = dz; L.btri = j;
                         L.limit = __builtin_sqrtf(dz) * 1.001f + ray_delta(L.o, S.scene_mag);
+                        if constexpr (STEAL) atomicMin(result + L.owner, result_key(dz, j));
                     }
                 }
                 MI_PHASE(pc_b);
@@ -1189,13 +1217,14 @@ k_raytrace(const DevScene S, const FrameParams P)
                     const float dz = distsq3(from, hit);
                     const bool nearer = dz < L.best;
                     if (inside && shadow && nearer) {                // a blocked shadow ray stops (Raytracer.cc:284)
-                        if constexpr (STEAL) { sflag[L.owner] = 1u; L.sp = L.base; } else { L.shadow_hit = true; L.sp = 0; }
+                        if constexpr (STEAL) { ((uint32_t *)result)[2 * L.owner + 1] = 0u; L.sp = L.base; } else { L.shadow_hit = true; L.sp = 0; }
                         L.cur = MI_END_LINK;
                     }
                     // candidates arrive in any order: lowest list position wins among equal distances
                     if (inside && !shadow && (nearer || (dz == L.best && L.pj < L.btri))) {
                         L.best = dz; L.btri = L.pj;
                         L.limit = __builtin_sqrtf(dz) * 1.001f + ray_delta(L.o, S.scene_mag);
+                        if constexpr (STEAL) atomicMin(result + L.owner, result_key(dz, L.pj));
                     }
                     L.pend = false;
                 }
@@ -1217,12 +1246,38 @@ k_raytrace(const DevScene S, const FrameParams P)
             }
             }
             if constexpr (STEAL) {
-                // a blocker found by anyone ends the ray for everyone who walks a part of it
-                if (blocked_word != 0u && L.mode == MODE_SHADOW) { L.cur = MI_END_LINK; L.sp = L.base; L.pend = false; }
+                if (lent) {
+                    // a blocker found by anyone ends a shadow ray for everyone who walks a part of it; a hit found by anyone bounds
+                    // a closest-hit ray for everyone who walks a part of it
+                    if (L.mode == MODE_SHADOW) {
+                        if ((uint32_t)(seen >> 32) == 0u) { L.cur = MI_END_LINK; L.sp = L.base; L.pend = false; }
+                    } else {
+                        const float sb = __uint_as_float((uint32_t)(seen >> 32));
+                        if (sb < L.best) {
+                            L.best = sb; L.btri = (int)(uint32_t)seen;
+                            L.limit = __builtin_sqrtf(sb) * 1.001f + ray_delta(L.o, S.scene_mag);
+                        }
+                    }
+                }
             }
             const unsigned long long mBusy = __ballot(L.cur != MI_END_LINK || L.pend);
             if (!mBusy) break;
             if (xmin_now < 64 && __popcll(__ballot(alive && L.cur == MI_END_LINK && !L.pend)) >= xmin_now) break;
+        }
+        if constexpr (STEAL) {
+            if (__ballot(took)) {
+                // lanes that walked for others: their own ray had ended before; what it found is in their result word, and what the
+                // shading of a closest-hit ray reads of the ray itself -- origin and direction -- is made again the way it was made
+                if (took) {
+                    L.owner = (int)threadIdx.x;
+                    L.mode = own_closest ? MODE_CLOSEST : MODE_SHADOW;
+                    if (alive && !own_closest) L.btri = (int)(uint32_t)result[threadIdx.x];     // (the hit the shadow ray started on)
+                    if (own_closest) {
+                        if (L.depth == 0) { L.o = cam_eye<BATCH>(P, L.fid); L.d = primary_dir<BATCH>(P, L, L.samples_left); }
+                        else { L.o = L.hit; L.d = mk3(lds_refl[0], lds_refl[256], lds_refl[512]); }
+                    }
+                }
+            }
         }
         } else {
         // ---- walk in the reference's order (threaded links): counting builds, unchecked trees ----
@@ -1546,7 +1601,7 @@ rt_kernel pick_kernel(int stats, int exact, int ordered, int waves, int batch, i
 // (stack rows, verdict row, giver table, three light rows, three rows of reflected directions; 4 spp: three rows of pixel sums)
 // (`rows` as the launcher passes it: three per depth level of the ray tree, the tree's stack rows if the walk is ordered, three
 //  more for a 4 spp frame)
-size_t stack_bytes(int ordered, int rows) { return (size_t)(rows + (ordered ? 8 : 0)) * 256u * sizeof(uint32_t); }
+size_t stack_bytes(int ordered, int rows) { return (size_t)(rows + (ordered ? 9 : 0)) * 256u * sizeof(uint32_t); }
 } // namespace
 
 // can this build render several frames per launch?  (the ordered, non-counting kernels only)
