@@ -103,7 +103,7 @@ typedef struct {
      *            children; where the tree's boxes are exact unions of their children's) instead of the two-wide one
      *            | 256 raytrace: no work sharing inside a wave (default: lanes without a ray of their own walk postponed
      *            subtrees of other lanes' shadow rays -- a shadow ray's verdict is an OR over the triangles its walk reaches)
-     * [6] raytrace: idle lanes of a wave before subtrees are handed over (default 8)
+     * [6] raytrace: idle lanes of a wave before subtrees are handed over (default 16)
      * [7] reserved */
     int32_t tune[8];
     /* Compile-time extras of the reference, off by default like there: */

@@ -345,9 +345,9 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.no_cull = (flags & 16) ? 1 : 0;
     P.no_pipe = (flags & 32) ? 1 : (flags & 64) ? 2 : 0;
     P.quad = (flags & 128) ? 1 : 0;
-    // work sharing inside a wave (k_raytrace.hip): on by default with 8 idle lanes as the threshold; tune[6] sets the threshold,
+    // work sharing inside a wave (k_raytrace.hip): on by default with 16 idle lanes as the threshold; tune[6] sets the threshold,
     // flag 256 turns it off; it needs the wave in lockstep (xmin 64)
-    P.steal_min = ((flags & 256) || P.xmin < 64) ? 0 : (t[6] > 0 ? (t[6] > 64 ? 64 : t[6]) : 8);
+    P.steal_min = ((flags & 256) || P.xmin < 64) ? 0 : (t[6] > 0 ? (t[6] > 64 ? 64 : t[6]) : 16);
     // A profiler collecting hardware counters runs one kernel at a time (rocprofv3 --pmc): frames that wait for each other
     // across streams gain nothing there and were seen to stall for minutes.  MI355_NO_OVERLAP=1 asks for the same.
     static const int no_overlap = [] {

@@ -17,7 +17,7 @@ stream = torch.cuda.current_stream(dev)
 cams = [R.benchmark_frame(k) for k in range(200)]
 B = 8
 bufs = [torch.zeros((H, W), dtype=torch.int32, device=dev) for _ in range(B)]
-variants = [("default", {}), ("noshare", dict(noshare=1)), ("sharemin1", dict(sharemin=1)), ("sharemin4", dict(sharemin=4)), ("sharemin16", dict(sharemin=16)),
+variants = [("default", {}), ("noshare", dict(noshare=1)), ("sharemin1", dict(sharemin=1)), ("sharemin4", dict(sharemin=4)), ("sharemin12", dict(sharemin=12)), ("sharemin16", dict(sharemin=16)), ("sharemin24", dict(sharemin=24)),
             ("sharemin32", dict(sharemin=32)), ("bpc3", dict(bpc=3)), ("bpc3 noshare", dict(bpc=3, noshare=1)), ("bpc3 sharemin16", dict(bpc=3, sharemin=16)), ("bpc3 sharemin4", dict(bpc=3, sharemin=4)), ("bpc2", dict(bpc=2)),
             ("quad", dict(quad=1)), ("quad bpc3", dict(quad=1, bpc=3)), ("quad bpc2", dict(quad=1, bpc=2)),
             # bounds, not variants (other pictures): what is left when shadow rays / reflected rays cost nothing

@@ -206,7 +206,7 @@ def write_coloured_ply(path, verts, faces, colours):
 def test_traced_frames_on_synthetic_meshes_match_the_oracle(case, tmp_path, oracle):
     """Equal hit distances are where an order-free walk could differ from the reference's first-found-wins: identical
     triangles in different colours (every ray has several hits at exactly the same distance) and overlapping coplanar
-    ones.  The production kernel (near-first walk, shadow rays on helper lanes) must give the oracle's pixels."""
+    ones.  The production kernel (near-first walk, parts of a ray's walk done by other lanes of its wave) must give the oracle's pixels."""
     rng = np.random.default_rng({"stacked_duplicates": 11, "coplanar_overlaps": 12, "random_soup": 13}[case])
     if case == "stacked_duplicates":
         v0, f0 = soup(rng, 60, scale=1.0)
@@ -240,3 +240,11 @@ def test_traced_frames_on_synthetic_meshes_match_the_oracle(case, tmp_path, orac
         assert float(np.abs(f32 - of32).max()) == 0.0
         assert (st.normal_rays, st.shadow_rays) == (ost.normal_rays, ost.shadow_rays)
         assert int((img != 0).sum()) > 500, "the case is meant to put the mesh on screen"
+        if frame == 23:
+            # a closest-hit ray walked by several lanes at once (its hit = the atomic minimum of what they find: nearest,
+            # then lowest triangle): at every hand-over threshold and in every register build the same frame, bit for bit
+            for knobs in (dict(sharemin=1), dict(sharemin=1, bpc=3), dict(sharemin=1, bpc=4), dict(sharemin=4, bpc=2), dict(sharemin=40),
+                          dict(noshare=1), dict(sharemin=1, exact=1)):
+                img2, f2, st2 = g.render(9, cam, lights, n, R.default_opts(W, H, tune=R.tune(**knobs)), want_f32=True)
+                assert np.array_equal(img2, oimg) and np.array_equal(f2, of32), knobs
+                assert (st2.normal_rays, st2.shadow_rays) == (ost.normal_rays, ost.shadow_rays), knobs
