@@ -2,13 +2,14 @@
 # after the other and of the default overlapped run, the rasterizer's kernels, the shadow map, frame-by-frame rates, variants.
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
-(timeout 900 python -m pytest tests -m gpu -q -rs 2>&1 | tail -12) > gpurun_out/pytest_full.log
+(timeout 900 python -m pytest tests -m gpu -q -rs --capture=sys 2>&1 | tail -12) > gpurun_out/pytest_full.log
 tail -3 gpurun_out/pytest_full.log
 (timeout 600 python bench.py 2>gpurun_out/bench_full.err | tail -1) > gpurun_out/bench_full.log
 tail -1 gpurun_out/bench_full.log | cut -c1-300
 {
   echo "== scripts/rt_variants.py (dragon 1080p: batches of 8, single frames; work sharing, register builds, four-wide walk, bounds)"; timeout 300 python scripts/rt_variants.py 2>&1 | grep variant
   echo "== scripts/rt_variants.py statue.ply depth 1"; RT_VARIANTS="default,noshare,bpc3,quad" timeout 200 python scripts/rt_variants.py statue.ply 1 2>&1 | grep variant
+  echo "== scripts/rt_variants.py chessboard.tri depth 3"; RT_VARIANTS="default,noshare,bpc3" timeout 200 python scripts/rt_variants.py chessboard.tri 3 2>&1 | grep variant
   echo "== scripts/shadowmap_time.py"; timeout 100 python scripts/shadowmap_time.py 2>&1 | grep "us per"; MI355_SM_LEGACY=1 timeout 100 python scripts/shadowmap_time.py 2>&1 | grep "us per"
   echo "== scripts/raster_pipe_variants.py"; timeout 100 python scripts/raster_pipe_variants.py 2>&1 | tail -1
   echo "== scripts/raytrace_frame_by_frame.py"; timeout 100 python scripts/raytrace_frame_by_frame.py 2>&1 | tail -8

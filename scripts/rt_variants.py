@@ -18,7 +18,7 @@ cams = [R.benchmark_frame(k) for k in range(200)]
 B = 8
 bufs = [torch.zeros((H, W), dtype=torch.int32, device=dev) for _ in range(B)]
 variants = [("default", {}), ("noshare", dict(noshare=1)), ("sharemin1", dict(sharemin=1)), ("sharemin4", dict(sharemin=4)), ("sharemin12", dict(sharemin=12)), ("sharemin16", dict(sharemin=16)), ("sharemin24", dict(sharemin=24)),
-            ("sharemin32", dict(sharemin=32)), ("bpc3", dict(bpc=3)), ("bpc3 noshare", dict(bpc=3, noshare=1)), ("bpc3 sharemin16", dict(bpc=3, sharemin=16)), ("bpc3 sharemin4", dict(bpc=3, sharemin=4)), ("bpc2", dict(bpc=2)),
+            ("sharemin32", dict(sharemin=32)), ("bpc3", dict(bpc=3)), ("bpc3 noshare", dict(bpc=3, noshare=1)), ("bpc3 sharemin16", dict(bpc=3, sharemin=16)), ("bpc3 sharemin4", dict(bpc=3, sharemin=4)), ("bpc2", dict(bpc=2)), ("bpc4", dict(bpc=4)),
             ("quad", dict(quad=1)), ("quad bpc3", dict(quad=1, bpc=3)), ("quad bpc2", dict(quad=1, bpc=2)),
             # bounds, not variants (other pictures): what is left when shadow rays / reflected rays cost nothing
             ("noshadows", dict(_opts=dict(use_shadows=0))), ("noshadows noshare", dict(noshare=1, _opts=dict(use_shadows=0))), ("norefl", dict(_opts=dict(use_reflections=0)))]
