@@ -605,6 +605,9 @@ __global__ void __launch_bounds__(256) k_sm_spans(const ShadowParams Q, const Ro
 // 112-116) without taking the steps -- and walks the row's span; spans of more than SM_LONG pixels are cut into 64 pieces by
 // the whole wave, each piece starting from ff_add of the span's first pixel.  Same plots, same values, same maximum.
 #define SM_LONG 48
+#ifndef SM_COOP
+#define SM_COOP 64      // a span is taken by the whole wave only if it is longer than this many pixels per long span the wave holds
+#endif
 
 // the projected corners of triangle t (Light.cc:100-128): false = rejected (all above / below the map)
 MI_DEV bool sm_project(const DevScene &S, const ShadowParams &Q, uint32_t t, float (&f)[3][3], int (&iy)[3])
@@ -718,8 +721,15 @@ __global__ void __launch_bounds__(256) k_sm_rows(const DevScene S, const ShadowP
                 dx = (r[0] - sx) / fsteps; dz = (r[2] - sz) / fsteps;
             }
         }
-        // short spans: this lane walks its own; long ones: the wave takes them one after the other
-        const bool is_long = steps > SM_LONG && steps < (1 << 22);         // (ff_add's jump arithmetic is exact for chains below 2^22)
+        // short spans: this lane walks its own; long ones: the wave takes them one after the other -- where that is the cheaper
+        // way: a span taken by the wave costs every lane two jumps into its chains (ff_add: ~600 instructions with the pieces'
+        // own pixels), a span walked by its own lane ~10 per pixel beside the other lanes' spans.  So the wave takes over only
+        // what is long against the NUMBER of long spans it holds (a wave full of 100-pixel spans walks them lane by lane).
+        bool is_long = steps > SM_LONG && steps < (1 << 22);               // (ff_add's jump arithmetic is exact for chains below 2^22)
+        {
+            const int n_long = __popcll(__ballot(is_long));
+            is_long = is_long && steps > n_long * SM_COOP;
+        }
         if (steps >= 0 && !is_long) {
             plot_at(row, sx, sz);
             for (int k = steps; k > 0; k--) { sx += dx; sz += dz; plot_at(row, sx, sz); }
