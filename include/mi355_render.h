@@ -101,8 +101,9 @@ typedef struct {
      *            tile kernel, the tile kernels in order on the caller's stream
      *            | 128 raytrace: the four-wide walk (128-byte records holding a node's leaf children and its inner children's
      *            children; where the tree's boxes are exact unions of their children's) instead of the two-wide one
-     *            | 256 raytrace: no work sharing inside a wave (default: lanes without a ray of their own walk postponed
-     *            subtrees of other lanes' shadow rays -- a shadow ray's verdict is an OR over the triangles its walk reaches)
+     *            | 256 raytrace: no work sharing inside a wave (default: lanes with nothing to walk take postponed subtrees of
+     *            other lanes' rays -- a shadow ray's verdict is an OR over the triangles its walk reaches, a closest-hit ray's
+     *            hit the minimum of (distance, triangle) over them: same pixels whoever walks what)
      * [6] raytrace: idle lanes of a wave before subtrees are handed over (default 16)
      * [7] reserved */
     int32_t tune[8];

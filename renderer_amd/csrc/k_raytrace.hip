@@ -31,6 +31,11 @@
 //    record is requested as soon as it is known, and a triangle that passes the plane test has its
 //    edge record requested at the end of the step and judged during the lane's NEXT step -- legal
 //    because a candidate only updates the running best, never the visiting order.
+//  * The same order-free property lets the lanes of a wave SHARE a ray's walk (production builds, STEAL): a lane with nothing
+//    to walk takes the oldest postponed subtree of any lane's ray; what the walkers of one ray find is merged in a 64-bit LDS
+//    word per owner -- atomic min of (distance^2 bits, triangle) for a closest-hit ray, a zeroed upper half for a blocked
+//    shadow ray -- which helpers read back as their culling bound.  The walk itself carries only what a step needs: the hit
+//    point and edge values of the winner are recomputed at shading, colour sums / lights / reflected directions wait in LDS rows.
 //
 // Arithmetic follows the cited reference lines operation by operation (dev_math.h).
 #include "dev_math.h"
