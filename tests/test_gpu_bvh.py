@@ -248,3 +248,73 @@ def test_traced_frames_on_synthetic_meshes_match_the_oracle(case, tmp_path, orac
                 img2, f2, st2 = g.render(9, cam, lights, n, R.default_opts(W, H, tune=R.tune(**knobs)), want_f32=True)
                 assert np.array_equal(img2, oimg) and np.array_equal(f2, of32), knobs
                 assert (st2.normal_rays, st2.shadow_rays) == (ost.normal_rays, ost.shadow_rays), knobs
+
+
+# ---- deep trees: the kernel's LDS (colour rows + one stack row per level + the sharing rows) is sized at launch ------------------
+def chain_tree(vpos, tri_index):
+    """A legal tree as deep as a tree of T triangles can be: inner node k = (leaf of triangle k, inner node k + 1), boxes the exact
+    unions; the reference's node format in its pre-order (Raytracer.cc:651-718: inner: idxLeft, idxRight; leaf: count | 1 << 31, start)."""
+    T = tri_index.shape[0]
+    tv = vpos[tri_index]                                   # (T, 3, 3)
+    lo, hi = tv.min(axis=1).astype(np.float32), tv.max(axis=1).astype(np.float32)
+    slo, shi = lo.copy(), hi.copy()
+    for k in range(T - 2, -1, -1):                         # suffix unions
+        slo[k] = np.minimum(lo[k], slo[k + 1]); shi[k] = np.maximum(hi[k], shi[k + 1])
+    nodes = np.zeros((2 * T - 1, 8), np.uint32)
+    f = nodes[:, :6].view(np.float32)
+    for k in range(T - 1):
+        i = 2 * k                                          # inner k, its leaf at i + 1, the rest at i + 2
+        f[i, :3], f[i, 3:] = slo[k], shi[k]
+        nodes[i, 6], nodes[i, 7] = i + 1, i + 2
+        f[i + 1, :3], f[i + 1, 3:] = lo[k], hi[k]
+        nodes[i + 1, 6], nodes[i + 1, 7] = 0x80000001, k
+    i = 2 * (T - 1)
+    f[i, :3], f[i, 3:] = lo[T - 1], hi[T - 1]
+    nodes[i, 6], nodes[i, 7] = 0x80000001, T - 1
+    return nodes, np.arange(T, dtype=np.int32)
+
+
+@pytest.mark.parametrize("n_tri", [31, 47])
+def test_deep_trees_render_in_every_build(n_tri, tmp_path, oracle):
+    """The ordered walk keeps a stack row per tree level in LDS, beside the colour rows of the ray tree's levels and the rows of
+    the work sharing; all of it is asked for at launch.  The deepest trees the ordered walk accepts (MI_MAX_STACK = 48 levels), the
+    deepest ray trees (4) and 4 spp together must still launch -- in whatever build fits -- and give the oracle's frame over the
+    same tree."""
+    rng = np.random.default_rng(100 + n_tri)
+    tri = rng.uniform(-0.7, 0.7, (n_tri, 1, 3)) + rng.uniform(-0.3, 0.3, (n_tri, 3, 3))       # large enough to fill the picture
+    verts, faces = tri.reshape(-1, 3), np.arange(3 * n_tri).reshape(n_tri, 3)
+    p = str(tmp_path / "deep.ply")
+    write_coloured_ply(p, verts, faces, rng.integers(40, 255, (n_tri, 3)))
+    g = R.Scene(p)
+    a = g.arrays()
+    nodes, idx = chain_tree(np.array(a["vertex_pos"]), np.array(a["tri_index"]))
+    g.set_bvh_arrays(nodes, idx)
+    ok, depth, n_nodes, _ = g.walk_info()
+    assert ok == 1 and depth == n_tri and n_nodes == 2 * n_tri - 1        # (inner levels n_tri - 1, one stack entry more)
+    bvh = str(tmp_path / "deep.bvh")
+    with open(bvh, "wb") as fp:
+        fp.write(np.array([nodes.shape[0], idx.shape[0]], np.uint32).tobytes()); fp.write(nodes.tobytes()); fp.write(idx.tobytes())
+    o = oracle.Scene(p)
+    assert o.bvh_load(bvh) == nodes.shape[0]
+    cam, lights, n = R.benchmark_frame(7)
+    ocam, olights, on = oracle.benchmark_frame(7)
+    W, H = 320, 200
+    for mode, depth_rays in ((9, 3), (9, 4), (10, 4)):
+        want, wf, wst = o.render(mode, ocam, olights, on, oracle.default_opts(W, H, max_ray_depth=depth_rays, threads=os.cpu_count() or 1), want_f32=True)
+        assert int((want != 0).sum()) > 3000
+        for knobs in (dict(), dict(bpc=2), dict(bpc=3), dict(bpc=4), dict(noshare=1), dict(sharemin=1, bpc=4), dict(quad=1), dict(reforder=1)):
+            img, f32, st = g.render(mode, cam, lights, n, R.default_opts(W, H, max_ray_depth=depth_rays, tune=R.tune(**knobs)), want_f32=True)
+            assert np.array_equal(img, want) and np.array_equal(f32, wf), (mode, depth_rays, knobs)
+            assert (st.normal_rays, st.shadow_rays) == (wst.normal_rays, wst.shadow_rays), (mode, depth_rays, knobs)
+    # batches of frames (their own kernel variant), the deepest ray trees
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    frames = [R.benchmark_frame(k) for k in (7, 8, 9, 10)]
+    for knobs in (dict(), dict(bpc=3), dict(bpc=4)):
+        bo = R.default_opts(W, H, max_ray_depth=4, tune=R.tune(**knobs))
+        bufs = [torch.zeros((H, W), dtype=torch.int32, device=dev) for _ in frames]
+        g.render_batch_device(9, [f[0] for f in frames], [f[1] for f in frames], frames[0][2], bo, [b.data_ptr() for b in bufs], W * 4, None,
+                              torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize(dev)
+        for k, f in enumerate(frames):
+            assert np.array_equal(bufs[k].cpu().numpy().view(np.uint32), g.render(9, f[0], f[1], f[2], R.default_opts(W, H, max_ray_depth=4))[0]), (knobs, k)
