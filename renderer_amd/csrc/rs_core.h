@@ -35,6 +35,7 @@
 #define RS_TW 16              // tile width  (pixels)
 #define RS_TH 16              // tile height (pixels)
 #define RS_TPIX (RS_TW * RS_TH)
+#define RS_PIX_BITS (RS_TPIX <= 256 ? 8 : 9)   // bits of a pixel's index in its tile (a run: first pixel | length - 1 << RS_PIX_BITS, 16 bits)
 #define RS_DISPENSERS 16      // counters the tile kernel's blocks draw further tiles from
 #define RS_CB 4               // a coarse bin covers RS_CB x RS_CB tiles
 #define RS_COARSE_MAX 64      // largest coarse box binned bin by bin; beyond: the global bin
@@ -737,7 +738,7 @@ MI_HD void rs_tile_runs(RsTileLds &lds, int tid, int nt)
         if (px > 0 && lds.keys[i - 1] && (uint32_t)(lds.keys[i - 1] & 0xffffffffull) == low) continue;   // not the first of its run
         int len = 1;
         while (px + len < RS_TW && lds.keys[i + len] && (uint32_t)(lds.keys[i + len] & 0xffffffffull) == low) len++;
-        lds.items[RS_ATOMIC_ADD_U32(&lds.n_runs, 1u)] = (uint16_t)((uint32_t)i | ((uint32_t)(len - 1) << 8));
+        lds.items[RS_ATOMIC_ADD_U32(&lds.n_runs, 1u)] = (uint16_t)((uint32_t)i | ((uint32_t)(len - 1) << RS_PIX_BITS));
     }
 }
 
@@ -754,7 +755,7 @@ MI_HD void rs_tile_attr(const FrameParams &P, const RsBuffers &B, uint32_t n_tri
         const uint32_t run = lds.items[it >> 1];
         const int grp = (int)(it & 1u);
         const int k0 = N == 8 ? (grp ? 4 : 1) : (grp ? 3 : 1), nc = N == 8 ? (grp ? 4 : 3) : 2;
-        const int i = (int)(run & 255u), len = (int)(run >> 8) + 1;
+        const int i = (int)(run & ((1u << RS_PIX_BITS) - 1u)), len = (int)(run >> RS_PIX_BITS) + 1;
         const int px = i % RS_TW, row = i / RS_TW;
         const uint32_t tri = 0xffffffffu - (uint32_t)(lds.keys[i] & 0xffffffffull);
         const float *rec = (const float *)(B.rec + ((size_t)frame * n_tris + tri) * RS_REC4);
