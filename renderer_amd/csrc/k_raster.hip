@@ -407,8 +407,11 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
 // filters, [11] depth items, [12] runs, [13] bin entries read, [14] background tiles (cycles), [15] their number.
 #define RS_PROF_MARK(i) do { if (prof && tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); acc[i] += now_ - t_mark; t_mark = now_; } } while (0)
 
-template <int MODE>
-__global__ void __launch_bounds__(RS_MAX_THREADS) k_rs_tile(const DevScene S, const FrameParams P, const FrameParams *batch, int n_frames,
+// OCC = waves per SIMD the registers are allotted for: 4 (125 registers, no scratch) is the faster build for a single frame -- a
+// tile's chain of phases is what a frame waits for --, 5 (96 registers, 64-76 bytes of scratch) for a batch of frames, where one
+// more tile per CU in flight is worth more (measured both ways, profiles/r03_analysis.md).
+template <int MODE, int OCC>
+__global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) k_rs_tile(const DevScene S, const FrameParams P, const FrameParams *batch, int n_frames,
                                                         const RsGrid g, const RsBuffers B, const int clear_rows)
 {
     __shared__ RsTileLds lds;
@@ -906,8 +909,9 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     if (blocks > 2048) blocks = 2048;
     // threads per tile: mi355_opts::tune[3] (64..512, whole waves), default 256
     const int nt = P->rs_threads >= 64 && P->rs_threads <= RS_MAX_THREADS && (P->rs_threads & 63) == 0 ? P->rs_threads : 256;
-    if (piped || whole) hipExtLaunchKernelGGL((k_rs_tile<MODE>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, nullptr, tile_done, 0, *S, *P, d_batch, n_frames, g, s->B, 1);
-    else hipLaunchKernelGGL((k_rs_tile<MODE>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B, 0);
+    if (piped || whole) hipExtLaunchKernelGGL((k_rs_tile<MODE, 4>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, nullptr, tile_done, 0, *S, *P, d_batch, n_frames, g, s->B, 1);
+    else if (n_frames > 1) hipLaunchKernelGGL((k_rs_tile<MODE, 5>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B, 0);
+    else hipLaunchKernelGGL((k_rs_tile<MODE, 4>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B, 0);
     return hipGetLastError();
 }
 
