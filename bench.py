@@ -102,6 +102,9 @@ def main():
                     help="N > 1: 'bands' (= auto) every GPU renders its interleaved screen bands (rows of 8x8 tiles) of every frame "
                          "of the step, one gather assembles the framebuffers (north_star, SURVEY 8e); 'frames' = every GPU renders "
                          "whole frames of the step (every N-th one)")
+    ap.add_argument("--assemble", choices=("auto", "spread", "rank0"), default="auto",
+                    help="N > 1, band sharding: 'spread' = frame j of a step is assembled on rank j % N by one all-to-all exchange per step "
+                         "(no funnel; the default when the frames of a step divide over the ranks), 'rank0' = one gather per step onto rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (rasterizer) workloads")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -152,7 +155,11 @@ def main():
     if args.shard == "frames" and world > 1 and not by_frames:
         raise SystemExit("--shard frames needs a raytrace mode and frames-per-step divisible by the number of GPUs")
     B_local = B // world if by_frames else B          # frames per launch on this GPU
-    gather = multigpu.BatchGatherer(W, H, dev, B_local) if by_frames else multigpu.FrameGatherer(W, H, dev, frames=B)
+    # band sharding: where the frames of a step are put together (renderer_amd/multigpu.py)
+    spread = (not by_frames and B > 1 and B % world == 0 and
+              (args.assemble == "spread" or (args.assemble == "auto" and world > 1)))
+    gather = (multigpu.BatchGatherer(W, H, dev, B_local) if by_frames else
+              multigpu.SpreadAssembler(W, H, dev, frames=B) if spread else multigpu.FrameGatherer(W, H, dev, frames=B))
     my_rows = gather.my_rows
     stream = torch.cuda.current_stream(dev)
 
@@ -176,7 +183,8 @@ def main():
             scene.render_device(args.mode, cam, lights, n, o, buf[0].data_ptr(), W * 4, 0, stream.cuda_stream)
         else:
             scene.render_batch_device(args.mode, [cams[f][0] for f in fs], [cams[f][1] for f in fs], cams[fs[0]][2], o,
-                                      [buf[j].data_ptr() for j in range(B_local)], W * 4, None, stream.cuda_stream)
+                                      [buf[gather.slot_of_frame(j) if spread else j].data_ptr() for j in range(B_local)], W * 4, None,
+                                      stream.cuda_stream)
         gather.gather(slot)
 
     if args.pmc_child:
@@ -304,7 +312,7 @@ def main():
         last = gather.frame((K - 1) & 1)
         nonblack = int((last != 0).sum().item())
         if B > 1:
-            assert all(int((last[j] != 0).sum().item()) > 0 for j in range(B)), "a frame of the last batch is empty"
+            assert all(int((last[j] != 0).sum().item()) > 0 for j in range(last.shape[0])), "a frame of the last batch is empty"
         assert nonblack > 0, "rendered frame is empty"
 
     # ---- N > 1: what the step is made of (render / gather separately) and a weak-scaling run at 1080p
@@ -340,10 +348,12 @@ def main():
         tg = torch.tensor([(time.perf_counter() - t1) * 1e3 / n_g], dtype=torch.float64, device=dev)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         mg["gather_ms_per_step_standalone"] = round(float(tg[0]), 4)
-        recv_bytes = (world - 1) * gather.max_rows * W * 4 * B_local
-        mg["rank0_ingest_bytes_per_step"] = int(recv_bytes)
+        recv_bytes = gather.ingest_bytes_per_step() if spread else (world - 1) * gather.max_rows * W * 4 * B_local
+        mg["assembly"] = ("spread: frame j of a step on rank j % N, one all-to-all exchange per step" if spread else
+                          "rank0: one gather per step onto rank 0")
+        mg["rank0_ingest_bytes_per_step"] = int(recv_bytes)           # (spread: what EVERY rank takes in, rank 0 like the others)
         mg["rank0_ingest_GBs"] = round(recv_bytes / (float(tg[0]) * 1e-3) / 1e9, 2)
-        mg["note"] = ("a step = %d frames of %dx%d sharded over %d ranks by interleaved 8-scanline bands; in the timed region the gather of "
+        mg["note"] = ("a step = %d frames of %dx%d sharded over %d ranks by interleaved 8-scanline bands; in the timed region the exchange of "
                       "step k overlaps the rendering of step k+1 (two buffers)" % (B, W, H, world))
         # (c) weak scaling at 1080p: 8 whole frames per GPU and step, every rank keeps the frames it rendered (no funnel)
         if not args.no_weak and args.mode >= 9:
@@ -392,7 +402,9 @@ def main():
                                    % (args.mesh, args.mode, W, H),
                        "parallelism": ("single GPU" if world == 1 else
                                        "whole frames x%d (GPU r renders every %d-th frame of a step), 1 RCCL gather/step" % (world, world)
-                                       if by_frames else "screen bands x%d, 1 RCCL gather/step" % world),
+                                       if by_frames else
+                                       "screen bands x%d, 1 RCCL all-to-all exchange/step (frame j assembled on rank j %% %d)" % (world, world) if spread
+                                       else "screen bands x%d, 1 RCCL gather/step" % world),
                        "frames_per_step": B, "frames": K * B,
                        "rays_per_frame": round(total_rays / (K * B), 1), "tune": json.loads(args.tune)},
             "frames_per_sec": round(K * B / dt, 3),

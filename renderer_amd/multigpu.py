@@ -1,4 +1,4 @@
-"""Multi-GPU frames: interleaved screen bands + one gather per frame.
+"""Multi-GPU frames: interleaved screen bands + one exchange per step.
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" in CPU tests).
 The scene is replicated; rank r renders the bands b with b % world == r (bands of `band_rows`
@@ -107,6 +107,93 @@ class FrameGatherer:
             if self.pending[s] is not None:
                 self.pending[s].wait()
                 self.pending[s] = None
+
+
+class SpreadAssembler:
+    """Bands of a step of several frames, assembled WHERE THE FRAMES STAY: frame j of a step belongs to rank j % world, every rank
+    sends each frame's bands to the frame's owner and takes in the bands of the frames it owns -- one grouped all-to-all exchange
+    per step instead of a gather.  Rank 0 is no funnel: at N ranks a rank takes in (N - 1) / N of frames / N frames over N - 1
+    links at once (8 ranks, 8 frames of 3840 x 2160: 29 MB per rank and step against 234 MB into rank 0), and every link carries
+    traffic in both directions.  The frames of a step end up spread over the ranks in orbit order (rank r: frames r, r + N, ...):
+    what a presenter that takes frames in turn -- or the next stage of a pipeline -- wants anyway; a caller that needs them all on
+    one device uses FrameGatherer.
+
+    Same interface as FrameGatherer: send_buffer(slot) -> [frames, max_rows, W] (frame j of the step goes to index
+    slot_of_frame(j): the buffer is ordered by destination, so that every peer's chunk is contiguous), gather(slot), frame(slot)
+    -> this rank's frames [frames / world, H, W], drain()."""
+
+    def __init__(self, width: int, height: int, device, frames: int, band_rows: int = BAND_ROWS, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if frames % self.world:
+            raise ValueError("SpreadAssembler: %d frames per step do not divide over %d ranks" % (frames, self.world))
+        self.W, self.H, self.band_rows, self.device = width, height, band_rows, device
+        self.alone = self.world == 1
+        self.frames, self.n_own = frames, frames // self.world
+        self.my_rows = rows_of_rank(height, band_rows, self.world, self.rank)
+        self.max_rows = max(rows_of_rank(height, band_rows, self.world, r) for r in range(self.world))
+        owner, local = row_map(height, band_rows, self.world)
+        self.src_rows = torch.as_tensor(owner * self.max_rows + local, device=device)
+        self.send = [torch.zeros((frames, self.max_rows, width), dtype=torch.int32, device=device) for _ in range(2)]
+        # recv[slot][s] = rank s's bands of the frames this rank owns
+        self.recv = [torch.zeros((self.world, self.n_own, self.max_rows, width), dtype=torch.int32, device=device) for _ in range(2)]
+        self.pending = [None, None]
+
+    def slot_of_frame(self, j: int) -> int:
+        """Index in the send buffer of frame j of the step (frames of one owner side by side)."""
+        return (j % self.world) * self.n_own + j // self.world
+
+    def owned(self, step_frames):
+        """The frames of a step (in orbit order) this rank ends up with."""
+        return list(step_frames)[self.rank::self.world]
+
+    def send_buffer(self, slot: int):
+        self._wait(slot)
+        return self.send[slot]
+
+    def _wait(self, slot: int):
+        if self.pending[slot] is not None:
+            for w in self.pending[slot]:
+                w.wait()
+            self.pending[slot] = None
+
+    def gather(self, slot: int, async_op: bool = True):
+        """The step's exchange: every pair of ranks swaps the bands of each other's frames (grouped point-to-point operations:
+        one ncclGroup on RCCL)."""
+        n = self.n_own
+        self.recv[slot][self.rank].copy_(self.send[slot][self.rank * n:(self.rank + 1) * n])
+        if self.alone:
+            return None
+        ops = []
+        for s in range(self.world):
+            if s == self.rank:
+                continue
+            peer = s if self.group is None else self.dist.get_global_rank(self.group, s)
+            ops.append(self.dist.P2POp(self.dist.isend, self.send[slot][s * n:(s + 1) * n], peer, self.group))
+            ops.append(self.dist.P2POp(self.dist.irecv, self.recv[slot][s], peer, self.group))
+        works = self.dist.batch_isend_irecv(ops)
+        if async_op:
+            self.pending[slot] = works
+        else:
+            for w in works:
+                w.wait()
+        return works
+
+    def frame(self, slot: int):
+        """This rank's frames of the step, [frames / world, H, W] (waits for the exchange)."""
+        self._wait(slot)
+        flat = self.recv[slot].permute(1, 0, 2, 3).reshape(self.n_own, self.world * self.max_rows, self.W)
+        return flat.index_select(1, self.src_rows)
+
+    def ingest_bytes_per_step(self) -> int:
+        return (self.world - 1) * self.n_own * self.max_rows * self.W * 4
+
+    def drain(self):
+        for s in (0, 1):
+            self._wait(s)
 
 
 def frames_of_rank(frames, world: int, rank: int):

@@ -47,6 +47,34 @@ def main():
             open(out_path, "w").write("OK" if ok else "MISMATCH")
         dist.destroy_process_group()
         return
+    if len(sys.argv) > 6 and sys.argv[6] == "spread":          # bands of a step's frames, every frame assembled on its owner (SpreadAssembler)
+        g = multigpu.SpreadAssembler(W, H, torch.device("cpu"), frames=batch)
+        ys = np.arange(H)
+        mine = (ys // multigpu.BAND_ROWS) % world == rank
+        ok = g.my_rows == int(mine.sum())
+        for step in range(frames):
+            fs = [step * batch + j for j in range(batch)]
+            buf = g.send_buffer(step & 1)
+            buf.zero_()
+            for j, f in enumerate(fs):
+                cam, lights, n = O.benchmark_frame(f)
+                o = O.default_opts(W, H, band_rows=multigpu.BAND_ROWS, band_index=rank, band_count=world)
+                buf[g.slot_of_frame(j), : g.my_rows] = torch.from_numpy(s.render(9, cam, lights, n, o)[0][mine].astype(np.int32))
+            g.gather(step & 1)                   # async: the next step's frames render meanwhile
+            got = g.frame(step & 1).numpy().astype(np.uint32)
+            own = g.owned(fs)
+            ok = ok and got.shape == (batch // world, H, W) and own == fs[rank::world]
+            for m, f in enumerate(own):
+                cam, lights, n = O.benchmark_frame(f)
+                full = s.render(9, cam, lights, n, O.default_opts(W, H))[0]
+                ok = ok and bool(np.array_equal(got[m], full)) and int((full != 0).sum()) > 0
+        g.drain()
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank checks the frames it owns
+        if rank == 0:
+            open(out_path, "w").write("OK" if int(flag[0]) == 1 else "MISMATCH")
+        dist.destroy_process_group()
+        return
     g = multigpu.FrameGatherer(W, H, torch.device("cpu"), frames=batch)
     assert g.my_rows == multigpu.rows_of_rank(H, multigpu.BAND_ROWS, world, rank)
     ok = True

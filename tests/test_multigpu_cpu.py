@@ -70,3 +70,19 @@ def test_gloo_whole_frame_sharding_of_a_batch(tmp_path):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert out.read_text() == "OK"
+
+
+@pytest.mark.parametrize("world,batch,size", [(2, 4, ("160", "90")), (4, 4, ("128", "77")), (8, 8, ("128", "133"))])
+def test_gloo_frames_assembled_on_their_owners(tmp_path, world, batch, size):
+    """SpreadAssembler: a step of `batch` frames cut into bands over `world` ranks, frame j assembled on rank j % world by one
+    all-to-all exchange (no funnel into rank 0); every rank checks the frames it ends up with against the unsharded render.
+    (world 8 with 8 frames = the layout bench.py uses for BASELINE config 5; ragged last band.)"""
+    out = tmp_path / "result.txt"
+    port = 29500 + (os.getpid() % 2000) + 20 + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(os.path.dirname(__file__), "_gloo_band_worker.py"), str(out), size[0], size[1], "2", str(batch), "spread"]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert out.read_text() == "OK"
