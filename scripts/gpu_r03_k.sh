@@ -1,5 +1,7 @@
 #!/bin/bash
-# round 3, job K: builds of the library side by side (MI355_RENDER_SO): batches and single frames, then the whole GPU suite
+# round 3, job K: builds of the library side by side: batches and single frames, then the whole GPU suite.
+# Make the builds here first (the GPU box receives built files): for each variant, edit / build / copy renderer_amd/lib/libmi355render.so to
+# renderer_amd/lib/exp/libmi355render_<name>.so, then: gpurun -- 'BUILDS="a b" bash scripts/gpu_r03_k.sh' (renderer_amd loads MI355_RENDER_SO).
 mkdir -p gpurun_out
 : > gpurun_out/r03k_variants.log
 for b in $BUILDS; do
