@@ -22,7 +22,7 @@
 // kernel launchers (defined next to their kernels)
 extern "C" hipError_t mi355i_launch_tile_select(const FrameParams *P, const float4 *boxes, int n_boxes, const uint32_t *order, uint32_t *sel, uint32_t *cnt,
                                                 hipStream_t st);
-extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext, int quad);
+extern "C" int mi355i_raytrace_waves_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext, int quad);
 extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int ordered, int waves, int batch, int ext,
                                              int quad, int stack_depth, int n_blocks, hipStream_t);
 extern "C" hipError_t mi355i_launch_points(const DevScene *, const FrameParams *, int as_triangles, hipStream_t);
@@ -792,9 +792,11 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
             FrameParams Q = P;
             Q.out = fl.fb;
             Q.mlaa = 0;                                   // (the filter runs on the caller's buffer, below)
-            // (frames that share the GPU are a throughput problem: the four-wave build, which loses on a frame alone, wins
-            //  here -- 1080p frame by frame 2640 -> 3170 fps, measured)
-            if (Q.blocks_per_cu == 0) Q.blocks_per_cu = 4;
+            // (frames that share the GPU are a throughput problem: more waves per SIMD than a frame alone would take.  Round 2: the
+            //  four-wave build, 2640 -> 3170 fps frame by frame; round 3: the three-wave build -- no scratch, two triangles per
+            //  step -- 3 650 -> 3 850 fps at 1080p, 925 -> 965 at 4 spp)
+            //  -- up to a 1080p frame's 32 400 tiles; a 3840 x 2160 frame's 129 600 still want the four-wave build: 1 500 against 1 360 fps)
+            if (Q.blocks_per_cu == 0) Q.blocks_per_cu = ((long long)((P.W + 7) / 8) * ((P.n_rows + 7) / 8) > 65536ll) ? 4 : 3;
             Q.work_counter = (uint32_t *)((char *)c->pipe_ctrl[k].p + MI_CTRL_DISPENSER_OFF);
             Q.counters = (unsigned long long *)((char *)c->pipe_ctrl[k].p + 16);
             if (int r = enqueue_frame(c, mode, Q, 0, fl.ps, c->pipe_ctrl[k].p, nullptr, nullptr, nullptr, &c->pipe_sel[k])) return r;
@@ -882,17 +884,20 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
                 // (round 3, with work shared inside the waves: a single 1080p frame is 3 % faster on the three-wave build than on
                 //  the two-wave one -- 0.649 against 0.668 ms -- so the bar for three waves is half of what it is for four)
                 const bool wanted = P.blocks_per_cu == 0 ? work_tiles >= (w == 3 ? 10ll : 20ll) * w * c->n_cus * 4 : P.blocks_per_cu >= w;
-                if (wanted && mi355i_raytrace_blocks_per_cu(0, P.exact_box, 1, w, batch, stack_rows, 0, quad) >= w) { waves = w; break; }
+                // (a block is one wave, so LDS bounds the waves of a CU one by one: a build is worth its registers while it holds at
+                //  least two more waves per CU than the next smaller build would -- a tree two levels too deep for 16 waves of the
+                //  four-wave build still runs 15 of them, not 12)
+                if (wanted && mi355i_raytrace_waves_per_cu(0, P.exact_box, 1, w, batch, stack_rows, 0, quad) >= 4 * (w - 1) + 2) { waves = w; break; }
             }
         }
-        int per_cu = mi355i_raytrace_blocks_per_cu(stats, P.exact_box, ordered, waves, batch, stack_rows, ext, quad);
-        if (per_cu > waves) per_cu = waves;
-        if (P.blocks_per_cu > 0 && P.blocks_per_cu < per_cu) per_cu = P.blocks_per_cu;
-        int n_blocks = per_cu * c->n_cus;
-        const long long lanes_needed = ((long long)P.W * P.n_rows * P.n_frames + 255) / 256;
+        int per_cu = mi355i_raytrace_waves_per_cu(stats, P.exact_box, ordered, waves, batch, stack_rows, ext, quad);      // waves
+        if (per_cu > 4 * waves) per_cu = 4 * waves;
+        if (P.blocks_per_cu > 0 && 4 * P.blocks_per_cu < per_cu) per_cu = 4 * P.blocks_per_cu;
+        int n_blocks = per_cu * c->n_cus;                   // waves of the launch (mi355i_launch_raytrace: one per block)
+        const long long lanes_needed = ((long long)P.W * P.n_rows * P.n_frames + 63) / 64;
         if (n_blocks > lanes_needed) n_blocks = (int)(lanes_needed > 0 ? lanes_needed : 1);
         c->last_blocks = n_blocks;
-        if (P.wave_prof) HIP_TRY(hipMemsetAsync(c->wave_prof.p, 0, (size_t)n_blocks * 4 * 16 * 8, st), -40);
+        if (P.wave_prof) HIP_TRY(hipMemsetAsync(c->wave_prof.p, 0, (size_t)n_blocks * 16 * 8, st), -40);
         // Tiles no camera ray can hit anything in are not handed out at all (they are most of the frame: a tile costs a
         // dispenser round trip, 64 primary rays and a shading phase even when it is background).  Not for counting frames
         // (they count the reference's rays), bands that cut through tile rows, and trees that failed the checks.
@@ -1603,7 +1608,7 @@ int mi355i_fetch_wave_profiles(mi355_ctx *c, unsigned long long *out, int max_wa
 {
     if (!c || !out || !c->wave_prof.p) return fail(-3, "no wave profile");
     if (int r = select_device(c)) return r;
-    int n = c->last_blocks * 4;
+    int n = c->last_blocks;              // (waves)
     if (n > max_waves) n = max_waves;
     HIP_TRY(hipMemcpy(out, c->wave_prof.p, (size_t)n * 16 * 8, hipMemcpyDeviceToHost), -31);
     return n;

@@ -43,6 +43,11 @@
 
 namespace {
 
+// Threads per block of k_raytrace: ONE wavefront.  The waves of the kernel never talk to each other (no barrier, LDS rows indexed
+// by the thread), and a persistent block holds its registers and LDS until its last wave is done: with one wave per block a wave
+// that has finished its tiles frees its share at once for the next launch's blocks, instead of waiting for three neighbours.
+#define RT_BLK 64
+
 enum { MODE_CLOSEST = 0, MODE_SHADOW = 1 };
 
 struct Lane {
@@ -269,12 +274,12 @@ MI_DEV void primary_ray(const FrameParams &P, const DevScene &S, Lane &L, int tr
     L.btri = -1;
 }
 
-// Per-depth local colours live in LDS, one column per lane: lds[(depth*3 + channel)*256 + tid].
+// Per-depth local colours live in LDS, one column per lane: lds[(depth*3 + channel)*RT_BLK + tid].
 // They are written once per shaded hit and read once per pixel, so they are not worth 12 VGPRs.
 MI_DEV void set_c(float *lds, int col, int depth, float r, float g, float b)
 {
-    float *p = lds + depth * 3 * 256 + col;
-    p[0] = r; p[256] = g; p[512] = b;
+    float *p = lds + depth * 3 * RT_BLK + col;
+    p[0] = r; p[RT_BLK] = g; p[2 * RT_BLK] = b;
 }
 
 // Fold the per-depth colours back to front with Pixel::operator+'s clamp at every level
@@ -283,8 +288,8 @@ MI_DEV f3 fold_levels(const float *lds, int depth, float rate)
 {
     f3 a = mk3(0.f, 0.f, 0.f);
     for (int i = depth - 1; i >= 0; i--) {
-        const float *p = lds + i * 3 * 256 + threadIdx.x;
-        a = mk3(addclamp(p[0], rate * a.x), addclamp(p[256], rate * a.y), addclamp(p[512], rate * a.z));
+        const float *p = lds + i * 3 * RT_BLK + threadIdx.x;
+        a = mk3(addclamp(p[0], rate * a.x), addclamp(p[RT_BLK], rate * a.y), addclamp(p[2 * RT_BLK], rate * a.z));
     }
     return a;
 }
@@ -310,8 +315,8 @@ MI_DEV void add_light(const FrameParams &P, const DevScene &S, Lane &L, float *l
             float sp = (float)u8cast(P.specular * i2);
             dr += sp; dg += sp; db += sp;
         }
-        float *c = lds_col + L.depth * 3 * 256 + threadIdx.x;    // color += dColor (the level's colour lives in its LDS column)
-        c[0] += dr; c[256] += dg; c[512] += db;
+        float *c = lds_col + L.depth * 3 * RT_BLK + threadIdx.x;    // color += dColor (the level's colour lives in its LDS column)
+        c[0] += dr; c[RT_BLK] += dg; c[2 * RT_BLK] += db;
     }
 }
 
@@ -511,16 +516,16 @@ MI_DEV uint32_t pick4(uint32_t i, uint32_t a, uint32_t b, uint32_t c, uint32_t d
 // QUAD = the four-wide walk (dev_scene.h): a step tests the four slots of a 128-byte quad record -- the node's leaf children
 // and its inner children's children -- enters the nearest, postpones the others: 0.56 of the binary walk's inner steps.
 template <bool STATS, bool EXACT_BOX, bool ORDERED, int WAVES, bool BATCH, bool EXT = false, bool QUAD = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+__global__ void __launch_bounds__(RT_BLK) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 k_raytrace(const DevScene S, const FrameParams P)
 {
     // LDS, sized at launch (stack_bytes below): first the per-lane colour columns of the ray tree's depth levels, three rows each
     extern __shared__ uint32_t lds_dyn[];
     float *const lds_col = (float *)lds_dyn;
     // LDS (EXT): the refracted ray waiting at each depth level: hit point, direction, triangle to avoid
-    __shared__ float lds_refr[EXT ? MI_MAX_DEPTH * 7 * 256 : 1];
+    __shared__ float lds_refr[EXT ? MI_MAX_DEPTH * 7 * RT_BLK : 1];
     // then (ordered walk only) the per-lane stack of postponed children, one row per level
-    uint32_t *const lds_stack = lds_dyn + 3u * 256u * (uint32_t)P.max_depth;
+    uint32_t *const lds_stack = lds_dyn + 3u * (uint32_t)RT_BLK * (uint32_t)P.max_depth;
     // Work sharing inside a wave (production builds): a shadow ray's verdict is an OR over the triangles its walk reaches, so any
     // part of that walk can be done by any lane.  Lanes without a ray of their own take the oldest postponed subtree of a lane
     // that still walks a shadow ray; a blocker found by anyone is reported in the owner's word of an LDS row.  Two more rows
@@ -532,16 +537,16 @@ k_raytrace(const DevScene S, const FrameParams P)
     // far (atomic min: the nearest hit, the lowest triangle among equals -- the rule of the walk itself), a shadow ray: 0 once a
     // blocker has been found (the upper half; the lower half keeps the triangle the ray starts on, which the lane needs back
     // after it has walked for others); both start at FLT_MAX in the upper half.
-    unsigned long long *const result = (unsigned long long *)(lds_stack + (QUAD ? S.qstack_depth : S.stack_depth) * 256u);
+    unsigned long long *const result = (unsigned long long *)(lds_stack + (QUAD ? S.qstack_depth : S.stack_depth) * (uint32_t)RT_BLK);
     // one row: per wave, rank among the givers of a hand-over -> lane
-    uint32_t *const stab = (uint32_t *)(result + 256) + (threadIdx.x & ~63u);
+    uint32_t *const stab = (uint32_t *)(result + RT_BLK) + (threadIdx.x & ~63u);
     // (work sharing: the light a lane's shadow ray aims at, three rows -- whoever walks a part of that ray looks it up when a
     //  triangle lies across the ray, instead of carrying it through the walk)
-    float *const lds_lp = (float *)(result + 256) + 256;
+    float *const lds_lp = (float *)(result + RT_BLK) + RT_BLK;
     // (ordered builds: a hit's reflected direction waits in three rows while the hit's shadow rays are walked; a 4 spp frame
     //  keeps its pixel sums in three more, which only such a launch allocates)
-    float *const lds_refl = lds_lp + 3 * 256 + threadIdx.x;
-    float *const lds_sum = lds_refl + 3 * 256;
+    float *const lds_refl = lds_lp + 3 * RT_BLK + threadIdx.x;
+    float *const lds_sum = lds_refl + 3 * RT_BLK;
     Lane L;
     bool alive = false;         // lane owns a pixel
     bool want_pixel = true;     // lane needs a (new) pixel
@@ -655,7 +660,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                                     L.px = x; L.fid = fid;
                                     L.py = band_row_to_y(r, P.band_rows, P.band_index, P.band_count);
                                     L.orow = P.compact ? r : L.py;
-                                    if constexpr (ORDERED) { if (P.aa) lds_sum[0] = lds_sum[256] = lds_sum[512] = 0.f; }
+                                    if constexpr (ORDERED) { if (P.aa) lds_sum[0] = lds_sum[RT_BLK] = lds_sum[2 * RT_BLK] = 0.f; }
                                     else L.fr = L.fg = L.fb = 0.f;
                                     L.samples_left = P.aa ? 3 : 0;
                                     primary_ray<BATCH>(P, S, L, L.samples_left);
@@ -711,7 +716,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     } else {
                         if (STATS) n_shaded++;
                         shade_begin(P, S, L, lds_col);
-                        if constexpr (ORDERED) { lds_refl[0] = L.refl.x; lds_refl[256] = L.refl.y; lds_refl[512] = L.refl.z; }
+                        if constexpr (ORDERED) { lds_refl[0] = L.refl.x; lds_refl[RT_BLK] = L.refl.y; lds_refl[2 * RT_BLK] = L.refl.z; }
                         lights = true;
                         if constexpr (EXT) {
                             if (P.use_refr && L.depth + 1 < P.max_depth) {
@@ -721,10 +726,10 @@ k_raytrace(const DevScene S, const FrameParams P)
                                 const float n = n1 / n2;
                                 const float c2 = __builtin_sqrtf(1.f - n * n * (1.f - c1 * c1));
                                 const f3 rd = norm3(add3(mul3(L.d, n), mul3(L.pn, n * c1 - c2)));
-                                float *q = lds_refr + L.depth * 7 * 256 + threadIdx.x;
-                                q[0] = L.hit.x; q[256] = L.hit.y; q[512] = L.hit.z;
-                                q[768] = rd.x; q[1024] = rd.y; q[1280] = rd.z;
-                                q[1536] = __int_as_float(L.btri);
+                                float *q = lds_refr + L.depth * 7 * RT_BLK + threadIdx.x;
+                                q[0] = L.hit.x; q[RT_BLK] = L.hit.y; q[2 * RT_BLK] = L.hit.z;
+                                q[3 * RT_BLK] = rd.x; q[4 * RT_BLK] = rd.y; q[5 * RT_BLK] = rd.z;
+                                q[6 * RT_BLK] = __int_as_float(L.btri);
                                 L.pendmask |= 1u << L.depth;
                             }
                             if (P.ao) {                             // Raytracer.cc:386-417 replaces the ambient term
@@ -806,7 +811,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         L.shadow_hit = false;
                         if constexpr (STEAL) {
                             result[threadIdx.x] = result_key(FLT_MAX, L.btri); L.owner = (int)threadIdx.x;
-                            lds_lp[threadIdx.x] = L.lp.x; lds_lp[256 + threadIdx.x] = L.lp.y; lds_lp[512 + threadIdx.x] = L.lp.z;
+                            lds_lp[threadIdx.x] = L.lp.x; lds_lp[RT_BLK + threadIdx.x] = L.lp.y; lds_lp[2 * RT_BLK + threadIdx.x] = L.lp.z;
                         }
                         begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
                         L.avoid = L.btri;                       // avoidSelf = the triangle just hit (Raytracer.cc:335)
@@ -821,7 +826,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     // all lights done for this hit (its colour is in the level's LDS column): bounce or finish
                     if constexpr (EXT) {
                         if (P.use_refl && L.depth + 1 < P.max_depth) {
-                            L.o = L.hit; L.d = ORDERED ? mk3(lds_refl[0], lds_refl[256], lds_refl[512]) : L.refl; L.avoid = L.btri;
+                            L.o = L.hit; L.d = ORDERED ? mk3(lds_refl[0], lds_refl[RT_BLK], lds_refl[2 * RT_BLK]) : L.refl; L.avoid = L.btri;
                             set_ray_aux(L, S.scene_mag);
                             L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
                             L.nocull = 0u;                          // Raytrace<true>
@@ -832,7 +837,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     } else {
                     L.depth++;
                     if (P.use_refl && L.depth < P.max_depth) {
-                        L.o = L.hit; L.d = ORDERED ? mk3(lds_refl[0], lds_refl[256], lds_refl[512]) : L.refl; L.avoid = L.btri;
+                        L.o = L.hit; L.d = ORDERED ? mk3(lds_refl[0], lds_refl[RT_BLK], lds_refl[2 * RT_BLK]) : L.refl; L.avoid = L.btri;
                         set_ray_aux(L, S.scene_mag);
                         L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
                         if constexpr (STEAL) { result[threadIdx.x] = MI_RESULT_NONE; L.owner = (int)threadIdx.x; }
@@ -846,15 +851,15 @@ k_raytrace(const DevScene S, const FrameParams P)
                 // Raytracer.cc:537-551 bottom up: value = (colour + reflected * rate) + refracted * rate, each + the clamping
                 // Pixel::operator+ (Types.h:137-142); L.path is the node at depth up_d while this loop runs
                 while (up) {
-                    float *a = lds_col + up_d * 3 * 256 + threadIdx.x;
+                    float *a = lds_col + up_d * 3 * RT_BLK + threadIdx.x;
                     bool complete = true;
                     if (up_which == 0u) {
-                        if (P.use_refl) { a[0] = addclamp(a[0], P.refl_rate * up_v.x); a[256] = addclamp(a[256], P.refl_rate * up_v.y); a[512] = addclamp(a[512], P.refl_rate * up_v.z); }
+                        if (P.use_refl) { a[0] = addclamp(a[0], P.refl_rate * up_v.x); a[RT_BLK] = addclamp(a[RT_BLK], P.refl_rate * up_v.y); a[2 * RT_BLK] = addclamp(a[2 * RT_BLK], P.refl_rate * up_v.z); }
                         if (L.pendmask & (1u << up_d)) {
                             L.pendmask &= ~(1u << up_d);
-                            const float *q = lds_refr + up_d * 7 * 256 + threadIdx.x;
-                            L.o = mk3(q[0], q[256], q[512]); L.d = mk3(q[768], q[1024], q[1280]);
-                            L.avoid = __float_as_int(q[1536]);
+                            const float *q = lds_refr + up_d * 7 * RT_BLK + threadIdx.x;
+                            L.o = mk3(q[0], q[RT_BLK], q[2 * RT_BLK]); L.d = mk3(q[3 * RT_BLK], q[4 * RT_BLK], q[5 * RT_BLK]);
+                            L.avoid = __float_as_int(q[6 * RT_BLK]);
                             set_ray_aux(L, S.scene_mag);
                             L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
                             L.nocull = (uint32_t)MI_TWOSIDED_BIT;   // Raytrace<false>
@@ -862,10 +867,10 @@ k_raytrace(const DevScene S, const FrameParams P)
                             begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
                             n_normal++;
                             complete = false; up = false;
-                        } else if (P.use_refr) { a[0] = addclamp(a[0], 0.f); a[256] = addclamp(a[256], 0.f); a[512] = addclamp(a[512], 0.f); }   // too deep: black * rate
-                    } else { a[0] = addclamp(a[0], P.refr_rate * up_v.x); a[256] = addclamp(a[256], P.refr_rate * up_v.y); a[512] = addclamp(a[512], P.refr_rate * up_v.z); }
+                        } else if (P.use_refr) { a[0] = addclamp(a[0], 0.f); a[RT_BLK] = addclamp(a[RT_BLK], 0.f); a[2 * RT_BLK] = addclamp(a[2 * RT_BLK], 0.f); }   // too deep: black * rate
+                    } else { a[0] = addclamp(a[0], P.refr_rate * up_v.x); a[RT_BLK] = addclamp(a[RT_BLK], P.refr_rate * up_v.y); a[2 * RT_BLK] = addclamp(a[2 * RT_BLK], P.refr_rate * up_v.z); }
                     if (complete) {
-                        up_v = mk3(a[0], a[256], a[512]);
+                        up_v = mk3(a[0], a[RT_BLK], a[2 * RT_BLK]);
                         if (up_d == 0) { ar = up_v.x; ag = up_v.y; ab = up_v.z; finish = true; up = false; }
                         else { up_which = L.path & 1u; L.path >>= 1; up_d--; }
                     }
@@ -875,12 +880,12 @@ k_raytrace(const DevScene S, const FrameParams P)
                 // fold c[depth-1] ... c[0] (Raytracer.cc:538-551 with Types.h:137-142)
                 if constexpr (!EXT) {
                 if (P.use_refl) { const f3 a = fold_levels(lds_col, L.depth, P.refl_rate); ar = a.x; ag = a.y; ab = a.z; }
-                else if (L.depth > 0) { ar = lds_col[threadIdx.x]; ag = lds_col[256 + threadIdx.x]; ab = lds_col[512 + threadIdx.x]; }
+                else if (L.depth > 0) { ar = lds_col[threadIdx.x]; ag = lds_col[RT_BLK + threadIdx.x]; ab = lds_col[2 * RT_BLK + threadIdx.x]; }
                 }
                 // finalColor += ... (ordered builds: a one-sample pixel needs no sum of its own, 0 + its colour is the sum)
                 float sr, sg, sb;
                 if constexpr (ORDERED) {
-                    if (P.aa) { sb = lds_sum[512] + ab; sg = lds_sum[256] + ag; sr = lds_sum[0] + ar; lds_sum[0] = sr; lds_sum[256] = sg; lds_sum[512] = sb; }
+                    if (P.aa) { sb = lds_sum[2 * RT_BLK] + ab; sg = lds_sum[RT_BLK] + ag; sr = lds_sum[0] + ar; lds_sum[0] = sr; lds_sum[RT_BLK] = sg; lds_sum[2 * RT_BLK] = sb; }
                     else { sb = 0.f + ab; sg = 0.f + ag; sr = 0.f + ar; }
                 } else { L.fb += ab; L.fg += ag; L.fr += ar; sr = L.fr; sg = L.fg; sb = L.fb; }
                 if (L.samples_left > 0) {
@@ -952,7 +957,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     // a giver hands over the OLDEST node it has postponed (the bottom of its stack): the largest subtree it owes
                     const bool deep = L.sp - L.base >= 2;
                     uint32_t give = L.top;
-                    if (giver && deep) give = stk[L.base * 256];
+                    if (giver && deep) give = stk[L.base * RT_BLK];
                     const bool takes = taker && tr < nG, robbed = giver && gr < nT;
                     const int v = takes ? (int)stab[tr] : lane;
                     const float ox = __shfl(L.o.x, v), oy = __shfl(L.o.y, v), oz = __shfl(L.o.z, v);
@@ -1059,12 +1064,12 @@ k_raytrace(const DevScene S, const FrameParams P)
                     if (s_1 < NONE) {
                         // postpone the others, the farthest first: entry #(sp-1) leaves the register for its row, then #sp .., the
                         // second nearest stays in the register
-                        if (L.sp > 0) stk[(L.sp - 1) * 256] = L.top;
+                        if (L.sp > 0) stk[(L.sp - 1) * RT_BLK] = L.top;
                         L.top = pick4(s_1, l0, l1, l2, l3);
                         if (s_2 < NONE) {
                             const bool four = s_3 < NONE;
-                            stk[(L.sp + (four ? 1 : 0)) * 256] = pick4(s_2, l0, l1, l2, l3);
-                            if (four) { stk[L.sp * 256] = pick4(s_3, l0, l1, l2, l3); L.sp++; }
+                            stk[(L.sp + (four ? 1 : 0)) * RT_BLK] = pick4(s_2, l0, l1, l2, l3);
+                            if (four) { stk[L.sp * RT_BLK] = pick4(s_3, l0, l1, l2, l3); L.sp++; }
                             L.sp++;
                         }
                         L.sp++;
@@ -1113,7 +1118,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     if (hL && hR) {
                         const bool left_first = kL <= kR;
                         next = left_first ? linkL : linkR;
-                        if (L.sp > sbase) stk[(L.sp - 1) * 256] = L.top;
+                        if (L.sp > sbase) stk[(L.sp - 1) * RT_BLK] = L.top;
                         L.top = left_first ? linkR : linkL;
                         L.sp++;
                     } else if (hL) next = linkL;
@@ -1167,7 +1172,7 @@ k_raytrace(const DevScene S, const FrameParams P)
             if (walking && next == MI_END_LINK && L.sp > sbase) {
                 next = L.top;
                 L.sp--;
-                if (L.sp > sbase) L.top = stk[(L.sp - 1) * 256];
+                if (L.sp > sbase) L.top = stk[(L.sp - 1) * RT_BLK];
             }
             if (walking) {
                 L.cur = next;
@@ -1216,7 +1221,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     if constexpr (STEAL) {
                         if (__ballot(inside && shadow)) {
                             const int ow = shadow ? L.owner : (int)threadIdx.x;
-                            const f3 lp = mk3(lds_lp[ow], lds_lp[256 + ow], lds_lp[512 + ow]);
+                            const f3 lp = mk3(lds_lp[ow], lds_lp[RT_BLK + ow], lds_lp[2 * RT_BLK + ow]);
                             if (shadow) from = lp;
                         }
                     } else if (shadow) from = L.lp;
@@ -1252,7 +1257,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     if constexpr (STEAL) {
                         if (__ballot(inside && shadow)) {
                             const int ow = shadow ? L.owner : (int)threadIdx.x;
-                            const f3 lp = mk3(lds_lp[ow], lds_lp[256 + ow], lds_lp[512 + ow]);
+                            const f3 lp = mk3(lds_lp[ow], lds_lp[RT_BLK + ow], lds_lp[2 * RT_BLK + ow]);
                             if (shadow) from = lp;
                         }
                     } else if (shadow) from = L.lp;
@@ -1316,7 +1321,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     if (alive && !own_closest) L.btri = (int)(uint32_t)result[threadIdx.x];     // (the hit the shadow ray started on)
                     if (own_closest) {
                         if (L.depth == 0) { L.o = cam_eye<BATCH>(P, L.fid); L.d = primary_dir<BATCH>(P, L, L.samples_left); }
-                        else { L.o = L.hit; L.d = mk3(lds_refl[0], lds_refl[256], lds_refl[512]); }
+                        else { L.o = L.hit; L.d = mk3(lds_refl[0], lds_refl[RT_BLK], lds_refl[2 * RT_BLK]); }
                     }
                 }
             }
@@ -1431,7 +1436,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                 atomicMax(&P.counters[CS_TIME0 + 2], __builtin_amdgcn_s_memrealtime());
                 atomicMax(&P.counters[CS_TIME0 + 3], it_loops);      // most loop iterations done by one wave
                 if (P.wave_prof) {
-                    unsigned long long *w = P.wave_prof + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * 16u;
+                    unsigned long long *w = P.wave_prof + (size_t)(blockIdx.x * (uint32_t)(RT_BLK / 64) + (threadIdx.x >> 6)) * 16u;
                     for (int i = 0; i < 15; i++) w[i] = prof[i];
                     w[15] = it_loops;
                 }
@@ -1643,14 +1648,15 @@ rt_kernel pick_kernel(int stats, int exact, int ordered, int waves, int batch, i
 // (stack rows, verdict row, giver table, three light rows, three rows of reflected directions; 4 spp: three rows of pixel sums)
 // (`rows` as the launcher passes it: three per depth level of the ray tree, the tree's stack rows if the walk is ordered, three
 //  more for a 4 spp frame)
-size_t stack_bytes(int ordered, int rows) { return (size_t)(rows + (ordered ? 9 : 0)) * 256u * sizeof(uint32_t); }
+size_t stack_bytes(int ordered, int rows) { return (size_t)(rows + (ordered ? 9 : 0)) * (size_t)RT_BLK * sizeof(uint32_t); }
 } // namespace
 
 // can this build render several frames per launch?  (the ordered, non-counting kernels only)
 extern "C" int mi355i_raytrace_can_batch(int stats, int ordered) { return ordered && !stats; }
 
-// blocks per CU the (stats, exact, ordered, waves, batch, quad) variant can hold with `stack_depth` rows of LDS asked for by the launcher
-extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext, int quad)
+// waves per CU the (stats, exact, ordered, waves, batch, quad) variant can hold with `stack_depth` rows of LDS asked for by the
+// launcher (a block is one wave: registers and LDS bound the count wave by wave, not in steps of four)
+extern "C" int mi355i_raytrace_waves_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext, int quad)
 {
     constexpr int MAX_ROWS = MI_MAX_QSTACK + 3 * MI_MAX_DEPTH + 3;
     static int cache[2][2][2][2][2][3][2][MAX_ROWS + 1];        // 0 = not asked yet
@@ -1659,17 +1665,18 @@ extern "C" int mi355i_raytrace_blocks_per_cu(int stats, int exact, int ordered, 
     int &slot = cache[quad ? 1 : 0][ext ? 1 : 0][stats ? 1 : 0][exact ? 1 : 0][ordered ? 1 : 0][w][batch ? 1 : 0][stack_depth];
     if (!slot) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_kernel(stats, exact, ordered, waves, batch, ext, quad), 256, stack_bytes(ordered, stack_depth)) != hipSuccess || nb < 1)
-            nb = 2;
-        slot = nb > 8 ? 8 : nb;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_kernel(stats, exact, ordered, waves, batch, ext, quad), RT_BLK, stack_bytes(ordered, stack_depth)) != hipSuccess || nb < 1)
+            nb = 8;
+        nb *= RT_BLK / 64;
+        slot = nb > 32 ? 32 : nb;
     }
     return slot;
 }
 
 // stack_depth = rows of the per-lane LDS stack (DevScene::stack_depth, or qstack_depth for the four-wide walk)
 extern "C" hipError_t mi355i_launch_raytrace(const DevScene *S, const FrameParams *P, int stats, int exact, int ordered, int waves,
-                                             int batch, int ext, int quad, int stack_depth, int n_blocks, hipStream_t st)
+                                             int batch, int ext, int quad, int stack_depth, int n_waves, hipStream_t st)
 {
-    hipLaunchKernelGGL(pick_kernel(stats, exact, ordered, waves, batch, ext, quad), dim3(n_blocks), dim3(256), stack_bytes(ordered, stack_depth), st, *S, *P);
+    hipLaunchKernelGGL(pick_kernel(stats, exact, ordered, waves, batch, ext, quad), dim3((n_waves * 64 + RT_BLK - 1) / RT_BLK), dim3(RT_BLK), stack_bytes(ordered, stack_depth), st, *S, *P);
     return hipGetLastError();
 }

@@ -8,3 +8,4 @@ echo "== chessboard" >> gpurun_out/r03p_variants.log; RT_VARIANTS="default,bpc3"
 cat gpurun_out/r03p_variants.log
 timeout 1200 python -m pytest tests -m gpu -x -q --capture=sys > gpurun_out/r03p_pytest.log 2>&1
 tail -5 gpurun_out/r03p_pytest.log | cut -c1-300
+echo "== frame by frame" ; timeout 100 python scripts/raytrace_frame_by_frame.py 2>&1 | tail -8 | tee -a gpurun_out/r03p_variants.log

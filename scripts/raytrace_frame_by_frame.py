@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import renderer_amd as R
-W, H = 1920, 1080
+W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
 s = R.Scene(R.assets.mesh_path("dragon_vis.ply")); s.bvh_create()
 dev = torch.device("cuda", 0); stream = torch.cuda.current_stream(dev)
 buf = torch.zeros((H, W), dtype=torch.int32, device=dev)
