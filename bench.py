@@ -10,11 +10,16 @@ call into host memory), the rasterizer (`roofline_raster`, configs[1]) and the C
 
 N > 1 (BASELINE.json configs[4]): dragon at 3840x2160, a step = 8 frames of the orbit whatever N is ("scaling": "strong"):
 every rank renders its interleaved 8-scanline bands of the 8 frames in one launch and ONE RCCL gather per step
-assembles them on rank 0.  `multi_gpu` reports render, gather and rank-0 ingest separately, and a short weak-scaling run
-at 1080p (8 whole frames per GPU and step, frames stay on the GPU that rendered them: no funnel).
+assembles them on rank 0 (north_star: "a single RCCL gather over xGMI"; `value` is this region's).  A second region in the
+same invocation assembles every frame on the rank that keeps it instead (one all-to-all exchange per step, no funnel);
+`multi_gpu` reports both: step period, the slowest / fastest rank's render-only time, the exchange alone, a rank's ingest
+rate, and a short weak-scaling run at 1080p (8 whole frames per GPU and step, no exchange).
 
-Usage: python bench.py [--gpus N] [--steps K] [--warmup W]
-       (N>1 is launched by torch.distributed.run, one rank per GPU)
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--dry-run]
+       `--gpus N` without WORLD_SIZE in the environment starts itself under torch.distributed.run, one rank per GPU (the
+       driver's own torchrun command line works as before: then WORLD_SIZE is set and must equal N).
+       `--dry-run` (N > 1): all N ranks on cuda:0, the exchange staged through host memory over gloo -- every line of the
+       N > 1 script path runs on a one-GPU box; the line says "transport": "dryrun" and is no scaling measurement.
 """
 from __future__ import annotations
 
@@ -85,6 +90,23 @@ def pmc_in_run(py_args, seconds=90):
     return {k: v[0] / v[1] for k, v in acc.items()}, "%d launches per counter, %.0f s" % (min(v[1] for v in acc.values()), time.perf_counter() - t_all)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: run the same command line under torch.distributed.run, one rank per
+    GPU on this node (127.0.0.1 rendezvous on a free port); returns the launcher's exit code.  Rank 0's JSON line is the child's
+    stdout, passed through."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,9 +124,14 @@ def main():
                     help="N > 1: 'bands' (= auto) every GPU renders its interleaved screen bands (rows of 8x8 tiles) of every frame "
                          "of the step, one gather assembles the framebuffers (north_star, SURVEY 8e); 'frames' = every GPU renders "
                          "whole frames of the step (every N-th one)")
-    ap.add_argument("--assemble", choices=("auto", "spread", "rank0"), default="auto",
-                    help="N > 1, band sharding: 'spread' = frame j of a step is assembled on rank j % N by one all-to-all exchange per step "
-                         "(no funnel; the default when the frames of a step divide over the ranks), 'rank0' = one gather per step onto rank 0")
+    ap.add_argument("--assemble", choices=("rank0", "spread"), default="rank0",
+                    help="N > 1, band sharding, the region `value` is taken from: 'rank0' = one gather per step onto rank 0 (north_star; the "
+                         "default), 'spread' = frame j of a step is assembled on rank j %% N by one all-to-all exchange per step.  The other "
+                         "of the two is timed as a second region and reported in multi_gpu (unless --one-assembly)")
+    ap.add_argument("--one-assembly", action="store_true", help="N > 1: time only the --assemble region")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="N > 1 on ONE GPU: every rank renders on cuda:0 and the exchange is staged through host memory over gloo; "
+                         "runs the whole N > 1 path, measures nothing about scaling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (rasterizer) workloads")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -113,9 +140,22 @@ def main():
     ap.add_argument("--pmc-child", action="store_true", help="(internal) a few launches of the bench workload and nothing else: run under rocprofv3 --pmc")
     ap.add_argument("--repeats", type=int, default=4, help="re-run the timed region this many more times for the spread (N = 1)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
     import numpy as np
     import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    n_dev = torch.cuda.device_count()
+    if args.gpus > 1 and not args.dry_run and n_dev < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible on this box (use --dry-run to run the N > 1 path on one GPU)"
+                         % (args.gpus, n_dev))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # one process per GPU: start ourselves under torch.distributed.run, exactly as the driver would
+        sys.exit(self_launch(args.gpus))
+
     import torch.distributed as dist
 
     import renderer_amd as R
@@ -124,15 +164,39 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's --nproc-per-node and --gpus must agree" % (args.gpus, world))
+    dry = bool(args.dry_run and world > 1)
+    if dry:
+        local_rank = 0                       # every rank plays its part on the one GPU there is
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def all_reduce(values, op="sum"):
+        """A few doubles reduced over the ranks (on the device with RCCL, on the host in a dry run)."""
+        if world == 1:
+            return [float(v) for v in values]
+        t = torch.tensor(list(values), dtype=torch.float64, device="cpu" if dry else dev)
+        dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op])
+        return [float(v) for v in t]
+
+    def all_gather(value):
+        if world == 1:
+            return [float(value)]
+        t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if dry else dev)
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [float(o[0]) for o in out]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
 
     K, WU = args.steps, args.warmup
     W = args.width or (3840 if world > 1 else 1920)
@@ -155,11 +219,22 @@ def main():
     if args.shard == "frames" and world > 1 and not by_frames:
         raise SystemExit("--shard frames needs a raytrace mode and frames-per-step divisible by the number of GPUs")
     B_local = B // world if by_frames else B          # frames per launch on this GPU
-    # band sharding: where the frames of a step are put together (renderer_amd/multigpu.py)
-    spread = (not by_frames and B > 1 and B % world == 0 and
-              (args.assemble == "spread" or (args.assemble == "auto" and world > 1)))
-    gather = (multigpu.BatchGatherer(W, H, dev, B_local) if by_frames else
-              multigpu.SpreadAssembler(W, H, dev, frames=B) if spread else multigpu.FrameGatherer(W, H, dev, frames=B))
+    # band sharding: where the frames of a step are put together (renderer_amd/multigpu.py).  The region `value` comes from is
+    # north_star's single gather onto rank 0 unless --assemble spread; the other assembly is a second region (multi_gpu).
+    can_spread = not by_frames and world > 1 and B > 1 and B % world == 0
+    if args.assemble == "spread" and world > 1 and not can_spread:
+        raise SystemExit("--assemble spread needs band sharding and frames-per-step divisible by the number of GPUs")
+
+    def make_assembler(kind):
+        if kind == "frames":
+            return multigpu.BatchGatherer(W, H, dev, B_local)
+        if kind == "spread":
+            return multigpu.SpreadAssembler(W, H, dev, frames=B, staged=dry)
+        return multigpu.FrameGatherer(W, H, dev, frames=B, staged=dry)
+
+    primary = "frames" if by_frames else ("spread" if (can_spread and args.assemble == "spread") else "rank0")
+    gather = make_assembler(primary)
+    spread = primary == "spread"
     my_rows = gather.my_rows
     stream = torch.cuda.current_stream(dev)
 
@@ -171,9 +246,11 @@ def main():
         fs = [(k * B + j) % N_CAMS for j in range(B)]
         return multigpu.frames_of_rank(fs, world, rank) if by_frames else fs
 
-    def enqueue(k, o, slot):
-        """One step: the next B frames of the orbit in one launch, then one gather (N>1)."""
-        buf = gather.send_buffer(slot)
+    def enqueue(k, o, slot, g=None, exchange=True):
+        """One step: the next B frames of the orbit in one launch, then one exchange (N>1) through assembler g."""
+        g = g or gather
+        to_owner = isinstance(g, multigpu.SpreadAssembler)
+        buf = g.send_buffer(slot)
         fs = frames_of_step(k)
         if B == 1:
             cam, lights, n = cams[fs[0]]
@@ -183,9 +260,31 @@ def main():
             scene.render_device(args.mode, cam, lights, n, o, buf[0].data_ptr(), W * 4, 0, stream.cuda_stream)
         else:
             scene.render_batch_device(args.mode, [cams[f][0] for f in fs], [cams[f][1] for f in fs], cams[fs[0]][2], o,
-                                      [buf[gather.slot_of_frame(j) if spread else j].data_ptr() for j in range(B_local)], W * 4, None,
+                                      [buf[g.slot_of_frame(j) if to_owner else j].data_ptr() for j in range(B_local)], W * 4, None,
                                       stream.cuda_stream)
-        gather.gather(slot)
+        if exchange:
+            g.gather(slot)
+
+    def timed_region(g, o, steps, warm):
+        """`warm` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides: wall seconds (max over
+        ranks) and the launch stream's HIP-event milliseconds of this rank."""
+        for k in range(warm):
+            enqueue(k, o, k & 1, g)
+        g.drain()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for k in range(steps):
+            enqueue(k, o, k & 1, g)
+        e1.record(stream)
+        g.drain()
+        torch.cuda.synchronize(dev)
+        barrier()
+        torch.cuda.synchronize(dev)
+        d = time.perf_counter() - t0
+        return all_reduce([d], "max")[0], e0.elapsed_time(e1)
 
     if args.pmc_child:
         # launches one after the other, as the roofline's kernel_ms times them (the library does not overlap calls while a profiler
@@ -204,6 +303,7 @@ def main():
         o_own.band_rows, o_own.band_index, o_own.band_count, o_own.compact_rows = multigpu.BAND_ROWS, rank, world, 1
     used = sorted({f for k in range(K) for f in frames_of_step(k)})
     rays_f = np.zeros(N_CAMS, np.float64)
+    culled_f = np.zeros(N_CAMS, np.float64)      # camera rays of tiles the production launch sets to black without tracing them
     abytes_f = np.zeros(N_CAMS, np.float64)
     obytes_f = np.zeros(N_CAMS, np.float64)      # the ordered walk's own bytes (raytrace modes)
     scratch = torch.zeros((gather.max_rows, W), dtype=torch.int32, device=dev)
@@ -218,42 +318,22 @@ def main():
             scene.render_device(args.mode, cam, lights, n, o_own, scratch.data_ptr(), W * 4, 0, stream.cuda_stream)
             torch.cuda.synchronize(dev)
             obytes_f[f] = own_bytes(scene.fetch_stats().as_dict(), W, my_rows)
+            # (the production frame itself, one launch by itself: how many of its camera rays the tile culling never generates)
+            t_c = dict(json.loads(args.tune)); t_c["nopipe"] = 1
+            o_c = R.default_opts(W, H, tune=t_c)
+            o_c.band_rows, o_c.band_index, o_c.band_count, o_c.compact_rows = o_own.band_rows, o_own.band_index, o_own.band_count, o_own.compact_rows
+            scene.render_device(args.mode, cam, lights, n, o_c, scratch.data_ptr(), W * 4, 0, stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            culled_f[f] = scene.culled_rays()
     my_rays = sum(rays_f[f] for k in range(K) for f in frames_of_step(k))
     my_abytes = sum(abytes_f[f] for k in range(K) for f in frames_of_step(k))
-    if world > 1:
-        t = torch.tensor([my_rays, my_abytes], dtype=torch.float64, device=dev)
-        dist.all_reduce(t)
-        total_rays, total_abytes = float(t[0]), float(t[1])
-    else:
-        total_rays, total_abytes = float(my_rays), float(my_abytes)
+    my_culled = sum(culled_f[f] for k in range(K) for f in frames_of_step(k))
+    total_rays, total_abytes, total_culled = all_reduce([my_rays, my_abytes, my_culled])
 
-    # ---- warmup
+    # ---- W untimed warmup steps, then the timed region: exactly K steps, barrier + synchronize on both sides, max over ranks
+    #      (gpu_ms: HIP events on the launch stream around the K launches)
     o_run = opts()
-    for k in range(WU):
-        enqueue(k, o_run, k & 1)
-    gather.drain()
-
-    # ---- timed region: exactly K frames, barrier + synchronize on both sides, max over ranks
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for k in range(K):
-        enqueue(k, o_run, k & 1)
-    ev1.record(stream)
-    gather.drain()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)        # HIP events on the launch stream: GPU time of the K launches
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
+    dt, gpu_ms = timed_region(gather, o_run, K, WU)
 
     # ---- the same K-step region a few more times (N = 1): the spread of ms_per_step; `value` stays the first region's
     repeats = None
@@ -315,47 +395,75 @@ def main():
             assert all(int((last[j] != 0).sum().item()) > 0 for j in range(last.shape[0])), "a frame of the last batch is empty"
         assert nonblack > 0, "rendered frame is empty"
 
-    # ---- N > 1: what the step is made of (render / gather separately) and a weak-scaling run at 1080p
+    # ---- N > 1: what the step is made of, for both assemblies (north_star's gather onto rank 0, and every frame assembled on the
+    #      rank that keeps it), and a weak-scaling run at 1080p
     mg = None
     if world > 1:
-        mg = {}
-        # (a) render only: the same launches, no collective
-        torch.cuda.synchronize(dev); dist.barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n_r = max(4, K // 4)
-        e0.record(stream)
-        for k in range(n_r):
-            buf = gather.send[k & 1]
-            fs = frames_of_step(k)
-            if B_local > 1:
-                scene.render_batch_device(args.mode, [cams[f][0] for f in fs], [cams[f][1] for f in fs], cams[fs[0]][2], o_run,
-                                          [buf[j].data_ptr() for j in range(B_local)], W * 4, None, stream.cuda_stream)
-            else:
-                cam, lights, n = cams[fs[0]]
-                scene.render_device(args.mode, cam, lights, n, o_run, (buf[0] if B > 1 else buf).data_ptr(), W * 4, 0, stream.cuda_stream)
-        e1.record(stream)
-        torch.cuda.synchronize(dev)
-        t = torch.tensor([e0.elapsed_time(e1) / n_r], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        mg["render_ms_per_step_slowest_rank"] = round(float(t[0]), 4)
-        # (b) gather only: the collective on already rendered buffers, one at a time
-        dist.barrier(); torch.cuda.synchronize(dev)
-        n_g = max(4, K // 4)
-        t1 = time.perf_counter()
-        for k in range(n_g):
-            gather.gather(k & 1, async_op=False)
-        torch.cuda.synchronize(dev)
-        tg = torch.tensor([(time.perf_counter() - t1) * 1e3 / n_g], dtype=torch.float64, device=dev)
-        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-        mg["gather_ms_per_step_standalone"] = round(float(tg[0]), 4)
-        recv_bytes = gather.ingest_bytes_per_step() if spread else (world - 1) * gather.max_rows * W * 4 * B_local
-        mg["assembly"] = ("spread: frame j of a step on rank j % N, one all-to-all exchange per step" if spread else
-                          "rank0: one gather per step onto rank 0")
-        mg["rank0_ingest_bytes_per_step"] = int(recv_bytes)           # (spread: what EVERY rank takes in, rank 0 like the others)
-        mg["rank0_ingest_GBs"] = round(recv_bytes / (float(tg[0]) * 1e-3) / 1e9, 2)
-        mg["note"] = ("a step = %d frames of %dx%d sharded over %d ranks by interleaved 8-scanline bands; in the timed region the exchange of "
-                      "step k overlaps the rendering of step k+1 (two buffers)" % (B, W, H, world))
-        # (c) weak scaling at 1080p: 8 whole frames per GPU and step, every rank keeps the frames it rendered (no funnel)
+        mg = {"transport": "dryrun: %d ranks on ONE GPU (cuda:0), exchange staged through host memory over gloo -- exercises the N > 1 "
+                           "script path, measures nothing about scaling" % world if dry else "rccl (torch.distributed backend nccl = RCCL over xGMI)",
+              "sharding": ("whole frames: rank r renders every %d-th frame of a step" % world if by_frames else
+                           "interleaved %d-scanline bands: band b -> rank b %% %d, compact [frames][rows][W] buffers" % (multigpu.BAND_ROWS, world)),
+              "step": "%d frames of %dx%d" % (B, W, H)}
+
+        def render_only(g):
+            """The same launches into g's send buffers, no exchange: ms per step of every rank."""
+            torch.cuda.synchronize(dev); barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n_r = max(4, K // 4)
+            for k in range(2):
+                enqueue(k, o_run, k & 1, g, exchange=False)
+            torch.cuda.synchronize(dev)
+            e0.record(stream)
+            for k in range(n_r):
+                enqueue(k, o_run, k & 1, g, exchange=False)
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            return all_gather(e0.elapsed_time(e1) / n_r)
+
+        def exchange_only(g):
+            """The exchange on already rendered buffers, one at a time: ms per step (slowest rank)."""
+            barrier(); torch.cuda.synchronize(dev)
+            n_g = max(4, K // 4)
+            g.gather(0, async_op=False)
+            torch.cuda.synchronize(dev); barrier()
+            t1 = time.perf_counter()
+            for k in range(n_g):
+                g.gather(k & 1, async_op=False)
+            torch.cuda.synchronize(dev)
+            return all_reduce([(time.perf_counter() - t1) * 1e3 / n_g], "max")[0]
+
+        def describe(g, kind, d_wall):
+            per_rank = render_only(g)
+            ex_ms = exchange_only(g)
+            ingest = g.ingest_bytes_per_step() if hasattr(g, "ingest_bytes_per_step") else (world - 1) * g.max_rows * W * 4 * B_local
+            return {"assembly": {"rank0": "one gather per step onto rank 0 (north_star: a single RCCL gather assembles the framebuffer)",
+                                 "spread": "frame j of a step assembled on rank j % N: one grouped all-to-all exchange per step, no funnel",
+                                 "frames": "whole frames gathered onto rank 0 in orbit order"}[kind],
+                    "ms_per_step": round(d_wall * 1e3 / K, 5), "frames_per_sec": round(K * B / d_wall, 3), "Mrays_per_s": round(total_rays / d_wall / 1e6, 3),
+                    "render_ms": {"min": round(min(per_rank), 4), "max": round(max(per_rank), 4), "per_rank": [round(v, 4) for v in per_rank],
+                                  "note": "the same launches without the exchange, HIP events on every rank's launch stream"},
+                    "exchange_ms": round(ex_ms, 4),
+                    "ingest_bytes_per_step": int(ingest),
+                    "ingest_GBs": round(ingest / (ex_ms * 1e-3) / 1e9, 2),
+                    "ingest_note": ("what rank 0 takes in per step" if kind != "spread" else "what EVERY rank takes in per step") +
+                                   ", over the standalone exchange's time; in the timed region the exchange of step k runs under the render of step k + 1 (two buffers)"}
+
+        mg[primary] = describe(gather, primary, dt)
+        mg["value_from"] = primary
+        other = None if (by_frames or args.one_assembly) else ("spread" if primary == "rank0" else "rank0")
+        if other == "spread" and not can_spread:
+            mg["spread"] = {"skipped": "frames-per-step %d does not divide over %d ranks" % (B, world)}
+            other = None
+        if other:
+            g2 = make_assembler(other)
+            d2, _ = timed_region(g2, o_run, K, min(WU, 3))
+            if rank == 0 or other == "spread":
+                fr = g2.frame((K - 1) & 1)
+                ok2 = all(int((fr[j] != 0).sum().item()) > 0 for j in range(fr.shape[0])) if fr is not None and fr.dim() == 3 else True
+                assert ok2, "a frame of the second region's last step is empty"
+            mg[other] = describe(g2, other, d2)
+            del g2
+        # weak scaling at 1080p: 8 whole frames per GPU and step, every rank keeps the frames it rendered (no exchange)
         if not args.no_weak and args.mode >= 9:
             w_W, w_H = 1920, 1080
             wo = R.default_opts(w_W, w_H, tune=json.loads(args.tune))
@@ -366,16 +474,15 @@ def main():
                                           [b.data_ptr() for b in wbuf], w_W * 4, None, stream.cuda_stream)
             for k in range(3):
                 wstep(k)
-            torch.cuda.synchronize(dev); dist.barrier(); torch.cuda.synchronize(dev)
+            torch.cuda.synchronize(dev); barrier(); torch.cuda.synchronize(dev)
             n_w = max(10, K // 2)
             t1 = time.perf_counter()
             for k in range(n_w):
                 wstep(k)
-            torch.cuda.synchronize(dev); dist.barrier(); torch.cuda.synchronize(dev)
-            tw = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-            mg["weak_1080p"] = {"frames_per_step_per_gpu": 8, "steps": n_w, "frames_per_sec": round(n_w * 8 * world / float(tw[0]), 2),
-                                "ms_per_step": round(float(tw[0]) * 1e3 / n_w, 4),
+            torch.cuda.synchronize(dev); barrier(); torch.cuda.synchronize(dev)
+            tw = all_reduce([time.perf_counter() - t1], "max")[0]
+            mg["weak_1080p"] = {"frames_per_step_per_gpu": 8, "steps": n_w, "frames_per_sec": round(n_w * 8 * world / tw, 2),
+                                "ms_per_step": round(tw * 1e3 / n_w, 4),
                                 "note": "every GPU renders 8 whole 1080p frames of the orbit per step and keeps them (no gather): the work per GPU is fixed"}
 
     result = None
@@ -404,12 +511,21 @@ def main():
                                        "whole frames x%d (GPU r renders every %d-th frame of a step), 1 RCCL gather/step" % (world, world)
                                        if by_frames else
                                        "screen bands x%d, 1 RCCL all-to-all exchange/step (frame j assembled on rank j %% %d)" % (world, world) if spread
-                                       else "screen bands x%d, 1 RCCL gather/step" % world),
+                                       else "screen bands x%d, 1 RCCL gather/step onto rank 0" % world) + (" [DRY RUN: all ranks on one GPU, gloo]" if dry else ""),
                        "frames_per_step": B, "frames": K * B,
-                       "rays_per_frame": round(total_rays / (K * B), 1), "tune": json.loads(args.tune)},
+                       "rays_per_frame": round(total_rays / (K * B), 1),
+                       "traced_rays_per_frame": round((total_rays - total_culled) / (K * B), 1),
+                       "rays_note": "rays_per_frame counts BVH_IntersectTriangles calls as the reference makes them (SURVEY 8d: a camera ray that misses "
+                                    "everything counts, and the CPU baseline counts the same rays); traced_rays_per_frame leaves out the camera rays of "
+                                    "8x8 tiles whose rays cannot reach any box of the tree's top -- the launch sets those pixels to black without "
+                                    "generating a ray (k_tile_select)",
+                       "tune": json.loads(args.tune)},
             "frames_per_sec": round(K * B / dt, 3),
+            "traced_Mrays_per_s": round((total_rays - total_culled) / dt / 1e6, 3),
             "roofline": None,
         }
+        if dry:
+            result["dry_run"] = True
         if repeats:
             result["repeats"] = repeats
         # ---- roofline of the traversal kernel.  No dense contraction -> no MFMA; the scene is cache resident -> HBM does not
@@ -448,6 +564,12 @@ def main():
                                        "resident (measured HBM traffic: see `hbm`); the vector ALUs' issue slots do.  achieved = lane-operations per second "
                                        "that do useful work = VALUBusy x VALUUtilization x peak; peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz",
                          "achieved": round(vb * vu * VALU_PEAK_TLANEOPS, 3), "peak": round(VALU_PEAK_TLANEOPS, 3), "unit": "Tlane-op/s", "frac": round(vb * vu, 4),
+                         "timed_schedule": (lambda vi: {"valu_busy": round(vi * 4.0 / (1024 * 2.4e9) / (ms_per_step * 1e-3), 4),
+                                                       "frac": round(vi * 4.0 / (1024 * 2.4e9) / (ms_per_step * 1e-3) * vu, 4),
+                                                       "note": "the same fraction for the schedule that is TIMED (launches overlapping three at a time): the launch's "
+                                                               "vector wave-instructions x 4 cycles / 1024 SIMDs / 2.4 GHz over ms_per_step, x the active-lane share; "
+                                                               "`frac` above is for one launch by itself (kernel_ms), which is how the counters are collected"})(pmc["SQ_INSTS_VALU"])
+                                           if pmc.get("SQ_INSTS_VALU") else None,
                          "counters": {"source": pmc_src, "valu_busy_pct": round(pmc["VALUBusy"], 2), "valu_active_lanes_pct": round(pmc.get("VALUUtilization", 0.0), 2),
                                       "salu_busy_pct": round(pmc.get("SALUBusy", 0.0), 2),
                                       "valu_wave_instructions_per_launch": pmc.get("SQ_INSTS_VALU"), "salu_wave_instructions_per_launch": pmc.get("SQ_INSTS_SALU")}})
@@ -696,13 +818,52 @@ def main():
                 done_rays += st.normal_rays + st.shadow_rays
                 done_frames += 1
                 k += 1
-            result["cpu_baseline"] = {
+            port = {
                 "value": round(done_rays / t_cpu / 1e6, 3), "unit": "Mrays/s", "cores": best_t, "kind": "port",
                 "sample": "oracle (strict-IEEE C++ port of the reference, OpenMP over pixels like Raytracer.cc:558) on "
                           "frames f0..f%d of the same workload, %.1f s; %d threads = fastest of a probe over {1,8,16,32,64,%d} on this %d-thread host"
                           % (done_frames - 1, t_cpu, best_t, ncpu, ncpu),
                 "frames_per_sec": round(done_frames / t_cpu, 3),
             }
+            result["cpu_baseline"] = port
+            # ---- the REFERENCE's own code as the baseline (north_star: "the reference's OpenMP/SSE CPU path is timed on the same
+            #      box"): oracle/_ref/refcore_omp = Raytracer.cc itself (RayIntersectsBox, BVH_IntersectTriangles<>, Raytrace<true>),
+            #      compiled from /root/reference with the pinned strict flags, under refcore.cc's frame loop (OpenMP over pixels; both
+            #      the reference's per-scanline shape and a per-frame loop are probed, the faster one is timed).  Rays per frame are
+            #      the counting build's (= the reference's own counters) for the same cameras.
+            if args.mode == 9:
+                try:
+                    from oracle import refcore as RC
+                    if RC.timing_available():
+                        ocams = [O.benchmark_frame(f) for f in range(N_CAMS)]
+                        lights0, n0 = ocams[0][1], ocams[0][2]
+                        probe = {}
+                        for sched in (1, 0):
+                            for t in sorted({ncpu, max(1, ncpu // 2), min(ncpu, 64), min(ncpu, 32)}, reverse=True):
+                                secs, _ = RC.time_frames(osc, [ocams[0][0]], lights0, n0, W, H, 2 * H, threads=t, schedule=sched)
+                                probe[(sched, t)] = float(secs[0])
+                        (b_sched, b_t), b_s = min(probe.items(), key=lambda kv: kv[1])
+                        sample = [f for f in used if rays_f[f] > 0][:max(4, min(len(used), int(round(args.cpu_seconds / max(b_s, 1e-3)))))]
+                        secs, _ = RC.time_frames(osc, [ocams[f][0] for f in sample], lights0, n0, W, H, 2 * H, threads=b_t, schedule=b_sched)
+                        r_rays, r_t = float(sum(rays_f[f] for f in sample)), float(secs.sum())
+                        ref_single = RC.time_frames(osc, [ocams[0][0]], lights0, n0, W, H, 2 * H, threads=1, schedule=1)[0][0] if args.cpu_seconds >= 8 else None
+                        result["cpu_baseline"] = {
+                            "value": round(r_rays / r_t / 1e6, 3), "unit": "Mrays/s", "cores": b_t, "kind": "reference",
+                            "sample": "oracle/_ref/refcore_omp: the reference's own Raytracer.cc (Raytrace<true>, strict flags -O2 -ffp-contract=off) "
+                                      "on orbit frames %s of the same workload (%d frames, %.1f s), OpenMP over pixels in refcore.cc's frame loop (%s), "
+                                      "%d threads = fastest of a probe over threads x loop shape on this %d-thread host; rays per frame from the "
+                                      "counting build (= the reference's counters)"
+                                      % ("f%d..f%d" % (sample[0], sample[-1]), len(sample), r_t,
+                                         "one parallel loop over the frame's scanlines" if b_sched == 1 else "the reference's shape: a parallel-for over x per scanline",
+                                         b_t, ncpu),
+                            "frames_per_sec": round(len(sample) / r_t, 3),
+                            "probe_ms_frame0": {"%s/%dt" % ("rows" if k[0] == 1 else "per-scanline", k[1]): round(v * 1e3, 1) for k, v in sorted(probe.items())},
+                        }
+                        if ref_single:
+                            result["cpu_baseline"]["single_thread_Mrays_per_s"] = round(float(rays_f[0]) / float(ref_single) / 1e6, 3)
+                        result["cpu_baseline_port"] = port
+                except Exception as e:
+                    result["cpu_baseline_reference_error"] = str(e)
             # the rasterizer's CPU baseline: the oracle draws triangles in index order on ONE thread -- the only deterministic
             # semantics the reference has (its OpenMP build races on the Z-buffer)
             if not args.no_extra:

@@ -272,7 +272,9 @@ int mi355_mgpu_render(mi355_mgpu *, int mode, const mi355_camera *, const mi355_
 int mi355_mgpu_render_batch(mi355_mgpu *, int mode, int n_frames, const mi355_camera *cams, const mi355_light *lights, int n_lights,
                             const mi355_opts *, void *const *d_out, int pitch_bytes, int *ticket);
 /* The frames of that step are complete when this returns.  stats (optional): ray counts summed over devices and frames.
- * Raster modes: -44 if a device's bin / band buffers were too small for a frame of the step (they have grown: draw it again). */
+ * Raster modes: -44 if a device's bin / band buffers were too small for a frame of the step (they have grown: draw it again);
+ * with two raster steps in flight the overflow cannot be pinned on one of them, so BOTH waits return -44.
+ * d_out[] of mi355_mgpu_render_batch is copied before the call returns; the caller's array may be a temporary. */
 int mi355_mgpu_wait(mi355_mgpu *, int ticket, mi355_stats *stats);
 
 #ifdef __cplusplus

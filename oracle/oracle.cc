@@ -1686,9 +1686,13 @@ int orc_frontend_trace(const char *script, int mode, int two_lights, int brakes,
             oldLight = light; oldEye = eye; oldLook = lookat; forceRedraw = false;
             bool completed = true, back = false;
             if (mode >= 9 && brakes) {                                     /* Raytracer.cc:812-866 + renderer.cc:553-573 */
+                /* the scanline polls go to a Keyboard of renderRaytracer's own (`Keyboard keys;`, Raytracer.cc:812): every flag
+                 * clear at the start, the event queue shared -- events it consumes never reach the loop's flags */
+                bool lis[K_N] = {false};
+                auto lpoll = [&] { if (at >= ev.size()) { quit = true; return; } const int e = ev[at++]; if (e > 0) lis[e] = true; else if (e < 0) lis[-e] = false; };
                 for (int y = 0; y < height && completed; y++) {
-                    poll();
-                    if (is[K_ESC] || quit) { while (is[K_ESC] && !quit) poll(); completed = false; }
+                    lpoll();
+                    if (lis[K_ESC] || quit) { while (lis[K_ESC] && !quit) lpoll(); completed = false; }
                 }
                 if (completed) { while (!is[K_ESC] && !quit) poll(); while (is[K_ESC] && !quit) poll(); }
                 back = true;

@@ -98,6 +98,35 @@ def raytrace(osc, cam, lights, n_lights, rays, max_depth=3, variant=""):
     return _run("raytrace", blobs, np.float32, variant=variant).reshape(-1, 3)
 
 
+OMP_BINARY = os.path.join(_HERE, "_ref", "refcore_omp")
+
+
+def timing_available() -> bool:
+    return os.path.exists(OMP_BINARY)
+
+
+def time_frames(osc, cams, lights, n_lights, W, H, SD, threads=1, schedule=1, want_last=False, timeout=1800):
+    """The reference's Raytrace<true> timed on whole frames (refcore.cc `timeframes`, the binary built with -fopenmp for the
+    driver's frame loop): cams = [(eye[3], mv[9]), ...] -> (seconds per frame, last frame's [H, W, 3] r,g,b floats or None).
+    schedule 0 = the reference's OpenMP shape (a parallel-for over x per scanline), 1 = one parallel loop over scanlines."""
+    lp = np.array([list(lights[i].pos) for i in range(n_lights)], np.float32).reshape(-1)
+    cam_rows = np.array([list(c.eye) + list(c.mv) for c in cams], np.float32).reshape(-1)
+    blobs = scene_blobs(osc) + bvh_blobs(osc) + [_u32(n_lights), lp, _i32(W), _i32(H), np.float32(SD).tobytes(), _i32(threads),
+                                                 _i32(schedule), _u32(len(cams)), cam_rows, _i32(1 if want_last else 0)]
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in"), os.path.join(d, "out")
+        with open(fin, "wb") as f:
+            for b in blobs:
+                f.write(b if isinstance(b, (bytes, bytearray)) else np.ascontiguousarray(b).tobytes())
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false")
+        subprocess.run([OMP_BINARY, "timeframes", fin, fout], check=True, timeout=timeout, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, env=env)
+        raw = open(fout, "rb").read()
+    secs = np.frombuffer(raw[:8 * len(cams)], np.float64).copy()
+    last = np.frombuffer(raw[8 * len(cams):], np.float32).reshape(H, W, 3).copy() if want_last else None
+    return secs, last
+
+
 def shadowmap(osc, light_pos):
     out = _run("shadowmap", scene_blobs(osc) + [np.array(light_pos, np.float32)], np.float32)
     return out[:9].copy(), out[9:].reshape(1024, 1024)

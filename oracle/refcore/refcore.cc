@@ -30,7 +30,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <string>
 #include <vector>
 
@@ -158,6 +162,89 @@ int cmd_raytrace(Reader &in, Writer &out)
     return 0;
 }
 
+// timeframes: the CPU BASELINE of bench.py -- the reference's own Raytrace<true> timed on whole frames.
+//   in : scene, bvh, n_lights, light positions, W, H (i32), screen distance (f32), threads (i32), schedule (i32), n_frames (u32),
+//        (eye[3], mv[9])[n_frames], want_last (i32)
+//   out: seconds[n_frames] (f64), then -- if want_last -- the last frame's r, g, b floats [H][W][3] (checked against the
+//        `raytrace` command, i.e. against the pinned path, by tests/test_refcore_pins.py)
+// The frame loop is this driver's: RaytraceHorizontalSegment / renderRaytracer (Raytracer.cc:555-606, 791-868) have WIDTH,
+// HEIGHT and SCREEN_DIST compiled in and end in SDL calls.  It follows them: per scanline, per pixel, the primary ray of
+// Raytracer.cc:570-593 (same float operations), Raytrace<true>(eye, dir, NULL, 0), the clamp and the byte casts of :597-602.
+// schedule 0 = the reference's own OpenMP shape: one `parallel for schedule(dynamic,10)` over x PER SCANLINE (Raytracer.cc:557-559,
+// forked from the y loop of :836-866); schedule 1 = one parallel loop over the frame's scanlines (dynamic, 1) -- fewer fork / joins,
+// what a many-core host wants.  Everything inside the loop body is the reference's code.
+int cmd_timeframes(Reader &in, Writer &out)
+{
+    Loaded L;
+    read_scene(in, L);
+    read_bvh(in, L);
+    const uint32_t nL = in.one<uint32_t>();
+    for (uint32_t i = 0; i < nL; i++) {
+        float p[3]; in.raw(p, 12);
+        L.scene._lights.push_back(new Light(p[0], p[1], p[2]));
+    }
+    const int32_t W = in.one<int32_t>(), H = in.one<int32_t>();
+    const float SD = in.one<float>();
+    const int32_t threads = in.one<int32_t>(), schedule = in.one<int32_t>();
+    const uint32_t nF = in.one<uint32_t>();
+    std::vector<float> cams = in.vec<float>(12 * (size_t)nF);
+    const int32_t want_last = in.one<int32_t>();
+#ifdef _OPENMP
+    omp_set_num_threads(threads > 0 ? threads : 1);
+#endif
+    static std::aligned_storage<sizeof(Screen), alignof(Screen)>::type canvas_mem;
+    Screen &canvas = *reinterpret_cast<Screen *>(&canvas_mem);
+    std::vector<float> rgb(want_last ? 3 * (size_t)W * H : 0);
+    std::vector<uint32_t> frame((size_t)W * H);
+    std::vector<double> secs(nF);
+    for (uint32_t f = 0; f < nF; f++) {
+        Camera cam(1.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+        set_camera(cam, &cams[12 * (size_t)f], &cams[12 * (size_t)f + 3]);
+        int y0 = 0;
+        RaytraceScanline<false> line(L.scene, cam, canvas, y0);
+        const bool keep = want_last && f + 1 == nF;
+        auto pixel = [&](int x, int y) {
+            coord xx = (coord)x, yy = (coord)y;
+            coord lx = coord((H / 2) - yy) / SD;
+            coord ly = coord(xx - (W / 2)) / SD;
+            coord lz = 1.0;
+            Vector3 rayInCameraSpace(lx, ly, lz);
+            rayInCameraSpace.normalize();
+            Vector3 rayInWorldSpace = cam._mv._row1 * rayInCameraSpace._x;
+            rayInWorldSpace += cam._mv._row2 * rayInCameraSpace._y;
+            rayInWorldSpace += cam._mv._row3 * rayInCameraSpace._z;
+            rayInWorldSpace.normalize();
+            Pixel c(0, 0, 0);
+            c += line.Raytrace<true>(cam, rayInWorldSpace, NULL, 0);
+            if (keep) { float *o = &rgb[3 * ((size_t)y * W + x)]; o[0] = c._r; o[1] = c._g; o[2] = c._b; }
+            if (c._r > 255.0f) c._r = 255.0f;
+            if (c._g > 255.0f) c._g = 255.0f;
+            if (c._b > 255.0f) c._b = 255.0f;
+            frame[(size_t)y * W + x] = ((uint32_t)(Uint8)c._r << 16) | ((uint32_t)(Uint8)c._g << 8) | (uint32_t)(Uint8)c._b;
+        };
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        if (schedule == 0) {
+            for (int y = 0; y < H; y++) {
+                #pragma omp parallel for schedule(dynamic, 10)
+                for (int x = 0; x < W; x++) pixel(x, y);
+            }
+        } else {
+            #pragma omp parallel for schedule(dynamic, 1)
+            for (int y = 0; y < H; y++)
+                for (int x = 0; x < W; x++) pixel(x, y);
+        }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        secs[f] = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    }
+    out.raw(secs.data(), secs.size() * 8);
+    if (want_last) out.raw(rgb.data(), rgb.size() * 4);
+    // keep the packed frame alive (the stores above are the reference's DrawPixel)
+    uint32_t sum = 0; for (uint32_t v : frame) sum += v;
+    fprintf(stderr, "refcore timeframes: %u frames, checksum %08x\n", nF, sum);
+    return 0;
+}
+
 // shadowmap: scene, light position  ->  _worldToLightSpace[9], _shadowBuffer[SHADOWMAPSIZE^2]
 int cmd_shadowmap(Reader &in, Writer &out)
 {
@@ -261,6 +348,7 @@ int main(int argc, char **argv)
     Writer out(argv[3]);
     const std::string cmd = argv[1];
     if (cmd == "raytrace") return cmd_raytrace(in, out);
+    if (cmd == "timeframes") return cmd_timeframes(in, out);
     if (cmd == "shadowmap") return cmd_shadowmap(in, out);
     if (cmd == "camera") return cmd_camera(in, out);
     if (cmd == "lighting") return cmd_lighting(in, out);

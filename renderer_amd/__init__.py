@@ -478,6 +478,15 @@ class Scene:
         _check(lib().mi355_fetch_stats(self.context(), C.byref(st)), "mi355_fetch_stats")
         return st
 
+    def culled_rays(self) -> int:
+        """Of the last call's normal_rays, the camera rays that were never generated: pixels of the tiles the tile culling set to
+        black without tracing (mi355_stats counts them, like the reference does)."""
+        f = lib().mi355i_fetch_culled_rays
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        v = C.c_uint64(0)
+        _check(f(self.context(), C.byref(v)), "mi355i_fetch_culled_rays")
+        return int(v.value)
+
     def render_frame_cxx(self, mode: int, width: int, height: int, eye, lookat, light_positions):
         """One frame through the C++ Scene::render* API (mi355::Scene, what a front-end calls)."""
         out = np.zeros((height, width), np.uint32)

@@ -1470,7 +1470,11 @@ int mi355_fetch_stats(mi355_ctx *c, mi355_stats *s)
     if (c->last_ctrl && c->last_ctrl != c->ctrl.p)
         HIP_TRY(hipMemcpy(&h[CS_OVERFLOW], (char *)c->ctrl.p + 16 + sizeof(unsigned long long) * CS_OVERFLOW, sizeof(unsigned long long), hipMemcpyDeviceToHost), -31);
     if (c->rs_light && c->ev_light_set) {
-        // (a map redrawn by mi355_light_update whose rows did not fit: the buffer doubles, the caller redraws the map)
+        // (a map redrawn by mi355_light_update whose rows did not fit: the buffer doubles, the caller redraws the map.  The redraw
+        //  may sit on a non-blocking stream the copy below does not order behind: its event is waited for first -- and, once it
+        //  has completed, no later frame needs to wait for it and no later fetch needs to look again)
+        HIP_TRY(hipEventSynchronize(c->ev_light), -40);
+        c->ev_light_set = false;
         const uint32_t dropped = mi355i_raster_overflow(c->rs_light);
         if (dropped) {
             const int grown = mi355i_raster_grow(c->rs_light);
@@ -1496,6 +1500,16 @@ int mi355_fetch_stats(mi355_ctx *c, mi355_stats *s)
 // Not part of the public ABI (mgpu.hip): device address of the ray counters (normal rays, shadow rays: two 64-bit words) of the
 // context's most recent call -- valid, in stream order, behind that call on the stream it was given
 void *mi355i_last_ray_counters(mi355_ctx *c) { return c ? (char *)(c->last_ctrl ? c->last_ctrl : c->ctrl.p) + 16 : nullptr; }
+
+// Not part of the public ABI (bench.py: `traced_rays_per_frame`): of the most recent call's normal_rays, the camera rays that were
+// never generated -- pixels of tiles the tile culling set to black (mi355_stats counts them: the reference traces one per pixel)
+int mi355i_fetch_culled_rays(mi355_ctx *c, unsigned long long *out)
+{
+    if (!c || !out) return fail(-3, "mi355i_fetch_culled_rays: null argument");
+    if (int r = select_device(c)) return r;
+    HIP_TRY(hipMemcpy(out, (char *)(c->last_ctrl ? c->last_ctrl : c->ctrl.p) + 16 + sizeof(unsigned long long) * CS_CULLED_RAYS, sizeof *out, hipMemcpyDeviceToHost), -31);
+    return 0;
+}
 
 // Not part of the public ABI: known-answer test of the device's float arithmetic (tests/test_gpu_parity.py).  Every
 // pixel of every mode rests on these operations rounding exactly like the strict x86-64 build of the reference:

@@ -166,7 +166,9 @@ struct FrameParams {
 enum CounterSlot {
     CS_NORMAL_RAYS = 0, CS_SHADOW_RAYS, CS_NODE_POPS, CS_INNER_HITS, CS_TRI_TESTS, CS_PLANE_PASS,
     CS_SHADED_HITS, CS_TRIS_DRAWN, CS_SPANS, CS_ZTESTS, CS_PLOTS, CS_OVERFLOW,
-    CS_PROF0, CS_TIME0 = CS_PROF0 + 16, CS_COUNT = CS_TIME0 + 4   // phase profile + time stamps (counting builds only)
+    CS_PROF0, CS_TIME0 = CS_PROF0 + 16,   // phase profile + time stamps (counting builds only)
+    CS_CULLED_RAYS = CS_TIME0 + 4,       // camera rays of the tiles k_tile_select set to black without tracing them (they are part of CS_NORMAL_RAYS too)
+    CS_COUNT
 };
 
 // compact row r (0..n_rows) -> screen row y for the band sharding of mi355_opts

@@ -130,20 +130,23 @@ void FrontEnd::showHelp()
 
 // Raytracer.cc:791-868 with HANDLERAYTRACER: the reference traces scanline by scanline, polls the keyboard once after each, gives
 // up when ESC is down (after waiting for its release) and shows the buffer every 16 scanlines.  Here the scanlines are traced 16
-// at a time -- one band-sharded frame call per band (mi355_opts::band_*: rows outside the band are not touched) -- and the polls
-// of a band's scanlines follow it, so an abort takes effect at the next multiple of 16 scanlines at the latest.
+// at a time -- Scene::renderRaytracerRows: one band-sharded frame call per band, rendered compactly and copied into the canvas's
+// own rows, the other rows keep what they hold -- and the polls of a band's scanlines follow it, so an abort takes effect at the
+// next multiple of 16 scanlines at the latest.
+// The keyboard is the CALL's OWN, as in the reference (`Keyboard keys;`, Raytracer.cc:812): it starts with every flag clear and
+// shares only the event queue (and the window's close request, on which the reference exits the process) with the loop's
+// keyboard -- a key that goes down during the frame is consumed here and never reaches the loop's flags, a key that goes up
+// during the frame leaves the loop's flag set.
 bool FrontEnd::renderRaytracerWithBrakes(bool antialias)
 {
     const int H = canvas ? canvas->_height : 600;
-    Keyboard &k = keys;
-    const mi355_opts saved = scene._opts;
+    Keyboard k;
+    k.source = [this] { return keys.source ? keys.source() : KeyEvent(); };
+    k._quit = keys._quit;
+    struct Merge { Keyboard &loop, &mine; ~Merge() { loop._quit = loop._quit || mine._quit; loop._polls += mine._polls; } } merge{keys, k};
     bool completed = true;
     for (int y0 = 0; y0 < H && completed; y0 += 16) {
-        if (canvas) {
-            scene._opts.band_rows = 16; scene._opts.band_count = (H + 15) / 16; scene._opts.band_index = y0 / 16; scene._opts.compact_rows = 0;
-            scene.renderRaytracer(sony, *canvas, antialias);
-            scene._opts = saved;
-        }
+        if (canvas) scene.renderRaytracerRows(sony, *canvas, antialias, y0, 16);
         for (int y = y0; y < std::min(H, y0 + 16); y++) {
             k.poll(false);                                                 // :842
             if (k._isAbort || k._quit) {
@@ -159,7 +162,6 @@ bool FrontEnd::renderRaytracerWithBrakes(bool antialias)
             }
         }
     }
-    scene._opts = saved;
     if (completed && canvas) canvas->ShowScreen(true, true);               // :866
     return completed;
 }

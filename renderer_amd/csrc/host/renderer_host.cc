@@ -846,6 +846,34 @@ bool Scene::renderRaytracer(Camera &eye, Screen &canvas, bool antiAlias)
     return true;          // the reference returns false only when the user aborts with ESC (HANDLERAYTRACER)
 }
 
+void Scene::renderRaytracerRows(Camera &eye, Screen &canvas, bool antiAlias, int y0, int rows)
+{
+    if (_pCFBVH.empty()) raise("renderRaytracer: call UpdateBoundingVolumeHierarchy(filename) first");
+    const int W = canvas._width, H = canvas._height;
+    if (rows <= 0 || y0 < 0 || y0 >= H || y0 % rows) raise("renderRaytracerRows: y0 must be a multiple of rows inside the frame");
+    // one band of the band-sharded frame (mi355_opts::band_*), written compactly: mi355_render defines the rows of the other
+    // bands of an un-compacted frame as black, so the band lands in a buffer of its own and is copied into place
+    mi355_opts o = _opts;
+    o.width = W; o.height = H; o.screen_dist = H * 2;
+    o.band_rows = rows; o.band_count = (H + rows - 1) / rows; o.band_index = y0 / rows; o.compact_rows = 1;
+    const int n_rows = std::min(rows, H - y0);
+    const mi355_camera cam = eye.abi();
+    mi355_light lights[MI355_MAX_LIGHTS];
+    const int n = (int)std::min<size_t>(_lights.size(), MI355_MAX_LIGHTS);
+    for (int i = 0; i < n; i++) lights[i] = _lights[i]->abi();
+    const int mode = antiAlias ? MI355_MODE_RAYTRACE_ANTIALIAS : MI355_MODE_RAYTRACE;
+    if (o.band_count <= 1) {        // (the band is the whole frame)
+        if (mi355_render(context(), mode, &cam, lights, n, &o, canvas._pixels.data(), canvas._pitch, nullptr, &_lastStats) != 0)
+            raise(std::string("mi355_render: ") + mi355_last_error());
+        return;
+    }
+    std::vector<uint32_t> band((size_t)W * (size_t)n_rows);
+    if (mi355_render(context(), mode, &cam, lights, n, &o, band.data(), W * 4, nullptr, &_lastStats) != 0)
+        raise(std::string("mi355_render: ") + mi355_last_error());
+    for (int r = 0; r < n_rows; r++)
+        memcpy((char *)canvas._pixels.data() + (size_t)(y0 + r) * (size_t)canvas._pitch, band.data() + (size_t)r * W, (size_t)W * 4);
+}
+
 // ---------------------------------------------------------------- benchmark orbit ----------------------
 #ifndef M_PI
 #define M_PI 3.14159265358979323846

@@ -141,6 +141,10 @@ struct Scene {                                         // Scene.h:32-86
     void renderPhongAndShadowed(const Camera &, Screen &);
     void renderPhongAndSoftShadowed(const Camera &, Screen &);
     bool renderRaytracer(Camera &, Screen &, bool antiAlias = false);       // Scene.h:85
+    // Scanlines [y0, y0 + rows) of that frame and nothing else: the canvas's other rows keep what they hold (the scanline-by-
+    // scanline progress of Raytracer.cc:812-866 under HANDLERAYTRACER; frontend.cc).  rows must be a multiple of 8 dividing y0.
+    // A multi-device Scene traces them on its first device.
+    void renderRaytracerRows(Camera &, Screen &, bool antiAlias, int y0, int rows);
 
     // The same frames, pipelined (no reference counterpart: its loop is synchronous).  renderAsync enqueues the frame of any
     // RenderMode into `canvas` and returns a ticket; up to MI355_MAX_IN_FLIGHT frames may be pending, each into its own

@@ -1559,7 +1559,7 @@ k_tile_select(const FrameParams P, const float4 *boxes, int n_boxes, const uint3
             px += (unsigned long long)((w < 8 ? w : 8) * (h < 8 ? h : 8));
         }
         for (int off = 32; off > 0; off >>= 1) px += __shfl_xor(px, off);
-        if (lane == 0 && px && P.counters) atomicAdd(&P.counters[CS_NORMAL_RAYS], px * (P.aa ? 4ull : 1ull));
+        if (lane == 0 && px && P.counters) { atomicAdd(&P.counters[CS_NORMAL_RAYS], px * (P.aa ? 4ull : 1ull)); atomicAdd(&P.counters[CS_CULLED_RAYS], px * (P.aa ? 4ull : 1ull)); }
     }
     // the other tiles are black: a wave per pixel row, four pixels per lane and step (whole cache lines per wave)
     uint32_t *const out = batch ? P.cams[f].out : P.out;

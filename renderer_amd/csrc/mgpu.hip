@@ -76,6 +76,10 @@ struct mi355_mgpu {
     bool sent_set[MGPU_SETS] = {}, asm_set[MGPU_SETS] = {};
     int ticket_of[MGPU_SETS] = {}, mode_of[MGPU_SETS] = {};
     bool busy[MGPU_SETS] = {};
+    // raster steps: a device's bin-overflow word is one per context, sticky until read -- with two steps in flight it cannot be
+    // pinned on one of them, so an overflow seen by one wait fails every raster step in flight (each is drawn again)
+    bool failed[MGPU_SETS] = {};
+    void **outs_h[MGPU_SETS] = {};         // page-locked copy of the step's destination pointers (the caller's array may be a temporary)
     int next_ticket = 1, turn = 0;
     uint32_t *frame = nullptr;             // device 0: assembled frame for the host-output path
     int32_t *owner = nullptr, *local = nullptr, *rows_d = nullptr;      // device 0: row maps
@@ -133,9 +137,11 @@ static int geometry(mi355_mgpu *m, int W, int H, int frames)
         MG_HIP(hipSetDevice(m->dev[0]), -10);
         if (m->gathered[b]) (void)hipFree(m->gathered[b]);
         if (m->outs_d[b]) (void)hipFree(m->outs_d[b]);
-        m->gathered[b] = nullptr; m->outs_d[b] = nullptr;
+        if (m->outs_h[b]) (void)hipHostFree(m->outs_h[b]);
+        m->gathered[b] = nullptr; m->outs_d[b] = nullptr; m->outs_h[b] = nullptr;
         MG_HIP(hipMalloc((void **)&m->gathered[b], (size_t)m->n * rank_words * 4), -31);
         MG_HIP(hipMalloc((void **)&m->outs_d[b], (size_t)cap * sizeof(uint32_t *)), -31);
+        MG_HIP(hipHostMalloc((void **)&m->outs_h[b], (size_t)cap * sizeof(void *), hipHostMallocDefault), -31);
         for (int r = 1; r < m->n; r++) {
             MG_HIP(hipSetDevice(m->dev[r]), -10);
             if (m->part[b][r]) (void)hipFree(m->part[b][r]);
@@ -213,6 +219,7 @@ void mi355_mgpu_destroy(mi355_mgpu *m)
         if (m->assembled[b]) (void)hipEventDestroy(m->assembled[b]);
         if (m->gathered[b]) (void)hipFree(m->gathered[b]);
         if (m->outs_d[b]) (void)hipFree(m->outs_d[b]);
+        if (m->outs_h[b]) (void)hipHostFree(m->outs_h[b]);
     }
     for (void *p : {(void *)m->frame, (void *)m->owner, (void *)m->local, (void *)m->rows_d}) if (p) (void)hipFree(p);
     delete m;
@@ -326,7 +333,9 @@ int mi355_mgpu_render_batch(mi355_mgpu *m, int mode, int n_frames, const mi355_c
     {
         hipError_t he = hipSetDevice(m->dev[0]);
         if (he == hipSuccess && m->rows[0]) he = hipStreamWaitEvent(m->cs[0], m->rendered[b][0], 0);
-        if (he == hipSuccess) he = hipMemcpyAsync(m->outs_d[b], d_out, (size_t)n_frames * sizeof(void *), hipMemcpyHostToDevice, m->cs[0]);
+        // (from the set's own page-locked array: the copy runs behind stream waits, long after the caller's array may be gone; the
+        //  set's previous step has been waited for -- busy[b] was clear -- so nothing still reads the array)
+        if (he == hipSuccess) { memcpy(m->outs_h[b], d_out, (size_t)n_frames * sizeof(void *)); he = hipMemcpyAsync(m->outs_d[b], m->outs_h[b], (size_t)n_frames * sizeof(void *), hipMemcpyHostToDevice, m->cs[0]); }
         if (he == hipSuccess) {
             hipLaunchKernelGGL(k_deinterleave, dim3(n_frames > 4 ? 512 : 2048, n_frames), dim3(256), 0, m->cs[0], m->gathered[b], m->owner, m->local, m->rows_d,
                                rank_words, m->outs_d[b], W, H, pitch_bytes / 4);
@@ -339,7 +348,7 @@ int mi355_mgpu_render_batch(mi355_mgpu *m, int mode, int n_frames, const mi355_c
         if ((he = hipEventRecord(m->assembled[b], m->cs[0])) != hipSuccess) { drain(m); return mfail(-40, "hipEventRecord: %s", hipGetErrorString(he)); }
         m->asm_set[b] = true;
     }
-    m->busy[b] = true; m->ticket_of[b] = m->next_ticket++; m->mode_of[b] = mode;
+    m->busy[b] = true; m->failed[b] = false; m->ticket_of[b] = m->next_ticket++; m->mode_of[b] = mode;
     m->turn = (b + 1) % MGPU_SETS;
     *ticket = m->ticket_of[b];
     return 0;
@@ -347,7 +356,8 @@ int mi355_mgpu_render_batch(mi355_mgpu *m, int mode, int n_frames, const mi355_c
 
 // The frames of step `ticket` are complete in their buffers when this returns.  stats (optional): ray counts of THAT step summed
 // over the devices and frames (each device copies its counters aside behind the step's launch).  Raster modes: -44 when a device's bin or band buffers were too small for a frame of the step; they have grown by
-// then and the step has to be drawn again.
+// then and the step has to be drawn again -- and so has every other raster step that was in flight with it: the overflow word is
+// one per device, so the wait of EACH of them returns -44.
 int mi355_mgpu_wait(mi355_mgpu *m, int ticket, mi355_stats *stats)
 {
     if (!m) return mfail(-3, "mi355_mgpu_wait: null argument");
@@ -379,7 +389,16 @@ int mi355_mgpu_wait(mi355_mgpu *m, int ticket, mi355_stats *stats)
             const int e = mi355_fetch_stats(m->ctx[r], &s);      // (the overflow word is sticky in the context's block until it is read)
             if (e && !rc) rc = e;                        // (-44: that rank's rasterizer buffers have grown: draw again; look at every rank)
         }
+        if (rc == -44)      // (whichever step in flight dropped the entries: each of them may hold an incomplete frame)
+            for (int k = 0; k < MGPU_SETS; k++)
+                if (k != b && m->busy[k] && m->mode_of[k] >= MI355_MODE_AMBIENT && m->mode_of[k] <= MI355_MODE_PHONG_SOFTSHADOWMAPS) m->failed[k] = true;
         if (rc) { (void)hipSetDevice(m->dev[0]); drain(m); return rc; }
+        if (m->failed[b]) {
+            m->failed[b] = false;
+            (void)hipSetDevice(m->dev[0]);
+            return mfail(-44, "a rasterizer buffer overflowed while this step and another were in flight (reported by the other step's wait); "
+                              "the buffers have grown: draw the step again");
+        }
     }
     (void)hipSetDevice(m->dev[0]);
     return 0;

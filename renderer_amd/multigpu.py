@@ -40,11 +40,39 @@ def assemble_numpy(parts, height: int, band_rows: int) -> np.ndarray:
     return out
 
 
+class _StagedWork:
+    """A collective that ran on host mirrors of device buffers: wait() = the collective's wait, then the copy back to the device
+    (the `staged` transport of the gatherers below: a backend without device collectives -- gloo -- moving device buffers)."""
+
+    def __init__(self, works, after=None):
+        self.works = works if isinstance(works, (list, tuple)) else [works]
+        self.after = after
+
+    def wait(self):
+        for w in self.works:
+            if w is not None:
+                w.wait()
+        if self.after is not None:
+            self.after()
+            self.after = None
+        return True
+
+
+def _host_like(torch, t):
+    """A host mirror of device tensor `t` (pinned when the device is a GPU)."""
+    pin = t.device.type == "cuda"
+    return torch.zeros(t.shape, dtype=t.dtype, device="cpu", pin_memory=pin)
+
+
 class FrameGatherer:
-    """Gathers per-rank compact band buffers on rank 0 and de-interleaves them (torch tensors)."""
+    """Gathers per-rank compact band buffers on rank 0 and de-interleaves them (torch tensors).
+
+    staged=True runs the collective on host mirrors of the buffers (device -> host, gather, host -> device on rank 0): the
+    transport of `bench.py --dry-run`, where N ranks share one GPU and the backend is gloo.  Everything else -- buffers, slots,
+    pending work, de-interleave -- is the path RCCL takes."""
 
     def __init__(self, width: int, height: int, device, band_rows: int = BAND_ROWS, group=None, frames: int = 1,
-                 collective_when_alone: bool = False):
+                 collective_when_alone: bool = False, staged: bool = False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -64,6 +92,10 @@ class FrameGatherer:
         self.recv = [torch.zeros((self.world,) + shape, dtype=torch.int32, device=device)
                      if self.rank == 0 else None for _ in range(2)]
         self.pending = [None, None]
+        self.staged = staged and not self.alone
+        if self.staged:
+            self.h_send = [_host_like(torch, t) for t in self.send]
+            self.h_recv = [_host_like(torch, t) if t is not None else None for t in self.recv]
 
     def send_buffer(self, slot: int):
         """Wait until buffer `slot` is free again and return it (rank-local compact band buffer)."""
@@ -76,6 +108,16 @@ class FrameGatherer:
         """Launch the gather of buffer `slot` to rank 0 (one collective per frame)."""
         if self.alone:
             return None
+        if self.staged:
+            self.h_send[slot].copy_(self.send[slot])          # (device -> host in stream order: the frames are complete)
+            lst = list(self.h_recv[slot].unbind(0)) if self.rank == 0 else None
+            w = self.dist.gather(self.h_send[slot], gather_list=lst, dst=0, group=self.group, async_op=async_op)
+            back = (lambda: self.recv[slot].copy_(self.h_recv[slot])) if self.rank == 0 else None
+            w = _StagedWork(w if async_op else None, back)
+            if not async_op:
+                w.wait()
+            self.pending[slot] = w if async_op else None
+            return w
         if self.rank == 0:
             lst = list(self.recv[slot].unbind(0))
             w = self.dist.gather(self.send[slot], gather_list=lst, dst=0, group=self.group, async_op=async_op)
@@ -83,6 +125,10 @@ class FrameGatherer:
             w = self.dist.gather(self.send[slot], gather_list=None, dst=0, group=self.group, async_op=async_op)
         self.pending[slot] = w if async_op else None
         return w
+
+    def ingest_bytes_per_step(self) -> int:
+        """What rank 0 takes in per step: the other ranks' band buffers."""
+        return (self.world - 1) * self.max_rows * self.W * 4 * self.frames
 
     def frame(self, slot: int):
         """Rank 0: the assembled [H, W] frame of buffer `slot` (waits for its gather)."""
@@ -122,7 +168,7 @@ class SpreadAssembler:
     slot_of_frame(j): the buffer is ordered by destination, so that every peer's chunk is contiguous), gather(slot), frame(slot)
     -> this rank's frames [frames / world, H, W], drain()."""
 
-    def __init__(self, width: int, height: int, device, frames: int, band_rows: int = BAND_ROWS, group=None):
+    def __init__(self, width: int, height: int, device, frames: int, band_rows: int = BAND_ROWS, group=None, staged: bool = False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -141,6 +187,10 @@ class SpreadAssembler:
         # recv[slot][s] = rank s's bands of the frames this rank owns
         self.recv = [torch.zeros((self.world, self.n_own, self.max_rows, width), dtype=torch.int32, device=device) for _ in range(2)]
         self.pending = [None, None]
+        self.staged = staged and not self.alone       # host mirrors for a backend without device collectives (FrameGatherer)
+        if self.staged:
+            self.h_send = [_host_like(torch, t) for t in self.send]
+            self.h_recv = [_host_like(torch, t) for t in self.recv]
 
     def slot_of_frame(self, j: int) -> int:
         """Index in the send buffer of frame j of the step (frames of one owner side by side)."""
@@ -167,14 +217,24 @@ class SpreadAssembler:
         self.recv[slot][self.rank].copy_(self.send[slot][self.rank * n:(self.rank + 1) * n])
         if self.alone:
             return None
+        src, dst = self.send[slot], self.recv[slot]
+        if self.staged:
+            self.h_send[slot].copy_(self.send[slot])
+            src, dst = self.h_send[slot], self.h_recv[slot]
         ops = []
         for s in range(self.world):
             if s == self.rank:
                 continue
             peer = s if self.group is None else self.dist.get_global_rank(self.group, s)
-            ops.append(self.dist.P2POp(self.dist.isend, self.send[slot][s * n:(s + 1) * n], peer, self.group))
-            ops.append(self.dist.P2POp(self.dist.irecv, self.recv[slot][s], peer, self.group))
+            ops.append(self.dist.P2POp(self.dist.isend, src[s * n:(s + 1) * n], peer, self.group))
+            ops.append(self.dist.P2POp(self.dist.irecv, dst[s], peer, self.group))
         works = self.dist.batch_isend_irecv(ops)
+        if self.staged:
+            def back(slot=slot):
+                for s in range(self.world):
+                    if s != self.rank:
+                        self.recv[slot][s].copy_(self.h_recv[slot][s])
+            works = [_StagedWork(works, back)]
         if async_op:
             self.pending[slot] = works
         else:

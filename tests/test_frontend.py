@@ -141,6 +141,43 @@ poll 6
     assert n2 == m2 and same(got2, want2) and (got2[:, 1] == 9).sum() >= 5
 
 
+def test_keys_typed_during_a_raytraced_frame_go_to_the_frames_own_keyboard(oracle):
+    """Raytracer.cc:812: renderRaytracer polls a LOCAL Keyboard.  A key that goes DOWN while the frame is traced is consumed there
+    and never reaches the loop's flags (no mode change, no rotation afterwards); a key that goes UP during the frame leaves the
+    loop's flag set (the eye keeps moving until the key comes up again outside a frame)."""
+    script = """
+poll 3
+down left               # held into the frame ...
+poll 2
+tap 9
+poll 100
+up left                 # ... and released while it is traced: the loop never sees the release
+poll 50
+tap 4                   # a mode key typed during the frame is swallowed
+down w
+poll 500
+tap esc                 # the frozen frame is released
+poll 6                  # (left is still down for the loop: angle1 keeps changing; W's release comes now, its press never arrived)
+up w
+poll 4
+down left
+up left                 # only now does the loop's flag clear
+poll 5
+"""
+    got, n = host_trace(script, mode=6, brakes=True)
+    want, m = oracle_trace(oracle, script, mode=6, brakes=True)
+    assert n == m and same(got, want), "first differing frame: %d" % int(np.flatnonzero((got.view(np.uint32) != want.view(np.uint32)).any(axis=1))[0])
+    i9 = int(np.flatnonzero(got[:, 1] == 9)[0])
+    assert got[i9, 22] == 1                                                # completed: the ESC-less keys did not abort it
+    after = got[i9 + 1:]
+    assert (after[:, 1] == 8).all()                                        # "tap 4" never reached the loop
+    assert len(np.unique(after[:, 8])) == 1                                # nor did W: the light stayed where it was
+    # (left is still held for the loop after the frame: the orbit's own step plus the key's, twice the untouched loop's)
+    plain, _ = host_trace("poll 3\ndown left\npoll 2\nup left\ntap 9\npoll 650\ntap esc\npoll 6\n", mode=6, brakes=True)
+    j9 = int(np.flatnonzero(plain[:, 1] == 9)[0])
+    assert not same(after[:4, 2:5].copy(), plain[j9 + 1:j9 + 5, 2:5].copy())
+
+
 def test_a_script_line_that_cannot_be_read_is_an_error():
     f = R.host().mi355h_frontend_trace
     f.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_void_p, C.c_int, C.c_void_p]

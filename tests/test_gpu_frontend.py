@@ -55,6 +55,39 @@ def test_rendered_key_trace(oracle, oracle_scene):
     assert np.array_equal(last, ref)
 
 
+@pytest.mark.parametrize("mode_key,mode,H", [("9", 9, 240), ("0", 10, 100)])
+def test_the_frozen_raytraced_frame_is_the_whole_frame(oracle, oracle_scene, mode_key, mode, H):
+    """The raytraced modes draw their frame 16 scanlines at a time between the keyboard polls (Raytracer.cc:812-866 under
+    HANDLERAYTRACER).  The finished frame -- what stays on the screen until ESC -- must be the frame a direct render gives:
+    every band in its own rows, no band disturbing another (each band call used to black out the earlier ones).
+    The script ends while the picture is frozen, so the canvas handed back IS that picture.  H = 100: a ragged last band."""
+    W = 320
+    mesh = "dragon_vis.ply"
+    s = R.Scene(R.assets.mesh_path(mesh))
+    s.bvh_create()
+    f = R.host().mi355h_frontend_trace
+    f.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_void_p, C.c_int, C.c_void_p]
+    f.restype = C.c_int
+    rows = np.zeros((100, 24), np.float32)
+    last = np.zeros((H, W), np.uint32)
+    script = "poll 3\ntap %s\npoll %d\n" % (mode_key, H + 20)
+    n = f(s._h, script.encode(), 6, 0, 1, W, H, 10, rows.ctypes.data, 100, last.ctypes.data)
+    assert n >= 3, R.host().mi355h_last_error().decode()
+    r = rows[n - 1]
+    assert int(r[1]) == mode and r[22] == 1                               # the last frame drawn: raytraced, completed
+    cam = R.camera(r[2:5], r[5:8])
+    lt = R.light(r[8:11], cam)
+    lights = (R.Light * 2)(lt)
+    direct = s.render(mode, cam, lights, 1, R.default_opts(W, H))[0]
+    assert int((direct != 0).sum()) > W * H // 50
+    assert np.array_equal(last, direct)
+    osc = oracle_scene(mesh, bvh=True)
+    ocam = oracle.camera(r[2:5], r[5:8])
+    ol = oracle.light(r[8:11], ocam)
+    ref = osc.render(mode, ocam, (oracle.Light * 2)(ol), 1, oracle.default_opts(W, H, threads=os.cpu_count() or 1))[0]
+    assert np.array_equal(last, ref)
+
+
 def test_render_cli_keys(tmp_path):
     cli = os.path.join(os.path.dirname(R.RENDER_SO), "render_cli")
     keys = tmp_path / "keys.txt"

@@ -131,6 +131,65 @@ def test_mgpu_steps_in_flight_equal_single_device_frames(mode, mesh, ranks, fram
         L.mi355_mgpu_destroy(m)
 
 
+def test_a_bin_overflow_fails_every_raster_step_in_flight(oracle, tmp_path):
+    """a device's bin-overflow word is sticky and one per context.  With two raster steps in flight the wait of the
+    first used to report (and clear) an overflow of either, and the wait of the second then returned 0 for frames that may
+    have dropped entries.  Now BOTH waits return -44; drawn again (the buffers have grown) the frames are the oracle's.
+    Scene: 150 000 triangles that each cover most of a small view (tests/test_gpu_parity.py)."""
+    torch = pytest.importorskip("torch")
+
+    def _write_soup(path, verts, faces, cols):
+        with open(path, "w") as f:
+            f.write("ply\nformat ascii 1.0\nelement vertex %d\nelement face %d\nend_header\n" % (len(verts), len(faces)))
+            for q in verts:
+                f.write("%r %r %r 200\n" % (float(q[0]), float(q[1]), float(q[2])))
+            for t, c in zip(faces, cols):
+                f.write("3 %d %d %d %d %d %d\n" % (t[0], t[1], t[2], c[0], c[1], c[2]))
+
+    L = _mgpu_api()
+    rng = np.random.default_rng(5)
+    n = 150000
+    c = rng.uniform(-0.2, 0.2, (n, 1, 3))
+    v = c + rng.uniform(-1.0, 1.0, (n, 3, 3)) * np.array([0.05, 1.0, 1.0])
+    p = str(tmp_path / "layers.ply")
+    _write_soup(p, v.reshape(-1, 3), np.arange(3 * n).reshape(n, 3), rng.integers(30, 255, (n, 3)))
+    s, o_s = R.Scene(p), oracle.Scene(p)
+    W, H, ranks = 200, 150, 2
+    eyes = [np.array([2.2, 0.2, 0.1], np.float32), np.array([2.1, 0.5, 0.2], np.float32)]
+    look = np.zeros(3, np.float32)
+    lp = np.array([3.0, 1.0, 1.0], np.float32)
+    m = L.mi355_mgpu_create(C.byref(s.desc), (C.c_int * ranks)(*([0] * ranks)), ranks)
+    assert m, L.mi355_last_error()
+    try:
+        o = R.default_opts(W, H)
+        bufs = [torch.zeros((H, W), dtype=torch.int32, device="cuda:0") for _ in range(2)]
+
+        def enqueue(k):
+            cam = R.camera(eyes[k], look)
+            cams, lights = (R.Camera * 1)(cam), (R.Light * 1)(R.light(lp, cam))
+            t = C.c_int(0)
+            # (the destination array is a temporary on purpose: the library keeps its own copy)
+            assert L.mi355_mgpu_render_batch(m, 4, 1, cams, lights, 1, C.byref(o), (C.c_void_p * 1)(bufs[k].data_ptr()), W * 4, C.byref(t)) == 0, L.mi355_last_error()
+            return t.value
+
+        t0, t1 = enqueue(0), enqueue(1)
+        assert L.mi355_mgpu_wait(m, t0, None) == -44
+        assert L.mi355_mgpu_wait(m, t1, None) == -44, "the second step in flight must be drawn again too"
+        for attempt in range(8):          # (the buffers double per report)
+            t0, t1 = enqueue(0), enqueue(1)
+            r0, r1 = L.mi355_mgpu_wait(m, t0, None), L.mi355_mgpu_wait(m, t1, None)
+            assert r0 in (0, -44) and r1 in (0, -44), L.mi355_last_error()
+            if r0 == 0 and r1 == 0:
+                break
+        assert r0 == 0 and r1 == 0
+        for k in range(2):
+            ocam = oracle.camera(eyes[k], look)
+            want = o_s.render(4, ocam, (oracle.Light * 2)(oracle.light(lp, ocam)), 1, oracle.default_opts(W, H))[0]
+            assert np.array_equal(bufs[k].cpu().numpy().view(np.uint32), want), k
+    finally:
+        L.mi355_mgpu_destroy(m)
+
+
 def test_config5_frame_on_eight_virtual_ranks(oracle):
     """BASELINE config 5's frame -- dragon, 3840x2160, depth 3 -- cut over eight ranks (one GPU plays them all), assembled on
     rank 0, against the oracle's frame."""

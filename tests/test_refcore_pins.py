@@ -58,6 +58,24 @@ def test_raytrace_floats_equal_the_reference(oracle, oracle_scene, mesh, w, h, d
     assert np.array_equal((c[..., 0] << 16) | (c[..., 1] << 8) | c[..., 2], img)
 
 
+@pytest.mark.parametrize("schedule,threads", [(0, 1), (0, 4), (1, 4)], ids=["per_scanline_1t", "per_scanline_4t", "rows_4t"])
+def test_cpu_baseline_driver_traces_the_pinned_frames(oracle, oracle_scene, schedule, threads):
+    """bench.py's `cpu_baseline` (kind "reference") times oracle/_ref/refcore_omp `timeframes`: the reference's Raytrace<true>
+    under the driver's own frame loop (OpenMP over pixels).  What it traces must be the frames everything else is pinned to:
+    its floats equal the `raytrace` command's on the python-made primary rays, for both loop shapes and any thread count."""
+    if not RC.timing_available():
+        pytest.skip("oracle/_ref/refcore_omp not built")
+    s = oracle_scene("dragon_vis.ply", bvh=True)
+    w, h = 160, 90
+    cams = [oracle.benchmark_frame(f) for f in (0, 37)]
+    lights, n = cams[0][1], cams[0][2]
+    secs, last = RC.time_frames(s, [c[0] for c in cams], lights, n, w, h, 2 * h, threads=threads, schedule=schedule, want_last=True)
+    assert secs.shape == (2,) and (secs > 0).all()
+    ref = RC.raytrace(s, cams[1][0], lights, n, RC.primary_rays(cams[1][0], w, h, 2 * h), 3).reshape(h, w, 3)
+    assert (ref.sum(-1) > 0).sum() > w * h // 50
+    assert _same(ref, last)
+
+
 def test_antialiased_frame_is_the_sum_of_the_reference_subsamples(oracle, oracle_scene):
     w, h = 320, 180
     s = oracle_scene("dragon_vis.ply", bvh=True)
