@@ -22,6 +22,7 @@ def main():
     batch = int(sys.argv[5]) if len(sys.argv) > 5 else 1      # frames per gather (a batched launch on the GPU)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    staged = os.environ.get("MI355_TEST_STAGED") == "1"        # the host-staged transport of `bench.py --dry-run`
     s = O.Scene(assets.mesh_path("dragon_vis.ply"))
     s.bvh_ensure(os.path.join(assets.cache_dir(), "dragon_vis.ply.oracle.bvh"))
     if len(sys.argv) > 6 and sys.argv[6] == "frames":          # whole-frame sharding of a batch (BatchGatherer)
@@ -48,7 +49,7 @@ def main():
         dist.destroy_process_group()
         return
     if len(sys.argv) > 6 and sys.argv[6] == "spread":          # bands of a step's frames, every frame assembled on its owner (SpreadAssembler)
-        g = multigpu.SpreadAssembler(W, H, torch.device("cpu"), frames=batch)
+        g = multigpu.SpreadAssembler(W, H, torch.device("cpu"), frames=batch, staged=staged)
         ys = np.arange(H)
         mine = (ys // multigpu.BAND_ROWS) % world == rank
         ok = g.my_rows == int(mine.sum())
@@ -75,7 +76,7 @@ def main():
             open(out_path, "w").write("OK" if int(flag[0]) == 1 else "MISMATCH")
         dist.destroy_process_group()
         return
-    g = multigpu.FrameGatherer(W, H, torch.device("cpu"), frames=batch)
+    g = multigpu.FrameGatherer(W, H, torch.device("cpu"), frames=batch, staged=staged)
     assert g.my_rows == multigpu.rows_of_rank(H, multigpu.BAND_ROWS, world, rank)
     ok = True
     if batch > 1:

@@ -86,3 +86,18 @@ def test_gloo_frames_assembled_on_their_owners(tmp_path, world, batch, size):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert out.read_text() == "OK"
+
+
+@pytest.mark.parametrize("kind", ["rank0", "spread"])
+def test_gloo_host_staged_transport(tmp_path, kind):
+    """`bench.py --dry-run` moves device buffers through host mirrors (multigpu `staged=True`: device -> host, the collective on
+    the mirrors, host -> device in the work's wait): the same gatherers, the same slots and pending work, frames identical."""
+    out = tmp_path / "result.txt"
+    port = 29500 + (os.getpid() % 2000) + 40 + (1 if kind == "spread" else 0)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(os.path.dirname(__file__), "_gloo_band_worker.py"), str(out), "160", "90", "2", "4"] + (["spread"] if kind == "spread" else [])
+    env = dict(os.environ, OMP_NUM_THREADS="2", MI355_TEST_STAGED="1")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert out.read_text() == "OK"
