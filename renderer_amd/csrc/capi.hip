@@ -52,6 +52,29 @@ namespace {
 
 thread_local std::string g_err;
 
+// MI355_HOST_PROF=1: where the HOST's time goes in the device entry points (scripts/raster_pipe_variants.py: at 25 k raster frames
+// per second the host has 40 us per frame for all of its calls).  Sections are summed and printed when the process ends.
+struct HostProf {
+    enum { N = 12 };
+    double sum[N] = {}; unsigned long long cnt[N] = {};
+    const char *name[N] = {"validate + fill_params", "stream choice + lease_begin", "raster: setup launch", "raster: fill launch", "raster: tile launch",
+                           "lease_done (wait on the caller's stream)", "frame copy launch", "raytrace: select + trace launches", "other", "", "", ""};
+    bool on = false;
+    HostProf() { const char *v = getenv("MI355_HOST_PROF"); on = v && *v && strcmp(v, "0"); }
+    ~HostProf()
+    {
+        if (!on) return;
+        for (int i = 0; i < N; i++) if (cnt[i]) fprintf(stderr, "mi355 host profile: %-44s %9llu x %7.2f us\n", name[i], cnt[i], sum[i] / (double)cnt[i]);
+    }
+    static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+};
+HostProf g_prof;
+struct ProfMark {
+    double t;
+    ProfMark() : t(g_prof.on ? HostProf::now() : 0.0) {}
+    void lap(int i) { if (g_prof.on) { const double n = HostProf::now(); g_prof.sum[i] += n - t; g_prof.cnt[i]++; t = n; } }
+};
+
 int fail(int code, const char *fmt, ...)
 {
     char buf[512];
@@ -115,6 +138,11 @@ inline float disth(V3h a, V3h b) { float dx = a.x - b.x, dy = a.y - b.y, dz = a.
 
 } // namespace
 
+// (for the launchers in the other translation units: laps of the calling thread's stopwatch; no-ops unless MI355_HOST_PROF is set)
+static thread_local ProfMark t_prof;
+extern "C" void mi355i_prof_start(void) { if (g_prof.on) t_prof = ProfMark(); }
+extern "C" void mi355i_prof_lap(int i) { t_prof.lap(i); }
+
 // layout of mi355_ctx::ctrl
 static const size_t MI_CTRL_DISPENSER_OFF = 4096;
 static const size_t MI_CTRL_BYTES = MI_CTRL_DISPENSER_OFF + (size_t)MI_DISPENSERS * MI_DISPENSER_STRIDE * 4;
@@ -148,7 +176,7 @@ struct mi355_ctx {
     // The ordered pipeline (tune flag 64; the fallback when fewer than two usable frame streams are found) keeps the tile
     // kernels on the caller's stream and runs setup + fill of a frame on `pre` beside the tile kernel of the frame before,
     // n_pipe = 3 sets taking turns (with two, a frame's setup waits for the tile kernel two frames back: measured slower).
-    enum { PIPE_SETS = 4 };
+    enum { PIPE_SETS = 7 };
     RasterScratch *rs_pipe[PIPE_SETS] = {};
     int n_pipe = 3;
     hipStream_t pre = nullptr;
@@ -160,7 +188,7 @@ struct mi355_ctx {
     // run in submission order -- a frame stream behind the caller's stream sits behind that stream's waits (measured: 16 k
     // fps with one such stream among three, 26 k with none).  Which streams share is not something the runtime tells:
     // probe_queues() measures it (a 200 us spin kernel on one stream, empty kernels on the others, device time stamps).
-    enum { PIPE_CANDS = 8 };
+    enum { PIPE_CANDS = 16 };
     hipStream_t cand_st[PIPE_CANDS] = {};
     int cand_class[PIPE_CANDS] = {}, n_class = -1;      // candidates with the same class share a queue (-1: not probed yet)
     hipEvent_t ev_probe[PIPE_CANDS + 1] = {};
@@ -189,6 +217,7 @@ struct mi355_ctx {
     hipEvent_t ev_light = nullptr;
     bool ev_light_set = false;
     RasterScratch *rs_light = nullptr;   // the redraw's own row buffer (frames in flight use the other sets)
+    int direct_turn = 0;                 // raytraced frames: whose turn it is to run on the caller's stream itself (enqueue_frame)
     RasterScratch *rscratch = nullptr;
     WireScratch *wscratch = nullptr;     // mode 3 (created with its first frame)
     // pipelined frames (mi355_render_async / _wait): each slot is a stream with its own control block (counters, pixel
@@ -718,7 +747,10 @@ static const mi355_ctx::PipeChoice *pipe_streams_for(mi355_ctx *c, hipStream_t s
         for (int i = 0; i < N; i++) if (c->cand_class[i] == cl) { reps[n] = c->cand_st[i]; rep_class[n++] = i; break; }
     if (!probe_queues(c, st, reps, n, shared)) return nullptr;
     mi355_ctx::PipeChoice pc; pc.caller = st; pc.n = 0;
-    for (int j = 0; j < n && pc.n < (int)mi355_ctx::PIPE_SETS; j++) if (!shared[j]) pc.cand[pc.n++] = rep_class[j];
+    // (how many frames in flight: as many as there are hardware queues besides the caller's -- three with the runtime's default of
+    //  four queues, up to PIPE_SETS when the process was started with GPU_MAX_HW_QUEUES=8; MI355_PIPE_SETS caps it)
+    static const int cap = [] { const char *v = getenv("MI355_PIPE_SETS"); const int k = v ? atoi(v) : 0; return k >= 1 && k <= (int)mi355_ctx::PIPE_SETS ? k : (int)mi355_ctx::PIPE_SETS; }();
+    for (int j = 0; j < n && pc.n < cap; j++) if (!shared[j]) pc.cand[pc.n++] = rep_class[j];
     if (getenv("MI355_PIPE_DEBUG")) {
         fprintf(stderr, "mi355: stream %p: queue classes of the frame streams", (void *)st);
         for (int i = 0; i < N; i++) fprintf(stderr, " %d", c->cand_class[i]);
@@ -731,11 +763,34 @@ static const mi355_ctx::PipeChoice *pipe_streams_for(mi355_ctx *c, hipStream_t s
     return &c->pipe_choice.back();
 }
 
+// The caller's stream sits on a hardware queue of its own (the frame streams were picked so), and all that stream carries for an
+// overlapped frame is a wait and a copy: every (n + 1)-th RAYTRACED frame of a caller therefore runs ON the caller's stream itself --
+// straight into the caller's buffer, no copy --, beside the n frames on the frame streams: four frames in flight on the runtime's
+// four queues instead of three (4 spp 1080p: 966 -> 1 061 fps).  Stream order is the stream's own.  MI355_NO_DIRECT_TURN=1: off.
+static bool direct_turn(mi355_ctx *c, const mi355_ctx::PipeChoice *pc)
+{
+    static const bool off = [] { const char *v = getenv("MI355_NO_DIRECT_TURN"); return v && *v && strcmp(v, "0"); }();
+    if (off) return false;
+    c->direct_turn = (c->direct_turn + 1) % (pc->n + 1);
+    return c->direct_turn == 0;
+}
+
 // One call in flight: resource set k (rasterizer scratch / control block, tile list, camera table), frame stream
 // ps, frame buffer fb = pipe_fb[b].  lease_begin orders ps behind the set's last call, if that ran elsewhere (a call of another
 // caller's stream, of the ordered pipeline, a counting frame, a batch), and behind the copy that last read the buffer;
 // lease_done makes the caller's stream wait for the call's last kernel (`recorded`: that kernel carries ev_tile[k] itself).
 struct FrameLease { int k, b; hipStream_t ps; uint32_t *fb; };
+
+// `st` behind `ev` -- unless the event has completed already: hipStreamWaitEvent costs the host ~5 us when it has to put a
+// barrier packet into the queue and 0.06 us for a query (scripts/ubench/apicost.hip), and the events the frame streams wait for
+// (the copy that last read a buffer two frames ago) have almost always completed
+static hipError_t wait_unless_done(hipStream_t st, hipEvent_t ev)
+{
+    const hipError_t q = hipEventQuery(ev);
+    if (q == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();                  // (hipErrorNotReady is not an error here; it must not be taken for a failed launch later)
+    return hipStreamWaitEvent(st, ev, 0);
+}
 
 static int lease_begin(mi355_ctx *c, const mi355_ctx::PipeChoice *pc, size_t fb_bytes, FrameLease &L)
 {
@@ -744,10 +799,10 @@ static int lease_begin(mi355_ctx *c, const mi355_ctx::PipeChoice *pc, size_t fb_
     L.b = 2 * L.k + c->fb_turn[L.k]; c->fb_turn[L.k] ^= 1;
     HIP_TRY(c->pipe_fb[L.b].ensure(fb_bytes), -31);
     L.fb = (uint32_t *)c->pipe_fb[L.b].p;
-    if (c->ev_tile_set[L.k] && (c->ev_tile_ext[L.k] || c->pipe_st[L.k] != L.ps)) HIP_TRY(hipStreamWaitEvent(L.ps, c->ev_tile[L.k], 0), -40);
+    if (c->ev_tile_set[L.k] && (c->ev_tile_ext[L.k] || c->pipe_st[L.k] != L.ps)) HIP_TRY(wait_unless_done(L.ps, c->ev_tile[L.k]), -40);
     c->pipe_st[L.k] = L.ps;
-    if (c->ev_copy_set[L.b]) HIP_TRY(hipStreamWaitEvent(L.ps, c->ev_copy[L.b], 0), -40);
-    if (c->ev_light_set) HIP_TRY(hipStreamWaitEvent(L.ps, c->ev_light, 0), -40);        // (a shadow map redrawn by mi355_light_update)
+    if (c->ev_copy_set[L.b]) HIP_TRY(wait_unless_done(L.ps, c->ev_copy[L.b]), -40);
+    if (c->ev_light_set) HIP_TRY(wait_unless_done(L.ps, c->ev_light), -40);        // (a shadow map redrawn by mi355_light_update)
     return 0;
 }
 
@@ -784,7 +839,7 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
     if (rt && !own_ctrl && !sel && !stats && !P.cams && !P.no_pipe && !P.outf && !P.wave_prof && c->has_bvh && c->cand_st[0] && P.out_rows > 0 &&
         (P.band_count <= 1 || P.compact)) {
         const mi355_ctx::PipeChoice *pc = pipe_streams_for(c, st);
-        if (pc && pc->n >= 2) {
+        if (pc && pc->n >= 2 && !direct_turn(c, pc)) {
             FrameLease fl;
             if (int r = lease_begin(c, pc, (size_t)P.pitch_words * (size_t)P.out_rows * 4, fl)) return r;
             const int k = fl.k;
@@ -813,6 +868,8 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
             }
             return 0;
         }
+        if (pc && pc->n >= 2 && P.blocks_per_cu == 0)           // (this frame's turn on the caller's stream: it shares the GPU like the others)
+            P.blocks_per_cu = ((long long)((P.W + 7) / 8) * ((P.n_rows + 7) / 8) > 65536ll) ? 4 : 3;
     }
     // (a raster frame that does not count zeroes its control block in its first kernel: one launch less per frame, ~4.7 us)
     const bool raster_self_clear = mode >= MI355_MODE_AMBIENT && mode <= MI355_MODE_PHONG_SOFTSHADOWMAPS && !stats && !P.cams;
@@ -830,17 +887,22 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
         if (c->ev_light_set && (mode == MI355_MODE_PHONG_SHADOWMAPS || mode == MI355_MODE_PHONG_SOFTSHADOWMAPS)) HIP_TRY(hipStreamWaitEvent(st, c->ev_light, 0), -40);
         const mi355_ctx::PipeChoice *pc = nullptr;
         if (raster_self_clear && rs == c->rscratch && c->pre && !P.no_pipe && c->cand_st[0] && P.out_rows > 0) pc = pipe_streams_for(c, st);
+        // (no turn on the caller's stream for raster frames -- measured: 26.1 k -> 22.4 k fps.  Their kernels are short, and the copies
+        //  of the frames behind a frame that occupies the caller's stream wait for it, and with them the frame streams' buffers.)
         if (pc && pc->n >= 2) {
             // overlapped: the whole frame on one of the frame streams, into a frame buffer of the library's; `st` waits for the
             // tile kernel and copies the frame to the caller's buffer
             FrameLease fl;
             if (int r = lease_begin(c, pc, (size_t)P.pitch_words * (size_t)P.out_rows * 4, fl)) return r;
+            mi355i_prof_lap(1);
             FrameParams Q = P;
             Q.out = fl.fb;
             e = mi355i_launch_raster_pipelined(&c->dev, &Q, mode, c->rs_pipe[fl.k], fl.ps, fl.ps, nullptr, c->ev_tile[fl.k]);
             if (e != hipSuccess) break;
             if (int r = lease_done(c, fl, st, true)) return r;       // (ev_tile is the tile kernel's own completion signal)
+            mi355i_prof_lap(5);
             e = mi355i_launch_frame_copy(P.out, Q.out, P.W, P.out_rows, P.pitch_words, st, c->ev_copy[fl.b]);
+            mi355i_prof_lap(6);
             if (e == hipSuccess) c->ev_copy_set[fl.b] = true;
             break;
         }
@@ -1338,11 +1400,15 @@ int mi355_render_device(mi355_ctx *c, int mode, const mi355_camera *cam, const m
                         const mi355_opts *o, void *d_out, int pitch_bytes, void *d_outf, void *hip_stream)
 {
     if (!c || !cam || !o || !d_out || (n_lights > 0 && !lights)) return fail(-3, "mi355_render_device: null argument");
+    mi355i_prof_start();
     if (int r = validate_opts(*o, mode)) return r;
     if (int r = select_device(c)) return r;
     FrameParams P;
     if (int r = fill_params(c, mode, cam, lights, n_lights, o, d_out, pitch_bytes, d_outf, P)) return r;
-    return enqueue_frame(c, mode, P, o->collect_stats, (hipStream_t)hip_stream);
+    mi355i_prof_lap(0);
+    const int r = enqueue_frame(c, mode, P, o->collect_stats, (hipStream_t)hip_stream);
+    mi355i_prof_lap(8);
+    return r;
 }
 
 int mi355_render_batch_device(mi355_ctx *c, int mode, int n_frames, const mi355_camera *cams, const mi355_light *lights,

@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstring>
 
+extern "C" void mi355i_prof_lap(int section);      // capi.hip: host-side stopwatch (MI355_HOST_PROF)
+
 struct RowRec {            // shadow map: one span row (40 B)
     float l[3];
     float r[3];
@@ -203,23 +205,25 @@ MI_DEV void block_pair(const BlockPairs &bp, uint32_t p, int &owner, int &k)
     owner = lo; k = (int)(p - bp.pre[lo]);
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(256) k_rs_setup(const DevScene S, const FrameParams P, const FrameParams *batch, const RsGrid g,
-                                                  const RsBuffers B)
+// One block's 256 triangles of frame f: records, boxes, bin counts, band records (chunk = which 256; n_frames = frames of the
+// launch).  Chunk 0 also zeroes what the later phases of the frame count in (ZERO_CURSOR = false, k_rs_front: not the fill phase's
+// cursors, which other blocks of the SAME launch add to with atomics -- plain stores in this block's L2 would fight them; the tile
+// kernel has left them at zero).
+template <int MODE, bool ZERO_CURSOR = true>
+MI_DEV uint32_t rs_setup_chunk(const DevScene &S, const FrameParams &P, const FrameParams *batch, const RsGrid &g, const RsBuffers &B, BlockPairs &bp,
+                               uint32_t &band_base, const uint32_t chunk, const uint32_t f, const uint32_t n_frames)
 {
-    __shared__ BlockPairs bp;
-    __shared__ uint32_t band_base;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    const uint32_t t = chunk * 256u + threadIdx.x;
     const FrameParams &F = batch ? batch[f] : P;
-    if (blockIdx.x == 0) {                                // rs_fill's cursors and rs_tile's dispenser start at zero
-        for (uint32_t i = threadIdx.x; i < (uint32_t)g.n_bins; i += blockDim.x) B.cursor[(size_t)f * g.n_bins + i] = 0u;
-        if (f == 0 && threadIdx.x < RS_DISPENSERS) B.band_top[gridDim.y + threadIdx.x] = 0u;
+    if (chunk == 0) {                                     // rs_fill's cursors and rs_tile's dispenser start at zero
+        if (ZERO_CURSOR) for (uint32_t i = threadIdx.x; i < (uint32_t)g.n_bins; i += 256u) B.cursor[(size_t)f * g.n_bins + i] = 0u;
+        if (f == 0 && threadIdx.x < RS_DISPENSERS) B.band_top[n_frames + threadIdx.x] = 0u;
         // the frame's control block (header + counters) starts at zero: nothing in this kernel touches it, the later kernels
         // of the frame report overflows there.  (Counting frames are zeroed by the host before the launch: they count here.)
         // (not the overflow counter: the frame before may have reported into it and the host not yet looked -- mi355_fetch_stats
         //  resets it when it reports it)
         if (f == 0 && P.counters && !P.raster_stats && !batch)
-            for (uint32_t i = threadIdx.x; i < (16u + 8u * CS_COUNT) / 4u; i += blockDim.x)
+            for (uint32_t i = threadIdx.x; i < (16u + 8u * CS_COUNT) / 4u; i += 256u)
                 if (i != 4u + 2u * CS_OVERFLOW && i != 5u + 2u * CS_OVERFLOW) ((uint32_t *)((char *)P.counters - 16))[i] = 0u;
     }
     uint4 box = make_uint4(0xffffffffu, 0u, 0u, 0u);
@@ -233,12 +237,12 @@ __global__ void __launch_bounds__(256) k_rs_setup(const DevScene S, const FrameP
         if (act) block_pair(bp, p, owner, k);
         wave_bin_add<false>(cnt, act ? rs_bin_at(g, bp.box[owner], k) : -1, act);
     }
-    // band records: the block's records are one allocation; (triangle, tile row) of each record for k_rs_fill, which
+    // band records: the block's records are one allocation; (triangle, tile row) of each record for the fill phase, which
     // computes them
     __syncthreads();                                      // (bp is reused)
     const uint32_t n_bands = block_pairs_begin(bp, box, rs_band_count(box));
     if (threadIdx.x == 0) {
-        band_base = n_bands ? atomicAdd(&B.band_top[f], n_bands) : 0u;     // (more than band_cap: k_rs_fill reports it)
+        band_base = n_bands ? atomicAdd(&B.band_top[f], n_bands) : 0u;     // (more than band_cap: the fill phase reports it)
     }
     __syncthreads();
     if (box.x != 0xffffffffu) rs_set_band_base(B, S.n_tris, f, t, band_base + bp.pre[threadIdx.x]);
@@ -249,8 +253,18 @@ __global__ void __launch_bounds__(256) k_rs_setup(const DevScene S, const FrameP
         int owner = 0, j = 0;
         block_pair(bp, p, owner, j);
         if (band_base + p < B.band_cap)
-            owner_of[band_base + p] = make_uint2(blockIdx.x * blockDim.x + (uint32_t)owner, (bp.box[owner].z & 0xffffu) / RS_BH + (uint32_t)j);
+            owner_of[band_base + p] = make_uint2(chunk * 256u + (uint32_t)owner, (bp.box[owner].z & 0xffffu) / RS_BH + (uint32_t)j);
     }
+    return n_bands;          // (the block's band records: band_base .. band_base + n_bands)
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_rs_setup(const DevScene S, const FrameParams P, const FrameParams *batch, const RsGrid g,
+                                                  const RsBuffers B)
+{
+    __shared__ BlockPairs bp;
+    __shared__ uint32_t band_base;
+    (void)rs_setup_chunk<MODE>(S, P, batch, g, B, bp, band_base, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
 // exclusive scan of one frame's bin counts (block f = frame f); offset[n] = the frame's total.  Only for frames with more
@@ -311,6 +325,7 @@ MI_DEV void tile_order(const RsGrid &g, const RsBuffers &B, uint32_t f, const ui
 }
 
 // exclusive scan of frame f's bin counts into LDS (soff[n_bins + 1]) by a 256-thread block; tot: 4 words of LDS
+template <bool COHERENT = false>
 MI_DEV uint32_t block_scan_counts(const RsGrid &g, const RsBuffers &B, uint32_t f, uint32_t *soff, uint32_t *tot)
 {
     const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -319,7 +334,10 @@ MI_DEV uint32_t block_scan_counts(const RsGrid &g, const RsBuffers &B, uint32_t 
     const uint32_t b = (uint32_t)tid * per < n ? (uint32_t)tid * per : n, e = b + per < n ? b + per : n;
     uint32_t c[(RS_SCAN_LDS + 255) / 256], s = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < (RS_SCAN_LDS + 255) / 256; i++) { c[i] = b + i < e ? cnt[b + i] : 0u; s += c[i]; }
+    for (uint32_t i = 0; i < (RS_SCAN_LDS + 255) / 256; i++) {
+        // (COHERENT: the counts were added to by other blocks of THIS launch -- read them where the atomics put them)
+        c[i] = b + i < e ? (COHERENT ? __hip_atomic_load(&cnt[b + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : cnt[b + i]) : 0u; s += c[i];
+    }
     uint32_t incl = s;
     for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += v; }
     if (lane == 63) tot[wid] = incl;
@@ -332,6 +350,31 @@ MI_DEV uint32_t block_scan_counts(const RsGrid &g, const RsBuffers &B, uint32_t 
     if (tid == 0) soff[n] = total;
     __syncthreads();
     return total;
+}
+
+// The bin entries of one block's 256 triangles (chunk) of frame f; off = the frame's bin offsets
+MI_DEV void rs_fill_chunk(const RsGrid &g, const RsBuffers &B, BlockPairs &bp, const uint32_t *off, uint32_t n_tris, const uint32_t chunk, const uint32_t f)
+{
+    const int tid = (int)threadIdx.x;
+    const uint32_t t = chunk * 256u + threadIdx.x;
+    uint4 box = make_uint4(0xffffffffu, 0u, 0u, 0u);
+    if (t < n_tris) box = B.box[(size_t)f * n_tris + t];
+    const uint32_t total = block_pairs_begin(bp, box, box.x == 0xffffffffu ? 0 : rs_bin_count(box));
+    uint32_t *cur = B.cursor + (size_t)f * g.n_bins;
+    uint4 *bins = B.bins + (size_t)f * B.bins_cap;
+    for (uint32_t base = 0; base < total; base += 256u) {
+        const uint32_t p = base + (uint32_t)tid;
+        const bool act = p < total;
+        int owner = 0, k = 0;
+        if (act) block_pair(bp, p, owner, k);
+        const uint4 pb = bp.box[owner];
+        const int bin = act ? rs_bin_at(g, pb, k) : -1;
+        const uint32_t pos = wave_bin_add<true>(cur, bin, act);
+        if (act) {
+            const uint32_t at = off[bin] + pos;
+            if (at < B.bins_cap) bins[at] = make_uint4(chunk * 256u + (uint32_t)owner, pb.x, pb.z, pb.w);   // (else: the overflow has been reported)
+        }
+    }
 }
 
 // Bin entries and band records.  LDS_SCAN: the bin offsets are the block's own exclusive scan of the frame's counts;
@@ -363,26 +406,7 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
             off = soff;
         }
         if (blockIdx.x == order_block) tile_order(g, B, f, off, stot);      // (off: this block's scan, or k_rs_scan's)
-        if (blockIdx.x < fill_blocks) {
-            uint4 box = make_uint4(0xffffffffu, 0u, 0u, 0u);
-            if (t < n_tris) box = B.box[(size_t)f * n_tris + t];
-            const uint32_t total = block_pairs_begin(bp, box, box.x == 0xffffffffu ? 0 : rs_bin_count(box));
-            uint32_t *cur = B.cursor + (size_t)f * g.n_bins;
-            uint4 *bins = B.bins + (size_t)f * B.bins_cap;
-            for (uint32_t base = 0; base < total; base += 256u) {
-                const uint32_t p = base + (uint32_t)tid;
-                const bool act = p < total;
-                int owner = 0, k = 0;
-                if (act) block_pair(bp, p, owner, k);
-                const uint4 pb = bp.box[owner];
-                const int bin = act ? rs_bin_at(g, pb, k) : -1;
-                const uint32_t pos = wave_bin_add<true>(cur, bin, act);
-                if (act) {
-                    const uint32_t at = off[bin] + pos;
-                    if (at < B.bins_cap) bins[at] = make_uint4(blockIdx.x * blockDim.x + (uint32_t)owner, pb.x, pb.z, pb.w);   // (else: the overflow has been reported)
-                }
-            }
-        }
+        if (blockIdx.x < fill_blocks) rs_fill_chunk(g, B, bp, off, n_tris, blockIdx.x, f);
     }
     uint32_t n_rec = B.band_top[f];
     if (n_rec > B.band_cap) {
@@ -399,6 +423,96 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
         rs_clear_out(F, per * (blockIdx.x - first_block), per, tid, (int)blockDim.x);
     }
     for (uint32_t p = (blockIdx.x - first_block) * blockDim.x + (uint32_t)tid; p < n_items; p += n_blocks * blockDim.x) rs_band_item(B, n_tris, f, p, height);
+}
+
+// ---- one launch in front of the tile kernel (single frames whose bins k_rs_fill would scan in LDS) --------------------------
+// k_rs_setup and k_rs_fill as the two phases of ONE kernel: a frame's three launches are three launch skeletons on the device --
+// ~10 us between dependent kernels of a stream, each boundary writing the eight L2s back and invalidating them -- and three of the
+// host's ~5 us calls.  The fill phase needs every triangle's bin count, i.e. the whole setup phase: a grid-wide dependency inside a
+// launch, on a GPU whose L2s are not coherent with each other.  Two things make it cheap and safe:
+//  * NOTHING but atomics crosses from one block to another.  A block keeps the chunks (256 triangles) it set up: it computes their
+//    band records itself, right away (k_rs_fill's blocks did that for everybody), and after the wait it writes the bin entries of
+//    the same chunks from the boxes it stored itself.  What it needs of the others are the bin counts -- atomic adds, read back
+//    with loads of agent scope -- so no block ever has to write its L2 back or invalidate it.  (The first version fenced per chunk:
+//    `buffer_wbl2 sc1` / `buffer_inv sc1` a few hundred times per launch made it 110 us against the two kernels' 28.)
+//  * The work is CLAIMED, not assigned: a block takes chunks (then 32-KB pieces of the background) from a counter until none are
+//    left and then waits until every claimed one is done -- chunks are only ever claimed by blocks that are running, so the wait
+//    ends however many blocks of the grid the GPU has admitted so far; a block admitted later finds nothing to claim and nothing
+//    to do.  (The wait polls with relaxed loads; bounded: a wait that never ended would take the GPU with it, the frame is reported
+//    incomplete instead, like one whose bins overflowed.)
+// B.sync: [0] items claimed, [32] done (a cache line each); B.cursor and B.sync are left at zero by the tile kernel (and by the
+// allocation).
+#define RS_CLEAR_WORDS 8192u       // words of the background per item
+#define RS_FRONT_KEEP 64           // chunks one block keeps at most (it stops claiming then)
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_rs_front(const DevScene S, const FrameParams P, const RsGrid g, const RsBuffers B, unsigned long long *counters,
+                                                  const int clear)
+{
+    __shared__ BlockPairs bp;
+    __shared__ uint32_t soff[RS_SCAN_LDS + 1];
+    __shared__ uint32_t stot[4];
+    __shared__ uint32_t s_item, band_base;
+    __shared__ uint32_t mine[RS_FRONT_KEEP];
+    const int tid = (int)threadIdx.x;
+    const uint32_t nbT = (S.n_tris + 255u) / 256u;
+    const unsigned long long words = (unsigned long long)P.out_rows * (unsigned long long)P.W;
+    const uint32_t n_clear = clear ? (uint32_t)((words + RS_CLEAR_WORDS - 1ull) / RS_CLEAR_WORDS) : 0u;
+    const uint32_t n_a = nbT + n_clear;
+    // ---- phase A: triangle setup (k_rs_setup's block) + the chunk's band records; the background (Screen::ClearScreen)
+    // (ONE thread-0 region per trip, at its top: the "done" of the item before and the next claim.  With the "done" at the bottom
+    //  the compiler threads thread 0 from there straight into the next claim and lets the other lanes of its wave run ahead into
+    //  the barrier -- a wave then arrives at s_barrier twice per trip and the block hangs: seen in the ISA, and on the GPU.)
+    bool prev = false;
+    uint32_t n_mine = 0;
+    for (;;) {
+        if (tid == 0) {
+            if (prev) atomicAdd(&B.sync[32], 1u);
+            s_item = n_mine < RS_FRONT_KEEP ? atomicAdd(&B.sync[0], 1u) : 0xffffffffu;
+        }
+        __syncthreads();
+        const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);
+        if (item >= n_a) break;
+        if (item < nbT) {
+            const uint32_t n_bands = rs_setup_chunk<MODE, false>(S, P, nullptr, g, B, bp, band_base, item, 0u, 1u);
+            __syncthreads();                              // (the chunk's records and band owners: written by this block, read by it)
+            const uint32_t r0 = band_base, r1 = r0 + n_bands < B.band_cap ? r0 + n_bands : B.band_cap;
+            if (r1 > r0) for (uint32_t p = 3u * r0 + (uint32_t)tid; p < 3u * r1; p += 256u) rs_band_item(B, S.n_tris, 0u, p, P.H);
+            if (tid == 0) mine[n_mine] = item;
+            n_mine++;
+        } else rs_clear_out(P, (unsigned long long)(item - nbT) * RS_CLEAR_WORDS, RS_CLEAR_WORDS, tid, 256);
+        __syncthreads();
+        prev = true;
+    }
+    if (n_mine == 0) return;                              // (nothing set up here: nothing to fill, nothing to wait for)
+    // ---- every claimed item of phase A done.  (Only the blocks that go on wait, and the word they poll has a cache line of its
+    //      own: with every block of the grid polling a word beside the claim counter, the polls -- they go to memory like the
+    //      atomics -- starved the claims and the band allocations of the blocks that were still working: 110 us per launch.)
+    if (tid == 0) {
+        uint32_t spins = 0;
+        while (__hip_atomic_load(&B.sync[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_a) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > (1u << 18)) { if (counters) atomicAdd(&counters[CS_OVERFLOW], 1ull); break; }      // (~0.4 s)
+        }
+    }
+    __syncthreads();
+    // ---- phase B: the bin entries of this block's own chunks; the block that set up chunk 0 publishes offsets and tile order
+    const uint32_t total = block_scan_counts<true>(g, B, 0u, soff, stot);
+    bool publish = false;
+    for (uint32_t k = 0; k < n_mine; k++) {
+        const uint32_t chunk = mine[k];
+        publish = publish || chunk == 0u;
+        rs_fill_chunk(g, B, bp, soff, S.n_tris, chunk, 0u);
+        __syncthreads();
+    }
+    if (publish) {
+        for (uint32_t i = (uint32_t)tid; i <= (uint32_t)g.n_bins; i += 256u) B.offset[i] = soff[i];
+        if (tid == 0 && counters) {
+            if (total > B.bins_cap) atomicAdd(&counters[CS_OVERFLOW], (unsigned long long)(total - B.bins_cap));
+            if (__hip_atomic_load(&B.band_top[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > B.band_cap) atomicAdd(&counters[CS_OVERFLOW], 1ull);
+        }
+        tile_order(g, B, 0u, soff, stot);
+    }
 }
 
 // Phase profile of counting frames (collect_stats): thread 0 of every block sums the cycles between the barriers and adds
@@ -428,11 +542,13 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
     uint32_t max_active = 0;
     for (int ff = 0; ff < n_frames; ff++) { const uint32_t a = B.order[(size_t)ff * ((size_t)g.n_tiles + 1)]; max_active = a > max_active ? a : max_active; }
     const uint32_t total_items = max_active * (uint32_t)n_frames;
-    if (blockIdx.x == 0)                                      // the next frame's rs_setup counts from zero
+    if (blockIdx.x == 0) {                                    // the next frame's rs_setup counts from zero
         for (int ff = 0; ff < n_frames; ff++) {
-            for (uint32_t i = (uint32_t)tid; i < (uint32_t)g.n_bins; i += (uint32_t)nt) B.count[(size_t)ff * g.n_bins + i] = 0u;
+            for (uint32_t i = (uint32_t)tid; i < (uint32_t)g.n_bins; i += (uint32_t)nt) { B.count[(size_t)ff * g.n_bins + i] = 0u; B.cursor[(size_t)ff * g.n_bins + i] = 0u; }
             if (tid == 0) B.band_top[ff] = 0u;
         }
+        if (tid < 2) B.sync[32 * tid] = 0u;                   // ... and its k_rs_front claims from zero, fills from cursors at zero
+    }
     for (uint32_t w = blockIdx.x; w < total_items;) {
         const uint32_t f = w % (uint32_t)n_frames, slot = w / (uint32_t)n_frames;
         const uint32_t *order = B.order + (size_t)f * ((size_t)g.n_tiles + 1);
@@ -796,6 +912,10 @@ template <class T> static hipError_t regrow(T *&p, size_t &have, size_t want)
     return e;
 }
 
+// words behind RsBuffers::band_top: the frames' band counters, the tile dispensers, then -- from the next 128-byte line -- two lines for
+// k_rs_front's counters (RsBuffers::sync)
+static size_t rs_top_words(int n_frames) { return (((size_t)n_frames + RS_DISPENSERS + 31) & ~(size_t)31) + 64; }
+
 // buffers of the tiled pipeline for n_frames frames of W x H with n_tris triangles
 static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tris, int n_frames, hipStream_t st)
 {
@@ -831,7 +951,8 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
     // cut short) starts from a cleared array
     if (s->count_bins != g.n_bins || s->count_frames != n_frames) {
         if ((e = hipMemsetAsync(s->B.count, 0, words * 4, st)) != hipSuccess) return e;
-        if (s->B.band_top && (e = hipMemsetAsync(s->B.band_top, 0, ((size_t)s->band_frames + RS_DISPENSERS) * 4, st)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(s->B.cursor, 0, words * 4, st)) != hipSuccess) return e;
+        if (s->B.band_top && (e = hipMemsetAsync(s->B.band_top, 0, rs_top_words(s->band_frames) * 4, st)) != hipSuccess) return e;
         s->count_bins = g.n_bins; s->count_frames = n_frames;
     }
     // Bin entries per frame (16 bytes each): three per triangle cover meshes of small triangles (chessboard, dragon:
@@ -861,11 +982,12 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
         s->band_words = (size_t)bcap * n_frames;
     }
     s->B.band_cap = (uint32_t)(s->band_words / (size_t)n_frames < bcap ? s->band_words / (size_t)n_frames : bcap);
+    struct SyncAt { RasterScratch *s; int nf; ~SyncAt() { s->B.sync = s->B.band_top ? s->B.band_top + rs_top_words(nf) - 64 : nullptr; } } sync_at{s, n_frames};   // (on every path out)
     if (n_frames != s->band_frames || !s->B.band_top) {
         if (s->B.band_top) (void)hipFree(s->B.band_top);
         s->B.band_top = nullptr; s->band_frames = 0;
-        if ((e = hipMalloc((void **)&s->B.band_top, ((size_t)n_frames + RS_DISPENSERS) * 4)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(s->B.band_top, 0, ((size_t)n_frames + RS_DISPENSERS) * 4, st)) != hipSuccess) return e;
+        if ((e = hipMalloc((void **)&s->B.band_top, rs_top_words(n_frames) * 4)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(s->B.band_top, 0, rs_top_words(n_frames) * 4, st)) != hipSuccess) return e;
         s->band_frames = n_frames;
     }
     return hipSuccess;
@@ -888,7 +1010,20 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     if (e != hipSuccess) return e;
     const int nbT = (int)((S->n_tris + 255) / 256);
     const dim3 per_tri(nbT > 0 ? nbT : 1, n_frames);
+    // single frames: setup and fill as the two phases of one launch (k_rs_front) on request -- MI355_RS_FUSED=1.  Measured slower
+    // (18.1 k against 26.1 k frames/s, the launch 92 us against the two kernels' 28): see the kernel's header.
+    static const bool fused_front = [] { const char *v = getenv("MI355_RS_FUSED"); return v && *v && strcmp(v, "0"); }();
+    const bool fused = !piped && n_frames == 1 && !d_batch && g.n_bins <= RS_SCAN_LDS && fused_front;
+    if (fused) {
+        // (blocks claim their work: enough of them for the setup chunks plus the background or band items beside them)
+        unsigned blocks = 2u * per_tri.x + 64u;
+        if (blocks < 256u) blocks = 256u;
+        if (blocks > 1024u) blocks = 1024u;
+        hipLaunchKernelGGL((k_rs_front<MODE>), dim3(blocks), dim3(256), 0, st, *S, *P, g, s->B, P->counters, whole ? 0 : 1);
+        mi355i_prof_lap(2);
+    } else {
     hipLaunchKernelGGL((k_rs_setup<MODE>), per_tri, dim3(256), 0, st, *S, *P, d_batch, g, s->B);
+    mi355i_prof_lap(2);
     // (the fill kernel's grid also has to carry the band items: at least four blocks per CU)
     const dim3 fill_grid(per_tri.x > 1024u ? per_tri.x : 1024u, n_frames);
     if (piped && g.n_bins <= RS_SCAN_LDS)       // (fill_done is this kernel's own completion signal)
@@ -897,6 +1032,8 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     else {
         hipLaunchKernelGGL(k_rs_scan, dim3(n_frames), dim3(1024), 0, st, g, s->B, P->counters);
         hipLaunchKernelGGL(k_rs_fill<false>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters, piped || whole ? 0 : 1);
+    }
+    mi355i_prof_lap(3);
     }
     if (piped) {
         if (g.n_bins > RS_SCAN_LDS && (e = hipEventRecord(fill_done, pre)) != hipSuccess) return e;
@@ -912,6 +1049,7 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     if (piped || whole) hipExtLaunchKernelGGL((k_rs_tile<MODE, 4>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, nullptr, tile_done, 0, *S, *P, d_batch, n_frames, g, s->B, 1);
     else if (n_frames > 1) hipLaunchKernelGGL((k_rs_tile<MODE, 5>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B, 0);
     else hipLaunchKernelGGL((k_rs_tile<MODE, 4>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B, 0);
+    mi355i_prof_lap(4);
     return hipGetLastError();
 }
 

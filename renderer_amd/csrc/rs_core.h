@@ -100,6 +100,8 @@ struct RsBuffers {
                                    //                        word: k_rs_tile's tile dispenser (zeroed by rs_setup)
     uint2 *band_owner;             // [frames][band_cap]     (triangle, band = scanline / RS_BH) of each band record
     uint32_t *order;               // [frames][n_tiles + 1]  [0] = number of tiles with bin entries, then those tiles, then the others (rs_fill)
+    uint32_t *sync;                // [64]                   k_rs_front's counters: [0] items claimed, [32] items done (a cache line each, behind
+                                   //                        band_top's words; zeroed again by rs_tile)
 };
 
 // y -> output row, or -1 when the row belongs to another GPU's band

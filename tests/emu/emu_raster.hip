@@ -153,6 +153,7 @@ extern "C" int emu_raster(uint32_t n_tris, uint32_t n_verts, const float *rs_tri
     std::vector<uint32_t> band_top((size_t)n_frames, 0u);
     std::vector<uint2> band_owner((size_t)band_cap * n_frames, make_uint2(0xdeadbeefu, 0xdeadbeefu));
     RsBuffers B;
+    B.order = nullptr; B.sync = nullptr;
     B.band = band.data(); B.band_cap = band_cap; B.band_top = band_top.data(); B.band_owner = band_owner.data();
     B.rec = rec.data(); B.box = box.data(); B.count = count.data(); B.cursor = cursor.data(); B.offset = offset.data(); B.bins = bins.data(); B.bins_cap = bins_cap;
     switch (mode) {
