@@ -105,7 +105,8 @@ typedef struct {
      *            other lanes' rays -- a shadow ray's verdict is an OR over the triangles its walk reaches, a closest-hit ray's
      *            hit the minimum of (distance, triangle) over them: same pixels whoever walks what)
      * [6] raytrace: idle lanes of a wave before subtrees are handed over (default 16)
-     * [7] reserved */
+     * [7] rasterizer: a 16x16-pixel tile whose triangle bins hold more than this many entries is drawn by 2 blocks (strips of 8
+     *     rows), beyond twice that by 4 (0 = never, the default: no threshold was faster than whole tiles) */
     int32_t tune[8];
     /* Compile-time extras of the reference, off by default like there: */
     int32_t mlaa;            /* configure --enable-mlaa && !$NOMLAA: the morphological anti-aliasing post filter (MLAA.cc) on

@@ -387,6 +387,9 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.tile_sel = nullptr; P.tile_cnt = nullptr;
     P.blocks_per_cu = t[4] > 0 ? t[4] : 0;
     P.rs_threads = t[3];
+    // (heavy tiles in strips of rows: tune[7] = the bin-entry threshold; 0 = never, the default -- measured: no threshold pays, a
+    //  tile's time is a chain of dependent round trips, not its volume of work: profiles/r04_analysis.md)
+    P.rs_split = t[7] > 0 ? t[7] : 0;
     P.mlaa = o->mlaa ? 1 : 0;
     if (P.mlaa) {
         if (o->band_count > 1) return fail(-20, "mlaa works on whole frames: no band sharding (mi355_mgpu_render filters the assembled frame)");

@@ -206,17 +206,15 @@ MI_DEV void block_pair(const BlockPairs &bp, uint32_t p, int &owner, int &k)
 }
 
 // One block's 256 triangles of frame f: records, boxes, bin counts, band records (chunk = which 256; n_frames = frames of the
-// launch).  Chunk 0 also zeroes what the later phases of the frame count in (ZERO_CURSOR = false, k_rs_front: not the fill phase's
-// cursors, which other blocks of the SAME launch add to with atomics -- plain stores in this block's L2 would fight them; the tile
-// kernel has left them at zero).
-template <int MODE, bool ZERO_CURSOR = true>
+// launch).  Chunk 0 also zeroes what the later phases of the frame count in.
+template <int MODE>
 MI_DEV uint32_t rs_setup_chunk(const DevScene &S, const FrameParams &P, const FrameParams *batch, const RsGrid &g, const RsBuffers &B, BlockPairs &bp,
                                uint32_t &band_base, const uint32_t chunk, const uint32_t f, const uint32_t n_frames)
 {
     const uint32_t t = chunk * 256u + threadIdx.x;
     const FrameParams &F = batch ? batch[f] : P;
     if (chunk == 0) {                                     // rs_fill's cursors and rs_tile's dispenser start at zero
-        if (ZERO_CURSOR) for (uint32_t i = threadIdx.x; i < (uint32_t)g.n_bins; i += 256u) B.cursor[(size_t)f * g.n_bins + i] = 0u;
+        for (uint32_t i = threadIdx.x; i < (uint32_t)g.n_bins; i += 256u) B.cursor[(size_t)f * g.n_bins + i] = 0u;
         if (f == 0 && threadIdx.x < RS_DISPENSERS) B.band_top[n_frames + threadIdx.x] = 0u;
         // the frame's control block (header + counters) starts at zero: nothing in this kernel touches it, the later kernels
         // of the frame report overflows there.  (Counting frames are zeroed by the host before the launch: they count here.)
@@ -296,36 +294,54 @@ __global__ void __launch_bounds__(1024) k_rs_scan(const RsGrid g, const RsBuffer
 
 #define RS_SCAN_LDS 2048          // frames with at most this many bins (1080p: 511, 4K: 2041): every block of k_rs_fill scans the counts itself
 
-// The tiles of a frame, those whose bins hold entries first: k_rs_tile starts with them and knows the others to be
-// background without reading anything.  One block; off = the frame's bin offsets; tot = 4 words of LDS.
-MI_DEV void tile_order(const RsGrid &g, const RsBuffers &B, uint32_t f, const uint32_t *off, uint32_t *tot)
+// The work items of the tile kernel: the tiles of a frame whose bins hold entries (the others are background: nobody reads
+// anything for them).  A tile's cost is that of its heaviest phases -- (triangle, scanline) items, then runs -- and the kernel lasts
+// as long as its heaviest tile: three times the average tile on the chessboard (counting frames: 322 k cycles against 110 k).  Both
+// phases work scanline by scanline, so a heavy tile is cut into STRIPS of rows, each a work item of its own: 2 strips of 8 rows
+// when the tile's bins hold more than `split` entries, 4 of 4 rows beyond twice that (the bin's entry count is the cost's proxy;
+// FrameParams::rs_split, tune[7]).  Item = tile | strip << 24 | (strips - 1) << 28; order[0] = their number.  A frame whose items
+// would not fit the list (n_tiles entries) is not split.  One block; off = the frame's bin offsets; tot = 4 words of LDS.
+#define RS_ITEM_TILE(i) ((i) & 0xffffffu)
+#define RS_ITEM_STRIP(i) (((i) >> 24) & 15u)
+#define RS_ITEM_STRIPS(i) (((i) >> 28) + 1u)
+
+MI_DEV void tile_order(const RsGrid &g, const RsBuffers &B, uint32_t f, const uint32_t *off, uint32_t *tot, uint32_t split)
 {
     const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t n = (uint32_t)g.n_tiles, per = (n + 255u) / 256u;
     const uint32_t b = (uint32_t)tid * per < n ? (uint32_t)tid * per : n, e = b + per < n ? b + per : n;
-    const bool global_any = off[g.n_coarse + 1] != off[g.n_coarse];
-    auto active = [&](uint32_t tile) {
-        const int tx = (int)(tile % (uint32_t)g.tiles_x), ty = (int)(tile / (uint32_t)g.tiles_x);
-        const int cb = (ty / RS_CB) * g.cx + tx / RS_CB;
-        return global_any || off[cb + 1] != off[cb];
-    };
-    uint32_t mine = 0;
-    for (uint32_t i = b; i < e; i++) mine += active(i) ? 1u : 0u;
-    uint32_t incl = mine;
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += v; }
-    __syncthreads();
-    if (lane == 63) tot[wid] = incl;
-    __syncthreads();
-    uint32_t before = 0, n_active = 0;
-    for (int w = 0; w < 4; w++) { const uint32_t v = tot[w]; if (w < wid) before += v; n_active += v; }
+    const uint32_t n_global = off[g.n_coarse + 1] - off[g.n_coarse];
     uint32_t *order = B.order + (size_t)f * (n + 1);
-    uint32_t ia = before + incl - mine, ib = n_active + (b - ia);          // (tiles before b that are not active: b - ia)
-    for (uint32_t i = b; i < e; i++) { if (active(i)) order[1 + ia++] = i; else order[1 + ib++] = i; }
-    if (tid == 0) order[0] = n_active;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        auto strips = [&](uint32_t tile) -> uint32_t {
+            const int tx = (int)(tile % (uint32_t)g.tiles_x), ty = (int)(tile / (uint32_t)g.tiles_x);
+            const int cb = (ty / RS_CB) * g.cx + tx / RS_CB;
+            const uint32_t entries = off[cb + 1] - off[cb] + n_global;
+            if (!entries) return 0u;
+            if (attempt || !split) return 1u;
+            return entries > 2u * split ? 4u : (entries > split ? 2u : 1u);
+        };
+        uint32_t mine = 0;
+        for (uint32_t i = b; i < e; i++) mine += strips(i);
+        uint32_t incl = mine;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += v; }
+        __syncthreads();
+        if (lane == 63) tot[wid] = incl;
+        __syncthreads();
+        uint32_t before = 0, n_items = 0;
+        for (int w = 0; w < 4; w++) { const uint32_t v = tot[w]; if (w < wid) before += v; n_items += v; }
+        if (n_items > n) continue;                       // (does not fit: once more without strips -- at most n items then)
+        uint32_t at = before + incl - mine;
+        for (uint32_t i = b; i < e; i++) {
+            const uint32_t ns = strips(i);
+            for (uint32_t k = 0; k < ns; k++) order[1 + at++] = i | (k << 24) | ((ns - 1u) << 28);
+        }
+        if (tid == 0) order[0] = n_items;
+        break;
+    }
 }
 
 // exclusive scan of frame f's bin counts into LDS (soff[n_bins + 1]) by a 256-thread block; tot: 4 words of LDS
-template <bool COHERENT = false>
 MI_DEV uint32_t block_scan_counts(const RsGrid &g, const RsBuffers &B, uint32_t f, uint32_t *soff, uint32_t *tot)
 {
     const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -334,10 +350,7 @@ MI_DEV uint32_t block_scan_counts(const RsGrid &g, const RsBuffers &B, uint32_t 
     const uint32_t b = (uint32_t)tid * per < n ? (uint32_t)tid * per : n, e = b + per < n ? b + per : n;
     uint32_t c[(RS_SCAN_LDS + 255) / 256], s = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < (RS_SCAN_LDS + 255) / 256; i++) {
-        // (COHERENT: the counts were added to by other blocks of THIS launch -- read them where the atomics put them)
-        c[i] = b + i < e ? (COHERENT ? __hip_atomic_load(&cnt[b + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : cnt[b + i]) : 0u; s += c[i];
-    }
+    for (uint32_t i = 0; i < (RS_SCAN_LDS + 255) / 256; i++) { c[i] = b + i < e ? cnt[b + i] : 0u; s += c[i]; }
     uint32_t incl = s;
     for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += v; }
     if (lane == 63) tot[wid] = incl;
@@ -405,7 +418,7 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
             }
             off = soff;
         }
-        if (blockIdx.x == order_block) tile_order(g, B, f, off, stot);      // (off: this block's scan, or k_rs_scan's)
+        if (blockIdx.x == order_block) tile_order(g, B, f, off, stot, (uint32_t)F.rs_split);      // (off: this block's scan, or k_rs_scan's)
         if (blockIdx.x < fill_blocks) rs_fill_chunk(g, B, bp, off, n_tris, blockIdx.x, f);
     }
     uint32_t n_rec = B.band_top[f];
@@ -423,96 +436,6 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
         rs_clear_out(F, per * (blockIdx.x - first_block), per, tid, (int)blockDim.x);
     }
     for (uint32_t p = (blockIdx.x - first_block) * blockDim.x + (uint32_t)tid; p < n_items; p += n_blocks * blockDim.x) rs_band_item(B, n_tris, f, p, height);
-}
-
-// ---- one launch in front of the tile kernel (single frames whose bins k_rs_fill would scan in LDS) --------------------------
-// k_rs_setup and k_rs_fill as the two phases of ONE kernel: a frame's three launches are three launch skeletons on the device --
-// ~10 us between dependent kernels of a stream, each boundary writing the eight L2s back and invalidating them -- and three of the
-// host's ~5 us calls.  The fill phase needs every triangle's bin count, i.e. the whole setup phase: a grid-wide dependency inside a
-// launch, on a GPU whose L2s are not coherent with each other.  Two things make it cheap and safe:
-//  * NOTHING but atomics crosses from one block to another.  A block keeps the chunks (256 triangles) it set up: it computes their
-//    band records itself, right away (k_rs_fill's blocks did that for everybody), and after the wait it writes the bin entries of
-//    the same chunks from the boxes it stored itself.  What it needs of the others are the bin counts -- atomic adds, read back
-//    with loads of agent scope -- so no block ever has to write its L2 back or invalidate it.  (The first version fenced per chunk:
-//    `buffer_wbl2 sc1` / `buffer_inv sc1` a few hundred times per launch made it 110 us against the two kernels' 28.)
-//  * The work is CLAIMED, not assigned: a block takes chunks (then 32-KB pieces of the background) from a counter until none are
-//    left and then waits until every claimed one is done -- chunks are only ever claimed by blocks that are running, so the wait
-//    ends however many blocks of the grid the GPU has admitted so far; a block admitted later finds nothing to claim and nothing
-//    to do.  (The wait polls with relaxed loads; bounded: a wait that never ended would take the GPU with it, the frame is reported
-//    incomplete instead, like one whose bins overflowed.)
-// B.sync: [0] items claimed, [32] done (a cache line each); B.cursor and B.sync are left at zero by the tile kernel (and by the
-// allocation).
-#define RS_CLEAR_WORDS 8192u       // words of the background per item
-#define RS_FRONT_KEEP 64           // chunks one block keeps at most (it stops claiming then)
-
-template <int MODE>
-__global__ void __launch_bounds__(256) k_rs_front(const DevScene S, const FrameParams P, const RsGrid g, const RsBuffers B, unsigned long long *counters,
-                                                  const int clear)
-{
-    __shared__ BlockPairs bp;
-    __shared__ uint32_t soff[RS_SCAN_LDS + 1];
-    __shared__ uint32_t stot[4];
-    __shared__ uint32_t s_item, band_base;
-    __shared__ uint32_t mine[RS_FRONT_KEEP];
-    const int tid = (int)threadIdx.x;
-    const uint32_t nbT = (S.n_tris + 255u) / 256u;
-    const unsigned long long words = (unsigned long long)P.out_rows * (unsigned long long)P.W;
-    const uint32_t n_clear = clear ? (uint32_t)((words + RS_CLEAR_WORDS - 1ull) / RS_CLEAR_WORDS) : 0u;
-    const uint32_t n_a = nbT + n_clear;
-    // ---- phase A: triangle setup (k_rs_setup's block) + the chunk's band records; the background (Screen::ClearScreen)
-    // (ONE thread-0 region per trip, at its top: the "done" of the item before and the next claim.  With the "done" at the bottom
-    //  the compiler threads thread 0 from there straight into the next claim and lets the other lanes of its wave run ahead into
-    //  the barrier -- a wave then arrives at s_barrier twice per trip and the block hangs: seen in the ISA, and on the GPU.)
-    bool prev = false;
-    uint32_t n_mine = 0;
-    for (;;) {
-        if (tid == 0) {
-            if (prev) atomicAdd(&B.sync[32], 1u);
-            s_item = n_mine < RS_FRONT_KEEP ? atomicAdd(&B.sync[0], 1u) : 0xffffffffu;
-        }
-        __syncthreads();
-        const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);
-        if (item >= n_a) break;
-        if (item < nbT) {
-            const uint32_t n_bands = rs_setup_chunk<MODE, false>(S, P, nullptr, g, B, bp, band_base, item, 0u, 1u);
-            __syncthreads();                              // (the chunk's records and band owners: written by this block, read by it)
-            const uint32_t r0 = band_base, r1 = r0 + n_bands < B.band_cap ? r0 + n_bands : B.band_cap;
-            if (r1 > r0) for (uint32_t p = 3u * r0 + (uint32_t)tid; p < 3u * r1; p += 256u) rs_band_item(B, S.n_tris, 0u, p, P.H);
-            if (tid == 0) mine[n_mine] = item;
-            n_mine++;
-        } else rs_clear_out(P, (unsigned long long)(item - nbT) * RS_CLEAR_WORDS, RS_CLEAR_WORDS, tid, 256);
-        __syncthreads();
-        prev = true;
-    }
-    if (n_mine == 0) return;                              // (nothing set up here: nothing to fill, nothing to wait for)
-    // ---- every claimed item of phase A done.  (Only the blocks that go on wait, and the word they poll has a cache line of its
-    //      own: with every block of the grid polling a word beside the claim counter, the polls -- they go to memory like the
-    //      atomics -- starved the claims and the band allocations of the blocks that were still working: 110 us per launch.)
-    if (tid == 0) {
-        uint32_t spins = 0;
-        while (__hip_atomic_load(&B.sync[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_a) {
-            __builtin_amdgcn_s_sleep(32);
-            if (++spins > (1u << 18)) { if (counters) atomicAdd(&counters[CS_OVERFLOW], 1ull); break; }      // (~0.4 s)
-        }
-    }
-    __syncthreads();
-    // ---- phase B: the bin entries of this block's own chunks; the block that set up chunk 0 publishes offsets and tile order
-    const uint32_t total = block_scan_counts<true>(g, B, 0u, soff, stot);
-    bool publish = false;
-    for (uint32_t k = 0; k < n_mine; k++) {
-        const uint32_t chunk = mine[k];
-        publish = publish || chunk == 0u;
-        rs_fill_chunk(g, B, bp, soff, S.n_tris, chunk, 0u);
-        __syncthreads();
-    }
-    if (publish) {
-        for (uint32_t i = (uint32_t)tid; i <= (uint32_t)g.n_bins; i += 256u) B.offset[i] = soff[i];
-        if (tid == 0 && counters) {
-            if (total > B.bins_cap) atomicAdd(&counters[CS_OVERFLOW], (unsigned long long)(total - B.bins_cap));
-            if (__hip_atomic_load(&B.band_top[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > B.band_cap) atomicAdd(&counters[CS_OVERFLOW], 1ull);
-        }
-        tile_order(g, B, 0u, soff, stot);
-    }
 }
 
 // Phase profile of counting frames (collect_stats): thread 0 of every block sums the cycles between the barriers and adds
@@ -542,13 +465,11 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
     uint32_t max_active = 0;
     for (int ff = 0; ff < n_frames; ff++) { const uint32_t a = B.order[(size_t)ff * ((size_t)g.n_tiles + 1)]; max_active = a > max_active ? a : max_active; }
     const uint32_t total_items = max_active * (uint32_t)n_frames;
-    if (blockIdx.x == 0) {                                    // the next frame's rs_setup counts from zero
+    if (blockIdx.x == 0)                                      // the next frame's rs_setup counts from zero
         for (int ff = 0; ff < n_frames; ff++) {
-            for (uint32_t i = (uint32_t)tid; i < (uint32_t)g.n_bins; i += (uint32_t)nt) { B.count[(size_t)ff * g.n_bins + i] = 0u; B.cursor[(size_t)ff * g.n_bins + i] = 0u; }
+            for (uint32_t i = (uint32_t)tid; i < (uint32_t)g.n_bins; i += (uint32_t)nt) B.count[(size_t)ff * g.n_bins + i] = 0u;
             if (tid == 0) B.band_top[ff] = 0u;
         }
-        if (tid < 2) B.sync[32 * tid] = 0u;                   // ... and its k_rs_front claims from zero, fills from cursors at zero
-    }
     for (uint32_t w = blockIdx.x; w < total_items;) {
         const uint32_t f = w % (uint32_t)n_frames, slot = w / (uint32_t)n_frames;
         const uint32_t *order = B.order + (size_t)f * ((size_t)g.n_tiles + 1);
@@ -560,8 +481,10 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
             next_w = total_items <= gridDim.x ? total_items : gridDim.x + c + nd * atomicAdd(&B.band_top[n_frames + c], 1u);
         }
         if (slot >= order[0]) { __syncthreads(); const uint32_t nw = next_w; __syncthreads(); w = nw; continue; }
-        const uint32_t tile = order[1 + slot];
+        const uint32_t item = order[1 + slot], tile = RS_ITEM_TILE(item);
         const int tx = (int)(tile % (uint32_t)g.tiles_x), ty = (int)(tile / (uint32_t)g.tiles_x);
+        // (the rows of the tile this block draws: all of them, or its strip of a heavy tile -- tile_order)
+        const int rows = RS_TH / (int)RS_ITEM_STRIPS(item), r0 = (int)RS_ITEM_STRIP(item) * rows, r1 = r0 + rows - 1;
         const FrameParams &F = batch ? batch[f] : P;
         unsigned long long t_mark = prof ? __builtin_readcyclecounter() : 0ull;
         const unsigned long long t_begin = t_mark;
@@ -573,14 +496,14 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
         bool any = false;
         int parity = 0;
         for (uint32_t first = 0; first < total; first += RS_LIST_CAP) {
-            rs_tile_filter(B, f, tx, ty, L, first, lds, tid, nt);
+            rs_tile_filter(B, f, tx, ty, L, first, lds, tid, nt, r0, r1);
             __syncthreads();
             RS_PROF_MARK(1);
             const uint32_t nl = lds.n_list;
             any = any || nl != 0u;
             if (prof && tid == 0) acc[10] += nl;
             for (uint32_t chunk = 0; chunk < nl; chunk += RS_CHUNK) {
-                rs_tile_stage(ty, chunk, nl, parity, lds, tid);
+                rs_tile_stage(ty, chunk, nl, parity, lds, tid, r0, r1);
                 __syncthreads();
                 RS_PROF_MARK(2);
                 if (prof && tid == 0) acc[11] += lds.n_items[parity];
@@ -600,8 +523,8 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
             rs_tile_attr<MODE>(F, B, S.n_tris, f, tx, ty, lds, tid, nt);
             __syncthreads();
             RS_PROF_MARK(5);
-            rs_tile_shade<MODE>(S, F, tx, ty, lds, tid, nt, plots);
-        } else if (clear_rows) rs_tile_blank(F, tx, ty, tid, nt);     // (nobody else clears a tile whose bin holds entries)
+            rs_tile_shade<MODE>(S, F, tx, ty, lds, tid, nt, plots, r0, r1);
+        } else if (clear_rows) rs_tile_blank(F, tx, ty, tid, nt, r0, r1);     // (nobody else clears a tile whose bin holds entries)
         const uint32_t nw = next_w;                           // (written by thread 0 at the top of this tile, barriers ago)
         __syncthreads();                                      // (the next tile clears the keys and draws the next item)
         w = nw;
@@ -912,10 +835,6 @@ template <class T> static hipError_t regrow(T *&p, size_t &have, size_t want)
     return e;
 }
 
-// words behind RsBuffers::band_top: the frames' band counters, the tile dispensers, then -- from the next 128-byte line -- two lines for
-// k_rs_front's counters (RsBuffers::sync)
-static size_t rs_top_words(int n_frames) { return (((size_t)n_frames + RS_DISPENSERS + 31) & ~(size_t)31) + 64; }
-
 // buffers of the tiled pipeline for n_frames frames of W x H with n_tris triangles
 static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tris, int n_frames, hipStream_t st)
 {
@@ -951,8 +870,7 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
     // cut short) starts from a cleared array
     if (s->count_bins != g.n_bins || s->count_frames != n_frames) {
         if ((e = hipMemsetAsync(s->B.count, 0, words * 4, st)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(s->B.cursor, 0, words * 4, st)) != hipSuccess) return e;
-        if (s->B.band_top && (e = hipMemsetAsync(s->B.band_top, 0, rs_top_words(s->band_frames) * 4, st)) != hipSuccess) return e;
+        if (s->B.band_top && (e = hipMemsetAsync(s->B.band_top, 0, ((size_t)s->band_frames + RS_DISPENSERS) * 4, st)) != hipSuccess) return e;
         s->count_bins = g.n_bins; s->count_frames = n_frames;
     }
     // Bin entries per frame (16 bytes each): three per triangle cover meshes of small triangles (chessboard, dragon:
@@ -982,12 +900,11 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
         s->band_words = (size_t)bcap * n_frames;
     }
     s->B.band_cap = (uint32_t)(s->band_words / (size_t)n_frames < bcap ? s->band_words / (size_t)n_frames : bcap);
-    struct SyncAt { RasterScratch *s; int nf; ~SyncAt() { s->B.sync = s->B.band_top ? s->B.band_top + rs_top_words(nf) - 64 : nullptr; } } sync_at{s, n_frames};   // (on every path out)
     if (n_frames != s->band_frames || !s->B.band_top) {
         if (s->B.band_top) (void)hipFree(s->B.band_top);
         s->B.band_top = nullptr; s->band_frames = 0;
-        if ((e = hipMalloc((void **)&s->B.band_top, rs_top_words(n_frames) * 4)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(s->B.band_top, 0, rs_top_words(n_frames) * 4, st)) != hipSuccess) return e;
+        if ((e = hipMalloc((void **)&s->B.band_top, ((size_t)n_frames + RS_DISPENSERS) * 4)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(s->B.band_top, 0, ((size_t)n_frames + RS_DISPENSERS) * 4, st)) != hipSuccess) return e;
         s->band_frames = n_frames;
     }
     return hipSuccess;
@@ -1010,18 +927,6 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     if (e != hipSuccess) return e;
     const int nbT = (int)((S->n_tris + 255) / 256);
     const dim3 per_tri(nbT > 0 ? nbT : 1, n_frames);
-    // single frames: setup and fill as the two phases of one launch (k_rs_front) on request -- MI355_RS_FUSED=1.  Measured slower
-    // (18.1 k against 26.1 k frames/s, the launch 92 us against the two kernels' 28): see the kernel's header.
-    static const bool fused_front = [] { const char *v = getenv("MI355_RS_FUSED"); return v && *v && strcmp(v, "0"); }();
-    const bool fused = !piped && n_frames == 1 && !d_batch && g.n_bins <= RS_SCAN_LDS && fused_front;
-    if (fused) {
-        // (blocks claim their work: enough of them for the setup chunks plus the background or band items beside them)
-        unsigned blocks = 2u * per_tri.x + 64u;
-        if (blocks < 256u) blocks = 256u;
-        if (blocks > 1024u) blocks = 1024u;
-        hipLaunchKernelGGL((k_rs_front<MODE>), dim3(blocks), dim3(256), 0, st, *S, *P, g, s->B, P->counters, whole ? 0 : 1);
-        mi355i_prof_lap(2);
-    } else {
     hipLaunchKernelGGL((k_rs_setup<MODE>), per_tri, dim3(256), 0, st, *S, *P, d_batch, g, s->B);
     mi355i_prof_lap(2);
     // (the fill kernel's grid also has to carry the band items: at least four blocks per CU)
@@ -1034,7 +939,6 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
         hipLaunchKernelGGL(k_rs_fill<false>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters, piped || whole ? 0 : 1);
     }
     mi355i_prof_lap(3);
-    }
     if (piped) {
         if (g.n_bins > RS_SCAN_LDS && (e = hipEventRecord(fill_done, pre)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(st_tile, fill_done, 0)) != hipSuccess) return e;

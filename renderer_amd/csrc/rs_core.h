@@ -100,8 +100,6 @@ struct RsBuffers {
                                    //                        word: k_rs_tile's tile dispenser (zeroed by rs_setup)
     uint2 *band_owner;             // [frames][band_cap]     (triangle, band = scanline / RS_BH) of each band record
     uint32_t *order;               // [frames][n_tiles + 1]  [0] = number of tiles with bin entries, then those tiles, then the others (rs_fill)
-    uint32_t *sync;                // [64]                   k_rs_front's counters: [0] items claimed, [32] items done (a cache line each, behind
-                                   //                        band_top's words; zeroed again by rs_tile)
 };
 
 // y -> output row, or -1 when the row belongs to another GPU's band
@@ -593,8 +591,11 @@ MI_HD void rs_tile_clear(RsTileLds &lds, int tid, int nt)
 }
 
 // phase 1: bin entries [first, first + RS_LIST_CAP) of the tile's bins -> LDS list of the triangles whose box touches the tile
-MI_HD void rs_tile_filter(const RsBuffers &B, uint32_t frame, int tx, int ty, const RsTileBins &L, uint32_t first, RsTileLds &lds, int tid, int nt)
+// (r0 .. r1: the rows of the tile this block draws -- all sixteen, or a strip of them when the tile is shared by several blocks)
+MI_HD void rs_tile_filter(const RsBuffers &B, uint32_t frame, int tx, int ty, const RsTileBins &L, uint32_t first, RsTileLds &lds, int tid, int nt,
+                          int r0 = 0, int r1 = RS_TH - 1)
 {
+    const int ya = ty * RS_TH + r0, yb = ty * RS_TH + r1;
     const uint32_t n = L.total();
     uint32_t end = first + RS_LIST_CAP;
     if (end > n) end = n;
@@ -607,8 +608,8 @@ MI_HD void rs_tile_filter(const RsBuffers &B, uint32_t frame, int tx, int ty, co
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (e0 + (uint32_t)u * (uint32_t)nt >= end) break;
-            const int tx0 = (int)(b[u].y & 0xffffu), tx1 = (int)(b[u].y >> 16), ty0 = (int)(b[u].z & 0xffffu) / RS_TH, ty1 = (int)(b[u].z >> 16) / RS_TH;
-            if (tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1) {
+            const int tx0 = (int)(b[u].y & 0xffffu), tx1 = (int)(b[u].y >> 16), y0 = (int)(b[u].z & 0xffffu), y1 = (int)(b[u].z >> 16);
+            if (tx >= tx0 && tx <= tx1 && yb >= y0 && ya <= y1) {
                 uint32_t *li = lds.list[RS_ATOMIC_ADD_U32(&lds.n_list, 1u)];
                 li[0] = b[u].x; li[1] = b[u].z; li[2] = b[u].w;
             }
@@ -617,13 +618,13 @@ MI_HD void rs_tile_filter(const RsBuffers &B, uint32_t frame, int tx, int ty, co
 }
 
 // phase 2a (thread = slot of the chunk): list entry `chunk + tid` -> one work item per scanline of the tile it touches
-MI_HD void rs_tile_stage(int ty, uint32_t chunk, uint32_t n_list, int parity, RsTileLds &lds, int tid)
+MI_HD void rs_tile_stage(int ty, uint32_t chunk, uint32_t n_list, int parity, RsTileLds &lds, int tid, int r0 = 0, int r1 = RS_TH - 1)
 {
     const uint32_t e = chunk + (uint32_t)tid;
     if (tid >= RS_CHUNK || e >= n_list) return;
     const int miny = (int)(lds.list[e][1] & 0xffffu), maxy = (int)(lds.list[e][1] >> 16);
     const int Y0 = ty * RS_TH;
-    const int ys = miny > Y0 ? miny : Y0, ye = maxy < Y0 + RS_TH - 1 ? maxy : Y0 + RS_TH - 1;
+    const int ys = miny > Y0 + r0 ? miny : Y0 + r0, ye = maxy < Y0 + r1 ? maxy : Y0 + r1;
     if (ys > ye) return;
     const uint32_t base = RS_ATOMIC_ADD_U32(&lds.n_items[parity], (uint32_t)(ye - ys + 1));
     for (int y = ys; y <= ye; y++) lds.items[base + (uint32_t)(y - ys)] = (uint16_t)(((uint32_t)tid << 4) | (uint32_t)(y - Y0));
@@ -784,9 +785,9 @@ MI_HD void rs_tile_attr(const FrameParams &P, const RsBuffers &B, uint32_t n_tri
 }
 
 // a tile without entries: the background (Screen::ClearScreen, Rasterizers.cc:326)
-MI_HD void rs_tile_blank(const FrameParams &P, int tx, int ty, int tid, int nt)
+MI_HD void rs_tile_blank(const FrameParams &P, int tx, int ty, int tid, int nt, int r0 = 0, int r1 = RS_TH - 1)
 {
-    for (int i = tid; i < RS_TPIX; i += nt) {
+    for (int i = r0 * RS_TW + tid; i < (r1 + 1) * RS_TW; i += nt) {
         const int x = tx * RS_TW + (i % RS_TW), y = ty * RS_TH + (i / RS_TW);
         if (x >= P.W || y >= P.H) continue;
         const int orow = rs_out_row(P, y);
@@ -797,9 +798,10 @@ MI_HD void rs_tile_blank(const FrameParams &P, int tx, int ty, int tid, int nt)
 // phase 4 (thread = pixel): Screen::Plot<> (Screen.cc:34-56) for the colour-interpolating modes, IlluminatePixel +
 // LightingEquation (Screen.cc:77-93, LightingEq.h:45-170) for the Phong modes.  Every pixel of the tile is written.
 template <int MODE>
-MI_HD void rs_tile_shade(const DevScene &S, const FrameParams &P, int tx, int ty, const RsTileLds &lds, int tid, int nt, unsigned long long &plots)
+MI_HD void rs_tile_shade(const DevScene &S, const FrameParams &P, int tx, int ty, const RsTileLds &lds, int tid, int nt, unsigned long long &plots,
+                         int r0 = 0, int r1 = RS_TH - 1)
 {
-    for (int i = tid; i < RS_TPIX; i += nt) {
+    for (int i = r0 * RS_TW + tid; i < (r1 + 1) * RS_TW; i += nt) {
         const int x = tx * RS_TW + (i % RS_TW), y = ty * RS_TH + (i / RS_TW);
         if (x >= P.W || y >= P.H) continue;
         const int orow = rs_out_row(P, y);
