@@ -21,7 +21,7 @@
 
 // kernel launchers (defined next to their kernels)
 extern "C" hipError_t mi355i_launch_tile_select(const FrameParams *P, const float4 *boxes, int n_boxes, const uint32_t *order, uint32_t *sel, uint32_t *cnt,
-                                                hipStream_t st);
+                                                uint32_t *gmask, hipStream_t st);
 extern "C" int mi355i_raytrace_waves_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext, int quad);
 extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int ordered, int waves, int batch, int ext,
                                              int quad, int stack_depth, int n_blocks, hipStream_t);
@@ -145,7 +145,9 @@ extern "C" void mi355i_prof_lap(int i) { t_prof.lap(i); }
 
 // layout of mi355_ctx::ctrl
 static const size_t MI_CTRL_DISPENSER_OFF = 4096;
-static const size_t MI_CTRL_BYTES = MI_CTRL_DISPENSER_OFF + (size_t)MI_DISPENSERS * MI_DISPENSER_STRIDE * 4;
+// (one more counter behind the dispenser's: the tile rows of the background, k_raytrace)
+static const size_t MI_CTRL_FILL_OFF = MI_CTRL_DISPENSER_OFF + (size_t)MI_DISPENSERS * MI_DISPENSER_STRIDE * 4;
+static const size_t MI_CTRL_BYTES = MI_CTRL_FILL_OFF + 256;
 static_assert(16 + sizeof(unsigned long long) * CS_COUNT <= MI_CTRL_DISPENSER_OFF, "counters overlap the dispenser");
 
 struct mi355_ctx {
@@ -218,6 +220,12 @@ struct mi355_ctx {
     bool ev_light_set = false;
     RasterScratch *rs_light = nullptr;   // the redraw's own row buffer (frames in flight use the other sets)
     int direct_turn = 0;                 // raytraced frames: whose turn it is to run on the caller's stream itself (enqueue_frame)
+    // ... with a control block and a tile list of its own, like the frames on the frame streams: a synchronous mi355_render or a
+    // frame of another caller's stream may come while it runs.  ev_direct = its launch; the next such frame, whatever stream it is
+    // on, follows it.
+    DevBuf direct_ctrl, direct_sel;
+    hipEvent_t ev_direct = nullptr;
+    bool ev_direct_set = false;
     RasterScratch *rscratch = nullptr;
     WireScratch *wscratch = nullptr;     // mode 3 (created with its first frame)
     // pipelined frames (mi355_render_async / _wait): each slot is a stream with its own control block (counters, pixel
@@ -384,7 +392,8 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
         return (on(getenv("MI355_NO_OVERLAP")) || on(getenv("ROCPROF_COUNTER_COLLECTION")) || getenv("ROCPROF_COUNTERS") || getenv("ROCPROF_COUNTER_GROUPS")) ? 1 : 0;
     }();
     if (no_overlap) P.no_pipe = 1;
-    P.tile_sel = nullptr; P.tile_cnt = nullptr;
+    P.tile_sel = nullptr; P.tile_cnt = nullptr; P.tile_mask = nullptr;
+    P.fill_counter = (uint32_t *)((char *)ctrl + MI_CTRL_FILL_OFF); P.fill_first = 0;
     P.blocks_per_cu = t[4] > 0 ? t[4] : 0;
     P.rs_threads = t[3];
     // (heavy tiles in strips of rows: tune[7] = the bin-entry threshold; 0 = never, the default -- measured: no threshold pays, a
@@ -856,6 +865,7 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
             //  -- up to a 1080p frame's 32 400 tiles; a 3840 x 2160 frame's 129 600 still want the four-wave build: 1 500 against 1 360 fps)
             if (Q.blocks_per_cu == 0) Q.blocks_per_cu = ((long long)((P.W + 7) / 8) * ((P.n_rows + 7) / 8) > 65536ll) ? 4 : 3;
             Q.work_counter = (uint32_t *)((char *)c->pipe_ctrl[k].p + MI_CTRL_DISPENSER_OFF);
+            Q.fill_counter = (uint32_t *)((char *)c->pipe_ctrl[k].p + MI_CTRL_FILL_OFF);
             Q.counters = (unsigned long long *)((char *)c->pipe_ctrl[k].p + 16);
             if (int r = enqueue_frame(c, mode, Q, 0, fl.ps, c->pipe_ctrl[k].p, nullptr, nullptr, nullptr, &c->pipe_sel[k])) return r;
             if (int r = lease_done(c, fl, st, false)) return r;
@@ -871,8 +881,24 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
             }
             return 0;
         }
-        if (pc && pc->n >= 2 && P.blocks_per_cu == 0)           // (this frame's turn on the caller's stream: it shares the GPU like the others)
-            P.blocks_per_cu = ((long long)((P.W + 7) / 8) * ((P.n_rows + 7) / 8) > 65536ll) ? 4 : 3;
+        if (pc && pc->n >= 2) {
+            // this frame's turn on the caller's stream (direct_turn): it shares the GPU like the others -- the three-wave build --, and it
+            // has a control block and a tile list of its own
+            FrameParams Q = P;
+            if (Q.blocks_per_cu == 0) Q.blocks_per_cu = ((long long)((P.W + 7) / 8) * ((P.n_rows + 7) / 8) > 65536ll) ? 4 : 3;
+            HIP_TRY(c->direct_ctrl.ensure(MI_CTRL_BYTES), -31);
+            if (!c->ev_direct) HIP_TRY(hipEventCreateWithFlags(&c->ev_direct, hipEventDisableTiming), -11);
+            if (c->ev_direct_set) HIP_TRY(wait_unless_done(st, c->ev_direct), -40);
+            Q.work_counter = (uint32_t *)((char *)c->direct_ctrl.p + MI_CTRL_DISPENSER_OFF);
+            Q.fill_counter = (uint32_t *)((char *)c->direct_ctrl.p + MI_CTRL_FILL_OFF);
+            Q.counters = (unsigned long long *)((char *)c->direct_ctrl.p + 16);
+            if (int r = enqueue_frame(c, mode, Q, 0, st, c->direct_ctrl.p, nullptr, nullptr, nullptr, &c->direct_sel)) return r;
+            HIP_TRY(hipEventRecord(c->ev_direct, st), -40);
+            c->ev_direct_set = true;
+            c->last_ctrl = c->direct_ctrl.p;
+            c->last_stats = false;
+            return 0;
+        }
     }
     // (a raster frame that does not count zeroes its control block in its first kernel: one launch less per frame, ~4.7 us)
     const bool raster_self_clear = mode >= MI355_MODE_AMBIENT && mode <= MI355_MODE_PHONG_SOFTSHADOWMAPS && !stats && !P.cams;
@@ -969,14 +995,20 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
         const long long n_tiles = (((long long)P.W + 7) / 8) * (((long long)P.n_rows + 7) / 8);
         if (ordered && !stats && (P.band_count <= 1 || (P.band_rows > 0 && P.band_rows % 8 == 0)) && c->n_cull_boxes > 0 && !P.no_cull && n_tiles <= MI_CULL_MAX_TILES) {
             DevBuf *buf = sel ? sel : &c->tile_sel;
-            HIP_TRY(buf->ensure(512 + (size_t)P.n_frames * (size_t)n_tiles * 4), -31);
+            // [512 B: the frames' counts][the frames' tile lists][the frames' masks]
+            const size_t list_bytes = (size_t)P.n_frames * (size_t)n_tiles * 4, mask_words = (size_t)((n_tiles + 31) / 32);
+            HIP_TRY(buf->ensure(512 + list_bytes + (size_t)P.n_frames * mask_words * 4 + 16), -31);
             P.tile_cnt = (const uint32_t *)buf->p;
             P.tile_sel = (const uint32_t *)((char *)buf->p + 512);
+            // (the background of the tiles that are not traced: written by the selection kernel before anything is traced -- or, P.fill_first
+            //  set: a frame that crosses PCIe as it is written, by waves of the tracing kernel while the others trace)
+            uint32_t *gmask = P.fill_first > 0 ? (uint32_t *)((char *)buf->p + 512 + list_bytes) : nullptr;
+            P.tile_mask = gmask;
             if ((e = mi355i_launch_tile_select(&P, (const float4 *)c->cull_boxes.p, c->n_cull_boxes, P.tile_order, (uint32_t *)((char *)buf->p + 512),
-                                               (uint32_t *)buf->p, st)) != hipSuccess) {
+                                               (uint32_t *)buf->p, gmask, st)) != hipSuccess) {
                 // (the selection could not be launched: the frame is traced without it -- every tile handed out, same pixels)
                 (void)hipGetLastError();
-                P.tile_cnt = nullptr; P.tile_sel = nullptr;
+                P.tile_cnt = nullptr; P.tile_sel = nullptr; P.tile_mask = nullptr;
             }
         }
         e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, waves, batch, ext, quad, stack_rows, n_blocks, st);
@@ -1162,6 +1194,8 @@ void mi355_scene_destroy(mi355_ctx *c)
         if (a.st && a.st_owned) (void)hipStreamDestroy(a.st);
     }
     for (auto &h : c->host_reg) if (h.p) (void)hipHostUnregister(h.p);
+    c->direct_ctrl.release(); c->direct_sel.release();
+    if (c->ev_direct) (void)hipEventDestroy(c->ev_direct);
     if (c->rs_light) mi355i_raster_scratch_destroy(c->rs_light);
     if (c->ev_light) (void)hipEventDestroy(c->ev_light);
     if (c->rscratch) mi355i_raster_scratch_destroy(c->rscratch);
@@ -1496,6 +1530,7 @@ int mi355_render_batch_device(mi355_ctx *c, int mode, int n_frames, const mi355_
             Q.n_frames = n_frames;
             Q.out = fl.fb;
             Q.work_counter = (uint32_t *)((char *)c->pipe_ctrl[k].p + MI_CTRL_DISPENSER_OFF);
+            Q.fill_counter = (uint32_t *)((char *)c->pipe_ctrl[k].p + MI_CTRL_FILL_OFF);
             Q.counters = (unsigned long long *)((char *)c->pipe_ctrl[k].p + 16);
             if (int r = enqueue_frame(c, mode, Q, 0, fl.ps, c->pipe_ctrl[k].p, nullptr, nullptr, nullptr, &c->pipe_sel[k])) return r;
             if (int r = lease_done(c, fl, st, false)) return r;
@@ -1747,11 +1782,25 @@ int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_li
         HIP_TRY(hipMemsetAsync(c->fb.p, 0, (size_t)W * o->height * 4, c->stream), -40);
         if (wantf) HIP_TRY(hipMemsetAsync(c->fbf.p, 0, (size_t)W * o->height * 12, c->stream), -40);
     }
+    // A raytraced frame into page-locked memory of the caller's (mi355_host_register: Screen::_pixels of the host layer) is written
+    // THERE by the kernels: the traced tiles a pixel at a time, the background -- most of the frame -- in whole cache lines by the
+    // waves that have run out of pixels, while the others trace (k_raytrace).  No copy behind the frame: 0.54 ms of kernel + 0.17 ms
+    // of DMA became the kernel's time alone.  Not for the rasterizer (its 80 us of kernels would wait for 8 MB to cross PCIe first),
+    // the post filter (it works in place) and bands (whose other rows are defined as black: a memset of device memory).
+    void *host_alias = nullptr;
+    static const bool no_zero_copy = [] { const char *v = getenv("MI355_NO_ZERO_COPY"); return v && *v && strcmp(v, "0"); }();
+    // (... and only where the tiles are culled: a frame traced tile by tile would cross PCIe 32 bytes at a time)
+    const bool culled = c->n_cull_boxes > 0 && !(o->tune[5] & (4 | 8 | 16)) && ((long long)((W + 7) / 8) * ((o->height + 7) / 8)) <= (long long)MI_CULL_MAX_TILES;
+    const bool zero_copy = !no_zero_copy && culled && mode >= MI355_MODE_RAYTRACE && !o->mlaa && o->band_count <= 1 && !o->collect_stats && pitch_bytes >= W * 4 && !(pitch_bytes & 3) &&
+                           host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4) &&
+                           hipHostGetDevicePointer(&host_alias, out_xrgb, 0) == hipSuccess && host_alias;
+    if (!zero_copy) (void)hipGetLastError();
     FrameParams P;
-    if (int r = fill_params(c, mode, cam, lights, n_lights, o, c->fb.p, W * 4, wantf ? c->fbf.p : nullptr, P)) return r;
+    if (int r = fill_params(c, mode, cam, lights, n_lights, o, zero_copy ? host_alias : c->fb.p, zero_copy ? pitch_bytes : W * 4, wantf ? c->fbf.p : nullptr, P)) return r;
     mi355_stats tmp;
     mi355_stats *st = stats ? stats : &tmp;
     P.no_pipe = 1;          // (a synchronous frame has nothing to overlap with: its kernels follow each other on the context's stream)
+    if (zero_copy) P.fill_first = 96;     // (waves that start with the background: it takes PCIe 0.28 ms, the frame 0.54)
     for (int attempt = 0;; attempt++) {
         HIP_TRY(hipEventRecord(c->ev0, c->stream), -40);
         if (int r = enqueue_frame(c, mode, P, o->collect_stats, c->stream)) return r;
@@ -1762,7 +1811,9 @@ int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_li
         if (r) return r;
         break;
     }
-    if (pitch_bytes > 0 && host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4)) {
+    if (zero_copy) {
+        // (the frame is where it belongs; the stream has been synchronised)
+    } else if (pitch_bytes > 0 && host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4)) {
         // page-locked by the caller (mi355_host_register): one DMA transfer, no staging by the runtime
         HIP_TRY(hipMemcpy2DAsync(out_xrgb, (size_t)pitch_bytes, c->fb.p, (size_t)W * 4, (size_t)W * 4, (size_t)rows, hipMemcpyDeviceToHost, c->stream), -31);
         HIP_TRY(hipStreamSynchronize(c->stream), -40);

@@ -153,6 +153,13 @@ struct FrameParams {
     // tile_sel[f * n_tiles + i] for i < tile_cnt[f] (the tile order restricted to tiles a ray can hit something in; the other
     // tiles are already black), else NULL.
     const uint32_t *tile_sel, *tile_cnt;
+    // ... and, for a frame that is written straight into the caller's host memory (mi355_render), the bit mask of the tiles that ARE
+    // traced ((n_tiles + 31) / 32 words per frame): waves of k_raytrace write the background of the others -- fill_first of them to
+    // begin with, the others when the dispenser has nothing left for them (fill_counter hands out the tile rows) --, else NULL (the
+    // selection kernel writes the background before anything is traced)
+    const uint32_t *tile_mask;
+    uint32_t *fill_counter;
+    int32_t fill_first;        // that many waves of the launch START with the background (a frame that crosses PCIe as it is written)
     int32_t blocks_per_cu;     // 0 = occupancy query
     int32_t rs_threads;        // rasterizer: threads per tile block (0 = default)
     int32_t rs_split;          // rasterizer: bin entries beyond which a tile is cut into strips of rows (0 = never; k_raster.hip: tile_order)

@@ -8,8 +8,12 @@
 //   --bench     the reference's `make bench` (src/Makefile.am:25-26): five runs of `-b -n 500` (or -n N), then
 //               Average / Std dev / Median / Min / Max of their frame rates, as its perl one-liner prints them
 //   -g N        draw every frame on N GPUs (devices 0..N-1; -g 0,0 lists devices explicitly)
-//   -p N        keep N frames in flight (2..4, Scene::renderAsync): frame k is copied out while frame k+1 renders; the
-//               reported rate is then frames / wall time of the loop (there is no "time inside render" to add up)
+//   -p N        keep N frames in flight (1..4, Scene::renderAsync): frame k is copied out while frame k+1 renders; the
+//               reported rate is then frames / wall time of the loop (there is no "time inside render" to add up).
+//               DEFAULT 3 on one device: in -b the cameras of the frames to come are known (renderer.cc:485-494: the orbit),
+//               so nothing keeps the loop from asking for frame k + 1 before it shows frame k; -p 1 = the reference's loop,
+//               one synchronous Scene::render* per pass, rate = frames / time inside those calls
+//   --depth N   MAX_RAY_DEPTH (Raytracer.cc:56; default 3): 1 = primary + shadow rays, BASELINE.json's configs[2]
 //   --keys FILE the INTERACTIVE loop instead (renderer.cc:338-615 without -b: frontend.h), its keyboard fed from a script
 //               ("poll N", "down KEY", "up KEY", "tap KEY"; keys as on the reference's help screen: arrows, a z, s d f e, r, w q,
 //               0-9, pgup pgdn, h, esc); --frame-ms T gives every frame T ms on the loop's clock (default: the measured time),
@@ -53,10 +57,13 @@ static void write_ppm(const char *prefix, int frame, const Screen &canvas)
 }
 
 // one `renderer -b -n frames` run; returns frames per second (time inside Scene::render* only, renderer.cc:584-585, 631-633)
+static int g_depth = 0;            // --depth (0: the reference's 3)
+
 static double run(const char *fname, int mode, int frames, int W, int H, const std::vector<int> &devices, bool twoLights, bool periodic, const char *dump,
                   int inFlight = 1)
 {
     Scene scene;
+    if (g_depth > 0) scene._opts.max_ray_depth = g_depth;
     if (devices.size() > 1) scene._devices = devices;
     else if (!devices.empty()) scene._device = devices[0];
     Screen canvas(scene, W, H);
@@ -78,22 +85,18 @@ static double run(const char *fname, int mode, int frames, int W, int H, const s
         // pipelined presentation: a ring of canvases, frame f waits for frame f - inFlight + 1 before it is shown
         std::vector<std::unique_ptr<Screen>> ring;
         for (int i = 0; i < inFlight; i++) {
-            ring.emplace_back(new Screen(scene, W, H));
-            mi355_host_register(scene.context(), ring.back()->_pixels.data(), ring.back()->_pixels.size() * 4);     // direct DMA into the canvas
+            ring.emplace_back(new Screen(scene, W, H));                    // (page-locked by its first frame: direct DMA into the canvas)
         }
         std::vector<int> ticket((size_t)inFlight, -1), frameOf((size_t)inFlight, 0);
         const int m = mode == 2 ? MI355_MODE_POINTS_FROM_TRIANGLES : mode;
         const auto t0 = std::chrono::steady_clock::now();
-        for (int f = 0; f < frames + inFlight - 1; f++) {
+        for (int f = 0; f < frames; f++) {
             const int slot = f % inFlight;
-            if (f >= inFlight - 1) {                                       // oldest pending frame: wait, present
-                const int old = (f + 1) % inFlight;
-                if (ticket[old] >= 0) {
-                    scene.renderWait(ticket[old]); ring[old]->ShowScreen(mode >= 9, true); ticket[old] = -1;
-                    if (dump) write_ppm(dump, frameOf[old], *ring[old]);
-                }
+            if (ticket[slot] >= 0) {                                       // the canvas's previous frame (f - inFlight): wait, present
+                scene.renderWait(ticket[slot]); ring[slot]->ShowScreen(mode >= 9, true); ticket[slot] = -1;
+                if (dump) write_ppm(dump, frameOf[slot], *ring[slot]);
             }
-            if (f < frames) {
+            {
                 orbit.advance();
                 sony.set(orbit.eye, orbit.lookat);
                 if (mode >= 5) for (Light *l : scene._lights) l->CalculatePositionInCameraSpace(sony);
@@ -102,10 +105,11 @@ static double run(const char *fname, int mode, int frames, int W, int H, const s
                 frameOf[slot] = f + 1;
             }
         }
-        for (int i = 0; i < inFlight; i++)
+        for (int k = 0; k < inFlight; k++) {                               // the last frames, oldest first
+            const int i = (frames + k) % inFlight;
             if (ticket[i] >= 0) { scene.renderWait(ticket[i]); ring[i]->ShowScreen(mode >= 9, true); if (dump) write_ppm(dump, frameOf[i], *ring[i]); }
+        }
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        for (auto &c : ring) mi355_host_unregister(scene.context(), c->_pixels.data());
         const double fps = frames / sec;
         printf("Rendering %d frames in %g seconds. (%g fps, %d in flight)\n", frames, sec, fps, inFlight);
         return fps;
@@ -185,7 +189,7 @@ int main(int argc, char **argv)
     const char *keysFile = nullptr; long frameMS = -1; bool brakes = true;
     std::vector<int> devices;
     bool twoLights = false, periodic = false, bench = false;
-    int inFlight = 1;
+    int inFlight = 0;                                              // 0: not given
     const char *dump = nullptr, *fname = nullptr;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
@@ -211,11 +215,14 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--keys")) keysFile = next();
         else if (!strcmp(a, "--frame-ms")) frameMS = atol(next());
         else if (!strcmp(a, "--no-brakes")) brakes = false;
+        else if (!strcmp(a, "--depth")) { g_depth = atoi(next()); if (g_depth < 1 || g_depth > 4) usage(); }
         else if (a[0] == '-') usage();
         else fname = a;
     }
     if (!fname || mode < 1 || mode > 10) usage();
     if (frames < 0) frames = bench ? 500 : 100;
+    // (frames in flight: one device, the tiled rasterizer and the raytracer; -r reports time inside the calls)
+    if (inFlight == 0) inFlight = (devices.size() > 1 || periodic || mode < 4) ? 1 : 3;
     try {
         if (keysFile) return runKeys(fname, keysFile, mode, W, H, devices, twoLights, frameMS, brakes, dump);
         if (!bench) { run(fname, mode, frames, W, H, devices, twoLights, periodic, dump, inFlight); return 0; }

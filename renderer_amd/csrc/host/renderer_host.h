@@ -83,7 +83,13 @@ struct Screen {                                        // Screen.h:49-171 (canva
     const Scene &_scene;
     void (*_present)(const Screen &, void *) = nullptr; // front-end hook called by ShowScreen (SDL_Flip)
     void *_presentArg = nullptr;
+    // the device context _pixels is page-locked for (mi355_host_register; Scene::render* does that on the first frame: frames are
+    // then written, or DMA'd, straight into the canvas -- SDL_Surface::pixels stays put from frame to frame, and so does this)
+    mutable mi355_ctx *_lockedFor = nullptr;
     Screen(const Scene &scene, int width, int height);
+    ~Screen();
+    Screen(const Screen &) = delete;
+    Screen &operator=(const Screen &) = delete;
     void ClearScreen();
     void ShowScreen(bool raytracerOutput = false, bool doMLAA = true);
 };

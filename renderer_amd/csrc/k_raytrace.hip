@@ -599,6 +599,46 @@ k_raytrace(const DevScene S, const FrameParams P)
     }
     const uint32_t n_slots_all = BATCH ? n_tiles_out * (uint32_t)P.n_frames : n_tiles_out;     // (tile, frame) pairs to hand out
 
+    // ---- the background of a frame that goes straight into the caller's page-locked host memory (mi355_render) ----
+    // Tiles the selection kernel found no camera ray can hit anything in are black (Raytracer.cc:327-331 for every sample of every
+    // pixel).  They are most of the frame -- 7 of a 1080p frame's 8.3 MB --, and in host memory they are 0.28 ms of PCIe: written by
+    // P.fill_first waves BEFORE they trace anything and by every wave that has run out of pixels, they cross while the others trace.
+    // A wave takes a row of tiles of a frame at a time: whole cache lines, 16 bytes per lane.  (Frames in device memory: the
+    // selection kernel has written the background -- P.tile_mask == NULL.)
+    const auto background = [&]() {
+        if (P.tile_mask) {
+            const int lane = (int)(threadIdx.x & 63u);
+            const uint32_t nf = BATCH ? (uint32_t)P.n_frames : 1u, n_words = (n_tiles + 31u) >> 5, n_items = (uint32_t)tiles_y * nf;
+            for (;;) {
+                uint32_t it = 0;
+                if (lane == 0) it = atomicAdd(P.fill_counter, 1u);
+                it = (uint32_t)__builtin_amdgcn_readfirstlane((int)it);
+                if (it >= n_items) break;
+                const uint32_t f = it % nf, ty = it / nf;
+                const uint32_t *mask = P.tile_mask + (size_t)f * n_words;
+                uint32_t *const out = BATCH ? P.cams[f].out : P.out;
+                float *const outf = BATCH ? P.cams[f].outf : P.outf;
+                const bool vec = (P.pitch_words & 3) == 0 && (((size_t)out) & 15u) == 0;
+                const uint32_t trow = ty * (uint32_t)tiles_x;
+                for (int r = (int)ty * 8; r < (int)ty * 8 + 8 && r < P.n_rows; r++) {
+                    const int out_r = P.compact ? r : band_row_to_y(r, P.band_rows, P.band_index, P.band_count);
+                    uint32_t *const orow = out + (size_t)out_r * P.pitch_words;
+                    for (int x = lane * 4; x < P.W; x += 256) {
+                        const uint32_t t = trow + (uint32_t)(x >> 3);             // (four pixels from a multiple of four: one tile)
+                        if ((mask[t >> 5] >> (t & 31u)) & 1u) continue;
+                        if (vec && x + 3 < P.W) *(uint4 *)(orow + x) = make_uint4(0u, 0u, 0u, 0u);
+                        else for (int k = 0; k < 4 && x + k < P.W; k++) orow[x + k] = 0u;
+                        if (outf) {
+                            float *q = outf + ((size_t)out_r * P.W + x) * 3;
+                            for (int k = 0; k < 12 && x + k / 3 < P.W; k++) q[k] = 0.f;
+                        }
+                    }
+                }
+            }
+        }
+    };
+    if (P.tile_mask && (int)blockIdx.x < P.fill_first) background();
+
     for (;;) {
         // ---------------- refill: hand new pixels to idle lanes --------------------------
         // The wave keeps a private pool [pool_next, pool_end) of pixel indices and takes a chunk of
@@ -1401,6 +1441,8 @@ k_raytrace(const DevScene S, const FrameParams P)
     }
     if (STATS) pc_total = __builtin_readcyclecounter() - tick0;
 
+    background();
+
     // ---------------- counters: one atomic per wave per slot ------------------------------
     if (P.counters) {
         auto wsum = [](unsigned v) {
@@ -1457,7 +1499,7 @@ k_raytrace(const DevScene S, const FrameParams P)
 // -- and set the pixels of the other tiles to the reference's result for a ray that hits nothing: black.
 namespace {
 __global__ void __launch_bounds__(1024)
-k_tile_select(const FrameParams P, const float4 *boxes, int n_boxes, const uint32_t *order, uint32_t *sel, uint32_t *cnt)
+k_tile_select(const FrameParams P, const float4 *boxes, int n_boxes, const uint32_t *order, uint32_t *sel, uint32_t *cnt, uint32_t *gmask)
 {
     extern __shared__ uint32_t mask[];               // one bit per tile
     __shared__ int s_rect[MI_CULL_BOXES][4];
@@ -1517,6 +1559,8 @@ k_tile_select(const FrameParams P, const float4 *boxes, int n_boxes, const uint3
         }
     }
     __syncthreads();
+    // (the mask itself, for the waves of k_raytrace that write the background)
+    if (blockIdx.y == 0 && gmask) for (uint32_t i = (uint32_t)tid; i < n_words; i += 1024u) gmask[(size_t)f * n_words + i] = mask[i];
     if (blockIdx.y == 0) {
         // the tile order restricted to marked tiles, order kept.  In pieces of 32768 entries: a wave owns 2048 contiguous
         // entries of the piece, loads them at once (32 independent loads per lane: one memory latency, not 32), counts its
@@ -1561,6 +1605,7 @@ k_tile_select(const FrameParams P, const float4 *boxes, int n_boxes, const uint3
         for (int off = 32; off > 0; off >>= 1) px += __shfl_xor(px, off);
         if (lane == 0 && px && P.counters) { atomicAdd(&P.counters[CS_NORMAL_RAYS], px * (P.aa ? 4ull : 1ull)); atomicAdd(&P.counters[CS_CULLED_RAYS], px * (P.aa ? 4ull : 1ull)); }
     }
+    if (gmask) return;                              // (k_raytrace writes the background: its waves without pixels do)
     // the other tiles are black: a wave per pixel row, four pixels per lane and step (whole cache lines per wave)
     uint32_t *const out = batch ? P.cams[f].out : P.out;
     float *const outf = batch ? P.cams[f].outf : P.outf;
@@ -1582,11 +1627,13 @@ k_tile_select(const FrameParams P, const float4 *boxes, int n_boxes, const uint3
     }
 }
 } // namespace
+// gmask != NULL: the selection only -- one block per frame; the mask goes to gmask for k_raytrace, which writes the background itself
 extern "C" hipError_t mi355i_launch_tile_select(const FrameParams *P, const float4 *boxes, int n_boxes, const uint32_t *order, uint32_t *sel, uint32_t *cnt,
-                                                hipStream_t st)
+                                                uint32_t *gmask, hipStream_t st)
 {
     const uint32_t n_tiles = (uint32_t)((P->W + 7) >> 3) * (uint32_t)((P->n_rows + 7) >> 3);
-    hipLaunchKernelGGL(k_tile_select, dim3((unsigned)P->n_frames, P->n_frames >= 8 ? 32 : 64), dim3(1024), ((n_tiles + 31u) >> 5) * 4u, st, *P, boxes, n_boxes, order, sel, cnt);
+    hipLaunchKernelGGL(k_tile_select, dim3((unsigned)P->n_frames, gmask ? 1 : (P->n_frames >= 8 ? 32 : 64)), dim3(1024), ((n_tiles + 31u) >> 5) * 4u, st, *P, boxes, n_boxes, order,
+                       sel, cnt, gmask);
     return hipGetLastError();
 }
 

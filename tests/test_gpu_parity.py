@@ -467,9 +467,10 @@ def test_render_cli_runs():
 
 @pytest.mark.parametrize("mode,mesh", [(9, "dragon_vis.ply"), (8, "chessboard.tri")])
 def test_render_cli_pipelined_frames_are_the_synchronous_frames(mode, mesh, tmp_path):
-    """render_cli -p 3 (mi355::Scene::renderAsync / renderWait, three canvases in flight) writes the frames of the plain loop"""
+    """render_cli -b (mi355::Scene::renderAsync / renderWait, three canvases in flight: its default) writes the frames of the
+    reference's own loop -- one synchronous Scene::render* per pass, -p 1"""
     import subprocess
-    for tag, extra in (("sync", []), ("pipe", ["-p", "3"])):
+    for tag, extra in (("sync", ["-p", "1"]), ("pipe", [])):          # (three frames in flight is the default of -b)
         out = subprocess.run([R.RENDER_CLI, "-b", "-n", "7", "-m", str(mode), "-W", "640", "-H", "360", "-o", str(tmp_path / tag)] + extra +
                              [R.assets.mesh_path(mesh)], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr
