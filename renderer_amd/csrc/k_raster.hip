@@ -800,6 +800,307 @@ __global__ void __launch_bounds__(256) k_sm_rows(const DevScene S, const ShadowP
 //  the kernels above.  The items of a mesh sit in the few bands its silhouette covers; 2048 blocks over all items beat 256 unequal
 //  bands.)
 
+// ---- round 4: the map in tiles whose depth keys live in LDS ------------------------------------------------------------------
+// The row-item kernels above give a lane a (triangle, row) and let it walk the row's span with one device-scope atomicMax per
+// pixel.  The lanes of a wave are on 64 different rows, so a wave instruction is 64 separate read-modify-writes at the L2s: the
+// chessboard, whose squares cover the map with ~20 000 spans of ~100 pixels, pays 2 M of them -- 220 of its 291 us (dragon: 82 us).
+// Here the map is cut into tiles of SMT_W x SMT_H pixels, a workgroup per tile with the tile's keys in LDS, and the triangles are
+// binned by BAND (the SMT_H rows of a row of tiles) first -- without a single global atomic per triangle:
+//   k_sm_prep   a block per 256 triangles: the projected corners (Light.cc:100-128), the rows a triangle touches and a conservative
+//               range of tile columns (the corners' x, widened by what the serial float chains can drift); the block bins ITS
+//               triangles by band in LDS and writes its own band lists, one allocation per block, and a row of the table
+//               [block][band] -> where that block's list for the band starts;
+//   k_sm_tiles  a workgroup per tile: the lists of its band, their entries dealt to the threads one by one, of those the triangles
+//               whose columns reach the tile, and for each (triangle, row of the tile) the three edge walkers brought to that row
+//               with ff_add, Light.cc's edge order and truncations (as k_sm_rows), and the part of the span that lies in the
+//               tile: from ff_add of the span's first pixel, a few pixels early, every plot checked against the tile's columns.
+//               The keys go to LDS with atomicMax; the tile's floats are stored once, whole rows of 1 KB.  No clear pass, no
+//               resolve pass, no global atomic on the map.
+// (Measured on the way: every workgroup running over every triangle's box, 200 barriers each: chessboard 213 us, dragon 307; over
+//  the boxes of chunks of 256 triangles first -- a scanned mesh's triangle order makes them useless --: 166 / 296; band lists filled
+//  through global counters, 75 000 atomic adds on 90 neighbouring words: 523 / 664.)
+// Same plots, same values, same maximum: the map is bit-identical (tests: the oracle's map = the real Light.cc's).
+#ifndef SMT_W
+#define SMT_W 512
+#endif
+#ifndef SMT_H
+#define SMT_H 2
+#endif
+#define SMT_LIST 2048         // triangles a tile collects before it draws them
+#ifndef SMT_T
+#define SMT_T 512            // threads of a tile's workgroup
+#endif
+#define SMT_BANDS 4096        // most bands a map has
+#define SMT_WIDE 4            // a triangle of more bands than this goes to the coarse bands' lists
+#define SMT_CB 16             // bands per coarse band
+
+struct SmPrep { float f[9]; int iy[3]; float d[9]; float pad[3]; };      // projected corners (x, y, 1/z), their truncated rows, the three edges' steps per row: 96 bytes
+
+// rs_edge_init with the edge's per-row steps already known (k_sm_prep made them with rs_edge_init itself: the same divisions, once
+// per triangle instead of once per row and tile)
+MI_DEV void sm_edge_init(RsEdge<3> &E, int ya, const float (&va)[3], int yb, const float (&vb)[3], const float *d, int height)
+{
+    E.horiz = false; E.y0 = 1; E.y1 = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { E.v[i] = 0.f; E.d[i] = 0.f; }
+    if (ya == yb) {
+        if (ya >= 0 && ya < height) { E.horiz = true; E.y0 = E.y1 = ya; }
+        return;
+    }
+    const bool sw = ya > yb;
+    int y1 = sw ? yb : ya, y2 = sw ? ya : yb;
+    if (y1 < 0 && y2 < 0) return;
+    if (y1 >= height && y2 >= height) return;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { E.v[i] = sw ? vb[i] : va[i]; E.d[i] = d[i]; }
+    if (y1 < 0) {
+        const float k = (float)-y1;
+#pragma unroll
+        for (int i = 0; i < 3; i++) E.v[i] += E.d[i] * k;
+        y1 = 0;
+    }
+    if (height - 1 < y2) y2 = height - 1;
+    E.y0 = y1; E.y1 = y2;
+}
+
+// ctl: [0] list entries handed out (one add per block), [1] entries that did not fit
+// Two kinds of lists per block: a triangle of up to SMT_WIDE bands is entered in each of them; a taller one in the COARSE bands
+// (SMT_CB bands each) it crosses -- the chessboard's squares cross hundreds of bands, and the thread that entered one of them alone,
+// a returning LDS atomic and a store per band, kept its whole workgroup waiting (prep 46 us; through coarse bands: 12).  A tile
+// reads its band's list and its coarse band's, and keeps of the second what reaches its rows.
+// Lists are numbered 0 .. n_bands (the bands, and one that stays empty), then n_bands + 1 + c for coarse band c (and an empty one).
+MI_HD int sm_lists(int n_bands) { return n_bands + 1 + (n_bands + SMT_CB - 1) / SMT_CB + 1; }
+
+__global__ void __launch_bounds__(256) k_sm_prep(const DevScene S, const ShadowParams Q, SmPrep *prep, uint2 *bbox, uint32_t *table, uint32_t *ids, uint32_t ids_cap,
+                                                 uint32_t *ctl)
+{
+    constexpr int NT = 256;
+    __shared__ uint32_t hist[SMT_BANDS + SMT_BANDS / SMT_CB + 4];         // triangles of the block per list, then the list's fill level
+    __shared__ uint32_t off[SMT_BANDS + SMT_BANDS / SMT_CB + 4];          // exclusive scan
+    __shared__ uint32_t tot[NT / 64], s_base;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int n_bands = (Q.size + SMT_H - 1) / SMT_H, n_lists = sm_lists(n_bands);
+    for (int i = tid; i < n_lists; i += NT) hist[i] = 0u;
+    __syncthreads();
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    float f[3][3]; int iy[3], miny = 0, maxy = 0;
+    uint2 bb = make_uint2(0xffffffffu, 0u);          // rows = ~0: touches nothing
+    if (t < S.n_tris && sm_project(S, Q, t, f, iy) && rs_tri_rows(iy, Q.size, miny, maxy)) {
+        // columns: every plotted x is a value of a serial chain between two of the corners' x (edges, then spans), so it lies in
+        // their range widened by the chains' drift (<= one ulp of the largest |x| per addition, <= size additions per chain, two
+        // chains) and the pixel it is truncated into.  Anything unordered or out of the integers' range: every column.
+        const float xa = f[0][0], xb = f[1][0], xc = f[2][0];
+        float lo = xa < xb ? xa : xb; lo = lo < xc ? lo : xc;
+        float hi = xa > xb ? xa : xb; hi = hi > xc ? hi : xc;
+        const float amax = __builtin_fmaxf(__builtin_fabsf(lo), __builtin_fabsf(hi));
+        const float drift = (float)(2 * Q.size + 8) * amax * 1.1920929e-07f + 2.0f;       // 2^-23 per addition
+        lo -= drift; hi += drift;
+        int c0 = 0, c1 = Q.size - 1;
+        if (lo == lo && hi == hi && amax < 4.f * (float)Q.size) {       // (a triangle that reaches far beyond the map: chains too long for the bound)
+            if (hi < 0.f || lo > (float)(Q.size - 1)) c1 = -1;                             // beside the map
+            else { c0 = lo > 0.f ? (int)lo : 0; c1 = hi < (float)(Q.size - 1) ? (int)hi : Q.size - 1; }
+        }
+        if (c1 >= c0) bb = make_uint2((uint32_t)miny | ((uint32_t)maxy << 16), (uint32_t)c0 | ((uint32_t)c1 << 16));
+    }
+    if (t < S.n_tris) bbox[t] = bb;
+    const bool drawn = bb.x != 0xffffffffu;
+    int b0 = miny / SMT_H, b1 = drawn ? maxy / SMT_H : b0 - 1;                   // the lists it is entered in: b0 .. b1
+    if (b1 - b0 >= SMT_WIDE) { b0 = n_bands + 1 + b0 / SMT_CB; b1 = n_bands + 1 + b1 / SMT_CB; }
+    // triangles per list: +1 where a triangle's lists start, -1 behind their end, summed up below
+    if (drawn) { atomicAdd(&hist[b0], 1u); atomicAdd(&hist[b1 + 1], 0xffffffffu); }
+    if (drawn) {
+        SmPrep &P = prep[t];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { P.f[3 * k] = f[k][0]; P.f[3 * k + 1] = f[k][1]; P.f[3 * k + 2] = f[k][2]; P.iy[k] = iy[k]; }
+        RsEdge<3> e0, e1, e2;                      // Light.cc:270-272: v1v2, v2v3, v1v3
+        rs_edge_init<3>(e0, iy[0], f[0], iy[1], f[1], Q.size);
+        rs_edge_init<3>(e1, iy[1], f[1], iy[2], f[2], Q.size);
+        rs_edge_init<3>(e2, iy[0], f[0], iy[2], f[2], Q.size);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { P.d[i] = e0.d[i]; P.d[3 + i] = e1.d[i]; P.d[6 + i] = e2.d[i]; }
+    }
+    // exclusive prefix of a per-thread number over the block (and the block's total)
+    const auto block_excl = [&](uint32_t mine, uint32_t &total) {
+        uint32_t incl = mine;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += v; }
+        __syncthreads();
+        if (lane == 63) tot[wid] = incl;
+        __syncthreads();
+        uint32_t before = 0; total = 0;
+        for (int w = 0; w < NT / 64; w++) { const uint32_t v = tot[w]; if (w < wid) before += v; total += v; }
+        return before + incl - mine;
+    };
+    __syncthreads();
+    const int per = (n_lists + NT - 1) / NT, cb = tid * per < n_lists ? tid * per : n_lists, ce = cb + per < n_lists ? cb + per : n_lists;
+    uint32_t total = 0;
+    {   // the differences summed: triangles per list
+        uint32_t sum = 0;
+        for (int i = cb; i < ce; i++) sum += hist[i];
+        uint32_t run = block_excl(sum, total);
+        for (int i = cb; i < ce; i++) { run += hist[i]; hist[i] = run; }
+    }
+    __syncthreads();
+    {   // exclusive scan of the counts: where each of the block's lists starts; one allocation for all of them
+        uint32_t sum = 0;
+        for (int i = cb; i < ce; i++) sum += hist[i];
+        uint32_t run = block_excl(sum, total);
+        for (int i = cb; i < ce; i++) { off[i] = run; run += hist[i]; }
+        if (tid == 0) s_base = total ? atomicAdd(&ctl[0], total) : 0u;
+        __syncthreads();
+        for (int i = cb; i < ce; i++) hist[i] = 0u;       // (from here on: the lists' fill levels)
+    }
+    __syncthreads();
+    const uint32_t base = s_base;
+    uint32_t *row = table + (size_t)blockIdx.x * (size_t)n_lists;             // (table[list][block], side by side for the tiles, made the
+    for (int i = tid; i < n_lists; i += NT) row[i] = base + off[i];            //  dragon's table entries scattered writes: prep 12 -> 19 us)
+    for (int band = b0; band <= b1; band++) {
+        const uint32_t at = base + off[band] + atomicAdd(&hist[band], 1u);
+        if (at < ids_cap) ids[at] = t; else atomicAdd(&ctl[1], 1u);      // (reported like a row buffer that was too small: it grows)
+    }
+}
+
+__global__ void __launch_bounds__(SMT_T) k_sm_tiles(const ShadowParams Q, const SmPrep *prep, const uint2 *bbox, const uint32_t *table, uint32_t n_blocks, const uint32_t *ids,
+                                                  uint32_t ids_cap, float *map)
+{
+    __shared__ uint32_t keys[SMT_H][SMT_W];
+    __shared__ uint32_t list[SMT_LIST], list_rows[SMT_LIST];
+    __shared__ uint32_t n_list;
+    __shared__ uint32_t seg_start[SMT_T], seg_pre[SMT_T + 1], seg_tot[SMT_T / 64];
+    const int tid = (int)threadIdx.x, SM = Q.size;
+    const int tiles_x = (SM + SMT_W - 1) / SMT_W, n_bands = (SM + SMT_H - 1) / SMT_H;
+    const int tx = (int)(blockIdx.x % (uint32_t)tiles_x), ty = (int)(blockIdx.x / (uint32_t)tiles_x);
+    const int X0 = tx * SMT_W, Y0 = ty * SMT_H;
+    const int X1 = (X0 + SMT_W < SM ? X0 + SMT_W : SM) - 1, Y1 = (Y0 + SMT_H < SM ? Y0 + SMT_H : SM) - 1;
+    for (int i = tid; i < SMT_H * SMT_W; i += SMT_T) keys[0][i] = ~0xFEFEFEFEu;             // Light::ClearShadowBuffer: bytes 0xFE (Light.h:48-52)
+    if (tid == 0) n_list = 0u;
+    __syncthreads();
+    // the rows ya .. yb of a triangle in this tile (corners and edge steps loaded once): k_sm_rows' body per row, the span cut to the tile's columns
+    const auto tri_rows = [&](uint32_t t, int ya, int yb) {
+        const int xs = X0, xe = X1;
+        const SmPrep P = prep[t];
+        const float f[3][3] = {{P.f[0], P.f[1], P.f[2]}, {P.f[3], P.f[4], P.f[5]}, {P.f[6], P.f[7], P.f[8]}};
+        RsEdge<3> e0, e1, e2;                      // Light.cc:270-272: v1v2, v2v3, v1v3
+        sm_edge_init(e0, P.iy[0], f[0], P.iy[1], f[1], P.d, SM);
+        sm_edge_init(e1, P.iy[1], f[1], P.iy[2], f[2], P.d + 3, SM);
+        sm_edge_init(e2, P.iy[0], f[0], P.iy[2], f[2], P.d + 6, SM);
+        for (int y = ya; y <= yb; y++) {
+        float l[3] = {0.f, 0.f, 0.f}, r[3] = {0.f, 0.f, 0.f};
+        uint32_t cnt = 0;
+        const auto feed = [&](const RsEdge<3> &E, const float (&a)[3], const float (&b)[3]) {
+            if (y < E.y0 || y > E.y1) return;
+            if (E.horiz) { scan_add<3>(l, r, cnt, a); scan_add<3>(l, r, cnt, b); return; }
+            float v[3];
+            sm_edge_at(E, y, v);
+            scan_add<3>(l, r, cnt, v);
+        };
+        feed(e0, f[0], f[1]); feed(e1, f[1], f[2]); feed(e2, f[0], f[2]);
+        uint32_t *row = keys[y - Y0];
+        const auto plot = [&](float x, float z) {                          // PlotShadowPixel, Light.cc:253-259 (this tile's share of it)
+            const int idx = cvtt_i32(x);
+            if (idx >= xs && idx <= xe && z == z) atomicMax(&row[idx - X0], f2key(z));
+            return idx;
+        };
+        if (cnt == 1) { plot(l[0], l[2]); continue; }
+        if (cnt != 2) continue;
+        const int x1 = cvtt_i32(l[0]), x2 = cvtt_i32(r[0]);
+        const long long st = llabs((long long)x2 - (long long)x1);
+        if (!st) { plot(l[0], l[2]); plot(r[0], r[2]); continue; }
+        if (st > (1ll << 24)) continue;                                    // a degenerate projection (geometry at the light's plane)
+        const int steps = (int)st;
+        const float fsteps = (float)steps;
+        const float dx = (r[0] - l[0]) / fsteps, dz = (r[2] - l[2]) / fsteps;
+        float sx = l[0], sz = l[2];
+        // the pixels 0 .. steps of the span whose x falls into the tile: start a few pixels before the estimate (the chain drifts
+        // from the straight line by far less), stop beyond the tile's last column; chains ff_add cannot jump into are walked whole
+        int j = 0;
+        if (dx > 0.f && x1 < xs) {
+            // (x of pixel k = k additions from the span's first: exact through ff_add, in pieces its arithmetic covers; it never
+            //  decreases with k, which is what the search and the stop below rest on)
+            const auto x_at = [&](int k) { float v = l[0]; for (int done = 0; done < k;) { const int n = k - done < (1 << 21) ? k - done : (1 << 21); v = ff_add(v, dx, n); done += n; } return v; };
+            const float est = ((float)xs - sx) / dx - 4.f;
+            if (est >= (float)steps) j = steps; else if (est > 0.f) j = (int)est;
+            if (j > 0 && cvtt_i32(x_at(j)) >= xs) {
+                // the estimate is not left of the tile (a span of millions of pixels drifts from the straight line): the last pixel that
+                // is, by bisection
+                int lo_j = 0, hi_j = j;                                     // x(lo_j) < xs <= x(hi_j)
+                while (hi_j - lo_j > 1) { const int mid = lo_j + (hi_j - lo_j) / 2; if (cvtt_i32(x_at(mid)) < xs) lo_j = mid; else hi_j = mid; }
+                j = lo_j;
+            }
+            if (j > 0) { sx = x_at(j); for (int done = 0; done < j;) { const int n = j - done < (1 << 21) ? j - done : (1 << 21); sz = ff_add(sz, dz, n); done += n; } }
+        }
+        for (;; j++) {
+            const int idx = plot(sx, sz);
+            if (j >= steps || (dx > 0.f && idx > xe && idx != (int)0x80000000)) break;
+            sx += dx; sz += dz;
+        }
+        }
+    };
+    const auto drain = [&]() {       // the triangles of the list over the threads
+        const uint32_t n = n_list < SMT_LIST ? n_list : SMT_LIST;
+        // (a thread per (triangle, row of the tile): a thread that took a triangle's rows one after the other made the chessboard's
+        //  large triangles twice as slow, 142 -> 284 us)
+        for (uint32_t it = (uint32_t)tid; it < n * SMT_H; it += SMT_T) {
+            const int y = Y0 + (int)(it % SMT_H);
+            const uint32_t rows = list_rows[it / SMT_H];
+            if (y > Y1 || y < (int)(rows & 0xffffu) || y > (int)(rows >> 16)) continue;
+            tri_rows(list[it / SMT_H], y, y);
+        }
+        // (a thread per 128 or 64 columns of a span as well -- the chessboard's spans cross the whole tile -- gave the chessboard nothing
+        //  and doubled and tripled the dragon: the lanes that skip their item wait for the ones that do not)
+    };
+    // The band's entries: a list per block of k_sm_prep.  SMT_T lists at a time, their entries numbered through (prefix of the lists'
+    // lengths) and dealt to the threads one by one -- a mesh whose neighbouring triangles sit in the same band hands one list of 256
+    // entries to a band, and a thread per LIST walked it alone: 380 us of dependent loads.
+    // First the band's own lists, then the lists of the coarse band it lies in (the tall triangles: the rows are checked here).
+    const int n_lists = sm_lists(n_bands);
+    for (int which = 0; which < 2; which++)
+    for (uint32_t blk0 = 0; blk0 < n_blocks; blk0 += SMT_T) {
+        const uint32_t blk = blk0 + (uint32_t)tid;
+        const int li = which ? n_bands + 1 + ty / SMT_CB : ty;
+        uint32_t cur = 0, end = 0;
+        if (blk < n_blocks) {
+            const uint32_t *row = table + (size_t)blk * (size_t)n_lists;
+            cur = row[li]; end = row[li + 1];
+            if (cur > ids_cap) cur = ids_cap;
+            if (end > ids_cap) end = ids_cap;
+            if (end < cur) end = cur;
+        }
+        {
+            const int lane = tid & 63, wid = tid >> 6;
+            const uint32_t cnt = end - cur;
+            uint32_t incl = cnt;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += v; }
+            if (lane == 63) seg_tot[wid] = incl;
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+            for (int w = 0; w < SMT_T / 64; w++) { const uint32_t v = seg_tot[w]; if (w < wid) before += v; total += v; }
+            seg_start[tid] = cur; seg_pre[tid] = before + incl - cnt;
+            if (tid == 0) seg_pre[SMT_T] = total;
+            __syncthreads();
+        }
+        const uint32_t total = seg_pre[SMT_T];
+        for (uint32_t e0 = 0; e0 < total; e0 += SMT_LIST) {
+            for (uint32_t e = e0 + (uint32_t)tid; e < total && e < e0 + SMT_LIST; e += SMT_T) {
+                int lo = 0, hi = SMT_T - 1;                          // the list entry e belongs to: the last one that starts at or before it
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (seg_pre[mid] <= e) lo = mid; else hi = mid - 1; }
+                const uint32_t t = ids[seg_start[lo] + (e - seg_pre[lo])];
+                const uint2 bb = bbox[t];
+                if ((int)(bb.y & 0xffffu) <= X1 && (int)(bb.y >> 16) >= X0 && (int)(bb.x & 0xffffu) <= Y1 && (int)(bb.x >> 16) >= Y0) { const uint32_t at = atomicAdd(&n_list, 1u); list[at] = t; list_rows[at] = bb.x; }
+            }
+            __syncthreads();
+            drain();
+            __syncthreads();
+            if (tid == 0) n_list = 0u;
+            __syncthreads();
+        }
+    }
+    // the tile's floats: whole rows
+    for (int i = tid; i < SMT_H * SMT_W; i += SMT_T) {
+        const int y = Y0 + i / SMT_W, x = X0 + i % SMT_W;
+        if (y <= Y1 && x <= X1) map[(size_t)y * SM + x] = key2f(keys[0][i]);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_sm_resolve(const uint32_t *smkeys, float *map, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -1126,6 +1427,34 @@ extern "C" hipError_t mi355i_launch_shadowmap(const DevScene *S, const float *li
     Q.size = size;
     if ((e = hipMemsetAsync(s->ctl, 0, 64, st)) != hipSuccess) return e;
     static const bool legacy = [] { const char *v = getenv("MI355_SM_LEGACY"); return v && *v && strcmp(v, "0"); }();     // the round-1 kernels, for comparison
+    static const bool row_items = [] { const char *v = getenv("MI355_SM_ROWS"); return v && *v && strcmp(v, "0"); }();    // the round-3 kernels, for comparison
+    if (!legacy && !row_items && size <= SMT_BANDS * SMT_H) {
+        // round 4: tiles with their keys in LDS (k_sm_prep, k_sm_tiles).  The row buffer holds the triangles' corners and boxes, the
+        // table [block of 256 triangles][list] and, behind them, the blocks' band lists.
+        const int per_block = 256;
+        const int nbT = (int)((S->n_tris + per_block - 1) / per_block) > 0 ? (int)((S->n_tris + per_block - 1) / per_block) : 1;
+        const int n_bands = (size + SMT_H - 1) / SMT_H;
+        const size_t prep_bytes = ((size_t)S->n_tris * sizeof(SmPrep) + 15) & ~(size_t)15, box_bytes = ((size_t)S->n_tris * sizeof(uint2) + 15) & ~(size_t)15;
+        const size_t table_bytes = (((size_t)nbT * (size_t)sm_lists(n_bands)) * 4 + 15) & ~(size_t)15, fixed = prep_bytes + box_bytes + table_bytes;
+        if ((size_t)s->rows_cap * sizeof(RowRec) < fixed + ((size_t)S->n_tris * 4 + 4096) * 4) {
+            if (s->rows) (void)hipFree(s->rows);
+            s->rows = nullptr; s->rows_cap = 0;
+            const size_t recs = (fixed + ((size_t)S->n_tris * 16 + 4096) * 4 + sizeof(RowRec) - 1) / sizeof(RowRec);
+            if ((e = hipMalloc((void **)&s->rows, recs * sizeof(RowRec))) != hipSuccess) return e;
+            s->rows_cap = (uint32_t)recs;
+        }
+        SmPrep *prep = (SmPrep *)s->rows;
+        uint2 *bbox = (uint2 *)((char *)s->rows + prep_bytes);
+        uint32_t *table = (uint32_t *)((char *)s->rows + prep_bytes + box_bytes);
+        uint32_t *ids = (uint32_t *)((char *)s->rows + fixed);
+        const size_t ids_cap_z = ((size_t)s->rows_cap * sizeof(RowRec) - fixed) / 4;
+        const uint32_t ids_cap = ids_cap_z > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)ids_cap_z;
+        hipLaunchKernelGGL(k_sm_prep, dim3(nbT), dim3(256), 0, st, *S, Q, prep, bbox, table, ids, ids_cap, s->ctl);
+        const unsigned tiles = (unsigned)(((size + SMT_W - 1) / SMT_W) * n_bands);
+        hipLaunchKernelGGL(k_sm_tiles, dim3(tiles), dim3(SMT_T), 0, st, Q, (const SmPrep *)prep, (const uint2 *)bbox, (const uint32_t *)table, (uint32_t)nbT, (const uint32_t *)ids, ids_cap,
+                           d_map);
+        return hipGetLastError();
+    }
     // Light::ClearShadowBuffer: bytes 0xFE (Light.h:48-52) -> key of the float 0xFEFEFEFE
     hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, st, s->smkeys, ~0xFEFEFEFEu, n);
     if (legacy) {     // the round-1 kernels: a lane per triangle, then a lane per row (kept for comparison)
