@@ -819,6 +819,9 @@ __global__ void __launch_bounds__(256) k_sm_rows(const DevScene S, const ShadowP
 // (Measured on the way: every workgroup running over every triangle's box, 200 barriers each: chessboard 213 us, dragon 307; over
 //  the boxes of chunks of 256 triangles first -- a scanned mesh's triangle order makes them useless --: 166 / 296; band lists filled
 //  through global counters, 75 000 atomic adds on 90 neighbouring words: 523 / 664.)
+// Tile shape and workgroup (1024^2 maps, us chessboard / dragon / statue; profiles/r04_analysis.md 4): 512 x 2 with 512 threads 97 / 71 / 72;
+// 256 x 4, 512 threads 104 / 118 / 114; 512 x 4 106 / 120 / 119; 1024 x 1 127 / 61 / 73; 512 x 1, 256 threads 108 / 67 / 81; 1024 threads per tile
+// never better than 129 / 87 / 78.  The row-item kernels: 291 / 82 / 84.
 // Same plots, same values, same maximum: the map is bit-identical (tests: the oracle's map = the real Light.cc's).
 #ifndef SMT_W
 #define SMT_W 512

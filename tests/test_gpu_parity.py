@@ -419,6 +419,31 @@ def test_shadow_map_bit_exact(oracle, oracle_scene, gpu_scene, mesh):
         assert int((gm > -1e30).sum()) > 1000
 
 
+@pytest.mark.parametrize("mesh,size,pos", [
+    ("chessboard.tri", 37, (3.394, 3.394, 4.8)),        # a map smaller than one tile
+    ("chessboard.tri", 600, (3.394, 3.394, 4.8)),       # ragged last column of tiles
+    ("chessboard.tri", 1025, (-2.0, 3.5, 3.0)),         # one pixel / one row beyond whole tiles and bands
+    ("chessboard.tri", 2050, (3.394, 3.394, 4.8)),      # more bands, coarse bands that end early
+    ("chessboard.tri", 1024, (0.9, 0.8, 0.7)),          # a light close to the board: triangles many times the map's size, most of them cut
+    ("chessboard.tri", 1024, (0.05, 0.02, 0.3)),        # ... above the middle of it: geometry on every side, degenerate projections
+    ("dragon_vis.ply", 777, (1.2, -0.9, 0.8)),
+    ("statue.ply", 1024, (0.4, 0.3, 0.5)),
+], ids=lambda v: str(v).replace(" ", ""))
+def test_shadow_map_sizes_and_close_lights(oracle, oracle_scene, gpu_scene, mesh, size, pos):
+    """The map's tiles (k_sm_prep / k_sm_tiles: bands of rows, coarse bands for tall triangles, columns from the corners' x) against the
+    oracle's serial Light.cc:84-296 where the tiling has edges: sizes that are no multiple of a tile, spans that start far left of
+    the map or of a tile (the exact skip-ahead and its bisection), triangles behind and through the light's plane."""
+    hs, osc = gpu_scene(mesh), oracle_scene(mesh)
+    cam, _, _ = R.benchmark_frame(0)
+    ocam, _, _ = oracle.benchmark_frame(0)
+    p32 = [np.float32(v) for v in pos]
+    gm = hs.shadowmap_render(0, R.light(p32, cam), size=size, fetch=True)
+    om = osc.shadowmap(oracle.light(np.array(p32, np.float32), ocam), size=size)
+    assert gm.shape == om.shape == (size, size)
+    assert np.array_equal(gm, om)           # (as values: +0 / -0 are interchangeable for every consumer, LightingEq.h:98,113)
+    assert int((gm > -1e30).sum()) > size
+
+
 @pytest.mark.parametrize("band_rows", [8, 15])       # multigpu.BAND_ROWS (tile rows) and a height that straddles tiles
 @pytest.mark.parametrize("mode", [9, 6, 2])
 def test_band_sharding_reassembles_the_frame(oracle, oracle_scene, gpu_scene, mode, band_rows):
