@@ -134,6 +134,7 @@ def main():
                          "runs the whole N > 1 path, measures nothing about scaling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (rasterizer) workloads")
+    ap.add_argument("--no-cli", action="store_true", help="skip the render_cli -b runs of the five BASELINE configurations")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the secondary weak-scaling run at 1080p")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect the hardware counters of the bench kernel in this run")
@@ -762,6 +763,52 @@ def main():
                             "workload": "%s, mode 9, max_ray_depth %d, %dx%d, orbit frames f0..f%d" % (mesh, depth, w, h, n_cam - 1)}
                 extra["statue_depth1_1080p"] = rt_workload("statue.ply", 1920, 1080, 1)
                 extra["dragon_4k"] = rt_workload("dragon_vis.ply", 3840, 2160, 3)
+            # one 1024^2 shadow map (Light::CalculateXformFromWorldToLightSpace + RenderSceneIntoShadowBuffer, Light.cc:84-296): mi355_light_update
+            # back to back on one stream, HIP events; k_sm_prep + k_sm_tiles (keys in LDS)
+            sm = {}
+            for mesh in ("chessboard.tri", args.mesh):
+                sc = chess if mesh == "chessboard.tri" else scene
+                for k in range(3):
+                    sc.light_update(0, [3.394, 3.394, 4.8], 1024, stream.cuda_stream)
+                torch.cuda.synchronize(dev)
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record(stream)
+                for k in range(50):
+                    a = 0.785 + 0.01 * k
+                    sc.light_update(0, [4.8 * float(np.cos(a)), 4.8 * float(np.sin(a)), 4.8], 1024, stream.cuda_stream)
+                g1.record(stream)
+                torch.cuda.synchronize(dev)
+                sc.fetch_stats()
+                sm[mesh] = round(g0.elapsed_time(g1) / 50 * 1e3, 1)
+                sc.light_update(0, [float(v) for v in cams[0][1][0].pos], 1024, stream.cuda_stream)       # (the benchmark's light again)
+                torch.cuda.synchronize(dev)
+            extra["shadowmap_1024_us"] = sm
+            # The reference's own benchmark procedure (`renderer -b -n N -m MODE FILE`, renderer.cc:243-341, 481-520) for BASELINE.json's five
+            # configurations, through the C++ host layer's render_cli (scripts/render_cli_configs.sh); fewer passes than the script's
+            cli = os.path.join(os.path.dirname(os.path.abspath(R.__file__)), "lib", "render_cli")
+            if os.path.exists(cli) and not args.no_cli:
+                import subprocess, re
+                md = os.path.dirname(R.assets.mesh_path("chessboard.tri"))
+                rows = []
+                for label, a in (("1: chessboard.tri -m 2 640x480", ["-n", "1000", "-m", "2", "-W", "640", "-H", "480", "chessboard.tri"]),
+                                 ("2: chessboard.tri -m 6 1920x1080", ["-n", "1000", "-m", "6", "-W", "1920", "-H", "1080", "chessboard.tri"]),
+                                 ("3: statue.ply -m 9 --depth 1 1920x1080", ["-n", "500", "-m", "9", "--depth", "1", "-W", "1920", "-H", "1080", "statue.ply"]),
+                                 ("4: dragon_vis.ply -m 9 1920x1080", ["-n", "500", "-m", "9", "-W", "1920", "-H", "1080", "dragon_vis.ply"]),
+                                 ("5: dragon_vis.ply -m 9 3840x2160 (one GPU)", ["-n", "200", "-m", "9", "-W", "3840", "-H", "2160", "dragon_vis.ply"])):
+                    row = {"config": label}
+                    for key, pre in (("fps_3_in_flight", []), ("fps_reference_loop", ["-p", "1"])):
+                        try:
+                            out = subprocess.run([cli, "-b"] + pre + a[:-1] + [os.path.join(md, a[-1])], capture_output=True, text=True, timeout=60,
+                                                 env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local_rank))))
+                            m = re.search(r"\(([0-9.]+) fps", out.stdout + out.stderr)
+                            row[key] = float(m.group(1)) if m else None
+                        except Exception as e:
+                            row[key] = None
+                            row["error"] = str(e)
+                    rows.append(row)
+                extra["render_cli_bench"] = {"rows": rows, "note": "render_cli -b: fps_3_in_flight = its default for -b (the cameras are known: three "
+                                             "frames in flight through Scene::renderAsync); fps_reference_loop = -p 1, one synchronous Scene::render* per "
+                                             "pass like renderer.cc:481-520, rate = frames / time inside the calls"}
             # BVH build of the benchmark mesh: GPU level kernels + download + flatten, host builder beside it
             import ctypes as C
             bs = R.Scene(R.assets.mesh_path(args.mesh), device=local_rank)
