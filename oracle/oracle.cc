@@ -539,7 +539,7 @@ static inline bool ray_box(const V3 &o, const V3 &d, const Node32 &box)
  * culled then).  Cost: one step per inner record visited, one per triangle of a leaf entered.  A shadow ray stops at its
  * first blocker.  Double-precision slabs: a cost model, not a parity path. */
 /* quad: a step looks at the node's grandchildren (a leaf child takes a slot of its own), nearest first, the others postponed:
- * the four-wide tree of DESIGN.md 8, priced.  *max_sp: the deepest the stack of postponed slots got. */
+ * the four-wide tree of profiles/history.md 4.1, priced.  *max_sp: the deepest the stack of postponed slots got. */
 template <bool shadow>
 static uint32_t ordered_walk_cost(const orc_scene &s, float nudge, const V3 &origin, const V3 &ray, int avoidSelf, const V3 &lightPos, bool doCulling,
                                   int quad_kind = 0, uint32_t *max_sp = nullptr)
@@ -1454,7 +1454,7 @@ void orc_trace_hits(const orc_scene *s, int n, const float *rays6, int32_t *tri,
     }
 }
 
-/* The reachability rule a four-wide record would use, as a checker of the rule only: at a node the reference has
+/* The reachability rule a four-wide record would use (profiles/history.md 4.1), as a checker of the rule only: at a node the reference has
  * entered, a LEAF child is entered; an inner child's INNER children are entered iff their OWN box passes RayIntersectsBox (which
  * implies the child's passes: the predicate is monotone in the box and a node's box is the union of its children's); an inner
  * child's LEAF children are entered iff the child's box passes.  Candidates in any order: the nearest wins, the lowest position

@@ -132,7 +132,7 @@ int orc_render(const orc_scene *, int mode, const orc_camera *, const orc_light 
  * (index into the scene's triangles, -1 = none) and the hit point.  For tests that need hits, not pixels. */
 void orc_trace_hits(const orc_scene *, int n, const float *rays6, int32_t *tri, float *hit3);
 
-/* The same question answered through the reachability rule of a four-wide tree (oracle.cc): a checker of that
+/* The same question answered through the reachability rule of a four-wide tree (profiles/history.md 4.1; oracle.cc): a checker of that
  * rule -- it must name the triangle orc_trace_hits names for every ray.  Nothing in the product uses it. */
 void orc_trace_hits_fourwide(const orc_scene *, int n, const float *rays6, int32_t *tri, float *hit3);
 

@@ -170,7 +170,7 @@ struct mi355_ctx {
     DevBuf bvh_prim, bvh_list[2], bvh_lvl[2], bvh_tree, bvh_cnt;   // mi355_build_bvh work buffers (kept for rebuilds)
     DevBuf bvh_big[2], bvh_task[2], bvh_gthr[2], bvh_gbin, bvh_tcnt, bvh_choff, bvh_num[5], bvh_out, bvh_in_td, bvh_in_te;
     bool bvh_inputs_ready = false;
-    // Calls of the device entry points overlap inside the library (DESIGN.md 4.5, enqueue_frame): a frame -- all its kernels --
+    // Calls of the device entry points overlap inside the library (DESIGN.md 4.6, enqueue_frame): a frame -- all its kernels --
     // runs on one of up to PIPE_SETS internal streams with resource set k (rasterizer scratch rs_pipe[k]; control block, tile
     // list and camera table pipe_ctrl / pipe_sel / pipe_cam[k]) into a frame buffer of the library's, and the caller's stream only
     // copies that buffer out: the kernels of consecutive frames do not wait for each other (a dependency that crosses streams
@@ -787,7 +787,7 @@ static bool direct_turn(mi355_ctx *c, const mi355_ctx::PipeChoice *pc)
     return c->direct_turn == 0;
 }
 
-// One call in flight (DESIGN.md 4.5): resource set k (rasterizer scratch / control block, tile list, camera table), frame stream
+// One call in flight (DESIGN.md 4.6): resource set k (rasterizer scratch / control block, tile list, camera table), frame stream
 // ps, frame buffer fb = pipe_fb[b].  lease_begin orders ps behind the set's last call, if that ran elsewhere (a call of another
 // caller's stream, of the ordered pipeline, a counting frame, a batch), and behind the copy that last read the buffer;
 // lease_done makes the caller's stream wait for the call's last kernel (`recorded`: that kernel carries ev_tile[k] itself).

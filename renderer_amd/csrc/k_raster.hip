@@ -1276,7 +1276,7 @@ static hipError_t raster_dispatch(const DevScene *S, const FrameParams *P, const
 }
 
 // One frame outside the caller's stream (capi.hip, enqueue_frame).  fill_done = NULL: the whole frame on `pre` (= st), the
-// overlapped frames of DESIGN.md 4.5.  Else the ordered pipeline: setup and fill on `pre` -- beside whatever `st` is still
+// overlapped frames of DESIGN.md 4.6.  Else the ordered pipeline: setup and fill on `pre` -- beside whatever `st` is still
 // doing, normally the previous frame's tile kernel -- and the tile kernel on `st` behind fill_done.  Either way the tile
 // kernel clears the background and carries tile_done; the scratch set must not be in use by a frame whose tile kernel has not
 // finished (the caller keeps several sets and orders them).

@@ -1,18 +1,21 @@
-# The evidence run behind profiles/r03_*: GPU tests, the bench line (counters collected in the run), kernel stats of launches one
-# after the other and of the default overlapped run, the rasterizer's kernels, the shadow map, frame-by-frame rates, variants.
+# The evidence run behind profiles/<tag>_*  (one gpurun call:  gpurun --timeout 1500 -- 'bash scripts/gpu_round_full.sh r04'):
+# GPU tests, the bench line (counters collected in the run), kernel stats of launches one after the other and of the default
+# overlapped run, the rasterizer's and the shadow map's kernels, side measurements (variants, frame by frame, the seam, render_cli -b),
+# counter passes of the bench kernel; scripts/make_profiles.py <tag> then copies what is tracked into profiles/.
+TAG=${1:-r04}
 mkdir -p gpurun_out
-R=$GRAFT_REPO_ROOT
+R=$(pwd)
 (timeout 900 python -m pytest tests -m gpu -q -rs --capture=sys 2>&1 | tail -12) > gpurun_out/pytest_full.log
 tail -3 gpurun_out/pytest_full.log
 (timeout 600 python bench.py 2>gpurun_out/bench_full.err | tail -1) > gpurun_out/bench_full.log
 tail -1 gpurun_out/bench_full.log | cut -c1-300
 {
   echo "== scripts/rt_variants.py (dragon 1080p: batches of 8, single frames; work sharing, register builds, four-wide walk, bounds)"; timeout 300 python scripts/rt_variants.py 2>&1 | grep variant
-  echo "== scripts/rt_variants.py statue.ply depth 1"; RT_VARIANTS="default,noshare,bpc3,quad" timeout 200 python scripts/rt_variants.py statue.ply 1 2>&1 | grep variant
-  echo "== scripts/rt_variants.py chessboard.tri depth 3"; RT_VARIANTS="default,noshare,bpc3" timeout 200 python scripts/rt_variants.py chessboard.tri 3 2>&1 | grep variant
-  echo "== scripts/shadowmap_time.py"; timeout 100 python scripts/shadowmap_time.py 2>&1 | grep "us per"; MI355_SM_LEGACY=1 timeout 100 python scripts/shadowmap_time.py 2>&1 | grep "us per"
+  echo "== scripts/shadowmap_time.py (LDS tiles; MI355_SM_ROWS=1: round 3's row-item kernels; MI355_SM_LEGACY=1: round 1's)"; timeout 100 python scripts/shadowmap_time.py 2>&1 | grep "us per"; MI355_SM_ROWS=1 timeout 100 python scripts/shadowmap_time.py 2>&1 | grep "us per"; MI355_SM_LEGACY=1 timeout 100 python scripts/shadowmap_time.py 2>&1 | grep "us per"
   echo "== scripts/raster_pipe_variants.py"; timeout 100 python scripts/raster_pipe_variants.py 2>&1 | tail -1
   echo "== scripts/raytrace_frame_by_frame.py"; timeout 100 python scripts/raytrace_frame_by_frame.py 2>&1 | tail -8
+  echo "== scripts/render_cli_configs.sh (render_cli -b, BASELINE.json's five configurations)"; timeout 200 bash scripts/render_cli_configs.sh 2>&1
+  echo "== scripts/ubench/apicost (host cost of the HIP calls a frame makes)"; (hipcc -O2 --offload-arch=gfx950 -o /tmp/apicost scripts/ubench/apicost.hip && timeout 60 /tmp/apicost) 2>&1 | tail -14
 } > gpurun_out/misc_full.log 2>&1
 cat gpurun_out/misc_full.log
 cd /tmp && export TMPDIR=/tmp
@@ -20,7 +23,7 @@ cd /tmp && export TMPDIR=/tmp
 (timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats_overlapped -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extra --no-pmc --repeats 0 2>&1 | tail -3) > $R/gpurun_out/prof_stats_overlapped.log
 (MI355_NO_OVERLAP=1 timeout 100 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats_raster -- python $R/scripts/raster_loop.py 6 200 2>&1 | tail -2) > $R/gpurun_out/prof_stats_raster.log
 (timeout 100 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats_shadowmap -- python $R/scripts/shadowmap_time.py 2>&1 | tail -3) > $R/gpurun_out/prof_stats_shadowmap.log
-# counters of the bench kernel: share / noshare / three-wave build (utilisation, instructions, HBM traffic)
+# counters of the bench kernel: share / noshare / three-wave build (utilisation, instructions, HBM traffic); --pmc passes by themselves
 for v in default noshare bpc3; do
   case $v in default) T='{}';; noshare) T='{"noshare": 1}';; bpc3) T='{"bpc": 3}';; esac
   for g in "VALUBusy VALUUtilization SALUBusy" "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
@@ -29,4 +32,5 @@ for v in default noshare bpc3; do
   done
 done
 cd $R
-python scripts/make_profiles.py r03
+find gpurun_out -name "*kernel_trace.csv" -size +2M -delete
+python scripts/make_profiles.py $TAG

@@ -1,4 +1,4 @@
-"""A property of the reference's box test the four-wide tree of DESIGN.md 8 rests on (nothing in the product uses it yet):
+"""A property of the reference's box test the four-wide tree of profiles/history.md 4.1 rests on (nothing in the product uses it yet):
 RayIntersectsBox (Raytracer.cc:99-151) is monotone in the box -- a ray that passes a box passes every box that contains it,
 in the reference's own float arithmetic, early returns and parallel-ray cases included.  A node's box is the exact union of
 its children's, so 'the grandchild's box passes' implies 'the child's box passes'."""
