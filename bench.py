@@ -682,22 +682,18 @@ def main():
                     kms += scene.render_into(args.mode, cams[k][0], cams[k][1], cams[k][2], o1, hb[0]).kernel_ms
                 seam["sync_host_pageable_fps"] = round(100 / (time.perf_counter() - t1), 1)
                 seam["single_frame_kernel_ms"] = round(kms / 100, 4)
-                # ... and into a page-locked canvas, which is what the C++ host layer's Screen is since round 4 (Scene::render* locks
-                # Screen::_pixels on the first frame): the kernels write the frame there themselves, no copy behind it
-                scene.host_register(hb[1])
-                try:
-                    for k in range(5):
-                        scene.render_into(args.mode, cams[k][0], cams[k][1], cams[k][2], o1, hb[1])
-                    t1 = time.perf_counter()
-                    for k in range(200):
-                        scene.render_into(args.mode, cams[k][0], cams[k][1], cams[k][2], o1, hb[1])
-                    seam["sync_host_fps"] = round(200 / (time.perf_counter() - t1), 1)
-                finally:
-                    scene.host_unregister(hb[1])
+                # ... and into a page-locked canvas, which is what the C++ host layer's Screen is since round 4 (Screen::_pixels is frame
+                # memory of the library's, mi355_host_alloc): the kernels write the frame there themselves, no copy behind it
+                pinned = [R.host_array((H, W)) for _ in range(R.MAX_IN_FLIGHT)]
+                for k in range(5):
+                    scene.render_into(args.mode, cams[k][0], cams[k][1], cams[k][2], o1, pinned[1])
+                t1 = time.perf_counter()
+                for k in range(200):
+                    scene.render_into(args.mode, cams[k][0], cams[k][1], cams[k][2], o1, pinned[1])
+                seam["sync_host_fps"] = round(200 / (time.perf_counter() - t1), 1)
                 seam["single_frame_own_bytes_frac_of_hbm_peak"] = round(float(np.mean([obytes_f[k] for k in range(100) if obytes_f[k] > 0] or [0])) / (kms / 100 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                 seam["single_frame_reference_work_x_hbm_peak"] = round(float(np.mean([abytes_f[k] for k in range(100) if abytes_f[k] > 0] or [0])) / (kms / 100 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                for b in hb:
-                    scene.host_register(b)
+                hb = pinned
                 # (three in flight, not the four the API allows: measured 3 785 against 3 283 frames/s for raytraced 1080p frames -- four
                 #  single-frame launches want more wave slots than a CU has, and four slot streams begin to share hardware queues)
                 depth = min(3, R.MAX_IN_FLIGHT)
@@ -718,13 +714,13 @@ def main():
                         scene.render_wait(t)
                     seam["host_path_fps"] = round(200 / (time.perf_counter() - t1), 1)
                 finally:
-                    for b in hb:
-                        scene.host_unregister(b)
+                    for b in pinned:
+                        R.host_array_free(b)
                 seam["note"] = ("sync_host_fps: mi355_render, one synchronous frame per call into a page-locked canvas (the host layer's Screen): written by "
                                 "the kernels themselves over PCIe, the background by the waves that have run out of pixels; sync_host_pageable_fps: the same "
                                 "call into pageable memory (kernel + 8.3 MB D2H); "
                                 "host_path_fps: the same frames through mi355_render_async / _wait, %d in flight on their own streams, into "
-                                "buffers registered with mi355_host_register; single_frame_kernel_ms: hipEvent time of one frame's launch"
+                                "frame memory of the library's (mi355_host_alloc); single_frame_kernel_ms: hipEvent time of one frame's launch"
                                 % depth)
                 result["seam"] = seam
                 extra["frame_by_frame_Mrays_per_s"] = round(float(sum(rays_f[k] for k in range(200) if rays_f[k] > 0)) / max(1, sum(1 for k in range(200) if rays_f[k] > 0)) * 200 / dt1 / 1e6, 1)

@@ -210,6 +210,16 @@ int mi355_render_wait(mi355_ctx *, int ticket, mi355_stats *stats);
 int mi355_host_register(mi355_ctx *, void *p, size_t bytes);
 int mi355_host_unregister(mi355_ctx *, void *p);
 
+/* Frame memory of the library's, page-locked from the start (hipHostMalloc, portable and mapped): a canvas allocated here takes
+ * frames from every context of the process the way a registered buffer does -- written by the kernels themselves (mi355_render,
+ * raytraced frames) or by one DMA transfer -- without mi355_host_register.  Preferred over registering memory of the malloc heap:
+ * a registered piece of the heap shares pages and an address range with unrelated allocations, and ROCm 7.2 faulted in later
+ * hipMemcpy calls into pageable heap memory at addresses that had been registered and unregistered before (the runtime pins such
+ * destinations in place).  The C++ host layer's Screen::_pixels lives here.  NULL when no HIP device is usable or
+ * the allocation fails (mi355_last_error); mi355_host_free(NULL) is a no-op.  Zero-filled. */
+void *mi355_host_alloc(size_t bytes);
+void mi355_host_free(void *p);
+
 /* Same frame, but asynchronous and device-resident: d_out_xrgb / d_out_rgb_f32 are device pointers
  * (e.g. a torch tensor's data_ptr()) and all work is enqueued on `hip_stream` (a hipStream_t; NULL =
  * the default stream).  Nothing is copied to the host and the call does not synchronise; this is the

@@ -202,6 +202,42 @@ def device_count() -> int:
     return n.value if lib().mi355_init(0, C.byref(n)) == 0 else 0
 
 
+def host_array(shape, dtype=np.uint32) -> np.ndarray:
+    """An array in frame memory of the library's (mi355_host_alloc: page-locked from the start, zero-filled): mi355_render writes
+    raytraced frames into it directly, mi355_render_async copies with one DMA transfer -- no host_register.  Give it back with
+    host_array_free(a) once no view of it is in use."""
+    f = lib().mi355_host_alloc
+    f.restype = C.c_void_p
+    f.argtypes = [C.c_size_t]
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = f(n)
+    if not p:
+        raise Mi355Error("mi355_host_alloc: " + lib().mi355_last_error().decode())
+    a = np.ctypeslib.as_array((C.c_ubyte * n).from_address(p)).view(dtype).reshape(shape)
+    _HOST_ARRAYS[a.ctypes.data] = p
+    return a
+
+
+_HOST_ARRAYS = {}
+
+
+def host_array_free(a: np.ndarray) -> None:
+    p = _HOST_ARRAYS.pop(a.ctypes.data)
+    f = lib().mi355_host_free
+    f.restype = None
+    f.argtypes = [C.c_void_p]
+    f(p)
+
+
+def own_mapping_array(shape, dtype=np.uint32) -> np.ndarray:
+    """An array over an anonymous private mapping of its own (page-aligned, not a piece of the malloc heap): what to hand to
+    Scene.host_register when the memory has to be the caller's.  Unmapped when the last reference goes."""
+    import mmap
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    mm = mmap.mmap(-1, (n + mmap.PAGESIZE - 1) // mmap.PAGESIZE * mmap.PAGESIZE)
+    return np.frombuffer(mm, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
 def benchmark_frame(k: int, second_light: bool = False):
     """Camera and lights of frame k of the reference's `renderer -b` loop (host C++ harness)."""
     cam = Camera()
@@ -438,7 +474,8 @@ class Scene:
         return st
 
     def host_register(self, a: np.ndarray) -> None:
-        """Page-lock a caller-owned output array (mi355_host_register)."""
+        """Page-lock a caller-owned output array (mi355_host_register).  Use memory with a mapping of its own (own_mapping_array), or
+        better host_array(): registering pieces of the malloc heap is what mi355_render.h warns about."""
         f = lib().mi355_host_register
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         _check(f(self.context(), a.ctypes.data, a.nbytes), "mi355_host_register")

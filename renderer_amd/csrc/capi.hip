@@ -14,6 +14,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <utility>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -74,6 +76,20 @@ struct ProfMark {
     ProfMark() : t(g_prof.on ? HostProf::now() : 0.0) {}
     void lap(int i) { if (g_prof.on) { const double n = HostProf::now(); g_prof.sum[i] += n - t; g_prof.cnt[i]++; t = n; } }
 };
+
+// MI355_HOST_TRACE=<file>: one line per operation that lets the GPU write into host memory of the caller's (registrations, frames,
+// read-backs), flushed line by line -- the address of a "Memory access fault by GPU" can then be matched to the call that caused it
+void host_trace(const char *fmt, ...)
+{
+    static FILE *f = [] { const char *p = getenv("MI355_HOST_TRACE"); return p && *p ? fopen(p, "a") : (FILE *)nullptr; }();
+    if (!f) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(f, fmt, ap);
+    va_end(ap);
+    fputc('\n', f);
+    fflush(f);
+}
 
 int fail(int code, const char *fmt, ...)
 {
@@ -1193,7 +1209,7 @@ void mi355_scene_destroy(mi355_ctx *c)
         if (a.ev1) (void)hipEventDestroy(a.ev1);
         if (a.st && a.st_owned) (void)hipStreamDestroy(a.st);
     }
-    for (auto &h : c->host_reg) if (h.p) (void)hipHostUnregister(h.p);
+    for (auto &h : c->host_reg) if (h.p) { const hipError_t ue = hipHostUnregister(h.p); host_trace("destroy ctx %p: unregister %p + %zu -> %d", (void *)c, (void *)h.p, h.bytes, (int)ue); }
     c->direct_ctrl.release(); c->direct_sel.release();
     if (c->ev_direct) (void)hipEventDestroy(c->ev_direct);
     if (c->rs_light) mi355i_raster_scratch_destroy(c->rs_light);
@@ -1380,6 +1396,7 @@ int mi355_shadowmap_render(mi355_ctx *c, int slot, const mi355_light *light, int
         return fail(-44, "shadow map span buffer overflowed (%u rows dropped)", dropped);
     }
     c->smap_size[slot] = size;
+    if (out_map) host_trace("shadowmap ctx %p: out %p + %zu", (void *)c, (void *)out_map, (size_t)size * size * 4);
     if (out_map) HIP_TRY(hipMemcpy(out_map, c->smap[slot].p, (size_t)size * size * 4, hipMemcpyDeviceToHost), -31);
     return 0;
 }
@@ -1717,6 +1734,7 @@ int mi355i_fetch_traversal(mi355_ctx *c, int which, void *out, size_t bytes)
     const DevBuf *b = which == 1 ? &c->walk : (which == 2 ? &c->tri_edge : (which == 3 ? &c->tri_shade : nullptr));
     if (!b || bytes > b->bytes) return fail(-3, "mi355i_fetch_traversal: stream %d holds %zu bytes, %zu asked", which, b ? b->bytes : (size_t)0, bytes);
     HIP_TRY(hipDeviceSynchronize(), -40);
+    host_trace("fetch buffer ctx %p: out %p + %zu", (void *)c, (void *)out, (size_t)bytes);
     HIP_TRY(hipMemcpy(out, b->p, bytes, hipMemcpyDeviceToHost), -31);
     return 0;
 }
@@ -1732,11 +1750,51 @@ int mi355i_fetch_wave_profiles(mi355_ctx *c, unsigned long long *out, int max_wa
     return n;
 }
 
+// frame memory handed out by mi355_host_alloc (process-wide: page-locked for every context)
+static std::mutex g_host_alloc_mu;
+static std::vector<std::pair<char *, size_t>> g_host_alloc;
+
 static bool host_range_registered(const mi355_ctx *c, const void *p, size_t bytes)
 {
     for (const auto &h : c->host_reg)
         if (h.p && (const char *)p >= h.p && (const char *)p + bytes <= h.p + h.bytes) return true;
+    std::lock_guard<std::mutex> lk(g_host_alloc_mu);
+    for (const auto &h : g_host_alloc)
+        if ((const char *)p >= h.first && (const char *)p + bytes <= h.first + h.second) return true;
     return false;
+}
+
+void *mi355_host_alloc(size_t bytes)
+{
+    if (!bytes) { (void)fail(-3, "mi355_host_alloc: zero bytes"); return nullptr; }
+    void *p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped);
+    host_trace("host_alloc %p + %zu -> %d", p, bytes, (int)e);
+    if (e != hipSuccess || !p) { (void)hipGetLastError(); (void)fail(-46, "mi355_host_alloc: hipHostMalloc of %zu bytes: %s", bytes, hipGetErrorString(e)); return nullptr; }
+    memset(p, 0, bytes);
+    std::lock_guard<std::mutex> lk(g_host_alloc_mu);
+    g_host_alloc.emplace_back((char *)p, bytes);
+    return p;
+}
+
+void mi355_host_free(void *p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_host_alloc_mu);
+        for (size_t i = 0; i < g_host_alloc.size(); i++)
+            if (g_host_alloc[i].first == (char *)p) { g_host_alloc.erase(g_host_alloc.begin() + (long)i); break; }
+    }
+    {   // (no copy or kernel of any device may still target it)
+        int cur = 0, n = 0;
+        if (hipGetDevice(&cur) == hipSuccess && hipGetDeviceCount(&n) == hipSuccess) {
+            for (int d = 0; d < n; d++) if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+            (void)hipSetDevice(cur);
+        }
+        (void)hipGetLastError();
+    }
+    host_trace("host_free %p", p);
+    (void)hipHostFree(p);
 }
 
 int mi355_host_register(mi355_ctx *c, void *p, size_t bytes)
@@ -1745,7 +1803,9 @@ int mi355_host_register(mi355_ctx *c, void *p, size_t bytes)
     if (int r = select_device(c)) return r;
     for (auto &h : c->host_reg)
         if (!h.p) {
-            HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault), -46);
+            const hipError_t re = hipHostRegister(p, bytes, hipHostRegisterDefault);
+            host_trace("register ctx %p: %p + %zu -> %d", (void *)c, p, bytes, (int)re);
+            HIP_TRY(re, -46);
             h.p = (char *)p; h.bytes = bytes;
             return 0;
         }
@@ -1760,7 +1820,9 @@ int mi355_host_unregister(mi355_ctx *c, void *p)
         if (h.p == (char *)p) {
             for (auto &a : c->slot) if (a.busy && a.st) HIP_TRY(hipStreamSynchronize(a.st), -40);   // no copy may still target it
             HIP_TRY(hipStreamSynchronize(c->stream), -40);
-            HIP_TRY(hipHostUnregister(p), -46);
+            const hipError_t ue = hipHostUnregister(p);
+            host_trace("unregister ctx %p: %p + %zu -> %d", (void *)c, p, h.bytes, (int)ue);
+            HIP_TRY(ue, -46);
             h.p = nullptr; h.bytes = 0;
             return 0;
         }
@@ -1795,6 +1857,9 @@ int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_li
                            host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4) &&
                            hipHostGetDevicePointer(&host_alias, out_xrgb, 0) == hipSuccess && host_alias;
     if (!zero_copy) (void)hipGetLastError();
+    host_trace("render ctx %p mode %d %dx%d: out %p + %zu zero_copy %d (alias %p) registered %d f32 %p + %zu", (void *)c, mode, W, o->height, (void *)out_xrgb,
+               (size_t)pitch_bytes * (size_t)(rows > 0 ? rows - 1 : 0) + (size_t)W * 4, (int)zero_copy, host_alias,
+               (int)host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows > 0 ? rows - 1 : 0) + (size_t)W * 4), (void *)(wantf ? out_rgb_f32 : nullptr), wantf ? (size_t)W * rows * 12 : (size_t)0);
     FrameParams P;
     if (int r = fill_params(c, mode, cam, lights, n_lights, o, zero_copy ? host_alias : c->fb.p, zero_copy ? pitch_bytes : W * 4, wantf ? c->fbf.p : nullptr, P)) return r;
     mi355_stats tmp;
@@ -1872,6 +1937,7 @@ int mi355_render_async(mi355_ctx *c, int mode, const mi355_camera *cam, const mi
     if (int r = enqueue_frame(c, mode, P, 0, a->st, a->ctrl.p, a->rs, &a->mlaa, nullptr, &a->sel)) return r;
     HIP_TRY(hipEventRecord(a->ev1, a->st), -40);
     a->staged = !host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4);
+    host_trace("render_async ctx %p mode %d %dx%d: out %p + %zu staged %d", (void *)c, mode, W, o->height, (void *)out_xrgb, (size_t)pitch_bytes * (size_t)(rows > 0 ? rows - 1 : 0) + (size_t)W * 4, (int)a->staged);
     if (a->staged) {
         HIP_TRY(a->pin.ensure((size_t)W * rows * 4), -31);
         HIP_TRY(hipMemcpyAsync(a->pin.p, a->fb.p, (size_t)W * rows * 4, hipMemcpyDeviceToHost, a->st), -31);

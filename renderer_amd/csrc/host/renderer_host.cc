@@ -133,18 +133,32 @@ void Light::RenderSceneIntoShadowBuffer(const Scene &scene, bool fetchToHost)
 // its pixels with it (the context took its registrations along)
 static std::vector<mi355_ctx *> &liveContexts() { static std::vector<mi355_ctx *> v; return v; }
 
+PixelBuffer::PixelBuffer(size_t n) : _n(n)
+{
+    if (!n) return;
+    _p = (uint32_t *)mi355_host_alloc(n * 4);          // (NULL without a usable device: the host-only uses of the layer)
+    _pinned = _p != nullptr;
+    if (!_p) _p = (uint32_t *)calloc(n, 4);
+    if (!_p) throw std::bad_alloc();
+}
+PixelBuffer::~PixelBuffer()
+{
+    if (_pinned) mi355_host_free(_p); else free(_p);
+}
+
 Screen::Screen(const Scene &scene, int width, int height)
-    : _width(width), _height(height), _pitch(width * 4), _pixels((size_t)width * height, 0u), _scene(scene) {}
+    : _width(width), _height(height), _pitch(width * 4), _pixels((size_t)width * height), _scene(scene) {}
 Screen::~Screen()
 {
     auto &live = liveContexts();
     if (_lockedFor && std::find(live.begin(), live.end(), _lockedFor) != live.end()) (void)mi355_host_unregister(_lockedFor, _pixels.data());
 }
 
-// page-lock the canvas for the scene's context (once; at most 8 canvases per context: further ones stay pageable, which only costs speed)
+// page-lock a canvas that is not page-locked already (PixelBuffer) for the scene's context (once; at most 8 per context: further
+// ones stay pageable, which only costs speed)
 static void lockCanvas(mi355_ctx *ctx, const Screen &canvas)
 {
-    if (canvas._lockedFor == ctx || canvas._pixels.empty()) return;
+    if (canvas._pixels.pinned() || canvas._lockedFor == ctx || canvas._pixels.empty()) return;
     auto &live = liveContexts();
     if (canvas._lockedFor && std::find(live.begin(), live.end(), canvas._lockedFor) != live.end())
         (void)mi355_host_unregister(canvas._lockedFor, (void *)canvas._pixels.data());

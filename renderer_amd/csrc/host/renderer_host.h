@@ -77,14 +77,39 @@ struct Light : public Vector3 {                        // Light.h:32-66
     mi355_light abi() const;
 };
 
+// The canvas's memory: mi355_host_alloc (page-locked by the library from the start: frames are written or DMA'd straight into it)
+// when a HIP device is usable, plain zeroed memory otherwise.  Not a piece of the malloc heap registered afterwards: see
+// mi355_host_alloc in mi355_render.h.
+class PixelBuffer {
+    uint32_t *_p = nullptr;
+    size_t _n = 0;
+    bool _pinned = false;
+public:
+    explicit PixelBuffer(size_t n);
+    ~PixelBuffer();
+    PixelBuffer(const PixelBuffer &) = delete;
+    PixelBuffer &operator=(const PixelBuffer &) = delete;
+    uint32_t *data() { return _p; }
+    const uint32_t *data() const { return _p; }
+    size_t size() const { return _n; }
+    bool empty() const { return _n == 0; }
+    bool pinned() const { return _pinned; }
+    uint32_t *begin() { return _p; }
+    uint32_t *end() { return _p + _n; }
+    const uint32_t *begin() const { return _p; }
+    const uint32_t *end() const { return _p + _n; }
+    uint32_t &operator[](size_t i) { return _p[i]; }
+    const uint32_t &operator[](size_t i) const { return _p[i]; }
+};
+
 struct Screen {                                        // Screen.h:49-171 (canvas only; Z lives on the GPU)
     int _width, _height, _pitch;                       // pitch in bytes
-    std::vector<uint32_t> _pixels;                     // XRGB8888, the SDL_Surface::pixels equivalent
+    PixelBuffer _pixels;                               // XRGB8888, the SDL_Surface::pixels equivalent (page-locked when a device is there)
     const Scene &_scene;
     void (*_present)(const Screen &, void *) = nullptr; // front-end hook called by ShowScreen (SDL_Flip)
     void *_presentArg = nullptr;
-    // the device context _pixels is page-locked for (mi355_host_register; Scene::render* does that on the first frame: frames are
-    // then written, or DMA'd, straight into the canvas -- SDL_Surface::pixels stays put from frame to frame, and so does this)
+    // (a canvas whose memory could not be page-locked at construction -- no device then -- is registered with the context that draws
+    //  into it first: mi355_host_register, undone by ~Screen)
     mutable mi355_ctx *_lockedFor = nullptr;
     Screen(const Scene &scene, int width, int height);
     ~Screen();

@@ -53,3 +53,13 @@ def oracle_scene(oracle):
             s.bvh_ensure(os.path.join(assets.cache_dir(), name + ".oracle.bvh"))
         return s
     return get
+
+
+@pytest.fixture(autouse=True)
+def _host_trace_marker(request):
+    """MI355_HOST_TRACE=<file> (capi.hip: host_trace): name the test in the library's trace of GPU writes into host memory."""
+    path = os.environ.get("MI355_HOST_TRACE")
+    if path:
+        with open(path, "a") as f:
+            f.write("TEST %s\n" % request.node.nodeid)
+    yield

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("mode,mesh", [(9, "dragon_vis.ply"), (6, "chessboard.tri"), (8, "chessboard.tri"), (2, "chessboard.tri")])
-@pytest.mark.parametrize("registered", [False, True])
+@pytest.mark.parametrize("registered", [False, True, "allocated"])     # pageable / mi355_host_register / mi355_host_alloc
 def test_pipelined_frames_equal_synchronous_frames(mode, mesh, registered):
     W, H = 640, 360
     s = R.Scene(R.assets.mesh_path(mesh))
@@ -20,8 +20,12 @@ def test_pipelined_frames_equal_synchronous_frames(mode, mesh, registered):
         s.shadowmap_render(0, cams[0][1][0])
     o = R.default_opts(W, H)
     want = [s.render(mode, *c, o)[0] for c in cams]
-    bufs = [np.full((H, W + 8), 0xdeadbeef, np.uint32) for _ in range(R.MAX_IN_FLIGHT)]        # (pitch wider than the frame)
-    if registered:
+    # (pitch wider than the frame; registered memory has a mapping of its own, not a piece of the heap: mi355_render.h)
+    make = {False: lambda: np.empty((H, W + 8), np.uint32), True: lambda: R.own_mapping_array((H, W + 8)), "allocated": lambda: R.host_array((H, W + 8))}[registered]
+    bufs = [make() for _ in range(R.MAX_IN_FLIGHT)]
+    for b in bufs:
+        b[:] = 0xdeadbeef
+    if registered is True:
         for b in bufs:
             s.host_register(b)
     try:
@@ -44,9 +48,12 @@ def test_pipelined_frames_equal_synchronous_frames(mode, mesh, registered):
         with pytest.raises(R.Mi355Error, match="no frame with ticket"):
             s.render_wait(12345)
     finally:
-        if registered:
+        if registered is True:
             for b in bufs:
                 s.host_unregister(b)
+        if registered == "allocated":
+            for b in bufs:
+                R.host_array_free(b)
     assert len(got) == len(want)
     for k in range(len(want)):
         assert np.array_equal(got[k], want[k]), "frame %d" % k
@@ -59,7 +66,7 @@ def test_synchronous_render_into_a_registered_buffer():
     cam, lights, n = R.benchmark_frame(3)
     o = R.default_opts(W, H)
     want = s.render(9, cam, lights, n, o)[0]
-    buf = np.zeros((H, W), np.uint32)
+    buf = R.own_mapping_array((H, W))
     s.host_register(buf)
     try:
         s.render_into(9, cam, lights, n, o, buf)
@@ -68,6 +75,28 @@ def test_synchronous_render_into_a_registered_buffer():
     assert np.array_equal(buf, want)
     with pytest.raises(R.Mi355Error, match="was not registered"):
         s.host_unregister(buf)
+
+
+def test_synchronous_render_into_frame_memory_of_the_librarys():
+    """mi355_host_alloc: the canvas the C++ host layer's Screen uses -- raytraced frames are written there by the kernels themselves
+    (no copy), raster frames by one DMA transfer; several contexts draw into the same memory."""
+    W, H = 800, 600
+    buf = R.host_array((H, W))
+    try:
+        assert not buf.any()
+        for mesh, mode in (("dragon_vis.ply", 9), ("chessboard.tri", 6), ("dragon_vis.ply", 10)):
+            s = R.Scene(R.assets.mesh_path(mesh))
+            if mode >= 9:
+                s.bvh_create()
+            for k in (3, 77):
+                cam, lights, n = R.benchmark_frame(k)
+                o = R.default_opts(W, H)
+                want = s.render(mode, cam, lights, n, o)[0]
+                buf[:] = 0x00c0ffee
+                s.render_into(mode, cam, lights, n, o, buf)
+                assert np.array_equal(buf, want), (mesh, mode, k)
+    finally:
+        R.host_array_free(buf)
 
 
 def test_many_frame_geometries_in_one_context():
