@@ -20,7 +20,8 @@ def per_launch(variant):
     for d in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%s_*" % variant)):
         if not os.path.isdir(d):
             continue
-        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        # (gpurun_out/ is merged from call to call: only the newest pass of each directory counts)
+        for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:
             for row in csv.DictReader(open(f)):
                 if KERNELS[variant] in row["Kernel_Name"]:
                     a = acc[row["Counter_Name"]]

@@ -444,6 +444,48 @@ def test_shadow_map_sizes_and_close_lights(oracle, oracle_scene, gpu_scene, mesh
     assert int((gm > -1e30).sum()) > size
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_shadow_map_of_random_soups(oracle, tmp_path, seed):
+    """Random triangle soups -- tiny to many times the map's size, slivers, exact duplicates, coordinates snapped to grids (equal
+    depths, shared edges), flat clouds -- lit from outside, from the edge of and from inside the cloud, at map sizes that are and are
+    not multiples of the tiles: the map the LDS-tile kernels draw is the oracle's serial map, bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    n_tri = int(rng.choice([1, 7, 60, 400, 3000, 20000]))
+    size = float(rng.choice([0.02, 0.1, 0.5, 2.5]))
+    c = rng.uniform(-1, 1, (n_tri, 1, 3))
+    v = c + rng.uniform(-size, size, (n_tri, 3, 3))
+    if rng.random() < 0.3:
+        v[:, :, int(rng.integers(0, 3))] *= 0.02
+    snap = [None, None, 0.25, 0.0625][int(rng.integers(0, 4))]
+    if snap:
+        v = np.round(v / snap) * snap
+    if rng.random() < 0.3:
+        v = np.concatenate([v, v[: max(1, n_tri // 2)]])
+    verts = v.reshape(-1, 3).astype(np.float32)
+    faces = np.arange(verts.shape[0]).reshape(-1, 3)
+    p = str(tmp_path / ("soup%d.ply" % seed))
+    with open(p, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nelement face %d\nend_header\n" % (len(verts), len(faces)))
+        for q in verts:
+            f.write("%r %r %r 60\n" % (float(q[0]), float(q[1]), float(q[2])))
+        for t in faces:
+            f.write("3 %d %d %d\n" % (t[0], t[1], t[2]))
+    try:
+        g = R.Scene(p)
+    except R.Mi355Error:
+        pytest.skip("degenerate soup: the loader declines it")
+    o = oracle.Scene(p)
+    cam, _, _ = R.benchmark_frame(0)
+    ocam, _, _ = oracle.benchmark_frame(0)
+    for trial in range(3):
+        lp = (rng.uniform(-1, 1, 3) * float(rng.choice([0.3, 1.2, 4.0]))).astype(np.float32)
+        msize = int(rng.choice([64, 257, 1024, 1500]))
+        gm = g.shadowmap_render(0, R.light(lp, cam), size=msize, fetch=True)
+        om = o.shadowmap(oracle.light(lp, ocam), size=msize)
+        assert np.array_equal(gm, om), "seed %d trial %d: %d triangles, light %s, map %d: %d texels differ" % (
+            seed, trial, faces.shape[0], lp.tolist(), msize, int((gm != om).sum()))
+
+
 @pytest.mark.parametrize("band_rows", [8, 15])       # multigpu.BAND_ROWS (tile rows) and a height that straddles tiles
 @pytest.mark.parametrize("mode", [9, 6, 2])
 def test_band_sharding_reassembles_the_frame(oracle, oracle_scene, gpu_scene, mode, band_rows):
