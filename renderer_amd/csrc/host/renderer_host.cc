@@ -131,7 +131,6 @@ void Light::RenderSceneIntoShadowBuffer(const Scene &scene, bool fetchToHost)
 // ---------------------------------------------------------------- screen -------------------------------
 // device contexts that exist (Scene::context / invalidateDevice): a canvas that outlives its scene's context must not unregister
 // its pixels with it (the context took its registrations along)
-static std::vector<mi355_ctx *> &liveContexts() { static std::vector<mi355_ctx *> v; return v; }
 
 PixelBuffer::PixelBuffer(size_t n) : _n(n)
 {
@@ -148,23 +147,7 @@ PixelBuffer::~PixelBuffer()
 
 Screen::Screen(const Scene &scene, int width, int height)
     : _width(width), _height(height), _pitch(width * 4), _pixels((size_t)width * height), _scene(scene) {}
-Screen::~Screen()
-{
-    auto &live = liveContexts();
-    if (_lockedFor && std::find(live.begin(), live.end(), _lockedFor) != live.end()) (void)mi355_host_unregister(_lockedFor, _pixels.data());
-}
-
-// page-lock a canvas that is not page-locked already (PixelBuffer) for the scene's context (once; at most 8 per context: further
-// ones stay pageable, which only costs speed)
-static void lockCanvas(mi355_ctx *ctx, const Screen &canvas)
-{
-    if (canvas._pixels.pinned() || canvas._lockedFor == ctx || canvas._pixels.empty()) return;
-    auto &live = liveContexts();
-    if (canvas._lockedFor && std::find(live.begin(), live.end(), canvas._lockedFor) != live.end())
-        (void)mi355_host_unregister(canvas._lockedFor, (void *)canvas._pixels.data());
-    canvas._lockedFor = nullptr;
-    if (mi355_host_register(ctx, (void *)canvas._pixels.data(), canvas._pixels.size() * 4) == 0) canvas._lockedFor = ctx;
-}
+Screen::~Screen() = default;
 void Screen::ClearScreen() { std::fill(_pixels.begin(), _pixels.end(), 0u); }
 void Screen::ShowScreen(bool, bool) { if (_present) _present(*this, _presentArg); }
 
@@ -180,7 +163,6 @@ Scene::~Scene() { invalidateDevice(); }
 
 void Scene::invalidateDevice()
 {
-    if (_ctx) { auto &live = liveContexts(); live.erase(std::remove(live.begin(), live.end(), _ctx), live.end()); }
     if (_mgpu) mi355_mgpu_destroy(_mgpu);          // (owns its contexts, _ctx among them)
     else if (_ctx) mi355_scene_destroy(_ctx);
     _mgpu = nullptr;
@@ -799,7 +781,6 @@ mi355_ctx *Scene::context() const
             _ctx = mi355_scene_create(&d, _devices.empty() ? _device : _devices[0]);
             if (!_ctx) raise(std::string("mi355_scene_create: ") + mi355_last_error());
         }
-        liveContexts().push_back(_ctx);
         _bvhOnDevice = false;
     }
     if (!_bvhOnDevice && !_pCFBVH.empty()) {
@@ -837,7 +818,6 @@ void Scene::renderMode(int mode, const Camera &eye, Screen &canvas)
         return;
     }
     mi355_ctx *ctx = context();
-    lockCanvas(ctx, canvas);
     if (mi355_render(ctx, mode, &cam, lights, n, &o, canvas._pixels.data(), canvas._pitch, nullptr, &_lastStats) != 0)
         raise(std::string("mi355_render: ") + mi355_last_error());
 }
@@ -854,7 +834,6 @@ int Scene::renderAsync(int mode, const Camera &eye, Screen &canvas)
     const int n = (int)std::min<size_t>(_lights.size(), MI355_MAX_LIGHTS);
     for (int i = 0; i < n; i++) lights[i] = _lights[i]->abi();
     int ticket = -1;
-    lockCanvas(context(), canvas);
     if (mi355_render_async(context(), mode, &cam, lights, n, &o, canvas._pixels.data(), canvas._pitch, &ticket) != 0)
         raise(std::string("mi355_render_async: ") + mi355_last_error());
     return ticket;

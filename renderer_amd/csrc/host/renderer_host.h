@@ -108,9 +108,6 @@ struct Screen {                                        // Screen.h:49-171 (canva
     const Scene &_scene;
     void (*_present)(const Screen &, void *) = nullptr; // front-end hook called by ShowScreen (SDL_Flip)
     void *_presentArg = nullptr;
-    // (a canvas whose memory could not be page-locked at construction -- no device then -- is registered with the context that draws
-    //  into it first: mi355_host_register, undone by ~Screen)
-    mutable mi355_ctx *_lockedFor = nullptr;
     Screen(const Scene &scene, int width, int height);
     ~Screen();
     Screen(const Screen &) = delete;
