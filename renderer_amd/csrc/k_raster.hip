@@ -8,6 +8,7 @@
 // independent): one lane per triangle walks its edges, one lane per row its span, 32-bit atomicMax on an
 // order-preserving float key.
 #include "rs_core.h"
+#include "sm_core.h"
 #include <hip/hip_ext.h>
 #include <cstdlib>
 #include <cstring>
@@ -44,46 +45,6 @@ struct RasterScratch {
 };
 
 namespace {
-
-// ---- shadow-map edge walk: ScanConverter on {x, y, z} fat points, Light.cc:261-296 ------------------------------
-// One edge of the triangle as ScanConverter::ScanConvert / InnerLoop walk it (ScanConverter.h:90-136), advanced scanline
-// by scanline: rows y0..y1 inclusive after clipping (y0 > y1: contributes nothing); a horizontal edge adds both end points.
-template <int N> struct RsEdge {
-    float v[N], d[N];
-    int y0, y1;
-    bool horiz;
-};
-
-template <int N>
-MI_DEV void rs_edge_init(RsEdge<N> &E, int ya, const float (&va)[N], int yb, const float (&vb)[N], int height)
-{
-    E.horiz = false; E.y0 = 1; E.y1 = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) { E.v[i] = 0.f; E.d[i] = 0.f; }
-    if (ya == yb) {
-        if (ya >= 0 && ya < height) { E.horiz = true; E.y0 = E.y1 = ya; }
-        return;
-    }
-    const bool sw = ya > yb;                    // InnerLoop(y1 < y2): walk from the smaller y
-    int y1 = sw ? yb : ya, y2 = sw ? ya : yb;
-    if (y1 < 0 && y2 < 0) return;
-    if (y1 >= height && y2 >= height) return;
-    const float dy = (float)(y2 - y1);
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        const float a = sw ? vb[i] : va[i], b = sw ? va[i] : vb[i];
-        E.v[i] = a;
-        E.d[i] = (b - a) / dy;
-    }
-    if (y1 < 0) {
-        const float k = (float)-y1;
-#pragma unroll
-        for (int i = 0; i < N; i++) E.v[i] += E.d[i] * k;
-        y1 = 0;
-    }
-    if (height - 1 < y2) y2 = height - 1;
-    E.y0 = y1; E.y1 = y2;
-}
 
 // feed row y with this edge's point(s); advances the walker
 template <int N>
@@ -577,14 +538,6 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
 
 // ---------------------------------------------------------------------------------------------
 // Shadow map (Light.cc:84-160, 253-296)
-struct ShadowParams {
-    float light[3];
-    float mv[9];
-    int size;
-};
-
-MI_DEV uint32_t f2key(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
-MI_DEV float key2f(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
 __global__ void __launch_bounds__(128) k_sm_setup(const DevScene S, const ShadowParams Q, RowRec *rows,
                                                   uint32_t rows_cap, uint32_t *ctl)
@@ -651,30 +604,6 @@ __global__ void __launch_bounds__(256) k_sm_spans(const ShadowParams Q, const Ro
 #define SM_COOP 64      // a span is taken by the whole wave only if it is longer than this many pixels per long span the wave holds
 #endif
 
-// the projected corners of triangle t (Light.cc:100-128): false = rejected (all above / below the map)
-MI_DEV bool sm_project(const DevScene &S, const ShadowParams &Q, uint32_t t, float (&f)[3][3], int (&iy)[3])
-{
-    const uint4 id = S.rs_idx[t];
-    const uint32_t vid[3] = {id.x, id.y, id.z};
-    const f3 light = mk3(Q.light[0], Q.light[1], Q.light[2]);
-    const int SM = Q.size;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const float4 pv = S.rs_vert[(size_t)vid[k] * 2];
-        f3 x = mulright(Q.mv, sub3(mk3(pv.x, pv.y, pv.z), light));
-        x.x = (float)(SM / 2) + (float)(SM * 2) * x.x / x.z;
-        x.y = (float)(SM / 2) + (float)(SM * 2) * x.y / x.z;
-        x.z = 1.0f / x.z;
-        f[k][0] = x.x; f[k][1] = x.y; f[k][2] = x.z;
-    }
-    if (f[0][1] < 0.f && f[1][1] < 0.f && f[2][1] < 0.f) return false;
-    const float fS = (float)SM;
-    if (f[0][1] >= fS && f[1][1] >= fS && f[2][1] >= fS) return false;
-#pragma unroll
-    for (int k = 0; k < 3; k++) iy[k] = cvtt_i32(f[k][1]);
-    return true;
-}
-
 // rows[i] = (triangle, row of the map) for every row a triangle touches; ctl[0] = rows used, ctl[1] = rows that did not fit
 __global__ void __launch_bounds__(256) k_sm_count(const DevScene S, const ShadowParams Q, uint2 *items, uint32_t items_cap, uint32_t *ctl)
 {
@@ -699,13 +628,6 @@ __global__ void __launch_bounds__(256) k_sm_count(const DevScene S, const Shadow
         if (base + p < items_cap) items[base + p] = make_uint2(bp.box[owner].x, bp.box[owner].y + (uint32_t)k);
         else atomicAdd(&ctl[1], 1u);
     }
-}
-
-// value of an edge walker (rs_edge_init) at row y: (y - y0) additions of d, taken at once
-MI_DEV void sm_edge_at(const RsEdge<3> &E, int y, float (&v)[3])
-{
-#pragma unroll
-    for (int i = 0; i < 3; i++) v[i] = ff_add(E.v[i], E.d[i], y - E.y0);
 }
 
 __global__ void __launch_bounds__(256) k_sm_rows(const DevScene S, const ShadowParams Q, const uint2 *items, const uint32_t *ctl, uint32_t items_cap,
@@ -823,56 +745,12 @@ __global__ void __launch_bounds__(256) k_sm_rows(const DevScene S, const ShadowP
 // 256 x 4, 512 threads 104 / 118 / 114; 512 x 4 106 / 120 / 119; 1024 x 1 127 / 61 / 73; 512 x 1, 256 threads 108 / 67 / 81; 1024 threads per tile
 // never better than 129 / 87 / 78.  The row-item kernels: 291 / 82 / 84.
 // Same plots, same values, same maximum: the map is bit-identical (tests: the oracle's map = the real Light.cc's).
-#ifndef SMT_W
-#define SMT_W 512
-#endif
-#ifndef SMT_H
-#define SMT_H 2
-#endif
-#define SMT_LIST 2048         // triangles a tile collects before it draws them
-#ifndef SMT_T
-#define SMT_T 512            // threads of a tile's workgroup
-#endif
-#define SMT_BANDS 4096        // most bands a map has
-#define SMT_WIDE 4            // a triangle of more bands than this goes to the coarse bands' lists
-#define SMT_CB 16             // bands per coarse band
-
-struct SmPrep { float f[9]; int iy[3]; float d[9]; float pad[3]; };      // projected corners (x, y, 1/z), their truncated rows, the three edges' steps per row: 96 bytes
-
-// rs_edge_init with the edge's per-row steps already known (k_sm_prep made them with rs_edge_init itself: the same divisions, once
-// per triangle instead of once per row and tile)
-MI_DEV void sm_edge_init(RsEdge<3> &E, int ya, const float (&va)[3], int yb, const float (&vb)[3], const float *d, int height)
-{
-    E.horiz = false; E.y0 = 1; E.y1 = 0;
-#pragma unroll
-    for (int i = 0; i < 3; i++) { E.v[i] = 0.f; E.d[i] = 0.f; }
-    if (ya == yb) {
-        if (ya >= 0 && ya < height) { E.horiz = true; E.y0 = E.y1 = ya; }
-        return;
-    }
-    const bool sw = ya > yb;
-    int y1 = sw ? yb : ya, y2 = sw ? ya : yb;
-    if (y1 < 0 && y2 < 0) return;
-    if (y1 >= height && y2 >= height) return;
-#pragma unroll
-    for (int i = 0; i < 3; i++) { E.v[i] = sw ? vb[i] : va[i]; E.d[i] = d[i]; }
-    if (y1 < 0) {
-        const float k = (float)-y1;
-#pragma unroll
-        for (int i = 0; i < 3; i++) E.v[i] += E.d[i] * k;
-        y1 = 0;
-    }
-    if (height - 1 < y2) y2 = height - 1;
-    E.y0 = y1; E.y1 = y2;
-}
-
 // ctl: [0] list entries handed out (one add per block), [1] entries that did not fit
 // Two kinds of lists per block: a triangle of up to SMT_WIDE bands is entered in each of them; a taller one in the COARSE bands
 // (SMT_CB bands each) it crosses -- the chessboard's squares cross hundreds of bands, and the thread that entered one of them alone,
 // a returning LDS atomic and a store per band, kept its whole workgroup waiting (prep 46 us; through coarse bands: 12).  A tile
 // reads its band's list and its coarse band's, and keeps of the second what reaches its rows.
 // Lists are numbered 0 .. n_bands (the bands, and one that stays empty), then n_bands + 1 + c for coarse band c (and an empty one).
-MI_HD int sm_lists(int n_bands) { return n_bands + 1 + (n_bands + SMT_CB - 1) / SMT_CB + 1; }
 
 __global__ void __launch_bounds__(256) k_sm_prep(const DevScene S, const ShadowParams Q, SmPrep *prep, uint2 *bbox, uint32_t *table, uint32_t *ids, uint32_t ids_cap,
                                                  uint32_t *ctl)
@@ -886,42 +764,16 @@ __global__ void __launch_bounds__(256) k_sm_prep(const DevScene S, const ShadowP
     for (int i = tid; i < n_lists; i += NT) hist[i] = 0u;
     __syncthreads();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    float f[3][3]; int iy[3], miny = 0, maxy = 0;
-    uint2 bb = make_uint2(0xffffffffu, 0u);          // rows = ~0: touches nothing
-    if (t < S.n_tris && sm_project(S, Q, t, f, iy) && rs_tri_rows(iy, Q.size, miny, maxy)) {
-        // columns: every plotted x is a value of a serial chain between two of the corners' x (edges, then spans), so it lies in
-        // their range widened by the chains' drift (<= one ulp of the largest |x| per addition, <= size additions per chain, two
-        // chains) and the pixel it is truncated into.  Anything unordered or out of the integers' range: every column.
-        const float xa = f[0][0], xb = f[1][0], xc = f[2][0];
-        float lo = xa < xb ? xa : xb; lo = lo < xc ? lo : xc;
-        float hi = xa > xb ? xa : xb; hi = hi > xc ? hi : xc;
-        const float amax = __builtin_fmaxf(__builtin_fabsf(lo), __builtin_fabsf(hi));
-        const float drift = (float)(2 * Q.size + 8) * amax * 1.1920929e-07f + 2.0f;       // 2^-23 per addition
-        lo -= drift; hi += drift;
-        int c0 = 0, c1 = Q.size - 1;
-        if (lo == lo && hi == hi && amax < 4.f * (float)Q.size) {       // (a triangle that reaches far beyond the map: chains too long for the bound)
-            if (hi < 0.f || lo > (float)(Q.size - 1)) c1 = -1;                             // beside the map
-            else { c0 = lo > 0.f ? (int)lo : 0; c1 = hi < (float)(Q.size - 1) ? (int)hi : Q.size - 1; }
-        }
-        if (c1 >= c0) bb = make_uint2((uint32_t)miny | ((uint32_t)maxy << 16), (uint32_t)c0 | ((uint32_t)c1 << 16));
-    }
+    // the triangle's record for the tiles, its rows and columns (sm_core.h); the lists it is entered in: b0 .. b1
+    SmPrep rec;
+    uint2 bb;
+    const bool drawn = sm_prep_triangle(S, Q, t, rec, bb);
     if (t < S.n_tris) bbox[t] = bb;
-    const bool drawn = bb.x != 0xffffffffu;
-    int b0 = miny / SMT_H, b1 = drawn ? maxy / SMT_H : b0 - 1;                   // the lists it is entered in: b0 .. b1
-    if (b1 - b0 >= SMT_WIDE) { b0 = n_bands + 1 + b0 / SMT_CB; b1 = n_bands + 1 + b1 / SMT_CB; }
+    if (drawn) prep[t] = rec;
+    int b0 = 0, b1 = -1;
+    if (drawn) sm_lists_of(bb.x, n_bands, b0, b1);
     // triangles per list: +1 where a triangle's lists start, -1 behind their end, summed up below
     if (drawn) { atomicAdd(&hist[b0], 1u); atomicAdd(&hist[b1 + 1], 0xffffffffu); }
-    if (drawn) {
-        SmPrep &P = prep[t];
-#pragma unroll
-        for (int k = 0; k < 3; k++) { P.f[3 * k] = f[k][0]; P.f[3 * k + 1] = f[k][1]; P.f[3 * k + 2] = f[k][2]; P.iy[k] = iy[k]; }
-        RsEdge<3> e0, e1, e2;                      // Light.cc:270-272: v1v2, v2v3, v1v3
-        rs_edge_init<3>(e0, iy[0], f[0], iy[1], f[1], Q.size);
-        rs_edge_init<3>(e1, iy[1], f[1], iy[2], f[2], Q.size);
-        rs_edge_init<3>(e2, iy[0], f[0], iy[2], f[2], Q.size);
-#pragma unroll
-        for (int i = 0; i < 3; i++) { P.d[i] = e0.d[i]; P.d[3 + i] = e1.d[i]; P.d[6 + i] = e2.d[i]; }
-    }
     // exclusive prefix of a per-thread number over the block (and the block's total)
     const auto block_excl = [&](uint32_t mine, uint32_t &total) {
         uint32_t incl = mine;
@@ -977,67 +829,6 @@ __global__ void __launch_bounds__(SMT_T) k_sm_tiles(const ShadowParams Q, const 
     for (int i = tid; i < SMT_H * SMT_W; i += SMT_T) keys[0][i] = ~0xFEFEFEFEu;             // Light::ClearShadowBuffer: bytes 0xFE (Light.h:48-52)
     if (tid == 0) n_list = 0u;
     __syncthreads();
-    // the rows ya .. yb of a triangle in this tile (corners and edge steps loaded once): k_sm_rows' body per row, the span cut to the tile's columns
-    const auto tri_rows = [&](uint32_t t, int ya, int yb) {
-        const int xs = X0, xe = X1;
-        const SmPrep P = prep[t];
-        const float f[3][3] = {{P.f[0], P.f[1], P.f[2]}, {P.f[3], P.f[4], P.f[5]}, {P.f[6], P.f[7], P.f[8]}};
-        RsEdge<3> e0, e1, e2;                      // Light.cc:270-272: v1v2, v2v3, v1v3
-        sm_edge_init(e0, P.iy[0], f[0], P.iy[1], f[1], P.d, SM);
-        sm_edge_init(e1, P.iy[1], f[1], P.iy[2], f[2], P.d + 3, SM);
-        sm_edge_init(e2, P.iy[0], f[0], P.iy[2], f[2], P.d + 6, SM);
-        for (int y = ya; y <= yb; y++) {
-        float l[3] = {0.f, 0.f, 0.f}, r[3] = {0.f, 0.f, 0.f};
-        uint32_t cnt = 0;
-        const auto feed = [&](const RsEdge<3> &E, const float (&a)[3], const float (&b)[3]) {
-            if (y < E.y0 || y > E.y1) return;
-            if (E.horiz) { scan_add<3>(l, r, cnt, a); scan_add<3>(l, r, cnt, b); return; }
-            float v[3];
-            sm_edge_at(E, y, v);
-            scan_add<3>(l, r, cnt, v);
-        };
-        feed(e0, f[0], f[1]); feed(e1, f[1], f[2]); feed(e2, f[0], f[2]);
-        uint32_t *row = keys[y - Y0];
-        const auto plot = [&](float x, float z) {                          // PlotShadowPixel, Light.cc:253-259 (this tile's share of it)
-            const int idx = cvtt_i32(x);
-            if (idx >= xs && idx <= xe && z == z) atomicMax(&row[idx - X0], f2key(z));
-            return idx;
-        };
-        if (cnt == 1) { plot(l[0], l[2]); continue; }
-        if (cnt != 2) continue;
-        const int x1 = cvtt_i32(l[0]), x2 = cvtt_i32(r[0]);
-        const long long st = llabs((long long)x2 - (long long)x1);
-        if (!st) { plot(l[0], l[2]); plot(r[0], r[2]); continue; }
-        if (st > (1ll << 24)) continue;                                    // a degenerate projection (geometry at the light's plane)
-        const int steps = (int)st;
-        const float fsteps = (float)steps;
-        const float dx = (r[0] - l[0]) / fsteps, dz = (r[2] - l[2]) / fsteps;
-        float sx = l[0], sz = l[2];
-        // the pixels 0 .. steps of the span whose x falls into the tile: start a few pixels before the estimate (the chain drifts
-        // from the straight line by far less), stop beyond the tile's last column; chains ff_add cannot jump into are walked whole
-        int j = 0;
-        if (dx > 0.f && x1 < xs) {
-            // (x of pixel k = k additions from the span's first: exact through ff_add, in pieces its arithmetic covers; it never
-            //  decreases with k, which is what the search and the stop below rest on)
-            const auto x_at = [&](int k) { float v = l[0]; for (int done = 0; done < k;) { const int n = k - done < (1 << 21) ? k - done : (1 << 21); v = ff_add(v, dx, n); done += n; } return v; };
-            const float est = ((float)xs - sx) / dx - 4.f;
-            if (est >= (float)steps) j = steps; else if (est > 0.f) j = (int)est;
-            if (j > 0 && cvtt_i32(x_at(j)) >= xs) {
-                // the estimate is not left of the tile (a span of millions of pixels drifts from the straight line): the last pixel that
-                // is, by bisection
-                int lo_j = 0, hi_j = j;                                     // x(lo_j) < xs <= x(hi_j)
-                while (hi_j - lo_j > 1) { const int mid = lo_j + (hi_j - lo_j) / 2; if (cvtt_i32(x_at(mid)) < xs) lo_j = mid; else hi_j = mid; }
-                j = lo_j;
-            }
-            if (j > 0) { sx = x_at(j); for (int done = 0; done < j;) { const int n = j - done < (1 << 21) ? j - done : (1 << 21); sz = ff_add(sz, dz, n); done += n; } }
-        }
-        for (;; j++) {
-            const int idx = plot(sx, sz);
-            if (j >= steps || (dx > 0.f && idx > xe && idx != (int)0x80000000)) break;
-            sx += dx; sz += dz;
-        }
-        }
-    };
     const auto drain = [&]() {       // the triangles of the list over the threads
         const uint32_t n = n_list < SMT_LIST ? n_list : SMT_LIST;
         // (a thread per (triangle, row of the tile): a thread that took a triangle's rows one after the other made the chessboard's
@@ -1046,7 +837,10 @@ __global__ void __launch_bounds__(SMT_T) k_sm_tiles(const ShadowParams Q, const 
             const int y = Y0 + (int)(it % SMT_H);
             const uint32_t rows = list_rows[it / SMT_H];
             if (y > Y1 || y < (int)(rows & 0xffffu) || y > (int)(rows >> 16)) continue;
-            tri_rows(list[it / SMT_H], y, y);
+            // (sm_core.h: the three edge walkers brought to row y, Light.cc's edge order and truncations, the span entered at the tile's
+            //  first column; the keys of the tile's row take the maximum)
+            uint32_t *row = keys[y - Y0];
+            sm_tile_row(prep[list[it / SMT_H]], SM, y, X0, X1, [&](int x, float z) { atomicMax(&row[x - X0], f2key(z)); });
         }
         // (a thread per 128 or 64 columns of a span as well -- the chessboard's spans cross the whole tile -- gave the chessboard nothing
         //  and doubled and tripled the dragon: the lanes that skip their item wait for the ones that do not)

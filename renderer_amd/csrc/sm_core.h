@@ -1,0 +1,241 @@
+// sm_core.h -- the shadow map's per-thread arithmetic (Light.cc:84-296), shared by the HIP kernels (k_raster.hip: k_sm_prep /
+// k_sm_tiles and the older row kernels) and, compiled for the host, by tests/emu/emu_shadow.hip, which drives it tile by tile
+// against the oracle where there is no GPU.  Everything here is a function of one thread's own inputs: the binning, the LDS lists and
+// the atomics stay in the kernels.
+#pragma once
+#include "dev_math.h"
+#include "dev_scene.h"
+#include "rs_core.h"
+#include "ff_add.h"
+
+// ---- shadow-map edge walk: ScanConverter on {x, y, z} fat points, Light.cc:261-296 ------------------------------
+// One edge of the triangle as ScanConverter::ScanConvert / InnerLoop walk it (ScanConverter.h:90-136), advanced scanline
+// by scanline: rows y0..y1 inclusive after clipping (y0 > y1: contributes nothing); a horizontal edge adds both end points.
+template <int N> struct RsEdge {
+    float v[N], d[N];
+    int y0, y1;
+    bool horiz;
+};
+
+template <int N>
+MI_HD void rs_edge_init(RsEdge<N> &E, int ya, const float (&va)[N], int yb, const float (&vb)[N], int height)
+{
+    E.horiz = false; E.y0 = 1; E.y1 = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) { E.v[i] = 0.f; E.d[i] = 0.f; }
+    if (ya == yb) {
+        if (ya >= 0 && ya < height) { E.horiz = true; E.y0 = E.y1 = ya; }
+        return;
+    }
+    const bool sw = ya > yb;                    // InnerLoop(y1 < y2): walk from the smaller y
+    int y1 = sw ? yb : ya, y2 = sw ? ya : yb;
+    if (y1 < 0 && y2 < 0) return;
+    if (y1 >= height && y2 >= height) return;
+    const float dy = (float)(y2 - y1);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const float a = sw ? vb[i] : va[i], b = sw ? va[i] : vb[i];
+        E.v[i] = a;
+        E.d[i] = (b - a) / dy;
+    }
+    if (y1 < 0) {
+        const float k = (float)-y1;
+#pragma unroll
+        for (int i = 0; i < N; i++) E.v[i] += E.d[i] * k;
+        y1 = 0;
+    }
+    if (height - 1 < y2) y2 = height - 1;
+    E.y0 = y1; E.y1 = y2;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Shadow map (Light.cc:84-160, 253-296)
+struct ShadowParams {
+    float light[3];
+    float mv[9];
+    int size;
+};
+
+MI_HD uint32_t f2key(float f) { const uint32_t u = __builtin_bit_cast(uint32_t, f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+MI_HD float key2f(uint32_t k) { return __builtin_bit_cast(float, (uint32_t)((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k)); }
+
+// the projected corners of triangle t (Light.cc:100-128): false = rejected (all above / below the map)
+MI_HD bool sm_project(const DevScene &S, const ShadowParams &Q, uint32_t t, float (&f)[3][3], int (&iy)[3])
+{
+    const uint4 id = S.rs_idx[t];
+    const uint32_t vid[3] = {id.x, id.y, id.z};
+    const f3 light = mk3(Q.light[0], Q.light[1], Q.light[2]);
+    const int SM = Q.size;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float4 pv = S.rs_vert[(size_t)vid[k] * 2];
+        f3 x = mulright(Q.mv, sub3(mk3(pv.x, pv.y, pv.z), light));
+        x.x = (float)(SM / 2) + (float)(SM * 2) * x.x / x.z;
+        x.y = (float)(SM / 2) + (float)(SM * 2) * x.y / x.z;
+        x.z = 1.0f / x.z;
+        f[k][0] = x.x; f[k][1] = x.y; f[k][2] = x.z;
+    }
+    if (f[0][1] < 0.f && f[1][1] < 0.f && f[2][1] < 0.f) return false;
+    const float fS = (float)SM;
+    if (f[0][1] >= fS && f[1][1] >= fS && f[2][1] >= fS) return false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) iy[k] = cvtt_i32(f[k][1]);
+    return true;
+}
+
+// value of an edge walker (rs_edge_init) at row y: (y - y0) additions of d, taken at once
+MI_HD void sm_edge_at(const RsEdge<3> &E, int y, float (&v)[3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++) v[i] = ff_add(E.v[i], E.d[i], y - E.y0);
+}
+
+#ifndef SMT_W
+#define SMT_W 512
+#endif
+#ifndef SMT_H
+#define SMT_H 2
+#endif
+#define SMT_LIST 2048         // triangles a tile collects before it draws them
+#ifndef SMT_T
+#define SMT_T 512            // threads of a tile's workgroup
+#endif
+#define SMT_BANDS 4096        // most bands a map has
+#define SMT_WIDE 4            // a triangle of more bands than this goes to the coarse bands' lists
+#define SMT_CB 16             // bands per coarse band
+
+struct SmPrep { float f[9]; int iy[3]; float d[9]; float pad[3]; };      // projected corners (x, y, 1/z), their truncated rows, the three edges' steps per row: 96 bytes
+
+// rs_edge_init with the edge's per-row steps already known (k_sm_prep made them with rs_edge_init itself: the same divisions, once
+// per triangle instead of once per row and tile)
+MI_HD void sm_edge_init(RsEdge<3> &E, int ya, const float (&va)[3], int yb, const float (&vb)[3], const float *d, int height)
+{
+    E.horiz = false; E.y0 = 1; E.y1 = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { E.v[i] = 0.f; E.d[i] = 0.f; }
+    if (ya == yb) {
+        if (ya >= 0 && ya < height) { E.horiz = true; E.y0 = E.y1 = ya; }
+        return;
+    }
+    const bool sw = ya > yb;
+    int y1 = sw ? yb : ya, y2 = sw ? ya : yb;
+    if (y1 < 0 && y2 < 0) return;
+    if (y1 >= height && y2 >= height) return;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { E.v[i] = sw ? vb[i] : va[i]; E.d[i] = d[i]; }
+    if (y1 < 0) {
+        const float k = (float)-y1;
+#pragma unroll
+        for (int i = 0; i < 3; i++) E.v[i] += E.d[i] * k;
+        y1 = 0;
+    }
+    if (height - 1 < y2) y2 = height - 1;
+    E.y0 = y1; E.y1 = y2;
+}
+
+MI_HD int sm_lists(int n_bands) { return n_bands + 1 + (n_bands + SMT_CB - 1) / SMT_CB + 1; }
+
+// ---- what k_sm_prep computes for one triangle, apart from entering it in lists --------------------------------------------------
+// false = the triangle plots nothing (rejected, or beside the map).  bb = (first row | last row << 16, first column | last column
+// << 16), rows = ~0 when it plots nothing; P = its record for the tiles (only when drawn).
+// Columns: every plotted x is a value of a serial chain between two of the corners' x (edges, then spans), so it lies in their range
+// widened by the chains' drift (<= one ulp of the largest |x| per addition, <= size additions per chain, two chains) and the pixel
+// it is truncated into.  Anything unordered or out of the integers' range: every column.
+MI_HD bool sm_prep_triangle(const DevScene &S, const ShadowParams &Q, uint32_t t, SmPrep &P, uint2 &bb)
+{
+    bb = make_uint2(0xffffffffu, 0u);
+    float f[3][3]; int iy[3], miny = 0, maxy = 0;
+    if (!(t < S.n_tris && sm_project(S, Q, t, f, iy) && rs_tri_rows(iy, Q.size, miny, maxy))) return false;
+    const float xa = f[0][0], xb = f[1][0], xc = f[2][0];
+    float lo = xa < xb ? xa : xb; lo = lo < xc ? lo : xc;
+    float hi = xa > xb ? xa : xb; hi = hi > xc ? hi : xc;
+    const float amax = __builtin_fmaxf(__builtin_fabsf(lo), __builtin_fabsf(hi));
+    const float drift = (float)(2 * Q.size + 8) * amax * 1.1920929e-07f + 2.0f;       // 2^-23 per addition
+    lo -= drift; hi += drift;
+    int c0 = 0, c1 = Q.size - 1;
+    if (lo == lo && hi == hi && amax < 4.f * (float)Q.size) {       // (a triangle that reaches far beyond the map: chains too long for the bound)
+        if (hi < 0.f || lo > (float)(Q.size - 1)) c1 = -1;                             // beside the map
+        else { c0 = lo > 0.f ? (int)lo : 0; c1 = hi < (float)(Q.size - 1) ? (int)hi : Q.size - 1; }
+    }
+    if (c1 < c0) return false;
+    bb = make_uint2((uint32_t)miny | ((uint32_t)maxy << 16), (uint32_t)c0 | ((uint32_t)c1 << 16));
+#pragma unroll
+    for (int k = 0; k < 3; k++) { P.f[3 * k] = f[k][0]; P.f[3 * k + 1] = f[k][1]; P.f[3 * k + 2] = f[k][2]; P.iy[k] = iy[k]; }
+    RsEdge<3> e0, e1, e2;                      // Light.cc:270-272: v1v2, v2v3, v1v3
+    rs_edge_init<3>(e0, iy[0], f[0], iy[1], f[1], Q.size);
+    rs_edge_init<3>(e1, iy[1], f[1], iy[2], f[2], Q.size);
+    rs_edge_init<3>(e2, iy[0], f[0], iy[2], f[2], Q.size);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { P.d[i] = e0.d[i]; P.d[3 + i] = e1.d[i]; P.d[6 + i] = e2.d[i]; }
+    return true;
+}
+
+// the lists a drawn triangle with rows bb.x is entered in: b0 .. b1 (bands, or coarse bands when it crosses more than SMT_WIDE)
+MI_HD void sm_lists_of(uint32_t rows, int n_bands, int &b0, int &b1)
+{
+    b0 = (int)(rows & 0xffffu) / SMT_H; b1 = (int)(rows >> 16) / SMT_H;
+    if (b1 - b0 >= SMT_WIDE) { b0 = n_bands + 1 + b0 / SMT_CB; b1 = n_bands + 1 + b1 / SMT_CB; }
+}
+
+// ---- what a thread of k_sm_tiles does for (triangle, row y): k_sm_rows' body, the span cut to the columns xs .. xe ------------------
+// put(x, z) is called for every pixel of the row the triangle plots whose column lies in xs .. xe (PlotShadowPixel, Light.cc:253-259:
+// this range's share of it), in the reference's order along the span.
+template <class Put>
+MI_HD void sm_tile_row(const SmPrep &P, int SM, int y, int xs, int xe, Put put)
+{
+    const float f[3][3] = {{P.f[0], P.f[1], P.f[2]}, {P.f[3], P.f[4], P.f[5]}, {P.f[6], P.f[7], P.f[8]}};
+    RsEdge<3> e0, e1, e2;                      // Light.cc:270-272: v1v2, v2v3, v1v3
+    sm_edge_init(e0, P.iy[0], f[0], P.iy[1], f[1], P.d, SM);
+    sm_edge_init(e1, P.iy[1], f[1], P.iy[2], f[2], P.d + 3, SM);
+    sm_edge_init(e2, P.iy[0], f[0], P.iy[2], f[2], P.d + 6, SM);
+    float l[3] = {0.f, 0.f, 0.f}, r[3] = {0.f, 0.f, 0.f};
+    uint32_t cnt = 0;
+    const auto feed = [&](const RsEdge<3> &E, const float (&a)[3], const float (&b)[3]) {
+        if (y < E.y0 || y > E.y1) return;
+        if (E.horiz) { scan_add<3>(l, r, cnt, a); scan_add<3>(l, r, cnt, b); return; }
+        float v[3];
+        sm_edge_at(E, y, v);
+        scan_add<3>(l, r, cnt, v);
+    };
+    feed(e0, f[0], f[1]); feed(e1, f[1], f[2]); feed(e2, f[0], f[2]);
+    const auto plot = [&](float x, float z) {
+        const int idx = cvtt_i32(x);
+        if (idx >= xs && idx <= xe && z == z) put(idx, z);
+        return idx;
+    };
+    if (cnt == 1) { plot(l[0], l[2]); return; }
+    if (cnt != 2) return;
+    const int x1 = cvtt_i32(l[0]), x2 = cvtt_i32(r[0]);
+    long long st = (long long)x2 - (long long)x1;
+    if (st < 0) st = -st;
+    if (!st) { plot(l[0], l[2]); plot(r[0], r[2]); return; }
+    if (st > (1ll << 24)) return;                                      // a degenerate projection (geometry at the light's plane)
+    const int steps = (int)st;
+    const float fsteps = (float)steps;
+    const float dx = (r[0] - l[0]) / fsteps, dz = (r[2] - l[2]) / fsteps;
+    float sx = l[0], sz = l[2];
+    // the pixels 0 .. steps of the span whose x falls into xs .. xe: start a few pixels before the estimate (the chain drifts from the
+    // straight line by far less), stop beyond the last column; chains ff_add cannot jump into are walked whole
+    int j = 0;
+    if (dx > 0.f && x1 < xs) {
+        // (x of pixel k = k additions from the span's first: exact through ff_add, in pieces its arithmetic covers; it never
+        //  decreases with k, which is what the search and the stop below rest on)
+        const auto x_at = [&](int k) { float v = l[0]; for (int done = 0; done < k;) { const int n = k - done < (1 << 21) ? k - done : (1 << 21); v = ff_add(v, dx, n); done += n; } return v; };
+        const float est = ((float)xs - sx) / dx - 4.f;
+        if (est >= (float)steps) j = steps; else if (est > 0.f) j = (int)est;
+        if (j > 0 && cvtt_i32(x_at(j)) >= xs) {
+            // the estimate is not left of the range (a span of millions of pixels drifts from the straight line): the last pixel that
+            // is, by bisection
+            int lo_j = 0, hi_j = j;                                     // x(lo_j) < xs <= x(hi_j)
+            while (hi_j - lo_j > 1) { const int mid = lo_j + (hi_j - lo_j) / 2; if (cvtt_i32(x_at(mid)) < xs) lo_j = mid; else hi_j = mid; }
+            j = lo_j;
+        }
+        if (j > 0) { sx = x_at(j); for (int done = 0; done < j;) { const int n = j - done < (1 << 21) ? j - done : (1 << 21); sz = ff_add(sz, dz, n); done += n; } }
+    }
+    for (;; j++) {
+        const int idx = plot(sx, sz);
+        if (j >= steps || (dx > 0.f && idx > xe && idx != (int)0x80000000)) break;
+        sx += dx; sz += dz;
+    }
+}

@@ -69,3 +69,25 @@ def render(hs, mode, cams, lights_per_frame, n_lights, opts, shadow_maps=None, b
     if rc != 0:
         raise RuntimeError("emu_raster failed (%d)" % rc)
     return outs, dict(tris_drawn=stats[0], spans=stats[1], ztests=stats[2], plots=stats[3]), int(over.value)
+
+
+_slib = None
+
+
+def shadowmap(hs, light, size=1024, streams=None):
+    """tests/emu/libemu_shadow.so: the shadow map through the kernels' own per-thread code (sm_core.h) on the host -> (map, stats)."""
+    global _slib
+    if _slib is None:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        _slib = C.CDLL(os.path.join(_HERE, "libemu_shadow.so"))
+        _slib.emu_shadowmap.restype = C.c_int
+    _, _, rs_idx, rs_vert = streams or scene_streams(hs)
+    out = np.empty((size, size), np.float32)
+    st = (C.c_ulonglong * 6)()
+    pos = (C.c_float * 3)(*list(light.pos))
+    w2l = (C.c_float * 9)(*list(light.world_to_light))
+    rc = _slib.emu_shadowmap(C.c_uint32(hs.nt), C.c_uint32(hs.nv), C.c_void_p(rs_idx.ctypes.data), C.c_void_p(rs_vert.ctypes.data), pos, w2l,
+                             C.c_int(size), C.c_void_p(out.ctypes.data), st)
+    if rc != 0:
+        raise RuntimeError("emu_shadowmap failed (%d)" % rc)
+    return out, dict(drawn=st[0], list_entries=st[1], tile_entries=st[2], items=st[3], max_entries_per_tile=st[4], pixels=st[5])
