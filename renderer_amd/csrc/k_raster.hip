@@ -840,10 +840,14 @@ __global__ void __launch_bounds__(SMT_T) k_sm_tiles(const ShadowParams Q, const 
             // (sm_core.h: the three edge walkers brought to row y, Light.cc's edge order and truncations, the span entered at the tile's
             //  first column; the keys of the tile's row take the maximum)
             uint32_t *row = keys[y - Y0];
-            sm_tile_row(prep[list[it / SMT_H]], SM, y, X0, X1, [&](int x, float z) { atomicMax(&row[x - X0], f2key(z)); });
+            const SmPrep P = prep[list[it / SMT_H]];                         // (loaded whole, up front: six 16-byte loads)
+            sm_tile_row(P, SM, y, X0, X1, [&](int x, float z) { atomicMax(&row[x - X0], f2key(z)); });
         }
         // (a thread per 128 or 64 columns of a span as well -- the chessboard's spans cross the whole tile -- gave the chessboard nothing
         //  and doubled and tripled the dragon: the lanes that skip their item wait for the ones that do not)
+        // (measured as well, us chessboard / dragon / statue against 97 / 71 / 72: the list made of (triangle, row) items that have a row to draw
+        //  -- no lane skips, but a round of the list takes half the entries -- 100 / 79 / 87; the next item's record requested before this
+        //  one is drawn, 24 more registers: 128 / 76 / 77; the record read through a reference instead of loaded whole: 99 / 76 / 77)
     };
     // The band's entries: a list per block of k_sm_prep.  SMT_T lists at a time, their entries numbered through (prefix of the lists'
     // lengths) and dealt to the threads one by one -- a mesh whose neighbouring triangles sit in the same band hands one list of 256
