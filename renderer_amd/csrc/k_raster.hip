@@ -752,7 +752,7 @@ __global__ void __launch_bounds__(256) k_sm_rows(const DevScene S, const ShadowP
 // reads its band's list and its coarse band's, and keeps of the second what reaches its rows.
 // Lists are numbered 0 .. n_bands (the bands, and one that stays empty), then n_bands + 1 + c for coarse band c (and an empty one).
 
-__global__ void __launch_bounds__(256) k_sm_prep(const DevScene S, const ShadowParams Q, SmPrep *prep, uint2 *bbox, uint32_t *table, uint32_t *ids, uint32_t ids_cap,
+__global__ void __launch_bounds__(256) k_sm_prep(const DevScene S, const ShadowParams Q, SmPrep *prep, uint2 *bbox, uint32_t *table, uint4 *ids, uint32_t ids_cap,
                                                  uint32_t *ctl)
 {
     constexpr int NT = 256;
@@ -810,11 +810,12 @@ __global__ void __launch_bounds__(256) k_sm_prep(const DevScene S, const ShadowP
     for (int i = tid; i < n_lists; i += NT) row[i] = base + off[i];            //  dragon's table entries scattered writes: prep 12 -> 19 us)
     for (int band = b0; band <= b1; band++) {
         const uint32_t at = base + off[band] + atomicAdd(&hist[band], 1u);
-        if (at < ids_cap) ids[at] = t; else atomicAdd(&ctl[1], 1u);      // (reported like a row buffer that was too small: it grows)
+        // (an entry carries the triangle's rows and columns: a tile filters what it reads without a second, dependent load)
+        if (at < ids_cap) ids[at] = make_uint4(t, bb.x, bb.y, 0u); else atomicAdd(&ctl[1], 1u);      // (reported like a row buffer that was too small: it grows)
     }
 }
 
-__global__ void __launch_bounds__(SMT_T) k_sm_tiles(const ShadowParams Q, const SmPrep *prep, const uint2 *bbox, const uint32_t *table, uint32_t n_blocks, const uint32_t *ids,
+__global__ void __launch_bounds__(SMT_T) k_sm_tiles(const ShadowParams Q, const SmPrep *prep, const uint2 *bbox, const uint32_t *table, uint32_t n_blocks, const uint4 *ids,
                                                   uint32_t ids_cap, float *map)
 {
     __shared__ uint32_t keys[SMT_H][SMT_W];
@@ -852,14 +853,16 @@ __global__ void __launch_bounds__(SMT_T) k_sm_tiles(const ShadowParams Q, const 
     // The band's entries: a list per block of k_sm_prep.  SMT_T lists at a time, their entries numbered through (prefix of the lists'
     // lengths) and dealt to the threads one by one -- a mesh whose neighbouring triangles sit in the same band hands one list of 256
     // entries to a band, and a thread per LIST walked it alone: 380 us of dependent loads.
-    // First the band's own lists, then the lists of the coarse band it lies in (the tall triangles: the rows are checked here).
+    // The band's own lists and the lists of the coarse band it lies in (the tall triangles: the rows are checked here) side by side: 2 x
+    // n_blocks lists, SMT_T at a time (one pass for a mesh of up to 65 000 triangles: a pass is a chain of dependent loads and barriers).
     const int n_lists = sm_lists(n_bands);
-    for (int which = 0; which < 2; which++)
-    for (uint32_t blk0 = 0; blk0 < n_blocks; blk0 += SMT_T) {
-        const uint32_t blk = blk0 + (uint32_t)tid;
-        const int li = which ? n_bands + 1 + ty / SMT_CB : ty;
+    for (uint32_t sg0 = 0; sg0 < 2u * n_blocks; sg0 += SMT_T) {
+        const uint32_t sg = sg0 + (uint32_t)tid;
         uint32_t cur = 0, end = 0;
-        if (blk < n_blocks) {
+        if (sg < 2u * n_blocks) {
+            const bool coarse = sg >= n_blocks;
+            const uint32_t blk = coarse ? sg - n_blocks : sg;
+            const int li = coarse ? n_bands + 1 + ty / SMT_CB : ty;
             const uint32_t *row = table + (size_t)blk * (size_t)n_lists;
             cur = row[li]; end = row[li + 1];
             if (cur > ids_cap) cur = ids_cap;
@@ -884,8 +887,9 @@ __global__ void __launch_bounds__(SMT_T) k_sm_tiles(const ShadowParams Q, const 
             for (uint32_t e = e0 + (uint32_t)tid; e < total && e < e0 + SMT_LIST; e += SMT_T) {
                 int lo = 0, hi = SMT_T - 1;                          // the list entry e belongs to: the last one that starts at or before it
                 while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (seg_pre[mid] <= e) lo = mid; else hi = mid - 1; }
-                const uint32_t t = ids[seg_start[lo] + (e - seg_pre[lo])];
-                const uint2 bb = bbox[t];
+                const uint4 en = ids[seg_start[lo] + (e - seg_pre[lo])];
+                const uint32_t t = en.x;
+                const uint2 bb = make_uint2(en.y, en.z);
                 if ((int)(bb.y & 0xffffu) <= X1 && (int)(bb.y >> 16) >= X0 && (int)(bb.x & 0xffffu) <= Y1 && (int)(bb.x >> 16) >= Y0) { const uint32_t at = atomicAdd(&n_list, 1u); list[at] = t; list_rows[at] = bb.x; }
             }
             __syncthreads();
@@ -1237,22 +1241,22 @@ extern "C" hipError_t mi355i_launch_shadowmap(const DevScene *S, const float *li
         const int n_bands = (size + SMT_H - 1) / SMT_H;
         const size_t prep_bytes = ((size_t)S->n_tris * sizeof(SmPrep) + 15) & ~(size_t)15, box_bytes = ((size_t)S->n_tris * sizeof(uint2) + 15) & ~(size_t)15;
         const size_t table_bytes = (((size_t)nbT * (size_t)sm_lists(n_bands)) * 4 + 15) & ~(size_t)15, fixed = prep_bytes + box_bytes + table_bytes;
-        if ((size_t)s->rows_cap * sizeof(RowRec) < fixed + ((size_t)S->n_tris * 4 + 4096) * 4) {
+        if ((size_t)s->rows_cap * sizeof(RowRec) < fixed + ((size_t)S->n_tris * 4 + 4096) * sizeof(uint4)) {
             if (s->rows) (void)hipFree(s->rows);
             s->rows = nullptr; s->rows_cap = 0;
-            const size_t recs = (fixed + ((size_t)S->n_tris * 16 + 4096) * 4 + sizeof(RowRec) - 1) / sizeof(RowRec);
+            const size_t recs = (fixed + ((size_t)S->n_tris * 16 + 4096) * sizeof(uint4) + sizeof(RowRec) - 1) / sizeof(RowRec);
             if ((e = hipMalloc((void **)&s->rows, recs * sizeof(RowRec))) != hipSuccess) return e;
             s->rows_cap = (uint32_t)recs;
         }
         SmPrep *prep = (SmPrep *)s->rows;
         uint2 *bbox = (uint2 *)((char *)s->rows + prep_bytes);
         uint32_t *table = (uint32_t *)((char *)s->rows + prep_bytes + box_bytes);
-        uint32_t *ids = (uint32_t *)((char *)s->rows + fixed);
-        const size_t ids_cap_z = ((size_t)s->rows_cap * sizeof(RowRec) - fixed) / 4;
+        uint4 *ids = (uint4 *)((char *)s->rows + fixed);
+        const size_t ids_cap_z = ((size_t)s->rows_cap * sizeof(RowRec) - fixed) / sizeof(uint4);
         const uint32_t ids_cap = ids_cap_z > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)ids_cap_z;
         hipLaunchKernelGGL(k_sm_prep, dim3(nbT), dim3(256), 0, st, *S, Q, prep, bbox, table, ids, ids_cap, s->ctl);
         const unsigned tiles = (unsigned)(((size + SMT_W - 1) / SMT_W) * n_bands);
-        hipLaunchKernelGGL(k_sm_tiles, dim3(tiles), dim3(SMT_T), 0, st, Q, (const SmPrep *)prep, (const uint2 *)bbox, (const uint32_t *)table, (uint32_t)nbT, (const uint32_t *)ids, ids_cap,
+        hipLaunchKernelGGL(k_sm_tiles, dim3(tiles), dim3(SMT_T), 0, st, Q, (const SmPrep *)prep, (const uint2 *)bbox, (const uint32_t *)table, (uint32_t)nbT, (const uint4 *)ids, ids_cap,
                            d_map);
         return hipGetLastError();
     }

@@ -74,7 +74,7 @@ def render(hs, mode, cams, lights_per_frame, n_lights, opts, shadow_maps=None, b
 _slib = None
 
 
-def shadowmap(hs, light, size=1024, streams=None):
+def shadowmap(hs, light, size=1024, streams=None, items_per_tile=None):
     """tests/emu/libemu_shadow.so: the shadow map through the kernels' own per-thread code (sm_core.h) on the host -> (map, stats)."""
     global _slib
     if _slib is None:
@@ -87,7 +87,7 @@ def shadowmap(hs, light, size=1024, streams=None):
     pos = (C.c_float * 3)(*list(light.pos))
     w2l = (C.c_float * 9)(*list(light.world_to_light))
     rc = _slib.emu_shadowmap(C.c_uint32(hs.nt), C.c_uint32(hs.nv), C.c_void_p(rs_idx.ctypes.data), C.c_void_p(rs_vert.ctypes.data), pos, w2l,
-                             C.c_int(size), C.c_void_p(out.ctypes.data), st)
+                             C.c_int(size), C.c_void_p(out.ctypes.data), st, C.c_void_p(items_per_tile.ctypes.data if items_per_tile is not None else None))
     if rc != 0:
         raise RuntimeError("emu_shadowmap failed (%d)" % rc)
     return out, dict(drawn=st[0], list_entries=st[1], tile_entries=st[2], items=st[3], max_entries_per_tile=st[4], pixels=st[5])

@@ -11,9 +11,9 @@
 #include <vector>
 
 // stats: [0] triangles drawn, [1] list entries, [2] entries that pass a tile's filter, [3] (triangle, row) items plotted from,
-// [4] the largest number of entries one tile looks at, [5] pixels offered to the keys
+// [4] the largest number of entries one tile looks at, [5] pixels offered to the keys; items_per_tile (optional): [band][tile column]
 extern "C" int emu_shadowmap(uint32_t n_tris, uint32_t n_verts, const uint32_t *rs_idx, const float *rs_vert, const float *light_pos, const float *w2l,
-                             int size, float *out_map, unsigned long long *stats)
+                             int size, float *out_map, unsigned long long *stats, uint32_t *items_per_tile)
 {
     if (size <= 0 || size > SMT_BANDS * SMT_H) return -1;
     DevScene S;
@@ -52,7 +52,7 @@ extern "C" int emu_shadowmap(uint32_t n_tris, uint32_t n_verts, const uint32_t *
             const int X0 = tx * SMT_W, Y0 = ty * SMT_H;
             const int X1 = (X0 + SMT_W < SM ? X0 + SMT_W : SM) - 1, Y1 = (Y0 + SMT_H < SM ? Y0 + SMT_H : SM) - 1;
             for (auto &k : keys) k = ~0xFEFEFEFEu;                           // Light::ClearShadowBuffer: bytes 0xFE (Light.h:48-52)
-            unsigned long long looked = 0;
+            unsigned long long looked = 0, items0 = st[3];
             for (int which = 0; which < 2; which++) {
                 const int li = which ? n_bands + 1 + ty / SMT_CB : ty;
                 // (the kernels deal a list's entries to the threads in any order: here back to front)
@@ -71,6 +71,7 @@ extern "C" int emu_shadowmap(uint32_t n_tris, uint32_t n_verts, const uint32_t *
                 }
             }
             if (looked > st[4]) st[4] = looked;
+            if (items_per_tile) items_per_tile[(size_t)ty * tiles_x + tx] = (uint32_t)(st[3] - items0);
             for (int y = Y0; y <= Y1; y++)
                 for (int x = X0; x <= X1; x++) out_map[(size_t)y * SM + x] = key2f(keys[(size_t)(y - Y0) * SMT_W + (x - X0)]);
         }
