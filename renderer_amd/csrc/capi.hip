@@ -77,6 +77,16 @@ struct ProfMark {
     void lap(int i) { if (g_prof.on) { const double n = HostProf::now(); g_prof.sum[i] += n - t; g_prof.cnt[i]++; t = n; } }
 };
 
+// devices that hold contexts of this library (mi355_host_free waits for their work -- and must not initialise the others)
+static std::mutex g_dev_mu;
+static int g_dev_use[64];
+static void device_use(int device, int delta)
+{
+    if (device < 0 || device >= 64) return;
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    g_dev_use[device] += delta;
+}
+
 // MI355_HOST_TRACE=<file>: one line per operation that lets the GPU write into host memory of the caller's (registrations, frames,
 // read-backs), flushed line by line -- the address of a "Memory access fault by GPU" can then be matched to the call that caused it
 void host_trace(const char *fmt, ...)
@@ -1112,6 +1122,7 @@ mi355_ctx *mi355_scene_create(const mi355_scene_desc *d, int device)
         }
     mi355_ctx *c = new mi355_ctx;
     c->device = device;
+    device_use(device, +1);
     auto bail = [&](const char *what, hipError_t e) { fail(-4, "%s: %s", what, hipGetErrorString(e)); mi355_scene_destroy(c); return (mi355_ctx *)nullptr; };
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return bail("hipSetDevice", e);
@@ -1186,6 +1197,7 @@ mi355_ctx *mi355_scene_create(const mi355_scene_desc *d, int device)
 void mi355_scene_destroy(mi355_ctx *c)
 {
     if (!c) return;
+    device_use(c->device, -1);
     (void)hipSetDevice(c->device);
     // (nothing of this context may be in flight on any stream -- its own, the internal frame streams, a caller's -- while its
     //  buffers go away)
@@ -1795,10 +1807,13 @@ void mi355_host_free(void *p)
         for (size_t i = 0; i < g_host_alloc.size(); i++)
             if (g_host_alloc[i].first == (char *)p) { g_host_alloc.erase(g_host_alloc.begin() + (long)i); break; }
     }
-    {   // (no copy or kernel of any device may still target it)
-        int cur = 0, n = 0;
-        if (hipGetDevice(&cur) == hipSuccess && hipGetDeviceCount(&n) == hipSuccess) {
-            for (int d = 0; d < n; d++) if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+    {   // (no copy or kernel may still target it: the current device's and those of the devices that hold contexts)
+        int cur = 0;
+        if (hipGetDevice(&cur) == hipSuccess) {
+            (void)hipDeviceSynchronize();
+            bool used[64];
+            { std::lock_guard<std::mutex> lk(g_dev_mu); for (int d = 0; d < 64; d++) used[d] = g_dev_use[d] > 0; }
+            for (int d = 0; d < 64; d++) if (used[d] && d != cur && hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
             (void)hipSetDevice(cur);
         }
         (void)hipGetLastError();
