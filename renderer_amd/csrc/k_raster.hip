@@ -40,7 +40,8 @@ struct RasterScratch {
     int grow = 0;                  // doublings of the bins asked for after an overflow (mi355i_raster_grow)
     // shadow map
     RowRec *rows = nullptr; uint32_t rows_cap = 0;
-    uint32_t *ctl = nullptr;       // [0] rows used, [1] rows dropped because the row buffer was full
+    uint32_t *ctl = nullptr;       // [0] rows used, [1] rows dropped because the row buffer was full; the tile kernels: a pair per parity (below)
+    int ctl_pair = 0;              // the pair of control words the last launch of the tile kernels used (the launch clears the other one for the next)
     uint32_t *smkeys = nullptr; size_t sm_words = 0;
 };
 
@@ -816,7 +817,7 @@ __global__ void __launch_bounds__(256) k_sm_prep(const DevScene S, const ShadowP
 }
 
 __global__ void __launch_bounds__(SMT_T) k_sm_tiles(const ShadowParams Q, const SmPrep *prep, const uint2 *bbox, const uint32_t *table, uint32_t n_blocks, const uint4 *ids,
-                                                  uint32_t ids_cap, float *map)
+                                                  uint32_t ids_cap, float *map, uint32_t *ctl_next)
 {
     __shared__ uint32_t keys[SMT_H][SMT_W];
     __shared__ uint32_t list[SMT_LIST], list_rows[SMT_LIST];
@@ -829,6 +830,7 @@ __global__ void __launch_bounds__(SMT_T) k_sm_tiles(const ShadowParams Q, const 
     const int X1 = (X0 + SMT_W < SM ? X0 + SMT_W : SM) - 1, Y1 = (Y0 + SMT_H < SM ? Y0 + SMT_H : SM) - 1;
     for (int i = tid; i < SMT_H * SMT_W; i += SMT_T) keys[0][i] = ~0xFEFEFEFEu;             // Light::ClearShadowBuffer: bytes 0xFE (Light.h:48-52)
     if (tid == 0) n_list = 0u;
+    if (blockIdx.x == 0 && tid < 2) ctl_next[tid] = 0u;       // (the next launch's counters: k_sm_prep of THIS launch has finished with its own pair)
     __syncthreads();
     const auto drain = [&]() {       // the triangles of the list over the threads
         const uint32_t n = n_list < SMT_LIST ? n_list : SMT_LIST;
@@ -1216,6 +1218,7 @@ static hipError_t sm_ensure(RasterScratch *s, size_t sm_words, uint32_t n_tris, 
     }
     if (!s->ctl) {
         if ((e = hipMalloc((void **)&s->ctl, 64)) != hipSuccess) return e;
+        if ((e = hipMemset(s->ctl, 0, 64)) != hipSuccess) return e;
     }
     return hipSuccess;
 }
@@ -1230,7 +1233,6 @@ extern "C" hipError_t mi355i_launch_shadowmap(const DevScene *S, const float *li
     memcpy(Q.light, light_pos, 12);
     memcpy(Q.mv, w2l, 36);
     Q.size = size;
-    if ((e = hipMemsetAsync(s->ctl, 0, 64, st)) != hipSuccess) return e;
     static const bool legacy = [] { const char *v = getenv("MI355_SM_LEGACY"); return v && *v && strcmp(v, "0"); }();     // the round-1 kernels, for comparison
     static const bool row_items = [] { const char *v = getenv("MI355_SM_ROWS"); return v && *v && strcmp(v, "0"); }();    // the round-3 kernels, for comparison
     if (!legacy && !row_items && size <= SMT_BANDS * SMT_H) {
@@ -1254,12 +1256,18 @@ extern "C" hipError_t mi355i_launch_shadowmap(const DevScene *S, const float *li
         uint4 *ids = (uint4 *)((char *)s->rows + fixed);
         const size_t ids_cap_z = ((size_t)s->rows_cap * sizeof(RowRec) - fixed) / sizeof(uint4);
         const uint32_t ids_cap = ids_cap_z > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)ids_cap_z;
-        hipLaunchKernelGGL(k_sm_prep, dim3(nbT), dim3(256), 0, st, *S, Q, prep, bbox, table, ids, ids_cap, s->ctl);
+        // (no clearing launch in front: this launch counts in one pair of control words and its tile kernel clears the other pair for the next
+        //  launch -- 4 us of a 70 us chain)
+        s->ctl_pair ^= 1;
+        uint32_t *ctl = s->ctl + 2 * s->ctl_pair, *ctl_next = s->ctl + 2 * (s->ctl_pair ^ 1);
+        hipLaunchKernelGGL(k_sm_prep, dim3(nbT), dim3(256), 0, st, *S, Q, prep, bbox, table, ids, ids_cap, ctl);
         const unsigned tiles = (unsigned)(((size + SMT_W - 1) / SMT_W) * n_bands);
         hipLaunchKernelGGL(k_sm_tiles, dim3(tiles), dim3(SMT_T), 0, st, Q, (const SmPrep *)prep, (const uint2 *)bbox, (const uint32_t *)table, (uint32_t)nbT, (const uint4 *)ids, ids_cap,
-                           d_map);
+                           d_map, ctl_next);
         return hipGetLastError();
     }
+    if ((e = hipMemsetAsync(s->ctl, 0, 64, st)) != hipSuccess) return e;
+    s->ctl_pair = 0;
     // Light::ClearShadowBuffer: bytes 0xFE (Light.h:48-52) -> key of the float 0xFEFEFEFE
     hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, st, s->smkeys, ~0xFEFEFEFEu, n);
     if (legacy) {     // the round-1 kernels: a lane per triangle, then a lane per row (kept for comparison)
@@ -1289,7 +1297,7 @@ extern "C" int mi355i_raster_grow(RasterScratch *s)
 extern "C" uint32_t mi355i_raster_overflow(RasterScratch *s)
 {
     uint32_t h[2] = {0, 0};
-    if (s && s->ctl) (void)hipMemcpy(h, s->ctl, 8, hipMemcpyDeviceToHost);
+    if (s && s->ctl) (void)hipMemcpy(h, s->ctl + 2 * s->ctl_pair, 8, hipMemcpyDeviceToHost);
     return h[1];
 }
 
