@@ -1890,7 +1890,10 @@ int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_li
     mi355_stats tmp;
     mi355_stats *st = stats ? stats : &tmp;
     P.no_pipe = 1;          // (a synchronous frame has nothing to overlap with: its kernels follow each other on the context's stream)
-    if (zero_copy) P.fill_first = 96;     // (waves that start with the background: it takes PCIe 0.28 ms, the frame 0.54)
+    static const int fill_first_env = [] { const char *v = getenv("MI355_FILL_FIRST"); return v && *v ? atoi(v) : 0; }();       // (experiments)
+    // (waves that start with the background -- the rest of it is written by waves that have run out of pixels.  Measured, frames/s of the
+    //  synchronous call: 4: 1 584, 8: 1 601, 16: 1 593, 32: 1 559, 96: 1 555, 256: 1 570, 1024: 1 531; MI355_FILL_FIRST, scripts/seam_fill_sweep.py)
+    if (zero_copy) P.fill_first = fill_first_env > 0 ? fill_first_env : 16;
     for (int attempt = 0;; attempt++) {
         HIP_TRY(hipEventRecord(c->ev0, c->stream), -40);
         if (int r = enqueue_frame(c, mode, P, o->collect_stats, c->stream)) return r;
