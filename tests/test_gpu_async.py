@@ -115,3 +115,42 @@ def test_many_frame_geometries_in_one_context():
             fresh = R.Scene(R.assets.mesh_path("dragon_vis.ply"))
             fresh.bvh_create()
             assert np.array_equal(img, fresh.render(9, cam, lights, n, R.default_opts(W, H))[0])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_frames_written_in_place_at_odd_sizes_pitches_and_cameras(seed):
+    """The zero-copy frame (mi355_render into frame memory of the library's: traced tiles stored by their waves, the background by waves
+    that start with it or have run out of pixels) where its bookkeeping has edges: widths and heights that are no multiple of the 8x8
+    tiles, a pitch wider than the frame (the padding must stay untouched), a window into a larger canvas, cameras that see everything,
+    a sliver or nothing of the model, 4 spp; every frame equals the frame the plain call returns."""
+    rng = np.random.default_rng(900 + seed)
+    mesh = ["dragon_vis.ply", "statue.ply", "chessboard.tri"][seed % 3]
+    s = R.Scene(R.assets.mesh_path(mesh))
+    s.bvh_create()
+    canvas = R.host_array((1100, 2000))
+    try:
+        for trial in range(5):
+            W, H = int(rng.integers(1, 1900)), int(rng.integers(1, 1000))
+            x0, y0 = int(rng.integers(0, 2000 - W)), int(rng.integers(0, 1100 - H))
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                cam, lights, n = R.benchmark_frame(int(rng.integers(0, 200)))
+            else:
+                eye = (rng.normal(size=3) * [0.3, 1.5, 4.0][kind - 1]).astype(np.float32)
+                at = (rng.normal(size=3) * 0.5).astype(np.float32) if kind != 3 else (eye * 2).astype(np.float32)
+                if np.linalg.norm(np.cross(at - eye, [0, 0, 1])) < 1e-3:
+                    continue
+                cam = R.camera(eye, at)
+                lights = (R.Light * 2)(R.light(np.array([3.0, 3.0, 4.0], np.float32), cam))
+                n = 1
+            mode = 10 if trial == 4 else 9
+            o = R.default_opts(W, H)
+            want = s.render(mode, cam, lights, n, o)[0]
+            canvas[:] = 0x00abcdef
+            view = canvas[y0:y0 + H, x0:x0 + W]
+            s.render_into(mode, cam, lights, n, o, view)
+            assert np.array_equal(view, want), "seed %d trial %d: %dx%d at (%d, %d), camera kind %d" % (seed, trial, W, H, x0, y0, kind)
+            canvas[y0:y0 + H, x0:x0 + W] = 0x00abcdef
+            assert (canvas == 0x00abcdef).all(), "seed %d trial %d: pixels outside the window were written" % (seed, trial)
+    finally:
+        R.host_array_free(canvas)
