@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <unistd.h>
 #include <cstring>
 #include <numeric>
 #include <sstream>
@@ -747,13 +748,16 @@ void Scene::UpdateBoundingVolumeHierarchy(const char *filename, bool forceRecalc
         }
     }
     CreateBVH();
-    if (FILE *fp = fopen(cache.c_str(), "wb")) {
+    // (written beside its place and renamed into it: eight ranks of one job come here at the same moment on a fresh box, and a rank
+    //  must find either no cache or a whole one)
+    const std::string tmp = cache + ".tmp" + std::to_string((long long)getpid());
+    if (FILE *fp = fopen(tmp.c_str(), "wb")) {
         const uint32_t nN = (uint32_t)_pCFBVH.size(), nT = (uint32_t)_triIndexList.size();
         const bool ok = fwrite(&nN, 4, 1, fp) == 1 && fwrite(&nT, 4, 1, fp) == 1 &&
                         fwrite(_pCFBVH.data(), sizeof(CacheFriendlyBVHNode), nN, fp) == nN &&
                         fwrite(_triIndexList.data(), 4, nT, fp) == nT;
-        fclose(fp);
-        if (!ok) remove(cache.c_str());
+        const bool closed = fclose(fp) == 0;
+        if (!(ok && closed && rename(tmp.c_str(), cache.c_str()) == 0)) remove(tmp.c_str());
     }
 }
 
