@@ -428,6 +428,9 @@ def test_shadow_map_bit_exact(oracle, oracle_scene, gpu_scene, mesh):
     ("chessboard.tri", 1024, (0.05, 0.02, 0.3)),        # ... above the middle of it: geometry on every side, degenerate projections
     ("dragon_vis.ply", 777, (1.2, -0.9, 0.8)),
     ("statue.ply", 1024, (0.4, 0.3, 0.5)),
+    ("chessboard.tri", 4097, (3.394, 3.394, 4.8)),      # large maps: a workgroup per tile, 2049 bands
+    ("chessboard.tri", 8192, (3.394, 3.394, 4.8)),      # ... the largest the tile kernels take (SMT_BANDS bands): the lists' numbering at its limit
+    ("dragon_vis.ply", 8200, (3.394, 3.394, 4.8)),      # ... and one row more: the row-item kernels take over
 ], ids=lambda v: str(v).replace(" ", ""))
 def test_shadow_map_sizes_and_close_lights(oracle, oracle_scene, gpu_scene, mesh, size, pos):
     """The map's tiles (k_sm_prep / k_sm_tiles: bands of rows, coarse bands for tall triangles, columns from the corners' x) against the

@@ -104,6 +104,14 @@ def test_random_soups(oracle, tmp_path, seed):
             seed, trial, len(verts) // 3, lp.tolist(), msize, int((m != om).sum()))
 
 
+@pytest.mark.parametrize("size", [4097, 8192])
+def test_the_largest_maps_the_tile_kernels_take(oracle, scenes, size):
+    """8192 rows = SMT_BANDS bands of SMT_H rows: the list numbering (bands, an empty one, coarse bands, an empty one) at its limit."""
+    hs, osc, streams = scenes("chessboard.tri")
+    m, om, st = both(oracle, hs, osc, streams, (3.394, 3.394, 4.8), size)
+    assert np.array_equal(m, om), "%d texels differ" % int((m != om).sum())
+
+
 def test_a_triangle_is_entered_in_bands_or_in_coarse_bands(oracle, scenes):
     """The bookkeeping the kernels' scans rest on (emu_shadow.hip returns an error otherwise): the last list of each kind stays empty,
     no triangle is in both kinds; and the chessboard's squares do go through the coarse bands (far fewer entries than rows / 2)."""
