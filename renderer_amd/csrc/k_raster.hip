@@ -47,54 +47,6 @@ struct RasterScratch {
 
 namespace {
 
-// feed row y with this edge's point(s); advances the walker
-template <int N>
-MI_DEV void rs_edge_row(RsEdge<N> &E, int y, const float (&fa)[N], const float (&fb)[N], float (&l)[N], float (&r)[N], uint32_t &cnt)
-{
-    if (y < E.y0 || y > E.y1) return;
-    if (E.horiz) { scan_add<N>(l, r, cnt, fa); scan_add<N>(l, r, cnt, fb); return; }
-    if (y != E.y0) {
-#pragma unroll
-        for (int i = 0; i < N; i++) E.v[i] += E.d[i];
-    }
-    scan_add<N>(l, r, cnt, E.v);
-}
-
-template <int N>
-MI_DEV void emit_rows(int iy0, int iy1, int iy2, const float (&A)[N], const float (&B)[N], const float (&C)[N],
-                      int height, uint32_t tri, RowRec *rows, uint32_t rows_cap, uint32_t *ctl)
-{
-    const int iy[3] = {iy0, iy1, iy2};
-    int miny, maxy;
-    if (!rs_tri_rows(iy, height, miny, maxy)) return;
-    const uint32_t nrows = (uint32_t)(maxy - miny + 1);
-    const uint32_t base = atomicAdd(&ctl[0], nrows);
-    if (base + nrows > rows_cap) {
-        // dropped (the caller reports it and grows the buffer): the part of the reservation that lies inside the
-        // buffer is marked so that the span pass does not read records nobody wrote
-        atomicAdd(&ctl[1], nrows);
-        for (uint32_t i = base; i < rows_cap && i - base < nrows; i++) { rows[i].pad = 1u; rows[i].cnt = 0u; rows[i].y = 0; }
-        return;
-    }
-    RsEdge<N> e0, e1, e2;           // Light.cc:270-272: v1v2, v2v3, v1v3
-    rs_edge_init<N>(e0, iy0, A, iy1, B, height);
-    rs_edge_init<N>(e1, iy1, B, iy2, C, height);
-    rs_edge_init<N>(e2, iy0, A, iy2, C, height);
-    for (int y = miny; y <= maxy; y++) {
-        float l[N], r[N];
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int i = 0; i < N; i++) { l[i] = 0.f; r[i] = 0.f; }
-        rs_edge_row<N>(e0, y, A, B, l, r, cnt);
-        rs_edge_row<N>(e1, y, B, C, l, r, cnt);
-        rs_edge_row<N>(e2, y, A, C, l, r, cnt);
-        RowRec &R = rows[base + (uint32_t)(y - miny)];
-#pragma unroll
-        for (int i = 0; i < N; i++) { R.l[i] = l[i]; R.r[i] = r[i]; }
-        R.tri = tri; R.y = y; R.cnt = cnt; R.pad = 0;
-    }
-}
-
 } // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -540,60 +492,8 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
 // ---------------------------------------------------------------------------------------------
 // Shadow map (Light.cc:84-160, 253-296)
 
-__global__ void __launch_bounds__(128) k_sm_setup(const DevScene S, const ShadowParams Q, RowRec *rows,
-                                                  uint32_t rows_cap, uint32_t *ctl)
-{
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= S.n_tris) return;
-    const uint4 id = S.rs_idx[t];
-    const uint32_t vid[3] = {id.x, id.y, id.z};
-    const f3 light = mk3(Q.light[0], Q.light[1], Q.light[2]);
-    const int SM = Q.size;
-    float f[3][3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const float4 pv = S.rs_vert[(size_t)vid[k] * 2];
-        f3 x = mulright(Q.mv, sub3(mk3(pv.x, pv.y, pv.z), light));
-        x.x = (float)(SM / 2) + (float)(SM * 2) * x.x / x.z;
-        x.y = (float)(SM / 2) + (float)(SM * 2) * x.y / x.z;
-        x.z = 1.0f / x.z;
-        f[k][0] = x.x; f[k][1] = x.y; f[k][2] = x.z;
-    }
-    if (f[0][1] < 0.f && f[1][1] < 0.f && f[2][1] < 0.f) return;
-    const float fS = (float)SM;
-    if (f[0][1] >= fS && f[1][1] >= fS && f[2][1] >= fS) return;
-    emit_rows<3>(cvtt_i32(f[0][1]), cvtt_i32(f[1][1]), cvtt_i32(f[2][1]), f[0], f[1], f[2], SM, t, rows, rows_cap, ctl);
-}
-
-__global__ void __launch_bounds__(256) k_sm_spans(const ShadowParams Q, const RowRec *rows, const uint32_t *ctl,
-                                                  uint32_t rows_cap, uint32_t *smkeys)
-{
-    uint32_t n_rows = ctl[0];
-    if (n_rows > rows_cap) n_rows = rows_cap;
-    const int SM = Q.size;
-    for (uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x; ri < n_rows; ri += gridDim.x * blockDim.x) {
-        const RowRec &R = rows[ri];
-        if (R.pad) continue;                                              // reserved by a dropped triangle, never written
-        uint32_t *row = smkeys + (size_t)R.y * SM;
-        auto plot = [&](float x, float z) {                               // PlotShadowPixel, Light.cc:253-259
-            const int idx = cvtt_i32(x);
-            if (idx >= 0 && idx < SM && z == z) atomicMax(&row[idx], f2key(z));
-        };
-        if (R.cnt == 1) { plot(R.l[0], R.l[2]); continue; }
-        const int x1 = cvtt_i32(R.l[0]), x2 = cvtt_i32(R.r[0]);
-        long long steps = llabs((long long)x2 - (long long)x1);
-        if (!steps) { plot(R.l[0], R.l[2]); plot(R.r[0], R.r[2]); continue; }
-        if (steps > (1ll << 24)) continue;                                // degenerate projection (geometry at the light plane)
-        float sx = R.l[0], sz = R.l[2];
-        const float fsteps = (float)(int)steps;
-        const float dx = (R.r[0] - sx) / fsteps, dz = (R.r[2] - sz) / fsteps;
-        plot(sx, sz);
-        while (steps-- > 0) { sx += dx; sz += dz; plot(sx, sz); }
-    }
-}
-
 // ---- round 3: the same map from (triangle, row) items instead of one lane per triangle --------------------------------
-// k_sm_setup and k_sm_spans give a lane a whole triangle (all its rows, one after the other) and a whole row (all its pixels):
+// Round 1's kernels (removed in round 4) gave a lane a whole triangle (all its rows, one after the other) and a whole row (all its pixels):
 // a mesh's few large triangles and long rows keep single lanes busy for hundreds of dependent steps while the GPU idles
 // (0.25 + 0.21 ms per light).  Here every row of every triangle is an item of its own: k_sm_count reserves the rows of a block's
 // triangles in one allocation and names each row's owner; k_sm_rows recomputes the owner's projected corners, brings the three
@@ -1233,9 +1133,8 @@ extern "C" hipError_t mi355i_launch_shadowmap(const DevScene *S, const float *li
     memcpy(Q.light, light_pos, 12);
     memcpy(Q.mv, w2l, 36);
     Q.size = size;
-    static const bool legacy = [] { const char *v = getenv("MI355_SM_LEGACY"); return v && *v && strcmp(v, "0"); }();     // the round-1 kernels, for comparison
     static const bool row_items = [] { const char *v = getenv("MI355_SM_ROWS"); return v && *v && strcmp(v, "0"); }();    // the round-3 kernels, for comparison
-    if (!legacy && !row_items && size <= SMT_BANDS * SMT_H) {
+    if (!row_items && size <= SMT_BANDS * SMT_H) {
         // round 4: tiles with their keys in LDS (k_sm_prep, k_sm_tiles).  The row buffer holds the triangles' corners and boxes, the
         // table [block of 256 triangles][list] and, behind them, the blocks' band lists.
         const int per_block = 256;
@@ -1270,12 +1169,8 @@ extern "C" hipError_t mi355i_launch_shadowmap(const DevScene *S, const float *li
     s->ctl_pair = 0;
     // Light::ClearShadowBuffer: bytes 0xFE (Light.h:48-52) -> key of the float 0xFEFEFEFE
     hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, st, s->smkeys, ~0xFEFEFEFEu, n);
-    if (legacy) {     // the round-1 kernels: a lane per triangle, then a lane per row (kept for comparison)
-        const int nbT = (int)((S->n_tris + 127) / 128);
-        hipLaunchKernelGGL(k_sm_setup, dim3(nbT > 0 ? nbT : 1), dim3(128), 0, st, *S, Q, s->rows, s->rows_cap, s->ctl);
-        hipLaunchKernelGGL(k_sm_spans, dim3(2048), dim3(256), 0, st, Q, s->rows, s->ctl, s->rows_cap, s->smkeys);
-    } else {
-        // (the row buffer is the same allocation: 8-byte items in place of 40-byte records, five times as many fit)
+    {
+        // (the row buffer is one allocation for every generation of these kernels: 8-byte items here)
         const uint32_t items_cap = (uint32_t)(((size_t)s->rows_cap * sizeof(RowRec)) / sizeof(uint2) > 0xfffffff0ull ? 0xfffffff0ull : ((size_t)s->rows_cap * sizeof(RowRec)) / sizeof(uint2));
         const int nbT = (int)((S->n_tris + 255) / 256);
         hipLaunchKernelGGL(k_sm_count, dim3(nbT > 0 ? nbT : 1), dim3(256), 0, st, *S, Q, (uint2 *)s->rows, items_cap, s->ctl);
