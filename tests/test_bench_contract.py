@@ -63,3 +63,33 @@ def test_the_dry_run_line_of_the_multi_gpu_path(name, n):
     assert mg["rank0"]["ingest_bytes_per_step"] == (n - 1) * rows_max * 3840 * 4 * 8
     assert mg["spread"]["ingest_bytes_per_step"] == (n - 1) * (8 // n) * rows_max * 3840 * 4
     assert abs(r["ms_per_step"] - mg["rank0"]["ms_per_step"]) < 1e-3
+
+
+def test_the_committed_single_gpu_line_keeps_the_measurement_contract():
+    """profiles/r04_bench_n1.jsonl (the round's evidence run) has what the contract asks of the N = 1 line: BASELINE.json's metric and
+    unit on the configuration it is quoted on, a whole-job value that recomputes from the frames and the time, the roofline object with
+    a fraction that does not exceed 1 and the kernel time it was measured on, measured traffic, and the CPU baseline from the
+    reference's own code with its core count and its sample."""
+    path = os.path.join(ROOT, "profiles", "r04_bench_n1.jsonl")
+    d = json.loads([l for l in open(path) if l.startswith("{")][-1])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["unit"] == "Mrays/s" and d["metric"].lower().startswith("mrays") and "mrays" in json.dumps(base).lower()
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert "dragon_vis.ply" in d["config"]["workload"] and "1920x1080" in d["config"]["workload"] and "model" not in d["config"]
+    frames = d["config"]["frames"]
+    assert frames == d["steps"] * d["config"]["frames_per_step"]
+    recomputed = d["config"]["rays_per_frame"] * frames / (d["ms_per_step"] * 1e-3 * d["steps"]) / 1e6
+    assert abs(recomputed - d["value"]) / d["value"] < 0.01
+    assert d["config"]["traced_rays_per_frame"] < d["config"]["rays_per_frame"]
+    r = d["roofline"]
+    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["kernel_ms"] > 0 and r["traffic"] and r["traffic"] > 0
+    assert 0.0 < r["timed_schedule"]["frac"] <= 1.0
+    assert 0.0 < r["hbm"]["measured_frac"] < 1.0
+    assert "this run" in r["counters"]["source"]                    # counters collected inside the run, not a stale file
+    c = d["cpu_baseline"]
+    assert c["kind"] == "reference" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and "refcore_omp" in c["sample"]
+    assert d["cpu_baseline_port"]["kind"] == "port"
+    rows = d["other_workloads"]["render_cli_bench"]["rows"]
+    assert len(rows) == 5 and all(x["fps_3_in_flight"] and x["fps_reference_loop"] for x in rows)
+    assert set(d["other_workloads"]["shadowmap_1024_us"]) == {"chessboard.tri", "dragon_vis.ply"}
