@@ -431,6 +431,7 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
         if (o->band_count > 1) return fail(-20, "mlaa works on whole frames: no band sharding (mi355_mgpu_render filters the assembled frame)");
         if ((P.pitch_words & 3) || (o->height & 7) || P.pitch_words < 8 || o->height < 8)
             return fail(-20, "mlaa: pitch / 4 = %d must be a multiple of 4 and the height %d of 8 (MLAA.cc:395-396)", P.pitch_words, o->height);
+        if (P.pitch_words > 16384) return fail(-20, "mlaa: surfaces up to 16384 words wide (pitch / 4 = %d)", P.pitch_words);
     }
     P.exact_box = (flags & 1) ? 1 : 0;
     if (!c->boxes_tame) P.exact_box = 1;     // box coordinates outside the filtered test's validated range
@@ -1207,10 +1208,11 @@ void mi355_scene_destroy(mi355_ctx *c)
                       &c->rs_vert, &c->ctrl, &c->fb, &c->fbf, &c->mlaa, &c->cam_table, &c->wave_prof, &c->bvh_prim, &c->bvh_list[0], &c->bvh_list[1],
                       &c->bvh_lvl[0], &c->bvh_lvl[1], &c->bvh_tree, &c->bvh_cnt, &c->bvh_big[0], &c->bvh_big[1], &c->bvh_task[0], &c->bvh_task[1],
                       &c->bvh_gthr[0], &c->bvh_gthr[1], &c->bvh_gbin, &c->bvh_tcnt, &c->bvh_choff, &c->bvh_num[0], &c->bvh_num[1], &c->bvh_num[2],
-                      &c->bvh_num[3], &c->bvh_num[4], &c->bvh_out, &c->bvh_in_td, &c->bvh_in_te, &c->cull_boxes, &c->tile_sel, &c->pipe_fb[0], &c->pipe_fb[1], &c->pipe_fb[2], &c->pipe_fb[3], &c->pipe_fb[4], &c->pipe_fb[5], &c->pipe_fb[6], &c->pipe_fb[7], &c->pipe_ctrl[0], &c->pipe_ctrl[1], &c->pipe_ctrl[2], &c->pipe_ctrl[3],
-                      &c->pipe_sel[0], &c->pipe_sel[1], &c->pipe_sel[2], &c->pipe_sel[3],
-                      &c->pipe_cam[0], &c->pipe_cam[1], &c->pipe_cam[2], &c->pipe_cam[3]})
+                      &c->bvh_num[3], &c->bvh_num[4], &c->bvh_out, &c->bvh_in_td, &c->bvh_in_te, &c->cull_boxes, &c->tile_sel})
         b->release();
+    // (every resource set of the frame streams, however many PIPE_SETS there are)
+    for (DevBuf &b : c->pipe_fb) b.release();
+    for (int k = 0; k < mi355_ctx::PIPE_SETS; k++) { c->pipe_ctrl[k].release(); c->pipe_sel[k].release(); c->pipe_cam[k].release(); }
     for (PinBuf *b : {&c->pin_walk, &c->pin_edge, &c->pin_shade, &c->pin_tree, &c->pin_list, &c->pin_ctl, &c->pin_counters}) b->release();
     for (auto &m : c->smap) m.release();
     for (auto &o : c->orders) o.buf.release();
@@ -1587,6 +1589,8 @@ int mi355_mlaa_device(mi355_ctx *c, void *d_xrgb, int pitch_bytes, int height, v
     const int pw = pitch_bytes / 4;
     if (pitch_bytes <= 0 || (pitch_bytes & 3) || (pw & 3) || (height & 7) || pw < 8 || height < 8)
         return fail(-20, "mlaa: pitch / 4 = %d must be a multiple of 4 and the height %d of 8 (MLAA.cc:395-396)", pw, height);
+    // (k_mlaa_scan keeps the line starts of a row -- or, in its vertical pass, of a column -- in an LDS list sized for 16384 pixels)
+    if (pw > 16384 || height > 16384) return fail(-20, "mlaa: surfaces up to 16384 x 16384 words (got %d x %d)", pw, height);
     if (int r = select_device(c)) return r;
     HIP_TRY(c->mlaa.ensure((size_t)pw * height * 4), -31);
     const hipError_t e = mi355i_launch_mlaa((uint32_t *)d_xrgb, (uint32_t *)c->mlaa.p, pw, height, (hipStream_t)hip_stream);

@@ -296,6 +296,7 @@ __global__ void __launch_bounds__(256) k_mlaa_scan(uint32_t *fbi, const uint32_t
 // MLAA(pixels, NULL, width, height) on a dense frame (pitch = width); scratch: width * height words
 extern "C" hipError_t mi355i_launch_mlaa(uint32_t *d_pixels, uint32_t *d_scratch, int resX, int resY, hipStream_t st)
 {
+    if (resX > 2 * ML_LIST || resY > 2 * ML_LIST) return hipErrorInvalidValue;     // a row's line starts must fit k_mlaa_scan's list
     hipLaunchKernelGGL(k_mlaa_flags, dim3(2048), dim3(256), 0, st, d_pixels, d_scratch, resX, resY);
     for (int vertical = 0; vertical < 2; vertical++) {
         const int res = vertical ? resX : resY;

@@ -43,6 +43,9 @@ def test_mlaa_on_noise_and_patterns(oracle):
         assert np.array_equal(mlaa_device(s, img), oracle.mlaa(img)), "case %d (%dx%d)" % (it, W, H)
     f = R.lib().mi355_mlaa_device
     assert f(s.context(), C.c_void_p(16), 10 * 4, 16, None) == -20        # width not a multiple of four
+    # a surface wider or taller than the 16384 pixels the scan's LDS list of line starts is sized for: refused, not written
+    assert f(s.context(), C.c_void_p(16), 16388 * 4, 16, None) == -20
+    assert f(s.context(), C.c_void_p(16), 16 * 4, 16392, None) == -20
 
 
 @pytest.mark.parametrize("mode,mesh,W,H", [(6, "chessboard.tri", 1920, 1080), (8, "chessboard.tri", 800, 600), (9, "dragon_vis.ply", 800, 600),
