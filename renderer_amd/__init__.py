@@ -190,10 +190,10 @@ import atexit as _atexit  # noqa: E402
 _atexit.register(_mark_exit)
 
 
-def tune(xmin=0, rmin=0, chunk=0, lmin=0, bpc=0, exact=0, rowmajor=0, scatter=0, reforder=0, profordered=0, nohelp=0, nocull=0, nopipe=0, pipeordered=0, quad=0, noshare=0, sharemin=0, rssplit=0):
+def tune(xmin=0, rmin=0, chunk=0, lmin=0, bpc=0, exact=0, rowmajor=0, scatter=0, reforder=0, profordered=0, nohelp=0, nocull=0, nopipe=0, pipeordered=0, noshare=0, sharemin=0, rssplit=0):
     """mi355_opts::tune as a list (see include/mi355_render.h); every knob leaves the pixels unchanged.
     (lmin, scatter and nohelp are accepted for old scripts and ignored.)"""
-    flags = (1 if exact else 0) | (2 if rowmajor else 0) | (4 if reforder else 0) | (8 if profordered else 0) | (16 if nocull else 0) | (32 if nopipe else 0) | (64 if pipeordered else 0) | (128 if quad else 0) | (256 if noshare else 0)
+    flags = (1 if exact else 0) | (2 if rowmajor else 0) | (4 if reforder else 0) | (8 if profordered else 0) | (16 if nocull else 0) | (32 if nopipe else 0) | (64 if pipeordered else 0) | (256 if noshare else 0)
     return [xmin, rmin, chunk, 0, bpc, flags, sharemin, rssplit]
 
 
@@ -387,7 +387,7 @@ class Scene:
         sc = np.zeros(32, np.uint32)
         _check(f(self.context(), 0, sc.ctypes.data, sc.nbytes), "mi355i_fetch_traversal")
         tri_base, T = int(sc[17]), self.nt
-        n4 = int(sc[23]) + 8 * (tri_base // 2)          # walk + triangle blocks + wide records + (from quad_base) quad records
+        n4 = tri_base + 2 * T + 4 * (tri_base // 2)     # walk records (2 float4 per inner node) + triangle blocks (2 per triangle) + wide records (4 per inner node)
         out = [sc]
         for which, n in ((1, n4 * 4), (2, T * 12), (3, T * 20)):
             a = np.zeros(n, np.uint32)

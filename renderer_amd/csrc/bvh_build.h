@@ -36,9 +36,6 @@ struct BvCtl {
     uint32_t tame, bounded; float mag;
     uint32_t root_link;
     float4 root_a, root_b, vroot_a, vroot_b;
-    float4 qvroot_a, qvroot_b;                    // slot 0 of the virtual quad record above the root (dev_scene.h)
-    uint32_t quad_base, qunion;                   // qunion: every inner box is the exact union of its children's
-    uint32_t pad_q[2];
     uint32_t rkey[6], rzero[6];                   // root box: ordered keys of min / max, triangle index of the first zero
 };
 

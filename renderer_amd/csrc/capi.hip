@@ -24,9 +24,10 @@
 // kernel launchers (defined next to their kernels)
 extern "C" hipError_t mi355i_launch_tile_select(const FrameParams *P, const float4 *boxes, int n_boxes, const uint32_t *order, uint32_t *sel, uint32_t *cnt,
                                                 uint32_t *gmask, hipStream_t st);
-extern "C" int mi355i_raytrace_waves_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext, int quad);
+extern "C" int mi355i_raytrace_waves_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext);
+extern "C" void mi355i_raytrace_variant(int stats, int *exact, int *ordered, int *waves, int ext);
 extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int ordered, int waves, int batch, int ext,
-                                             int quad, int stack_depth, int n_blocks, hipStream_t);
+                                             int stack_depth, int n_blocks, hipStream_t);
 extern "C" hipError_t mi355i_launch_points(const DevScene *, const FrameParams *, int as_triangles, hipStream_t);
 extern "C" hipError_t mi355i_launch_mlaa(uint32_t *d_pixels, uint32_t *d_scratch, int resX, int resY, hipStream_t st);
 struct RasterScratch;
@@ -408,7 +409,6 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.prof_ordered = (flags & 8) ? 1 : 0;
     P.no_cull = (flags & 16) ? 1 : 0;
     P.no_pipe = (flags & 32) ? 1 : (flags & 64) ? 2 : 0;
-    P.quad = (flags & 128) ? 1 : 0;
     // work sharing inside a wave (k_raytrace.hip): on by default with 16 idle lanes as the threshold; tune[6] sets the threshold,
     // flag 256 turns it off; it needs the wave in lockstep (xmin 64)
     P.steal_min = ((flags & 256) || P.xmin < 64) ? 0 : (t[6] > 0 ? (t[6] > 64 ? 64 : t[6]) : 16);
@@ -449,15 +449,12 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
 // Thread the reference's flat BVH (pre-order CacheFriendlyBVHNode[], BVH.h:52-65) with hit/miss
 // links and build the leaf-ordered triangle streams.
 int upload_cull_boxes(mi355_ctx *c, const void *nodes32B, uint32_t nN);
-// Stack rows of the four-wide walk for a tree with `inner_levels` levels of inner nodes: a step postpones up to three slots
-// and descends two levels (a leaf child's slot is a leaf: nothing is postponed below it), plus one row of slack.
-uint32_t quad_stack_rows(uint32_t inner_levels) { return 3u * ((inner_levels + 1u) / 2u) + 1u; }
 // a tree is being replaced: frames of the device entry points run on internal streams and may still read the old streams, and a
 // failed build must not leave the context describing a tree whose buffers are half written
 int begin_tree_update(mi355_ctx *c)
 {
     HIP_TRY(hipDeviceSynchronize(), -40);
-    c->has_bvh = false; c->n_cull_boxes = 0; c->dev.ordered_ok = 0u; c->dev.quad_ok = 0u;
+    c->has_bvh = false; c->n_cull_boxes = 0; c->dev.ordered_ok = 0u;
     return 0;
 }
 int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int32_t *triIdx, uint32_t nI)
@@ -505,14 +502,13 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
         return tri_link(((size_t)off[i] - tri_base) / 2, true);
     };
     const size_t wide_base = n4;                      // wide records of the ordered walk: 4 float4 per inner node
-    const size_t quad_base = (n4 + 4 * n_inner + 7) & ~(size_t)7;     // quad records of the four-wide walk: 8 float4 per inner node
-    const size_t n4_all = quad_base + 8 * n_inner;
+    const size_t n4_all = n4 + 4 * n_inner;
     if (n4_all + 8 >= (size_t)MI_VROOT_LINK) return fail(-30, "BVH too large");
     HIP_TRY(c->pin_walk.ensure((n4_all + 4) * sizeof(float4)), -31);
     float4 *walk = (float4 *)c->pin_walk.p;
     memset(walk, 0, (n4_all + 4) * sizeof(float4));
     std::vector<uint32_t> order; order.reserve(nN);   // the reference's visiting order
-    bool list_in_visit_order = true, exact_unions = true;
+    bool list_in_visit_order = true;
     uint32_t list_end = 0;
     int inner_levels = 0;
     std::vector<uint8_t> visited(nN, 0);
@@ -544,29 +540,6 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
             w[1] = make_float4(ca.bottom[2], ca.top[2], u2f(wlink(n.a)), u2f(wlink(n.b)));
             w[2] = make_float4(cb.bottom[0], cb.top[0], cb.bottom[1], cb.top[1]);
             w[3] = make_float4(cb.bottom[2], cb.top[2], 0.f, 0.f);
-            // quad record (dev_scene.h): a leaf child is a slot; an inner child contributes its two children, own boxes
-            float4 *q = &walk[quad_base + 4 * (size_t)off[it.node]];
-            for (int k = 0; k < 2; k++) {
-                const uint32_t x = k ? n.b : n.a;
-                if (is_leaf(x)) {
-                    q[4 * k] = make_float4(rn[x].bottom[0], rn[x].top[0], rn[x].bottom[1], rn[x].top[1]);
-                    q[4 * k + 1] = make_float4(rn[x].bottom[2], rn[x].top[2], u2f(link(x)), 0.f);
-                    q[4 * k + 3] = make_float4(0.f, 0.f, u2f(MI_END_LINK), 0.f);
-                } else {
-                    if (rn[x].a >= nN || rn[x].b >= nN) return fail(-30, "BVH child index out of range at node %u", x);
-                    for (int g = 0; g < 2; g++) {
-                        const uint32_t y = g ? rn[x].b : rn[x].a;
-                        const uint32_t l = is_leaf(y) ? link(y) : (uint32_t)(quad_base + 4 * (size_t)off[y]);
-                        q[4 * k + 2 * g] = make_float4(rn[y].bottom[0], rn[y].top[0], rn[y].bottom[1], rn[y].top[1]);
-                        q[4 * k + 2 * g + 1] = make_float4(rn[y].bottom[2], rn[y].top[2], u2f(l), 0.f);
-                    }
-                }
-            }
-            // the four-wide walk derives a child's box from its children's: the node's box must be their exact union
-            for (int k = 0; k < 3; k++) {
-                const float lo = ca.bottom[k] < cb.bottom[k] ? ca.bottom[k] : cb.bottom[k], hi = ca.top[k] > cb.top[k] ? ca.top[k] : cb.top[k];
-                if (!(lo == n.bottom[k] && hi == n.top[k])) exact_unions = false;
-            }
         } else {
             const uint32_t cnt = n.a & 0x7fffffffu, first = n.b;
             if (cnt) { if (first < list_end) list_in_visit_order = false; list_end = first + cnt; }
@@ -632,9 +605,6 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
     c->dev.ordered_ok = (tame && bounded && list_in_visit_order && inner_levels + 1 <= MI_MAX_STACK) ? 1u : 0u;
     c->dev.stack_depth = (uint32_t)(inner_levels + 1);
     c->dev.scene_mag = mag;
-    c->dev.qstack_depth = quad_stack_rows((uint32_t)inner_levels);
-    c->dev.quad_ok = (c->dev.ordered_ok && exact_unions && c->dev.qstack_depth <= (uint32_t)MI_MAX_QSTACK) ? 1u : 0u;
-    c->dev.quad_base = (uint32_t)quad_base;
 
     const uint32_t T = c->nT;
     // (+ zeroed edge records behind the dummy blocks of empty leaves: a NaN ray can pass their plane test)
@@ -682,8 +652,6 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
         const uint32_t wroot = is_leaf(0) ? link(0) : (uint32_t)(wide_base + 2 * (size_t)off[0]);
         c->dev.vroot_a = make_float4(rn[0].bottom[0], rn[0].top[0], rn[0].bottom[1], rn[0].top[1]);
         c->dev.vroot_b = make_float4(rn[0].bottom[2], rn[0].top[2], u2f(wroot), u2f(MI_END_LINK));
-        c->dev.qvroot_a = c->dev.vroot_a;
-        c->dev.qvroot_b = make_float4(rn[0].bottom[2], rn[0].top[2], u2f(is_leaf(0) ? link(0) : (uint32_t)quad_base), 0.f);
     }
     c->dev.n_nodes = nN;
     c->has_bvh = true;
@@ -982,23 +950,23 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
     }
     case MI355_MODE_RAYTRACE: case MI355_MODE_RAYTRACE_ANTIALIAS: {
         if (!c->has_bvh) return fail(-41, "raytrace modes need mi355_scene_set_bvh first");
-        const int ordered = ((!stats || P.prof_ordered) && !P.ref_order && c->dev.ordered_ok) ? 1 : 0;
+        int ordered = ((!stats || P.prof_ordered) && !P.ref_order && c->dev.ordered_ok) ? 1 : 0;
         // More waves per SIMD pay when the launch is long enough to be throughput bound (batches, 4K, 4 spp: three waves
         // +10-18 %, four another +6 %); a single 1080p frame is bound by its slowest tiles and runs fastest with two
         // (measured, profiles/).  A build is only used if that many blocks of it fit a CU (registers, LDS stack).
         const int batch = (P.n_frames > 1 && P.cams) ? 1 : 0;
         const int ext = (P.use_refr || P.ao) ? 1 : 0;         // the build with refractions and ray-cast ambient occlusion
+        // (the request mapped onto a build that exists -- k_raytrace.hip: pick_kernel; fallbacks and measuring builds come with two
+        //  waves per SIMD only)
+        int waves = 2;
+        mi355i_raytrace_variant(stats, &P.exact_box, &ordered, &waves, ext);
         if (ext && (stats || batch)) return fail(-41, "refractions / ray-cast ambient occlusion: single frames without collect_stats only");
         if (batch && !(ordered && !stats)) return fail(-41, "batched frames need the ordered walk (checked tree, no collect_stats, no reference-order flag)");
         const long long work_tiles = (((long long)P.W + 7) / 8) * (((long long)P.n_rows + 7) / 8) * (P.aa ? 4 : 1) * P.n_frames;
-        // the four-wide walk (dev_scene.h) on request (tune flag 128) where the tree allows it: it visits 0.57 of the inner records
-        // but a step costs 635 instructions against 377 (scripts/isa_loop_stats.py), and the kernel is bound by instruction issue
-        const int quad = (ordered && !ext && c->dev.quad_ok && P.quad) ? 1 : 0;
         // (LDS rows the launch asks for: three colour rows per depth level, the tree's stack rows for the ordered walk, and a 4 spp
         //  frame's three rows of pixel sums behind the kernel's own)
-        const int stack_rows = 3 * P.max_depth + (ordered ? (quad ? (int)c->dev.qstack_depth : (int)c->dev.stack_depth) + (P.aa ? 3 : 0) : 0);
-        int waves = 2;
-        if (ordered && !stats && !ext) {
+        const int stack_rows = 3 * P.max_depth + (ordered ? (int)c->dev.stack_depth + (P.aa ? 3 : 0) : 0);
+        if (ordered && !stats && !ext && !P.exact_box) {
             for (int w = 4; w >= 3; w--) {
                 // (round 3, with work shared inside the waves: a single 1080p frame is 3 % faster on the three-wave build than on
                 //  the two-wave one -- 0.649 against 0.668 ms -- so the bar for three waves is half of what it is for four)
@@ -1006,10 +974,10 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
                 // (a block is one wave, so LDS bounds the waves of a CU one by one: a build is worth its registers while it holds at
                 //  least two more waves per CU than the next smaller build would -- a tree two levels too deep for 16 waves of the
                 //  four-wave build still runs 15 of them, not 12)
-                if (wanted && mi355i_raytrace_waves_per_cu(0, P.exact_box, 1, w, batch, stack_rows, 0, quad) >= 4 * (w - 1) + 2) { waves = w; break; }
+                if (wanted && mi355i_raytrace_waves_per_cu(0, 0, 1, w, batch, stack_rows, 0) >= 4 * (w - 1) + 2) { waves = w; break; }
             }
         }
-        int per_cu = mi355i_raytrace_waves_per_cu(stats, P.exact_box, ordered, waves, batch, stack_rows, ext, quad);      // waves
+        int per_cu = mi355i_raytrace_waves_per_cu(stats, P.exact_box, ordered, waves, batch, stack_rows, ext);      // waves
         if (per_cu > 4 * waves) per_cu = 4 * waves;
         if (P.blocks_per_cu > 0 && 4 * P.blocks_per_cu < per_cu) per_cu = 4 * P.blocks_per_cu;
         int n_blocks = per_cu * c->n_cus;                   // waves of the launch (mi355i_launch_raytrace: one per block)
@@ -1039,7 +1007,7 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
                 P.tile_cnt = nullptr; P.tile_sel = nullptr; P.tile_mask = nullptr;
             }
         }
-        e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, waves, batch, ext, quad, stack_rows, n_blocks, st);
+        e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, waves, batch, ext, stack_rows, n_blocks, st);
         break;
     }
     case MI355_MODE_LINES:
@@ -1286,7 +1254,7 @@ int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_
     for (int i = 0; i < 5; i++) HIP_TRY(c->bvh_num[i].ensure(max_tree * 4), -31);
     HIP_TRY(c->bvh_out.ensure(max_tree * 32), -31);
     // the finished streams go straight into the buffers the kernels read (dev_scene.h)
-    const size_t walk_bytes = ((size_t)9 * T + 32) * sizeof(float4);      // (2 + 4 + 8 float4 per inner node, 2 per triangle)
+    const size_t walk_bytes = ((size_t)8 * T + 32) * sizeof(float4);      // (2 + 4 float4 per inner node -- fewer than T of them --, 2 per triangle)
     HIP_TRY(c->walk.ensure(walk_bytes), -31);
     HIP_TRY(c->tri_edge.ensure((size_t)T * 3 * sizeof(float4) + 16), -31);
     HIP_TRY(c->tri_shade.ensure((size_t)T * 5 * sizeof(float4) + 16), -31);
@@ -1360,10 +1328,6 @@ int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_
     c->dev.ordered_ok = (ctl->tame && ctl->bounded && ctl->inner_levels + 1u <= (uint32_t)MI_MAX_STACK) ? 1u : 0u;
     c->dev.stack_depth = ctl->inner_levels + 1u;
     c->dev.scene_mag = ctl->mag;
-    c->dev.qstack_depth = quad_stack_rows(ctl->inner_levels);
-    c->dev.quad_ok = (c->dev.ordered_ok && ctl->qunion && c->dev.qstack_depth <= (uint32_t)MI_MAX_QSTACK) ? 1u : 0u;
-    c->dev.quad_base = ctl->quad_base;
-    c->dev.qvroot_a = ctl->qvroot_a; c->dev.qvroot_b = ctl->qvroot_b;
     c->dev.walk = (const float4 *)c->walk.p;
     c->dev.tri_edge = (const float4 *)c->tri_edge.p;
     c->dev.tri_shade = (const float4 *)c->tri_shade.p;
@@ -1753,7 +1717,6 @@ int mi355i_fetch_traversal(mi355_ctx *c, int which, void *out, size_t bytes)
         memcpy(w, &c->dev.root_a, 16); memcpy(w + 4, &c->dev.root_b, 16); memcpy(w + 8, &c->dev.vroot_a, 16); memcpy(w + 12, &c->dev.vroot_b, 16);
         w[16] = c->dev.root_link; w[17] = c->dev.tri_base; w[18] = c->dev.ordered_ok; w[19] = c->dev.stack_depth;
         memcpy(w + 20, &c->dev.scene_mag, 4); w[21] = c->dev.n_nodes; w[22] = c->boxes_tame ? 1u : 0u;
-        w[23] = c->dev.quad_base; w[24] = c->dev.quad_ok; w[25] = c->dev.qstack_depth; memcpy(w + 26, &c->dev.qvroot_b, 16);
         memcpy(out, w, bytes < sizeof w ? bytes : sizeof w);
         return 0;
     }

@@ -27,8 +27,6 @@
 #define MI_INDEX_MASK 0x1fffffffu   // float4 index of the target record
 #define MI_VROOT_LINK 0x1ffffff0u   // L.cur of a lane sitting on the virtual record above the root (ordered walk)
 #define MI_MAX_STACK 48             // deepest tree the ordered walk accepts (LDS: 1 KB per level per block)
-#define MI_MAX_QSTACK 64            // most stack rows the four-wide walk is launched with (worst case 3 per two tree levels)
-#define MI_QROOT_LINK 0x1ffffff8u   // L.cur of a lane sitting on the virtual four-wide record above the root
 
 // The pixel dispenser is split into one counter per XCD-sized share of the tile order (tile slot s belongs
 // to counter s % MI_DISPENSERS): a single device-wide atomic counter serialises at ~8-10 ns per grab, which
@@ -60,21 +58,6 @@
 // with links to wide records or (MI_LEAF_BIT) to the triangle blocks above.  A walk starts at a virtual
 // record in the kernel arguments whose only child is the root (link R = MI_END_LINK = no child).
 // The wide records are only used when the tree passed the checks of capi.hip (ordered_ok).
-//
-// Four-wide traversal (k_raytrace<.., QUAD>) reads "quad" records from the same buffer, eight float4 = 128 bytes = one
-// cache line per inner node, at quad_base + 8 * (rank of the inner node in array order); quad_base is a multiple of 8.
-// A record holds four SLOTS of two float4 each, slots 0, 1 for the left child's side and 2, 3 for the right child's:
-//   slot          : (min.x, max.x, min.y, max.y) (min.z, max.z, link, 0)          link == MI_END_LINK: empty slot
-//   a LEAF child  : one slot (the side's first), its own box, link to its first triangle block; the side's second slot is empty
-//   an INNER child: its two children (the node's grandchildren), each with its OWN box and a link to its quad record
-//                   or, a leaf, to its first triangle block
-// What the reference does at a node it has entered (Raytracer.cc:217-230) in terms of slots: a leaf child's triangles are
-// tested; an inner child's children are visited iff the child's box passes RayIntersectsBox, and then an inner
-// grandchild's children are visited iff ITS box passes, a leaf grandchild's triangles are tested.  A node's box is the exact
-// union of its children's (checked: quad_ok) and RayIntersectsBox is monotone in the box, so "the grandchild's box passes"
-// implies "the child's box passes": an inner grandchild is entered iff its own box passes; a leaf grandchild is entered iff
-// the child's box -- the union of the side's two slot boxes -- passes (and, like every leaf, only if the ray does not
-// surely miss its own grown box).  The walk starts at a virtual record whose only slot is the root.
 struct DevScene {
     const float4 *walk;
     const float4 *tri_edge;
@@ -86,11 +69,6 @@ struct DevScene {
     uint32_t ordered_ok;      // boxes bound their subtrees, list order = visiting order, depth fits the LDS stack
     uint32_t stack_depth;     // entries of the per-lane stack the ordered walk needs
     float scene_mag;          // largest |coordinate| of any box
-    // four-wide walk
-    float4 qvroot_a, qvroot_b; // slot 0 of the virtual quad record above the root (the other slots are empty)
-    uint32_t quad_base;       // float4 index of the quad record of inner node 0
-    uint32_t quad_ok;         // ordered_ok, every inner box is the exact union of its children's, the stack fits
-    uint32_t qstack_depth;    // entries of the per-lane stack the four-wide walk needs (3 per step in the worst case)
     uint32_t n_nodes;
     uint32_t n_tris;
     uint32_t n_verts;
@@ -143,7 +121,6 @@ struct FrameParams {
     int32_t prof_ordered;      // counting frames profile the ordered walk instead of reproducing the reference's counters
     int32_t no_cull;           // hand out every tile of the frame (tune flag 16)
     int32_t no_pipe;           // raster frames: setup, fill and tile kernels on the caller's stream (tune flag 32)
-    int32_t quad;              // raytrace: walk the four-wide records where the tree has them (tune flag 128)
     int32_t steal_min;         // raytrace: lanes without a ray take parts of other lanes' shadow rays once this many are idle (0: off)
     unsigned long long *wave_prof; // counting builds: 16 words of phase profile per wave (debug), or NULL
     const FrameCam *cams;      // batched launch: per-frame cameras / lights / outputs (device memory), else NULL

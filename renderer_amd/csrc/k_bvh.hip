@@ -57,7 +57,7 @@ k_bvh_init(BvWork W, size_t n_bin_words)
     if (i0 == 0) {
         BvCtl &c = *W.ctl;
         for (int k = 0; k < BV_MAX_LEVELS + 2; k++) c.n_level[k] = c.n_big[k] = c.n_task[k] = 0u;
-        c.n_tree = 0u; c.bad = 0u; c.levels = 0u; c.n_inner = c.n_nodes = c.inner_levels = 0u; c.tame = 1u; c.mag = 0.f; c.qunion = 1u; c.quad_base = 0u;
+        c.n_tree = 0u; c.bad = 0u; c.levels = 0u; c.n_inner = c.n_nodes = c.inner_levels = 0u; c.tame = 1u; c.mag = 0.f;
         for (int k = 0; k < 6; k++) { c.rkey[k] = k < 3 ? BV_KEY_HI : BV_KEY_LO; c.rzero[k] = 0xffffffffu; }
     }
     // bins: per (node, axis) 7 rows of max_planes + 1 words: counts, min x y z, max x y z
@@ -935,7 +935,6 @@ k_bvh_emit_nodes(const BvWork W)
     if (c.levels == 0u) return;
     const uint32_t n_tree = c.n_tree, tri_base = 2u * c.n_inner;
     const uint32_t wide_base = tri_base + 2u * W.T;
-    const uint32_t quad_base = (wide_base + 4u * c.n_inner + 7u) & ~7u;
     struct RefNode { float bb[6]; uint32_t a, b; };
     RefNode *out = (RefNode *)W.out_nodes;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_tree; i += gridDim.x * 256u) {
@@ -959,31 +958,6 @@ k_bvh_emit_nodes(const BvWork W)
             w[1] = make_float4(ca.bb[2], ca.bb[5], __uint_as_float(wl), __uint_as_float(wr));
             w[2] = make_float4(cb.bb[0], cb.bb[3], cb.bb[1], cb.bb[4]);
             w[3] = make_float4(cb.bb[2], cb.bb[5], 0.f, 0.f);
-            // quad record (dev_scene.h): a leaf child is a slot; an inner child contributes its two children, own boxes
-            float4 *q = W.walk + quad_base + 8u * W.irank[i];
-            for (int k = 0; k < 2; k++) {
-                const BvTreeNode &cx = k ? cb : ca;
-                const uint32_t x = k ? n.b : n.a;
-                if (cx.a & 0x80000000u) {
-                    q[4 * k] = make_float4(cx.bb[0], cx.bb[3], cx.bb[1], cx.bb[4]);
-                    q[4 * k + 1] = make_float4(cx.bb[2], cx.bb[5], __uint_as_float(bv_link(W, tri_base, x)), 0.f);
-                    q[4 * k + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    q[4 * k + 3] = make_float4(0.f, 0.f, __uint_as_float(MI_END_LINK), 0.f);
-                } else {
-                    for (int g = 0; g < 2; g++) {
-                        const uint32_t y = g ? cx.b : cx.a;
-                        const BvTreeNode gn = W.tree[y];
-                        const uint32_t l = (gn.a & 0x80000000u) ? bv_link(W, tri_base, y) : quad_base + 8u * W.irank[y];
-                        q[4 * k + 2 * g] = make_float4(gn.bb[0], gn.bb[3], gn.bb[1], gn.bb[4]);
-                        q[4 * k + 2 * g + 1] = make_float4(gn.bb[2], gn.bb[5], __uint_as_float(l), 0.f);
-                    }
-                }
-            }
-            // the four-wide walk derives a child's box from its children's: the node's box must be their exact union
-            for (int k = 0; k < 3; k++) {
-                const float lo = ca.bb[k] < cb.bb[k] ? ca.bb[k] : cb.bb[k], hi = ca.bb[3 + k] > cb.bb[3 + k] ? ca.bb[3 + k] : cb.bb[3 + k];
-                if (!(lo == n.bb[k] && hi == n.bb[3 + k])) W.ctl->qunion = 0u;
-            }
         } else {
             r.a = n.a; r.b = n.b;
             const uint32_t cnt = n.a & 0x7fffffffu, first = n.b;
@@ -1007,9 +981,6 @@ k_bvh_emit_nodes(const BvWork W)
         const uint32_t wroot = leaf0 ? cw.root_link : wide_base;
         cw.vroot_a = make_float4(r0.bb[0], r0.bb[3], r0.bb[1], r0.bb[4]);
         cw.vroot_b = make_float4(r0.bb[2], r0.bb[5], __uint_as_float(wroot), __uint_as_float(MI_END_LINK));
-        cw.qvroot_a = cw.vroot_a;
-        cw.qvroot_b = make_float4(r0.bb[2], r0.bb[5], __uint_as_float(leaf0 ? cw.root_link : quad_base), 0.f);
-        cw.quad_base = quad_base;
     }
 }
 

@@ -388,16 +388,10 @@ MI_DEV void rec_fetch(const DevScene &S, uint32_t link, Rec &r)
 
 // every walk starts at the root, whose record is a kernel argument
 // (ordered walk: at the virtual record above the root, both of whose boxes are the root's)
-template <bool ORDERED, bool QUAD = false>
-MI_DEV void begin_walk(const DevScene &S, Lane &L, Rec &R, Rec &R2, Rec &R3, Rec &R4)
+template <bool ORDERED>
+MI_DEV void begin_walk(const DevScene &S, Lane &L, Rec &R, Rec &R2)
 {
-    if (QUAD) {
-        // the virtual quad record above the root: slot 0 = the root, the other slots empty
-        L.cur = MI_QROOT_LINK; L.sp = 0; L.base = 0; L.top = MI_END_LINK;
-        R.a = S.qvroot_a; R.b = S.qvroot_b;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f), e = make_float4(0.f, 0.f, __uint_as_float(MI_END_LINK), 0.f);
-        R2.a = z; R2.b = e; R3.a = z; R3.b = e; R4.a = z; R4.b = e;
-    } else if (ORDERED) {
+    if (ORDERED) {
         L.cur = MI_VROOT_LINK; L.sp = 0; L.base = 0; L.top = MI_END_LINK;
         R.a = S.vroot_a; R.b = S.vroot_b; R2.a = S.vroot_a; R2.b = S.vroot_b;
     } else {
@@ -468,41 +462,6 @@ MI_DEV bool tri_edge_test(Lane &L, float scene_mag)
     return false;
 }
 
-// ---- four-wide walk: the rare exact decisions of a step (dev_scene.h; one lane's view) -----------------------------
-// need: bit i (0..3) = slot i is an inner slot whose filtered test is not sure (or the ray is not tame): RayIntersectsBox on
-// its own box; bit 4 / 5 = a leaf grandchild of the left / right side needs the verdict of its parent, whose box is the
-// union of the side's two slot boxes.  Returns the verdicts at the same bit positions.
-MI_DEV uint32_t quad_exact(const f3 o, const f3 d, uint32_t need, const Rec &R, const Rec &R2, const Rec &R3, const Rec &R4)
-{
-    uint32_t res = 0u;
-    while (need) {
-        const uint32_t b = (uint32_t)__builtin_ctz(need);
-        need &= need - 1u;
-        const bool right = b == 2u || b == 3u || b == 5u;
-        const float4 xa = right ? R3.a : R.a, xb = right ? R3.b : R.b, ya = right ? R4.a : R2.a, yb = right ? R4.b : R2.b;
-        const bool second = b == 1u || b == 3u, both = b >= 4u;
-        // own box of the side's first / second slot, or the union of the two (min of the mins, max of the maxes)
-        float4 lo = second ? make_float4(ya.x, ya.z, yb.x, 0.f) : make_float4(xa.x, xa.z, xb.x, 0.f);
-        float4 hi = second ? make_float4(ya.y, ya.w, yb.y, 0.f) : make_float4(xa.y, xa.w, xb.y, 0.f);
-        if (both) {
-            lo = make_float4(__builtin_fminf(xa.x, ya.x), __builtin_fminf(xa.z, ya.z), __builtin_fminf(xb.x, yb.x), 0.f);
-            hi = make_float4(__builtin_fmaxf(xa.y, ya.y), __builtin_fmaxf(xa.w, ya.w), __builtin_fmaxf(xb.y, yb.y), 0.f);
-        }
-        if (ray_box_exact(o, d, lo, hi)) res |= 1u << b;
-    }
-    return res;
-}
-
-// median of three (v_med3_u32)
-MI_DEV uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) { return max(min(a, b), min(max(a, b), c)); }
-
-// select one of four words by a two-bit index
-MI_DEV uint32_t pick4(uint32_t i, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
-{
-    const uint32_t x = (i & 1u) ? b : a, y = (i & 1u) ? d : c;
-    return (i & 2u) ? y : x;
-}
-
 } // namespace
 
 // WAVES = wavefronts per SIMD the register allocation aims at: 2 for the latency of a single 1080p frame (deferred edge
@@ -513,9 +472,7 @@ MI_DEV uint32_t pick4(uint32_t i, uint32_t a, uint32_t b, uint32_t c, uint32_t d
 // EXT = the build that also knows the reference's two compile-time extras (Raytracer.cc:70-80): refractions -- every
 // hit spawns a second, unculled child ray, so the chain of depth levels becomes a binary tree walked depth first with
 // the waiting refracted rays parked in LDS -- and ray-cast ambient occlusion (AMBIENT_SAMPLES shadow-type rays per hit).
-// QUAD = the four-wide walk (dev_scene.h): a step tests the four slots of a 128-byte quad record -- the node's leaf children
-// and its inner children's children -- enters the nearest, postpones the others: 0.56 of the binary walk's inner steps.
-template <bool STATS, bool EXACT_BOX, bool ORDERED, int WAVES, bool BATCH, bool EXT = false, bool QUAD = false>
+template <bool STATS, bool EXACT_BOX, bool ORDERED, int WAVES, bool BATCH, bool EXT = false>
 __global__ void __launch_bounds__(RT_BLK) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 k_raytrace(const DevScene S, const FrameParams P)
 {
@@ -530,14 +487,14 @@ k_raytrace(const DevScene S, const FrameParams P)
     // part of that walk can be done by any lane.  Lanes without a ray of their own take the oldest postponed subtree of a lane
     // that still walks a shadow ray; a blocker found by anyone is reported in the owner's word of an LDS row.  Two more rows
     // behind the stack's: the verdict words, and a per-wave table (rank among the givers -> lane).
-    constexpr bool STEAL = ORDERED && !STATS && !EXT && !QUAD;
+    constexpr bool STEAL = ORDERED && !STATS && !EXT;
     const bool steal_on = STEAL && P.steal_min > 0;
     // Rows behind the stack's.  Two rows of 64-bit RESULT words, one per thread of the block: the state of the ray that thread
     // owns, as everybody who walks a part of it sees it -- a closest-hit ray: distance^2 bits << 32 | triangle of the best hit so
     // far (atomic min: the nearest hit, the lowest triangle among equals -- the rule of the walk itself), a shadow ray: 0 once a
     // blocker has been found (the upper half; the lower half keeps the triangle the ray starts on, which the lane needs back
     // after it has walked for others); both start at FLT_MAX in the upper half.
-    unsigned long long *const result = (unsigned long long *)(lds_stack + (QUAD ? S.qstack_depth : S.stack_depth) * (uint32_t)RT_BLK);
+    unsigned long long *const result = (unsigned long long *)(lds_stack + S.stack_depth * (uint32_t)RT_BLK);
     // one row: per wave, rank among the givers of a hand-over -> lane
     uint32_t *const stab = (uint32_t *)(result + RT_BLK) + (threadIdx.x & ~63u);
     // (work sharing: the light a lane's shadow ray aims at, three rows -- whoever walks a part of that ray looks it up when a
@@ -553,15 +510,14 @@ k_raytrace(const DevScene S, const FrameParams P)
     bool exhausted = false;     // dispenser ran dry (wave-uniform)
     Rec R;                      // record of the node this lane visits next
     Rec R2;                     // ordered walk: second half of a wide record (the right child's box)
-    Rec R3, R4;                 // four-wide walk: R, R2, R3, R4 = the four slots of a quad record
     // Single frames on the three- and four-wave builds: a step at a triangle looks at TWO triangles of the leaf -- a leaf's blocks
     // lie side by side in list order, so block q + 1 arrives in R2 with block q in R, a 64-byte request like a wide record's --
     // and plane-tests them before the next record is requested (no copy of the block): 0.89 of the lockstep steps of a frame
     // (oracle cost model, kind 4).  Measured: a single frame 1-6 % shorter (chessboard 0.608 -> 0.573 ms); batches, which are bound
     // by instruction issue and not by the length of a tile's chain, 2.5 % SLOWER (38 more vector instructions per such step):
     // not in the batch builds.
-    constexpr bool PAIR = ORDERED && WAVES >= 3 && !QUAD && !STATS && !BATCH;
-    R.a = R.b = R2.a = R2.b = R3.a = R3.b = R4.a = R4.b = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr bool PAIR = ORDERED && WAVES >= 3 && !STATS && !BATCH;
+    R.a = R.b = R2.a = R2.b = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t pool_next = 0, pool_end = 0;   // wave-local pixel pool (wave-uniform): local indices of share pool_share
     uint32_t pool_share = 0;
     uint32_t share = blockIdx.x % MI_DISPENSERS;   // the share this wave draws from (consecutive blocks sit on different XCDs)
@@ -706,7 +662,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                                     primary_ray<BATCH>(P, S, L, L.samples_left);
                                     if constexpr (EXT) { L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; }
                                     if constexpr (STEAL) { result[threadIdx.x] = MI_RESULT_NONE; L.owner = (int)threadIdx.x; }
-                                    begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
+                                    begin_walk<ORDERED>(S, L, R, R2);
                                     n_normal++;
                                     alive = true;
                                     want_pixel = false;
@@ -818,7 +774,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         L.mode = MODE_SHADOW;
                         L.shadow_hit = false;
                         L.nocull = 0u;                              // BVH_IntersectTriangles<true,true>
-                        begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
+                        begin_walk<ORDERED>(S, L, R, R2);
                         L.avoid = L.btri;
                         n_shadow++;
                     } else {
@@ -853,7 +809,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                             result[threadIdx.x] = result_key(FLT_MAX, L.btri); L.owner = (int)threadIdx.x;
                             lds_lp[threadIdx.x] = L.lp.x; lds_lp[RT_BLK + threadIdx.x] = L.lp.y; lds_lp[2 * RT_BLK + threadIdx.x] = L.lp.z;
                         }
-                        begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
+                        begin_walk<ORDERED>(S, L, R, R2);
                         L.avoid = L.btri;                       // avoidSelf = the triangle just hit (Raytracer.cc:335)
                         n_shadow++;
                         launched = true;
@@ -871,7 +827,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                             L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
                             L.nocull = 0u;                          // Raytrace<true>
                             L.path = 2u * L.path; L.depth++;
-                            begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
+                            begin_walk<ORDERED>(S, L, R, R2);
                             n_normal++;
                         } else { up = true; up_d = L.depth; up_which = 0u; }     // "the reflected ray returned black"
                     } else {
@@ -881,7 +837,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         set_ray_aux(L, S.scene_mag);
                         L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
                         if constexpr (STEAL) { result[threadIdx.x] = MI_RESULT_NONE; L.owner = (int)threadIdx.x; }
-                        begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
+                        begin_walk<ORDERED>(S, L, R, R2);
                         n_normal++;
                     } else finish = true;
                     }
@@ -904,7 +860,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                             L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
                             L.nocull = (uint32_t)MI_TWOSIDED_BIT;   // Raytrace<false>
                             L.path = 2u * L.path + 1u; L.depth = up_d + 1;
-                            begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
+                            begin_walk<ORDERED>(S, L, R, R2);
                             n_normal++;
                             complete = false; up = false;
                         } else if (P.use_refr) { a[0] = addclamp(a[0], 0.f); a[RT_BLK] = addclamp(a[RT_BLK], 0.f); a[2 * RT_BLK] = addclamp(a[2 * RT_BLK], 0.f); }   // too deep: black * rate
@@ -933,7 +889,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     primary_ray<BATCH>(P, S, L, L.samples_left);
                     if constexpr (EXT) { L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; }
                     if constexpr (STEAL) { result[threadIdx.x] = MI_RESULT_NONE; L.owner = (int)threadIdx.x; }
-                    begin_walk<ORDERED, QUAD>(S, L, R, R2, R3, R4);
+                    begin_walk<ORDERED>(S, L, R, R2);
                     n_normal++;
                 } else {
                     float r = sr, g = sg, b = sb;
@@ -1038,86 +994,6 @@ k_raytrace(const DevScene S, const FrameParams P)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 MI_PHASE(pc_wait);
             }
-            // 1q. quad records: the four slots' box tests, the nearest entered slot next, the others postponed
-            if constexpr (QUAD) {
-            if (mI) {
-                if (STATS) { it_a++; ln_a += __popcll(mI); }
-                if (inner) {
-                    const uint32_t l0 = __float_as_uint(R.b.z), l1 = __float_as_uint(R2.b.z), l2 = __float_as_uint(R3.b.z), l3 = __float_as_uint(R4.b.z);
-                    // (MI_END_LINK has no leaf bit: an empty slot is neither a leaf nor, below, an inner slot)
-                    const bool e0 = l0 == MI_END_LINK, e1 = l1 == MI_END_LINK, e2 = l2 == MI_END_LINK, e3 = l3 == MI_END_LINK;
-                    const bool f0 = (l0 & MI_LEAF_BIT) != 0u, f1 = (l1 & MI_LEAF_BIT) != 0u, f2 = (l2 & MI_LEAF_BIT) != 0u, f3_ = (l3 & MI_LEAF_BIT) != 0u;
-                    // a leaf slot whose side has a second slot is a GRANDCHILD: entered iff its parent's box passes
-                    const bool g0 = f0 && !e1, g1 = f1, g2 = f2 && !e3, g3 = f3_;
-                    bool h0, h1, h2, h3;
-                    float k0 = 0.f, k1 = 0.f, k2 = 0.f, k3 = 0.f;
-                    if (EXACT_BOX) {
-                        uint32_t need = (!f0 && !e0 ? 1u : 0u) | (!f1 && !e1 ? 2u : 0u) | (!f2 && !e2 ? 4u : 0u) | (!f3_ && !e3 ? 8u : 0u) |
-                                        ((g0 || g1) ? 16u : 0u) | ((g2 || g3) ? 32u : 0u);
-                        const uint32_t r = quad_exact(L.o, L.d, need, R, R2, R3, R4);
-                        h0 = f0 ? (!g0 || (r & 16u)) : (r & 1u) != 0u; h1 = f1 ? (r & 16u) != 0u : (r & 2u) != 0u;
-                        h2 = f2 ? (!g2 || (r & 32u)) : (r & 4u) != 0u; h3 = f3_ ? (r & 32u) != 0u : (r & 8u) != 0u;
-                    } else {
-                        bool s0, s1, s2, s3;
-                        float n0, n1, n2, n3, t0, t1, t2, t3;
-                        const bool p0 = ray_box_fast_ordered(L.o, L.inv, L.dmax, R.a, R.b, s0, k0, n0, t0);
-                        const bool p1 = ray_box_fast_ordered(L.o, L.inv, L.dmax, R2.a, R2.b, s1, k1, n1, t1);
-                        const bool p2 = ray_box_fast_ordered(L.o, L.inv, L.dmax, R3.a, R3.b, s2, k2, n2, t2);
-                        const bool p3 = ray_box_fast_ordered(L.o, L.inv, L.dmax, R4.a, R4.b, s3, k3, n3, t3);
-                        // the ray may reach something in the slot: it does not surely miss the grown box, and enters it before
-                        // the best hit so far (every slot); a leaf needs no more than that of its own box
-                        const bool tame = L.tame;
-                        const bool m0 = !tame || (!(n0 > t0) && !(t0 < 0.f) && !(n0 > L.limit)), m1 = !tame || (!(n1 > t1) && !(t1 < 0.f) && !(n1 > L.limit));
-                        const bool m2 = !tame || (!(n2 > t2) && !(t2 < 0.f) && !(n2 > L.limit)), m3 = !tame || (!(n3 > t3) && !(t3 < 0.f) && !(n3 > L.limit));
-                        // a side's parent box surely passes when one of its slot boxes does (the predicate is monotone in the box)
-                        const bool kl = tame && ((p0 && s0) || (p1 && s1)), kr = tame && ((p2 && s2) || (p3 && s3));
-                        uint32_t need = 0u;
-                        if (!f0 && !e0 && m0 && !(tame && s0)) need |= 1u;
-                        if (!f1 && !e1 && m1 && !(tame && s1)) need |= 2u;
-                        if (!f2 && !e2 && m2 && !(tame && s2)) need |= 4u;
-                        if (!f3_ && !e3 && m3 && !(tame && s3)) need |= 8u;
-                        if (((g0 && m0) || (g1 && m1)) && !kl) need |= 16u;
-                        if (((g2 && m2) || (g3 && m3)) && !kr) need |= 32u;
-                        uint32_t r = 0u;
-                        if (__builtin_expect(need != 0u, 0)) {
-                            if (STATS) n_slow++;
-                            r = quad_exact(L.o, L.d, need, R, R2, R3, R4);
-                        }
-                        const bool cl = kl || (r & 16u) != 0u, cr = kr || (r & 32u) != 0u;
-                        h0 = m0 && (f0 ? (!g0 || cl) : ((need & 1u) ? (r & 1u) != 0u : p0));
-                        h1 = m1 && (f1 ? cl : ((need & 2u) ? (r & 2u) != 0u : p1));
-                        h2 = m2 && (f2 ? (!g2 || cr) : ((need & 4u) ? (r & 4u) != 0u : p2));
-                        h3 = m3 && (f3_ ? cr : ((need & 8u) ? (r & 8u) != 0u : p3));
-                    }
-                    h0 = h0 && !e0; h1 = h1 && !e1; h2 = h2 && !e2; h3 = h3 && !e3;
-                    if (STATS) { n_pops += (e0 ? 0u : 1u) + (e1 ? 0u : 1u) + (e2 ? 0u : 1u) + (e3 ? 0u : 1u); n_ihits += (h0 ? 1u : 0u) + (h1 ? 1u : 0u) + (h2 ? 1u : 0u) + (h3 ? 1u : 0u); }
-                    // order: entry bounds clamped at 0 order like their bits; the slot number rides in the two lowest bits, so
-                    // the four keys are distinct and ANY bit patterns sort to a permutation (the order is advisory, the set is not)
-                    const uint32_t q0 = h0 ? ((__float_as_uint(__builtin_fmaxf(k0, 0.f)) & ~3u) | 0u) : 0xfffffffcu;
-                    const uint32_t q1 = h1 ? ((__float_as_uint(__builtin_fmaxf(k1, 0.f)) & ~3u) | 1u) : 0xfffffffdu;
-                    const uint32_t q2 = h2 ? ((__float_as_uint(__builtin_fmaxf(k2, 0.f)) & ~3u) | 2u) : 0xfffffffeu;
-                    const uint32_t q3 = h3 ? ((__float_as_uint(__builtin_fmaxf(k3, 0.f)) & ~3u) | 3u) : 0xffffffffu;
-                    const uint32_t lo3 = min(min(q0, q1), q2), hi3 = max(max(q0, q1), q2), mid3 = umed3(q0, q1, q2);
-                    const uint32_t s_0 = min(lo3, q3), s_1 = umed3(lo3, mid3, q3), s_2 = umed3(mid3, hi3, q3), s_3 = max(hi3, q3);
-                    const uint32_t NONE = 0xfffffffcu;
-                    if (s_0 < NONE) next = pick4(s_0, l0, l1, l2, l3);
-                    if (s_1 < NONE) {
-                        // postpone the others, the farthest first: entry #(sp-1) leaves the register for its row, then #sp .., the
-                        // second nearest stays in the register
-                        if (L.sp > 0) stk[(L.sp - 1) * RT_BLK] = L.top;
-                        L.top = pick4(s_1, l0, l1, l2, l3);
-                        if (s_2 < NONE) {
-                            const bool four = s_3 < NONE;
-                            stk[(L.sp + (four ? 1 : 0)) * RT_BLK] = pick4(s_2, l0, l1, l2, l3);
-                            if (four) { stk[L.sp * RT_BLK] = pick4(s_3, l0, l1, l2, l3); L.sp++; }
-                            L.sp++;
-                        }
-                        L.sp++;
-                    }
-                }
-                MI_PHASE(pc_a);
-            }
-            } else {
             // 1. wide nodes: both children's box tests (Raytracer.cc:222-230 for each)
             if (mI) {
                 if (STATS) { it_a++; ln_a += __popcll(mI); }
@@ -1165,7 +1041,6 @@ k_raytrace(const DevScene S, const FrameParams P)
                     else if (hR) next = linkR;
                 }
                 MI_PHASE(pc_a);
-            }
             }
             // 2. triangle blocks: the chain continues while the next link stays inside the leaf
             const uint32_t tcur = L.cur;
@@ -1221,7 +1096,6 @@ k_raytrace(const DevScene S, const FrameParams P)
                     R.a = p[0]; R.b = p[1];
                     if (PAIR || (next & MI_LEAF_BIT) == 0) {
                         R2.a = p[2]; R2.b = p[3];
-                        if constexpr (QUAD) { R3.a = p[4]; R3.b = p[5]; R4.a = p[6]; R4.b = p[7]; }
                     }
                 }
             }
@@ -1667,27 +1541,25 @@ extern "C" hipError_t mi355i_launch_cull_probe(const float *rays6, const uint32_
 // ---- launch helper (called from capi.hip) ------------------------------------------------
 namespace {
 typedef void (*rt_kernel)(const DevScene, const FrameParams);
-// waves = wavefronts per SIMD the build is allocated for (2, 3 or 4; counting and reference-order builds: 2)
-template <bool EXACT, bool BATCH, bool QUAD> rt_kernel ordered_kernel(int waves)
+// The builds that exist (16).  Production = the ordered walk with the filtered box test: three register builds (waves = wavefronts
+// per SIMD: 2, 3 or 4) x single frame / batch.  Everything else is a fallback or a measuring tool and comes in ONE register build
+// (two waves per SIMD): the exact-only box test (scenes whose box coordinates are outside the filtered test's range, tune flag 1),
+// the walk in the reference's order (unchecked trees, tune flag 4; its counting builds reproduce the reference's counters), the
+// counting build of the ordered walk (tune flag 8), and EXT (refractions / ray-cast ambient occlusion).  mi355i_raytrace_variant
+// maps a request onto what exists; capi.hip asks it before it sizes the launch.
+rt_kernel pick_kernel(int stats, int exact, int ordered, int waves, int batch, int ext)
 {
-    if (waves >= 4) return k_raytrace<false, EXACT, true, 4, BATCH, false, QUAD>;
-    if (waves == 3) return k_raytrace<false, EXACT, true, 3, BATCH, false, QUAD>;
-    return k_raytrace<false, EXACT, true, 2, BATCH, false, QUAD>;
-}
-template <bool QUAD> rt_kernel ordered_kernel_q(int exact, int waves, int batch)
-{
-    if (batch) return exact ? ordered_kernel<true, true, QUAD>(waves) : ordered_kernel<false, true, QUAD>(waves);
-    return exact ? ordered_kernel<true, false, QUAD>(waves) : ordered_kernel<false, false, QUAD>(waves);
-}
-rt_kernel pick_kernel(int stats, int exact, int ordered, int waves, int batch, int ext, int quad)
-{
-    if (ext) {      // refractions / ray-cast ambient occlusion: single frames, no counters, two waves per SIMD
+    if (ext) {
         if (ordered) return exact ? k_raytrace<false, true, true, 2, false, true> : k_raytrace<false, false, true, 2, false, true>;
-        return exact ? k_raytrace<false, true, false, 2, false, true> : k_raytrace<false, false, false, 2, false, true>;
+        return k_raytrace<false, true, false, 2, false, true>;
     }
-    if (ordered && !stats) return quad ? ordered_kernel_q<true>(exact, waves, batch) : ordered_kernel_q<false>(exact, waves, batch);
-    if (ordered && quad) return exact ? k_raytrace<true, true, true, 2, false, false, true> : k_raytrace<true, false, true, 2, false, false, true>;
-    if (ordered) return exact ? k_raytrace<true, true, true, 2, false> : k_raytrace<true, false, true, 2, false>;
+    if (ordered && stats) return k_raytrace<true, false, true, 2, false>;
+    if (ordered && exact) return batch ? k_raytrace<false, true, true, 2, true> : k_raytrace<false, true, true, 2, false>;
+    if (ordered) {
+        if (waves >= 4) return batch ? k_raytrace<false, false, true, 4, true> : k_raytrace<false, false, true, 4, false>;
+        if (waves == 3) return batch ? k_raytrace<false, false, true, 3, true> : k_raytrace<false, false, true, 3, false>;
+        return batch ? k_raytrace<false, false, true, 2, true> : k_raytrace<false, false, true, 2, false>;
+    }
     if (stats) return exact ? k_raytrace<true, true, false, 2, false> : k_raytrace<true, false, false, 2, false>;
     return exact ? k_raytrace<false, true, false, 2, false> : k_raytrace<false, false, false, 2, false>;
 }
@@ -1701,18 +1573,30 @@ size_t stack_bytes(int ordered, int rows) { return (size_t)(rows + (ordered ? 9 
 // can this build render several frames per launch?  (the ordered, non-counting kernels only)
 extern "C" int mi355i_raytrace_can_batch(int stats, int ordered) { return ordered && !stats; }
 
-// waves per CU the (stats, exact, ordered, waves, batch, quad) variant can hold with `stack_depth` rows of LDS asked for by the
-// launcher (a block is one wave: registers and LDS bound the count wave by wave, not in steps of four)
-extern "C" int mi355i_raytrace_waves_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext, int quad)
+// What a request is served by: *exact / *ordered / *waves are adjusted to a build that exists (see pick_kernel).  A counting frame
+// of the ordered walk on a scene that needs the exact box test is counted in the reference's order instead; EXT in the reference's
+// order always uses the exact test.
+extern "C" void mi355i_raytrace_variant(int stats, int *exact, int *ordered, int *waves, int ext)
 {
-    constexpr int MAX_ROWS = MI_MAX_QSTACK + 3 * MI_MAX_DEPTH + 3;
-    static int cache[2][2][2][2][2][3][2][MAX_ROWS + 1];        // 0 = not asked yet
+    if (*ordered && stats && *exact && !ext) *ordered = 0;
+    if (ext && !*ordered) *exact = 1;
+    if (ext || stats || !*ordered || *exact) *waves = 2;
+    if (*waves > 4) *waves = 4;
+    if (*waves < 2) *waves = 2;
+}
+
+// waves per CU the (stats, exact, ordered, waves, batch, ext) variant can hold with `stack_depth` rows of LDS asked for by the
+// launcher (a block is one wave: registers and LDS bound the count wave by wave, not in steps of four)
+extern "C" int mi355i_raytrace_waves_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext)
+{
+    constexpr int MAX_ROWS = MI_MAX_STACK + 3 * MI_MAX_DEPTH + 3;
+    static int cache[2][2][2][2][3][2][MAX_ROWS + 1];        // 0 = not asked yet
     if (stack_depth < 0 || stack_depth > MAX_ROWS) stack_depth = MAX_ROWS;
     const int w = waves >= 4 ? 2 : (waves == 3 ? 1 : 0);
-    int &slot = cache[quad ? 1 : 0][ext ? 1 : 0][stats ? 1 : 0][exact ? 1 : 0][ordered ? 1 : 0][w][batch ? 1 : 0][stack_depth];
+    int &slot = cache[ext ? 1 : 0][stats ? 1 : 0][exact ? 1 : 0][ordered ? 1 : 0][w][batch ? 1 : 0][stack_depth];
     if (!slot) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_kernel(stats, exact, ordered, waves, batch, ext, quad), RT_BLK, stack_bytes(ordered, stack_depth)) != hipSuccess || nb < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_kernel(stats, exact, ordered, waves, batch, ext), RT_BLK, stack_bytes(ordered, stack_depth)) != hipSuccess || nb < 1)
             nb = 8;
         nb *= RT_BLK / 64;
         slot = nb > 32 ? 32 : nb;
@@ -1720,10 +1604,10 @@ extern "C" int mi355i_raytrace_waves_per_cu(int stats, int exact, int ordered, i
     return slot;
 }
 
-// stack_depth = rows of the per-lane LDS stack (DevScene::stack_depth, or qstack_depth for the four-wide walk)
+// stack_depth = rows of the per-lane LDS stack (DevScene::stack_depth)
 extern "C" hipError_t mi355i_launch_raytrace(const DevScene *S, const FrameParams *P, int stats, int exact, int ordered, int waves,
-                                             int batch, int ext, int quad, int stack_depth, int n_waves, hipStream_t st)
+                                             int batch, int ext, int stack_depth, int n_waves, hipStream_t st)
 {
-    hipLaunchKernelGGL(pick_kernel(stats, exact, ordered, waves, batch, ext, quad), dim3((n_waves * 64 + RT_BLK - 1) / RT_BLK), dim3(RT_BLK), stack_bytes(ordered, stack_depth), st, *S, *P);
+    hipLaunchKernelGGL(pick_kernel(stats, exact, ordered, waves, batch, ext), dim3((n_waves * 64 + RT_BLK - 1) / RT_BLK), dim3(RT_BLK), stack_bytes(ordered, stack_depth), st, *S, *P);
     return hipGetLastError();
 }

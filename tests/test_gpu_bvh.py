@@ -302,7 +302,7 @@ def test_deep_trees_render_in_every_build(n_tri, tmp_path, oracle):
     for mode, depth_rays in ((9, 3), (9, 4), (10, 4)):
         want, wf, wst = o.render(mode, ocam, olights, on, oracle.default_opts(W, H, max_ray_depth=depth_rays, threads=os.cpu_count() or 1), want_f32=True)
         assert int((want != 0).sum()) > 3000
-        for knobs in (dict(), dict(bpc=2), dict(bpc=3), dict(bpc=4), dict(noshare=1), dict(sharemin=1, bpc=4), dict(quad=1), dict(reforder=1)):
+        for knobs in (dict(), dict(bpc=2), dict(bpc=3), dict(bpc=4), dict(noshare=1), dict(sharemin=1, bpc=4), dict(exact=1), dict(reforder=1)):
             img, f32, st = g.render(mode, cam, lights, n, R.default_opts(W, H, max_ray_depth=depth_rays, tune=R.tune(**knobs)), want_f32=True)
             assert np.array_equal(img, want) and np.array_equal(f32, wf), (mode, depth_rays, knobs)
             assert (st.normal_rays, st.shadow_rays) == (wst.normal_rays, wst.shadow_rays), (mode, depth_rays, knobs)

@@ -249,8 +249,7 @@ def test_raytrace_ragged_sizes(oracle, oracle_scene, gpu_scene, size):
     dict(xmin=1, rmin=1, chunk=64, lmin=1), dict(xmin=32, rmin=48, chunk=512, lmin=64), dict(xmin=64, rmin=64, chunk=4096),
     dict(exact=1), dict(rowmajor=1), dict(exact=1, lmin=16), dict(scatter=1), dict(bpc=1), dict(bpc=2, exact=1, lmin=4),
     dict(chunk=64, rmin=64, xmin=1, lmin=2), dict(bpc=3), dict(bpc=4), dict(bpc=4, exact=1), dict(reforder=1), dict(reforder=1, exact=1), dict(reforder=1, xmin=1, rmin=1),
-    # the four-wide walk (every register build, the exact-only box test) and the work sharing inside a wave (off, eager, late)
-    dict(quad=1), dict(quad=1, bpc=3), dict(quad=1, bpc=4), dict(quad=1, exact=1), dict(quad=1, exact=1, bpc=4), dict(quad=1, noshare=1),
+    # the work sharing inside a wave (off, eager, late)
     dict(noshare=1), dict(noshare=1, bpc=4), dict(sharemin=1), dict(sharemin=1, bpc=3), dict(sharemin=1, bpc=4), dict(sharemin=32), dict(sharemin=64, bpc=4),
     dict(sharemin=1, exact=1)],
     ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
