@@ -99,8 +99,6 @@ typedef struct {
      *            stream copies it to the caller's frame buffer, which holds the frame in stream order as always)
      *            | 64 the round-2 pipeline instead: setup and fill of a frame on an internal stream beside the previous frame's
      *            tile kernel, the tile kernels in order on the caller's stream
-     *            | 128 raytrace: the four-wide walk (128-byte records holding a node's leaf children and its inner children's
-     *            children; where the tree's boxes are exact unions of their children's) instead of the two-wide one
      *            | 256 raytrace: no work sharing inside a wave (default: lanes with nothing to walk take postponed subtrees of
      *            other lanes' rays -- a shadow ray's verdict is an OR over the triangles its walk reaches, a closest-hit ray's
      *            hit the minimum of (distance, triangle) over them: same pixels whoever walks what)
