@@ -47,6 +47,9 @@ namespace {
 // by the thread), and a persistent block holds its registers and LDS until its last wave is done: with one wave per block a wave
 // that has finished its tiles frees its share at once for the next launch's blocks, instead of waiting for three neighbours.
 #define RT_BLK 64
+#ifndef RT_COUNT
+#define RT_COUNT 0      // measuring variant: wave-uniform counters of the production loop (iterations, lanes per phase) in CS_PROF0 ..
+#endif
 
 enum { MODE_CLOSEST = 0, MODE_SHADOW = 1 };
 
@@ -516,7 +519,7 @@ k_raytrace(const DevScene S, const FrameParams P)
     // (oracle cost model, kind 4).  Measured: a single frame 1-6 % shorter (chessboard 0.608 -> 0.573 ms); batches, which are bound
     // by instruction issue and not by the length of a tile's chain, 2.5 % SLOWER (38 more vector instructions per such step):
     // not in the batch builds.
-    constexpr bool PAIR = ORDERED && WAVES >= 3 && !STATS && !BATCH;
+    constexpr bool PAIR = ORDERED && WAVES >= 3 && !STATS && !BATCH && !RT_COUNT;
     R.a = R.b = R2.a = R2.b = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t pool_next = 0, pool_end = 0;   // wave-local pixel pool (wave-uniform): local indices of share pool_share
     uint32_t pool_share = 0;
@@ -532,6 +535,7 @@ k_raytrace(const DevScene S, const FrameParams P)
     L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; L.ao_draw = 0u; L.ao_total = L.ao_max = L.ao_cos = 0.f;
 
     unsigned n_normal = 0, n_shadow = 0, n_steal = 0, n_event = 0;
+    unsigned long long cq[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // RT_COUNT
     unsigned n_pops = 0, n_ihits = 0, n_tris = 0, n_plane = 0, n_shaded = 0;
     // phase profile (STATS builds only; wave-uniform): cycles and lane occupancy per phase
     unsigned long long pc_refill = 0, pc_trans = 0, pc_a = 0, pc_b = 0, pc_total = 0, pc_wait = 0;
@@ -693,6 +697,7 @@ k_raytrace(const DevScene S, const FrameParams P)
             // ---------------- transitions ------------------------------------------------
             MI_PHASE(pc_refill);
             if (STATS) { it_trans++; ln_trans += __popcll(mX); }
+            if (RT_COUNT) { cq[7]++; cq[8] += __popcll(mX); }
             bool finish = false;     // ray tree complete -> fold
             bool lights = false;     // continue with light loop
             // EXT: value of the finished ray tree; the child that just returned `up_v` to the hit at depth `up_d`
@@ -988,6 +993,8 @@ k_raytrace(const DevScene S, const FrameParams P)
             const bool inner = walking && (L.cur & MI_LEAF_BIT) == 0;
             const bool tri = walking && (L.cur & MI_LEAF_BIT) != 0;
             const unsigned long long mI = __ballot(inner), mL = __ballot(tri);
+            if (RT_COUNT) { cq[0]++; cq[1] += mI ? 1 : 0; cq[2] += __popcll(mI); cq[3] += mL ? 1 : 0; cq[4] += __popcll(mL);
+                            cq[9] += __popcll(__ballot(tri && (L.cur & MI_FIRST_BIT) != 0u)); cq[10] += __popcll(__ballot(L.cur == MI_END_LINK)); }
             uint32_t next = MI_END_LINK;                            // END = nothing to enter from here: pop
             if (STATS) {                                            // profile: time spent waiting for the record
                 MI_PHASE(pc_b);
@@ -1118,6 +1125,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     cand = tri && j != L.avoid && facing && !(k == 0.0f) && !(sp <= 0.0f) && !(sp <= P.nudge);
                 }
                 if (STATS && tri) { n_tris++; if (cand) n_plane++; }
+                if (RT_COUNT) { const unsigned long long mc = __ballot(cand); cq[5] += mc ? 1 : 0; cq[6] += __popcll(mc); }
                 if (__ballot(cand)) {
                     // (every lane loads: the others read triangle 0's record, one broadcast line, instead of twelve
                     //  register clears and a divergent region)
@@ -1331,6 +1339,7 @@ k_raytrace(const DevScene S, const FrameParams P)
         const unsigned long long a = wsum(n_normal), b = wsum(n_shadow);
         const bool lead = (threadIdx.x & 63u) == 0;
         if (lead) { atomicAdd(&P.counters[CS_NORMAL_RAYS], a); atomicAdd(&P.counters[CS_SHADOW_RAYS], b); }
+        if (RT_COUNT && lead) for (int i = 0; i < 11; i++) atomicAdd(&P.counters[CS_PROF0 + i], cq[i]);
         if constexpr (STEAL) {      // (debug: subtrees handed from lane to lane, in a word the counting builds use for their profile)
             const unsigned long long ns = wsum(n_steal);
             if (lead && ns) { atomicAdd(&P.counters[CS_PROF0 + 12], ns); atomicAdd(&P.counters[CS_PROF0 + 11], (unsigned long long)n_event); }

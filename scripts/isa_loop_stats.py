@@ -9,7 +9,7 @@ is the first-order model of a change's effect before it is measured on the GPU.
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.environ.get("ISA_SRC") or os.path.join(ROOT, "renderer_amd", "csrc", "k_raytrace.hip")
-FLAGS = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -Wno-unused-function -Wno-unused-variable --cuda-device-only -S".split()
+FLAGS = ("-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -Wno-unused-function -Wno-unused-variable --cuda-device-only -S " + os.environ.get("ISA_EXTRA", "")).split()
 
 def main():
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
