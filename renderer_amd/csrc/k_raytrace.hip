@@ -69,8 +69,10 @@ struct Lane {
     bool tame;             // ray_is_tame(d)
     int avoid;             // leaf-order index of the triangle to skip (avoidSelf), -1 = none
     float best;            // bestTriDist
-    float limit;           // ordered walk: a box whose entry lies beyond this cannot change the result
-    float dmax;            // ordered walk: ray_delta * max |inv| -- how far (in ray parameter) growing a box by the slack can move its faces
+    float cull;            // ordered walk: a box whose entry (lower bound tn_lo of the filtered test) lies beyond this cannot change the
+                           // result: the bound on the distance of anything that still matters + dmax, see cull_from
+    float dmax2;           // ordered walk: 2 * dmax (and a rounding) with dmax = ray_delta * max |inv| -- how far (in ray parameter) growing
+                           // a box by the slack can move its faces
     int sp;                // ordered walk: postponed children of this lane (the newest in `top`, the rest in LDS rows base .. sp - 2)
     uint32_t top;
     int base;              // work sharing: rows below this one were handed to other lanes (0 otherwise)
@@ -183,8 +185,7 @@ MI_DEV bool ray_box_fast(const f3 o, const f3 inv, const float4 lo, const float4
 //         triangle and of the ray), and directions are unit vectors, so its distance from the origin is at
 //         least near_g -- and if near_g > far_g or far_g < 0 the ray misses the grown box and no triangle
 //         below it can be hit at all.
-MI_DEV bool ray_box_fast_ordered(const f3 o, const f3 inv, const float dmax, const float4 a, const float4 b, bool &sure,
-                                 float &key, float &near_g, float &far_g)
+MI_DEV void box_bounds(const f3 o, const f3 inv, const float4 a, const float4 b, float &tn_lo, float &tn_hi, float &tf_lo, float &tf_hi, float &tf)
 {
     // (a, b) = one child's half of a wide record: (min.x, max.x, min.y, max.y) (min.z, max.z, ..): both planes of an
     // axis go through the packed subtract and multiply side by side -- each half is (plane - o) * inv as before
@@ -193,11 +194,19 @@ MI_DEV bool ray_box_fast_ordered(const f3 o, const f3 inv, const float dmax, con
     const v2f y = (v2f{a.z, a.w} - o.y) * inv.y;
     const v2f z = (v2f{b.x, b.y} - o.z) * inv.z;
     const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x.x, x.y), __builtin_fminf(y.x, y.y)), __builtin_fminf(z.x, z.y));
-    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x.x, x.y), __builtin_fmaxf(y.x, y.y)), __builtin_fmaxf(z.x, z.y));
+    tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x.x, x.y), __builtin_fmaxf(y.x, y.y)), __builtin_fmaxf(z.x, z.y));
     // interval ends of Tnear and Tfar: t -> fma(+-E, |t|, t) is non-decreasing (also after rounding), so widening the
     // largest entry point equals the largest widened entry point (what ray_box_fast spells out axis by axis)
-    const float tn_lo = __builtin_fmaf(-E, __builtin_fabsf(tn), tn), tn_hi = __builtin_fmaf(E, __builtin_fabsf(tn), tn);
-    const float tf_lo = __builtin_fmaf(-E, __builtin_fabsf(tf), tf), tf_hi = __builtin_fmaf(E, __builtin_fabsf(tf), tf);
+    tn_lo = __builtin_fmaf(-E, __builtin_fabsf(tn), tn); tn_hi = __builtin_fmaf(E, __builtin_fabsf(tn), tn);
+    tf_lo = __builtin_fmaf(-E, __builtin_fabsf(tf), tf); tf_hi = __builtin_fmaf(E, __builtin_fabsf(tf), tf);
+}
+
+// (the same as one predicate with the bounds spelled out: what the probe kernel of the tests reports, and what the step's masks decide)
+MI_DEV bool ray_box_fast_ordered(const f3 o, const f3 inv, const float dmax, const float4 a, const float4 b, bool &sure,
+                                 float &key, float &near_g, float &far_g)
+{
+    float tn_lo, tn_hi, tf_lo, tf_hi, tf;
+    box_bounds(o, inv, a, b, tn_lo, tn_hi, tf_lo, tf_hi, tf);
     const bool pass = (tn_hi <= tf_lo) && (tf_lo >= 0.f);
     const bool fail = (tn_lo > tf_hi) || (tf_hi < 0.f);
     sure = pass || fail;
@@ -216,13 +225,29 @@ MI_DEV float ray_delta(const f3 o, float scene_mag)
     return 1e-4f * __builtin_fmaxf(__builtin_fmaxf(scene_mag, __builtin_fabsf(o.x)), __builtin_fmaxf(__builtin_fabsf(o.y), __builtin_fabsf(o.z)));
 }
 
+// ordered walk: the ray parameter beyond which nothing can change a closest-hit ray's result, from the squared distance of its best
+// hit so far.  A bound, not a result: the hardware's square root (1 ulp) under the 1.001 is as good as the IEEE one and 18
+// instructions shorter; the floor keeps a denormal distance^2 (which v_sqrt_f32 may flush) from giving a smaller bound than its root.
+MI_DEV float limit_from(float dist_sq, const f3 o, float scene_mag)
+{
+    return __builtin_amdgcn_sqrtf(__builtin_fmaxf(dist_sq, 1e-30f)) * 1.001f + ray_delta(o, scene_mag);
+}
+// The step's cull test from such a bound: a subtree is skipped when the entry into its box GROWN by the slack lies beyond the
+// bound; growing moves the entry by at most dmax, so that is tn_lo - dmax > bound, asked as tn_lo > bound + dmax (rounded up).
+MI_DEV float cull_from(float bound, float dmax2) { return (bound + 0.5f * dmax2) * 1.000001f; }
+// dmax as set_ray_aux makes it (the probe kernel of the tests reports it)
+MI_DEV float ray_dmax(const f3 o, const f3 inv, float scene_mag)
+{
+    return ray_delta(o, scene_mag) * __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(inv.x), __builtin_fabsf(inv.y)), __builtin_fabsf(inv.z));
+}
+
 // per-ray constants of the filtered box test
 MI_DEV void set_ray_aux(Lane &L, float scene_mag)
 {
     L.inv = mk3(__builtin_amdgcn_rcpf(L.d.x), __builtin_amdgcn_rcpf(L.d.y), __builtin_amdgcn_rcpf(L.d.z));
     L.tame = ray_is_tame(L.o, L.d);
     L.pend = false;
-    L.dmax = ray_delta(L.o, scene_mag) * __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(L.inv.x), __builtin_fabsf(L.inv.y)), __builtin_fabsf(L.inv.z));
+    L.dmax2 = 2.000002f * ray_dmax(L.o, L.inv, scene_mag);      // (rounded up: "gap > dmax2" must imply "gap > 2 dmax" after the gap's own rounding)
 }
 
 // Camera, lights and output of the frame a lane works on: kernel arguments for a single frame, a small table in
@@ -273,7 +298,7 @@ MI_DEV void primary_ray(const FrameParams &P, const DevScene &S, Lane &L, int tr
     L.cur = 0;          // patched by caller with the root link
     L.avoid = -1;
     L.best = FLT_MAX;
-    L.limit = FLT_MAX;
+    L.cull = FLT_MAX;
     L.btri = -1;
 }
 
@@ -459,7 +484,7 @@ MI_DEV bool tri_edge_test(Lane &L, float scene_mag)
         const bool better = ORDERED ? (hitZ < L.best || (hitZ == L.best && L.pj < L.btri)) : (hitZ < L.best);
         if (better) {
             L.best = hitZ; L.btri = L.pj;
-            if (ORDERED) L.limit = __builtin_sqrtf(hitZ) * 1.001f + ray_delta(L.o, scene_mag);
+            if (ORDERED) L.cull = cull_from(limit_from(hitZ, L.o, scene_mag), L.dmax2);
         }
     }
     return false;
@@ -530,7 +555,7 @@ k_raytrace(const DevScene S, const FrameParams P)
     L.shadow_hit = false; L.li = 0;
     L.o = L.d = L.hit = L.pn = L.refl = L.lp = L.inv = L.ph = mk3(0.f, 0.f, 0.f);
     L.tame = false; L.pend = false; L.pj = -1;
-    L.limit = 0.f; L.dmax = 0.f; L.sp = 0; L.top = MI_END_LINK; L.base = 0; L.owner = (int)threadIdx.x;
+    L.cull = 0.f; L.dmax2 = 0.f; L.sp = 0; L.top = MI_END_LINK; L.base = 0; L.owner = (int)threadIdx.x;
     L.pe1 = L.pe2 = L.pe3 = make_float4(0.f, 0.f, 0.f, 0.f);
     L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; L.ao_draw = 0u; L.ao_total = L.ao_max = L.ao_cos = 0.f;
 
@@ -775,7 +800,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         L.o = L.hit; L.d = v;
                         set_ray_aux(L, S.scene_mag);
                         L.best = distsq3(L.o, L.lp);
-                        L.limit = 2.f * __builtin_sqrtf(L.best) * 1.001f + ray_delta(L.o, S.scene_mag);
+                        L.cull = cull_from(2.f * __builtin_sqrtf(L.best) * 1.001f + ray_delta(L.o, S.scene_mag), L.dmax2);
                         L.mode = MODE_SHADOW;
                         L.shadow_hit = false;
                         L.nocull = 0u;                              // BVH_IntersectTriangles<true,true>
@@ -807,7 +832,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         L.best = distsq3(L.o, L.lp);            // Raytracer.cc:209
                         // a hit blocks when it is nearer to the light than the origin is, i.e. at a ray
                         // parameter below twice the light's distance
-                        L.limit = 2.f * __builtin_sqrtf(L.best) * 1.001f + ray_delta(L.o, S.scene_mag);
+                        L.cull = cull_from(2.f * __builtin_sqrtf(L.best) * 1.001f + ray_delta(L.o, S.scene_mag), L.dmax2);
                         L.mode = MODE_SHADOW;
                         L.shadow_hit = false;
                         if constexpr (STEAL) {
@@ -829,7 +854,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         if (P.use_refl && L.depth + 1 < P.max_depth) {
                             L.o = L.hit; L.d = ORDERED ? mk3(lds_refl[0], lds_refl[RT_BLK], lds_refl[2 * RT_BLK]) : L.refl; L.avoid = L.btri;
                             set_ray_aux(L, S.scene_mag);
-                            L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
+                            L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.cull = FLT_MAX; L.btri = -1;
                             L.nocull = 0u;                          // Raytrace<true>
                             L.path = 2u * L.path; L.depth++;
                             begin_walk<ORDERED>(S, L, R, R2);
@@ -840,7 +865,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     if (P.use_refl && L.depth < P.max_depth) {
                         L.o = L.hit; L.d = ORDERED ? mk3(lds_refl[0], lds_refl[RT_BLK], lds_refl[2 * RT_BLK]) : L.refl; L.avoid = L.btri;
                         set_ray_aux(L, S.scene_mag);
-                        L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
+                        L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.cull = FLT_MAX; L.btri = -1;
                         if constexpr (STEAL) { result[threadIdx.x] = MI_RESULT_NONE; L.owner = (int)threadIdx.x; }
                         begin_walk<ORDERED>(S, L, R, R2);
                         n_normal++;
@@ -862,7 +887,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                             L.o = mk3(q[0], q[RT_BLK], q[2 * RT_BLK]); L.d = mk3(q[3 * RT_BLK], q[4 * RT_BLK], q[5 * RT_BLK]);
                             L.avoid = __float_as_int(q[6 * RT_BLK]);
                             set_ray_aux(L, S.scene_mag);
-                            L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.limit = FLT_MAX; L.btri = -1;
+                            L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.cull = FLT_MAX; L.btri = -1;
                             L.nocull = (uint32_t)MI_TWOSIDED_BIT;   // Raytrace<false>
                             L.path = 2u * L.path + 1u; L.depth = up_d + 1;
                             begin_walk<ORDERED>(S, L, R, R2);
@@ -944,9 +969,11 @@ k_raytrace(const DevScene S, const FrameParams P)
                 // takers: lanes with nothing to walk -- no pixel, or a ray that has ended: what it found is in its result word, and
                 // what shading needs of a closest-hit ray (origin, direction) is made again after the burst; givers: lanes with
                 // a postponed node
-                const bool taker = L.cur == MI_END_LINK && !L.pend;
-                const bool giver = L.cur != MI_END_LINK && L.sp > L.base;
-                const unsigned long long mTk = __ballot(taker), mGv = __ballot(giver);
+                // (lane predicates as wave masks: combined on the scalar unit, not through registers)
+                const unsigned long long mWk = __ballot(L.cur != MI_END_LINK);
+                const unsigned long long mTk = (WAVES >= 3 ? ~mWk : ~mWk & ~__ballot(L.pend)) & __ballot(true), mGv = mWk & __ballot(L.sp > L.base);
+                const bool taker = __builtin_amdgcn_inverse_ballot_w64(mTk), giver = __builtin_amdgcn_inverse_ballot_w64(mGv);
+
                 if (mGv && __popcll(mTk) >= P.steal_min) {
                     const int lane = (int)(threadIdx.x & 63u);
                     n_event++;
@@ -964,13 +991,13 @@ k_raytrace(const DevScene S, const FrameParams P)
                     const float ox = __shfl(L.o.x, v), oy = __shfl(L.o.y, v), oz = __shfl(L.o.z, v);
                     const float dx = __shfl(L.d.x, v), dy = __shfl(L.d.y, v), dz = __shfl(L.d.z, v);
                     const float ix = __shfl(L.inv.x, v), iy = __shfl(L.inv.y, v), iz = __shfl(L.inv.z, v);
-                    const float vdmax = __shfl(L.dmax, v), vlimit = __shfl(L.limit, v), vbest = __shfl(L.best, v);
+                    const float vdmax = __shfl(L.dmax2, v), vlimit = __shfl(L.cull, v), vbest = __shfl(L.best, v);
                     const int vavoid = __shfl(L.avoid, v), vowner = __shfl(L.owner, v), vtame = __shfl(L.tame ? 1 : 0, v);
                     const int vmode = __shfl(L.mode, v), vbtri = __shfl(L.btri, v);
                     const uint32_t vgive = (uint32_t)__shfl((int)give, v);
                     if (takes) {
                         L.o = mk3(ox, oy, oz); L.d = mk3(dx, dy, dz); L.inv = mk3(ix, iy, iz);
-                        L.dmax = vdmax; L.limit = vlimit; L.best = vbest; L.avoid = vavoid; L.owner = vowner; L.tame = vtame != 0;
+                        L.dmax2 = vdmax; L.cull = vlimit; L.best = vbest; L.avoid = vavoid; L.owner = vowner; L.tame = vtame != 0;
                         L.mode = vmode; L.btri = vbtri; L.sp = 0; L.base = 0; L.top = MI_END_LINK;
                         L.cur = vgive;
                         const float4 *p = S.walk + (size_t)(vgive & MI_INDEX_MASK);
@@ -989,10 +1016,9 @@ k_raytrace(const DevScene S, const FrameParams P)
             }
             const int sbase = STEAL ? L.base : 0;
             // (a lane without a ray has L.cur == END and no pending candidate, so `alive` need not be looked at here)
-            const bool walking = L.cur != MI_END_LINK;
-            const bool inner = walking && (L.cur & MI_LEAF_BIT) == 0;
-            const bool tri = walking && (L.cur & MI_LEAF_BIT) != 0;
-            const unsigned long long mI = __ballot(inner), mL = __ballot(tri);
+            // (END has no leaf bit)
+            const unsigned long long mWalk = __ballot(L.cur != MI_END_LINK), mL = __ballot((int)L.cur < 0), mI = mWalk & ~mL;
+            const bool walking = __builtin_amdgcn_inverse_ballot_w64(mWalk), inner = __builtin_amdgcn_inverse_ballot_w64(mI), tri = __builtin_amdgcn_inverse_ballot_w64(mL);
             if (RT_COUNT) { cq[0]++; cq[1] += mI ? 1 : 0; cq[2] += __popcll(mI); cq[3] += mL ? 1 : 0; cq[4] += __popcll(mL);
                             cq[9] += __popcll(__ballot(tri && (L.cur & MI_FIRST_BIT) != 0u)); cq[10] += __popcll(__ballot(L.cur == MI_END_LINK)); }
             uint32_t next = MI_END_LINK;                            // END = nothing to enter from here: pop
@@ -1001,60 +1027,82 @@ k_raytrace(const DevScene S, const FrameParams P)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 MI_PHASE(pc_wait);
             }
-            // 1. wide nodes: both children's box tests (Raytracer.cc:222-230 for each)
+            // 1. wide nodes: both children's box tests (Raytracer.cc:222-230 for each).  The lanes' verdicts are kept as wave masks and
+            //    combined on the scalar unit (ballots in here cover the lanes at a node).
             if (mI) {
                 if (STATS) { it_a++; ln_a += __popcll(mI); }
                 if (inner) {
+                    typedef unsigned long long u64;
                     const uint32_t linkL = __float_as_uint(R.b.z), linkR = __float_as_uint(R.b.w);
                     // wide record: (min.x, max.x, min.y, max.y) (min.z, max.z, ..) per child
                     const float4 loL = make_float4(R.a.x, R.a.z, R.b.x, 0.f), hiL = make_float4(R.a.y, R.a.w, R.b.y, 0.f);
                     const float4 loR = make_float4(R2.a.x, R2.a.z, R2.b.x, 0.f), hiR = make_float4(R2.a.y, R2.a.w, R2.b.y, 0.f);
-                    bool hL, hR;
-                    float kL = 0.f, kR = 0.f;
                     // The reference tests a node's box when it pops that node, and only if it is an inner node
                     // (Raytracer.cc:222-230): a LEAF is entered whenever its parent's box was hit.  So the exact
                     // predicate decides inner children; a leaf child is entered unless the ray certainly misses
                     // its grown box (then none of its triangles can be hit).  Both are then subject to the
                     // distance cull.
-                    const bool leafL = (linkL & MI_LEAF_BIT) != 0u, leafR = (linkR & MI_LEAF_BIT) != 0u;
+                    const u64 mleafL = __ballot((int)linkL < 0), mleafR = __ballot((int)linkR < 0);
+                    u64 mhL, mhR, mlf = ~0ull;                      // child entered; left child first (any order is correct)
                     if (EXACT_BOX) {
-                        hL = leafL || ray_box_exact(L.o, L.d, loL, hiL);
-                        hR = leafR || ray_box_exact(L.o, L.d, loR, hiR);
+                        mhL = mleafL | __ballot(ray_box_exact(L.o, L.d, loL, hiL));
+                        mhR = mleafR | __ballot(ray_box_exact(L.o, L.d, loR, hiR));
                     } else {
-                        bool sL, sR;
-                        float nL, nR, fL, fR;
-                        hL = ray_box_fast_ordered(L.o, L.inv, L.dmax, R.a, R.b, sL, kL, nL, fL);
-                        hR = ray_box_fast_ordered(L.o, L.inv, L.dmax, R2.a, R2.b, sR, kR, nR, fR);
-                        if (__builtin_expect(!((sL || leafL) && (sR || leafR) && L.tame), 0)) {
-                            if (STATS) n_slow++;
-                            hL = leafL || ray_box_exact(L.o, L.d, loL, hiL);
-                            hR = leafR || ray_box_exact(L.o, L.d, loR, hiR);
-                        } else {
-                            // (lane masks combined with & and |: a ?: on bools makes the compiler move them through registers)
-                            const bool gL = !(nL > fL) & !(fL < 0.f), gR = !(nR > fR) & !(fR < 0.f);
-                            hL = ((leafL & gL) | (!leafL & hL)) & !(nL > L.limit);
-                            hR = ((leafR & gR) | (!leafR & hR)) & !(nR > L.limit);
+                        const float ndm = -0.5f * L.dmax2;
+                        const auto half = [&](const float4 a, const float4 b, const u64 mleaf, float &key, u64 &msure) -> u64 {
+                            float tn_lo, tn_hi, tf_lo, tf_hi, tf;
+                            box_bounds(L.o, L.inv, a, b, tn_lo, tn_hi, tf_lo, tf_hi, tf);
+                            // RayIntersectsBox's verdict where the intervals decide it (ray_box_fast): tf < 0 is `Tfar's interval lies below 0`
+                            // and tn_lo - tf_hi > 0 is `Tnear's lies above Tfar's`, bit for bit (no difference of two floats rounds to 0)
+                            const u64 mneg = __ballot(tf < 0.f);
+                            const float gap = tn_lo - tf_hi;
+                            const u64 mpass = __ballot(tn_hi <= tf_lo) & ~mneg;
+                            msure = mpass | mneg | __ballot(gap > 0.f);
+                            key = tn_lo;
+                            // a leaf: entered unless the ray surely misses its box grown by the slack -- the grown box is entered at least
+                            // at tn_lo - dmax and left at most at tf_hi + dmax: it is missed when that interval is empty or lies below 0
+                            const u64 mmiss = __ballot(gap > L.dmax2) | __ballot(tf_hi < ndm);
+                            // ... and nothing is entered whose grown box the ray reaches beyond what can still change its result (L.cull)
+                            return ((mleaf & ~mmiss) | (~mleaf & mpass)) & ~__ballot(tn_lo > L.cull);
+                        };
+                        u64 msL, msR;
+                        float kL, kR;
+                        mhL = half(R.a, R.b, mleafL, kL, msL);
+                        mhR = half(R2.a, R2.b, mleafR, kR, msR);
+                        mlf = __ballot(kL <= kR);
+                        // (intervals that overlap, a ray outside the filtered test's range: RayIntersectsBox itself, ~6e-4 of the tests)
+                        const u64 mneed = ~((msL | mleafL) & (msR | mleafR) & __ballot(L.tame)) & __ballot(true);
+                        if (__builtin_expect(mneed != 0ull, 0)) {
+                            bool eL = false, eR = false;
+                            if (__builtin_amdgcn_inverse_ballot_w64(mneed)) {
+                                if (STATS) n_slow++;
+                                eL = (int)linkL < 0 || ray_box_exact(L.o, L.d, loL, hiL);
+                                eR = (int)linkR < 0 || ray_box_exact(L.o, L.d, loR, hiR);
+                            }
+                            mhL = (mhL & ~mneed) | __ballot(eL);
+                            mhR = (mhR & ~mneed) | __ballot(eR);
                         }
                     }
-                    hR = hR && linkR != MI_END_LINK;                // the virtual record above the root has one child
-                    if (STATS) { n_pops += linkR != MI_END_LINK ? 2u : 1u; n_ihits += (hL ? 1u : 0u) + (hR ? 1u : 0u); }
-                    if (hL && hR) {
-                        const bool left_first = kL <= kR;
-                        next = left_first ? linkL : linkR;
+                    mhR &= __ballot(linkR != MI_END_LINK);          // the virtual record above the root has one child
+                    if (STATS) { n_pops += linkR != MI_END_LINK ? 2u : 1u; n_ihits += (__builtin_amdgcn_inverse_ballot_w64(mhL) ? 1u : 0u) + (__builtin_amdgcn_inverse_ballot_w64(mhR) ? 1u : 0u); }
+                    // the nearer of the entered children next, the other one postponed
+                    const u64 mtakeL = mhL & (~mhR | mlf), mtakeR = mhR & ~mtakeL;
+                    next = __builtin_amdgcn_inverse_ballot_w64(mtakeL) ? linkL : (__builtin_amdgcn_inverse_ballot_w64(mtakeR) ? linkR : (uint32_t)MI_END_LINK);
+                    if (__builtin_amdgcn_inverse_ballot_w64(mhL & mhR)) {
                         if (L.sp > sbase) stk[(L.sp - 1) * RT_BLK] = L.top;
-                        L.top = left_first ? linkR : linkL;
+                        L.top = __builtin_amdgcn_inverse_ballot_w64(mlf) ? linkR : linkL;
                         L.sp++;
-                    } else if (hL) next = linkL;
-                    else if (hR) next = linkR;
+                    }
                 }
                 MI_PHASE(pc_a);
             }
             // 2. triangle blocks: the chain continues while the next link stays inside the leaf
             const uint32_t tcur = L.cur;
-            float4 ta, tb;
             bool cand2 = false; int j2 = 0; float sp2 = 0.f;     // PAIR: the triangle of this step that goes on to the edge test
+            // (the other builds: what the plane half of this step's triangle test needs of the block -- R is about to be overwritten)
+            float tk = 0.f, tnum = 0.f;
+            unsigned long long mface = 0ull;
             if constexpr (PAIR) {
-                ta = R.a; tb = R.b;                             // (unused: the blocks are read where they are)
                 if (mL) {
                     const auto chain = [](uint32_t l) { return (l & (MI_LEAF_BIT | MI_FIRST_BIT)) == MI_LEAF_BIT; };
                     // plane half of the triangle test (Raytracer.cc:245-267) as a straight-line predicate
@@ -1078,15 +1126,19 @@ k_raytrace(const DevScene S, const FrameParams P)
                     else if (has2 && chain(nx2)) next = nx2;
                 }
             } else {
-            // keep the block for the plane test below (R is about to be overwritten; explicit moves: a plain copy makes the
-            // compiler load the next record into fresh registers and move it home at the loop's end -- behind a wait for the load)
-            asm volatile("v_mov_b32 %0, %8\n\tv_mov_b32 %1, %9\n\tv_mov_b32 %2, %10\n\tv_mov_b32 %3, %11\n\t"
-                         "v_mov_b32 %4, %12\n\tv_mov_b32 %5, %13\n\tv_mov_b32 %6, %14\n\tv_mov_b32 %7, %15"
-                         : "=&v"(ta.x), "=&v"(ta.y), "=&v"(ta.z), "=&v"(ta.w), "=&v"(tb.x), "=&v"(tb.y), "=&v"(tb.z), "=&v"(tb.w)
-                         : "v"(R.a.x), "v"(R.a.y), "v"(R.a.z), "v"(R.a.w), "v"(R.b.x), "v"(R.b.y), "v"(R.b.z), "v"(R.b.w));
-            if (tri) {
-                const uint32_t nx = __float_as_uint(R.a.w);
-                if ((nx & (MI_LEAF_BIT | MI_FIRST_BIT)) == MI_LEAF_BIT) next = nx;
+            // The dot products of the plane half (Raytracer.cc:245-262) now, from the block where it lies: the block's registers
+            // are free for the next record, and k, the numerator of s and the facing verdict are all that stays (a copy of the
+            // block cost eight moves in EVERY step).  Same operations on the same values as before, only earlier.
+            if (mL) {
+                const f3 n = mk3(R.a.x, R.a.y, R.a.z);
+                const f3 fto = sub3(L.o, mk3(R.b.x, R.b.y, R.b.z));
+                mface = __ballot(((tcur | L.nocull) & MI_TWOSIDED_BIT) != 0u) | __ballot(!(dot3(fto, n) < 0.f));
+                tk = dot3(n, L.d);
+                tnum = R.b.w - dot3(n, L.o);
+                if (tri) {
+                    const uint32_t nx = __float_as_uint(R.a.w);
+                    if ((nx & (MI_LEAF_BIT | MI_FIRST_BIT)) == MI_LEAF_BIT) next = nx;
+                }
             }
             }
             // 3. nothing to enter: resume at the most recently postponed child (the one below it comes up from
@@ -1117,12 +1169,8 @@ k_raytrace(const DevScene S, const FrameParams P)
                 if constexpr (PAIR) { j = j2; sp = sp2; cand = cand2; }
                 else {
                     j = (int)(((tcur & MI_INDEX_MASK) - S.tri_base) >> 1);
-                    const f3 n = mk3(ta.x, ta.y, ta.z);
-                    const f3 fto = sub3(L.o, mk3(tb.x, tb.y, tb.z));
-                    const bool facing = ((tcur | L.nocull) & MI_TWOSIDED_BIT) != 0u || !(dot3(fto, n) < 0.f);
-                    const float k = dot3(n, L.d);
-                    sp = (tb.w - dot3(n, L.o)) / k;
-                    cand = tri && j != L.avoid && facing && !(k == 0.0f) && !(sp <= 0.0f) && !(sp <= P.nudge);
+                    sp = tnum / tk;
+                    cand = tri && j != L.avoid && __builtin_amdgcn_inverse_ballot_w64(mface) && !(tk == 0.0f) && !(sp <= 0.0f) && !(sp <= P.nudge);
                 }
                 if (STATS && tri) { n_tris++; if (cand) n_plane++; }
                 if (RT_COUNT) { const unsigned long long mc = __ballot(cand); cq[5] += mc ? 1 : 0; cq[6] += __popcll(mc); }
@@ -1154,9 +1202,10 @@ k_raytrace(const DevScene S, const FrameParams P)
                         L.cur = MI_END_LINK;
                     }
                     // candidates arrive in any order: lowest list position wins among equal distances
-                    if (inside && !shadow && (nearer || (dz == L.best && j < L.btri))) {
+                    const bool better = inside && !shadow && (nearer || (dz == L.best && j < L.btri));
+                    if (better) {
                         L.best = dz; L.btri = j;
-                        L.limit = __builtin_sqrtf(dz) * 1.001f + ray_delta(L.o, S.scene_mag);
+                        L.cull = cull_from(limit_from(dz, L.o, S.scene_mag), L.dmax2);
                         if constexpr (STEAL) atomicMin(result + L.owner, result_key(dz, j));
                     }
                 }
@@ -1190,21 +1239,18 @@ k_raytrace(const DevScene S, const FrameParams P)
                         L.cur = MI_END_LINK;
                     }
                     // candidates arrive in any order: lowest list position wins among equal distances
-                    if (inside && !shadow && (nearer || (dz == L.best && L.pj < L.btri))) {
+                    const bool better = inside && !shadow && (nearer || (dz == L.best && L.pj < L.btri));
+                    if (better) {
                         L.best = dz; L.btri = L.pj;
-                        L.limit = __builtin_sqrtf(dz) * 1.001f + ray_delta(L.o, S.scene_mag);
+                        L.cull = cull_from(limit_from(dz, L.o, S.scene_mag), L.dmax2);
                         if constexpr (STEAL) atomicMin(result + L.owner, result_key(dz, L.pj));
                     }
                     L.pend = false;
                 }
                 {   // plane half of this step's triangle (Raytracer.cc:245-267)
                     const int j = (int)(((tcur & MI_INDEX_MASK) - S.tri_base) >> 1);
-                    const f3 n = mk3(ta.x, ta.y, ta.z);
-                    const f3 fto = sub3(L.o, mk3(tb.x, tb.y, tb.z));
-                    const bool facing = ((tcur | L.nocull) & MI_TWOSIDED_BIT) != 0u || !(dot3(fto, n) < 0.f);
-                    const float k = dot3(n, L.d);
-                    const float sp = (tb.w - dot3(n, L.o)) / k;
-                    const bool cand = tri && j != L.avoid && facing && !(k == 0.0f) && !(sp <= 0.0f) && !(sp <= P.nudge);
+                    const float sp = tnum / tk;
+                    const bool cand = tri && j != L.avoid && __builtin_amdgcn_inverse_ballot_w64(mface) && !(tk == 0.0f) && !(sp <= 0.0f) && !(sp <= P.nudge);
                     if (STATS && tri) { n_tris++; if (cand) n_plane++; }
                     if (cand) {
                         load_edges(S.tri_edge + (size_t)j * 3, L.pe1, L.pe2, L.pe3);
@@ -1224,7 +1270,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         const float sb = __uint_as_float((uint32_t)(seen >> 32));
                         if (sb < L.best) {
                             L.best = sb; L.btri = (int)(uint32_t)seen;
-                            L.limit = __builtin_sqrtf(sb) * 1.001f + ray_delta(L.o, S.scene_mag);
+                            L.cull = cull_from(limit_from(sb, L.o, S.scene_mag), L.dmax2);
                         }
                     }
                 }
@@ -1535,8 +1581,9 @@ k_cull_probe(const float *rays6, const uint32_t *pair_ray, const float *pair_box
     set_ray_aux(L, scene_mag);
     bool sure;
     float key, near_g, far_g;
-    const bool pass = ray_box_fast_ordered(L.o, L.inv, L.dmax, make_float4(b[0], b[3], b[1], b[4]), make_float4(b[2], b[5], 0.f, 0.f), sure, key, near_g, far_g);
-    out4[4 * (size_t)i] = near_g; out4[4 * (size_t)i + 1] = far_g; out4[4 * (size_t)i + 2] = L.dmax;
+    const float dmax = ray_dmax(L.o, L.inv, scene_mag);
+    const bool pass = ray_box_fast_ordered(L.o, L.inv, dmax, make_float4(b[0], b[3], b[1], b[4]), make_float4(b[2], b[5], 0.f, 0.f), sure, key, near_g, far_g);
+    out4[4 * (size_t)i] = near_g; out4[4 * (size_t)i + 1] = far_g; out4[4 * (size_t)i + 2] = dmax;
     out4[4 * (size_t)i + 3] = (float)((sure ? 1 : 0) | (pass ? 2 : 0) | (L.tame ? 4 : 0));
 }
 } // namespace
