@@ -36,6 +36,7 @@ struct BvCtl {
     uint32_t tame, bounded; float mag;
     uint32_t root_link;
     float4 root_a, root_b, vroot_a, vroot_b;
+    float4 wroot[4]; uint32_t root_direct, pad_rd[3];     // dev_scene.h
     uint32_t rkey[6], rzero[6];                   // root box: ordered keys of min / max, triangle index of the first zero
 };
 

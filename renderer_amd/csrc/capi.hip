@@ -652,6 +652,16 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
         const uint32_t wroot = is_leaf(0) ? link(0) : (uint32_t)(wide_base + 2 * (size_t)off[0]);
         c->dev.vroot_a = make_float4(rn[0].bottom[0], rn[0].top[0], rn[0].bottom[1], rn[0].top[1]);
         c->dev.vroot_b = make_float4(rn[0].bottom[2], rn[0].top[2], u2f(wroot), u2f(MI_END_LINK));
+        // (a walk may start at the root's wide record instead of at the virtual record above it -- begin_walk, k_raytrace.hip)
+        c->dev.root_direct = 0u;
+        for (int k = 0; k < 4; k++) c->dev.wroot[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!is_leaf(0) && rn[0].a < nN && rn[0].b < nN) {
+            const RefNode &ca = rn[rn[0].a], &cb = rn[rn[0].b];
+            bool in = !is_leaf(rn[0].a) && !is_leaf(rn[0].b);
+            for (int k = 0; k < 3; k++) in = in && ca.bottom[k] >= rn[0].bottom[k] && cb.bottom[k] >= rn[0].bottom[k] && ca.top[k] <= rn[0].top[k] && cb.top[k] <= rn[0].top[k];
+            for (int k = 0; k < 4; k++) c->dev.wroot[k] = walk[wide_base + 2 * (size_t)off[0] + k];
+            c->dev.root_direct = in ? 1u : 0u;
+        }
     }
     c->dev.n_nodes = nN;
     c->has_bvh = true;
@@ -1334,6 +1344,8 @@ int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_
     c->dev.root_link = ctl->root_link;
     c->dev.root_a = ctl->root_a; c->dev.root_b = ctl->root_b;
     c->dev.vroot_a = ctl->vroot_a; c->dev.vroot_b = ctl->vroot_b;
+    for (int k = 0; k < 4; k++) c->dev.wroot[k] = ctl->wroot[k];
+    c->dev.root_direct = ctl->root_direct;
     c->dev.tri_base = 2u * ctl->n_inner;
     c->dev.n_nodes = n_out;
     c->has_bvh = true;
@@ -1716,7 +1728,7 @@ int mi355i_fetch_traversal(mi355_ctx *c, int which, void *out, size_t bytes)
         uint32_t w[32] = {0};
         memcpy(w, &c->dev.root_a, 16); memcpy(w + 4, &c->dev.root_b, 16); memcpy(w + 8, &c->dev.vroot_a, 16); memcpy(w + 12, &c->dev.vroot_b, 16);
         w[16] = c->dev.root_link; w[17] = c->dev.tri_base; w[18] = c->dev.ordered_ok; w[19] = c->dev.stack_depth;
-        memcpy(w + 20, &c->dev.scene_mag, 4); w[21] = c->dev.n_nodes; w[22] = c->boxes_tame ? 1u : 0u;
+        memcpy(w + 20, &c->dev.scene_mag, 4); w[21] = c->dev.n_nodes; w[22] = c->boxes_tame ? 1u : 0u; w[23] = c->dev.root_direct;
         memcpy(out, w, bytes < sizeof w ? bytes : sizeof w);
         return 0;
     }

@@ -64,6 +64,8 @@ struct DevScene {
     const float4 *tri_shade;
     float4 root_a, root_b;    // walk record behind root_link
     float4 vroot_a, vroot_b;  // virtual wide record above the root: the root's box as the left child, END as the right link
+    float4 wroot[4];          // the root's own wide record (its children's boxes), where root_direct is set
+    uint32_t root_direct;     // walks may start at the root's wide record: see begin_walk (k_raytrace.hip)
     uint32_t root_link;
     uint32_t tri_base;        // float4 index of triangle block 0
     uint32_t ordered_ok;      // boxes bound their subtrees, list order = visiting order, depth fits the LDS stack

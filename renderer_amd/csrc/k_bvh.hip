@@ -57,7 +57,7 @@ k_bvh_init(BvWork W, size_t n_bin_words)
     if (i0 == 0) {
         BvCtl &c = *W.ctl;
         for (int k = 0; k < BV_MAX_LEVELS + 2; k++) c.n_level[k] = c.n_big[k] = c.n_task[k] = 0u;
-        c.n_tree = 0u; c.bad = 0u; c.levels = 0u; c.n_inner = c.n_nodes = c.inner_levels = 0u; c.tame = 1u; c.mag = 0.f;
+        c.n_tree = 0u; c.bad = 0u; c.levels = 0u; c.n_inner = c.n_nodes = c.inner_levels = 0u; c.tame = 1u; c.mag = 0.f; c.root_direct = 0u;
         for (int k = 0; k < 6; k++) { c.rkey[k] = k < 3 ? BV_KEY_HI : BV_KEY_LO; c.rzero[k] = 0xffffffffu; }
     }
     // bins: per (node, axis) 7 rows of max_planes + 1 words: counts, min x y z, max x y z
@@ -958,6 +958,13 @@ k_bvh_emit_nodes(const BvWork W)
             w[1] = make_float4(ca.bb[2], ca.bb[5], __uint_as_float(wl), __uint_as_float(wr));
             w[2] = make_float4(cb.bb[0], cb.bb[3], cb.bb[1], cb.bb[4]);
             w[3] = make_float4(cb.bb[2], cb.bb[5], 0.f, 0.f);
+            if (i == 0u) {
+                // (a walk may start here instead of at the virtual record above: both children inner nodes whose boxes lie in the root's)
+                bool in = !(ca.a & 0x80000000u) && !(cb.a & 0x80000000u);
+                for (int k = 0; k < 3; k++) in = in && ca.bb[k] >= n.bb[k] && cb.bb[k] >= n.bb[k] && ca.bb[3 + k] <= n.bb[3 + k] && cb.bb[3 + k] <= n.bb[3 + k];
+                for (int k = 0; k < 4; k++) W.ctl->wroot[k] = w[k];
+                W.ctl->root_direct = in ? 1u : 0u;
+            }
         } else {
             r.a = n.a; r.b = n.b;
             const uint32_t cnt = n.a & 0x7fffffffu, first = n.b;

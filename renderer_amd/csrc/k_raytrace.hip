@@ -47,6 +47,15 @@ namespace {
 // by the thread), and a persistent block holds its registers and LDS until its last wave is done: with one wave per block a wave
 // that has finished its tiles frees its share at once for the next launch's blocks, instead of waiting for three neighbours.
 #define RT_BLK 64
+#ifndef RT_ROOTDIRECT
+#define RT_ROOTDIRECT 1
+#endif
+#ifndef RT_PAIRBATCH
+#define RT_PAIRBATCH 0
+#endif
+#ifndef RT_EDGEMASK
+#define RT_EDGEMASK 1
+#endif
 #ifndef RT_COUNT
 #define RT_COUNT 0      // measuring variant: wave-uniform counters of the production loop (iterations, lanes per phase) in CS_PROF0 ..
 #endif
@@ -417,11 +426,20 @@ MI_DEV void rec_fetch(const DevScene &S, uint32_t link, Rec &r)
 // every walk starts at the root, whose record is a kernel argument
 // (ordered walk: at the virtual record above the root, both of whose boxes are the root's)
 template <bool ORDERED>
-MI_DEV void begin_walk(const DevScene &S, Lane &L, Rec &R, Rec &R2)
+MI_DEV void begin_walk(const DevScene &S, Lane &L, Rec &R, Rec &R2, const bool direct_ok = true)
 {
     if (ORDERED) {
-        L.cur = MI_VROOT_LINK; L.sp = 0; L.base = 0; L.top = MI_END_LINK;
-        R.a = S.vroot_a; R.b = S.vroot_b; R2.a = S.vroot_a; R2.b = S.vroot_b;
+        L.sp = 0; L.base = 0; L.top = MI_END_LINK;
+#if RT_ROOTDIRECT
+        // (single frames: -2.4 % per frame; not in the batch builds: 12 more bytes of scratch per lane there, batches 1 % slower)
+        // The step at the virtual record only decides whether the root's box is hit.  Where both children of the root are inner nodes
+        // with boxes inside the root's, that step can go: RayIntersectsBox is monotone in the box (every operation of it is), so a ray
+        // that misses the root's box misses both children's and ends after the same one step, and a ray that hits it is where it
+        // would have been a step later.  (A leaf child is different: the reference enters it on the ROOT's verdict.)
+        if (direct_ok && S.root_direct) { L.cur = __float_as_uint(S.vroot_b.z); R.a = S.wroot[0]; R.b = S.wroot[1]; R2.a = S.wroot[2]; R2.b = S.wroot[3]; }
+        else
+#endif
+        { L.cur = MI_VROOT_LINK; R.a = S.vroot_a; R.b = S.vroot_b; R2.a = S.vroot_a; R2.b = S.vroot_b; }
     } else {
         L.cur = S.root_link;
         R.a = S.root_a; R.b = S.root_b;
@@ -544,7 +562,7 @@ k_raytrace(const DevScene S, const FrameParams P)
     // (oracle cost model, kind 4).  Measured: a single frame 1-6 % shorter (chessboard 0.608 -> 0.573 ms); batches, which are bound
     // by instruction issue and not by the length of a tile's chain, 2.5 % SLOWER (38 more vector instructions per such step):
     // not in the batch builds.
-    constexpr bool PAIR = ORDERED && WAVES >= 3 && !STATS && !BATCH && !RT_COUNT;
+    constexpr bool PAIR = ORDERED && WAVES >= 3 && !STATS && (!BATCH || RT_PAIRBATCH) && !RT_COUNT;
     R.a = R.b = R2.a = R2.b = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t pool_next = 0, pool_end = 0;   // wave-local pixel pool (wave-uniform): local indices of share pool_share
     uint32_t pool_share = 0;
@@ -691,7 +709,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                                     primary_ray<BATCH>(P, S, L, L.samples_left);
                                     if constexpr (EXT) { L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; }
                                     if constexpr (STEAL) { result[threadIdx.x] = MI_RESULT_NONE; L.owner = (int)threadIdx.x; }
-                                    begin_walk<ORDERED>(S, L, R, R2);
+                                    begin_walk<ORDERED>(S, L, R, R2, !BATCH);
                                     n_normal++;
                                     alive = true;
                                     want_pixel = false;
@@ -804,7 +822,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         L.mode = MODE_SHADOW;
                         L.shadow_hit = false;
                         L.nocull = 0u;                              // BVH_IntersectTriangles<true,true>
-                        begin_walk<ORDERED>(S, L, R, R2);
+                        begin_walk<ORDERED>(S, L, R, R2, !BATCH);
                         L.avoid = L.btri;
                         n_shadow++;
                     } else {
@@ -839,7 +857,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                             result[threadIdx.x] = result_key(FLT_MAX, L.btri); L.owner = (int)threadIdx.x;
                             lds_lp[threadIdx.x] = L.lp.x; lds_lp[RT_BLK + threadIdx.x] = L.lp.y; lds_lp[2 * RT_BLK + threadIdx.x] = L.lp.z;
                         }
-                        begin_walk<ORDERED>(S, L, R, R2);
+                        begin_walk<ORDERED>(S, L, R, R2, !BATCH);
                         L.avoid = L.btri;                       // avoidSelf = the triangle just hit (Raytracer.cc:335)
                         n_shadow++;
                         launched = true;
@@ -857,7 +875,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                             L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.cull = FLT_MAX; L.btri = -1;
                             L.nocull = 0u;                          // Raytrace<true>
                             L.path = 2u * L.path; L.depth++;
-                            begin_walk<ORDERED>(S, L, R, R2);
+                            begin_walk<ORDERED>(S, L, R, R2, !BATCH);
                             n_normal++;
                         } else { up = true; up_d = L.depth; up_which = 0u; }     // "the reflected ray returned black"
                     } else {
@@ -867,7 +885,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         set_ray_aux(L, S.scene_mag);
                         L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.cull = FLT_MAX; L.btri = -1;
                         if constexpr (STEAL) { result[threadIdx.x] = MI_RESULT_NONE; L.owner = (int)threadIdx.x; }
-                        begin_walk<ORDERED>(S, L, R, R2);
+                        begin_walk<ORDERED>(S, L, R, R2, !BATCH);
                         n_normal++;
                     } else finish = true;
                     }
@@ -890,7 +908,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                             L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.cull = FLT_MAX; L.btri = -1;
                             L.nocull = (uint32_t)MI_TWOSIDED_BIT;   // Raytrace<false>
                             L.path = 2u * L.path + 1u; L.depth = up_d + 1;
-                            begin_walk<ORDERED>(S, L, R, R2);
+                            begin_walk<ORDERED>(S, L, R, R2, !BATCH);
                             n_normal++;
                             complete = false; up = false;
                         } else if (P.use_refr) { a[0] = addclamp(a[0], 0.f); a[RT_BLK] = addclamp(a[RT_BLK], 0.f); a[2 * RT_BLK] = addclamp(a[2 * RT_BLK], 0.f); }   // too deep: black * rate
@@ -919,7 +937,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     primary_ray<BATCH>(P, S, L, L.samples_left);
                     if constexpr (EXT) { L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; }
                     if constexpr (STEAL) { result[threadIdx.x] = MI_RESULT_NONE; L.owner = (int)threadIdx.x; }
-                    begin_walk<ORDERED>(S, L, R, R2);
+                    begin_walk<ORDERED>(S, L, R, R2, !BATCH);
                     n_normal++;
                 } else {
                     float r = sr, g = sg, b = sb;
@@ -1175,10 +1193,17 @@ k_raytrace(const DevScene S, const FrameParams P)
                 if (STATS && tri) { n_tris++; if (cand) n_plane++; }
                 if (RT_COUNT) { const unsigned long long mc = __ballot(cand); cq[5] += mc ? 1 : 0; cq[6] += __popcll(mc); }
                 if (__ballot(cand)) {
-                    // (every lane loads: the others read triangle 0's record, one broadcast line, instead of twelve
-                    //  register clears and a divergent region)
+                    // (only the candidates load: the load path's data return is as busy as the vector ALUs -- TD_BUSY 0.87 --, and a record
+                    //  for each of 64 lanes where a dozen need one was a quarter of its bytes; the other lanes' registers keep whatever
+                    //  they held -- `inside` below starts with `cand` --, declared without an instruction)
+#if RT_EDGEMASK
+                    float4 e1, q, r;
+                    asm volatile("" : "=v"(e1.x), "=v"(e1.y), "=v"(e1.z), "=v"(e1.w), "=v"(q.x), "=v"(q.y), "=v"(q.z), "=v"(q.w), "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w));
+                    if (cand) { const float4 *e = S.tri_edge + (size_t)j * 3; e1 = e[0]; q = e[1]; r = e[2]; }
+#else
                     const float4 *e = S.tri_edge + (size_t)(cand ? j : 0) * 3;
                     const float4 e1 = e[0], q = e[1], r = e[2];
+#endif
                     const f3 hit = add3(mul3(L.d, sp), L.o);
                     const float kt1 = dot3(mk3(e1.x, e1.y, e1.z), hit) - e1.w;
                     // e2 and e3 together (each half is dot3(e_i, hit) - d_i, operation for operation)
