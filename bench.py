@@ -55,6 +55,24 @@ def own_bytes(st, width, rows):
     return 64 * wide + 32 * st["tri_tests"] + 48 * st["plane_pass"] + 80 * st["shaded_hits"] + 4 * width * rows
 
 
+# The fewest vector instructions a lane can spend on a visited record (no FMA contraction: the reference's operations, each rounded):
+#   a wide record = RayIntersectsBox for two children (Raytracer.cc:99-151): per child 3 packed subtractions + 3 packed multiplications
+#     (both planes of an axis side by side), 3 min + 3 max, max3 + min3, 2 compares                                  = 16, x 2 = 32
+#   the plane half of a triangle test (Raytracer.cc:245-267): o - centre (3), three dot products (5 each), d - n.o (1), the IEEE
+#     division (10), 4 compares                                                                                        = 33
+#   the edge half where it is reached (Raytracer.cc:269-297): hit = o + d s (6), three (dot product - d_i) (6 each), 3 compares,
+#     squared distance (8), 1 compare                                                                                  = 36
+# Shading, ray generation, the stack, the dispenser and the work sharing are NOT in it: it is the floor of the traversal itself.
+USEFUL_OPS = {"wide": 32, "plane": 33, "edge": 36}
+
+
+def useful_ops(st):
+    """Lane-instructions of that floor for the records the ORDERED walk visits (its counting build, tune flag 8)."""
+    rays = st["normal_rays"] + st["shadow_rays"]
+    wide = max(0, st["node_pops"] - rays) // 2
+    return USEFUL_OPS["wide"] * wide + USEFUL_OPS["plane"] * st["tri_tests"] + USEFUL_OPS["edge"] * st["plane_pass"]
+
+
 def pmc_in_run(py_args, seconds=90):
     """Hardware counters of the bench kernel, measured NOW: this script again as a child under `rocprofv3 --pmc` (one pass per
     counter group: FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md), a handful of the same launches, averages
@@ -116,6 +134,7 @@ def main():
     ap.add_argument("--height", type=int, default=0, help="default 1080")
     ap.add_argument("--mesh", default="dragon_vis.ply")
     ap.add_argument("--mode", type=int, default=9)
+    ap.add_argument("--depth", type=int, default=3, help="max_ray_depth of the raytrace modes (3 = the reference's default; 1 = primary + shadow rays, BASELINE configs[2])")
     ap.add_argument("--tune", default="{}", help="JSON dict of renderer_amd.tune() knobs")
     ap.add_argument("--frames-per-step", type=int, default=0,
                     help="frames of the orbit rendered by one launch per GPU (raytrace modes; mi355_render_batch_device, 1..64); "
@@ -214,7 +233,7 @@ def main():
     cams = [R.benchmark_frame(k) for k in range(N_CAMS)]
 
     def opts(**kw):
-        o = R.default_opts(W, H, tune=json.loads(args.tune), **kw)
+        o = R.default_opts(W, H, tune=json.loads(args.tune), max_ray_depth=args.depth, **kw)
         if world > 1 and not by_frames:
             o.band_rows, o.band_index, o.band_count, o.compact_rows = multigpu.BAND_ROWS, rank, world, 1
         return o
@@ -302,7 +321,7 @@ def main():
     #      the tree in the reference's order: these ARE the reference algorithm's counts), once per orbit camera used
     o_stats = opts(collect_stats=1)
     t_own = dict(json.loads(args.tune)); t_own["profordered"] = 1
-    o_own = R.default_opts(W, H, tune=t_own, collect_stats=1)
+    o_own = R.default_opts(W, H, tune=t_own, collect_stats=1, max_ray_depth=args.depth)
     if world > 1 and not by_frames:
         o_own.band_rows, o_own.band_index, o_own.band_count, o_own.compact_rows = multigpu.BAND_ROWS, rank, world, 1
     used = sorted({f for k in range(K) for f in frames_of_step(k)})
@@ -310,6 +329,7 @@ def main():
     culled_f = np.zeros(N_CAMS, np.float64)      # camera rays of tiles the production launch sets to black without tracing them
     abytes_f = np.zeros(N_CAMS, np.float64)
     obytes_f = np.zeros(N_CAMS, np.float64)      # the ordered walk's own bytes (raytrace modes)
+    uops_f = np.zeros(N_CAMS, np.float64)        # ... and the floor of its vector instructions (useful_ops)
     scratch = torch.zeros((gather.max_rows, W), dtype=torch.int32, device=dev)
     for f in used:
         cam, lights, n = cams[f]
@@ -321,10 +341,12 @@ def main():
         if args.mode >= 9:
             scene.render_device(args.mode, cam, lights, n, o_own, scratch.data_ptr(), W * 4, 0, stream.cuda_stream)
             torch.cuda.synchronize(dev)
-            obytes_f[f] = own_bytes(scene.fetch_stats().as_dict(), W, my_rows)
+            st_own = scene.fetch_stats().as_dict()
+            obytes_f[f] = own_bytes(st_own, W, my_rows)
+            uops_f[f] = useful_ops(st_own)
             # (the production frame itself, one launch by itself: how many of its camera rays the tile culling never generates)
             t_c = dict(json.loads(args.tune)); t_c["nopipe"] = 1
-            o_c = R.default_opts(W, H, tune=t_c)
+            o_c = R.default_opts(W, H, tune=t_c, max_ray_depth=args.depth)
             o_c.band_rows, o_c.band_index, o_c.band_count, o_c.compact_rows = o_own.band_rows, o_own.band_index, o_own.band_count, o_own.compact_rows
             scene.render_device(args.mode, cam, lights, n, o_c, scratch.data_ptr(), W * 4, 0, stream.cuda_stream)
             torch.cuda.synchronize(dev)
@@ -363,7 +385,7 @@ def main():
     iso_ms = None
     if args.mode >= 9:
         t_iso = dict(json.loads(args.tune)); t_iso["nopipe"] = 1
-        o_iso = R.default_opts(W, H, tune=t_iso)
+        o_iso = R.default_opts(W, H, tune=t_iso, max_ray_depth=args.depth)
         if world > 1 and not by_frames:
             o_iso.band_rows, o_iso.band_index, o_iso.band_count, o_iso.compact_rows = multigpu.BAND_ROWS, rank, world, 1
         n_iso = max(5, min(K, 50))
@@ -390,6 +412,7 @@ def main():
         iso_ms = i0.elapsed_time(i1) / n_iso
         iso_abytes = sum(abytes_f[f] for k in range(n_iso) for f in frames_of_step(k)) / n_iso       # (this rank's launches)
         iso_obytes = sum(obytes_f[f] for k in range(n_iso) for f in frames_of_step(k)) / n_iso
+        iso_uops = sum(uops_f[f] for k in range(n_iso) for f in frames_of_step(k)) / n_iso
 
     # sanity: the last assembled frame is a real picture
     if rank == 0:
@@ -593,7 +616,7 @@ def main():
         own_launch = iso_obytes if (iso_ms and args.mode >= 9) else None
         pmc, pmc_note, pmc_src = None, "not collected (N > 1, --no-pmc or a raster mode)", None
         if world == 1 and args.mode >= 9 and not args.no_pmc:
-            child = ["--frames-per-step", str(B), "--mesh", args.mesh, "--mode", str(args.mode), "--tune", args.tune, "--width", str(W), "--height", str(H)]
+            child = ["--frames-per-step", str(B), "--mesh", args.mesh, "--mode", str(args.mode), "--tune", args.tune, "--width", str(W), "--height", str(H), "--depth", str(args.depth)]
             pmc, pmc_note = pmc_in_run(child)
             pmc_src = "this run: rocprofv3 --pmc passes of the same launches (%s)" % pmc_note if pmc else None
         if pmc is None and world == 1:
@@ -635,6 +658,14 @@ def main():
             roof.update({"bound": "hbm", "achieved": round((own_launch or abytes_launch) / ks / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round((own_launch or abytes_launch) / ks / 1e9 / HBM_PEAK_GBS, 5),
                          "bound_note": "no hardware counters available (%s): the kernel's own algorithmic bytes over its time against the HBM peak" % pmc_note})
+        if iso_ms and args.mode >= 9 and iso_uops > 0:
+            roof["useful"] = {"lane_ops_per_launch": round(iso_uops, 1), "achieved": round(iso_uops / ks / 1e12, 3), "peak": round(VALU_PEAK_TLANEOPS, 3), "unit": "Tlane-op/s",
+                              "frac": round(iso_uops / ks / 1e12 / VALU_PEAK_TLANEOPS, 4), "ops_per_record": USEFUL_OPS,
+                              "means": "the FLOOR of the traversal's vector work over the kernel's time: the fewest instructions a lane can spend on the records the "
+                                       "ordered walk visits (two slab tests per wide record, the plane half per triangle tested, the edge half where it is reached; "
+                                       "counted on the same frames by the counting build of that walk) against the chip's lane-operations.  `frac` above is issue-slot "
+                                       "occupancy; this one is work: the distance between the two is idle lanes of lockstep generations, the step's own bookkeeping "
+                                       "(links, stack, masks, the next record's address), the work sharing and the shading between the walks"}
         hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s"}
         if own_launch:
             hbm.update({"own_bytes_per_launch": round(own_launch, 1), "achieved": round(own_launch / ks / 1e9, 3), "frac_own": round(own_launch / ks / 1e9 / HBM_PEAK_GBS, 5),
@@ -718,7 +749,7 @@ def main():
                 extra[name + "_fps"] = round(200 / (time.perf_counter() - t1), 2)
             # the headline workload frame by frame (one launch per frame: the latency-bound way to run the same frames)
             if args.mode >= 9:
-                o1 = R.default_opts(W, H, tune=json.loads(args.tune))
+                o1 = R.default_opts(W, H, tune=json.loads(args.tune), max_ray_depth=args.depth)
                 for k in range(5):
                     scene.render_device(args.mode, cams[k][0], cams[k][1], cams[k][2], o1, buf.data_ptr(), W * 4, 0, stream.cuda_stream)
                 torch.cuda.synchronize(dev)
@@ -811,9 +842,54 @@ def main():
                     torch.cuda.synchronize(dev)
                     d = time.perf_counter() - t1
                     kms = [sc.render(9, cams[f][0], cams[f][1], cams[f][2], ow)[2].kernel_ms for f in range(0, n_cam, 4)]
-                    return {"Mrays_per_s": round(sum(rays) / n_cam * 8 * n_s / d / 1e6, 1), "frames_per_sec": round(8 * n_s / d, 1), "frames_per_launch": 8,
-                            "rays_per_frame": round(sum(rays) / n_cam, 1), "single_frame_kernel_ms": round(float(np.mean(kms)), 4),
-                            "workload": "%s, mode 9, max_ray_depth %d, %dx%d, orbit frames f0..f%d" % (mesh, depth, w, h, n_cam - 1)}
+                    row = {"Mrays_per_s": round(sum(rays) / n_cam * 8 * n_s / d / 1e6, 1), "frames_per_sec": round(8 * n_s / d, 1), "frames_per_launch": 8,
+                           "rays_per_frame": round(sum(rays) / n_cam, 1), "single_frame_kernel_ms": round(float(np.mean(kms)), 4),
+                           "workload": "%s, mode 9, max_ray_depth %d, %dx%d, orbit frames f0..f%d" % (mesh, depth, w, h, n_cam - 1)}
+                    # the same roofline block as the headline's: one launch by itself (tune flag 32), the floor of its vector work from the
+                    # counting build of the ordered walk, issue fraction and HBM traffic from counter passes of the same launches
+                    try:
+                        t_p = dict(json.loads(args.tune)); t_p["profordered"] = 1
+                        op = R.default_opts(w, h, max_ray_depth=depth, tune=t_p, collect_stats=1)
+                        uops = []
+                        for f in range(0, n_cam, 4):
+                            sc.render_device(9, cams[f][0], cams[f][1], cams[f][2], op, bufs[0].data_ptr(), w * 4, 0, stream.cuda_stream)
+                            torch.cuda.synchronize(dev)
+                            uops.append(useful_ops(sc.fetch_stats().as_dict()))
+                        t_i = dict(json.loads(args.tune)); t_i["nopipe"] = 1
+                        oi = R.default_opts(w, h, max_ray_depth=depth, tune=t_i)
+                        def istep(i):
+                            fs = [(8 * i + j) % n_cam for j in range(8)]
+                            sc.render_batch_device(9, [cams[f][0] for f in fs], [cams[f][1] for f in fs], cams[fs[0]][2], oi, [b.data_ptr() for b in bufs], w * 4, None, stream.cuda_stream)
+                        for i in range(2):
+                            istep(i)
+                        torch.cuda.synchronize(dev)
+                        i0, i1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        i0.record(stream)
+                        for i in range(10):
+                            istep(i)
+                        i1.record(stream)
+                        torch.cuda.synchronize(dev)
+                        k_ms = i0.elapsed_time(i1) / 10
+                        ks_ = k_ms * 1e-3
+                        u_launch = float(np.mean(uops)) * 8
+                        rf = {"kernel_ms": round(k_ms, 5), "frames_per_launch": 8,
+                              "useful": {"lane_ops_per_launch": round(u_launch, 1), "frac": round(u_launch / ks_ / 1e12 / VALU_PEAK_TLANEOPS, 4), "peak": round(VALU_PEAK_TLANEOPS, 3), "unit": "Tlane-op/s"}}
+                        if not args.no_pmc:
+                            pm, note = pmc_in_run(["--frames-per-step", "8", "--mesh", mesh, "--mode", "9", "--tune", args.tune, "--width", str(w), "--height", str(h), "--depth", str(depth)])
+                            if pm and "VALUBusy" in pm:
+                                vb_, vu_ = pm["VALUBusy"] / 100.0, pm.get("VALUUtilization", 0.0) / 100.0
+                                rf.update({"bound": "valu-issue", "frac": round(vb_ * vu_, 4), "achieved": round(vb_ * vu_ * VALU_PEAK_TLANEOPS, 3), "peak": round(VALU_PEAK_TLANEOPS, 3),
+                                           "unit": "Tlane-op/s", "valu_busy_pct": round(pm["VALUBusy"], 2), "valu_active_lanes_pct": round(pm.get("VALUUtilization", 0.0), 2),
+                                           "valu_wave_instructions_per_launch": pm.get("SQ_INSTS_VALU"), "counters": note})
+                                if pm.get("FETCH_SIZE") is not None and pm.get("WRITE_SIZE") is not None:
+                                    tr = 2.0 * pm["FETCH_SIZE"] * 1024.0 + pm["WRITE_SIZE"] * 1024.0
+                                    rf.update({"traffic": round(tr, 1), "hbm_measured_GBs": round(tr / ks_ / 1e9, 2), "hbm_measured_frac": round(tr / ks_ / 1e9 / HBM_PEAK_GBS, 5)})
+                            else:
+                                rf["counters"] = "not collected: %s" % note
+                        row["roofline"] = rf
+                    except Exception as e:
+                        row["roofline_error"] = str(e)
+                    return row
                 extra["statue_depth1_1080p"] = rt_workload("statue.ply", 1920, 1080, 1)
                 extra["dragon_4k"] = rt_workload("dragon_vis.ply", 3840, 2160, 3)
             # one 1024^2 shadow map (Light::CalculateXformFromWorldToLightSpace + RenderSceneIntoShadowBuffer, Light.cc:84-296): mi355_light_update
@@ -963,7 +1039,9 @@ def main():
                                     probe[(sched, t)] = float("inf")
                         (b_sched, b_t), b_s = min(probe.items(), key=lambda kv: kv[1])
                         sample = [f for f in used if rays_f[f] > 0][:max(4, min(len(used), int(round(args.cpu_seconds / max(b_s, 1e-3)))))]
-                        secs, _ = RC.time_frames(osc, [ocams[f][0] for f in sample], lights0, n0, W, H, 2 * H, threads=b_t, schedule=b_sched)
+                        # (the sample twice: the box's CPU quota makes single samples move by a quarter from box to box; the better run counts)
+                        runs = [RC.time_frames(osc, [ocams[f][0] for f in sample], lights0, n0, W, H, 2 * H, threads=b_t, schedule=b_sched)[0] for _ in range(2)]
+                        secs = min(runs, key=lambda v: float(v.sum()))
                         r_rays, r_t = float(sum(rays_f[f] for f in sample)), float(secs.sum())
                         ref_single = RC.time_frames(osc, [ocams[0][0]], lights0, n0, W, H, 2 * H, threads=1, schedule=1)[0][0] if args.cpu_seconds >= 8 else None
                         result["cpu_baseline"] = {
@@ -979,15 +1057,41 @@ def main():
                             "probe_ms_per_frame": {"%s/%dt" % ("rows" if k[0] == 1 else "per-scanline", k[1]): (round(v * 1e3, 1) if v < 1e9 else "timed out")
                                                    for k, v in sorted(probe.items())},
                         }
+                        result["cpu_baseline"]["runs_Mrays_per_s"] = [round(r_rays / float(v.sum()) / 1e6, 2) for v in runs]
                         if ref_single:
                             result["cpu_baseline"]["single_thread_Mrays_per_s"] = round(float(rays_f[0]) / float(ref_single) / 1e6, 3)
                         result["cpu_baseline_port"] = port
+                        # ... and the reference's SHIPPING configuration: the same code and frame loop with the flags its own configure.ac
+                        # gives a release build (-O3 -ffast-math -funsafe-math-optimizations -mrecip -msse2 ... -DSIMD_SSE): faster, and
+                        # not bit-compatible with the strict build the parity is pinned to (92 pixels of a dragon frame move)
+                        if os.path.exists(RC.AUTHOR_BINARY):
+                            aruns = [RC.time_frames(osc, [ocams[f][0] for f in sample], lights0, n0, W, H, 2 * H, threads=b_t, schedule=b_sched, binary=RC.AUTHOR_BINARY)[0] for _ in range(2)]
+                            a_t = min(float(v.sum()) for v in aruns)
+                            result["cpu_baseline_author"] = {
+                                "value": round(r_rays / a_t / 1e6, 3), "unit": "Mrays/s", "cores": b_t, "kind": "reference",
+                                "sample": "oracle/_ref/refcore_omp_author: the same Raytracer.cc and frame loop with the reference's own release flags "
+                                          "(configure.ac:47-50, 193-264: -O3 -fomit-frame-pointer -ffast-math -funsafe-math-optimizations -mtune=native -flto "
+                                          "-msse -mrecip -mfpmath=sse -msse2 -mssse3 -DSIMD_SSE -DSIMD_SSE2 -DNDEBUG), the same %d frames, threads and loop "
+                                          "shape as cpu_baseline; the better of two runs" % len(sample),
+                                "frames_per_sec": round(len(sample) / a_t, 3), "runs_Mrays_per_s": [round(r_rays / float(v.sum()) / 1e6, 2) for v in aruns],
+                                "x_strict": round((r_rays / a_t) / (r_rays / r_t), 3)}
                 except Exception as e:
                     result["cpu_baseline_reference_error"] = str(e)
             # the rasterizer's CPU baseline: the oracle draws triangles in index order on ONE thread -- the only deterministic
             # semantics the reference has (its OpenMP build races on the Z-buffer)
             if not args.no_extra:
                 oc = O.Scene(R.assets.mesh_path("chessboard.tri"))
+                # BASELINE configs[0]: chessboard.tri, points-only rasterizer (mode 2), 640x480, CPU path, single thread
+                n_c, t_c = 0, 0.0
+                while t_c < 2.0 or n_c < 200:
+                    ocam, olights, on = O.benchmark_frame(n_c % N_CAMS)
+                    t1 = time.perf_counter()
+                    oc.render(2, ocam, olights, on, O.default_opts(640, 480, threads=1))
+                    t_c += time.perf_counter() - t1
+                    n_c += 1
+                result["cpu_baseline_config1"] = {"value": round(n_c / t_c, 1), "unit": "frames/s", "cores": 1, "kind": "port",
+                                                  "sample": "oracle, chessboard.tri, mode 2 (points from triangles), 640x480, single thread, %d orbit frames, %.1f s "
+                                                            "(BASELINE configs[0]; the GPU's rate for the same frames: other_workloads.render_cli_bench row 1)" % (n_c, t_c)}
                 for mode, name in ((6, "chessboard_phong_1080p"), (8, "chessboard_softshadow_1080p")):
                     ocam, olights, on = O.benchmark_frame(0)
                     rmaps = [oc.shadowmap(olights[0])] if mode == 8 else None

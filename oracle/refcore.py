@@ -99,13 +99,16 @@ def raytrace(osc, cam, lights, n_lights, rays, max_depth=3, variant=""):
 
 
 OMP_BINARY = os.path.join(_HERE, "_ref", "refcore_omp")
+# the same driver compiled with the flags of the reference's own release build (configure.ac:47-50, 193-264; oracle/refcore/Makefile):
+# a speed baseline only -- fast-math changes pixels
+AUTHOR_BINARY = os.path.join(_HERE, "_ref", "refcore_omp_author")
 
 
 def timing_available() -> bool:
     return os.path.exists(OMP_BINARY)
 
 
-def time_frames(osc, cams, lights, n_lights, W, H, SD, threads=1, schedule=1, want_last=False, timeout=1800):
+def time_frames(osc, cams, lights, n_lights, W, H, SD, threads=1, schedule=1, want_last=False, timeout=1800, binary=None):
     """The reference's Raytrace<true> timed on whole frames (refcore.cc `timeframes`, the binary built with -fopenmp for the
     driver's frame loop): cams = [(eye[3], mv[9]), ...] -> (seconds per frame, last frame's [H, W, 3] r,g,b floats or None).
     schedule 0 = the reference's OpenMP shape (a parallel-for over x per scanline), 1 = one parallel loop over scanlines."""
@@ -119,7 +122,7 @@ def time_frames(osc, cams, lights, n_lights, W, H, SD, threads=1, schedule=1, wa
             for b in blobs:
                 f.write(b if isinstance(b, (bytes, bytearray)) else np.ascontiguousarray(b).tobytes())
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false")
-        subprocess.run([OMP_BINARY, "timeframes", fin, fout], check=True, timeout=timeout, stdout=subprocess.DEVNULL,
+        subprocess.run([binary or OMP_BINARY, "timeframes", fin, fout], check=True, timeout=timeout, stdout=subprocess.DEVNULL,
                        stderr=subprocess.DEVNULL, env=env)
         raw = open(fout, "rb").read()
     secs = np.frombuffer(raw[:8 * len(cams)], np.float64).copy()

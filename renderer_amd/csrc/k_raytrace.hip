@@ -709,7 +709,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                                     primary_ray<BATCH>(P, S, L, L.samples_left);
                                     if constexpr (EXT) { L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; }
                                     if constexpr (STEAL) { result[threadIdx.x] = MI_RESULT_NONE; L.owner = (int)threadIdx.x; }
-                                    begin_walk<ORDERED>(S, L, R, R2, !BATCH);
+                                    begin_walk<ORDERED>(S, L, R, R2, !BATCH && !STATS);
                                     n_normal++;
                                     alive = true;
                                     want_pixel = false;
@@ -822,7 +822,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         L.mode = MODE_SHADOW;
                         L.shadow_hit = false;
                         L.nocull = 0u;                              // BVH_IntersectTriangles<true,true>
-                        begin_walk<ORDERED>(S, L, R, R2, !BATCH);
+                        begin_walk<ORDERED>(S, L, R, R2, !BATCH && !STATS);
                         L.avoid = L.btri;
                         n_shadow++;
                     } else {
@@ -857,7 +857,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                             result[threadIdx.x] = result_key(FLT_MAX, L.btri); L.owner = (int)threadIdx.x;
                             lds_lp[threadIdx.x] = L.lp.x; lds_lp[RT_BLK + threadIdx.x] = L.lp.y; lds_lp[2 * RT_BLK + threadIdx.x] = L.lp.z;
                         }
-                        begin_walk<ORDERED>(S, L, R, R2, !BATCH);
+                        begin_walk<ORDERED>(S, L, R, R2, !BATCH && !STATS);
                         L.avoid = L.btri;                       // avoidSelf = the triangle just hit (Raytracer.cc:335)
                         n_shadow++;
                         launched = true;
@@ -875,7 +875,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                             L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.cull = FLT_MAX; L.btri = -1;
                             L.nocull = 0u;                          // Raytrace<true>
                             L.path = 2u * L.path; L.depth++;
-                            begin_walk<ORDERED>(S, L, R, R2, !BATCH);
+                            begin_walk<ORDERED>(S, L, R, R2, !BATCH && !STATS);
                             n_normal++;
                         } else { up = true; up_d = L.depth; up_which = 0u; }     // "the reflected ray returned black"
                     } else {
@@ -885,7 +885,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         set_ray_aux(L, S.scene_mag);
                         L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.cull = FLT_MAX; L.btri = -1;
                         if constexpr (STEAL) { result[threadIdx.x] = MI_RESULT_NONE; L.owner = (int)threadIdx.x; }
-                        begin_walk<ORDERED>(S, L, R, R2, !BATCH);
+                        begin_walk<ORDERED>(S, L, R, R2, !BATCH && !STATS);
                         n_normal++;
                     } else finish = true;
                     }
@@ -908,7 +908,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                             L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.cull = FLT_MAX; L.btri = -1;
                             L.nocull = (uint32_t)MI_TWOSIDED_BIT;   // Raytrace<false>
                             L.path = 2u * L.path + 1u; L.depth = up_d + 1;
-                            begin_walk<ORDERED>(S, L, R, R2, !BATCH);
+                            begin_walk<ORDERED>(S, L, R, R2, !BATCH && !STATS);
                             n_normal++;
                             complete = false; up = false;
                         } else if (P.use_refr) { a[0] = addclamp(a[0], 0.f); a[RT_BLK] = addclamp(a[RT_BLK], 0.f); a[2 * RT_BLK] = addclamp(a[2 * RT_BLK], 0.f); }   // too deep: black * rate
@@ -937,7 +937,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     primary_ray<BATCH>(P, S, L, L.samples_left);
                     if constexpr (EXT) { L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; }
                     if constexpr (STEAL) { result[threadIdx.x] = MI_RESULT_NONE; L.owner = (int)threadIdx.x; }
-                    begin_walk<ORDERED>(S, L, R, R2, !BATCH);
+                    begin_walk<ORDERED>(S, L, R, R2, !BATCH && !STATS);
                     n_normal++;
                 } else {
                     float r = sr, g = sg, b = sb;
