@@ -22,7 +22,7 @@ def child():
     out = {"variant": os.environ.get("RT_VARIANT_NAME", "?")}
     for mesh, depth, tag in (("dragon_vis.ply", 3, "dragon"), ("statue.ply", 1, "statue")):
         s = R.Scene(R.assets.mesh_path(mesh)); s.bvh_create()
-        o = R.default_opts(W, H, max_ray_depth=depth)
+        o = R.default_opts(W, H, max_ray_depth=depth, tune=R.tune(**json.loads(os.environ.get('RT_TUNE', '{}'))))
         def step(i):
             ks = [(i * B + j) % 200 for j in range(B)]
             s.render_batch_device(9, [cams[k][0] for k in ks], [cams[k][1] for k in ks], 1, o, [b.data_ptr() for b in bufs], W * 4, None, stream.cuda_stream)
