@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""tests/golden/refcore_frame_pins.json: SHA-256 of full-size raytraced orbit frames BEYOND the first one, from the reference's own
+code run here.  (tests/golden/reference_pins.json holds frame f0 of every BASELINE configuration, recorded by the survey from a
+whole build of the program; nobody can regenerate those in this image.)
+
+For BASELINE configs[2] (statue.ply, max depth 1) and configs[3] (dragon_vis.ply, depth 3) at 1920x1080, orbit frames f37, f100, f150:
+every pixel's colour is Raytrace<true>() of /root/reference/src/Raytracer.cc, compiled from where it lies with the pinned strict flags
+(oracle/refcore/Makefile -> oracle/_ref/refcore, command `raytrace`), on the frame's camera rays; the packed pixel is that colour
+clamped at 255 and truncated as Raytracer.cc:600-604 does.  Frame f0 made the same way must reproduce the survey's pin -- the check
+that this recipe IS the reference's frame -- and the script refuses to write anything if it does not.
+
+Needs /root/reference (to build oracle/_ref) -- i.e. this container, not the GPU box."""
+import hashlib, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from oracle import oracle_ctypes as O, refcore as RC
+
+def frame(osc, k, w, h, depth):
+    cam, lights, n = O.benchmark_frame(k)
+    f = RC.raytrace(osc, cam, lights, n, RC.primary_rays(cam, w, h, 2 * h), depth).reshape(h, w, 3)
+    c = np.minimum(f, np.float32(255.0)).astype(np.uint32)          # Raytracer.cc:600-603, then (Uint8) truncation
+    rgb = np.stack([c[..., 0], c[..., 1], c[..., 2]], axis=-1).astype(np.uint8)
+    return f, rgb
+
+def main():
+    assert RC.build(), "oracle/_ref/refcore could not be built (is /root/reference present?)"
+    survey = {p["id"]: p for p in json.load(open(os.path.join(ROOT, "tests", "golden", "reference_pins.json")))["frames"]}
+    out = []
+    for cid, mesh, depth in (("cfg3", "statue.ply", 1), ("cfg4", "dragon_vis.ply", 3)):
+        import renderer_amd.assets as A
+        osc = O.Scene(A.mesh_path(mesh)); osc.bvh_build()
+        w, h = 1920, 1080
+        _, rgb0 = frame(osc, 0, w, h, depth)
+        assert hashlib.sha256(rgb0.tobytes()).hexdigest() == survey[cid]["sha256"], "%s: frame f0 made this way is not the survey's frame" % cid
+        for k in (37, 100, 150):
+            f, rgb = frame(osc, k, w, h, depth)
+            out.append({"id": "%s_f%d" % (cid, k), "mesh": mesh, "mode": 9, "w": w, "h": h, "depth": depth, "frame": k,
+                        "nonblack": int((rgb.astype(np.uint32).sum(-1) != 0).sum()), "sha256": hashlib.sha256(rgb.tobytes()).hexdigest(),
+                        "sha256_f32": hashlib.sha256(np.minimum(f, np.float32(255.0)).astype(np.float32).tobytes()).hexdigest()})
+            print(out[-1], flush=True)
+    doc = {"_comment": "Full-size orbit frames beyond f0 from the reference's own Raytracer.cc compiled here (scripts/make_refcore_frame_pins.py: "
+                       "oracle/_ref/refcore `raytrace`, strict flags, camera rays of benchmark frame k; f0 made the same way reproduces the survey's "
+                       "pins of tests/golden/reference_pins.json).  sha256 over raw R,G,B bytes, row-major, top row first; sha256_f32 over the r,g,b "
+                       "float32 values clamped at 255 (what mi355_render hands out as out_rgb_f32).",
+           "frames": out}
+    json.dump(doc, open(os.path.join(ROOT, "tests", "golden", "refcore_frame_pins.json"), "w"), indent=1)
+
+if __name__ == "__main__":
+    main()
