@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
             any = any || nl != 0u;
             if (prof && tid == 0) acc[10] += nl;
             for (uint32_t chunk = 0; chunk < nl; chunk += RS_CHUNK) {
-                rs_tile_stage(ty, chunk, nl, parity, lds, tid, r0, r1);
+                rs_tile_stage(ty, chunk, nl, parity, lds, tid, nt, r0, r1);
                 __syncthreads();
                 RS_PROF_MARK(2);
                 if (prof && tid == 0) acc[11] += lds.n_items[parity];

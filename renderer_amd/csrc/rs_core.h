@@ -618,16 +618,20 @@ MI_HD void rs_tile_filter(const RsBuffers &B, uint32_t frame, int tx, int ty, co
 }
 
 // phase 2a (thread = slot of the chunk): list entry `chunk + tid` -> one work item per scanline of the tile it touches
-MI_HD void rs_tile_stage(int ty, uint32_t chunk, uint32_t n_list, int parity, RsTileLds &lds, int tid, int r0 = 0, int r1 = RS_TH - 1)
+MI_HD void rs_tile_stage(int ty, uint32_t chunk, uint32_t n_list, int parity, RsTileLds &lds, int tid, int nt, int r0 = 0, int r1 = RS_TH - 1)
 {
-    const uint32_t e = chunk + (uint32_t)tid;
-    if (tid >= RS_CHUNK || e >= n_list) return;
-    const int miny = (int)(lds.list[e][1] & 0xffffu), maxy = (int)(lds.list[e][1] >> 16);
-    const int Y0 = ty * RS_TH;
-    const int ys = miny > Y0 + r0 ? miny : Y0 + r0, ye = maxy < Y0 + r1 ? maxy : Y0 + r1;
-    if (ys > ye) return;
-    const uint32_t base = RS_ATOMIC_ADD_U32(&lds.n_items[parity], (uint32_t)(ye - ys + 1));
-    for (int y = ys; y <= ye; y++) lds.items[base + (uint32_t)(y - ys)] = (uint16_t)(((uint32_t)tid << 4) | (uint32_t)(y - Y0));
+    // (a block of fewer than RS_CHUNK threads takes several slots per thread: round 4 staged only the first `nt` entries of a
+    //  chunk and a 64- or 128-thread block -- tune[3] -- lost the triangles behind them)
+    for (uint32_t slot = (uint32_t)tid; slot < RS_CHUNK; slot += (uint32_t)nt) {
+        const uint32_t e = chunk + slot;
+        if (e >= n_list) return;
+        const int miny = (int)(lds.list[e][1] & 0xffffu), maxy = (int)(lds.list[e][1] >> 16);
+        const int Y0 = ty * RS_TH;
+        const int ys = miny > Y0 + r0 ? miny : Y0 + r0, ye = maxy < Y0 + r1 ? maxy : Y0 + r1;
+        if (ys > ye) continue;
+        const uint32_t base = RS_ATOMIC_ADD_U32(&lds.n_items[parity], (uint32_t)(ye - ys + 1));
+        for (int y = ys; y <= ye; y++) lds.items[base + (uint32_t)(y - ys)] = (uint16_t)((slot << 4) | (uint32_t)(y - Y0));
+    }
 }
 
 // the band record of scanline y for a triangle whose records start at `base` and whose first scanline is miny

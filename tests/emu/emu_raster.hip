@@ -117,7 +117,7 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
                     const uint32_t nl = lds.n_list;
                     any = any || nl != 0u;
                     for (uint32_t chunk = 0; chunk < nl; chunk += RS_CHUNK) {
-                        ALL_THREADS_REVERSED(rs_tile_stage(ty, chunk, nl, parity, lds, tid, r0, r1));
+                        ALL_THREADS_REVERSED(rs_tile_stage(ty, chunk, nl, parity, lds, tid, nt, r0, r1));
                         ALL_THREADS(rs_tile_depth<MODE>(F[f], B, S.n_tris, (uint32_t)f, tx, ty, chunk, parity, lds, tid, nt, zt));
                         lds.n_items[parity ^ 1] = 0u;
                         if (chunk + RS_CHUNK >= nl) lds.n_list = 0u;

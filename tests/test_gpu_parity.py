@@ -300,6 +300,14 @@ def test_raster_modes(oracle, oracle_scene, gpu_scene, mesh, mode):
         assert g[2].tris_drawn == o[2].tris_drawn and g[2].spans == o[2].spans and g[2].ztests == o[2].ztests
 
 
+@pytest.mark.parametrize("nt", [64, 128, 512])
+def test_raster_threads_per_tile_do_not_change_pixels(oracle, oracle_scene, gpu_scene, nt):
+    """tune[3] (threads per tile block): 64- and 128-thread blocks lost triangles before round 5 (rs_tile_stage)."""
+    for mode in (6, 8):
+        g, o = both_frames(oracle, oracle_scene, gpu_scene, "chessboard.tri", mode, 1920, 1080, 0, tune=dict(rsnt=nt))
+        assert_same(g, o)
+
+
 @pytest.mark.parametrize("mesh,mode,split", [("chessboard.tri", 8, 64), ("chessboard.tri", 6, 400), ("dragon_vis.ply", 5, 1), ("dragon_vis.ply", 4, 150)])
 def test_heavy_tiles_drawn_in_strips_of_rows(oracle, oracle_scene, gpu_scene, mesh, mode, split):
     """mi355_opts::tune[7]: a tile whose bins hold more entries than the threshold is drawn by two or four blocks, strips of 8 / 4

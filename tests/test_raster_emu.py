@@ -156,3 +156,13 @@ extern "C" void ff_many(const float *x, const float *d, const int *k, float *fas
                 C.c_void_p(slow.ctypes.data), C.c_int(len(x)))
     same = (fast.view(np.uint32) == slow.view(np.uint32)) | (np.isnan(fast) & np.isnan(slow))
     assert same.all(), "%d of %d chains differ, e.g. x=%r d=%r k=%d" % (int((~same).sum()), len(x), x[~same][0], d[~same][0], k[~same][0])
+
+
+@pytest.mark.parametrize("nt", [64, 128, 512])
+def test_threads_per_tile_do_not_change_the_frame(oracle, oracle_scene, host_scene, nt):
+    """mi355_opts::tune[3] = threads of a tile's block, 64..512.  A chunk of the tile's list has RS_CHUNK = 256 slots whatever the
+    block's size: round 4 staged one slot per THREAD, so a block of 64 or 128 threads dropped the triangles behind its first 64 /
+    128 list entries (found in round 5 by a sweep whose frames differed).  A frame dense enough for tiles with > 64 triangles."""
+    outs, refs, st, stats = frames(oracle, oracle_scene, host_scene, "chessboard.tri", 6, 960, 540, tune=R.tune(rsnt=nt))
+    assert np.array_equal(outs[0], refs[0])
+    assert st["ztests"] == stats[0].ztests
