@@ -639,6 +639,9 @@ __global__ void __launch_bounds__(256) k_sm_rows(const DevScene S, const ShadowP
 //               tile: from ff_add of the span's first pixel, a few pixels early, every plot checked against the tile's columns.
 //               The keys go to LDS with atomicMax; the tile's floats are stored once, whole rows of 1 KB.  No clear pass, no
 //               resolve pass, no global atomic on the map.
+// (Round 5: the tiles from a run-time dispenser, fewer workgroups than tiles -- what a simulation of the per-CU load had suggested -- is
+//  SLOWER: chessboard / dragon / statue 89 / 66 / 68 us with a workgroup per tile, 102 / 73 / 75 with 896 workgroups, 114 / 73 / 76 with 768,
+//  134 / 79 / 75 with 512: a tile's time is its chain of dependent steps, and a workgroup that draws two tiles walks two chains.)
 // (Measured on the way: every workgroup running over every triangle's box, 200 barriers each: chessboard 213 us, dragon 307; over
 //  the boxes of chunks of 256 triangles first -- a scanned mesh's triangle order makes them useless --: 166 / 296; band lists filled
 //  through global counters, 75 000 atomic adds on 90 neighbouring words: 523 / 664.)
@@ -1133,8 +1136,8 @@ extern "C" hipError_t mi355i_launch_shadowmap(const DevScene *S, const float *li
     memcpy(Q.light, light_pos, 12);
     memcpy(Q.mv, w2l, 36);
     Q.size = size;
-    static const bool row_items = [] { const char *v = getenv("MI355_SM_ROWS"); return v && *v && strcmp(v, "0"); }();    // the round-3 kernels, for comparison
-    if (!row_items && size <= SMT_BANDS * SMT_H) {
+    // (maps of more than SMT_BANDS * SMT_H = 8192 rows: the row-item kernels below, which have no such limit)
+    if (size <= SMT_BANDS * SMT_H) {
         // round 4: tiles with their keys in LDS (k_sm_prep, k_sm_tiles).  The row buffer holds the triangles' corners and boxes, the
         // table [block of 256 triangles][list] and, behind them, the blocks' band lists.
         const int per_block = 256;

@@ -11,7 +11,7 @@ tail -3 gpurun_out/pytest_full.log
 tail -1 gpurun_out/bench_full.log | cut -c1-300
 {
   echo "== scripts/rt_variants.py (dragon 1080p: batches of 8, single frames; work sharing, register builds, four-wide walk, bounds)"; timeout 300 python scripts/rt_variants.py 2>&1 | grep variant
-  echo "== scripts/shadowmap_time.py (LDS tiles; MI355_SM_ROWS=1: round 3's row-item kernels)"; timeout 100 python scripts/shadowmap_time.py 2>&1 | grep "us per"; MI355_SM_ROWS=1 timeout 100 python scripts/shadowmap_time.py 2>&1 | grep "us per"
+  echo "== scripts/shadowmap_time.py (LDS tiles from a dispenser)"; timeout 100 python scripts/shadowmap_time.py 2>&1 | grep "us per"
   echo "== scripts/raster_pipe_variants.py"; timeout 100 python scripts/raster_pipe_variants.py 2>&1 | tail -1
   echo "== scripts/raytrace_frame_by_frame.py"; timeout 100 python scripts/raytrace_frame_by_frame.py 2>&1 | tail -8
   echo "== scripts/render_cli_configs.sh (render_cli -b, BASELINE.json's five configurations)"; timeout 200 bash scripts/render_cli_configs.sh 2>&1

@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""Time of one 1024^2 shadow map (mi355_light_update, back to back on one stream; HIP events) per mesh; MI355_SM_ROWS=1 in the
-environment selects round 3's row-item kernels (which also draw maps of more than 8192 rows)."""
+"""Time of one 1024^2 shadow map (mi355_light_update, back to back on one stream; HIP events) per mesh."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -22,4 +21,4 @@ for mesh in ("chessboard.tri", "dragon_vis.ply", "statue.ply"):
     e1.record(stream)
     torch.cuda.synchronize(dev)
     s.fetch_stats()
-    print("%s: %.1f us per 1024^2 map (%s kernels)" % (mesh, e0.elapsed_time(e1) / n * 1e3, "row-item" if os.environ.get("MI355_SM_ROWS") else "LDS-tile"), flush=True)
+    print("%s: %.1f us per 1024^2 map" % (mesh, e0.elapsed_time(e1) / n * 1e3), flush=True)
