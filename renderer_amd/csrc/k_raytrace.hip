@@ -1006,17 +1006,17 @@ k_raytrace(const DevScene S, const FrameParams P)
                     if (giver && deep) give = stk[L.base * RT_BLK];
                     const bool takes = taker && tr < nG, robbed = giver && gr < nT;
                     const int v = takes ? (int)stab[tr] : lane;
-                    const float ox = __shfl(L.o.x, v), oy = __shfl(L.o.y, v), oz = __shfl(L.o.z, v);
-                    const float dx = __shfl(L.d.x, v), dy = __shfl(L.d.y, v), dz = __shfl(L.d.z, v);
-                    const float ix = __shfl(L.inv.x, v), iy = __shfl(L.inv.y, v), iz = __shfl(L.inv.z, v);
-                    const float vdmax = __shfl(L.dmax2, v), vlimit = __shfl(L.cull, v), vbest = __shfl(L.best, v);
-                    const int vavoid = __shfl(L.avoid, v), vowner = __shfl(L.owner, v), vtame = __shfl(L.tame ? 1 : 0, v);
-                    const int vmode = __shfl(L.mode, v), vbtri = __shfl(L.btri, v);
+                    // (every lane reads from v -- a lane that takes nothing from itself -- so what arrives is assigned without a condition:
+                    //  the values land in the lane's own registers, not in temporaries that nineteen conditional moves then copy)
+                    L.o = mk3(__shfl(L.o.x, v), __shfl(L.o.y, v), __shfl(L.o.z, v));
+                    L.d = mk3(__shfl(L.d.x, v), __shfl(L.d.y, v), __shfl(L.d.z, v));
+                    L.inv = mk3(__shfl(L.inv.x, v), __shfl(L.inv.y, v), __shfl(L.inv.z, v));
+                    L.dmax2 = __shfl(L.dmax2, v); L.cull = __shfl(L.cull, v); L.best = __shfl(L.best, v);
+                    L.avoid = __shfl(L.avoid, v); L.owner = __shfl(L.owner, v); L.tame = __shfl(L.tame ? 1 : 0, v) != 0;
+                    L.mode = __shfl(L.mode, v); L.btri = __shfl(L.btri, v);
                     const uint32_t vgive = (uint32_t)__shfl((int)give, v);
                     if (takes) {
-                        L.o = mk3(ox, oy, oz); L.d = mk3(dx, dy, dz); L.inv = mk3(ix, iy, iz);
-                        L.dmax2 = vdmax; L.cull = vlimit; L.best = vbest; L.avoid = vavoid; L.owner = vowner; L.tame = vtame != 0;
-                        L.mode = vmode; L.btri = vbtri; L.sp = 0; L.base = 0; L.top = MI_END_LINK;
+                        L.sp = 0; L.base = 0; L.top = MI_END_LINK;
                         L.cur = vgive;
                         const float4 *p = S.walk + (size_t)(vgive & MI_INDEX_MASK);
                         R.a = p[0]; R.b = p[1];
@@ -1210,25 +1210,27 @@ k_raytrace(const DevScene S, const FrameParams P)
                     const v2f xs = {q.x, q.y}, ys = {q.z, q.w}, zs = {r.x, r.y}, ds = {r.z, r.w};
                     const v2f kt23 = ((xs * hit.x + ys * hit.y) + zs * hit.z) - ds;
                     const float kt2 = kt23.x, kt3 = kt23.y;
-                    const bool inside = cand && !(kt1 < 0.0f) && !(kt2 < 0.0f) && !(kt3 < 0.0f);
-                    const bool shadow = L.mode == MODE_SHADOW;
+                    // (the verdicts as wave masks, like the box tests')
+                    typedef unsigned long long u64;
+                    const u64 minside = __ballot(cand) & __ballot(!(kt1 < 0.0f)) & __ballot(!(kt2 < 0.0f)) & __ballot(!(kt3 < 0.0f));
+                    const u64 mshadow = __ballot(L.mode == MODE_SHADOW);
+                    const bool shadow = __builtin_amdgcn_inverse_ballot_w64(mshadow);
                     f3 from = L.o;
                     if constexpr (STEAL) {
-                        if (__ballot(inside && shadow)) {
+                        if (minside & mshadow) {
                             const int ow = shadow ? L.owner : (int)threadIdx.x;
                             const f3 lp = mk3(lds_lp[ow], lds_lp[RT_BLK + ow], lds_lp[2 * RT_BLK + ow]);
                             if (shadow) from = lp;
                         }
                     } else if (shadow) from = L.lp;
                     const float dz = distsq3(from, hit);
-                    const bool nearer = dz < L.best;
-                    if (inside && shadow && nearer) {                // a blocked shadow ray stops (Raytracer.cc:284)
+                    const u64 mnearer = __ballot(dz < L.best);
+                    if (__builtin_amdgcn_inverse_ballot_w64(minside & mshadow & mnearer)) {                // a blocked shadow ray stops (Raytracer.cc:284)
                         if constexpr (STEAL) { ((uint32_t *)result)[2 * L.owner + 1] = 0u; L.sp = L.base; } else { L.shadow_hit = true; L.sp = 0; }
                         L.cur = MI_END_LINK;
                     }
                     // candidates arrive in any order: lowest list position wins among equal distances
-                    const bool better = inside && !shadow && (nearer || (dz == L.best && j < L.btri));
-                    if (better) {
+                    if (__builtin_amdgcn_inverse_ballot_w64(minside & ~mshadow & (mnearer | (__ballot(dz == L.best) & __ballot(j < L.btri))))) {
                         L.best = dz; L.btri = j;
                         L.cull = cull_from(limit_from(dz, L.o, S.scene_mag), L.dmax2);
                         if constexpr (STEAL) atomicMin(result + L.owner, result_key(dz, j));
