@@ -97,14 +97,11 @@ typedef struct {
      *            | 32 raster frames of the device entry points: all three kernels on the caller's stream (default: consecutive
      *            frames overlap -- each runs on one of three internal streams into a buffer of the library's, and the caller's
      *            stream copies it to the caller's frame buffer, which holds the frame in stream order as always)
-     *            | 64 the round-2 pipeline instead: setup and fill of a frame on an internal stream beside the previous frame's
-     *            tile kernel, the tile kernels in order on the caller's stream
      *            | 256 raytrace: no work sharing inside a wave (default: lanes with nothing to walk take postponed subtrees of
      *            other lanes' rays -- a shadow ray's verdict is an OR over the triangles its walk reaches, a closest-hit ray's
      *            hit the minimum of (distance, triangle) over them: same pixels whoever walks what)
      * [6] raytrace: idle lanes of a wave before subtrees are handed over (default 16)
-     * [7] rasterizer: a 16x16-pixel tile whose triangle bins hold more than this many entries is drawn by 2 blocks (strips of 8
-     *     rows), beyond twice that by 4 (0 = never, the default: no threshold was faster than whole tiles) */
+     * [7] unused (0) */
     int32_t tune[8];
     /* Compile-time extras of the reference, off by default like there: */
     int32_t mlaa;            /* configure --enable-mlaa && !$NOMLAA: the morphological anti-aliasing post filter (MLAA.cc) on

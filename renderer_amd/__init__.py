@@ -190,11 +190,11 @@ import atexit as _atexit  # noqa: E402
 _atexit.register(_mark_exit)
 
 
-def tune(xmin=0, rmin=0, chunk=0, lmin=0, bpc=0, exact=0, rowmajor=0, scatter=0, reforder=0, profordered=0, nohelp=0, nocull=0, nopipe=0, pipeordered=0, noshare=0, sharemin=0, rssplit=0, rsnt=0):
+def tune(xmin=0, rmin=0, chunk=0, lmin=0, bpc=0, exact=0, rowmajor=0, scatter=0, reforder=0, profordered=0, nohelp=0, nocull=0, nopipe=0, noshare=0, sharemin=0, rsnt=0):
     """mi355_opts::tune as a list (see include/mi355_render.h); every knob leaves the pixels unchanged.
     (lmin, scatter and nohelp are accepted for old scripts and ignored.)"""
-    flags = (1 if exact else 0) | (2 if rowmajor else 0) | (4 if reforder else 0) | (8 if profordered else 0) | (16 if nocull else 0) | (32 if nopipe else 0) | (64 if pipeordered else 0) | (256 if noshare else 0)
-    return [xmin, rmin, chunk, rsnt, bpc, flags, sharemin, rssplit]
+    flags = (1 if exact else 0) | (2 if rowmajor else 0) | (4 if reforder else 0) | (8 if profordered else 0) | (16 if nocull else 0) | (32 if nopipe else 0) | (256 if noshare else 0)
+    return [xmin, rmin, chunk, rsnt, bpc, flags, sharemin, 0]
 
 
 def device_count() -> int:

@@ -45,8 +45,7 @@ extern "C" WireScratch *mi355i_wire_scratch_create(void);
 extern "C" void mi355i_wire_scratch_destroy(WireScratch *);
 extern "C" int mi355i_wireframe_fits(int W, int H, uint32_t n_tris);
 extern "C" hipError_t mi355i_launch_wireframe(const DevScene *S, const FrameParams *P, WireScratch *w, hipStream_t st);
-extern "C" hipError_t mi355i_launch_raster_pipelined(const DevScene *S, const FrameParams *P, int mode, RasterScratch *s, hipStream_t st,
-                                                     hipStream_t pre, hipEvent_t fill_done, hipEvent_t tile_done);
+extern "C" hipError_t mi355i_launch_raster_overlapped(const DevScene *S, const FrameParams *P, int mode, RasterScratch *s, hipStream_t st, hipEvent_t tile_done);
 extern "C" hipError_t mi355i_launch_frame_copy(uint32_t *dst, const uint32_t *src, int W, int rows, int pitch_words, hipStream_t st, hipEvent_t done);
 extern "C" hipError_t mi355i_launch_frames_copy(void *const *dst, int n_frames, const uint32_t *src, int W, int rows, int pitch_words, hipStream_t st, hipEvent_t done);
 extern "C" int mi355i_raster_grow(RasterScratch *);
@@ -202,14 +201,11 @@ struct mi355_ctx {
     // list and camera table pipe_ctrl / pipe_sel / pipe_cam[k]) into a frame buffer of the library's, and the caller's stream only
     // copies that buffer out: the kernels of consecutive frames do not wait for each other (a dependency that crosses streams
     // costs ~10 us on this stack, a fifth of a raster frame).  ev_tile[k] = the last kernel of set k's last call.
-    // The ordered pipeline (tune flag 64; the fallback when fewer than two usable frame streams are found) keeps the tile
-    // kernels on the caller's stream and runs setup + fill of a frame on `pre` beside the tile kernel of the frame before,
-    // n_pipe = 3 sets taking turns (with two, a frame's setup waits for the tile kernel two frames back: measured slower).
+    // (Where fewer than two usable frame streams are found a frame's kernels simply follow each other on the caller's stream.)
     enum { PIPE_SETS = 7 };
     RasterScratch *rs_pipe[PIPE_SETS] = {};
-    int n_pipe = 3;
-    hipStream_t pre = nullptr;
-    hipEvent_t ev_fill[PIPE_SETS] = {}, ev_tile[PIPE_SETS] = {};
+    bool pre = false;                                   // the resource sets and events below exist
+    hipEvent_t ev_tile[PIPE_SETS] = {};
     bool ev_tile_set[PIPE_SETS] = {};
     int pipe_turn = 0;
     // The frames' streams are picked from PIPE_CANDS candidates so that no two of them, and none and the caller's stream,
@@ -408,7 +404,7 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.ref_order = (flags & 4) ? 1 : 0;
     P.prof_ordered = (flags & 8) ? 1 : 0;
     P.no_cull = (flags & 16) ? 1 : 0;
-    P.no_pipe = (flags & 32) ? 1 : (flags & 64) ? 2 : 0;
+    P.no_pipe = (flags & 32) ? 1 : 0;
     // work sharing inside a wave (k_raytrace.hip): on by default with 16 idle lanes as the threshold; tune[6] sets the threshold,
     // flag 256 turns it off; it needs the wave in lockstep (xmin 64)
     P.steal_min = ((flags & 256) || P.xmin < 64) ? 0 : (t[6] > 0 ? (t[6] > 64 ? 64 : t[6]) : 16);
@@ -423,9 +419,6 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.fill_counter = (uint32_t *)((char *)ctrl + MI_CTRL_FILL_OFF); P.fill_first = 0;
     P.blocks_per_cu = t[4] > 0 ? t[4] : 0;
     P.rs_threads = t[3];
-    // (heavy tiles in strips of rows: tune[7] = the bin-entry threshold; 0 = never, the default -- measured: no threshold pays, a
-    //  tile's time is a chain of dependent round trips, not its volume of work: profiles/r04_analysis.md)
-    P.rs_split = t[7] > 0 ? t[7] : 0;
     P.mlaa = o->mlaa ? 1 : 0;
     if (P.mlaa) {
         if (o->band_count > 1) return fail(-20, "mlaa works on whole frames: no band sharding (mi355_mgpu_render filters the assembled frame)");
@@ -769,13 +762,6 @@ static const mi355_ctx::PipeChoice *pipe_streams_for(mi355_ctx *c, hipStream_t s
     //  four queues, up to PIPE_SETS when the process was started with GPU_MAX_HW_QUEUES=8; MI355_PIPE_SETS caps it)
     static const int cap = [] { const char *v = getenv("MI355_PIPE_SETS"); const int k = v ? atoi(v) : 0; return k >= 1 && k <= (int)mi355_ctx::PIPE_SETS ? k : (int)mi355_ctx::PIPE_SETS; }();
     for (int j = 0; j < n && pc.n < cap; j++) if (!shared[j]) pc.cand[pc.n++] = rep_class[j];
-    if (getenv("MI355_PIPE_DEBUG")) {
-        fprintf(stderr, "mi355: stream %p: queue classes of the frame streams", (void *)st);
-        for (int i = 0; i < N; i++) fprintf(stderr, " %d", c->cand_class[i]);
-        fprintf(stderr, "; chosen");
-        for (int k = 0; k < pc.n; k++) fprintf(stderr, " %d", pc.cand[k]);
-        fprintf(stderr, "\n");
-    }
     if (c->pipe_choice.size() >= 16) c->pipe_choice.erase(c->pipe_choice.begin());
     c->pipe_choice.push_back(pc);
     return &c->pipe_choice.back();
@@ -784,11 +770,9 @@ static const mi355_ctx::PipeChoice *pipe_streams_for(mi355_ctx *c, hipStream_t s
 // The caller's stream sits on a hardware queue of its own (the frame streams were picked so), and all that stream carries for an
 // overlapped frame is a wait and a copy: every (n + 1)-th RAYTRACED frame of a caller therefore runs ON the caller's stream itself --
 // straight into the caller's buffer, no copy --, beside the n frames on the frame streams: four frames in flight on the runtime's
-// four queues instead of three (4 spp 1080p: 966 -> 1 061 fps).  Stream order is the stream's own.  MI355_NO_DIRECT_TURN=1: off.
+// four queues instead of three (4 spp 1080p: 966 -> 1 061 fps).  Stream order is the stream's own.
 static bool direct_turn(mi355_ctx *c, const mi355_ctx::PipeChoice *pc)
 {
-    static const bool off = [] { const char *v = getenv("MI355_NO_DIRECT_TURN"); return v && *v && strcmp(v, "0"); }();
-    if (off) return false;
     c->direct_turn = (c->direct_turn + 1) % (pc->n + 1);
     return c->direct_turn == 0;
 }
@@ -932,22 +916,13 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
             mi355i_prof_lap(1);
             FrameParams Q = P;
             Q.out = fl.fb;
-            e = mi355i_launch_raster_pipelined(&c->dev, &Q, mode, c->rs_pipe[fl.k], fl.ps, fl.ps, nullptr, c->ev_tile[fl.k]);
+            e = mi355i_launch_raster_overlapped(&c->dev, &Q, mode, c->rs_pipe[fl.k], fl.ps, c->ev_tile[fl.k]);
             if (e != hipSuccess) break;
             if (int r = lease_done(c, fl, st, true)) return r;       // (ev_tile is the tile kernel's own completion signal)
             mi355i_prof_lap(5);
             e = mi355i_launch_frame_copy(P.out, Q.out, P.W, P.out_rows, P.pitch_words, st, c->ev_copy[fl.b]);
             mi355i_prof_lap(6);
             if (e == hipSuccess) c->ev_copy_set[fl.b] = true;
-            break;
-        }
-        if (raster_self_clear && rs == c->rscratch && c->pre && P.no_pipe != 1) {
-            // pipelined: this frame's setup + fill on `pre` while `st` still runs the previous frame's tile kernel; the events
-            // ride on the kernels' own completion signals (no marker packets between the tile kernels of `st`)
-            const int k = c->pipe_turn % c->n_pipe; c->pipe_turn = (k + 1) % c->n_pipe;
-            if (c->ev_tile_set[k]) HIP_TRY(hipStreamWaitEvent(c->pre, c->ev_tile[k], 0), -40);     // the set's last user is done
-            e = mi355i_launch_raster_pipelined(&c->dev, &P, mode, c->rs_pipe[k], st, c->pre, c->ev_fill[k], c->ev_tile[k]);
-            if (e == hipSuccess) { c->ev_tile_set[k] = true; c->ev_tile_ext[k] = true; }
             break;
         }
         // (a frame outside the pipeline -- counting frames -- first lets the pipelined frames on other streams finish with
@@ -1144,17 +1119,12 @@ mi355_ctx *mi355_scene_create(const mi355_scene_desc *d, int device)
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     c->rscratch = mi355i_raster_scratch_create();
-    // the raster pipeline of the device entry points: the context's scratch set and a second one, a stream for the
-    // setup / fill kernels, events ordering the two streams (if any of this fails the frames simply are not pipelined)
+    // the overlapped frames of the device entry points: a rasterizer scratch set per frame stream and the event of each set's last
+    // kernel (if any of this fails the frames simply are not overlapped)
     c->rs_pipe[0] = c->rscratch;
     for (int k = 1; k < mi355_ctx::PIPE_SETS; k++) c->rs_pipe[k] = mi355i_raster_scratch_create();
-    if (c->rs_pipe[1] && c->rs_pipe[2] && c->rs_pipe[3] && hipStreamCreateWithFlags(&c->pre, hipStreamNonBlocking) == hipSuccess) {
-        bool ok = true;
-        for (int k = 0; k < mi355_ctx::PIPE_SETS; k++)
-            ok = ok && hipEventCreateWithFlags(&c->ev_fill[k], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&c->ev_tile[k], hipEventDisableTiming) == hipSuccess;
-        if (!ok) { (void)hipStreamDestroy(c->pre); c->pre = nullptr; }
-    } else c->pre = nullptr;
+    c->pre = c->rs_pipe[1] && c->rs_pipe[2] && c->rs_pipe[3];
+    for (int k = 0; c->pre && k < mi355_ctx::PIPE_SETS; k++) c->pre = hipEventCreateWithFlags(&c->ev_tile[k], hipEventDisableTiming) == hipSuccess;
     if (c->pre) {
         // the frames' own streams have a priority of their own: the runtime hands out hardware queues per priority, and a
         // frame stream that shares a queue with the caller's stream would sit behind that stream's waits (measured: every
@@ -1210,8 +1180,7 @@ void mi355_scene_destroy(mi355_ctx *c)
     if (c->rscratch) mi355i_raster_scratch_destroy(c->rscratch);
     if (c->wscratch) mi355i_wire_scratch_destroy(c->wscratch);
     for (int k = 1; k < mi355_ctx::PIPE_SETS; k++) if (c->rs_pipe[k]) mi355i_raster_scratch_destroy(c->rs_pipe[k]);
-    for (int k = 0; k < mi355_ctx::PIPE_SETS; k++) { if (c->ev_fill[k]) (void)hipEventDestroy(c->ev_fill[k]); if (c->ev_tile[k]) (void)hipEventDestroy(c->ev_tile[k]); }
-    if (c->pre) (void)hipStreamDestroy(c->pre);
+    for (int k = 0; k < mi355_ctx::PIPE_SETS; k++) if (c->ev_tile[k]) (void)hipEventDestroy(c->ev_tile[k]);
     for (int k = 0; k < mi355_ctx::PIPE_CANDS; k++) if (c->cand_st[k]) { (void)hipStreamSynchronize(c->cand_st[k]); (void)hipStreamDestroy(c->cand_st[k]); }
     for (int k = 0; k < 2 * mi355_ctx::PIPE_SETS; k++) if (c->ev_copy[k]) (void)hipEventDestroy(c->ev_copy[k]);
     for (int k = 0; k <= mi355_ctx::PIPE_CANDS; k++) if (c->ev_probe[k]) (void)hipEventDestroy(c->ev_probe[k]);
@@ -1854,10 +1823,9 @@ int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_li
     // of DMA became the kernel's time alone.  Not for the rasterizer (its 80 us of kernels would wait for 8 MB to cross PCIe first),
     // the post filter (it works in place) and bands (whose other rows are defined as black: a memset of device memory).
     void *host_alias = nullptr;
-    static const bool no_zero_copy = [] { const char *v = getenv("MI355_NO_ZERO_COPY"); return v && *v && strcmp(v, "0"); }();
     // (... and only where the tiles are culled: a frame traced tile by tile would cross PCIe 32 bytes at a time)
     const bool culled = c->n_cull_boxes > 0 && !(o->tune[5] & (4 | 8 | 16)) && ((long long)((W + 7) / 8) * ((o->height + 7) / 8)) <= (long long)MI_CULL_MAX_TILES;
-    const bool zero_copy = !no_zero_copy && culled && mode >= MI355_MODE_RAYTRACE && !o->mlaa && o->band_count <= 1 && !o->collect_stats && pitch_bytes >= W * 4 && !(pitch_bytes & 3) &&
+    const bool zero_copy = culled && mode >= MI355_MODE_RAYTRACE && !o->mlaa && o->band_count <= 1 && !o->collect_stats && pitch_bytes >= W * 4 && !(pitch_bytes & 3) &&
                            host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4) &&
                            hipHostGetDevicePointer(&host_alias, out_xrgb, 0) == hipSuccess && host_alias;
     if (!zero_copy) (void)hipGetLastError();
@@ -1869,10 +1837,9 @@ int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_li
     mi355_stats tmp;
     mi355_stats *st = stats ? stats : &tmp;
     P.no_pipe = 1;          // (a synchronous frame has nothing to overlap with: its kernels follow each other on the context's stream)
-    static const int fill_first_env = [] { const char *v = getenv("MI355_FILL_FIRST"); return v && *v ? atoi(v) : 0; }();       // (experiments)
     // (waves that start with the background -- the rest of it is written by waves that have run out of pixels.  Measured, frames/s of the
-    //  synchronous call: 4: 1 584, 8: 1 601, 16: 1 593, 32: 1 559, 96: 1 555, 256: 1 570, 1024: 1 531; MI355_FILL_FIRST, scripts/seam_fill_sweep.py)
-    if (zero_copy) P.fill_first = fill_first_env > 0 ? fill_first_env : 16;
+    //  synchronous call: 4: 1 584, 8: 1 601, 16: 1 593, 32: 1 559, 96: 1 555, 256: 1 570, 1024: 1 531; profiles/r04_analysis.md 3)
+    if (zero_copy) P.fill_first = 16;
     for (int attempt = 0;; attempt++) {
         HIP_TRY(hipEventRecord(c->ev0, c->stream), -40);
         if (int r = enqueue_frame(c, mode, P, o->collect_stats, c->stream)) return r;

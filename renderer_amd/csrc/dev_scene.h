@@ -141,7 +141,6 @@ struct FrameParams {
     int32_t fill_first;        // that many waves of the launch START with the background (a frame that crosses PCIe as it is written)
     int32_t blocks_per_cu;     // 0 = occupancy query
     int32_t rs_threads;        // rasterizer: threads per tile block (0 = default)
-    int32_t rs_split;          // rasterizer: bin entries beyond which a tile is cut into strips of rows (0 = never; k_raster.hip: tile_order)
     // the raytracer's compile-time extras (Raytracer.cc:70-80)
     int32_t use_refr;          // REFRACTIONS
     float refr_rate;           // REFRACTIONS_RATE

@@ -209,50 +209,33 @@ __global__ void __launch_bounds__(1024) k_rs_scan(const RsGrid g, const RsBuffer
 #define RS_SCAN_LDS 2048          // frames with at most this many bins (1080p: 511, 4K: 2041): every block of k_rs_fill scans the counts itself
 
 // The work items of the tile kernel: the tiles of a frame whose bins hold entries (the others are background: nobody reads
-// anything for them).  A tile's cost is that of its heaviest phases -- (triangle, scanline) items, then runs -- and the kernel lasts
-// as long as its heaviest tile: three times the average tile on the chessboard (counting frames: 322 k cycles against 110 k).  Both
-// phases work scanline by scanline, so a heavy tile is cut into STRIPS of rows, each a work item of its own: 2 strips of 8 rows
-// when the tile's bins hold more than `split` entries, 4 of 4 rows beyond twice that (the bin's entry count is the cost's proxy;
-// FrameParams::rs_split, tune[7]).  Item = tile | strip << 24 | (strips - 1) << 28; order[0] = their number.  A frame whose items
-// would not fit the list (n_tiles entries) is not split.  One block; off = the frame's bin offsets; tot = 4 words of LDS.
-#define RS_ITEM_TILE(i) ((i) & 0xffffffu)
-#define RS_ITEM_STRIP(i) (((i) >> 24) & 15u)
-#define RS_ITEM_STRIPS(i) (((i) >> 28) + 1u)
-
-MI_DEV void tile_order(const RsGrid &g, const RsBuffers &B, uint32_t f, const uint32_t *off, uint32_t *tot, uint32_t split)
+// anything for them): order[0] = their number, order[1 ..] = the tiles.  One block; off = the frame's bin offsets; tot = 4 words of LDS.
+// (Rounds 4 and 5 measured heavy tiles drawn as strips of rows by several blocks -- of 256, 128 and 64 threads --: never faster than
+//  whole tiles, 12-17 k frames/s against 26 k; a tile's time is its chain of dependent steps, and a strip walks the same chain.)
+MI_DEV void tile_order(const RsGrid &g, const RsBuffers &B, uint32_t f, const uint32_t *off, uint32_t *tot)
 {
     const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t n = (uint32_t)g.n_tiles, per = (n + 255u) / 256u;
     const uint32_t b = (uint32_t)tid * per < n ? (uint32_t)tid * per : n, e = b + per < n ? b + per : n;
     const uint32_t n_global = off[g.n_coarse + 1] - off[g.n_coarse];
     uint32_t *order = B.order + (size_t)f * (n + 1);
-    for (int attempt = 0; attempt < 2; attempt++) {
-        auto strips = [&](uint32_t tile) -> uint32_t {
-            const int tx = (int)(tile % (uint32_t)g.tiles_x), ty = (int)(tile / (uint32_t)g.tiles_x);
-            const int cb = (ty / RS_CB) * g.cx + tx / RS_CB;
-            const uint32_t entries = off[cb + 1] - off[cb] + n_global;
-            if (!entries) return 0u;
-            if (attempt || !split) return 1u;
-            return entries > 2u * split ? 4u : (entries > split ? 2u : 1u);
-        };
-        uint32_t mine = 0;
-        for (uint32_t i = b; i < e; i++) mine += strips(i);
-        uint32_t incl = mine;
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += v; }
-        __syncthreads();
-        if (lane == 63) tot[wid] = incl;
-        __syncthreads();
-        uint32_t before = 0, n_items = 0;
-        for (int w = 0; w < 4; w++) { const uint32_t v = tot[w]; if (w < wid) before += v; n_items += v; }
-        if (n_items > n) continue;                       // (does not fit: once more without strips -- at most n items then)
-        uint32_t at = before + incl - mine;
-        for (uint32_t i = b; i < e; i++) {
-            const uint32_t ns = strips(i);
-            for (uint32_t k = 0; k < ns; k++) order[1 + at++] = i | (k << 24) | ((ns - 1u) << 28);
-        }
-        if (tid == 0) order[0] = n_items;
-        break;
-    }
+    auto active = [&](uint32_t tile) -> uint32_t {
+        const int tx = (int)(tile % (uint32_t)g.tiles_x), ty = (int)(tile / (uint32_t)g.tiles_x);
+        const int cb = (ty / RS_CB) * g.cx + tx / RS_CB;
+        return (off[cb + 1] - off[cb] + n_global) ? 1u : 0u;
+    };
+    uint32_t mine = 0;
+    for (uint32_t i = b; i < e; i++) mine += active(i);
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += v; }
+    __syncthreads();
+    if (lane == 63) tot[wid] = incl;
+    __syncthreads();
+    uint32_t before = 0, n_items = 0;
+    for (int w = 0; w < 4; w++) { const uint32_t v = tot[w]; if (w < wid) before += v; n_items += v; }
+    uint32_t at = before + incl - mine;
+    for (uint32_t i = b; i < e; i++) if (active(i)) order[1 + at++] = i;
+    if (tid == 0) order[0] = n_items;
 }
 
 // exclusive scan of frame f's bin counts into LDS (soff[n_bins + 1]) by a 256-thread block; tot: 4 words of LDS
@@ -332,7 +315,7 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
             }
             off = soff;
         }
-        if (blockIdx.x == order_block) tile_order(g, B, f, off, stot, (uint32_t)F.rs_split);      // (off: this block's scan, or k_rs_scan's)
+        if (blockIdx.x == order_block) tile_order(g, B, f, off, stot);      // (off: this block's scan, or k_rs_scan's)
         if (blockIdx.x < fill_blocks) rs_fill_chunk(g, B, bp, off, n_tris, blockIdx.x, f);
     }
     uint32_t n_rec = B.band_top[f];
@@ -395,10 +378,8 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
             next_w = total_items <= gridDim.x ? total_items : gridDim.x + c + nd * atomicAdd(&B.band_top[n_frames + c], 1u);
         }
         if (slot >= order[0]) { __syncthreads(); const uint32_t nw = next_w; __syncthreads(); w = nw; continue; }
-        const uint32_t item = order[1 + slot], tile = RS_ITEM_TILE(item);
+        const uint32_t tile = order[1 + slot];
         const int tx = (int)(tile % (uint32_t)g.tiles_x), ty = (int)(tile / (uint32_t)g.tiles_x);
-        // (the rows of the tile this block draws: all of them, or its strip of a heavy tile -- tile_order)
-        const int rows = RS_TH / (int)RS_ITEM_STRIPS(item), r0 = (int)RS_ITEM_STRIP(item) * rows, r1 = r0 + rows - 1;
         const FrameParams &F = batch ? batch[f] : P;
         unsigned long long t_mark = prof ? __builtin_readcyclecounter() : 0ull;
         const unsigned long long t_begin = t_mark;
@@ -410,14 +391,14 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
         bool any = false;
         int parity = 0;
         for (uint32_t first = 0; first < total; first += RS_LIST_CAP) {
-            rs_tile_filter(B, f, tx, ty, L, first, lds, tid, nt, r0, r1);
+            rs_tile_filter(B, f, tx, ty, L, first, lds, tid, nt);
             __syncthreads();
             RS_PROF_MARK(1);
             const uint32_t nl = lds.n_list;
             any = any || nl != 0u;
             if (prof && tid == 0) acc[10] += nl;
             for (uint32_t chunk = 0; chunk < nl; chunk += RS_CHUNK) {
-                rs_tile_stage(ty, chunk, nl, parity, lds, tid, nt, r0, r1);
+                rs_tile_stage(ty, chunk, nl, parity, lds, tid, nt);
                 __syncthreads();
                 RS_PROF_MARK(2);
                 if (prof && tid == 0) acc[11] += lds.n_items[parity];
@@ -437,8 +418,8 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
             rs_tile_attr<MODE>(F, B, S.n_tris, f, tx, ty, lds, tid, nt);
             __syncthreads();
             RS_PROF_MARK(5);
-            rs_tile_shade<MODE>(S, F, tx, ty, lds, tid, nt, plots, r0, r1);
-        } else if (clear_rows) rs_tile_blank(F, tx, ty, tid, nt, r0, r1);     // (nobody else clears a tile whose bin holds entries)
+            rs_tile_shade<MODE>(S, F, tx, ty, lds, tid, nt, plots);
+        } else if (clear_rows) rs_tile_blank(F, tx, ty, tid, nt);     // (nobody else clears a tile whose bin holds entries)
         const uint32_t nw = next_w;                           // (written by thread 0 at the top of this tile, barriers ago)
         __syncthreads();                                      // (the next tile clears the keys and draws the next item)
         w = nw;
@@ -451,10 +432,9 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
         }
     }
     if (clear_rows) {
-        // Pipelined single frames (mi355i_launch_raster_pipelined): the background (Screen::ClearScreen) is written here, by the
+        // Overlapped single frames (mi355i_launch_raster_overlapped): the background (Screen::ClearScreen) is written here, by the
         // blocks without a tile of their own, a wave per output row and 16 bytes per lane; the 16x16 tiles that hold triangles
-        // are written in full by their blocks.  (The fill kernel of this frame ran beside the previous frame's tile kernel: it
-        // must not touch the output.)
+        // are written in full by their blocks.
         const uint32_t *off = B.offset;
         const bool global_any = off[g.n_coarse + 1] != off[g.n_coarse];
         const uint32_t first = total_items + 64u <= gridDim.x ? total_items : 0u, nb = gridDim.x - first;
@@ -921,18 +901,14 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
     return hipSuccess;
 }
 
-// pre / fill_done: pipelined single frames -- setup and fill go to the stream `pre` (beside the previous frame's tile kernel on
-// `st`), the tile kernel waits for them on `st` and also writes the background (the fill kernel must not touch the output then)
+// tile_done != NULL: one of the overlapped frames of the device entry points (capi.hip, enqueue_frame) -- the whole frame on its
+// own stream `st`; the tile kernel also writes the background (the fill kernel leaves the output alone) and carries tile_done as
+// its own completion signal.
 template <int MODE>
 static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const FrameParams *d_batch, int n_frames, RasterScratch *s,
-                                hipStream_t st, hipStream_t pre = nullptr, hipEvent_t fill_done = nullptr, hipEvent_t tile_done = nullptr)
+                                hipStream_t st, hipEvent_t tile_done = nullptr)
 {
-    // piped: setup + fill on `pre`, the tile kernel on `st` behind fill_done.  whole: the frame's own stream carries all
-    // three kernels (pre == st, no fill_done); the tile kernel clears the background and signals tile_done as in a piped frame.
-    const bool whole = pre != nullptr && fill_done == nullptr && tile_done != nullptr && n_frames == 1;
-    const bool piped = pre != nullptr && fill_done != nullptr && n_frames == 1;
-    hipStream_t st_tile = st;
-    if (piped) st = pre;
+    const bool whole = tile_done != nullptr && n_frames == 1;
     const RsGrid g = rs_grid(P->W, P->H);
     hipError_t e = tiled_ensure(s, g, S->n_tris, n_frames, st);
     if (e != hipSuccess) return e;
@@ -942,26 +918,19 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     mi355i_prof_lap(2);
     // (the fill kernel's grid also has to carry the band items: at least four blocks per CU)
     const dim3 fill_grid(per_tri.x > 1024u ? per_tri.x : 1024u, n_frames);
-    if (piped && g.n_bins <= RS_SCAN_LDS)       // (fill_done is this kernel's own completion signal)
-        hipExtLaunchKernelGGL(k_rs_fill<true>, fill_grid, dim3(256), 0, st, nullptr, fill_done, 0, g, s->B, S->n_tris, *P, d_batch, P->counters, 0);
-    else if (g.n_bins <= RS_SCAN_LDS) hipLaunchKernelGGL(k_rs_fill<true>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters, piped || whole ? 0 : 1);
+    if (g.n_bins <= RS_SCAN_LDS) hipLaunchKernelGGL(k_rs_fill<true>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters, whole ? 0 : 1);
     else {
         hipLaunchKernelGGL(k_rs_scan, dim3(n_frames), dim3(1024), 0, st, g, s->B, P->counters);
-        hipLaunchKernelGGL(k_rs_fill<false>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters, piped || whole ? 0 : 1);
+        hipLaunchKernelGGL(k_rs_fill<false>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters, whole ? 0 : 1);
     }
     mi355i_prof_lap(3);
-    if (piped) {
-        if (g.n_bins > RS_SCAN_LDS && (e = hipEventRecord(fill_done, pre)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(st_tile, fill_done, 0)) != hipSuccess) return e;
-        st = st_tile;
-    }
     // Tiles that hold triangles are handed out by a dispenser (a fixed assignment to resident blocks balances unequal
     // tiles badly: measured); 2048 blocks = eight per CU cover a 1080p frame's ~1100 such tiles with one tile per block.
     long long blocks = (long long)n_frames * g.n_tiles;
     if (blocks > 2048) blocks = 2048;
     // threads per tile: mi355_opts::tune[3] (64..512, whole waves), default 256
     const int nt = P->rs_threads >= 64 && P->rs_threads <= RS_MAX_THREADS && (P->rs_threads & 63) == 0 ? P->rs_threads : 256;
-    if (piped || whole) hipExtLaunchKernelGGL((k_rs_tile<MODE, 4>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, nullptr, tile_done, 0, *S, *P, d_batch, n_frames, g, s->B, 1);
+    if (whole) hipExtLaunchKernelGGL((k_rs_tile<MODE, 4>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, nullptr, tile_done, 0, *S, *P, d_batch, n_frames, g, s->B, 1);
     else if (n_frames > 1) hipLaunchKernelGGL((k_rs_tile<MODE, 5>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B, 0);
     else hipLaunchKernelGGL((k_rs_tile<MODE, 4>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B, 0);
     mi355i_prof_lap(4);
@@ -969,28 +938,24 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
 }
 
 static hipError_t raster_dispatch(const DevScene *S, const FrameParams *P, const FrameParams *d_batch, int n_frames, int mode,
-                                  RasterScratch *s, hipStream_t st, hipStream_t pre = nullptr, hipEvent_t fill_done = nullptr,
-                                  hipEvent_t tile_done = nullptr)
+                                  RasterScratch *s, hipStream_t st, hipEvent_t tile_done = nullptr)
 {
     switch (mode) {
-    case M_AMBIENT: return raster_frames<M_AMBIENT>(S, P, d_batch, n_frames, s, st, pre, fill_done, tile_done);
-    case M_GOURAUD: return raster_frames<M_GOURAUD>(S, P, d_batch, n_frames, s, st, pre, fill_done, tile_done);
-    case M_PHONG: return raster_frames<M_PHONG>(S, P, d_batch, n_frames, s, st, pre, fill_done, tile_done);
-    case M_PHONG_SH: return raster_frames<M_PHONG_SH>(S, P, d_batch, n_frames, s, st, pre, fill_done, tile_done);
-    case M_PHONG_SOFT: return raster_frames<M_PHONG_SOFT>(S, P, d_batch, n_frames, s, st, pre, fill_done, tile_done);
+    case M_AMBIENT: return raster_frames<M_AMBIENT>(S, P, d_batch, n_frames, s, st, tile_done);
+    case M_GOURAUD: return raster_frames<M_GOURAUD>(S, P, d_batch, n_frames, s, st, tile_done);
+    case M_PHONG: return raster_frames<M_PHONG>(S, P, d_batch, n_frames, s, st, tile_done);
+    case M_PHONG_SH: return raster_frames<M_PHONG_SH>(S, P, d_batch, n_frames, s, st, tile_done);
+    case M_PHONG_SOFT: return raster_frames<M_PHONG_SOFT>(S, P, d_batch, n_frames, s, st, tile_done);
     }
     return hipErrorInvalidValue;
 }
 
-// One frame outside the caller's stream (capi.hip, enqueue_frame).  fill_done = NULL: the whole frame on `pre` (= st), the
-// overlapped frames of DESIGN.md 4.6.  Else the ordered pipeline: setup and fill on `pre` -- beside whatever `st` is still
-// doing, normally the previous frame's tile kernel -- and the tile kernel on `st` behind fill_done.  Either way the tile
-// kernel clears the background and carries tile_done; the scratch set must not be in use by a frame whose tile kernel has not
-// finished (the caller keeps several sets and orders them).
-extern "C" hipError_t mi355i_launch_raster_pipelined(const DevScene *S, const FrameParams *P, int mode, RasterScratch *s, hipStream_t st,
-                                                     hipStream_t pre, hipEvent_t fill_done, hipEvent_t tile_done)
+// One overlapped frame (capi.hip, enqueue_frame): all three kernels on the frame's own stream `st`; the tile kernel
+// clears the background and carries tile_done.  The scratch set must not be in use by a frame whose tile kernel has not finished
+// (the caller keeps several sets and orders them).
+extern "C" hipError_t mi355i_launch_raster_overlapped(const DevScene *S, const FrameParams *P, int mode, RasterScratch *s, hipStream_t st, hipEvent_t tile_done)
 {
-    return raster_dispatch(S, P, nullptr, 1, mode, s, st, pre, fill_done, tile_done);
+    return raster_dispatch(S, P, nullptr, 1, mode, s, st, tile_done);
 }
 
 // The finished frame of an overlapped raster frame (capi.hip) from the library's buffer to the caller's: `rows` rows of W

@@ -591,11 +591,9 @@ MI_HD void rs_tile_clear(RsTileLds &lds, int tid, int nt)
 }
 
 // phase 1: bin entries [first, first + RS_LIST_CAP) of the tile's bins -> LDS list of the triangles whose box touches the tile
-// (r0 .. r1: the rows of the tile this block draws -- all sixteen, or a strip of them when the tile is shared by several blocks)
-MI_HD void rs_tile_filter(const RsBuffers &B, uint32_t frame, int tx, int ty, const RsTileBins &L, uint32_t first, RsTileLds &lds, int tid, int nt,
-                          int r0 = 0, int r1 = RS_TH - 1)
+MI_HD void rs_tile_filter(const RsBuffers &B, uint32_t frame, int tx, int ty, const RsTileBins &L, uint32_t first, RsTileLds &lds, int tid, int nt)
 {
-    const int ya = ty * RS_TH + r0, yb = ty * RS_TH + r1;
+    const int ya = ty * RS_TH, yb = ty * RS_TH + RS_TH - 1;
     const uint32_t n = L.total();
     uint32_t end = first + RS_LIST_CAP;
     if (end > n) end = n;
@@ -618,7 +616,7 @@ MI_HD void rs_tile_filter(const RsBuffers &B, uint32_t frame, int tx, int ty, co
 }
 
 // phase 2a (thread = slot of the chunk): list entry `chunk + tid` -> one work item per scanline of the tile it touches
-MI_HD void rs_tile_stage(int ty, uint32_t chunk, uint32_t n_list, int parity, RsTileLds &lds, int tid, int nt, int r0 = 0, int r1 = RS_TH - 1)
+MI_HD void rs_tile_stage(int ty, uint32_t chunk, uint32_t n_list, int parity, RsTileLds &lds, int tid, int nt)
 {
     // (a block of fewer than RS_CHUNK threads takes several slots per thread: round 4 staged only the first `nt` entries of a
     //  chunk and a 64- or 128-thread block -- tune[3] -- lost the triangles behind them)
@@ -627,7 +625,7 @@ MI_HD void rs_tile_stage(int ty, uint32_t chunk, uint32_t n_list, int parity, Rs
         if (e >= n_list) return;
         const int miny = (int)(lds.list[e][1] & 0xffffu), maxy = (int)(lds.list[e][1] >> 16);
         const int Y0 = ty * RS_TH;
-        const int ys = miny > Y0 + r0 ? miny : Y0 + r0, ye = maxy < Y0 + r1 ? maxy : Y0 + r1;
+        const int ys = miny > Y0 ? miny : Y0, ye = maxy < Y0 + RS_TH - 1 ? maxy : Y0 + RS_TH - 1;
         if (ys > ye) continue;
         const uint32_t base = RS_ATOMIC_ADD_U32(&lds.n_items[parity], (uint32_t)(ye - ys + 1));
         for (int y = ys; y <= ye; y++) lds.items[base + (uint32_t)(y - ys)] = (uint16_t)((slot << 4) | (uint32_t)(y - Y0));
@@ -789,9 +787,9 @@ MI_HD void rs_tile_attr(const FrameParams &P, const RsBuffers &B, uint32_t n_tri
 }
 
 // a tile without entries: the background (Screen::ClearScreen, Rasterizers.cc:326)
-MI_HD void rs_tile_blank(const FrameParams &P, int tx, int ty, int tid, int nt, int r0 = 0, int r1 = RS_TH - 1)
+MI_HD void rs_tile_blank(const FrameParams &P, int tx, int ty, int tid, int nt)
 {
-    for (int i = r0 * RS_TW + tid; i < (r1 + 1) * RS_TW; i += nt) {
+    for (int i = tid; i < RS_TPIX; i += nt) {
         const int x = tx * RS_TW + (i % RS_TW), y = ty * RS_TH + (i / RS_TW);
         if (x >= P.W || y >= P.H) continue;
         const int orow = rs_out_row(P, y);
@@ -802,10 +800,9 @@ MI_HD void rs_tile_blank(const FrameParams &P, int tx, int ty, int tid, int nt, 
 // phase 4 (thread = pixel): Screen::Plot<> (Screen.cc:34-56) for the colour-interpolating modes, IlluminatePixel +
 // LightingEquation (Screen.cc:77-93, LightingEq.h:45-170) for the Phong modes.  Every pixel of the tile is written.
 template <int MODE>
-MI_HD void rs_tile_shade(const DevScene &S, const FrameParams &P, int tx, int ty, const RsTileLds &lds, int tid, int nt, unsigned long long &plots,
-                         int r0 = 0, int r1 = RS_TH - 1)
+MI_HD void rs_tile_shade(const DevScene &S, const FrameParams &P, int tx, int ty, const RsTileLds &lds, int tid, int nt, unsigned long long &plots)
 {
-    for (int i = r0 * RS_TW + tid; i < (r1 + 1) * RS_TW; i += nt) {
+    for (int i = tid; i < RS_TPIX; i += nt) {
         const int x = tx * RS_TW + (i % RS_TW), y = ty * RS_TH + (i / RS_TW);
         if (x >= P.W || y >= P.H) continue;
         const int orow = rs_out_row(P, y);

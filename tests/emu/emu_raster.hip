@@ -49,7 +49,6 @@ void fill(FrameParams &P, const mi355_camera &cam, const mi355_light *lights, in
     P.n_frames = 1;
 }
 
-int g_emu_strips = 1;
 
 template <int MODE>
 void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, RsBuffers &B)
@@ -104,20 +103,16 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
 #define ALL_THREADS(stmt) for (int tid = 0; tid < nt; tid++) { stmt; }
 #define ALL_THREADS_REVERSED(stmt) for (int tid = nt - 1; tid >= 0; tid--) { stmt; }
                 if (!total) continue;                          // background: cleared by rs_setup
-                // (EMU_STRIPS = 2 / 4: every tile as that many work items, strips of 8 / 4 rows -- what k_rs_tile does with heavy tiles)
-                const int n_strips = g_emu_strips;
-                for (int strip = 0; strip < n_strips; strip++) {
-                const int rows = RS_TH / n_strips, r0 = strip * rows, r1 = r0 + rows - 1;
                 memset(&lds, 0xcd, sizeof lds);                // LDS is not initialised on the device either
                 ALL_THREADS(rs_tile_clear(lds, tid, nt));
                 bool any = false;
                 int parity = 0;
                 for (uint32_t first = 0; first < total; first += RS_LIST_CAP) {
-                    ALL_THREADS_REVERSED(rs_tile_filter(B, (uint32_t)f, tx, ty, L, first, lds, tid, nt, r0, r1));      // (any thread order)
+                    ALL_THREADS_REVERSED(rs_tile_filter(B, (uint32_t)f, tx, ty, L, first, lds, tid, nt));      // (any thread order)
                     const uint32_t nl = lds.n_list;
                     any = any || nl != 0u;
                     for (uint32_t chunk = 0; chunk < nl; chunk += RS_CHUNK) {
-                        ALL_THREADS_REVERSED(rs_tile_stage(ty, chunk, nl, parity, lds, tid, nt, r0, r1));
+                        ALL_THREADS_REVERSED(rs_tile_stage(ty, chunk, nl, parity, lds, tid, nt));
                         ALL_THREADS(rs_tile_depth<MODE>(F[f], B, S.n_tris, (uint32_t)f, tx, ty, chunk, parity, lds, tid, nt, zt));
                         lds.n_items[parity ^ 1] = 0u;
                         if (chunk + RS_CHUNK >= nl) lds.n_list = 0u;
@@ -127,8 +122,7 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
                 if (!any) continue;
                 ALL_THREADS_REVERSED(rs_tile_runs(lds, tid, nt));
                 ALL_THREADS(rs_tile_attr<MODE>(F[f], B, S.n_tris, (uint32_t)f, tx, ty, lds, tid, nt));
-                ALL_THREADS(rs_tile_shade<MODE>(S, F[f], tx, ty, lds, tid, nt, plots, r0, r1));
-                }
+                ALL_THREADS(rs_tile_shade<MODE>(S, F[f], tx, ty, lds, tid, nt, plots));
                 if (F[0].counters && F[0].raster_stats) { F[0].counters[CS_ZTESTS] += zt; F[0].counters[CS_PLOTS] += plots; }
             }
 }
@@ -142,7 +136,6 @@ extern "C" int emu_raster(uint32_t n_tris, uint32_t n_verts, const float *rs_tri
                           const mi355_opts *o, const float *const *shadow_maps, uint32_t *const *outs, int pitch_words,
                           unsigned long long *stats4, uint32_t bins_cap, unsigned long long *overflow, uint32_t band_cap_arg)
 {
-    { const char *v = getenv("EMU_STRIPS"); const int k = v ? atoi(v) : 1; g_emu_strips = (k == 2 || k == 4 || k == 8 || k == 16) ? k : 1; }
     DevScene S;
     memset(&S, 0, sizeof S);
     S.n_tris = n_tris; S.n_verts = n_verts;

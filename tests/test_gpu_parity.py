@@ -308,18 +308,6 @@ def test_raster_threads_per_tile_do_not_change_pixels(oracle, oracle_scene, gpu_
         assert_same(g, o)
 
 
-@pytest.mark.parametrize("mesh,mode,split", [("chessboard.tri", 8, 64), ("chessboard.tri", 6, 400), ("dragon_vis.ply", 5, 1), ("dragon_vis.ply", 4, 150)])
-def test_heavy_tiles_drawn_in_strips_of_rows(oracle, oracle_scene, gpu_scene, mesh, mode, split):
-    """mi355_opts::tune[7]: a tile whose bins hold more entries than the threshold is drawn by two or four blocks, strips of 8 / 4
-    rows each (k_raster.hip: tile_order).  Off by default -- no threshold was faster than whole tiles, profiles/r04_analysis.md --
-    but the frames are the frames: thresholds from "every tile with a triangle in four strips" upwards, counters included."""
-    g, o = both_frames(oracle, oracle_scene, gpu_scene, mesh, mode, 1000, 563, 9, tune=R.tune(rssplit=split))
-    assert_same(g, o)
-    g, o = both_frames(oracle, oracle_scene, gpu_scene, mesh, mode, 1000, 563, 9, collect_stats=1, tune=R.tune(rssplit=split))
-    assert_same(g, o)
-    assert g[2].tris_drawn == o[2].tris_drawn and g[2].spans == o[2].spans and g[2].ztests == o[2].ztests
-
-
 @pytest.mark.parametrize("mode", [1, 2, 4, 5, 6, 7, 8, 9, 10])
 def test_model_loaded_from_3ds(oracle, oracle_scene, gpu_scene, mode):
     """legocar.3ds through the host layer's own .3ds reader vs the oracle fed with the REAL lib3ds' dump of the same

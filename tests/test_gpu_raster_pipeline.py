@@ -83,13 +83,12 @@ def test_frames_on_two_streams(scene):
         assert np.array_equal(got[k], reference(scene, 6, 5 * k, W, H))
 
 
-@pytest.mark.parametrize("variant", ["overlapped", "ordered"])
-def test_padded_pitch_and_bands(scene, variant):
+def test_padded_pitch_and_bands(scene):
     """overlapped frames go through a buffer of the library's with the caller's pitch: the caller's padding words stay as they
     were, banded frames (interleaved rows, compact or in place) land where the one-stream path puts them"""
     W, H, PAD = 500, 300, 12
     stream = torch.cuda.current_stream()
-    tn = R.tune(pipeordered=1) if variant == "ordered" else R.tune()
+    tn = R.tune()
     jobs = []
     for i in range(10):
         cam, lights, n = R.benchmark_frame(11 * i)
@@ -110,17 +109,3 @@ def test_padded_pitch_and_bands(scene, variant):
         torch.cuda.synchronize()
         assert torch.equal(a, b), "mode %d %r" % (mode, kw)
         assert bool((a[:, W:] == 0x5a5a5a).all())
-
-
-def test_the_ordered_pipeline_draws_the_same_frames(scene):
-    W, H = 640, 480
-    stream = torch.cuda.current_stream()
-    bufs = torch.zeros((9, H, W), dtype=torch.int32, device="cuda")
-    for k in range(9):
-        cam, lights, n = R.benchmark_frame(4 * k)
-        tn = R.tune(pipeordered=1) if k % 3 else R.tune()         # the two pipelines take turns on the same scratch sets
-        scene.render_device(6 + 2 * (k % 2), cam, lights, n, R.default_opts(W, H, tune=tn), bufs[k].data_ptr(), W * 4, 0, stream.cuda_stream)
-    torch.cuda.synchronize()
-    got = bufs.cpu().numpy().view(np.uint32)
-    for k in range(9):
-        assert np.array_equal(got[k], reference(scene, 6 + 2 * (k % 2), 4 * k, W, H)), "frame %d" % k

@@ -64,19 +64,6 @@ def test_emulated_tiles_equal_the_oracle(oracle, oracle_scene, host_scene, mesh,
     assert st["plots"] == int((refs[0] != 0).sum()) or mode in (4, 5)        # winners only (black winners are possible in 4/5)
 
 
-@pytest.mark.parametrize("strips", [2, 4])
-@pytest.mark.parametrize("mesh,mode,W,H", [("chessboard.tri", 8, 640, 360), ("dragon_vis.ply", 5, 333, 217), ("statue.ply", 6, 500, 283)])
-def test_tiles_drawn_in_strips_of_rows_equal_the_oracle(oracle, oracle_scene, host_scene, monkeypatch, mesh, mode, W, H, strips):
-    """k_rs_tile cuts a heavy tile into strips of 8 or 4 rows, each a work item of its own (k_raster.hip: tile_order): the filter,
-    the (triangle, scanline) items, the runs and the shading restricted to the strip's rows.  Here EVERY tile is drawn that way;
-    same frame, same Z-test and plot counts (a scanline belongs to one strip)."""
-    monkeypatch.setenv("EMU_STRIPS", str(strips))
-    outs, refs, st, ost = frames(oracle, oracle_scene, host_scene, mesh, mode, W, H, frame=3)
-    assert np.array_equal(outs[0], refs[0])
-    assert (st["ztests"], st["tris_drawn"]) == (ost[0].ztests, ost[0].tris_drawn)
-    assert st["plots"] == int((refs[0] != 0).sum()) or mode in (4, 5)
-
-
 def test_emulated_batch_equals_single_frames(oracle, oracle_scene, host_scene):
     outs, refs, _, _ = frames(oracle, oracle_scene, host_scene, "chessboard.tri", 8, 640, 360, frame=10, n_frames=5)
     for f in range(5):
