@@ -1,287 +1,20 @@
-// capi.hip -- implementation of include/mi355_render.h: context, HBM layouts, dispatch.
+// capi.hip -- implementation of include/mi355_render.h: dispatch (options, frame parameters, one frame's launches) and the entry
+// points.  The context and what the library's other translation units share: capi_ctx.h; trees: capi_tree.hip; the frame streams:
+// capi_streams.hip; statistics, probes and known-answer tests: capi_diag.hip.
 //
 // There is no CPU rendering path in this library: every mode runs as HIP kernels and every
 // entry point fails (negative return + mi355_last_error) when no HIP device is usable.
-#include "../../include/mi355_render.h"
-#include "dev_math.h"
-#include "dev_scene.h"
-#include "bvh_build.h"
+#include "capi_ctx.h"
 
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cfloat>
-#include <chrono>
-#include <cmath>
-#include <cstdarg>
-#include <utility>
-#include <mutex>
-#include <cstdio>
-#include <cstring>
-#include <string>
-#include <vector>
-
-// kernel launchers (defined next to their kernels)
-extern "C" hipError_t mi355i_launch_tile_select(const FrameParams *P, const float4 *boxes, int n_boxes, const uint32_t *order, uint32_t *sel, uint32_t *cnt,
-                                                uint32_t *gmask, hipStream_t st);
-extern "C" int mi355i_raytrace_waves_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext);
-extern "C" void mi355i_raytrace_variant(int stats, int *exact, int *ordered, int *waves, int ext);
-extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int ordered, int waves, int batch, int ext,
-                                             int stack_depth, int n_blocks, hipStream_t);
-extern "C" hipError_t mi355i_launch_points(const DevScene *, const FrameParams *, int as_triangles, hipStream_t);
-extern "C" hipError_t mi355i_launch_mlaa(uint32_t *d_pixels, uint32_t *d_scratch, int resX, int resY, hipStream_t st);
-struct RasterScratch;
-extern "C" hipError_t mi355i_launch_raster(const DevScene *, const FrameParams *, int mode, RasterScratch *,
-                                           hipStream_t);
-extern "C" hipError_t mi355i_launch_raster_batch(const DevScene *, const FrameParams *frames, int n_frames, int mode, RasterScratch *,
-                                                 hipStream_t);
-extern "C" hipError_t mi355i_launch_shadowmap(const DevScene *, const float *light_pos, const float *w2l, int size,
-                                              float *d_map, RasterScratch *, hipStream_t);
-extern "C" RasterScratch *mi355i_raster_scratch_create(void);
-extern "C" void mi355i_raster_scratch_destroy(RasterScratch *);
-extern "C" uint32_t mi355i_raster_overflow(RasterScratch *);
-struct WireScratch;
-extern "C" WireScratch *mi355i_wire_scratch_create(void);
-extern "C" void mi355i_wire_scratch_destroy(WireScratch *);
-extern "C" int mi355i_wireframe_fits(int W, int H, uint32_t n_tris);
-extern "C" hipError_t mi355i_launch_wireframe(const DevScene *S, const FrameParams *P, WireScratch *w, hipStream_t st);
-extern "C" hipError_t mi355i_launch_raster_overlapped(const DevScene *S, const FrameParams *P, int mode, RasterScratch *s, hipStream_t st, hipEvent_t tile_done);
-extern "C" hipError_t mi355i_launch_frame_copy(uint32_t *dst, const uint32_t *src, int W, int rows, int pitch_words, hipStream_t st, hipEvent_t done);
-extern "C" hipError_t mi355i_launch_frames_copy(void *const *dst, int n_frames, const uint32_t *src, int W, int rows, int pitch_words, hipStream_t st, hipEvent_t done);
-extern "C" int mi355i_raster_grow(RasterScratch *);
-
-namespace {
-
-thread_local std::string g_err;
-
-// MI355_HOST_PROF=1: where the HOST's time goes in the device entry points (scripts/raster_pipe_variants.py: at 25 k raster frames
-// per second the host has 40 us per frame for all of its calls).  Sections are summed and printed when the process ends.
-struct HostProf {
-    enum { N = 12 };
-    double sum[N] = {}; unsigned long long cnt[N] = {};
-    const char *name[N] = {"validate + fill_params", "stream choice + lease_begin", "raster: setup launch", "raster: fill launch", "raster: tile launch",
-                           "lease_done (wait on the caller's stream)", "frame copy launch", "raytrace: select + trace launches", "other", "", "", ""};
-    bool on = false;
-    HostProf() { const char *v = getenv("MI355_HOST_PROF"); on = v && *v && strcmp(v, "0"); }
-    ~HostProf()
-    {
-        if (!on) return;
-        for (int i = 0; i < N; i++) if (cnt[i]) fprintf(stderr, "mi355 host profile: %-44s %9llu x %7.2f us\n", name[i], cnt[i], sum[i] / (double)cnt[i]);
-    }
-    static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-};
-HostProf g_prof;
-struct ProfMark {
-    double t;
-    ProfMark() : t(g_prof.on ? HostProf::now() : 0.0) {}
-    void lap(int i) { if (g_prof.on) { const double n = HostProf::now(); g_prof.sum[i] += n - t; g_prof.cnt[i]++; t = n; } }
-};
-
-// devices that hold contexts of this library (mi355_host_free waits for their work -- and must not initialise the others)
-static std::mutex g_dev_mu;
-static int g_dev_use[64];
-static void device_use(int device, int delta)
-{
-    if (device < 0 || device >= 64) return;
-    std::lock_guard<std::mutex> lk(g_dev_mu);
-    g_dev_use[device] += delta;
-}
-
-// MI355_HOST_TRACE=<file>: one line per operation that lets the GPU write into host memory of the caller's (registrations, frames,
-// read-backs), flushed line by line -- the address of a "Memory access fault by GPU" can then be matched to the call that caused it
-void host_trace(const char *fmt, ...)
-{
-    static FILE *f = [] { const char *p = getenv("MI355_HOST_TRACE"); return p && *p ? fopen(p, "a") : (FILE *)nullptr; }();
-    if (!f) return;
-    va_list ap;
-    va_start(ap, fmt);
-    vfprintf(f, fmt, ap);
-    va_end(ap);
-    fputc('\n', f);
-    fflush(f);
-}
-
-int fail(int code, const char *fmt, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_err = buf;
-    return code;
-}
-
-#define HIP_TRY(expr, code)                                                              \
-    do {                                                                                 \
-        hipError_t e_ = (expr);                                                          \
-        if (e_ != hipSuccess) return fail(code, "%s: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-    hipError_t ensure(size_t n)
-    {
-        if (n <= bytes) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr; bytes = 0;
-        hipError_t e = hipMalloc(&p, n);
-        if (e == hipSuccess) bytes = n;
-        return e;
-    }
-    template <class T> hipError_t upload(const std::vector<T> &v)
-    {
-        hipError_t e = ensure(v.size() * sizeof(T) + 16);
-        if (e != hipSuccess) return e;
-        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
-};
-
-// page-locked host staging, kept per context: copies from / to it are DMA transfers on the context's stream (a plain
-// hipMemcpy of pageable memory goes through the runtime's own staging and pinning, measured at up to 25 ms per call)
-struct PinBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-    hipError_t ensure(size_t n)
-    {
-        if (n <= bytes) return hipSuccess;
-        if (p) (void)hipHostFree(p);
-        p = nullptr; bytes = 0;
-        hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
-        if (e == hipSuccess) bytes = n;
-        return e;
-    }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
-};
-
-struct V3h { float x, y, z; };
-inline V3h subh(V3h a, V3h b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-inline V3h crossh(V3h l, V3h r) { return {l.y * r.z - r.y * l.z, r.x * l.z - l.x * r.z, l.x * r.y - l.y * r.x}; }
-inline float lenh(V3h v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
-inline float disth(V3h a, V3h b) { float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z; return sqrtf(dx * dx + dy * dy + dz * dz); }
-
-} // namespace
 
 // (for the launchers in the other translation units: laps of the calling thread's stopwatch; no-ops unless MI355_HOST_PROF is set)
 static thread_local ProfMark t_prof;
 extern "C" void mi355i_prof_start(void) { if (g_prof.on) t_prof = ProfMark(); }
 extern "C" void mi355i_prof_lap(int i) { t_prof.lap(i); }
 
-// layout of mi355_ctx::ctrl
-static const size_t MI_CTRL_DISPENSER_OFF = 4096;
-// (one more counter behind the dispenser's: the tile rows of the background, k_raytrace)
-static const size_t MI_CTRL_FILL_OFF = MI_CTRL_DISPENSER_OFF + (size_t)MI_DISPENSERS * MI_DISPENSER_STRIDE * 4;
-static const size_t MI_CTRL_BYTES = MI_CTRL_FILL_OFF + 256;
-static_assert(16 + sizeof(unsigned long long) * CS_COUNT <= MI_CTRL_DISPENSER_OFF, "counters overlap the dispenser");
 
-struct mi355_ctx {
-    int device = 0;
-    int n_cus = 256;
-    // host copy of the scene (needed again when the BVH arrives / changes)
-    uint32_t nV = 0, nT = 0;
-    std::vector<float> vpos, vnrm, tcenter, tnormal, tcolorf, td, te;
-    std::vector<uint32_t> vao, tcolor32;
-    std::vector<int32_t> tidx;
-    std::vector<uint8_t> ttwo;
-    bool has_bvh = false;
-    // device
-    DevBuf walk, tri_edge, tri_shade, rs_tri, rs_col, rs_idx, rs_vert;
-    DevBuf ctrl;            // [0] (16 B, unused) | counters[CS_COUNT] | at MI_CTRL_DISPENSER_OFF: the raytrace pixel
-                            // dispenser (MI_DISPENSERS counters, MI_DISPENSER_STRIDE words apart) -- one memset per frame
-    DevBuf fb, fbf;         // internal framebuffer for the host-output path
-    DevBuf mlaa;            // MLAA's "input" copy of the frame (colours + separation flags)
-    DevBuf cam_table;       // batched launches: FrameCam[MI355_MAX_BATCH]
-    DevBuf bvh_prim, bvh_list[2], bvh_lvl[2], bvh_tree, bvh_cnt;   // mi355_build_bvh work buffers (kept for rebuilds)
-    DevBuf bvh_big[2], bvh_task[2], bvh_gthr[2], bvh_gbin, bvh_tcnt, bvh_choff, bvh_num[5], bvh_out, bvh_in_td, bvh_in_te;
-    bool bvh_inputs_ready = false;
-    // Calls of the device entry points overlap inside the library (enqueue_frame): a frame -- all its kernels --
-    // runs on one of up to PIPE_SETS internal streams with resource set k (rasterizer scratch rs_pipe[k]; control block, tile
-    // list and camera table pipe_ctrl / pipe_sel / pipe_cam[k]) into a frame buffer of the library's, and the caller's stream only
-    // copies that buffer out: the kernels of consecutive frames do not wait for each other (a dependency that crosses streams
-    // costs ~10 us on this stack, a fifth of a raster frame).  ev_tile[k] = the last kernel of set k's last call.
-    // (Where fewer than two usable frame streams are found a frame's kernels simply follow each other on the caller's stream.)
-    enum { PIPE_SETS = 7 };
-    RasterScratch *rs_pipe[PIPE_SETS] = {};
-    bool pre = false;                                   // the resource sets and events below exist
-    hipEvent_t ev_tile[PIPE_SETS] = {};
-    bool ev_tile_set[PIPE_SETS] = {};
-    int pipe_turn = 0;
-    // The frames' streams are picked from PIPE_CANDS candidates so that no two of them, and none and the caller's stream,
-    // share a hardware queue: the runtime spreads all streams of the process over four queues, and streams that share one
-    // run in submission order -- a frame stream behind the caller's stream sits behind that stream's waits (measured: 16 k
-    // fps with one such stream among three, 26 k with none).  Which streams share is not something the runtime tells:
-    // probe_queues() measures it (a 200 us spin kernel on one stream, empty kernels on the others, device time stamps).
-    enum { PIPE_CANDS = 16 };
-    hipStream_t cand_st[PIPE_CANDS] = {};
-    int cand_class[PIPE_CANDS] = {}, n_class = -1;      // candidates with the same class share a queue (-1: not probed yet)
-    hipEvent_t ev_probe[PIPE_CANDS + 1] = {};
-    struct PipeChoice { hipStream_t caller; int n; int cand[PIPE_SETS]; };
-    std::vector<PipeChoice> pipe_choice;                // per caller's stream: the candidates that carry its frames
-    hipStream_t pipe_st[PIPE_SETS] = {};                // the stream set k's last frame ran on
-    // (two frame buffers per set: the set's next frame does not wait for the copy of its last one)
-    hipEvent_t ev_copy[2 * PIPE_SETS] = {};
-    bool ev_copy_set[2 * PIPE_SETS] = {}, ev_tile_ext[PIPE_SETS] = {};
-    int fb_turn[PIPE_SETS] = {};
-    DevBuf pipe_fb[2 * PIPE_SETS];
-    // (raytraced frames and batches: control block = counters + pixel dispenser)  last_ctrl: the control block of the most
-    // recent call, what mi355_fetch_stats reads.
-    DevBuf pipe_ctrl[PIPE_SETS], pipe_sel[PIPE_SETS], pipe_cam[PIPE_SETS];
-    void *last_ctrl = nullptr;
-    DevBuf cull_boxes, tile_sel;     // boxes of the tree's top (tile culling of raytraced frames) and the culled tile lists of the frame in flight
-    int n_cull_boxes = 0;
-    PinBuf pin_walk, pin_edge, pin_shade, pin_tree, pin_list, pin_ctl;   // host staging of the BVH streams and the builder
-    PinBuf pin_counters;                                                 // a synchronous frame's counters, copied behind its kernels
-    DevBuf wave_prof;       // per-wave phase profile of counting launches (debug)
-    int last_blocks = 0;
-    bool boxes_tame = false; // every BVH box coordinate is 0 or within [1e-30, 1e17] in magnitude
-    DevBuf smap[MI355_MAX_LIGHTS];
-    int smap_size[MI355_MAX_LIGHTS] = {0, 0, 0, 0};
-    // mi355_light_update: a map redrawn in stream order.  ev_light = the redraw's last kernel; frames enqueued later wait for it
-    // on whatever stream they run, the redraw waits for the frames enqueued before it (ev_tile of every set in use).
-    hipEvent_t ev_light = nullptr;
-    bool ev_light_set = false;
-    RasterScratch *rs_light = nullptr;   // the redraw's own row buffer (frames in flight use the other sets)
-    int direct_turn = 0;                 // raytraced frames: whose turn it is to run on the caller's stream itself (enqueue_frame)
-    // ... with a control block and a tile list of its own, like the frames on the frame streams: a synchronous mi355_render or a
-    // frame of another caller's stream may come while it runs.  ev_direct = its launch; the next such frame, whatever stream it is
-    // on, follows it.
-    DevBuf direct_ctrl, direct_sel;
-    hipEvent_t ev_direct = nullptr;
-    bool ev_direct_set = false;
-    RasterScratch *rscratch = nullptr;
-    WireScratch *wscratch = nullptr;     // mode 3 (created with its first frame)
-    // pipelined frames (mi355_render_async / _wait): each slot is a stream with its own control block (counters, pixel
-    // dispenser), framebuffer, page-locked staging and rasterizer scratch
-    struct AsyncSlot {
-        hipStream_t st = nullptr;     // one of cand_st (slot i: a stream of queue class i, so that no two slots share a hardware queue), or its own
-        bool st_owned = false;
-        hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        DevBuf ctrl, fb, mlaa, sel;
-        PinBuf pin;
-        RasterScratch *rs = nullptr;
-        bool busy = false, ready = false;   // ready: stream, events, control block and scratch all exist
-        int ticket = 0, mode = 0, n_lights = 0, pitch_bytes = 0;
-        uint32_t *user = nullptr;
-        bool staged = false;          // the frame lands in `pin` and is copied to `user` by mi355_render_wait
-        mi355_camera cam{};
-        mi355_light lights[MI355_MAX_LIGHTS]{};
-        mi355_opts opts{};
-    } slot[MI355_MAX_IN_FLIGHT];
-    int next_ticket = 1;
-    // caller's page-locked output buffers (mi355_host_register): frames are copied straight into them
-    struct HostRange { char *p = nullptr; size_t bytes = 0; } host_reg[8];
-    // dispenser orders of the last few frame geometries (a buffer in use by an enqueued frame is never rewritten)
-    struct TileOrder { DevBuf buf; long long key[6] = {0, 0, 0, 0, 0, 0}; unsigned long long used = 0; } orders[4];
-    unsigned long long order_clock = 0;
-    DevScene dev{};
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool last_stats = false;
-};
+namespace mi355i {
 
-namespace {
 
 int select_device(mi355_ctx *c)
 {
@@ -289,8 +22,6 @@ int select_device(mi355_ctx *c)
     return 0;
 }
 
-inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
-inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
 int count_rows(const mi355_opts &o)
 {
@@ -439,382 +170,6 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     return 0;
 }
 
-// Thread the reference's flat BVH (pre-order CacheFriendlyBVHNode[], BVH.h:52-65) with hit/miss
-// links and build the leaf-ordered triangle streams.
-int upload_cull_boxes(mi355_ctx *c, const void *nodes32B, uint32_t nN);
-// a tree is being replaced: frames of the device entry points run on internal streams and may still read the old streams, and a
-// failed build must not leave the context describing a tree whose buffers are half written
-int begin_tree_update(mi355_ctx *c)
-{
-    HIP_TRY(hipDeviceSynchronize(), -40);
-    c->has_bvh = false; c->n_cull_boxes = 0; c->dev.ordered_ok = 0u;
-    return 0;
-}
-int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int32_t *triIdx, uint32_t nI)
-{
-    struct RefNode { float bottom[3], top[3]; uint32_t a, b; };
-    const RefNode *rn = (const RefNode *)nodes32B;
-    if (nN == 0) return fail(-30, "empty BVH");
-    if (nI != c->nT) return fail(-30, "triangle index list has %u entries, scene has %u triangles", nI, c->nT);
-    std::vector<uint8_t> seen(c->nT, 0);
-    for (uint32_t i = 0; i < nI; i++) {
-        if (triIdx[i] < 0 || (uint32_t)triIdx[i] >= c->nT || seen[triIdx[i]]) return fail(-30, "triangle index list is not a permutation (entry %u)", i);
-        seen[triIdx[i]] = 1;
-    }
-    auto is_leaf = [&](uint32_t i) { return (rn[i].a & 0x80000000u) != 0; };
-    // Record offsets (float4 units): inner nodes first, two float4 each in array order (the reference's
-    // flattening is pre-order); then triangle block j at tri_base + 2*j for every position j of the
-    // triangle list; then one dummy block per empty leaf (never produced by the reference builder).
-    std::vector<uint32_t> off(nN, 0);
-    std::vector<uint8_t> owned(nI, 0);
-    size_t n_inner = 0, n_dummy = 0;
-    for (uint32_t i = 0; i < nN; i++)
-        if (!is_leaf(i)) off[i] = (uint32_t)(2 * n_inner++);
-    const size_t tri_base = 2 * n_inner;
-    for (uint32_t i = 0; i < nN; i++) {
-        if (!is_leaf(i)) continue;
-        const uint32_t cnt = rn[i].a & 0x7fffffffu, first = rn[i].b;
-        if ((uint64_t)first + cnt > nI) return fail(-30, "BVH leaf %u exceeds the triangle list", i);
-        for (uint32_t k = 0; k < cnt; k++) {
-            if (owned[first + k]) return fail(-30, "BVH leaves overlap at triangle list entry %u", first + k);
-            owned[first + k] = 1;
-        }
-        off[i] = cnt ? (uint32_t)(tri_base + 2 * (size_t)first) : (uint32_t)(tri_base + 2 * ((size_t)nI + n_dummy++));
-    }
-    const size_t n4 = tri_base + 2 * ((size_t)nI + n_dummy);
-    if (n4 + 8 >= (size_t)MI_INDEX_MASK) return fail(-30, "BVH too large");
-    auto tri_link = [&](size_t j, bool first_of_leaf) {     // link to triangle block j (list position)
-        uint32_t l = (uint32_t)(tri_base + 2 * j) | MI_LEAF_BIT;
-        if (first_of_leaf) l |= MI_FIRST_BIT;
-        if (j < nI && c->ttwo[triIdx[j]]) l |= MI_TWOSIDED_BIT;
-        return l;
-    };
-    auto link = [&](uint32_t i) {
-        if (i == MI_END_LINK) return (uint32_t)MI_END_LINK;
-        if (!is_leaf(i)) return off[i];
-        return tri_link(((size_t)off[i] - tri_base) / 2, true);
-    };
-    const size_t wide_base = n4;                      // wide records of the ordered walk: 4 float4 per inner node
-    const size_t n4_all = n4 + 4 * n_inner;
-    if (n4_all + 8 >= (size_t)MI_VROOT_LINK) return fail(-30, "BVH too large");
-    HIP_TRY(c->pin_walk.ensure((n4_all + 4) * sizeof(float4)), -31);
-    float4 *walk = (float4 *)c->pin_walk.p;
-    memset(walk, 0, (n4_all + 4) * sizeof(float4));
-    std::vector<uint32_t> order; order.reserve(nN);   // the reference's visiting order
-    bool list_in_visit_order = true;
-    uint32_t list_end = 0;
-    int inner_levels = 0;
-    std::vector<uint8_t> visited(nN, 0);
-    struct Item { uint32_t node, escape; int depth; };
-    std::vector<Item> st;
-    st.push_back({0u, MI_END_LINK, 0});
-    size_t nvis = 0;
-    while (!st.empty()) {
-        Item it = st.back(); st.pop_back();
-        if (it.node >= nN || visited[it.node]) return fail(-30, "BVH is not a tree (node %u)", it.node);
-        if (it.depth >= 64) return fail(-30, "BVH deeper than 64 levels");
-        visited[it.node] = 1; nvis++;
-        order.push_back(it.node);
-        const RefNode &n = rn[it.node];
-        float4 *rec = &walk[off[it.node]];
-        if (!is_leaf(it.node)) {
-            if (n.a >= nN || n.b >= nN) return fail(-30, "BVH child index out of range at node %u", it.node);
-            rec[0] = make_float4(n.bottom[0], n.bottom[1], n.bottom[2], u2f(link(n.a)));
-            rec[1] = make_float4(n.top[0], n.top[1], n.top[2], u2f(link(it.escape)));
-            st.push_back({n.b, it.escape, it.depth + 1});
-            st.push_back({n.a, n.b, it.depth + 1});
-            if (it.depth + 1 > inner_levels) inner_levels = it.depth + 1;
-            // wide record: both children's boxes
-            auto wlink = [&](uint32_t x) { return is_leaf(x) ? link(x) : (uint32_t)(wide_base + 2 * (size_t)off[x]); };
-            float4 *w = &walk[wide_base + 2 * (size_t)off[it.node]];
-            const RefNode &ca = rn[n.a], &cb = rn[n.b];
-            // (min and max of an axis side by side: the two slab distances of an axis are then one packed operation)
-            w[0] = make_float4(ca.bottom[0], ca.top[0], ca.bottom[1], ca.top[1]);
-            w[1] = make_float4(ca.bottom[2], ca.top[2], u2f(wlink(n.a)), u2f(wlink(n.b)));
-            w[2] = make_float4(cb.bottom[0], cb.top[0], cb.bottom[1], cb.top[1]);
-            w[3] = make_float4(cb.bottom[2], cb.top[2], 0.f, 0.f);
-        } else {
-            const uint32_t cnt = n.a & 0x7fffffffu, first = n.b;
-            if (cnt) { if (first < list_end) list_in_visit_order = false; list_end = first + cnt; }
-            // an empty leaf is a block with a zero normal: its plane rejects every ray (k == 0)
-            if (cnt == 0) rec[0] = make_float4(0.f, 0.f, 0.f, u2f(link(it.escape)));
-            for (uint32_t k = 0; k < cnt; k++) {
-                const uint32_t t = (uint32_t)triIdx[first + k];
-                const float *nrm = &c->tnormal[3 * t], *cen = &c->tcenter[3 * t];
-                const uint32_t next = k + 1 < cnt ? tri_link((size_t)first + k + 1, false) : link(it.escape);
-                rec[2 * k] = make_float4(nrm[0], nrm[1], nrm[2], u2f(next));
-                rec[2 * k + 1] = make_float4(cen[0], cen[1], cen[2], c->td[4 * t]);
-            }
-        }
-    }
-    if (nvis != nN) return fail(-30, "BVH has %u nodes but only %zu are reachable", nN, nvis);
-    bool tame = true;
-    for (uint32_t i = 0; i < nN && tame; i++)
-        if (!is_leaf(i))
-            for (int k = 0; k < 6; k++) {
-                const float x = fabsf(k < 3 ? rn[i].bottom[k] : rn[i].top[k - 3]);
-                if (!(x == 0.f || (x >= 1e-30f && x <= 1e17f))) { tame = false; break; }
-            }
-    c->boxes_tame = tame;
-    // The ordered walk (near child first, subtrees farther than the best hit skipped) returns the
-    // reference's pixels only if (1) every box contains all triangles below it -- then "the box starts
-    // beyond the best hit" implies "so does every hit in it" -- and (2) a triangle's position in the
-    // list is its rank in the reference's visiting order -- then "lowest j among equal distances" is the
-    // reference's "first found wins".  The reference's own builder guarantees both; a foreign tree that
-    // does not is walked in the reference's order instead.
-    bool bounded = true;
-    float mag = 0.f;
-    {
-        std::vector<float> bb((size_t)nN * 6);
-        for (size_t q = order.size(); q-- > 0 && bounded;) {       // reverse pre-order: children before parents
-            const uint32_t i = order[q];
-            float *b = &bb[(size_t)i * 6];
-            b[0] = b[1] = b[2] = INFINITY; b[3] = b[4] = b[5] = -INFINITY;
-            if (is_leaf(i)) {
-                const uint32_t cnt = rn[i].a & 0x7fffffffu, first = rn[i].b;
-                for (uint32_t k = 0; k < cnt; k++) {
-                    const int32_t *ix = &c->tidx[3 * (size_t)triIdx[first + k]];
-                    for (int v = 0; v < 3; v++)
-                        for (int a = 0; a < 3; a++) {
-                            const float x = c->vpos[3 * (size_t)ix[v] + a];
-                            if (!(x == x)) bounded = false;
-                            if (x < b[a]) b[a] = x;
-                            if (x > b[3 + a]) b[3 + a] = x;
-                        }
-                }
-            } else {
-                const float *l = &bb[(size_t)rn[i].a * 6], *r = &bb[(size_t)rn[i].b * 6];
-                for (int a = 0; a < 3; a++) { b[a] = l[a] < r[a] ? l[a] : r[a]; b[3 + a] = l[3 + a] > r[3 + a] ? l[3 + a] : r[3 + a]; }
-            }
-            for (int a = 0; a < 3; a++) {
-                if (b[a] <= b[3 + a] && !(rn[i].bottom[a] <= b[a] && rn[i].top[a] >= b[3 + a])) bounded = false;
-                const float m0 = fabsf(rn[i].bottom[a]), m1 = fabsf(rn[i].top[a]);
-                if (!(m0 <= 1e17f && m1 <= 1e17f)) bounded = false;
-                if (m0 > mag) mag = m0;
-                if (m1 > mag) mag = m1;
-            }
-        }
-    }
-    c->dev.ordered_ok = (tame && bounded && list_in_visit_order && inner_levels + 1 <= MI_MAX_STACK) ? 1u : 0u;
-    c->dev.stack_depth = (uint32_t)(inner_levels + 1);
-    c->dev.scene_mag = mag;
-
-    const uint32_t T = c->nT;
-    // (+ zeroed edge records behind the dummy blocks of empty leaves: a NaN ray can pass their plane test)
-    const size_t n_edge = ((size_t)T + n_dummy) * 3, n_shade = (size_t)T * 5;
-    HIP_TRY(c->pin_edge.ensure(n_edge * sizeof(float4) + 16), -31);
-    HIP_TRY(c->pin_shade.ensure(n_shade * sizeof(float4) + 16), -31);
-    float4 *edge = (float4 *)c->pin_edge.p, *shade = (float4 *)c->pin_shade.p;
-    memset(edge + (size_t)T * 3, 0, n_dummy * 3 * sizeof(float4));
-    for (uint32_t j = 0; j < T; j++) {
-        const uint32_t t = (uint32_t)triIdx[j];
-        const float *d = &c->td[4 * t], *e = &c->te[9 * t];
-        // e1 whole, e2 and e3 side by side component by component: their two half-plane tests run as packed arithmetic
-        edge[(size_t)j * 3] = make_float4(e[0], e[1], e[2], d[1]);
-        edge[(size_t)j * 3 + 1] = make_float4(e[3], e[6], e[4], e[7]);
-        edge[(size_t)j * 3 + 2] = make_float4(e[5], e[8], d[2], d[3]);
-        const int32_t *ix = &c->tidx[3 * t];
-        const V3h A = {c->vpos[3 * ix[0]], c->vpos[3 * ix[0] + 1], c->vpos[3 * ix[0] + 2]};
-        const V3h B = {c->vpos[3 * ix[1]], c->vpos[3 * ix[1] + 1], c->vpos[3 * ix[1] + 2]};
-        const V3h C = {c->vpos[3 * ix[2]], c->vpos[3 * ix[2] + 1], c->vpos[3 * ix[2] + 2]};
-        // Raytracer.cc:352-361: |AB|, |BC|, |CA| and 2*area depend only on the triangle, so they
-        // are evaluated once here with the same float operations the reference repeats per hit.
-        const float area = lenh(crossh(subh(B, A), subh(C, B)));
-        shade[(size_t)j * 5] = make_float4(disth(A, B), disth(B, C), disth(C, A), area);
-        for (int k = 0; k < 3; k++) {
-            const float *vn = &c->vnrm[3 * ix[k]];
-            shade[(size_t)j * 5 + 1 + k] = make_float4(vn[0], vn[1], vn[2], (float)c->vao[ix[k]]);
-        }
-        shade[(size_t)j * 5 + 4] = make_float4(c->tcolorf[3 * t], c->tcolorf[3 * t + 1], c->tcolorf[3 * t + 2], 0.f);
-    }
-    HIP_TRY(c->walk.ensure((n4_all + 4) * sizeof(float4) + 16), -31);
-    HIP_TRY(c->tri_edge.ensure(n_edge * sizeof(float4) + 16), -31);
-    HIP_TRY(c->tri_shade.ensure(n_shade * sizeof(float4) + 16), -31);
-    HIP_TRY(hipMemcpyAsync(c->walk.p, walk, (n4_all + 4) * sizeof(float4), hipMemcpyHostToDevice, c->stream), -31);
-    HIP_TRY(hipMemcpyAsync(c->tri_edge.p, edge, n_edge * sizeof(float4), hipMemcpyHostToDevice, c->stream), -31);
-    HIP_TRY(hipMemcpyAsync(c->tri_shade.p, shade, n_shade * sizeof(float4), hipMemcpyHostToDevice, c->stream), -31);
-    HIP_TRY(hipStreamSynchronize(c->stream), -40);
-    c->dev.walk = (const float4 *)c->walk.p;
-    c->dev.tri_edge = (const float4 *)c->tri_edge.p;
-    c->dev.tri_shade = (const float4 *)c->tri_shade.p;
-    c->dev.root_link = link(0);
-    c->dev.root_a = walk[c->dev.root_link & MI_INDEX_MASK];
-    c->dev.root_b = walk[(c->dev.root_link & MI_INDEX_MASK) + 1];
-    c->dev.tri_base = (uint32_t)tri_base;
-    {
-        const uint32_t wroot = is_leaf(0) ? link(0) : (uint32_t)(wide_base + 2 * (size_t)off[0]);
-        c->dev.vroot_a = make_float4(rn[0].bottom[0], rn[0].top[0], rn[0].bottom[1], rn[0].top[1]);
-        c->dev.vroot_b = make_float4(rn[0].bottom[2], rn[0].top[2], u2f(wroot), u2f(MI_END_LINK));
-        // (a walk may start at the root's wide record instead of at the virtual record above it -- begin_walk, k_raytrace.hip)
-        c->dev.root_direct = 0u;
-        for (int k = 0; k < 4; k++) c->dev.wroot[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!is_leaf(0) && rn[0].a < nN && rn[0].b < nN) {
-            const RefNode &ca = rn[rn[0].a], &cb = rn[rn[0].b];
-            bool in = !is_leaf(rn[0].a) && !is_leaf(rn[0].b);
-            for (int k = 0; k < 3; k++) in = in && ca.bottom[k] >= rn[0].bottom[k] && cb.bottom[k] >= rn[0].bottom[k] && ca.top[k] <= rn[0].top[k] && cb.top[k] <= rn[0].top[k];
-            for (int k = 0; k < 4; k++) c->dev.wroot[k] = walk[wide_base + 2 * (size_t)off[0] + k];
-            c->dev.root_direct = in ? 1u : 0u;
-        }
-    }
-    c->dev.n_nodes = nN;
-    c->has_bvh = true;
-    return upload_cull_boxes(c, nodes32B, nN);
-}
-
-// The boxes raytraced frames are culled against (k_tile_select): start from the root and keep replacing the inner node of the
-// largest surface by its two children, up to MI_CULL_BOXES boxes.  Together they hold every triangle of a checked tree.
-int upload_cull_boxes(mi355_ctx *c, const void *nodes32B, uint32_t nN)
-{
-    struct RefNode { float bottom[3], top[3]; uint32_t a, b; };
-    const RefNode *rn = (const RefNode *)nodes32B;
-    c->n_cull_boxes = 0;
-    if (!c->dev.ordered_ok || nN == 0) return 0;          // (an unchecked tree's boxes need not bound its triangles)
-    std::vector<uint32_t> set{0u};
-    auto area = [&](uint32_t i) { const float x = rn[i].top[0] - rn[i].bottom[0], y = rn[i].top[1] - rn[i].bottom[1], z = rn[i].top[2] - rn[i].bottom[2]; return x * y + y * z + z * x; };
-    while (set.size() < (size_t)MI_CULL_BOXES) {
-        int best = -1;
-        for (size_t k = 0; k < set.size(); k++)
-            if (!(rn[set[k]].a & 0x80000000u) && (best < 0 || area(set[k]) > area(set[(size_t)best]))) best = (int)k;
-        if (best < 0) break;
-        const uint32_t n = set[(size_t)best];
-        set[(size_t)best] = rn[n].a; set.push_back(rn[n].b);
-    }
-    std::vector<float4> b(set.size() * 2);
-    for (size_t k = 0; k < set.size(); k++) {
-        const RefNode &n = rn[set[k]];
-        b[2 * k] = make_float4(n.bottom[0], n.bottom[1], n.bottom[2], 0.f);
-        b[2 * k + 1] = make_float4(n.top[0], n.top[1], n.top[2], 0.f);
-    }
-    HIP_TRY(c->cull_boxes.upload(b), -31);
-    c->n_cull_boxes = (int)set.size();
-    return 0;
-}
-
-// ---- which streams share a hardware queue (see mi355_ctx::cand_st) -------------------------------------------------
-__global__ void k_probe_spin(unsigned long long ticks)
-{
-    const unsigned long long t0 = wall_clock64();
-    for (int i = 0; i < (1 << 16) && wall_clock64() - t0 < ticks; i++) __builtin_amdgcn_s_sleep(16);      // (bounded either way)
-}
-__global__ void k_probe_touch() {}
-
-// `a` spins for 200 us; every stream of `others` gets an empty kernel.  shared[j] = that kernel ended after the spin did,
-// i.e. others[j] runs behind `a`: same hardware queue.  (Device time stamps: the host's scheduling does not enter.)
-static bool probe_queues(mi355_ctx *c, hipStream_t a, const hipStream_t *others, int n, bool *shared)
-{
-    int khz = 0;
-    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
-    hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, a, (unsigned long long)khz / 5ull);              // 200 us
-    if (hipEventRecord(c->ev_probe[mi355_ctx::PIPE_CANDS], a) != hipSuccess) return false;
-    for (int j = 0; j < n; j++) {
-        hipLaunchKernelGGL(k_probe_touch, dim3(1), dim3(64), 0, others[j]);
-        if (hipEventRecord(c->ev_probe[j], others[j]) != hipSuccess) return false;
-    }
-    if (hipEventSynchronize(c->ev_probe[mi355_ctx::PIPE_CANDS]) != hipSuccess) return false;
-    for (int j = 0; j < n; j++) {
-        float ms = 0.f;
-        if (hipEventSynchronize(c->ev_probe[j]) != hipSuccess || hipEventElapsedTime(&ms, c->ev_probe[mi355_ctx::PIPE_CANDS], c->ev_probe[j]) != hipSuccess) return false;
-        shared[j] = ms > -0.1f;           // (not shared: it ended ~190 us BEFORE the spin did)
-    }
-    return hipGetLastError() == hipSuccess;
-}
-
-// The queue classes of the candidate streams (once per context).
-static bool probe_classes(mi355_ctx *c)
-{
-    const int N = mi355_ctx::PIPE_CANDS;
-    if (!c->cand_st[0]) return false;
-    // (frames may still be running on the candidates: the probe must find them idle)
-    for (int i = 0; i < N; i++) if (hipStreamSynchronize(c->cand_st[i]) != hipSuccess) return false;
-    if (c->n_class >= 0) return true;
-    // (a stream's first kernel may take milliseconds -- the runtime binds it to a hardware queue then: not inside a probe)
-    for (int i = 0; i < N; i++) hipLaunchKernelGGL(k_probe_touch, dim3(1), dim3(64), 0, c->cand_st[i]);
-    for (int i = 0; i < N; i++) if (hipStreamSynchronize(c->cand_st[i]) != hipSuccess) return false;
-    int n_class = 0;
-    for (int i = 0; i < N; i++) c->cand_class[i] = -1;
-    for (int i = 0; i < N; i++) {
-        if (c->cand_class[i] >= 0) continue;
-        c->cand_class[i] = n_class;
-        hipStream_t others[N]; int idx[N], n = 0; bool shared[N];
-        for (int j = i + 1; j < N; j++) if (c->cand_class[j] < 0) { others[n] = c->cand_st[j]; idx[n++] = j; }
-        if (n > 0 && !probe_queues(c, c->cand_st[i], others, n, shared)) { for (int j = 0; j < N; j++) c->cand_class[j] = -1; return false; }
-        for (int j = 0; j < n; j++) if (shared[j]) c->cand_class[idx[j]] = n_class;
-        n_class++;
-    }
-    c->n_class = n_class;
-    return true;
-}
-
-// The frame streams for raster frames the caller enqueues on `st`: one candidate of every queue class but st's own (at most
-// PIPE_SETS).  Probed once per context (the classes) and once per caller's stream; nullptr = probing failed, fewer than
-// two = the ordered pipeline is used instead.
-static const mi355_ctx::PipeChoice *pipe_streams_for(mi355_ctx *c, hipStream_t st)
-{
-    for (const auto &pc : c->pipe_choice) if (pc.caller == st) return &pc;
-    const int N = mi355_ctx::PIPE_CANDS;
-    if (!probe_classes(c)) return nullptr;
-    hipStream_t reps[N]; int rep_class[N], n = 0; bool shared[N];
-    for (int cl = 0; cl < c->n_class; cl++)
-        for (int i = 0; i < N; i++) if (c->cand_class[i] == cl) { reps[n] = c->cand_st[i]; rep_class[n++] = i; break; }
-    if (!probe_queues(c, st, reps, n, shared)) return nullptr;
-    mi355_ctx::PipeChoice pc; pc.caller = st; pc.n = 0;
-    // (how many frames in flight: as many as there are hardware queues besides the caller's -- three with the runtime's default of
-    //  four queues, up to PIPE_SETS when the process was started with GPU_MAX_HW_QUEUES=8; MI355_PIPE_SETS caps it)
-    static const int cap = [] { const char *v = getenv("MI355_PIPE_SETS"); const int k = v ? atoi(v) : 0; return k >= 1 && k <= (int)mi355_ctx::PIPE_SETS ? k : (int)mi355_ctx::PIPE_SETS; }();
-    for (int j = 0; j < n && pc.n < cap; j++) if (!shared[j]) pc.cand[pc.n++] = rep_class[j];
-    if (c->pipe_choice.size() >= 16) c->pipe_choice.erase(c->pipe_choice.begin());
-    c->pipe_choice.push_back(pc);
-    return &c->pipe_choice.back();
-}
-
-// The caller's stream sits on a hardware queue of its own (the frame streams were picked so), and all that stream carries for an
-// overlapped frame is a wait and a copy: every (n + 1)-th RAYTRACED frame of a caller therefore runs ON the caller's stream itself --
-// straight into the caller's buffer, no copy --, beside the n frames on the frame streams: four frames in flight on the runtime's
-// four queues instead of three (4 spp 1080p: 966 -> 1 061 fps).  Stream order is the stream's own.
-static bool direct_turn(mi355_ctx *c, const mi355_ctx::PipeChoice *pc)
-{
-    c->direct_turn = (c->direct_turn + 1) % (pc->n + 1);
-    return c->direct_turn == 0;
-}
-
-// One call in flight: resource set k (rasterizer scratch / control block, tile list, camera table), frame stream
-// ps, frame buffer fb = pipe_fb[b].  lease_begin orders ps behind the set's last call, if that ran elsewhere (a call of another
-// caller's stream, of the ordered pipeline, a counting frame, a batch), and behind the copy that last read the buffer;
-// lease_done makes the caller's stream wait for the call's last kernel (`recorded`: that kernel carries ev_tile[k] itself).
-struct FrameLease { int k, b; hipStream_t ps; uint32_t *fb; };
-
-// `st` behind `ev` -- unless the event has completed already: hipStreamWaitEvent costs the host ~5 us when it has to put a
-// barrier packet into the queue and 0.06 us for a query (scripts/ubench/apicost.hip), and the events the frame streams wait for
-// (the copy that last read a buffer two frames ago) have almost always completed
-static hipError_t wait_unless_done(hipStream_t st, hipEvent_t ev)
-{
-    const hipError_t q = hipEventQuery(ev);
-    if (q == hipSuccess) return hipSuccess;
-    (void)hipGetLastError();                  // (hipErrorNotReady is not an error here; it must not be taken for a failed launch later)
-    return hipStreamWaitEvent(st, ev, 0);
-}
-
-static int lease_begin(mi355_ctx *c, const mi355_ctx::PipeChoice *pc, size_t fb_bytes, FrameLease &L)
-{
-    L.k = c->pipe_turn % pc->n; c->pipe_turn = (L.k + 1) % pc->n;
-    L.ps = c->cand_st[pc->cand[L.k]];
-    L.b = 2 * L.k + c->fb_turn[L.k]; c->fb_turn[L.k] ^= 1;
-    HIP_TRY(c->pipe_fb[L.b].ensure(fb_bytes), -31);
-    L.fb = (uint32_t *)c->pipe_fb[L.b].p;
-    if (c->ev_tile_set[L.k] && (c->ev_tile_ext[L.k] || c->pipe_st[L.k] != L.ps)) HIP_TRY(wait_unless_done(L.ps, c->ev_tile[L.k]), -40);
-    c->pipe_st[L.k] = L.ps;
-    if (c->ev_copy_set[L.b]) HIP_TRY(wait_unless_done(L.ps, c->ev_copy[L.b]), -40);
-    if (c->ev_light_set) HIP_TRY(wait_unless_done(L.ps, c->ev_light), -40);        // (a shadow map redrawn by mi355_light_update)
-    return 0;
-}
-
-static int lease_done(mi355_ctx *c, const FrameLease &L, hipStream_t st, bool recorded)
-{
-    if (!recorded) HIP_TRY(hipEventRecord(c->ev_tile[L.k], L.ps), -40);
-    c->ev_tile_set[L.k] = true; c->ev_tile_ext[L.k] = false;
-    HIP_TRY(hipStreamWaitEvent(st, c->ev_tile[L.k], 0), -40);
-    return 0;
-}
 
 int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hipStream_t st, void *ctrl = nullptr, RasterScratch *rs = nullptr,
                   DevBuf *mlaa_scratch = nullptr, uint32_t *const *frame_outs = nullptr, DevBuf *sel = nullptr)
@@ -1020,7 +375,7 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
     return 0;
 }
 
-} // namespace
+} // namespace mi355i
 
 extern "C" {
 
@@ -1189,141 +544,6 @@ void mi355_scene_destroy(mi355_ctx *c)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
-
-int mi355_scene_set_bvh(mi355_ctx *c, const void *nodes32B, uint32_t n_nodes, const int32_t *tri_idx, uint32_t n_idx)
-{
-    if (!c || !nodes32B || !tri_idx) return fail(-3, "mi355_scene_set_bvh: null argument");
-    if (int r = select_device(c)) return r;
-    if (int r = begin_tree_update(c)) return r;
-    return build_bvh_streams(c, nodes32B, n_nodes, tri_idx, n_idx);
-}
-
-// CreateBVH + PopulateCacheFriendlyBVH (BVH.cc:96-371, Raytracer.cc:651-718) on the device: the SAH sweeps run as
-// k_bvh_level (one launch per tree level), the result is flattened here to the reference's pre-order array and is
-// byte for byte what the reference's scalar builder writes to its `.bvh` cache.  Also installs the tree in the context.
-static thread_local double g_bvh_level_ms[64]; static thread_local uint32_t g_bvh_level_nodes[64]; static thread_local int g_bvh_levels = 0;   // (of the calling thread's last build)
-extern "C" int mi355i_bvh_level_times(double *ms64, uint32_t *nodes64) { for (int i = 0; i < g_bvh_levels; i++) { ms64[i] = g_bvh_level_ms[i]; nodes64[i] = g_bvh_level_nodes[i]; } return g_bvh_levels; }
-static thread_local double g_bvh_ms[4] = {0, 0, 0, 0};     // last mi355_build_bvh: setup, level kernels (incl. per-level sync), download + flatten, install
-extern "C" void mi355i_bvh_last_times(double *out4) { for (int i = 0; i < 4; i++) out4[i] = g_bvh_ms[i]; }
-
-int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_nodes, int32_t *max_depth)
-{
-    const auto clk = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t_start = clk();
-    if (!c || !nodes32B || !tri_idx || !n_nodes) return fail(-3, "mi355_build_bvh: null argument");
-    if (int r = select_device(c)) return r;
-    const uint32_t T = c->nT;
-    if (T == 0) return fail(-50, "mi355_build_bvh: scene has no triangles");
-    if ((size_t)9 * T + 32 >= (size_t)MI_VROOT_LINK) return fail(-30, "BVH too large");
-    if (int r = begin_tree_update(c)) return r;
-    static_assert(sizeof(BvLevelNode) == 48 && sizeof(BvTreeNode) == 32, "layouts shared with k_bvh.hip");
-    // ---- buffers (kept for rebuilds) ----
-    const size_t max_level_nodes = (size_t)T / 2 + 4, max_tree = (size_t)2 * T + 4;
-    const uint32_t max_big = T / BV_CH + 2u, max_task = 2u * (T / BV_CH) + 4u;
-    HIP_TRY(c->bvh_prim.ensure((size_t)T * 3 * sizeof(float4)), -31);
-    for (int i = 0; i < 2; i++) {
-        HIP_TRY(c->bvh_list[i].ensure((size_t)T * 4), -31);
-        HIP_TRY(c->bvh_lvl[i].ensure(max_level_nodes * sizeof(BvLevelNode)), -31);
-        HIP_TRY(c->bvh_big[i].ensure((size_t)max_big * sizeof(BvBig)), -31);
-        HIP_TRY(c->bvh_task[i].ensure((size_t)max_task * sizeof(BvTask)), -31);
-    }
-    HIP_TRY(c->bvh_tree.ensure(max_tree * sizeof(BvTreeNode)), -31);
-    HIP_TRY(c->bvh_cnt.ensure(sizeof(BvCtl)), -31);
-    HIP_TRY(c->bvh_choff.ensure((size_t)max_task * 4), -31);
-    for (int i = 0; i < 5; i++) HIP_TRY(c->bvh_num[i].ensure(max_tree * 4), -31);
-    HIP_TRY(c->bvh_out.ensure(max_tree * 32), -31);
-    // the finished streams go straight into the buffers the kernels read (dev_scene.h)
-    const size_t walk_bytes = ((size_t)8 * T + 32) * sizeof(float4);      // (2 + 4 float4 per inner node -- fewer than T of them --, 2 per triangle)
-    HIP_TRY(c->walk.ensure(walk_bytes), -31);
-    HIP_TRY(c->tri_edge.ensure((size_t)T * 3 * sizeof(float4) + 16), -31);
-    HIP_TRY(c->tri_shade.ensure((size_t)T * 5 * sizeof(float4) + 16), -31);
-    if (!c->bvh_inputs_ready) {
-        // the per-triangle plane data in input order (once per scene)
-        HIP_TRY(c->bvh_in_td.ensure((size_t)T * 16), -31);
-        HIP_TRY(c->bvh_in_te.ensure((size_t)T * 36), -31);
-        HIP_TRY(hipMemcpy(c->bvh_in_td.p, c->td.data(), (size_t)T * 16, hipMemcpyHostToDevice), -31);
-        HIP_TRY(hipMemcpy(c->bvh_in_te.p, c->te.data(), (size_t)T * 36, hipMemcpyHostToDevice), -31);
-        c->bvh_inputs_ready = true;
-    }
-    HIP_TRY(c->pin_ctl.ensure(sizeof(BvCtl)), -31);
-    HIP_TRY(c->pin_tree.ensure(max_tree * 32), -31);
-    HIP_TRY(c->pin_list.ensure((size_t)T * 4), -31);
-    BvCtl *ctl = (BvCtl *)c->pin_ctl.p;
-    const double t_setup = clk();
-    double t_levels = t_setup;
-    for (uint32_t planes = 1100u; ; planes = 2200u) {
-        // (a node with more candidate planes than the fast build holds: the whole build again with the large one)
-        HIP_TRY(c->bvh_gbin.ensure((size_t)max_big * 3 * 7 * (planes + 1) * 4), -31);
-        HIP_TRY(c->bvh_tcnt.ensure((size_t)max_task * 3 * (planes + 1) * 4), -31);
-        for (int i = 0; i < 2; i++) HIP_TRY(c->bvh_gthr[i].ensure((size_t)max_big * 3 * planes * 4), -31);
-        BvWork W{};
-        W.rs_vert = (const float4 *)c->rs_vert.p; W.rs_tri = (const float4 *)c->rs_tri.p; W.rs_col = (const float4 *)c->rs_col.p;
-        W.rs_idx = (const uint4 *)c->rs_idx.p; W.in_td = (const float4 *)c->bvh_in_td.p; W.in_te = (const float *)c->bvh_in_te.p;
-        W.T = T; W.max_planes = planes;
-        W.prim = (float4 *)c->bvh_prim.p; W.tree = (BvTreeNode *)c->bvh_tree.p; W.ctl = (BvCtl *)c->bvh_cnt.p;
-        for (int i = 0; i < 2; i++) {
-            W.list[i] = (uint32_t *)c->bvh_list[i].p; W.lvl[i] = (BvLevelNode *)c->bvh_lvl[i].p;
-            W.big[i] = (BvBig *)c->bvh_big[i].p; W.task[i] = (BvTask *)c->bvh_task[i].p; W.gthr[i] = (float *)c->bvh_gthr[i].p;
-        }
-        W.gbin = (uint32_t *)c->bvh_gbin.p; W.tcnt = (uint32_t *)c->bvh_tcnt.p; W.chunk_off = (uint32_t *)c->bvh_choff.p;
-        W.max_big = max_big; W.max_task = max_task;
-        W.sub = (uint32_t *)c->bvh_num[0].p; W.subi = (uint32_t *)c->bvh_num[1].p; W.pre = (uint32_t *)c->bvh_num[2].p;
-        W.irank = (uint32_t *)c->bvh_num[3].p; W.esc = (uint32_t *)c->bvh_num[4].p;
-        W.out_nodes = c->bvh_out.p; W.walk = (float4 *)c->walk.p; W.tri_edge = (float4 *)c->tri_edge.p; W.tri_shade = (float4 *)c->tri_shade.p;
-        HIP_TRY(hipMemsetAsync(c->walk.p, 0, walk_bytes, c->stream), -40);
-        hipError_t e = mi355i_bvh_build_begin(&W, c->stream);
-        if (e != hipSuccess) return fail(-43, "BVH build launch failed: %s", hipGetErrorString(e));
-        // Levels are enqueued in batches without reading anything back; the flatten / emit kernels behind a batch do
-        // nothing until the level loop has run dry, so one look at the control block per batch is all the host does.
-        int depth = 0;
-        for (int batch = BV_FIRST_BATCH; ; batch = 8) {
-            if ((e = mi355i_bvh_build_levels(&W, depth, batch, c->stream)) != hipSuccess) return fail(-43, "BVH level launch failed: %s", hipGetErrorString(e));
-            depth += batch;
-            if ((e = mi355i_bvh_build_finish(&W, depth, c->stream)) != hipSuccess) return fail(-43, "BVH flatten launch failed: %s", hipGetErrorString(e));
-            HIP_TRY(hipMemcpyAsync(ctl, c->bvh_cnt.p, sizeof(BvCtl), hipMemcpyDeviceToHost, c->stream), -31);
-            HIP_TRY(hipStreamSynchronize(c->stream), -40);
-            if (ctl->levels || ctl->bad || depth >= BV_MAX_LEVELS) break;
-        }
-        if (ctl->bad & 1u) return fail(-50, "mi355_build_bvh: non-finite vertex coordinates (use the host builder)");
-        if ((ctl->bad & 2u) && planes == 1100u) continue;
-        if (ctl->bad & 2u) return fail(-50, "mi355_build_bvh: more than 2200 candidate planes on an axis (use the host builder)");
-        if (ctl->bad) return fail(-51, "BVH build failed (internal error bits %#x)", ctl->bad);
-        if (!ctl->levels) return fail(-51, "BVH deeper than %d levels", BV_MAX_LEVELS);
-        break;
-    }
-    t_levels = clk();
-    const uint32_t n_out = ctl->n_nodes;
-    if (n_out == 0 || (size_t)n_out > max_tree || n_out != ctl->n_tree) return fail(-51, "BVH build produced %u nodes (%u allocated) for %u triangles", n_out, ctl->n_tree, T);
-    HIP_TRY(hipMemcpyAsync(c->pin_tree.p, c->bvh_out.p, (size_t)n_out * 32, hipMemcpyDeviceToHost, c->stream), -31);
-    HIP_TRY(hipMemcpyAsync(c->pin_list.p, c->bvh_list[0].p, (size_t)T * 4, hipMemcpyDeviceToHost, c->stream), -31);
-    HIP_TRY(hipStreamSynchronize(c->stream), -40);
-    memcpy(nodes32B, c->pin_tree.p, (size_t)n_out * 32);
-    memcpy(tri_idx, c->pin_list.p, (size_t)T * 4);
-    *n_nodes = n_out;
-    if (max_depth) *max_depth = (int32_t)ctl->levels - 1;
-    const double t_down = clk();
-    // install: the streams are already where the kernels read them
-    c->boxes_tame = ctl->tame != 0u;
-    c->dev.ordered_ok = (ctl->tame && ctl->bounded && ctl->inner_levels + 1u <= (uint32_t)MI_MAX_STACK) ? 1u : 0u;
-    c->dev.stack_depth = ctl->inner_levels + 1u;
-    c->dev.scene_mag = ctl->mag;
-    c->dev.walk = (const float4 *)c->walk.p;
-    c->dev.tri_edge = (const float4 *)c->tri_edge.p;
-    c->dev.tri_shade = (const float4 *)c->tri_shade.p;
-    c->dev.root_link = ctl->root_link;
-    c->dev.root_a = ctl->root_a; c->dev.root_b = ctl->root_b;
-    c->dev.vroot_a = ctl->vroot_a; c->dev.vroot_b = ctl->vroot_b;
-    for (int k = 0; k < 4; k++) c->dev.wroot[k] = ctl->wroot[k];
-    c->dev.root_direct = ctl->root_direct;
-    c->dev.tri_base = 2u * ctl->n_inner;
-    c->dev.n_nodes = n_out;
-    c->has_bvh = true;
-    if (int r = upload_cull_boxes(c, nodes32B, n_out)) return r;
-    g_bvh_levels = 0;
-    g_bvh_ms[0] = t_setup - t_start; g_bvh_ms[1] = t_levels - t_setup; g_bvh_ms[2] = t_down - t_levels; g_bvh_ms[3] = clk() - t_down;
-    return 0;
-}
-
 int mi355_shadowmap_set(mi355_ctx *c, int slot, const float *map, int size)
 {
     if (!c || !map) return fail(-3, "mi355_shadowmap_set: null argument");
@@ -1542,184 +762,6 @@ int mi355_mlaa_device(mi355_ctx *c, void *d_xrgb, int pitch_bytes, int height, v
     if (e != hipSuccess) return fail(-43, "MLAA launch failed: %s", hipGetErrorString(e));
     return 0;
 }
-
-static int stats_from_counters(mi355_ctx *c, mi355_stats *s, unsigned long long *h);
-
-int mi355_fetch_stats(mi355_ctx *c, mi355_stats *s)
-{
-    if (!c || !s) return fail(-3, "mi355_fetch_stats: null argument");
-    if (int r = select_device(c)) return r;
-    unsigned long long h[CS_COUNT];
-    HIP_TRY(hipMemcpy(h, (char *)(c->last_ctrl ? c->last_ctrl : c->ctrl.p) + 16, sizeof h, hipMemcpyDeviceToHost), -31);
-    // (the rasterizer reports a bin overflow in the context's own block, whichever block the last call counted in)
-    if (c->last_ctrl && c->last_ctrl != c->ctrl.p)
-        HIP_TRY(hipMemcpy(&h[CS_OVERFLOW], (char *)c->ctrl.p + 16 + sizeof(unsigned long long) * CS_OVERFLOW, sizeof(unsigned long long), hipMemcpyDeviceToHost), -31);
-    return stats_from_counters(c, s, h);
-}
-
-// the counters h[] of a call that has completed -> mi355_stats; what an overflow asks for (mi355_fetch_stats; mi355_render reads the
-// counters with a copy enqueued behind the frame's kernels instead of a blocking one after them: 40 us of a 650 us call)
-static int stats_from_counters(mi355_ctx *c, mi355_stats *s, unsigned long long *h)
-{
-    if (c->rs_light && c->ev_light_set) {
-        // (a map redrawn by mi355_light_update whose rows did not fit: the buffer doubles, the caller redraws the map.  The redraw
-        //  may sit on a non-blocking stream the copy below does not order behind: its event is waited for first -- and, once it
-        //  has completed, no later frame needs to wait for it and no later fetch needs to look again)
-        HIP_TRY(hipEventSynchronize(c->ev_light), -40);
-        c->ev_light_set = false;
-        const uint32_t dropped = mi355i_raster_overflow(c->rs_light);
-        if (dropped) {
-            const int grown = mi355i_raster_grow(c->rs_light);
-            return fail(-44, "mi355_light_update: the shadow map's row buffer overflowed (%u rows dropped)%s", dropped, grown ? "; it has grown: update the light again" : "");
-        }
-    }
-    memset(s, 0, sizeof *s);
-    s->normal_rays = h[CS_NORMAL_RAYS]; s->shadow_rays = h[CS_SHADOW_RAYS];
-    s->node_pops = h[CS_NODE_POPS]; s->inner_box_hits = h[CS_INNER_HITS]; s->tri_tests = h[CS_TRI_TESTS];
-    s->plane_pass = h[CS_PLANE_PASS]; s->shaded_hits = h[CS_SHADED_HITS];
-    s->tris_drawn = h[CS_TRIS_DRAWN]; s->spans = h[CS_SPANS]; s->ztests = h[CS_ZTESTS]; s->plots = h[CS_PLOTS];
-    if (h[CS_OVERFLOW]) {
-        // the frame is incomplete; the next one gets span buffers twice as large (mi355_render retries by itself)
-        HIP_TRY(hipMemset((char *)c->ctrl.p + 16 + sizeof(unsigned long long) * CS_OVERFLOW, 0, sizeof(unsigned long long)), -31);
-        int grown = mi355i_raster_grow(c->rscratch);
-        for (int k = 0; k < mi355_ctx::PIPE_SETS; k++) if (c->rs_pipe[k] && c->rs_pipe[k] != c->rscratch) grown |= mi355i_raster_grow(c->rs_pipe[k]);
-        return fail(-44, "rasterizer triangle bins overflowed (%llu entries dropped)%s", h[CS_OVERFLOW],
-                    grown ? "; the buffers grow for the next frame" : "");
-    }
-    return 0;
-}
-
-// Not part of the public ABI (mgpu.hip): device address of the ray counters (normal rays, shadow rays: two 64-bit words) of the
-// context's most recent call -- valid, in stream order, behind that call on the stream it was given
-void *mi355i_last_ray_counters(mi355_ctx *c) { return c ? (char *)(c->last_ctrl ? c->last_ctrl : c->ctrl.p) + 16 : nullptr; }
-
-// Not part of the public ABI (bench.py: `traced_rays_per_frame`): of the most recent call's normal_rays, the camera rays that were
-// never generated -- pixels of tiles the tile culling set to black (mi355_stats counts them: the reference traces one per pixel)
-int mi355i_fetch_culled_rays(mi355_ctx *c, unsigned long long *out)
-{
-    if (!c || !out) return fail(-3, "mi355i_fetch_culled_rays: null argument");
-    if (int r = select_device(c)) return r;
-    HIP_TRY(hipMemcpy(out, (char *)(c->last_ctrl ? c->last_ctrl : c->ctrl.p) + 16 + sizeof(unsigned long long) * CS_CULLED_RAYS, sizeof *out, hipMemcpyDeviceToHost), -31);
-    return 0;
-}
-
-// Not part of the public ABI: known-answer test of the device's float arithmetic (tests/test_gpu_parity.py).  Every
-// pixel of every mode rests on these operations rounding exactly like the strict x86-64 build of the reference:
-// out[0..8][i] = a/b, sqrt(a), a*b+c (two roundings: no contraction), a+b, a*b, cvtt_i32(a), myfloor(a), u8cast(a),
-// (float)((double)(a*b)/255.0)
-__global__ void k_float_kat(const float *a, const float *b, const float *c, uint32_t *out, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float x = a[i], y = b[i], z = c[i];
-    out[i] = __float_as_uint(x / y);
-    out[n + i] = __float_as_uint(__builtin_sqrtf(x));
-    out[2 * n + i] = __float_as_uint(x * y + z);
-    out[3 * n + i] = __float_as_uint(x + y);
-    out[4 * n + i] = __float_as_uint(x * y);
-    out[5 * n + i] = (uint32_t)cvtt_i32(x);
-    out[6 * n + i] = (uint32_t)myfloor_i(x);
-    out[7 * n + i] = u8cast(x);
-    out[8 * n + i] = __float_as_uint((float)((double)(x * y) / 255.0));
-}
-
-int mi355i_float_kat(const float *a, const float *b, const float *c, uint32_t *out9n, uint32_t n)
-{
-    if (!a || !b || !c || !out9n || !n) return fail(-3, "mi355i_float_kat: null argument");
-    int ndev = 0;
-    if (int r = mi355_init(0, &ndev)) return r;
-    float *d_in = nullptr; uint32_t *d_out = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_in, (size_t)n * 12), -31);
-    HIP_TRY(hipMalloc((void **)&d_out, (size_t)n * 36), -31);
-    HIP_TRY(hipMemcpy(d_in, a, (size_t)n * 4, hipMemcpyHostToDevice), -31);
-    HIP_TRY(hipMemcpy(d_in + n, b, (size_t)n * 4, hipMemcpyHostToDevice), -31);
-    HIP_TRY(hipMemcpy(d_in + 2 * (size_t)n, c, (size_t)n * 4, hipMemcpyHostToDevice), -31);
-    hipLaunchKernelGGL(k_float_kat, dim3((n + 255) / 256), dim3(256), 0, 0, d_in, d_in + n, d_in + 2 * (size_t)n, d_out, n);
-    HIP_TRY(hipGetLastError(), -43);
-    HIP_TRY(hipMemcpy(out9n, d_out, (size_t)n * 36, hipMemcpyDeviceToHost), -31);
-    (void)hipFree(d_in); (void)hipFree(d_out);
-    return 0;
-}
-
-// Not part of the public ABI: kernel phase profile of the last frame rendered with collect_stats
-// (20 words: total/refill/transition/inner/leaf cycles, iteration and lane-occupancy sums, wave count, LDS visits,
-// then 100 MHz stamps: launch start, dispenser dry, last wave end, and the largest per-wave iteration count).
-int mi355i_fetch_profile(mi355_ctx *c, unsigned long long *out16)
-{
-    if (!c || !out16) return fail(-3, "mi355i_fetch_profile: null argument");
-    if (int r = select_device(c)) return r;
-    HIP_TRY(hipMemcpy(out16, (char *)c->ctrl.p + 16 + sizeof(unsigned long long) * CS_PROF0, 20 * sizeof(unsigned long long), hipMemcpyDeviceToHost), -31);
-    return 0;
-}
-
-// Not part of the public ABI: how the raytracer will walk this scene's tree.
-// out[0] = 1 when the ordered walk is available (tree passed the checks), out[1] = per-lane stack entries,
-// out[2] = BVH nodes, out[3] = 1 when every box coordinate is in the filtered box test's range.
-int mi355i_scene_info(mi355_ctx *c, uint32_t *out4)
-{
-    if (!c || !out4) return fail(-3, "mi355i_scene_info: null argument");
-    out4[0] = c->has_bvh ? c->dev.ordered_ok : 0u;
-    out4[1] = c->dev.stack_depth;
-    out4[2] = c->dev.n_nodes;
-    out4[3] = c->boxes_tame ? 1u : 0u;
-    return 0;
-}
-
-// tests: what a lane of the ordered walk computes for (ray, box) pairs (k_raytrace.hip k_cull_probe); out4 = n_pairs * 4 floats
-extern "C" hipError_t mi355i_launch_cull_probe(const float *rays6, const uint32_t *pair_ray, const float *pair_box6, uint32_t n_pairs, float scene_mag,
-                                               float *out4, hipStream_t st);
-int mi355i_cull_probe(mi355_ctx *c, const float *rays6, uint32_t n_rays, const uint32_t *pair_ray, const float *pair_box6, uint32_t n_pairs, float *out4)
-{
-    if (!c || !rays6 || !pair_ray || !pair_box6 || !out4) return fail(-3, "mi355i_cull_probe: null argument");
-    if (!c->has_bvh) return fail(-41, "no BVH installed");
-    if (int r = select_device(c)) return r;
-    DevBuf d_r, d_p, d_b, d_o;
-    auto done = [&](int rc) { d_r.release(); d_p.release(); d_b.release(); d_o.release(); return rc; };
-    if (d_r.ensure((size_t)n_rays * 24 + 16) != hipSuccess || d_p.ensure((size_t)n_pairs * 4 + 16) != hipSuccess ||
-        d_b.ensure((size_t)n_pairs * 24 + 16) != hipSuccess || d_o.ensure((size_t)n_pairs * 16 + 16) != hipSuccess) return done(fail(-31, "mi355i_cull_probe: out of device memory"));
-    if (hipMemcpy(d_r.p, rays6, (size_t)n_rays * 24, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_p.p, pair_ray, (size_t)n_pairs * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d_b.p, pair_box6, (size_t)n_pairs * 24, hipMemcpyHostToDevice) != hipSuccess) return done(fail(-31, "mi355i_cull_probe: upload failed"));
-    if (mi355i_launch_cull_probe((const float *)d_r.p, (const uint32_t *)d_p.p, (const float *)d_b.p, n_pairs, c->dev.scene_mag, (float *)d_o.p, c->stream) != hipSuccess)
-        return done(fail(-43, "mi355i_cull_probe: launch failed"));
-    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out4, d_o.p, (size_t)n_pairs * 16, hipMemcpyDeviceToHost) != hipSuccess)
-        return done(fail(-40, "mi355i_cull_probe: kernel failed"));
-    return done(0);
-}
-
-// debug / tests: the installed traversal state.  which = 0: the DevScene scalars (as 32 words: root_a, root_b, vroot_a, vroot_b, root_link,
-// tri_base, ordered_ok, stack_depth, scene_mag, n_nodes); 1, 2, 3: the first `bytes` bytes of the walk / edge / shading streams.
-int mi355i_fetch_traversal(mi355_ctx *c, int which, void *out, size_t bytes)
-{
-    if (!c || !out) return fail(-3, "mi355i_fetch_traversal: null argument");
-    if (!c->has_bvh) return fail(-41, "no BVH installed");
-    if (int r = select_device(c)) return r;
-    if (which == 0) {
-        uint32_t w[32] = {0};
-        memcpy(w, &c->dev.root_a, 16); memcpy(w + 4, &c->dev.root_b, 16); memcpy(w + 8, &c->dev.vroot_a, 16); memcpy(w + 12, &c->dev.vroot_b, 16);
-        w[16] = c->dev.root_link; w[17] = c->dev.tri_base; w[18] = c->dev.ordered_ok; w[19] = c->dev.stack_depth;
-        memcpy(w + 20, &c->dev.scene_mag, 4); w[21] = c->dev.n_nodes; w[22] = c->boxes_tame ? 1u : 0u; w[23] = c->dev.root_direct;
-        memcpy(out, w, bytes < sizeof w ? bytes : sizeof w);
-        return 0;
-    }
-    const DevBuf *b = which == 1 ? &c->walk : (which == 2 ? &c->tri_edge : (which == 3 ? &c->tri_shade : nullptr));
-    if (!b || bytes > b->bytes) return fail(-3, "mi355i_fetch_traversal: stream %d holds %zu bytes, %zu asked", which, b ? b->bytes : (size_t)0, bytes);
-    HIP_TRY(hipDeviceSynchronize(), -40);
-    host_trace("fetch buffer ctx %p: out %p + %zu", (void *)c, (void *)out, (size_t)bytes);
-    HIP_TRY(hipMemcpy(out, b->p, bytes, hipMemcpyDeviceToHost), -31);
-    return 0;
-}
-
-// debug: per-wave profiles of the last counting raytrace launch; returns the number of waves written
-int mi355i_fetch_wave_profiles(mi355_ctx *c, unsigned long long *out, int max_waves)
-{
-    if (!c || !out || !c->wave_prof.p) return fail(-3, "no wave profile");
-    if (int r = select_device(c)) return r;
-    int n = c->last_blocks;              // (waves)
-    if (n > max_waves) n = max_waves;
-    HIP_TRY(hipMemcpy(out, c->wave_prof.p, (size_t)n * 16 * 8, hipMemcpyDeviceToHost), -31);
-    return n;
-}
-
 // frame memory handed out by mi355_host_alloc (process-wide: page-locked for every context)
 static std::mutex g_host_alloc_mu;
 static std::vector<std::pair<char *, size_t>> g_host_alloc;
