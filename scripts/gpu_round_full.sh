@@ -1,8 +1,8 @@
-# The evidence run behind profiles/<tag>_*  (one gpurun call:  gpurun --timeout 1500 -- 'bash scripts/gpu_round_full.sh r04'):
+# The evidence run behind profiles/<tag>_*  (one gpurun call:  gpurun --timeout 1500 -- 'bash scripts/gpu_round_full.sh r05'):
 # GPU tests, the bench line (counters collected in the run), kernel stats of launches one after the other and of the default
 # overlapped run, the rasterizer's and the shadow map's kernels, side measurements (variants, frame by frame, the seam, render_cli -b),
 # counter passes of the bench kernel; scripts/make_profiles.py <tag> then copies what is tracked into profiles/.
-TAG=${1:-r04}
+TAG=${1:-r05}
 mkdir -p gpurun_out
 R=$(pwd)
 (timeout 900 python -m pytest tests -m gpu -q -rs --capture=sys 2>&1 | tail -12) > gpurun_out/pytest_full.log
@@ -10,9 +10,10 @@ tail -3 gpurun_out/pytest_full.log
 (timeout 600 python bench.py 2>gpurun_out/bench_full.err | tail -1) > gpurun_out/bench_full.log
 tail -1 gpurun_out/bench_full.log | cut -c1-300
 {
-  echo "== scripts/rt_variants.py (dragon 1080p: batches of 8, single frames; work sharing, register builds, four-wide walk, bounds)"; timeout 300 python scripts/rt_variants.py 2>&1 | grep variant
+  echo "== scripts/rt_variants.py (dragon 1080p depth 3 and statue depth 1: batches of 8, single frames, frame hashes; work sharing off / register builds / 16 frames per launch as knobs)"
+  timeout 300 python scripts/rt_variants.py default 'default:RT_TUNE={"noshare":1}' 'default:RT_TUNE={"bpc":3}' 'default:RT_B=16' 2>&1 | grep variant
   echo "== scripts/shadowmap_time.py (LDS tiles from a dispenser)"; timeout 100 python scripts/shadowmap_time.py 2>&1 | grep "us per"
-  echo "== scripts/raster_pipe_variants.py"; timeout 100 python scripts/raster_pipe_variants.py 2>&1 | tail -1
+  echo "== scripts/raster_phases.py (the tile kernel's phases on counting frames; frames/s by threads per tile)"; timeout 100 python scripts/raster_phases.py 2>&1 | tail -14
   echo "== scripts/raytrace_frame_by_frame.py"; timeout 100 python scripts/raytrace_frame_by_frame.py 2>&1 | tail -8
   echo "== scripts/render_cli_configs.sh (render_cli -b, BASELINE.json's five configurations)"; timeout 200 bash scripts/render_cli_configs.sh 2>&1
   echo "== scripts/ubench/apicost (host cost of the HIP calls a frame makes)"; (hipcc -O2 --offload-arch=gfx950 -o /tmp/apicost scripts/ubench/apicost.hip && timeout 60 /tmp/apicost) 2>&1 | tail -14
@@ -32,5 +33,6 @@ for v in default noshare bpc3; do
   done
 done
 cd $R
+echo "== scripts/rt_pmc.py (TA / TD / wait counters of the bench kernel)"; (timeout 200 python scripts/rt_pmc.py > gpurun_out/rt_pmc.json 2>&1; tail -40 gpurun_out/rt_pmc.json)
 find gpurun_out -name "*kernel_trace.csv" -size +2M -delete
 python scripts/make_profiles.py $TAG

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Distil the rocprofv3 output of scripts/gpu_round_full.sh (under gpurun_out/) into the tracked files in profiles/.
 
-    python scripts/make_profiles.py [round-tag, default r04]
+    python scripts/make_profiles.py [round-tag, default r05]
 """
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 KERNELS = {"default": "k_raytrace<false, false, true, 4, true", "noshare": "k_raytrace<false, false, true, 4, true", "bpc3": "k_raytrace<false, false, true, 3, true"}
 
 
