@@ -160,7 +160,8 @@ int build_bvh_streams(mi355_ctx *c, const void *nodes32B, uint32_t nN, const int
             }
         }
     }
-    c->dev.ordered_ok = (tame && bounded && list_in_visit_order && inner_levels + 1 <= MI_MAX_STACK) ? 1u : 0u;
+    // (... and fewer than 2^24 triangles: a queued leaf names its first triangle in 24 bits, k_raytrace.hip)
+    c->dev.ordered_ok = (tame && bounded && list_in_visit_order && inner_levels + 1 <= MI_MAX_STACK && c->nT < (1u << 24)) ? 1u : 0u;
     c->dev.stack_depth = (uint32_t)(inner_levels + 1);
     c->dev.scene_mag = mag;
 
@@ -373,7 +374,7 @@ int mi355_build_bvh(mi355_ctx *c, void *nodes32B, int32_t *tri_idx, uint32_t *n_
     const double t_down = clk();
     // install: the streams are already where the kernels read them
     c->boxes_tame = ctl->tame != 0u;
-    c->dev.ordered_ok = (ctl->tame && ctl->bounded && ctl->inner_levels + 1u <= (uint32_t)MI_MAX_STACK) ? 1u : 0u;
+    c->dev.ordered_ok = (ctl->tame && ctl->bounded && ctl->inner_levels + 1u <= (uint32_t)MI_MAX_STACK && c->nT < (1u << 24)) ? 1u : 0u;
     c->dev.stack_depth = ctl->inner_levels + 1u;
     c->dev.scene_mag = ctl->mag;
     c->dev.walk = (const float4 *)c->walk.p;

@@ -53,6 +53,12 @@ namespace {
 #ifndef RT_PAIRBATCH
 #define RT_PAIRBATCH 0
 #endif
+#ifndef RT_DEFER
+#define RT_DEFER 1          // single frames on the two- and three-wave builds: leaf triangles queued per wave and tested 64 at a time (see the DEFER loop)
+#endif
+#ifndef RT_FLUSH_AT
+#define RT_FLUSH_AT 48
+#endif
 #ifndef RT_EDGEMASK
 #define RT_EDGEMASK 1
 #endif
@@ -535,6 +541,7 @@ k_raytrace(const DevScene S, const FrameParams P)
     // behind the stack's: the verdict words, and a per-wave table (rank among the givers -> lane).
     constexpr bool STEAL = ORDERED && !STATS && !EXT;
     const bool steal_on = STEAL && P.steal_min > 0;
+    constexpr bool DEFER = STEAL && RT_DEFER && !BATCH && WAVES <= 3;
     // Rows behind the stack's.  Two rows of 64-bit RESULT words, one per thread of the block: the state of the ray that thread
     // owns, as everybody who walks a part of it sees it -- a closest-hit ray: distance^2 bits << 32 | triangle of the best hit so
     // far (atomic min: the nearest hit, the lowest triangle among equals -- the rule of the walk itself), a shadow ray: 0 once a
@@ -545,7 +552,9 @@ k_raytrace(const DevScene S, const FrameParams P)
     uint32_t *const stab = (uint32_t *)(result + RT_BLK) + (threadIdx.x & ~63u);
     // (work sharing: the light a lane's shadow ray aims at, three rows -- whoever walks a part of that ray looks it up when a
     //  triangle lies across the ray, instead of carrying it through the walk)
-    float *const lds_lp = (float *)(result + RT_BLK) + RT_BLK;
+    // (DEFER: two rows of queued leaves, see the walk)
+    uint32_t *const lds_q = (uint32_t *)(result + RT_BLK) + RT_BLK;
+    float *const lds_lp = (float *)(lds_q + (DEFER ? 2 * RT_BLK : 0));
     // (ordered builds: a hit's reflected direction waits in three rows while the hit's shadow rays are walked; a 4 spp frame
     //  keeps its pixel sums in three more, which only such a launch allocates)
     float *const lds_refl = lds_lp + 3 * RT_BLK + threadIdx.x;
@@ -977,6 +986,234 @@ k_raytrace(const DevScene S, const FrameParams P)
         const bool share_now = STEAL && steal_on;
         const bool own_closest = alive && L.mode == MODE_CLOSEST;
         bool lent = false, took = false;
+        if constexpr (DEFER) {
+        // ---- the same walk with the leaves' triangles tested apart (RT_DEFER) ----------------------------------------------------------
+        // A step only visits wide records.  A leaf child that would be entered is QUEUED instead -- an entry per lane and step in two
+        // LDS rows: the lane it came from, the leaf's first triangle, `both` when the node's two children are leaves that are both
+        // entered (their triangles lie side by side in list order) -- and the lane goes on with its next node at once.  When
+        // RT_FLUSH_AT leaves wait (or nobody walks any more) the wave tests them 64 at a time: a lane takes an entry, fetches the ray
+        // from the lane it names (whoever walks a part of a ray holds a copy of it), walks the leaf's chain of triangle blocks with
+        // the plane and edge tests of Raytracer.cc:245-297, and puts what it finds into the ray's result word -- the word the work
+        // sharing already merges results in: atomic min of (distance^2, triangle) for a closest-hit ray, a zeroed upper half for a
+        // blocked shadow ray.  Then every lane that still walks reads its ray's word and tightens its bound (or stops).
+        // Legal for the reason the ordered walk is: the result is an order-free function of the accepted hits, and which triangles
+        // are TESTED does not change -- the leaves entered are a superset (a bound that arrives later culls less), never a subset.
+        // What it buys: the triangle tests run for 64 lanes at a time instead of for the dozen that happen to sit on a triangle, and
+        // a leaf costs its ray no steps.
+        uint32_t q_len = 0;                           // leaves queued (wave-uniform)
+        unsigned long long q_src = 0ull;              // lanes named by a queued entry: their copy of the ray must stay where it is
+        const int lane = (int)(threadIdx.x & 63u);
+        for (;;) {
+            unsigned long long mWalk = __ballot(L.cur != MI_END_LINK);
+            // (leave when enough rays have ended -- every one of them in the default lockstep mode --, with nothing left in the queue)
+            const bool leave = !mWalk || (xmin_now < 64 && __popcll(__ballot(alive && L.cur == MI_END_LINK)) >= xmin_now);
+            if (q_len >= (uint32_t)RT_FLUSH_AT || (leave && q_len)) {
+                for (uint32_t qb = 0; qb < q_len; qb += 64u) {
+                    const bool have = qb + (uint32_t)lane < q_len;
+                    const uint32_t en = have ? lds_q[qb + (uint32_t)lane] : 0u;
+                    const int src = (int)(en >> 26);
+                    bool both = ((en >> 25) & 1u) != 0u;
+                    uint32_t two = (en >> 24) & 1u;
+                    uint32_t j = en & 0xffffffu;
+                    const f3 fo = mk3(__shfl(L.o.x, src), __shfl(L.o.y, src), __shfl(L.o.z, src));
+                    const f3 fd = mk3(__shfl(L.d.x, src), __shfl(L.d.y, src), __shfl(L.d.z, src));
+                    const int favoid = __shfl(L.avoid, src), fown = __shfl(L.owner, src), fmode = __shfl(L.mode, src);
+                    typedef unsigned long long u64;
+                    const u64 mshadow = __ballot(fmode == MODE_SHADOW);
+                    const bool shadow = __builtin_amdgcn_inverse_ballot_w64(mshadow);
+                    bool act = have;
+                    while (__ballot(act)) {
+                        const float4 *tp = S.walk + (size_t)S.tri_base + (size_t)(act ? j : 0u) * 2;
+                        const float4 ba = tp[0], bb = tp[1];
+                        // plane half (Raytracer.cc:245-267), the same operations as in the step of the other builds
+                        const f3 n = mk3(ba.x, ba.y, ba.z);
+                        const f3 fto = sub3(fo, mk3(bb.x, bb.y, bb.z));
+                        const u64 mface = __ballot(two != 0u) | __ballot(!(dot3(fto, n) < 0.f));
+                        const float tk = dot3(n, fd);
+                        const float sp = (bb.w - dot3(n, fo)) / tk;
+                        const u64 mcand = __ballot(act) & __ballot((int)j != favoid) & mface & ~__ballot(tk == 0.0f) & ~__ballot(sp <= 0.0f) & ~__ballot(sp <= P.nudge);
+                        if (mcand) {
+                            const bool cand = __builtin_amdgcn_inverse_ballot_w64(mcand);
+                            float4 e1, q, r;
+                            asm volatile("" : "=v"(e1.x), "=v"(e1.y), "=v"(e1.z), "=v"(e1.w), "=v"(q.x), "=v"(q.y), "=v"(q.z), "=v"(q.w), "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w));
+                            if (cand) { const float4 *e = S.tri_edge + (size_t)j * 3; e1 = e[0]; q = e[1]; r = e[2]; }
+                            const f3 hit = add3(mul3(fd, sp), fo);
+                            const float kt1 = dot3(mk3(e1.x, e1.y, e1.z), hit) - e1.w;
+                            const v2f xs = {q.x, q.y}, ys = {q.z, q.w}, zs = {r.x, r.y}, ds = {r.z, r.w};
+                            const v2f kt23 = ((xs * hit.x + ys * hit.y) + zs * hit.z) - ds;
+                            const u64 minside = mcand & __ballot(!(kt1 < 0.0f)) & __ballot(!(kt23.x < 0.0f)) & __ballot(!(kt23.y < 0.0f));
+                            if (minside) {
+                                // a shadow ray is blocked by a hit nearer to the light than the ray's origin is (Raytracer.cc:209, 282-284:
+                                // bestTriDist starts as |o - light|^2, made here by the operations that made L.best); a closest-hit ray
+                                // takes the minimum of (distance^2, list position): strict `<`, ties to the first in the list (:288)
+                                f3 from = fo;
+                                float bound = 0.f;
+                                if (minside & mshadow) {
+                                    const int ow = shadow ? fown : (int)threadIdx.x;
+                                    const f3 lp = mk3(lds_lp[ow], lds_lp[RT_BLK + ow], lds_lp[2 * RT_BLK + ow]);
+                                    if (shadow) { from = lp; bound = distsq3(fo, lp); }
+                                }
+                                const float dz = distsq3(from, hit);
+                                if (__builtin_amdgcn_inverse_ballot_w64(minside & mshadow & __ballot(dz < bound))) ((uint32_t *)result)[2 * fown + 1] = 0u;
+                                if (__builtin_amdgcn_inverse_ballot_w64(minside & ~mshadow)) atomicMin(result + fown, result_key(dz, (int)j));
+                            }
+                        }
+                        // the chain: the next block while it lies in this leaf -- or, `both`, in the sibling leaf behind it
+                        const uint32_t nx = __float_as_uint(ba.w);
+                        const bool leafnx = (nx & MI_LEAF_BIT) != 0u && nx != MI_END_LINK, firstnx = (nx & MI_FIRST_BIT) != 0u;
+                        act = act && leafnx && (!firstnx || both);
+                        if (firstnx) both = false;
+                        two = (nx & MI_TWOSIDED_BIT) ? 1u : 0u;
+                        j++;
+                    }
+                }
+                q_len = 0u; q_src = 0ull;
+                // what the tests found, for everyone who still walks: a blocked shadow ray ends, a closest-hit ray's bound tightens
+                if (L.cur != MI_END_LINK) {
+                    const unsigned long long seen = result[L.owner];
+                    if (L.mode == MODE_SHADOW) {
+                        if ((uint32_t)(seen >> 32) == 0u) { L.cur = MI_END_LINK; L.sp = L.base; }
+                    } else {
+                        const float sb = __uint_as_float((uint32_t)(seen >> 32));
+                        if (sb < L.best) { L.best = sb; L.btri = (int)(uint32_t)seen; L.cull = cull_from(limit_from(sb, L.o, S.scene_mag), L.dmax2); }
+                    }
+                }
+                // (the lanes' records were not kept through the tests: requested again)
+                {
+                    const uint32_t c = L.cur;
+                    const bool real = c != MI_END_LINK && c != MI_VROOT_LINK;
+                    const float4 *p = S.walk + (size_t)(real ? (c & MI_INDEX_MASK) : 0u);
+                    const float4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+                    const bool vr = c == MI_VROOT_LINK;
+                    R.a = vr ? S.vroot_a : a0; R.b = vr ? S.vroot_b : a1; R2.a = vr ? S.vroot_a : a2; R2.b = vr ? S.vroot_b : a3;
+                }
+                continue;
+            }
+            if (leave) break;
+            if (RT_COUNT) { cq[0]++; cq[1]++; cq[2] += __popcll(mWalk); cq[10] += 64 - __popcll(mWalk); }
+            // -- work sharing: as in the other builds; a lane named by a queued entry takes nothing (its copy of the ray is read at the flush)
+            if (share_now) {
+                const unsigned long long mTk = ~mWalk & ~q_src & __ballot(true), mGv = mWalk & __ballot(L.sp > L.base);
+                if (mGv && __popcll(mTk) >= P.steal_min) {
+                    const bool taker = __builtin_amdgcn_inverse_ballot_w64(mTk), giver = __builtin_amdgcn_inverse_ballot_w64(mGv);
+                    n_event++;
+                    lent = true;
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    const int gr = __popcll(mGv & below), tr = __popcll(mTk & below);
+                    const int nG = __popcll(mGv), nT = __popcll(mTk);
+                    if (giver) stab[gr] = (uint32_t)lane;
+                    const bool deep = L.sp - L.base >= 2;
+                    uint32_t give = L.top;
+                    if (giver && deep) give = stk[L.base * RT_BLK];
+                    const bool takes = taker && tr < nG, robbed = giver && gr < nT;
+                    const int v = takes ? (int)stab[tr] : lane;
+                    L.o = mk3(__shfl(L.o.x, v), __shfl(L.o.y, v), __shfl(L.o.z, v));
+                    L.d = mk3(__shfl(L.d.x, v), __shfl(L.d.y, v), __shfl(L.d.z, v));
+                    L.inv = mk3(__shfl(L.inv.x, v), __shfl(L.inv.y, v), __shfl(L.inv.z, v));
+                    L.dmax2 = __shfl(L.dmax2, v); L.cull = __shfl(L.cull, v); L.best = __shfl(L.best, v);
+                    L.avoid = __shfl(L.avoid, v); L.owner = __shfl(L.owner, v); L.tame = __shfl(L.tame ? 1 : 0, v) != 0;
+                    L.mode = __shfl(L.mode, v); L.btri = __shfl(L.btri, v);
+                    const uint32_t vgive = (uint32_t)__shfl((int)give, v);
+                    if (takes) {
+                        L.sp = 0; L.base = 0; L.top = MI_END_LINK;
+                        L.cur = vgive;
+                        const float4 *p = S.walk + (size_t)(vgive & MI_INDEX_MASK);
+                        R.a = p[0]; R.b = p[1]; R2.a = p[2]; R2.b = p[3];
+                        n_steal++;
+                        took = true;
+                    }
+                    if (robbed) {
+                        if (deep) L.base++;
+                        else { L.sp = L.base; L.top = MI_END_LINK; }
+                    }
+                    mWalk = __ballot(L.cur != MI_END_LINK);
+                }
+            }
+            const int sbase = L.base;
+            const bool walking = __builtin_amdgcn_inverse_ballot_w64(mWalk);
+            uint32_t next = MI_END_LINK;
+            // -- the step: both children's box tests; inner children entered / postponed, leaf children queued.  Straight-line for the
+            //    whole wave (the queue's fill level is the wave's, not a lane's): lanes that do not walk are masked out of every verdict
+            {
+                typedef unsigned long long u64;
+                const uint32_t linkL = __float_as_uint(R.b.z), linkR = __float_as_uint(R.b.w);
+                const float4 loL = make_float4(R.a.x, R.a.z, R.b.x, 0.f), hiL = make_float4(R.a.y, R.a.w, R.b.y, 0.f);
+                const float4 loR = make_float4(R2.a.x, R2.a.z, R2.b.x, 0.f), hiR = make_float4(R2.a.y, R2.a.w, R2.b.y, 0.f);
+                const u64 mleafL = __ballot((int)linkL < 0), mleafR = __ballot((int)linkR < 0);
+                u64 mhL, mhR, mlf = ~0ull;
+                if (EXACT_BOX) {
+                    mhL = mleafL | __ballot(ray_box_exact(L.o, L.d, loL, hiL));
+                    mhR = mleafR | __ballot(ray_box_exact(L.o, L.d, loR, hiR));
+                } else {
+                    const float ndm = -0.5f * L.dmax2;
+                    const auto half = [&](const float4 a, const float4 b, const u64 mleaf, float &key, u64 &msure) -> u64 {
+                        float tn_lo, tn_hi, tf_lo, tf_hi, tf;
+                        box_bounds(L.o, L.inv, a, b, tn_lo, tn_hi, tf_lo, tf_hi, tf);
+                        const u64 mneg = __ballot(tf < 0.f);
+                        const float gap = tn_lo - tf_hi;
+                        const u64 mpass = __ballot(tn_hi <= tf_lo) & ~mneg;
+                        msure = mpass | mneg | __ballot(gap > 0.f);
+                        key = tn_lo;
+                        const u64 mmiss = __ballot(gap > L.dmax2) | __ballot(tf_hi < ndm);
+                        return ((mleaf & ~mmiss) | (~mleaf & mpass)) & ~__ballot(tn_lo > L.cull);
+                    };
+                    u64 msL, msR;
+                    float kL, kR;
+                    mhL = half(R.a, R.b, mleafL, kL, msL);
+                    mhR = half(R2.a, R2.b, mleafR, kR, msR);
+                    mlf = __ballot(kL <= kR);
+                    const u64 mneed = ~((msL | mleafL) & (msR | mleafR) & __ballot(L.tame)) & mWalk;
+                    if (__builtin_expect(mneed != 0ull, 0)) {
+                        bool eL = false, eR = false;
+                        if (__builtin_amdgcn_inverse_ballot_w64(mneed)) {
+                            eL = (int)linkL < 0 || ray_box_exact(L.o, L.d, loL, hiL);
+                            eR = (int)linkR < 0 || ray_box_exact(L.o, L.d, loR, hiR);
+                        }
+                        mhL = (mhL & ~mneed) | __ballot(eL);
+                        mhR = (mhR & ~mneed) | __ballot(eR);
+                    }
+                }
+                mhL &= mWalk;
+                mhR &= mWalk & __ballot(linkR != MI_END_LINK);
+                // inner children: the nearer one next, the other postponed
+                const u64 meL = mhL & ~mleafL, meR = mhR & ~mleafR;
+                const u64 mtakeL = meL & (~meR | mlf), mtakeR = meR & ~mtakeL;
+                next = __builtin_amdgcn_inverse_ballot_w64(mtakeL) ? linkL : (__builtin_amdgcn_inverse_ballot_w64(mtakeR) ? linkR : (uint32_t)MI_END_LINK);
+                if (__builtin_amdgcn_inverse_ballot_w64(meL & meR)) {
+                    if (L.sp > sbase) stk[(L.sp - 1) * RT_BLK] = L.top;
+                    L.top = __builtin_amdgcn_inverse_ballot_w64(mlf) ? linkR : linkL;
+                    L.sp++;
+                }
+                // leaf children: one entry per lane (`both`: the left leaf's chain runs on into the right one's)
+                const u64 mpL = mhL & mleafL, mpR = mhR & mleafR, mpush = mpL | mpR;
+                if (mpush) {
+                    if (RT_COUNT) cq[9] += __popcll(mpL) + __popcll(mpR);
+                    if (__builtin_amdgcn_inverse_ballot_w64(mpush)) {
+                        const bool pl = __builtin_amdgcn_inverse_ballot_w64(mpL), pb = __builtin_amdgcn_inverse_ballot_w64(mpL & mpR);
+                        const uint32_t lk = pl ? linkL : linkR;
+                        const uint32_t j0 = ((lk & MI_INDEX_MASK) - S.tri_base) >> 1;
+                        const uint32_t at = q_len + (uint32_t)__popcll(mpush & ((1ull << lane) - 1ull));
+                        lds_q[at] = ((uint32_t)lane << 26) | (pb ? 1u << 25 : 0u) | ((lk & MI_TWOSIDED_BIT) ? 1u << 24 : 0u) | (j0 & 0xffffffu);
+                    }
+                    q_len += (uint32_t)__popcll(mpush);
+                    q_src |= mpush;
+                }
+                // nothing to enter: the most recently postponed node
+                if (walking && next == MI_END_LINK && L.sp > sbase) {
+                    next = L.top;
+                    L.sp--;
+                    if (L.sp > sbase) L.top = stk[(L.sp - 1) * RT_BLK];
+                }
+                if (walking) {
+                    L.cur = next;
+                    if (next != MI_END_LINK) {
+                        const float4 *p = S.walk + (size_t)(next & MI_INDEX_MASK);
+                        R.a = p[0]; R.b = p[1]; R2.a = p[2]; R2.b = p[3];
+                    }
+                }
+            }
+        }
+        } else {
         for (;;) {
             if (STATS) it_loops++;
             unsigned long long seen = MI_RESULT_NONE;
@@ -1305,6 +1542,7 @@ k_raytrace(const DevScene S, const FrameParams P)
             const unsigned long long mBusy = __ballot(L.cur != MI_END_LINK || L.pend);
             if (!mBusy) break;
             if (xmin_now < 64 && __popcll(__ballot(alive && L.cur == MI_END_LINK && !L.pend)) >= xmin_now) break;
+        }
         }
         if constexpr (STEAL) {
             if (__ballot(took)) {
@@ -1650,7 +1888,10 @@ rt_kernel pick_kernel(int stats, int exact, int ordered, int waves, int batch, i
 // (stack rows, verdict row, giver table, three light rows, three rows of reflected directions; 4 spp: three rows of pixel sums)
 // (`rows` as the launcher passes it: three per depth level of the ray tree, the tree's stack rows if the walk is ordered, three
 //  more for a 4 spp frame)
-size_t stack_bytes(int ordered, int rows) { return (size_t)(rows + (ordered ? 9 : 0)) * (size_t)RT_BLK * sizeof(uint32_t); }
+// (`defer`: the build queues leaves -- two more rows)
+size_t stack_bytes(int ordered, int rows, int defer) { return (size_t)(rows + (ordered ? 9 + (defer ? 2 : 0) : 0)) * (size_t)RT_BLK * sizeof(uint32_t); }
+// which builds queue their leaves (k_raytrace: DEFER)
+int uses_defer(int stats, int ordered, int waves, int batch, int ext) { return RT_DEFER && ordered && !stats && !ext && !batch && waves <= 3; }
 } // namespace
 
 // can this build render several frames per launch?  (the ordered, non-counting kernels only)
@@ -1679,7 +1920,7 @@ extern "C" int mi355i_raytrace_waves_per_cu(int stats, int exact, int ordered, i
     int &slot = cache[ext ? 1 : 0][stats ? 1 : 0][exact ? 1 : 0][ordered ? 1 : 0][w][batch ? 1 : 0][stack_depth];
     if (!slot) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_kernel(stats, exact, ordered, waves, batch, ext), RT_BLK, stack_bytes(ordered, stack_depth)) != hipSuccess || nb < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_kernel(stats, exact, ordered, waves, batch, ext), RT_BLK, stack_bytes(ordered, stack_depth, uses_defer(stats, ordered, waves, batch, ext))) != hipSuccess || nb < 1)
             nb = 8;
         nb *= RT_BLK / 64;
         slot = nb > 32 ? 32 : nb;
@@ -1691,6 +1932,6 @@ extern "C" int mi355i_raytrace_waves_per_cu(int stats, int exact, int ordered, i
 extern "C" hipError_t mi355i_launch_raytrace(const DevScene *S, const FrameParams *P, int stats, int exact, int ordered, int waves,
                                              int batch, int ext, int stack_depth, int n_waves, hipStream_t st)
 {
-    hipLaunchKernelGGL(pick_kernel(stats, exact, ordered, waves, batch, ext), dim3((n_waves * 64 + RT_BLK - 1) / RT_BLK), dim3(RT_BLK), stack_bytes(ordered, stack_depth), st, *S, *P);
+    hipLaunchKernelGGL(pick_kernel(stats, exact, ordered, waves, batch, ext), dim3((n_waves * 64 + RT_BLK - 1) / RT_BLK), dim3(RT_BLK), stack_bytes(ordered, stack_depth, uses_defer(stats, ordered, waves, batch, ext)), st, *S, *P);
     return hipGetLastError();
 }
