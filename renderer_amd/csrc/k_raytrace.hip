@@ -552,9 +552,9 @@ k_raytrace(const DevScene S, const FrameParams P)
     uint32_t *const stab = (uint32_t *)(result + RT_BLK) + (threadIdx.x & ~63u);
     // (work sharing: the light a lane's shadow ray aims at, three rows -- whoever walks a part of that ray looks it up when a
     //  triangle lies across the ray, instead of carrying it through the walk)
-    // (DEFER: two rows of queued leaves, see the walk)
+    // (DEFER: three rows of queued leaves -- up to RT_FLUSH_AT - 1 waiting and two per lane from one step --, see the walk)
     uint32_t *const lds_q = (uint32_t *)(result + RT_BLK) + RT_BLK;
-    float *const lds_lp = (float *)(lds_q + (DEFER ? 2 * RT_BLK : 0));
+    float *const lds_lp = (float *)(lds_q + (DEFER ? 3 * RT_BLK : 0));
     // (ordered builds: a hit's reflected direction waits in three rows while the hit's shadow rays are walked; a 4 spp frame
     //  keeps its pixel sums in three more, which only such a launch allocates)
     float *const lds_refl = lds_lp + 3 * RT_BLK + threadIdx.x;
@@ -988,9 +988,9 @@ k_raytrace(const DevScene S, const FrameParams P)
         bool lent = false, took = false;
         if constexpr (DEFER) {
         // ---- the same walk with the leaves' triangles tested apart (RT_DEFER) ----------------------------------------------------------
-        // A step only visits wide records.  A leaf child that would be entered is QUEUED instead -- an entry per lane and step in two
-        // LDS rows: the lane it came from, the leaf's first triangle, `both` when the node's two children are leaves that are both
-        // entered (their triangles lie side by side in list order) -- and the lane goes on with its next node at once.  When
+        // A step only visits wide records.  A leaf child that would be entered is QUEUED instead -- an entry in three LDS rows: the lane
+        // it came from, the leaf's first triangle (a node's two leaves as ONE entry made the chains longer and the tests emptier:
+        // +3.5 % per frame) -- and the lane goes on with its next node at once.  When
         // RT_FLUSH_AT leaves wait (or nobody walks any more) the wave tests them 64 at a time: a lane takes an entry, fetches the ray
         // from the lane it names (whoever walks a part of a ray holds a copy of it), walks the leaf's chain of triangle blocks with
         // the plane and edge tests of Raytracer.cc:245-297, and puts what it finds into the ray's result word -- the word the work
@@ -1012,7 +1012,6 @@ k_raytrace(const DevScene S, const FrameParams P)
                     const bool have = qb + (uint32_t)lane < q_len;
                     const uint32_t en = have ? lds_q[qb + (uint32_t)lane] : 0u;
                     const int src = (int)(en >> 26);
-                    bool both = ((en >> 25) & 1u) != 0u;
                     uint32_t two = (en >> 24) & 1u;
                     uint32_t j = en & 0xffffffu;
                     const f3 fo = mk3(__shfl(L.o.x, src), __shfl(L.o.y, src), __shfl(L.o.z, src));
@@ -1058,11 +1057,9 @@ k_raytrace(const DevScene S, const FrameParams P)
                                 if (__builtin_amdgcn_inverse_ballot_w64(minside & ~mshadow)) atomicMin(result + fown, result_key(dz, (int)j));
                             }
                         }
-                        // the chain: the next block while it lies in this leaf -- or, `both`, in the sibling leaf behind it
+                        // the chain: the next block while it lies in this leaf
                         const uint32_t nx = __float_as_uint(ba.w);
-                        const bool leafnx = (nx & MI_LEAF_BIT) != 0u && nx != MI_END_LINK, firstnx = (nx & MI_FIRST_BIT) != 0u;
-                        act = act && leafnx && (!firstnx || both);
-                        if (firstnx) both = false;
+                        act = act && (nx & (MI_LEAF_BIT | MI_FIRST_BIT)) == MI_LEAF_BIT;
                         two = (nx & MI_TWOSIDED_BIT) ? 1u : 0u;
                         j++;
                     }
@@ -1184,18 +1181,15 @@ k_raytrace(const DevScene S, const FrameParams P)
                     L.top = __builtin_amdgcn_inverse_ballot_w64(mlf) ? linkR : linkL;
                     L.sp++;
                 }
-                // leaf children: one entry per lane (`both`: the left leaf's chain runs on into the right one's)
+                // leaf children: an entry each
                 const u64 mpL = mhL & mleafL, mpR = mhR & mleafR, mpush = mpL | mpR;
                 if (mpush) {
                     if (RT_COUNT) cq[9] += __popcll(mpL) + __popcll(mpR);
-                    if (__builtin_amdgcn_inverse_ballot_w64(mpush)) {
-                        const bool pl = __builtin_amdgcn_inverse_ballot_w64(mpL), pb = __builtin_amdgcn_inverse_ballot_w64(mpL & mpR);
-                        const uint32_t lk = pl ? linkL : linkR;
-                        const uint32_t j0 = ((lk & MI_INDEX_MASK) - S.tri_base) >> 1;
-                        const uint32_t at = q_len + (uint32_t)__popcll(mpush & ((1ull << lane) - 1ull));
-                        lds_q[at] = ((uint32_t)lane << 26) | (pb ? 1u << 25 : 0u) | ((lk & MI_TWOSIDED_BIT) ? 1u << 24 : 0u) | (j0 & 0xffffffu);
-                    }
-                    q_len += (uint32_t)__popcll(mpush);
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    if (__builtin_amdgcn_inverse_ballot_w64(mpL)) lds_q[q_len + (uint32_t)__popcll(mpL & below)] = ((uint32_t)lane << 26) | ((linkL & MI_TWOSIDED_BIT) ? 1u << 24 : 0u) | ((((linkL & MI_INDEX_MASK) - S.tri_base) >> 1) & 0xffffffu);
+                    q_len += (uint32_t)__popcll(mpL);
+                    if (__builtin_amdgcn_inverse_ballot_w64(mpR)) lds_q[q_len + (uint32_t)__popcll(mpR & below)] = ((uint32_t)lane << 26) | ((linkR & MI_TWOSIDED_BIT) ? 1u << 24 : 0u) | ((((linkR & MI_INDEX_MASK) - S.tri_base) >> 1) & 0xffffffu);
+                    q_len += (uint32_t)__popcll(mpR);
                     q_src |= mpush;
                 }
                 // nothing to enter: the most recently postponed node
@@ -1889,7 +1883,7 @@ rt_kernel pick_kernel(int stats, int exact, int ordered, int waves, int batch, i
 // (`rows` as the launcher passes it: three per depth level of the ray tree, the tree's stack rows if the walk is ordered, three
 //  more for a 4 spp frame)
 // (`defer`: the build queues leaves -- two more rows)
-size_t stack_bytes(int ordered, int rows, int defer) { return (size_t)(rows + (ordered ? 9 + (defer ? 2 : 0) : 0)) * (size_t)RT_BLK * sizeof(uint32_t); }
+size_t stack_bytes(int ordered, int rows, int defer) { return (size_t)(rows + (ordered ? 9 + (defer ? 3 : 0) : 0)) * (size_t)RT_BLK * sizeof(uint32_t); }
 // which builds queue their leaves (k_raytrace: DEFER)
 int uses_defer(int stats, int ordered, int waves, int batch, int ext) { return RT_DEFER && ordered && !stats && !ext && !batch && waves <= 3; }
 } // namespace
