@@ -1000,6 +1000,10 @@ k_raytrace(const DevScene S, const FrameParams P)
         // are TESTED does not change -- the leaves entered are a superset (a bound that arrives later culls less), never a subset.
         // What it buys: the triangle tests run for 64 lanes at a time instead of for the dozen that happen to sit on a triangle, and
         // a leaf costs its ray no steps.
+        // Single frames only (two- and three-wave builds), where a frame waits for the chains of its slowest tiles: 0.540 -> 0.469 ms for
+        // a 1080p dragon frame.  Batches are bound by issue slots, not by chains: on the three-wave build they gain 4 % (5 363 -> 5 590
+        // frames/s) and stay behind the four-wave build without the queue (5 920), and the four-wave build WITH it needs 204 bytes of
+        // scratch per lane, some inside the walk (4 320).
         uint32_t q_len = 0;                           // leaves queued (wave-uniform)
         unsigned long long q_src = 0ull;              // lanes named by a queued entry: their copy of the ray must stay where it is
         const int lane = (int)(threadIdx.x & 63u);
