@@ -299,7 +299,7 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
         // (the request mapped onto a build that exists -- k_raytrace.hip: pick_kernel; fallbacks and measuring builds come with two
         //  waves per SIMD only)
         int waves = 2;
-        mi355i_raytrace_variant(stats, &P.exact_box, &ordered, &waves, ext);
+        mi355i_raytrace_variant(stats, &P.exact_box, &ordered, &waves, ext, batch);
         if (ext && (stats || batch)) return fail(-41, "refractions / ray-cast ambient occlusion: single frames without collect_stats only");
         if (batch && !(ordered && !stats)) return fail(-41, "batched frames need the ordered walk (checked tree, no collect_stats, no reference-order flag)");
         const long long work_tiles = (((long long)P.W + 7) / 8) * (((long long)P.n_rows + 7) / 8) * (P.aa ? 4 : 1) * P.n_frames;
@@ -307,7 +307,9 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
         //  frame's three rows of pixel sums behind the kernel's own)
         const int stack_rows = 3 * P.max_depth + (ordered ? (int)c->dev.stack_depth + (P.aa ? 3 : 0) : 0);
         if (ordered && !stats && !ext && !P.exact_box) {
-            for (int w = 4; w >= 3; w--) {
+            // (round 5: single frames queue their leaves' triangles -- k_raytrace.hip, DEFER -- and are never faster on the four-wave build:
+            //  4K 0.912 ms on three waves against 0.935, 4 spp 1080p 1.85 against 2.25; batches keep it)
+            for (int w = batch ? 4 : 3; w >= 3; w--) {
                 // (round 3, with work shared inside the waves: a single 1080p frame is 3 % faster on the three-wave build than on
                 //  the two-wave one -- 0.649 against 0.668 ms -- so the bar for three waves is half of what it is for four)
                 const bool wanted = P.blocks_per_cu == 0 ? work_tiles >= (w == 3 ? 10ll : 20ll) * w * c->n_cus * 4 : P.blocks_per_cu >= w;

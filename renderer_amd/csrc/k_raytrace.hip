@@ -47,20 +47,11 @@ namespace {
 // by the thread), and a persistent block holds its registers and LDS until its last wave is done: with one wave per block a wave
 // that has finished its tiles frees its share at once for the next launch's blocks, instead of waiting for three neighbours.
 #define RT_BLK 64
-#ifndef RT_ROOTDIRECT
-#define RT_ROOTDIRECT 1
-#endif
-#ifndef RT_PAIRBATCH
-#define RT_PAIRBATCH 0
-#endif
 #ifndef RT_DEFER
 #define RT_DEFER 1          // single frames on the two- and three-wave builds: leaf triangles queued per wave and tested 64 at a time (see the DEFER loop)
 #endif
 #ifndef RT_FLUSH_AT
 #define RT_FLUSH_AT 48
-#endif
-#ifndef RT_EDGEMASK
-#define RT_EDGEMASK 1
 #endif
 #ifndef RT_COUNT
 #define RT_COUNT 0      // measuring variant: wave-uniform counters of the production loop (iterations, lanes per phase) in CS_PROF0 ..
@@ -436,7 +427,6 @@ MI_DEV void begin_walk(const DevScene &S, Lane &L, Rec &R, Rec &R2, const bool d
 {
     if (ORDERED) {
         L.sp = 0; L.base = 0; L.top = MI_END_LINK;
-#if RT_ROOTDIRECT
         // (single frames: -2.4 % per frame; not in the batch builds: 12 more bytes of scratch per lane there, batches 1 % slower)
         // The step at the virtual record only decides whether the root's box is hit.  Where both children of the root are inner nodes
         // with boxes inside the root's, that step can go: RayIntersectsBox is monotone in the box (every operation of it is), so a ray
@@ -444,7 +434,6 @@ MI_DEV void begin_walk(const DevScene &S, Lane &L, Rec &R, Rec &R2, const bool d
         // would have been a step later.  (A leaf child is different: the reference enters it on the ROOT's verdict.)
         if (direct_ok && S.root_direct) { L.cur = __float_as_uint(S.vroot_b.z); R.a = S.wroot[0]; R.b = S.wroot[1]; R2.a = S.wroot[2]; R2.b = S.wroot[3]; }
         else
-#endif
         { L.cur = MI_VROOT_LINK; R.a = S.vroot_a; R.b = S.vroot_b; R2.a = S.vroot_a; R2.b = S.vroot_b; }
     } else {
         L.cur = S.root_link;
@@ -565,13 +554,6 @@ k_raytrace(const DevScene S, const FrameParams P)
     bool exhausted = false;     // dispenser ran dry (wave-uniform)
     Rec R;                      // record of the node this lane visits next
     Rec R2;                     // ordered walk: second half of a wide record (the right child's box)
-    // Single frames on the three- and four-wave builds: a step at a triangle looks at TWO triangles of the leaf -- a leaf's blocks
-    // lie side by side in list order, so block q + 1 arrives in R2 with block q in R, a 64-byte request like a wide record's --
-    // and plane-tests them before the next record is requested (no copy of the block): 0.89 of the lockstep steps of a frame
-    // (oracle cost model, kind 4).  Measured: a single frame 1-6 % shorter (chessboard 0.608 -> 0.573 ms); batches, which are bound
-    // by instruction issue and not by the length of a tile's chain, 2.5 % SLOWER (38 more vector instructions per such step):
-    // not in the batch builds.
-    constexpr bool PAIR = ORDERED && WAVES >= 3 && !STATS && (!BATCH || RT_PAIRBATCH) && !RT_COUNT;
     R.a = R.b = R2.a = R2.b = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t pool_next = 0, pool_end = 0;   // wave-local pixel pool (wave-uniform): local indices of share pool_share
     uint32_t pool_share = 0;
@@ -1255,7 +1237,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         L.cur = vgive;
                         const float4 *p = S.walk + (size_t)(vgive & MI_INDEX_MASK);
                         R.a = p[0]; R.b = p[1];
-                        if (PAIR || (vgive & MI_LEAF_BIT) == 0) { R2.a = p[2]; R2.b = p[3]; }
+                        if ((vgive & MI_LEAF_BIT) == 0) { R2.a = p[2]; R2.b = p[3]; }
                         n_steal++;
                         took = true;
                         seen = MI_RESULT_NONE;           // (the word read above was the one of the ray this lane walked before)
@@ -1351,34 +1333,9 @@ k_raytrace(const DevScene S, const FrameParams P)
             }
             // 2. triangle blocks: the chain continues while the next link stays inside the leaf
             const uint32_t tcur = L.cur;
-            bool cand2 = false; int j2 = 0; float sp2 = 0.f;     // PAIR: the triangle of this step that goes on to the edge test
-            // (the other builds: what the plane half of this step's triangle test needs of the block -- R is about to be overwritten)
+            // (what the plane half of this step's triangle test needs of the block -- R is about to be overwritten)
             float tk = 0.f, tnum = 0.f;
             unsigned long long mface = 0ull;
-            if constexpr (PAIR) {
-                if (mL) {
-                    const auto chain = [](uint32_t l) { return (l & (MI_LEAF_BIT | MI_FIRST_BIT)) == MI_LEAF_BIT; };
-                    // plane half of the triangle test (Raytracer.cc:245-267) as a straight-line predicate
-                    const auto plane = [&](const float4 a, const float4 b, const uint32_t link, const int j, float &sp) {
-                        const f3 n = mk3(a.x, a.y, a.z);
-                        const f3 fto = sub3(L.o, mk3(b.x, b.y, b.z));
-                        const bool facing = ((link | L.nocull) & MI_TWOSIDED_BIT) != 0u || !(dot3(fto, n) < 0.f);
-                        const float k = dot3(n, L.d);
-                        sp = (b.w - dot3(n, L.o)) / k;
-                        return j != L.avoid && facing && !(k == 0.0f) && !(sp <= 0.0f) && !(sp <= P.nudge);
-                    };
-                    const int j0 = (int)(((tcur & MI_INDEX_MASK) - S.tri_base) >> 1);
-                    const uint32_t nx1 = __float_as_uint(R.a.w), nx2 = __float_as_uint(R2.a.w);
-                    const bool has2 = tri && chain(nx1);         // block q + 1 belongs to this leaf
-                    float s0, s1;
-                    const bool c0 = plane(R.a, R.b, tcur, j0, s0) && tri;
-                    const bool c1 = plane(R2.a, R2.b, nx1, j0 + 1, s1) && has2;
-                    cand2 = c0 || c1; j2 = c0 ? j0 : j0 + 1; sp2 = c0 ? s0 : s1;
-                    // both pass: the first goes to the edge test now, the second comes again as the first of the next pair
-                    if (c0 && c1) next = nx1;
-                    else if (has2 && chain(nx2)) next = nx2;
-                }
-            } else {
             // The dot products of the plane half (Raytracer.cc:245-262) now, from the block where it lies: the block's registers
             // are free for the next record, and k, the numerator of s and the facing verdict are all that stays (a copy of the
             // block cost eight moves in EVERY step).  Same operations on the same values as before, only earlier.
@@ -1393,7 +1350,6 @@ k_raytrace(const DevScene S, const FrameParams P)
                     if ((nx & (MI_LEAF_BIT | MI_FIRST_BIT)) == MI_LEAF_BIT) next = nx;
                 }
             }
-            }
             // 3. nothing to enter: resume at the most recently postponed child (the one below it comes up from
             //    LDS; it is not needed before this lane's next push or pop); then request the next record
             if (walking && next == MI_END_LINK && L.sp > sbase) {
@@ -1406,9 +1362,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                 if (next != MI_END_LINK) {
                     const float4 *p = S.walk + (size_t)(next & MI_INDEX_MASK);
                     R.a = p[0]; R.b = p[1];
-                    if (PAIR || (next & MI_LEAF_BIT) == 0) {
-                        R2.a = p[2]; R2.b = p[3];
-                    }
+                    if ((next & MI_LEAF_BIT) == 0) { R2.a = p[2]; R2.b = p[3]; }
                 }
             }
             if constexpr (WAVES >= 3) {
@@ -1418,27 +1372,18 @@ k_raytrace(const DevScene S, const FrameParams P)
             //    record is covered by the other waves, and without a deferred candidate the lane state fits 168 registers.
             if (mL) {
                 if (STATS) { it_b++; ln_b += __popcll(mL); }
-                int j; float sp; bool cand;
-                if constexpr (PAIR) { j = j2; sp = sp2; cand = cand2; }
-                else {
-                    j = (int)(((tcur & MI_INDEX_MASK) - S.tri_base) >> 1);
-                    sp = tnum / tk;
-                    cand = tri && j != L.avoid && __builtin_amdgcn_inverse_ballot_w64(mface) && !(tk == 0.0f) && !(sp <= 0.0f) && !(sp <= P.nudge);
-                }
+                const int j = (int)(((tcur & MI_INDEX_MASK) - S.tri_base) >> 1);
+                const float sp = tnum / tk;
+                const bool cand = tri && j != L.avoid && __builtin_amdgcn_inverse_ballot_w64(mface) && !(tk == 0.0f) && !(sp <= 0.0f) && !(sp <= P.nudge);
                 if (STATS && tri) { n_tris++; if (cand) n_plane++; }
                 if (RT_COUNT) { const unsigned long long mc = __ballot(cand); cq[5] += mc ? 1 : 0; cq[6] += __popcll(mc); }
                 if (__ballot(cand)) {
                     // (only the candidates load: the load path's data return is as busy as the vector ALUs -- TD_BUSY 0.87 --, and a record
                     //  for each of 64 lanes where a dozen need one was a quarter of its bytes; the other lanes' registers keep whatever
                     //  they held -- `inside` below starts with `cand` --, declared without an instruction)
-#if RT_EDGEMASK
                     float4 e1, q, r;
                     asm volatile("" : "=v"(e1.x), "=v"(e1.y), "=v"(e1.z), "=v"(e1.w), "=v"(q.x), "=v"(q.y), "=v"(q.z), "=v"(q.w), "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w));
                     if (cand) { const float4 *e = S.tri_edge + (size_t)j * 3; e1 = e[0]; q = e[1]; r = e[2]; }
-#else
-                    const float4 *e = S.tri_edge + (size_t)(cand ? j : 0) * 3;
-                    const float4 e1 = e[0], q = e[1], r = e[2];
-#endif
                     const f3 hit = add3(mul3(L.d, sp), L.o);
                     const float kt1 = dot3(mk3(e1.x, e1.y, e1.z), hit) - e1.w;
                     // e2 and e3 together (each half is dot3(e_i, hit) - d_i, operation for operation)
@@ -1860,7 +1805,7 @@ extern "C" hipError_t mi355i_launch_cull_probe(const float *rays6, const uint32_
 // ---- launch helper (called from capi.hip) ------------------------------------------------
 namespace {
 typedef void (*rt_kernel)(const DevScene, const FrameParams);
-// The builds that exist (16).  Production = the ordered walk with the filtered box test: three register builds (waves = wavefronts
+// The builds that exist (15).  Production = the ordered walk with the filtered box test: three register builds (waves = wavefronts
 // per SIMD: 2, 3 or 4) x single frame / batch.  Everything else is a fallback or a measuring tool and comes in ONE register build
 // (two waves per SIMD): the exact-only box test (scenes whose box coordinates are outside the filtered test's range, tune flag 1),
 // the walk in the reference's order (unchecked trees, tune flag 4; its counting builds reproduce the reference's counters), the
@@ -1875,8 +1820,8 @@ rt_kernel pick_kernel(int stats, int exact, int ordered, int waves, int batch, i
     if (ordered && stats) return k_raytrace<true, false, true, 2, false>;
     if (ordered && exact) return batch ? k_raytrace<false, true, true, 2, true> : k_raytrace<false, true, true, 2, false>;
     if (ordered) {
-        if (waves >= 4) return batch ? k_raytrace<false, false, true, 4, true> : k_raytrace<false, false, true, 4, false>;
-        if (waves == 3) return batch ? k_raytrace<false, false, true, 3, true> : k_raytrace<false, false, true, 3, false>;
+        if (waves >= 4 && batch) return k_raytrace<false, false, true, 4, true>;
+        if (waves >= 3) return batch ? k_raytrace<false, false, true, 3, true> : k_raytrace<false, false, true, 3, false>;
         return batch ? k_raytrace<false, false, true, 2, true> : k_raytrace<false, false, true, 2, false>;
     }
     if (stats) return exact ? k_raytrace<true, true, false, 2, false> : k_raytrace<true, false, false, 2, false>;
@@ -1898,12 +1843,13 @@ extern "C" int mi355i_raytrace_can_batch(int stats, int ordered) { return ordere
 // What a request is served by: *exact / *ordered / *waves are adjusted to a build that exists (see pick_kernel).  A counting frame
 // of the ordered walk on a scene that needs the exact box test is counted in the reference's order instead; EXT in the reference's
 // order always uses the exact test.
-extern "C" void mi355i_raytrace_variant(int stats, int *exact, int *ordered, int *waves, int ext)
+extern "C" void mi355i_raytrace_variant(int stats, int *exact, int *ordered, int *waves, int ext, int batch_)
 {
     if (*ordered && stats && *exact && !ext) *ordered = 0;
     if (ext && !*ordered) *exact = 1;
     if (ext || stats || !*ordered || *exact) *waves = 2;
     if (*waves > 4) *waves = 4;
+    if (*waves == 4 && !batch_) *waves = 3;      // (single frames queue their leaves: never faster on the four-wave build)
     if (*waves < 2) *waves = 2;
 }
 
