@@ -61,7 +61,7 @@ def main():
             "raster_kernels": old.get("raster_kernels"), "raster_kernels_round": old.get("round") if old.get("raster_kernels") else None,
         }, open(tf, "w"), indent=1)
     for src, dst in (("gpurun_out/bench_full.log", "%s_bench_n1.jsonl" % TAG), ("gpurun_out/pytest_full.log", "%s_pytest_gpu.log" % TAG),
-                     ("gpurun_out/misc_full.log", "%s_side_measurements.log" % TAG)):
+                     ("gpurun_out/misc_full.log", "%s_side_measurements.log" % TAG), ("gpurun_out/rt_pmc.json", "%s_pmc_bench_kernel.json" % TAG)):
         p = os.path.join(ROOT, src)
         if os.path.exists(p):
             lines = [l for l in open(p).read().splitlines() if l.strip()]
