@@ -3,7 +3,8 @@
 code run here.  (tests/golden/reference_pins.json holds frame f0 of every BASELINE configuration, recorded by the survey from a
 whole build of the program; nobody can regenerate those in this image.)
 
-For BASELINE configs[2] (statue.ply, max depth 1) and configs[3] (dragon_vis.ply, depth 3) at 1920x1080, orbit frames f37, f100, f150:
+For BASELINE configs[2] (statue.ply, max depth 1) and configs[3] (dragon_vis.ply, depth 3) at 1920x1080, orbit frames f37, f100, f150,
+configs[4]'s 3840x2160 at f37 and f100, the 4 spp mode (10) and frames with the second light:
 every pixel's colour is Raytrace<true>() of /root/reference/src/Raytracer.cc, compiled from where it lies with the pinned strict flags
 (oracle/refcore/Makefile -> oracle/_ref/refcore, command `raytrace`), on the frame's camera rays; the packed pixel is that colour
 clamped at 255 and truncated as Raytracer.cc:600-604 does.  Frame f0 made the same way must reproduce the survey's pin -- the check
@@ -16,9 +17,15 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from oracle import oracle_ctypes as O, refcore as RC
 
-def frame(osc, k, w, h, depth):
-    cam, lights, n = O.benchmark_frame(k)
-    f = RC.raytrace(osc, cam, lights, n, RC.primary_rays(cam, w, h, 2 * h), depth).reshape(h, w, 3)
+def frame(osc, k, w, h, depth, mode=9, two=False):
+    cam, lights, n = O.benchmark_frame(k, two)
+    if mode == 9:
+        f = RC.raytrace(osc, cam, lights, n, RC.primary_rays(cam, w, h, 2 * h), depth).reshape(h, w, 3)
+    else:                                                           # mode 10: while(pixelsTraced--), Raytracer.cc:570-597, then / 4
+        f = np.zeros((h, w, 3), np.float32)
+        for sub in (3, 2, 1, 0):
+            f = f + RC.raytrace(osc, cam, lights, n, RC.primary_rays(cam, w, h, 2 * h, sub=sub), depth).reshape(h, w, 3)
+        f = f / np.float32(4.0)
     c = np.minimum(f, np.float32(255.0)).astype(np.uint32)          # Raytracer.cc:600-603, then (Uint8) truncation
     rgb = np.stack([c[..., 0], c[..., 1], c[..., 2]], axis=-1).astype(np.uint8)
     return f, rgb
@@ -27,15 +34,24 @@ def main():
     assert RC.build(), "oracle/_ref/refcore could not be built (is /root/reference present?)"
     survey = {p["id"]: p for p in json.load(open(os.path.join(ROOT, "tests", "golden", "reference_pins.json")))["frames"]}
     out = []
+    import renderer_amd.assets as A
+    scenes = {}
+    def scene(mesh):
+        if mesh not in scenes:
+            scenes[mesh] = O.Scene(A.mesh_path(mesh)); scenes[mesh].bvh_build()
+        return scenes[mesh]
     for cid, mesh, depth in (("cfg3", "statue.ply", 1), ("cfg4", "dragon_vis.ply", 3)):
-        import renderer_amd.assets as A
-        osc = O.Scene(A.mesh_path(mesh)); osc.bvh_build()
-        w, h = 1920, 1080
-        _, rgb0 = frame(osc, 0, w, h, depth)
+        _, rgb0 = frame(scene(mesh), 0, 1920, 1080, depth)
         assert hashlib.sha256(rgb0.tobytes()).hexdigest() == survey[cid]["sha256"], "%s: frame f0 made this way is not the survey's frame" % cid
-        for k in (37, 100, 150):
-            f, rgb = frame(osc, k, w, h, depth)
-            out.append({"id": "%s_f%d" % (cid, k), "mesh": mesh, "mode": 9, "w": w, "h": h, "depth": depth, "frame": k,
+    # (id, mesh, mode, w, h, depth, frames, second light): the two raytrace configurations along the orbit; config 5's size; the 4 spp
+    # mode; two lights
+    for cid, mesh, mode, w, h, depth, frames, two in (
+            ("cfg3", "statue.ply", 9, 1920, 1080, 1, (37, 100, 150), False), ("cfg4", "dragon_vis.ply", 9, 1920, 1080, 3, (37, 100, 150), False),
+            ("cfg5", "dragon_vis.ply", 9, 3840, 2160, 3, (37, 100), False), ("cfg4_aa", "dragon_vis.ply", 10, 1920, 1080, 3, (37,), False),
+            ("cfg3_aa_2lights", "statue.ply", 10, 1920, 1080, 1, (100,), True), ("cfg4_2lights", "dragon_vis.ply", 9, 1920, 1080, 3, (150,), True)):
+        for k in frames:
+            f, rgb = frame(scene(mesh), k, w, h, depth, mode, two)
+            out.append({"id": "%s_f%d" % (cid, k), "mesh": mesh, "mode": mode, "w": w, "h": h, "depth": depth, "frame": k, "second_light": two,
                         "nonblack": int((rgb.astype(np.uint32).sum(-1) != 0).sum()), "sha256": hashlib.sha256(rgb.tobytes()).hexdigest(),
                         "sha256_f32": hashlib.sha256(np.minimum(f, np.float32(255.0)).astype(np.float32).tobytes()).hexdigest()})
             print(out[-1], flush=True)

@@ -135,25 +135,27 @@ def test_reference_frame_hashes(gpu_scene, pin):
 
 @pytest.mark.parametrize("pin", ORBIT_PINS["frames"], ids=[p["id"] for p in ORBIT_PINS["frames"]])
 def test_reference_orbit_frame_hashes(gpu_scene, pin):
-    """The raytrace configurations at full size further along the orbit (frames f37, f100, f150): the production kernel's packed frame
-    AND its float buffer hash to what the reference's own Raytrace<true> gives for those cameras -- no oracle in the loop --, alone,
-    as one of a batch, and from the walk in the reference's order."""
+    """The raytrace configurations at full size further along the orbit (frames f37, f100, f150), config 5's 3840x2160, the 4 spp mode
+    and frames with two lights: the production kernel's packed frame AND its float buffer hash to what the reference's own
+    Raytrace<true> gives for those cameras -- no oracle in the loop --, alone, as one of a batch, and from the walk in the reference's
+    order."""
     hs = gpu_scene(pin["mesh"], True)
-    cam, lights, n = R.benchmark_frame(pin["frame"])
+    mode, two = pin["mode"], pin.get("second_light", False)
+    cam, lights, n = R.benchmark_frame(pin["frame"], two)
     o = R.default_opts(pin["w"], pin["h"], max_ray_depth=pin["depth"])
-    img, imgf, _ = hs.render(9, cam, lights, n, o, want_f32=True)
+    img, imgf, _ = hs.render(mode, cam, lights, n, o, want_f32=True)
     assert int((img != 0).sum()) == pin["nonblack"]
     assert hashlib.sha256(R.rgb_bytes(img)).hexdigest() == pin["sha256"]
     assert hashlib.sha256(np.ascontiguousarray(imgf, dtype=np.float32).tobytes()).hexdigest() == pin["sha256_f32"]
-    img2, _, _ = hs.render(9, cam, lights, n, R.default_opts(pin["w"], pin["h"], max_ray_depth=pin["depth"], tune=R.tune(reforder=1)))
+    img2, _, _ = hs.render(mode, cam, lights, n, R.default_opts(pin["w"], pin["h"], max_ray_depth=pin["depth"], tune=R.tune(reforder=1)))
     assert hashlib.sha256(R.rgb_bytes(img2)).hexdigest() == pin["sha256"]
     # the same camera as frame 3 of a batch of 8 (the launch the bench line times)
     import torch
     dev = torch.device("cuda", 0)
     frames = [(pin["frame"] - 3 + j) % 200 for j in range(8)]
-    cs = [R.benchmark_frame(f) for f in frames]
+    cs = [R.benchmark_frame(f, two) for f in frames]
     outs = [torch.zeros((pin["h"], pin["w"]), dtype=torch.int32, device=dev) for _ in range(8)]
-    hs.render_batch_device(9, [c[0] for c in cs], [c[1] for c in cs], n, o, [t.data_ptr() for t in outs], pin["w"] * 4, None, torch.cuda.current_stream(dev).cuda_stream)
+    hs.render_batch_device(mode, [c[0] for c in cs], [c[1] for c in cs], n, o, [t.data_ptr() for t in outs], pin["w"] * 4, None, torch.cuda.current_stream(dev).cuda_stream)
     torch.cuda.synchronize(dev)
     got = outs[3].cpu().numpy().view(np.uint32)
     assert hashlib.sha256(R.rgb_bytes(got)).hexdigest() == pin["sha256"]

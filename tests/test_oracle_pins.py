@@ -24,11 +24,12 @@ ORBIT_PINS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "r
 
 @pytest.mark.parametrize("pin", ORBIT_PINS["frames"], ids=[p["id"] for p in ORBIT_PINS["frames"]])
 def test_oracle_reproduces_the_orbit_frame_pins(oracle, oracle_scene, pin):
-    """Full-size frames f37 / f100 / f150 of the two raytrace configurations, hashed from the reference's own Raytracer.cc in the build
-    container (scripts/make_refcore_frame_pins.py): the oracle's frame and float buffer must hash to the same."""
+    """Full-size frames f37 / f100 / f150 of the two raytrace configurations, config 5's 3840x2160, the 4 spp mode and frames with two
+    lights, hashed from the reference's own Raytracer.cc in the build container (scripts/make_refcore_frame_pins.py): the oracle's frame
+    and float buffer must hash to the same."""
     s = oracle_scene(pin["mesh"], bvh=True)
-    cam, lights, n = oracle.benchmark_frame(pin["frame"])
-    img, imgf, _ = s.render(9, cam, lights, n, oracle.default_opts(pin["w"], pin["h"], max_ray_depth=pin["depth"], threads=os.cpu_count() or 1), want_f32=True)
+    cam, lights, n = oracle.benchmark_frame(pin["frame"], pin.get("second_light", False))
+    img, imgf, _ = s.render(pin["mode"], cam, lights, n, oracle.default_opts(pin["w"], pin["h"], max_ray_depth=pin["depth"], threads=os.cpu_count() or 1), want_f32=True)
     rgb = np.stack([(img >> 16) & 255, (img >> 8) & 255, img & 255], axis=-1).astype(np.uint8)
     assert hashlib.sha256(rgb.tobytes()).hexdigest() == pin["sha256"]
     assert hashlib.sha256(np.ascontiguousarray(imgf, dtype=np.float32).tobytes()).hexdigest() == pin["sha256_f32"]
