@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from oracle import oracle_ctypes as O, refcore as RC
+import renderer_amd.assets as A
 
 def frame(osc, k, w, h, depth, mode=9, two=False):
     cam, lights, n = O.benchmark_frame(k, two)
@@ -30,11 +31,19 @@ def frame(osc, k, w, h, depth, mode=9, two=False):
     rgb = np.stack([c[..., 0], c[..., 1], c[..., 2]], axis=-1).astype(np.uint8)
     return f, rgb
 
+def winners_hash(tri, passes, fat):
+    bits = np.ascontiguousarray(fat, np.float32).view(np.uint32).copy()
+    bits[np.isnan(fat)] = 0x7fc00000
+    bits[tri < 0] = 0
+    h = hashlib.sha256()
+    for x in (np.ascontiguousarray(tri, np.int32), np.ascontiguousarray(passes, np.int32), bits):
+        h.update(x.tobytes())
+    return h.hexdigest()
+
 def main():
     assert RC.build(), "oracle/_ref/refcore could not be built (is /root/reference present?)"
     survey = {p["id"]: p for p in json.load(open(os.path.join(ROOT, "tests", "golden", "reference_pins.json")))["frames"]}
     out = []
-    import renderer_amd.assets as A
     scenes = {}
     def scene(mesh):
         if mesh not in scenes:
@@ -55,11 +64,27 @@ def main():
                         "nonblack": int((rgb.astype(np.uint32).sum(-1) != 0).sum()), "sha256": hashlib.sha256(rgb.tobytes()).hexdigest(),
                         "sha256_f32": hashlib.sha256(np.minimum(f, np.float32(255.0)).astype(np.float32).tobytes()).hexdigest()})
             print(out[-1], flush=True)
+    # the rasterizer (BASELINE configs[1]: chessboard.tri, mode 6) along the orbit: what the reference's own DrawTriangles / Filler<> /
+    # ScanConverter / RasterizeTriangle hand its plotter (oracle/_ref/refraster, at the reference's compile-time 800 x 600)
+    rout = []
+    if RC.raster_available():
+        osc = O.Scene(A.mesh_path("chessboard.tri"))
+        for k in (0, 37, 100, 150):
+            cam, lights, n = O.benchmark_frame(k)
+            W, H, mv, tri, passes, fat = RC.raster_winners(osc, 6, list(cam.eye), [0.0, 0.0, 0.0], [list(lights[0].pos)])
+            assert np.array_equal(mv.view(np.uint32), np.array(list(cam.mv), np.float32).view(np.uint32)), "frame %d: not the orbit's camera" % k
+            rout.append({"id": "cfg2_f%d" % k, "mesh": "chessboard.tri", "mode": 6, "w": W, "h": H, "frame": k, "covered": int((tri >= 0).sum()),
+                         "overdrawn": int((passes > 1).sum()), "sha256_winners": winners_hash(tri, passes, fat)})
+            print(rout[-1], flush=True)
     doc = {"_comment": "Full-size orbit frames beyond f0 from the reference's own Raytracer.cc compiled here (scripts/make_refcore_frame_pins.py: "
                        "oracle/_ref/refcore `raytrace`, strict flags, camera rays of benchmark frame k; f0 made the same way reproduces the survey's "
                        "pins of tests/golden/reference_pins.json).  sha256 over raw R,G,B bytes, row-major, top row first; sha256_f32 over the r,g,b "
                        "float32 values clamped at 255 (what mi355_render hands out as out_rgb_f32).",
-           "frames": out}
+           "frames": out,
+           "_comment_raster": "oracle/_ref/refraster (the reference's Rasterizers.cc with recording plotters, 800 x 600 = its compile-time size) on "
+                              "orbit cameras: sha256 over the winning triangle per pixel (int32, -1 = none), the Z-pass count per pixel (int32) and, for "
+                              "covered pixels, the bits of the eight floats of the fat point the plotter received (NaN -> 0x7fc00000).",
+           "raster_winners": rout}
     json.dump(doc, open(os.path.join(ROOT, "tests", "golden", "refcore_frame_pins.json"), "w"), indent=1)
 
 if __name__ == "__main__":

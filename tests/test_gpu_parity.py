@@ -161,6 +161,31 @@ def test_reference_orbit_frame_hashes(gpu_scene, pin):
     assert hashlib.sha256(R.rgb_bytes(got)).hexdigest() == pin["sha256"]
 
 
+def winners_hash(tri, passes, fat):
+    """scripts/make_refcore_frame_pins.py: winners_hash"""
+    bits = np.ascontiguousarray(fat, np.float32).view(np.uint32).copy()
+    bits[np.isnan(fat)] = 0x7fc00000
+    bits[tri < 0] = 0
+    h = hashlib.sha256()
+    for x in (np.ascontiguousarray(tri, np.int32), np.ascontiguousarray(passes, np.int32), bits):
+        h.update(x.tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("pin", ORBIT_PINS["raster_winners"], ids=[p["id"] for p in ORBIT_PINS["raster_winners"]])
+def test_raster_frames_on_the_pinned_winner_maps(oracle, oracle_scene, gpu_scene, pin):
+    """The rasterizer along the orbit at the reference's compile-time 800 x 600: the oracle's winner maps are the ones the reference's
+    own Rasterizers.cc produced in the build container (hash pin), and the HIP frame is the frame the oracle plots from them."""
+    osc, hs = oracle_scene(pin["mesh"]), gpu_scene(pin["mesh"])
+    ocam, olights, on = oracle.benchmark_frame(pin["frame"])
+    oimg, tri, passes, fat = oracle.raster_winners(osc, pin["mode"], ocam, olights, on, oracle.default_opts(pin["w"], pin["h"]))
+    assert winners_hash(tri, passes, fat) == pin["sha256_winners"]
+    cam, lights, n = R.benchmark_frame(pin["frame"])
+    img, _, _ = hs.render(pin["mode"], cam, lights, n, R.default_opts(pin["w"], pin["h"]))
+    assert np.array_equal(img, oimg)
+    assert int((img != 0).sum()) >= pin["covered"] * 9 // 10        # (a lit picture: nearly every covered pixel has a colour)
+
+
 @pytest.mark.parametrize("cfg", [
     ("cfg5", "dragon_vis.ply", 9, 3840, 2160, 3), ("statue_depth3_1080p", "statue.ply", 9, 1920, 1080, 3),
     ("chessboard_depth3_1080p", "chessboard.tri", 9, 1920, 1080, 3), ("dragon_aa_1080p", "dragon_vis.ply", 10, 1920, 1080, 3)],

@@ -35,6 +35,29 @@ def test_oracle_reproduces_the_orbit_frame_pins(oracle, oracle_scene, pin):
     assert hashlib.sha256(np.ascontiguousarray(imgf, dtype=np.float32).tobytes()).hexdigest() == pin["sha256_f32"]
 
 
+def winners_hash(tri, passes, fat):
+    """scripts/make_refcore_frame_pins.py: winners_hash"""
+    bits = np.ascontiguousarray(fat, np.float32).view(np.uint32).copy()
+    bits[np.isnan(fat)] = 0x7fc00000
+    bits[tri < 0] = 0
+    h = hashlib.sha256()
+    for x in (np.ascontiguousarray(tri, np.int32), np.ascontiguousarray(passes, np.int32), bits):
+        h.update(x.tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("pin", ORBIT_PINS["raster_winners"], ids=[p["id"] for p in ORBIT_PINS["raster_winners"]])
+def test_oracle_reproduces_the_rasterizer_winner_pins(oracle, oracle_scene, pin):
+    """BASELINE configs[1] (chessboard.tri, per-pixel Phong) along the orbit at the reference's own compile-time frame size: the winning
+    triangle, the Z-pass count and the fat point of every pixel as the reference's Rasterizers.cc hands them to its plotter
+    (oracle/_ref/refraster in the build container) -- hashed there, reproduced here by the oracle."""
+    s = oracle_scene(pin["mesh"])
+    cam, lights, n = oracle.benchmark_frame(pin["frame"])
+    _, tri, passes, fat = oracle.raster_winners(s, pin["mode"], cam, lights, n, oracle.default_opts(pin["w"], pin["h"]))
+    assert int((tri >= 0).sum()) == pin["covered"] and int((passes > 1).sum()) == pin["overdrawn"]
+    assert winners_hash(tri, passes, fat) == pin["sha256_winners"]
+
+
 def test_benchmark_cameras(oracle):
     c0, lights, n = oracle.benchmark_frame(0)
     assert n == 1
