@@ -7,7 +7,7 @@ import renderer_amd as R
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-W, H = 1920, 1080
+W, H = (int(os.environ.get("RL_W", "1920")), int(os.environ.get("RL_H", "1080")))
 dev = torch.device("cuda", 0); stream = torch.cuda.current_stream(dev)
 s = R.Scene(R.assets.mesh_path("chessboard.tri"))
 cams = [R.benchmark_frame(k) for k in range(200)]
