@@ -491,12 +491,6 @@ struct RtCtx {
     int nLights;
     orc_stats st;
     int px, py, sample;   /* ray-cast ambient occlusion, generator 2: the pixel sample being traced */
-    /* orc_chain_profile: per ray of the pixel, in the order the rays are cast, what a NEAR-FIRST walk of the tree with
-     * distance culling (the device's ordered walk, modelled) would cost: inner records visited | triangles tested << 16 */
-    uint32_t *chain = nullptr;
-    int chain_n = 0;
-    int chain_quad = 0;        /* price the four-wide walk instead */
-    uint32_t chain_max_sp = 0;
 };
 
 /* lowbias32-style integer mixer; the device path (k_raytrace.hip) draws the same numbers */
@@ -533,107 +527,6 @@ static inline bool ray_box(const V3 &o, const V3 &d, const Node32 &box)
     return true;
 }
 
-/* A model of the device's ordered walk (k_raytrace.hip), for orc_chain_profile only -- it does not decide any pixel: visit the
- * nearer child first, postpone the other, skip children whose box the ray enters beyond the best hit so far (a shadow ray:
- * beyond the light); a postponed child is entered when it comes up, whatever has been found meanwhile (its children are
- * culled then).  Cost: one step per inner record visited, one per triangle of a leaf entered.  A shadow ray stops at its
- * first blocker.  Double-precision slabs: a cost model, not a parity path. */
-/* quad: a step looks at the node's grandchildren (a leaf child takes a slot of its own), nearest first, the others postponed:
- * the four-wide tree of profiles/history.md 4.1, priced.  *max_sp: the deepest the stack of postponed slots got. */
-template <bool shadow>
-static uint32_t ordered_walk_cost(const orc_scene &s, float nudge, const V3 &origin, const V3 &ray, int avoidSelf, const V3 &lightPos, bool doCulling,
-                                  int quad_kind = 0, uint32_t *max_sp = nullptr)
-{
-    /* kinds 4 / 5 (two-wide walk): a step tests two triangles of a leaf / the whole leaf (what a leaf-contiguous layout would cost) */
-    const bool quad = quad_kind != 0 && quad_kind < 4;
-    uint32_t inner = 0, tris = 0;
-    const double o[3] = {origin.x, origin.y, origin.z}, d[3] = {ray.x, ray.y, ray.z};
-    double best = shadow ? sqrt((double)distancesq(origin, lightPos)) : 1e300;
-    const float lightDistSq = shadow ? distancesq(origin, lightPos) : 0.f;
-    auto enter = [&](const Node32 &n, double &tn) -> bool {
-        double t0 = -1e300, t1 = 1e300;
-        for (int a = 0; a < 3; a++) {
-            if (d[a] == 0.0) { if (o[a] < n.bottom[a] || o[a] > n.top[a]) return false; continue; }
-            double ta = (n.bottom[a] - o[a]) / d[a], tb = (n.top[a] - o[a]) / d[a];
-            if (ta > tb) { const double t = ta; ta = tb; tb = t; }
-            if (ta > t0) t0 = ta;
-            if (tb < t1) t1 = tb;
-        }
-        if (t0 > t1 || t1 < 0.0) return false;
-        tn = t0;
-        return true;
-    };
-    unsigned stack[128];
-    int sp = 0;
-    double tn;
-    if (!enter(s.nodes[0], tn)) return 1u;
-    unsigned cur = 0;
-    for (;;) {
-        const Node32 &n = s.nodes[cur];
-        bool have_next = false;
-        if (!(n.a & 0x80000000u) && quad) {
-            inner++;
-            unsigned slot[4]; double key[4]; int ns = 0;
-            for (unsigned child : {n.a, n.b}) {
-                const Node32 &cn = s.nodes[child];
-                if (cn.a & 0x80000000u) { double t; if (enter(cn, t) && !(t > best)) { slot[ns] = child; key[ns++] = t; } }
-                else if (quad_kind == 2 && ((s.nodes[cn.a].a | s.nodes[cn.b].a) & 0x80000000u)) {
-                    /* variant 2: a child with a leaf below it is a slot by itself (every rule stays local to a slot) */
-                    double t; if (enter(cn, t) && !(t > best)) { slot[ns] = child; key[ns++] = t; }
-                } else for (unsigned g : {cn.a, cn.b}) {
-                    double t;
-                    /* variant 3: a leaf grandchild is entered iff its PARENT's box is (the reference's rule, kept local by storing that box) */
-                    const Node32 &gb = (quad_kind == 3 && (s.nodes[g].a & 0x80000000u)) ? cn : s.nodes[g];
-                    if (enter(gb, t) && !(t > best)) { slot[ns] = g; key[ns++] = t; }
-                }
-            }
-            for (int i = 1; i < ns; i++)                        /* nearest first */
-                for (int j = i; j > 0 && key[j] < key[j - 1]; j--) { const double t = key[j]; key[j] = key[j - 1]; key[j - 1] = t; const unsigned u = slot[j]; slot[j] = slot[j - 1]; slot[j - 1] = u; }
-            if (ns) {
-                cur = slot[0]; have_next = true;
-                for (int i = ns - 1; i >= 1; i--) if (sp < 128) stack[sp++] = slot[i];
-                if (max_sp && (uint32_t)sp > *max_sp) *max_sp = (uint32_t)sp;
-            }
-        } else if (!(n.a & 0x80000000u)) {
-            inner++;
-            double ta = 0, tb = 0;
-            bool ha = enter(s.nodes[n.a], ta) && !(ta > best), hb = enter(s.nodes[n.b], tb) && !(tb > best);
-            if (ha && hb) {
-                const bool a_first = ta <= tb;
-                cur = a_first ? n.a : n.b;
-                if (sp < 128) stack[sp++] = a_first ? n.b : n.a;
-                if (max_sp && (uint32_t)sp > *max_sp) *max_sp = (uint32_t)sp;
-                have_next = true;
-            } else if (ha) { cur = n.a; have_next = true; }
-            else if (hb) { cur = n.b; have_next = true; }
-        } else {
-            const unsigned start = n.b, cnt = n.a & 0x7fffffffu;
-            for (unsigned i = start; i < start + cnt; i++) {
-                if (quad_kind == 4) tris += ((i - start) & 1u) ? 0u : 1u;
-                else if (quad_kind == 5) tris += i == start ? 1u : 0u;
-                else tris++;
-                const int ti = s.triIdx[i];
-                const Tri &t = s.tris[ti];
-                if (avoidSelf == ti) continue;
-                if (doCulling && !t.twoSided && dot(sub(origin, t.center), t.normal) < 0) continue;
-                const float k = dot(t.normal, ray);
-                if (k == 0.0) continue;
-                const float sdist = (t.d - dot(t.normal, origin)) / k;
-                if (sdist <= 0.0 || sdist <= nudge) continue;
-                const V3 hit = add(mul(ray, sdist), origin);
-                if (dot(t.e1, hit) - t.d1 < 0.0 || dot(t.e2, hit) - t.d2 < 0.0 || dot(t.e3, hit) - t.d3 < 0.0) continue;
-                if (shadow) { if (distancesq(lightPos, hit) < lightDistSq) return inner | (tris << 16); }
-                else if ((double)sdist < best) best = sdist;
-            }
-        }
-        if (!have_next) {
-            if (!sp) break;
-            cur = stack[--sp];
-        }
-    }
-    return inner | (tris << 16);
-}
-
 /* Raytracer.cc:183-308.  shadow: pointHit holds the light position on entry. */
 template <bool shadow>
 static bool bvh_intersect(RtCtx &c, const V3 &origin, const V3 &ray, int avoidSelf, int &bestTri,
@@ -646,7 +539,6 @@ static bool bvh_intersect(RtCtx &c, const V3 &origin, const V3 &ray, int avoidSe
     const V3 lightPos = pointHit;
     if (shadow) { bestTriDist = distancesq(origin, lightPos); c.st.shadow_rays++; }
     else { bestTriDist = FLT_MAX; c.st.normal_rays++; }
-    if (c.chain && c.chain_n < 8) c.chain[c.chain_n++] = ordered_walk_cost<shadow>(s, nudge, origin, ray, avoidSelf, lightPos, doCulling, c.chain_quad, &c.chain_max_sp);
     unsigned stack[64];
     int sp = 0;
     stack[sp++] = 0;
@@ -1454,109 +1346,12 @@ void orc_trace_hits(const orc_scene *s, int n, const float *rays6, int32_t *tri,
     }
 }
 
-/* The reachability rule a four-wide record would use (profiles/history.md 4.1), as a checker of the rule only: at a node the reference has
- * entered, a LEAF child is entered; an inner child's INNER children are entered iff their OWN box passes RayIntersectsBox (which
- * implies the child's passes: the predicate is monotone in the box and a node's box is the union of its children's); an inner
- * child's LEAF children are entered iff the child's box passes.  Candidates in any order: the nearest wins, the lowest position
- * in the triangle list among equal distances (the reference's left-first order finds that one first).  Must name the triangle
- * BVH_IntersectTriangles<false> names, for every ray. */
-void orc_trace_hits_fourwide(const orc_scene *sc, int n, const float *rays6, int32_t *tri, float *hit3)
-{
-    const orc_scene &s = *sc;
-    orc_opts o;
-    orc_default_opts(&o, 16, 16);
-    const float nudge = o.nudge;
-    for (int r = 0; r < n; r++) {
-        const float *q = rays6 + 6 * (size_t)r;
-        const V3 origin(q[0], q[1], q[2]), ray(q[3], q[4], q[5]);
-        int best = -1; unsigned bestPos = 0; float bestDist = FLT_MAX; V3 bestHit(0.f, 0.f, 0.f);
-        auto leaf = [&](const Node32 &n) {
-            const unsigned start = n.b, cnt = n.a & 0x7fffffffu;
-            for (unsigned i = start; i < start + cnt; i++) {
-                const int ti = s.triIdx[i];
-                const Tri &t = s.tris[ti];
-                if (!t.twoSided && dot(sub(origin, t.center), t.normal) < 0) continue;
-                const float k = dot(t.normal, ray);
-                if (k == 0.0) continue;
-                const float sdist = (t.d - dot(t.normal, origin)) / k;
-                if (sdist <= 0.0 || sdist <= nudge) continue;
-                const V3 hit = add(mul(ray, sdist), origin);
-                if (dot(t.e1, hit) - t.d1 < 0.0 || dot(t.e2, hit) - t.d2 < 0.0 || dot(t.e3, hit) - t.d3 < 0.0) continue;
-                const float hitZ = distancesq(origin, hit);
-                if (hitZ < bestDist || (hitZ == bestDist && best >= 0 && i < bestPos)) { bestDist = hitZ; best = ti; bestPos = i; bestHit = hit; }
-            }
-        };
-        std::vector<unsigned> stack;
-        const Node32 &root = s.nodes[0];
-        if (root.a & 0x80000000u) leaf(root);
-        else if (ray_box(origin, ray, root)) stack.push_back(0u);
-        while (!stack.empty()) {
-            const Node32 &n = s.nodes[stack.back()];             /* an inner node the reference has entered */
-            stack.pop_back();
-            for (unsigned child : {n.b, n.a}) {                  /* (any order) */
-                const Node32 &c = s.nodes[child];
-                if (c.a & 0x80000000u) { leaf(c); continue; }
-                bool child_passes = false, asked = false;
-                for (unsigned g : {c.a, c.b}) {
-                    const Node32 &gn = s.nodes[g];
-                    if (gn.a & 0x80000000u) {
-                        if (!asked) { child_passes = ray_box(origin, ray, c); asked = true; }
-                        if (child_passes) leaf(gn);
-                    } else if (ray_box(origin, ray, gn)) stack.push_back(g);
-                }
-            }
-        }
-        tri[r] = best;
-        hit3[3 * (size_t)r] = bestHit.x; hit3[3 * (size_t)r + 1] = bestHit.y; hit3[3 * (size_t)r + 2] = bestHit.z;
-    }
-}
-
 int orc_ray_box(const float *origin3, const float *ray3, const float *bottom3, const float *top3)
 {
     Node32 n;
     for (int i = 0; i < 3; i++) { n.bottom[i] = bottom3[i]; n.top[i] = top3[i]; }
     n.a = n.b = 0;
     return ray_box(V3(origin3[0], origin3[1], origin3[2]), V3(ray3[0], ray3[1], ray3[2]), n) ? 1 : 0;
-}
-
-uint32_t orc_chain_profile(const orc_scene *s, const orc_camera *cam, const orc_light *lights, int n_lights, const orc_opts *oo, uint32_t *out8, int quad)
-{
-    uint32_t max_sp = 0;
-    const orc_opts &o = *oo;
-    const int W = o.width, H = o.height, SD = o.screen_dist;
-    const M3 mv = m3_from(cam->mv);
-    const V3 eye(cam->eye[0], cam->eye[1], cam->eye[2]);
-    int threads = o.threads > 1 ? o.threads : 1;
-    (void)threads;
-    memset(out8, 0, (size_t)W * H * 8 * sizeof(uint32_t));
-#ifdef _OPENMP
-#pragma omp parallel num_threads(threads)
-#endif
-    {
-        RtCtx c; c.s = s; c.o = &o; c.eye = eye; c.lights = lights; c.nLights = n_lights;
-        memset(&c.st, 0, sizeof c.st);
-        c.chain_quad = quad;
-#ifdef _OPENMP
-#pragma omp for schedule(dynamic, 1)
-#endif
-        for (int y = 0; y < H; y++)
-            for (int x = 0; x < W; x++) {                      /* the camera ray of render_raytrace, one sample */
-                const float lx = float((H / 2) - (float)y) / SD, ly = float((float)x - (W / 2)) / SD;
-                const V3 rc = normalized(V3(lx, ly, 1.0f));
-                V3 rw = mul(mv.r1, rc.x);
-                rw = add(rw, mul(mv.r2, rc.y));
-                rw = add(rw, mul(mv.r3, rc.z));
-                rw = normalized(rw);
-                c.px = x; c.py = y; c.sample = 0;
-                c.chain = out8 + ((size_t)y * W + x) * 8; c.chain_n = 0;
-                (void)raytrace(c, eye, rw, -1, 0);
-            }
-#ifdef _OPENMP
-#pragma omp critical
-#endif
-        if (c.chain_max_sp > max_sp) max_sp = c.chain_max_sp;
-    }
-    return max_sp;
 }
 
 /* The interactive frame loop of renderer.cc:243-642 (with Keyboard.cc:30-119 and the scanline polls of Raytracer.cc:840-864), as a

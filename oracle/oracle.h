@@ -132,18 +132,8 @@ int orc_render(const orc_scene *, int mode, const orc_camera *, const orc_light 
  * (index into the scene's triangles, -1 = none) and the hit point.  For tests that need hits, not pixels. */
 void orc_trace_hits(const orc_scene *, int n, const float *rays6, int32_t *tri, float *hit3);
 
-/* The same question answered through the reachability rule of a four-wide tree (profiles/history.md 4.1; oracle.cc): a checker of that
- * rule -- it must name the triangle orc_trace_hits names for every ray.  Nothing in the product uses it. */
-void orc_trace_hits_fourwide(const orc_scene *, int n, const float *rays6, int32_t *tri, float *hit3);
-
 /* RayIntersectsBox (Raytracer.cc:99-151) on one ray and one box: 1 = the reference enters the node's children */
 int orc_ray_box(const float *origin3, const float *ray3, const float *bottom3, const float *top3);
-
-/* Analysis only (scripts/chain_model.py): for every pixel of a raytraced frame, the rays cast for it in casting order (camera,
- * shadow, reflection, shadow, ...; at most 8) with the cost a near-first walk with distance culling -- a MODEL of the device's
- * ordered walk -- would have: inner records visited | triangles tested << 16.  out8: width * height * 8 words.  quad: price the four-wide walk (a
- * step looks at a node's grandchildren).  Returns the deepest stack of postponed nodes any ray needed. */
-uint32_t orc_chain_profile(const orc_scene *, const orc_camera *, const orc_light *lights, int n_lights, const orc_opts *, uint32_t *out8, int quad);
 
 /* my_aalineColor(surface, x1, y1, x2, y2, greyPixel) (Wu.cc:1509, as Rasterizers.cc:166-183 calls it) for n lines in order,
  * blended into `pixels` (for tests of the wireframe's line generator) */

@@ -221,15 +221,6 @@ class Scene:
         f(self._h, len(rays), rays.ctypes.data, tri.ctypes.data, hit.ctypes.data)
         return tri, hit
 
-    def chain_profile(self, cam: Camera, lights, n_lights: int, opts: Opts, quad: bool = False):
-        """orc_chain_profile: ((H, W, 8) words: inner records | triangles << 16 per ray of the pixel in casting order, deepest stack)"""
-        out = np.zeros((opts.height, opts.width, 8), np.uint32)
-        f = lib().orc_chain_profile
-        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
-        f.restype = C.c_uint32
-        sp = f(self._h, C.byref(cam), lights, n_lights, C.byref(opts), out.ctypes.data, int(quad))
-        return out, int(sp)
-
     def render(self, mode: int, cam: Camera, lights, n_lights: int, opts: Opts, shadow_maps=None,
                want_f32: bool = False):
         W, H = opts.width, opts.height

@@ -58,7 +58,7 @@ namespace mi355i {
 
 inline thread_local std::string g_err;
 
-// MI355_HOST_PROF=1: where the HOST's time goes in the device entry points (scripts/raster_pipe_variants.py: at 25 k raster frames
+// MI355_HOST_PROF=1: where the HOST's time goes in the device entry points (scripts/raster_host_rate.py: at 25 k raster frames
 // per second the host has 40 us per frame for all of its calls).  Sections are summed and printed when the process ends.
 struct HostProf {
     enum { N = 12 };

@@ -1,5 +1,6 @@
-"""A property of the reference's box test the four-wide tree of profiles/history.md 4.1 rests on (nothing in the product uses it yet):
-RayIntersectsBox (Raytracer.cc:99-151) is monotone in the box -- a ray that passes a box passes every box that contains it,
+"""A property of the reference's box test the product rests on where it skips a test (a single frame's walk starts at the root's own
+record when both its children are inner nodes: a ray that passes a child's box passes the root's -- DevScene::root_direct,
+DESIGN.md 4.1): RayIntersectsBox (Raytracer.cc:99-151) is monotone in the box -- a ray that passes a box passes every box that contains it,
 in the reference's own float arithmetic, early returns and parallel-ray cases included.  A node's box is the exact union of
 its children's, so 'the grandchild's box passes' implies 'the child's box passes'."""
 import ctypes as C
@@ -71,30 +72,3 @@ def test_on_a_real_tree_boxes_are_unions_and_the_predicate_follows(oracle):
             passed += 1
             assert L.orc_ray_box(o.ctypes.data, d.ctypes.data, lo_p.ctypes.data, hi_p.ctypes.data), "node %d child %d" % (p, c)
     assert passed > 10000
-
-
-def test_the_four_wide_reachability_rule_names_the_reference_s_triangle(oracle):
-    """enter an inner grandchild iff its own box passes, a leaf grandchild iff its parent's does, a leaf child always: the same
-    closest triangle and hit point as the reference's walk, for camera-like, random and grazing rays on three trees"""
-    import renderer_amd.assets as A
-    L = oracle.lib()
-    L.orc_trace_hits_fourwide.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-    L.orc_trace_hits_fourwide.restype = None
-    rng = np.random.default_rng(8)
-    for mesh in ("dragon_vis.ply", "statue.ply", "chessboard.tri"):
-        s = oracle.Scene(A.mesh_path(mesh))
-        s.bvh_build()
-        n = 150000
-        o = rng.normal(0, 1, (n, 3)); o = o / np.linalg.norm(o, axis=1, keepdims=True) * rng.uniform(0.3, 3.0, (n, 1))
-        t = rng.uniform(-0.6, 0.6, (n, 3))                     # towards the model, through it, past it
-        d = t - o
-        d[: n // 5] = rng.normal(0, 1, (n // 5, 3))           # and anywhere
-        d[n // 5: n // 4, rng.integers(0, 3)] = 0.0            # axis-parallel components
-        d = d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-20)
-        rays = np.ascontiguousarray(np.concatenate([o, d], 1), np.float32)
-        tri, hit = s.trace_hits(rays)
-        tri4 = np.zeros(n, np.int32); hit4 = np.zeros((n, 3), np.float32)
-        L.orc_trace_hits_fourwide(s._h, n, rays.ctypes.data, tri4.ctypes.data, hit4.ctypes.data)
-        assert (tri >= 0).sum() > n // 20, mesh
-        assert np.array_equal(tri, tri4), "%s: %d rays name another triangle" % (mesh, int((tri != tri4).sum()))
-        assert np.array_equal(hit.view(np.uint32), hit4.view(np.uint32)), mesh
