@@ -107,6 +107,9 @@ def test_the_committed_single_gpu_line_keeps_the_measurement_contract():
     for row in ("statue_depth1_1080p", "dragon_4k"):
         rf = d["other_workloads"][row]["roofline"]
         assert 0.0 < rf["useful"]["frac"] < rf["frac"] <= 1.0 and rf["kernel_ms"] > 0 and rf["traffic"] > 0
+    for name, rr in d["roofline_raster"].items():                    # the rasterizer: overlapped schedule and a frame by itself
+        assert 0.0 < rr["frac"] < 1.0 and rr["gpu_ms_per_frame"] > 0 and "2000 frames" in rr["kernels"]
+        assert 0.0 < rr["single_frame_frac"] <= rr["frac"] and rr["single_frame_gpu_ms"] >= rr["gpu_ms_per_frame"]
     c = d["cpu_baseline"]
     assert c["kind"] == "reference" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and "refcore_omp" in c["sample"]
     assert len(c["runs_Mrays_per_s"]) == 2
