@@ -50,12 +50,24 @@ namespace {
 #ifndef RT_DEFER
 #define RT_DEFER 1          // single frames on the two- and three-wave builds: leaf triangles queued per wave and tested 64 at a time (see the DEFER loop)
 #endif
+#ifndef RT_DEFER_BATCH
+#define RT_DEFER_BATCH 1    // the batch builds queue their leaves too (round 6: +7 % once the tests left the walk loop, see RT_FLUSH_OUT)
+#endif
+#ifndef RT_FLUSH_OUT
+#define RT_FLUSH_OUT 1      // the queued leaves are tested at the top of the main loop, not inside the walk loop (0: inside, rounds 5's shape)
+#endif
 #ifndef RT_FLUSH_AT
 #define RT_FLUSH_AT 48
+#endif
+#ifndef RT_SLOAD
+#define RT_SLOAD 0          // experiment: a wide record every lane of the wave goes to next is read through the scalar cache
 #endif
 #ifndef RT_COUNT
 #define RT_COUNT 0      // measuring variant: wave-uniform counters of the production loop (iterations, lanes per phase) in CS_PROF0 ..
 #endif
+
+// the queue's three LDS rows hold what waits below the threshold plus the two entries per lane one step can add
+static_assert(RT_FLUSH_AT >= 1 && RT_FLUSH_AT - 1 + 2 * RT_BLK <= 3 * RT_BLK, "RT_FLUSH_AT: the leaf queue has 3 * RT_BLK entries");
 
 enum { MODE_CLOSEST = 0, MODE_SHADOW = 1 };
 
@@ -530,7 +542,7 @@ k_raytrace(const DevScene S, const FrameParams P)
     // behind the stack's: the verdict words, and a per-wave table (rank among the givers -> lane).
     constexpr bool STEAL = ORDERED && !STATS && !EXT;
     const bool steal_on = STEAL && P.steal_min > 0;
-    constexpr bool DEFER = STEAL && RT_DEFER && !BATCH && WAVES <= 3;
+    constexpr bool DEFER = STEAL && RT_DEFER && (BATCH ? RT_DEFER_BATCH != 0 : WAVES <= 3);
     // Rows behind the stack's.  Two rows of 64-bit RESULT words, one per thread of the block: the state of the ray that thread
     // owns, as everybody who walks a part of it sees it -- a closest-hit ray: distance^2 bits << 32 | triangle of the best hit so
     // far (atomic min: the nearest hit, the lowest triangle among equals -- the rule of the walk itself), a shadow ray: 0 once a
@@ -546,8 +558,11 @@ k_raytrace(const DevScene S, const FrameParams P)
     float *const lds_lp = (float *)(lds_q + (DEFER ? 3 * RT_BLK : 0));
     // (ordered builds: a hit's reflected direction waits in three rows while the hit's shadow rays are walked; a 4 spp frame
     //  keeps its pixel sums in three more, which only such a launch allocates)
+    //  (a batch build that queues its leaves keeps the direction in the lane instead -- the compiler parks it in scratch with the rest of
+    //   the transition state --: the queue's three rows take the place of these, and sixteen waves of the dragon's tree still fit a CU)
+    constexpr bool REFL_LDS = ORDERED && !(DEFER && BATCH);
     float *const lds_refl = lds_lp + 3 * RT_BLK + threadIdx.x;
-    float *const lds_sum = lds_refl + 3 * RT_BLK;
+    float *const lds_sum = lds_refl + (REFL_LDS ? 3 * RT_BLK : 0);
     Lane L;
     bool alive = false;         // lane owns a pixel
     bool want_pixel = true;     // lane needs a (new) pixel
@@ -569,7 +584,7 @@ k_raytrace(const DevScene S, const FrameParams P)
     L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; L.ao_draw = 0u; L.ao_total = L.ao_max = L.ao_cos = 0.f;
 
     unsigned n_normal = 0, n_shadow = 0, n_steal = 0, n_event = 0;
-    unsigned long long cq[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // RT_COUNT
+    unsigned long long cq[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // RT_COUNT
     unsigned n_pops = 0, n_ihits = 0, n_tris = 0, n_plane = 0, n_shaded = 0;
     // phase profile (STATS builds only; wave-uniform): cycles and lane occupancy per phase
     unsigned long long pc_refill = 0, pc_trans = 0, pc_a = 0, pc_b = 0, pc_total = 0, pc_wait = 0;
@@ -632,8 +647,94 @@ k_raytrace(const DevScene S, const FrameParams P)
         }
     };
     if (P.tile_mask && (int)blockIdx.x < P.fill_first) background();
+    // (DEFER) the queue of leaves, and the state of a burst that breaks off to have them tested
+    uint32_t q_len = 0;                           // leaves queued (wave-uniform)
+    unsigned long long q_src = 0ull;              // lanes named by a queued entry: their copy of the ray must stay where it is
+    bool in_burst = false, lent = false, took = false, own_closest = false, drain = false;
+    int xmin_now = 64;
+    const auto flush_leaves = [&]() {
+                const int lane = (int)(threadIdx.x & 63u);
+                for (uint32_t qb = 0; qb < q_len; qb += 64u) {
+                    const bool have = qb + (uint32_t)lane < q_len;
+                    const uint32_t en = have ? lds_q[qb + (uint32_t)lane] : 0u;
+                    const int src = (int)(en >> 26);
+                    uint32_t two = (en >> 24) & 1u;
+                    uint32_t j = en & 0xffffffu;
+                    const f3 fo = mk3(__shfl(L.o.x, src), __shfl(L.o.y, src), __shfl(L.o.z, src));
+                    const f3 fd = mk3(__shfl(L.d.x, src), __shfl(L.d.y, src), __shfl(L.d.z, src));
+                    const int favoid = __shfl(L.avoid, src), fown = __shfl(L.owner, src), fmode = __shfl(L.mode, src);
+                    typedef unsigned long long u64;
+                    const u64 mshadow = __ballot(fmode == MODE_SHADOW);
+                    const bool shadow = __builtin_amdgcn_inverse_ballot_w64(mshadow);
+                    bool act = have;
+                    while (__ballot(act)) {
+                        const float4 *tp = S.walk + (size_t)S.tri_base + (size_t)(act ? j : 0u) * 2;
+                        const float4 ba = tp[0], bb = tp[1];
+                        // plane half (Raytracer.cc:245-267), the same operations as in the step of the other builds
+                        const f3 n = mk3(ba.x, ba.y, ba.z);
+                        const f3 fto = sub3(fo, mk3(bb.x, bb.y, bb.z));
+                        const u64 mface = __ballot(two != 0u) | __ballot(!(dot3(fto, n) < 0.f));
+                        const float tk = dot3(n, fd);
+                        const float sp = (bb.w - dot3(n, fo)) / tk;
+                        const u64 mcand = __ballot(act) & __ballot((int)j != favoid) & mface & ~__ballot(tk == 0.0f) & ~__ballot(sp <= 0.0f) & ~__ballot(sp <= P.nudge);
+                        if (mcand) {
+                            const bool cand = __builtin_amdgcn_inverse_ballot_w64(mcand);
+                            float4 e1, q, r;
+                            asm volatile("" : "=v"(e1.x), "=v"(e1.y), "=v"(e1.z), "=v"(e1.w), "=v"(q.x), "=v"(q.y), "=v"(q.z), "=v"(q.w), "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w));
+                            if (cand) { const float4 *e = S.tri_edge + (size_t)j * 3; e1 = e[0]; q = e[1]; r = e[2]; }
+                            const f3 hit = add3(mul3(fd, sp), fo);
+                            const float kt1 = dot3(mk3(e1.x, e1.y, e1.z), hit) - e1.w;
+                            const v2f xs = {q.x, q.y}, ys = {q.z, q.w}, zs = {r.x, r.y}, ds = {r.z, r.w};
+                            const v2f kt23 = ((xs * hit.x + ys * hit.y) + zs * hit.z) - ds;
+                            const u64 minside = mcand & __ballot(!(kt1 < 0.0f)) & __ballot(!(kt23.x < 0.0f)) & __ballot(!(kt23.y < 0.0f));
+                            if (minside) {
+                                // a shadow ray is blocked by a hit nearer to the light than the ray's origin is (Raytracer.cc:209, 282-284:
+                                // bestTriDist starts as |o - light|^2, made here by the operations that made L.best); a closest-hit ray
+                                // takes the minimum of (distance^2, list position): strict `<`, ties to the first in the list (:288)
+                                f3 from = fo;
+                                float bound = 0.f;
+                                if (minside & mshadow) {
+                                    const int ow = shadow ? fown : (int)threadIdx.x;
+                                    const f3 lp = mk3(lds_lp[ow], lds_lp[RT_BLK + ow], lds_lp[2 * RT_BLK + ow]);
+                                    if (shadow) { from = lp; bound = distsq3(fo, lp); }
+                                }
+                                const float dz = distsq3(from, hit);
+                                if (__builtin_amdgcn_inverse_ballot_w64(minside & mshadow & __ballot(dz < bound))) ((uint32_t *)result)[2 * fown + 1] = 0u;
+                                if (__builtin_amdgcn_inverse_ballot_w64(minside & ~mshadow)) atomicMin(result + fown, result_key(dz, (int)j));
+                            }
+                        }
+                        // the chain: the next block while it lies in this leaf
+                        const uint32_t nx = __float_as_uint(ba.w);
+                        act = act && (nx & (MI_LEAF_BIT | MI_FIRST_BIT)) == MI_LEAF_BIT;
+                        two = (nx & MI_TWOSIDED_BIT) ? 1u : 0u;
+                        j++;
+                    }
+                }
+                q_len = 0u; q_src = 0ull;
+                // what the tests found, for everyone who still walks: a blocked shadow ray ends, a closest-hit ray's bound tightens
+                if (L.cur != MI_END_LINK) {
+                    const unsigned long long seen = result[L.owner];
+                    if (L.mode == MODE_SHADOW) {
+                        if ((uint32_t)(seen >> 32) == 0u) { L.cur = MI_END_LINK; L.sp = L.base; }
+                    } else {
+                        const float sb = __uint_as_float((uint32_t)(seen >> 32));
+                        if (sb < L.best) { L.best = sb; L.btri = (int)(uint32_t)seen; L.cull = cull_from(limit_from(sb, L.o, S.scene_mag), L.dmax2); }
+                    }
+                }
+                // (the lanes' records were not kept through the tests: requested again)
+                {
+                    const uint32_t c = L.cur;
+                    const bool real = c != MI_END_LINK && c != MI_VROOT_LINK;
+                    const float4 *p = S.walk + (size_t)(real ? (c & MI_INDEX_MASK) : 0u);
+                    const float4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+                    const bool vr = c == MI_VROOT_LINK;
+                    R.a = vr ? S.vroot_a : a0; R.b = vr ? S.vroot_b : a1; R2.a = vr ? S.vroot_a : a2; R2.b = vr ? S.vroot_b : a3;
+                }
+    };
 
     for (;;) {
+        if constexpr (DEFER && RT_FLUSH_OUT) { if (q_len) flush_leaves(); }
+        if (!(DEFER && RT_FLUSH_OUT && in_burst)) {
         // ---------------- refill: hand new pixels to idle lanes --------------------------
         // The wave keeps a private pool [pool_next, pool_end) of pixel indices and takes a chunk of
         // P.chunk indices from the global dispenser only when the pool is dry, so the dispenser sees
@@ -722,10 +823,10 @@ k_raytrace(const DevScene S, const FrameParams P)
             if (!__ballot(want_pixel)) break;
             continue;
         }
-        const bool drain = exhausted && pool_next == pool_end;
+        drain = exhausted && pool_next == pool_end;
         // nothing left to batch with once the dispenser is dry (with work sharing the wave stays in lockstep: a lane whose
         // shadow ray is helped by others must not look at the verdict before they are done)
-        const int xmin_now = (drain && !steal_on) ? 1 : P.xmin;
+        xmin_now = (drain && !steal_on) ? 1 : P.xmin;
 
         if (mX && (__popcll(mX) >= xmin_now || !mT)) {
             // ---------------- transitions ------------------------------------------------
@@ -751,7 +852,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     } else {
                         if (STATS) n_shaded++;
                         shade_begin(P, S, L, lds_col);
-                        if constexpr (ORDERED) { lds_refl[0] = L.refl.x; lds_refl[RT_BLK] = L.refl.y; lds_refl[2 * RT_BLK] = L.refl.z; }
+                        if constexpr (REFL_LDS) { lds_refl[0] = L.refl.x; lds_refl[RT_BLK] = L.refl.y; lds_refl[2 * RT_BLK] = L.refl.z; }
                         lights = true;
                         if constexpr (EXT) {
                             if (P.use_refr && L.depth + 1 < P.max_depth) {
@@ -861,7 +962,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     // all lights done for this hit (its colour is in the level's LDS column): bounce or finish
                     if constexpr (EXT) {
                         if (P.use_refl && L.depth + 1 < P.max_depth) {
-                            L.o = L.hit; L.d = ORDERED ? mk3(lds_refl[0], lds_refl[RT_BLK], lds_refl[2 * RT_BLK]) : L.refl; L.avoid = L.btri;
+                            L.o = L.hit; L.d = REFL_LDS ? mk3(lds_refl[0], lds_refl[RT_BLK], lds_refl[2 * RT_BLK]) : L.refl; L.avoid = L.btri;
                             set_ray_aux(L, S.scene_mag);
                             L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.cull = FLT_MAX; L.btri = -1;
                             L.nocull = 0u;                          // Raytrace<true>
@@ -872,7 +973,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     } else {
                     L.depth++;
                     if (P.use_refl && L.depth < P.max_depth) {
-                        L.o = L.hit; L.d = ORDERED ? mk3(lds_refl[0], lds_refl[RT_BLK], lds_refl[2 * RT_BLK]) : L.refl; L.avoid = L.btri;
+                        L.o = L.hit; L.d = REFL_LDS ? mk3(lds_refl[0], lds_refl[RT_BLK], lds_refl[2 * RT_BLK]) : L.refl; L.avoid = L.btri;
                         set_ray_aux(L, S.scene_mag);
                         L.mode = MODE_CLOSEST; L.best = FLT_MAX; L.cull = FLT_MAX; L.btri = -1;
                         if constexpr (STEAL) { result[threadIdx.x] = MI_RESULT_NONE; L.owner = (int)threadIdx.x; }
@@ -953,6 +1054,7 @@ k_raytrace(const DevScene S, const FrameParams P)
             continue;
         }
 
+        }
         // ---------------- traversal burst ------------------------------------------------
         // Keep walking until enough lanes have finished their ray to make servicing them worthwhile.
         MI_PHASE(pc_refill);
@@ -966,8 +1068,7 @@ k_raytrace(const DevScene S, const FrameParams P)
         // Work sharing: `lent` = a subtree has changed lanes in this burst -- only then can somebody else change the result of the ray
         // a lane walks; `took` = this lane has walked for others in this burst: its own ray (ended before) is put back afterwards.
         const bool share_now = STEAL && steal_on;
-        const bool own_closest = alive && L.mode == MODE_CLOSEST;
-        bool lent = false, took = false;
+        if constexpr (!DEFER) { lent = false; took = false; own_closest = alive && L.mode == MODE_CLOSEST; }
         if constexpr (DEFER) {
         // ---- the same walk with the leaves' triangles tested apart (RT_DEFER) ----------------------------------------------------------
         // A step only visits wide records.  A leaf child that would be entered is QUEUED instead -- an entry in three LDS rows: the lane
@@ -986,93 +1087,18 @@ k_raytrace(const DevScene S, const FrameParams P)
         // a 1080p dragon frame.  Batches are bound by issue slots, not by chains: on the three-wave build they gain 4 % (5 363 -> 5 590
         // frames/s) and stay behind the four-wave build without the queue (5 920), and the four-wave build WITH it needs 204 bytes of
         // scratch per lane, some inside the walk (4 320).
-        uint32_t q_len = 0;                           // leaves queued (wave-uniform)
-        unsigned long long q_src = 0ull;              // lanes named by a queued entry: their copy of the ray must stay where it is
         const int lane = (int)(threadIdx.x & 63u);
+        if (!in_burst) { lent = false; took = false; own_closest = alive && L.mode == MODE_CLOSEST; in_burst = true; }
         for (;;) {
             unsigned long long mWalk = __ballot(L.cur != MI_END_LINK);
             // (leave when enough rays have ended -- every one of them in the default lockstep mode --, with nothing left in the queue)
             const bool leave = !mWalk || (xmin_now < 64 && __popcll(__ballot(alive && L.cur == MI_END_LINK)) >= xmin_now);
             if (q_len >= (uint32_t)RT_FLUSH_AT || (leave && q_len)) {
-                for (uint32_t qb = 0; qb < q_len; qb += 64u) {
-                    const bool have = qb + (uint32_t)lane < q_len;
-                    const uint32_t en = have ? lds_q[qb + (uint32_t)lane] : 0u;
-                    const int src = (int)(en >> 26);
-                    uint32_t two = (en >> 24) & 1u;
-                    uint32_t j = en & 0xffffffu;
-                    const f3 fo = mk3(__shfl(L.o.x, src), __shfl(L.o.y, src), __shfl(L.o.z, src));
-                    const f3 fd = mk3(__shfl(L.d.x, src), __shfl(L.d.y, src), __shfl(L.d.z, src));
-                    const int favoid = __shfl(L.avoid, src), fown = __shfl(L.owner, src), fmode = __shfl(L.mode, src);
-                    typedef unsigned long long u64;
-                    const u64 mshadow = __ballot(fmode == MODE_SHADOW);
-                    const bool shadow = __builtin_amdgcn_inverse_ballot_w64(mshadow);
-                    bool act = have;
-                    while (__ballot(act)) {
-                        const float4 *tp = S.walk + (size_t)S.tri_base + (size_t)(act ? j : 0u) * 2;
-                        const float4 ba = tp[0], bb = tp[1];
-                        // plane half (Raytracer.cc:245-267), the same operations as in the step of the other builds
-                        const f3 n = mk3(ba.x, ba.y, ba.z);
-                        const f3 fto = sub3(fo, mk3(bb.x, bb.y, bb.z));
-                        const u64 mface = __ballot(two != 0u) | __ballot(!(dot3(fto, n) < 0.f));
-                        const float tk = dot3(n, fd);
-                        const float sp = (bb.w - dot3(n, fo)) / tk;
-                        const u64 mcand = __ballot(act) & __ballot((int)j != favoid) & mface & ~__ballot(tk == 0.0f) & ~__ballot(sp <= 0.0f) & ~__ballot(sp <= P.nudge);
-                        if (mcand) {
-                            const bool cand = __builtin_amdgcn_inverse_ballot_w64(mcand);
-                            float4 e1, q, r;
-                            asm volatile("" : "=v"(e1.x), "=v"(e1.y), "=v"(e1.z), "=v"(e1.w), "=v"(q.x), "=v"(q.y), "=v"(q.z), "=v"(q.w), "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w));
-                            if (cand) { const float4 *e = S.tri_edge + (size_t)j * 3; e1 = e[0]; q = e[1]; r = e[2]; }
-                            const f3 hit = add3(mul3(fd, sp), fo);
-                            const float kt1 = dot3(mk3(e1.x, e1.y, e1.z), hit) - e1.w;
-                            const v2f xs = {q.x, q.y}, ys = {q.z, q.w}, zs = {r.x, r.y}, ds = {r.z, r.w};
-                            const v2f kt23 = ((xs * hit.x + ys * hit.y) + zs * hit.z) - ds;
-                            const u64 minside = mcand & __ballot(!(kt1 < 0.0f)) & __ballot(!(kt23.x < 0.0f)) & __ballot(!(kt23.y < 0.0f));
-                            if (minside) {
-                                // a shadow ray is blocked by a hit nearer to the light than the ray's origin is (Raytracer.cc:209, 282-284:
-                                // bestTriDist starts as |o - light|^2, made here by the operations that made L.best); a closest-hit ray
-                                // takes the minimum of (distance^2, list position): strict `<`, ties to the first in the list (:288)
-                                f3 from = fo;
-                                float bound = 0.f;
-                                if (minside & mshadow) {
-                                    const int ow = shadow ? fown : (int)threadIdx.x;
-                                    const f3 lp = mk3(lds_lp[ow], lds_lp[RT_BLK + ow], lds_lp[2 * RT_BLK + ow]);
-                                    if (shadow) { from = lp; bound = distsq3(fo, lp); }
-                                }
-                                const float dz = distsq3(from, hit);
-                                if (__builtin_amdgcn_inverse_ballot_w64(minside & mshadow & __ballot(dz < bound))) ((uint32_t *)result)[2 * fown + 1] = 0u;
-                                if (__builtin_amdgcn_inverse_ballot_w64(minside & ~mshadow)) atomicMin(result + fown, result_key(dz, (int)j));
-                            }
-                        }
-                        // the chain: the next block while it lies in this leaf
-                        const uint32_t nx = __float_as_uint(ba.w);
-                        act = act && (nx & (MI_LEAF_BIT | MI_FIRST_BIT)) == MI_LEAF_BIT;
-                        two = (nx & MI_TWOSIDED_BIT) ? 1u : 0u;
-                        j++;
-                    }
-                }
-                q_len = 0u; q_src = 0ull;
-                // what the tests found, for everyone who still walks: a blocked shadow ray ends, a closest-hit ray's bound tightens
-                if (L.cur != MI_END_LINK) {
-                    const unsigned long long seen = result[L.owner];
-                    if (L.mode == MODE_SHADOW) {
-                        if ((uint32_t)(seen >> 32) == 0u) { L.cur = MI_END_LINK; L.sp = L.base; }
-                    } else {
-                        const float sb = __uint_as_float((uint32_t)(seen >> 32));
-                        if (sb < L.best) { L.best = sb; L.btri = (int)(uint32_t)seen; L.cull = cull_from(limit_from(sb, L.o, S.scene_mag), L.dmax2); }
-                    }
-                }
-                // (the lanes' records were not kept through the tests: requested again)
-                {
-                    const uint32_t c = L.cur;
-                    const bool real = c != MI_END_LINK && c != MI_VROOT_LINK;
-                    const float4 *p = S.walk + (size_t)(real ? (c & MI_INDEX_MASK) : 0u);
-                    const float4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
-                    const bool vr = c == MI_VROOT_LINK;
-                    R.a = vr ? S.vroot_a : a0; R.b = vr ? S.vroot_b : a1; R2.a = vr ? S.vroot_a : a2; R2.b = vr ? S.vroot_b : a3;
-                }
+                if (RT_FLUSH_OUT) break;              // (the tests run at the top of the main loop; in_burst brings the wave back here)
+                flush_leaves();
                 continue;
             }
-            if (leave) break;
+            if (leave) { in_burst = false; break; }
             if (RT_COUNT) { cq[0]++; cq[1]++; cq[2] += __popcll(mWalk); cq[10] += 64 - __popcll(mWalk); }
             // -- work sharing: as in the other builds; a lane named by a queued entry takes nothing (its copy of the ray is read at the flush)
             if (share_now) {
@@ -1193,6 +1219,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                 }
             }
         }
+        if (in_burst) continue;
         } else {
         for (;;) {
             if (STATS) it_loops++;
@@ -1255,7 +1282,14 @@ k_raytrace(const DevScene S, const FrameParams P)
             const unsigned long long mWalk = __ballot(L.cur != MI_END_LINK), mL = __ballot((int)L.cur < 0), mI = mWalk & ~mL;
             const bool walking = __builtin_amdgcn_inverse_ballot_w64(mWalk), inner = __builtin_amdgcn_inverse_ballot_w64(mI), tri = __builtin_amdgcn_inverse_ballot_w64(mL);
             if (RT_COUNT) { cq[0]++; cq[1] += mI ? 1 : 0; cq[2] += __popcll(mI); cq[3] += mL ? 1 : 0; cq[4] += __popcll(mL);
-                            cq[9] += __popcll(__ballot(tri && (L.cur & MI_FIRST_BIT) != 0u)); cq[10] += __popcll(__ballot(L.cur == MI_END_LINK)); }
+                            cq[9] += __popcll(__ballot(tri && (L.cur & MI_FIRST_BIT) != 0u)); cq[10] += __popcll(__ballot(L.cur == MI_END_LINK));
+                            // how many DIFFERENT wide records the lanes at a node sit on: [13] iterations with one, [19] their lanes, [15] two, [18] three or four, [14] the sum
+                            if (mI) {
+                                unsigned long long m = mI; int nd = 0;
+                                while (m) { const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)L.cur, __ffsll((long long)m) - 1); m &= ~__ballot(L.cur == c); nd++; }
+                                cq[14] += nd;
+                                if (nd == 1) { cq[13]++; cq[19] += __popcll(mI); } else if (nd == 2) cq[15]++; else if (nd <= 4) cq[18]++;
+                            } }
             uint32_t next = MI_END_LINK;                            // END = nothing to enter from here: pop
             if (STATS) {                                            // profile: time spent waiting for the record
                 MI_PHASE(pc_b);
@@ -1357,6 +1391,32 @@ k_raytrace(const DevScene S, const FrameParams P)
                 L.sp--;
                 if (L.sp > sbase) L.top = stk[(L.sp - 1) * RT_BLK];
             }
+#if RT_SLOAD
+            // Lanes that all go to the SAME wide record next (every ray starts at the root, and the rays of a tile stay together for
+            // the first levels) take it through the scalar cache: one s_load of 64 bytes for the wave instead of 64 lanes x 4 x 16 bytes
+            // through the texture path, which is the busiest unit of this kernel (TD_BUSY 0.85).  The scalar load is issued here and
+            // its registers are copied at the end of the step, behind the triangle phase.
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            v4f s0, s1, s2, s3;
+            unsigned long long mS = 0ull;
+            if (walking) L.cur = next;
+            {
+                const unsigned long long mNi = mWalk & __ballot((int)next >= 0 && next != MI_END_LINK);
+                uint32_t n0 = 0u;
+                if (mNi) {
+                    n0 = (uint32_t)__builtin_amdgcn_readlane((int)next, __ffsll((long long)mNi) - 1);
+                    if ((mNi & __ballot(next != n0)) == 0ull) mS = mNi; else n0 = 0u;
+                }
+                typedef const v4f __attribute__((address_space(4))) *cptr;
+                cptr p = (cptr)(S.walk + (size_t)(n0 & MI_INDEX_MASK));
+                s0 = p[0]; s1 = p[1]; s2 = p[2]; s3 = p[3];
+                if (walking && next != MI_END_LINK && !__builtin_amdgcn_inverse_ballot_w64(mS)) {
+                    const float4 *p = S.walk + (size_t)(next & MI_INDEX_MASK);
+                    R.a = p[0]; R.b = p[1];
+                    if ((next & MI_LEAF_BIT) == 0) { R2.a = p[2]; R2.b = p[3]; }
+                }
+            }
+#else
             if (walking) {
                 L.cur = next;
                 if (next != MI_END_LINK) {
@@ -1365,6 +1425,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     if ((next & MI_LEAF_BIT) == 0) { R2.a = p[2]; R2.b = p[3]; }
                 }
             }
+#endif
             if constexpr (WAVES >= 3) {
             // 4. while that request is in flight: this step's triangle -- plane half, and for the lanes that pass it the
             //    edge half at once (Raytracer.cc:245-297 as straight-line predicates: the same float operations in the
@@ -1482,6 +1543,14 @@ k_raytrace(const DevScene S, const FrameParams P)
                     }
                 }
             }
+#if RT_SLOAD
+            if (mS) {
+                if (__builtin_amdgcn_inverse_ballot_w64(mS)) {
+                    R.a = make_float4(s0.x, s0.y, s0.z, s0.w); R.b = make_float4(s1.x, s1.y, s1.z, s1.w);
+                    R2.a = make_float4(s2.x, s2.y, s2.z, s2.w); R2.b = make_float4(s3.x, s3.y, s3.z, s3.w);
+                }
+            }
+#endif
             const unsigned long long mBusy = __ballot(L.cur != MI_END_LINK || L.pend);
             if (!mBusy) break;
             if (xmin_now < 64 && __popcll(__ballot(alive && L.cur == MI_END_LINK && !L.pend)) >= xmin_now) break;
@@ -1497,7 +1566,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                     if (alive && !own_closest) L.btri = (int)(uint32_t)result[threadIdx.x];     // (the hit the shadow ray started on)
                     if (own_closest) {
                         if (L.depth == 0) { L.o = cam_eye<BATCH>(P, L.fid); L.d = primary_dir<BATCH>(P, L, L.samples_left); }
-                        else { L.o = L.hit; L.d = mk3(lds_refl[0], lds_refl[RT_BLK], lds_refl[2 * RT_BLK]); }
+                        else { L.o = L.hit; L.d = REFL_LDS ? mk3(lds_refl[0], lds_refl[RT_BLK], lds_refl[2 * RT_BLK]) : L.refl; }
                     }
                 }
             }
@@ -1593,7 +1662,7 @@ k_raytrace(const DevScene S, const FrameParams P)
         const unsigned long long a = wsum(n_normal), b = wsum(n_shadow);
         const bool lead = (threadIdx.x & 63u) == 0;
         if (lead) { atomicAdd(&P.counters[CS_NORMAL_RAYS], a); atomicAdd(&P.counters[CS_SHADOW_RAYS], b); }
-        if (RT_COUNT && lead) for (int i = 0; i < 11; i++) atomicAdd(&P.counters[CS_PROF0 + i], cq[i]);
+        if (RT_COUNT && lead) for (int i = 0; i < 20; i++) if (i < 11 || i == 13 || i == 14 || i == 15 || i >= 18) atomicAdd(&P.counters[CS_PROF0 + i], cq[i]);
         if constexpr (STEAL) {      // (debug: subtrees handed from lane to lane, in a word the counting builds use for their profile)
             const unsigned long long ns = wsum(n_steal);
             if (lead && ns) { atomicAdd(&P.counters[CS_PROF0 + 12], ns); atomicAdd(&P.counters[CS_PROF0 + 11], (unsigned long long)n_event); }
@@ -1831,10 +1900,15 @@ rt_kernel pick_kernel(int stats, int exact, int ordered, int waves, int batch, i
 // (stack rows, verdict row, giver table, three light rows, three rows of reflected directions; 4 spp: three rows of pixel sums)
 // (`rows` as the launcher passes it: three per depth level of the ray tree, the tree's stack rows if the walk is ordered, three
 //  more for a 4 spp frame)
-// (`defer`: the build queues leaves -- two more rows)
-size_t stack_bytes(int ordered, int rows, int defer) { return (size_t)(rows + (ordered ? 9 + (defer ? 3 : 0) : 0)) * (size_t)RT_BLK * sizeof(uint32_t); }
+// (`defer`: the build queues leaves -- three more rows; 2 = a batch build that does: the queue's rows instead of the reflected directions')
+size_t stack_bytes(int ordered, int rows, int defer) { return (size_t)(rows + (ordered ? 9 + (defer == 1 ? 3 : 0) : 0)) * (size_t)RT_BLK * sizeof(uint32_t); }
 // which builds queue their leaves (k_raytrace: DEFER)
-int uses_defer(int stats, int ordered, int waves, int batch, int ext) { return RT_DEFER && ordered && !stats && !ext && !batch && waves <= 3; }
+// (pick_kernel serves a single frame with the three-wave build at most, whatever was asked for: the same clamp here)
+int uses_defer(int stats, int ordered, int waves, int batch, int ext)
+{
+    if (!(RT_DEFER && ordered && !stats && !ext)) return 0;
+    return batch ? (RT_DEFER_BATCH != 0 ? 2 : 0) : 1;
+}
 } // namespace
 
 // can this build render several frames per launch?  (the ordered, non-counting kernels only)
