@@ -73,6 +73,125 @@ def useful_ops(st):
     return USEFUL_OPS["wide"] * wide + USEFUL_OPS["plane"] * st["tri_tests"] + USEFUL_OPS["edge"] * st["plane_pass"]
 
 
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read()
+    except OSError:
+        return None
+
+
+def _cgroup_dirs():
+    """Directories whose CPU controller files bound this process, innermost first: cgroup v2 (unified) and v1 (cpu / cpuacct)."""
+    v2, v1 = [], []
+    txt = _read("/proc/self/cgroup") or ""
+    for line in txt.splitlines():
+        parts = line.split(":", 2)
+        if len(parts) != 3:
+            continue
+        hid, ctrl, path = parts
+        if hid == "0" and ctrl == "":
+            base = "/sys/fs/cgroup" if os.path.exists("/sys/fs/cgroup/cgroup.controllers") else "/sys/fs/cgroup/unified"
+            p = path
+            while True:
+                v2.append(os.path.normpath(base + "/" + p))
+                if p in ("", "/"):
+                    break
+                p = os.path.dirname(p)
+        elif "cpu" in ctrl.split(","):
+            p = path
+            while True:
+                v1.append(os.path.normpath("/sys/fs/cgroup/cpu/" + p))
+                if p in ("", "/"):
+                    break
+                p = os.path.dirname(p)
+    return v2, v1
+
+
+def cpu_grant():
+    """What the host grants this process: hardware threads it sees, its affinity mask, and the CFS quota of the tightest
+    cgroup above it (v2 cpu.max / v1 cpu.cfs_quota_us) in cores -- None where no quota is set or none is visible from inside."""
+    ncpu = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = ncpu
+    quota, where = None, None
+    v2, v1 = _cgroup_dirs()
+    for d in v2:
+        t = _read(d + "/cpu.max")
+        if t:
+            a = t.split()
+            if len(a) == 2 and a[0] != "max" and float(a[1]) > 0:
+                q = float(a[0]) / float(a[1])
+                if quota is None or q < quota:
+                    quota, where = q, d + "/cpu.max"
+    for d in v1:
+        q_us, p_us = _read(d + "/cpu.cfs_quota_us"), _read(d + "/cpu.cfs_period_us")
+        if q_us and p_us and float(q_us) > 0 and float(p_us) > 0:
+            q = float(q_us) / float(p_us)
+            if quota is None or q < quota:
+                quota, where = q, d + "/cpu.cfs_quota_us"
+    granted = min(aff, ncpu) if quota is None else min(float(aff), quota)
+    return {"host_threads": ncpu, "affinity_threads": aff, "cpu_quota_cores": None if quota is None else round(quota, 2),
+            "cpu_quota_from": where, "granted_cores": round(granted, 2)}
+
+
+def cpu_stat():
+    """Throttling counters of the cgroups above this process (summed over the levels that have them; the tightest level is the
+    one that moves) and the CPU seconds this process and its finished children have used."""
+    import resource
+    out = {"nr_periods": 0, "nr_throttled": 0, "throttled_usec": 0.0, "seen": False}
+    v2, v1 = _cgroup_dirs()
+    for d in v2 + v1:
+        t = _read(d + "/cpu.stat")
+        if not t:
+            continue
+        kv = dict((a.split()[0], float(a.split()[1])) for a in t.splitlines() if len(a.split()) == 2)
+        if "nr_periods" in kv:
+            out["seen"] = True
+            out["nr_periods"] += kv.get("nr_periods", 0)
+            out["nr_throttled"] += kv.get("nr_throttled", 0)
+            out["throttled_usec"] += kv.get("throttled_usec", kv.get("throttled_time", 0) / 1e3)
+    ru_s, ru_c = resource.getrusage(resource.RUSAGE_SELF), resource.getrusage(resource.RUSAGE_CHILDREN)
+    out["cpu_seconds"] = ru_s.ru_utime + ru_s.ru_stime + ru_c.ru_utime + ru_c.ru_stime
+    out["wall"] = time.perf_counter()
+    return out
+
+
+def cpu_stat_delta(a, b, threads):
+    """Between two cpu_stat() snapshots: the share of CFS periods in which the group was throttled, the time its threads were kept
+    off the CPUs, and how many cores' worth of CPU time the sample actually got (CPU seconds / wall seconds)."""
+    wall = max(b["wall"] - a["wall"], 1e-9)
+    periods = b["nr_periods"] - a["nr_periods"]
+    d = {"effective_cores_used": round((b["cpu_seconds"] - a["cpu_seconds"]) / wall, 2), "threads": threads}
+    if a["seen"] and periods > 0:
+        d["throttled_fraction"] = round((b["nr_throttled"] - a["nr_throttled"]) / periods, 3)
+        d["throttled_seconds_per_wall_second"] = round((b["throttled_usec"] - a["throttled_usec"]) / 1e6 / wall, 2)
+    else:
+        d["throttled_fraction"] = None      # no CFS quota above this process (or its counters are not visible from inside)
+    return d
+
+
+def frame_pins(mesh, mode, w, h, depth):
+    """{orbit frame: SHA-256 of its R,G,B bytes} for a configuration the reference's own output is pinned for: the survey's first
+    frames (tests/golden/reference_pins.json) and the frames further along the orbit made from Raytracer.cc compiled in the build
+    container (tests/golden/refcore_frame_pins.json).  Data files of the repository: nothing of the reference is read at run time."""
+    pins = {}
+    try:
+        a = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_pins.json")))
+        for f in a.get("frames", []):
+            if (f["mesh"], f["mode"], f["w"], f["h"]) == (mesh, mode, w, h) and (mode < 9 or f["depth"] == depth):
+                pins[0] = f["sha256"]
+        b = json.load(open(os.path.join(ROOT, "tests", "golden", "refcore_frame_pins.json")))
+        for f in b.get("frames", []):
+            if (f["mesh"], f["mode"], f["w"], f["h"], f["depth"]) == (mesh, mode, w, h, depth) and not f.get("second_light"):
+                pins[int(f["frame"])] = f["sha256"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return pins
+
+
 def pmc_in_run(py_args, seconds=90):
     """Hardware counters of the bench kernel, measured NOW: this script again as a child under `rocprofv3 --pmc` (one pass per
     counter group: FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md), a handful of the same launches, averages
@@ -309,6 +428,31 @@ def main():
         d = time.perf_counter() - t0
         return all_reduce([d], "max")[0], e0.elapsed_time(e1)
 
+    def verify_assembled(g, kind, step_fn, frames_per_step, pins):
+        """Outside every timed region: the steps that hold orbit frames with a reference pin are rendered and exchanged through
+        assembler g, and the ASSEMBLED frames are hashed where they end up (rank 0 for a gather, rank j % N for the spread assembly).
+        -> (frames checked, frames whose hash differs), the same on every rank."""
+        import hashlib
+        checked, bad = 0, 0
+        for f, sha in sorted(pins.items()):
+            k, j = divmod(f, frames_per_step)
+            step_fn(k, 0)
+            g.drain()
+            torch.cuda.synchronize(dev)
+            fr = g.frame(0)
+            mine = None
+            if kind == "spread":
+                if j % world == rank:
+                    mine = fr[j // world]
+            elif rank == 0:
+                mine = fr[j] if fr.dim() == 3 else fr
+            if mine is not None:
+                px = mine.contiguous().cpu().numpy().view(np.uint32)
+                checked += 1
+                bad += 0 if hashlib.sha256(R.rgb_bytes(px)).hexdigest() == sha else 1
+        tot = all_reduce([checked, bad])
+        return int(tot[0]), int(tot[1])
+
     if args.pmc_child:
         # launches one after the other, as the roofline's kernel_ms times them (the library does not overlap calls while a profiler
         # collects counters anyway)
@@ -491,6 +635,18 @@ def main():
                 assert ok2, "a frame of the second region's last step is empty"
             mg[other] = describe(g2, other, d2)
             dt_other = d2
+        # ---- self-check (not timed): the assembled frames hash to the reference's pins, for every assembly that was timed
+        pins_main = frame_pins(args.mesh, args.mode, W, H, args.depth)
+        sha = {"pinned_frames": sorted(pins_main), "note": "orbit frames with a SHA-256 pin of the reference's own output (tests/golden/): rendered as part of their "
+                                                          "step through each assembly and hashed where the assembled frame ends up; not in any timed region"}
+        if pins_main:
+            n_c, n_b = verify_assembled(gather, primary, lambda k, slot: enqueue(k, o_run, slot, gather), B, pins_main)
+            sha[primary] = {"checked": n_c, "differ": n_b}
+            if other:
+                n_c2, n_b2 = verify_assembled(g2, other, lambda k, slot: enqueue(k, o_run, slot, g2), B, pins_main)
+                sha[other] = {"checked": n_c2, "differ": n_b2}
+        mg["assembled_sha"] = sha
+        if other:
             del g2
         if dt_other is not None and args.assemble == "auto" and dt_other < dt:
             # `value` is the faster assembly's (both were timed the same way: K steps, barriers and synchronisation on both sides)
@@ -560,11 +716,63 @@ def main():
             torch.cuda.synchronize(dev); barrier(); torch.cuda.synchronize(dev)
             t5 = all_reduce([time.perf_counter() - t1], "max")[0]
             r5 = all_reduce([float(sum(rays5[(k * c_B + j) % N_CAMS] for k in range(n5) for j in range(c_B)))])[0]
+            pins5 = frame_pins(args.mesh, args.mode, c_W, c_H, 3)
+            c5_checked, c5_bad = verify_assembled(g5, kind5, lambda k, slot: step5(k, slot), c_B, pins5) if pins5 else (0, 0)
+            mg["assembled_sha"]["config5"] = {"checked": c5_checked, "differ": c5_bad, "pinned_frames": sorted(pins5)}
             mg["config5"] = {"workload": "%s, mode %d, %dx%d, screen bands x%d, %d frames per step (strong scaling: the step is the same for every N)"
                                          % (args.mesh, args.mode, c_W, c_H, world, c_B),
                              "assembly": kind5, "steps": n5, "ms_per_step": round(t5 * 1e3 / n5, 4), "frames_per_sec": round(n5 * c_B / t5, 2),
                              "Mrays_per_s": round(r5 / t5 / 1e6, 2), "rays_per_frame": round(r5 / (n5 * c_B), 1)}
             del g5
+        # ---- the rasterizer at N > 1 (north_star: frames/s on chessboard.tri at 1 / 2 / 4 / 8 GPUs; the reference's frame loop is
+        #      Rasterizers.cc:320-356 under renderer.cc:522-583): chessboard.tri at 1920x1080, per-pixel Phong (mode 6) and Phong + 3x3-PCF
+        #      soft shadow map (mode 8); like the headline 8 frames per GPU and step, every GPU rasterizes its interleaved bands of all
+        #      of them in one batched launch, ONE exchange per step assembles the frames; the first frame of the orbit is hashed
+        #      against the reference's pins (BASELINE configs[1] and its soft-shadow variant) after assembly
+        if not args.no_weak and not by_frames:
+            try:
+                r_W, r_H, r_B = 1920, 1080, min(64, 8 * world)
+                kind_r = mg["value_from"] if (mg["value_from"] != "spread" or r_B % world == 0) else "rank0"
+                g_r = (multigpu.SpreadAssembler(r_W, r_H, dev, frames=r_B, staged=dry) if kind_r == "spread" else
+                       multigpu.FrameGatherer(r_W, r_H, dev, frames=r_B, staged=dry))
+                rsc = R.Scene(R.assets.mesh_path("chessboard.tri"), device=local_rank)
+                rsc.shadowmap_render(0, cams[0][1][0])
+                ras = {"step": "%d frames of %dx%d (8 per GPU), bands x%d, one exchange per step" % (r_B, r_W, r_H, world), "assembly": kind_r}
+                for r_mode, r_name in ((6, "phong"), (8, "softshadow")):
+                    o_r = R.default_opts(r_W, r_H, tune=json.loads(args.tune))
+                    o_r.band_rows, o_r.band_index, o_r.band_count, o_r.compact_rows = multigpu.BAND_ROWS, rank, world, 1
+
+                    def rstep(k, slot, r_mode=r_mode, o_r=o_r):
+                        fs = [(k * r_B + j) % N_CAMS for j in range(r_B)]
+                        buf = g_r.send_buffer(slot)
+                        rsc.render_batch_device(r_mode, [cams[f][0] for f in fs], [cams[f][1] for f in fs], cams[fs[0]][2], o_r,
+                                                [buf[g_r.slot_of_frame(j) if kind_r == "spread" else j].data_ptr() for j in range(r_B)], r_W * 4, None,
+                                                stream.cuda_stream)
+                        g_r.gather(slot)
+                    for k in range(3):
+                        rstep(k, k & 1)
+                    g_r.drain()
+                    barrier(); torch.cuda.synchronize(dev)
+                    n_r = max(20, K)
+                    t1 = time.perf_counter()
+                    for k in range(n_r):
+                        rstep(k, k & 1)
+                    g_r.drain()
+                    torch.cuda.synchronize(dev); barrier(); torch.cuda.synchronize(dev)
+                    t_r = all_reduce([time.perf_counter() - t1], "max")[0]
+                    pins_r = frame_pins("chessboard.tri", r_mode, r_W, r_H, 3)
+                    rc, rb = verify_assembled(g_r, kind_r, rstep, r_B, pins_r) if pins_r else (0, 0)
+                    ras[r_name] = {"mode": r_mode, "steps": n_r, "ms_per_step": round(t_r * 1e3 / n_r, 4), "frames_per_sec": round(n_r * r_B / t_r, 1),
+                                   "assembled_sha": {"checked": rc, "differ": rb, "pinned_frames": sorted(pins_r)}}
+                    mg["assembled_sha"]["raster_" + r_name] = {"checked": rc, "differ": rb}
+                mg["raster_1080p"] = ras
+                del g_r, rsc
+            except Exception as e:      # (a secondary region must not take the headline with it -- but its hashes, if it got that far, still count)
+                mg["raster_1080p"] = {"error": str(e)}
+        # one verdict over every assembly that was checked: a frame that differs anywhere voids the line's `value`
+        checks = [v for k, v in mg["assembled_sha"].items() if isinstance(v, dict) and "differ" in v]
+        mg["assembled_sha_ok"] = bool(checks) and all(v["differ"] == 0 for v in checks) and all(v["checked"] > 0 for v in checks)
+        mg["assembled_sha_checked"] = int(sum(v["checked"] for v in checks))
 
     result = None
     if rank == 0:
@@ -605,6 +813,10 @@ def main():
             "traced_Mrays_per_s": round((total_rays - total_culled) / dt / 1e6, 3),
             "roofline": None,
         }
+        if mg is not None and not mg.get("assembled_sha_ok", False) and mg.get("assembled_sha", {}).get("pinned_frames"):
+            # (the frames the ranks assembled are NOT the reference's: no number is reported for a wrong picture)
+            result["invalid"] = "assembled frames do not hash to the reference's pins (multi_gpu.assembled_sha): value withheld (would have been %.3f)" % result["value"]
+            result["value"] = None
         if dry:
             result["dry_run"] = True
         if repeats:
@@ -1029,7 +1241,7 @@ def main():
                 done_frames += 1
                 k += 1
             port = {
-                "value": round(done_rays / t_cpu / 1e6, 3), "unit": "Mrays/s", "cores": best_t, "kind": "port",
+                "value": round(done_rays / t_cpu / 1e6, 3), "unit": "Mrays/s", "cores": cpu_grant()["granted_cores"], "threads": best_t, "kind": "port",
                 "sample": "oracle (strict-IEEE C++ port of the reference, OpenMP over pixels like Raytracer.cc:558) on "
                           "frames f0..f%d of the same workload, %.1f s; %d threads = fastest of a probe over {1,8,16,32,64,%d} on this %d-thread host"
                           % (done_frames - 1, t_cpu, best_t, ncpu, ncpu),
@@ -1060,19 +1272,38 @@ def main():
                         (b_sched, b_t), b_s = min(probe.items(), key=lambda kv: kv[1])
                         sample = [f for f in used if rays_f[f] > 0][:max(4, min(len(used), int(round(args.cpu_seconds / max(b_s, 1e-3)))))]
                         # (the sample twice: the box's CPU quota makes single samples move by a quarter from box to box; the better run counts)
-                        runs = [RC.time_frames(osc, [ocams[f][0] for f in sample], lights0, n0, W, H, 2 * H, threads=b_t, schedule=b_sched)[0] for _ in range(2)]
-                        secs = min(runs, key=lambda v: float(v.sum()))
+                        grant = cpu_grant()
+                        snaps = [cpu_stat()]
+                        runs = []
+                        for _ in range(2):
+                            runs.append(RC.time_frames(osc, [ocams[f][0] for f in sample], lights0, n0, W, H, 2 * H, threads=b_t, schedule=b_sched)[0])
+                            snaps.append(cpu_stat())
+                        best_run = min(range(2), key=lambda i: float(runs[i].sum()))
+                        secs = runs[best_run]
+                        usage = cpu_stat_delta(snaps[best_run], snaps[best_run + 1], b_t)
                         r_rays, r_t = float(sum(rays_f[f] for f in sample)), float(secs.sum())
                         ref_single = RC.time_frames(osc, [ocams[0][0]], lights0, n0, W, H, 2 * H, threads=1, schedule=1)[0][0] if args.cpu_seconds >= 8 else None
+                        # `cores` = what the box grants this process (its CFS quota if it has one, else its affinity mask), `threads` = what
+                        # was launched; `burst_Mrays_per_s` = the fastest probe (two frames: what the host does before any quota bites)
+                        burst = float(np.mean([rays_f[1], rays_f[2]])) / b_s / 1e6 if b_s > 0 and rays_f[1] > 0 and rays_f[2] > 0 else None
+                        thr = usage.get("throttled_fraction")
+                        note = ("; the cgroup's CFS quota throttled this sample in %.0f %% of its periods" % (100 * thr)) if (thr is not None and thr > 0.10) else ""
+                        if usage["effective_cores_used"] < 0.5 * min(b_t, grant["granted_cores"]):
+                            note += ("; the sample got %.1f cores' worth of CPU time for its %d threads (the host does not grant more, whatever it shows)"
+                                     % (usage["effective_cores_used"], b_t))
                         result["cpu_baseline"] = {
-                            "value": round(r_rays / r_t / 1e6, 3), "unit": "Mrays/s", "cores": b_t, "kind": "reference",
+                            "value": round(r_rays / r_t / 1e6, 3), "unit": "Mrays/s", "cores": grant["granted_cores"], "threads": b_t, "kind": "reference",
+                            "cpu_quota_cores": grant["cpu_quota_cores"], "host_threads": grant["host_threads"], "affinity_threads": grant["affinity_threads"],
+                            "effective_cores_used": usage["effective_cores_used"], "throttled_fraction": thr,
+                            "throttled_seconds_per_wall_second": usage.get("throttled_seconds_per_wall_second"),
+                            "burst_Mrays_per_s": None if burst is None else round(burst, 2),
                             "sample": "oracle/_ref/refcore_omp: the reference's own Raytracer.cc (Raytrace<true>, strict flags -O2 -ffp-contract=off) "
                                       "on orbit frames %s of the same workload (%d frames, %.1f s), OpenMP over pixels in refcore.cc's frame loop (%s), "
                                       "%d threads = fastest of a probe over threads x loop shape on this %d-thread host; rays per frame from the "
-                                      "counting build (= the reference's counters)"
+                                      "counting build (= the reference's counters)%s"
                                       % ("f%d..f%d" % (sample[0], sample[-1]), len(sample), r_t,
                                          "one parallel loop over the frame's scanlines" if b_sched == 1 else "the reference's shape: a parallel-for over x per scanline",
-                                         b_t, ncpu),
+                                         b_t, ncpu, note),
                             "frames_per_sec": round(len(sample) / r_t, 3),
                             "probe_ms_per_frame": {"%s/%dt" % ("rows" if k[0] == 1 else "per-scanline", k[1]): (round(v * 1e3, 1) if v < 1e9 else "timed out")
                                                    for k, v in sorted(probe.items())},
@@ -1088,7 +1319,7 @@ def main():
                             aruns = [RC.time_frames(osc, [ocams[f][0] for f in sample], lights0, n0, W, H, 2 * H, threads=b_t, schedule=b_sched, binary=RC.AUTHOR_BINARY)[0] for _ in range(2)]
                             a_t = min(float(v.sum()) for v in aruns)
                             result["cpu_baseline_author"] = {
-                                "value": round(r_rays / a_t / 1e6, 3), "unit": "Mrays/s", "cores": b_t, "kind": "reference",
+                                "value": round(r_rays / a_t / 1e6, 3), "unit": "Mrays/s", "cores": grant["granted_cores"], "threads": b_t, "kind": "reference",
                                 "sample": "oracle/_ref/refcore_omp_author: the same Raytracer.cc and frame loop with the reference's own release flags "
                                           "(configure.ac:47-50, 193-264: -O3 -fomit-frame-pointer -ffast-math -funsafe-math-optimizations -mtune=native -flto "
                                           "-msse -mrecip -mfpmath=sse -msse2 -mssse3 -DSIMD_SSE -DSIMD_SSE2 -DNDEBUG), the same %d frames, threads and loop "

@@ -214,7 +214,7 @@ def host_array(shape, dtype=np.uint32) -> np.ndarray:
     if not p:
         raise Mi355Error("mi355_host_alloc: " + lib().mi355_last_error().decode())
     a = np.ctypeslib.as_array((C.c_ubyte * n).from_address(p)).view(dtype).reshape(shape)
-    _HOST_ARRAYS[a.ctypes.data] = p
+    _HOST_ARRAYS[p] = n
     return a
 
 
@@ -222,7 +222,13 @@ _HOST_ARRAYS = {}
 
 
 def host_array_free(a: np.ndarray) -> None:
-    p = _HOST_ARRAYS.pop(a.ctypes.data)
+    """Give back the allocation `a` lies in -- `a` may be the array host_array() returned or any view of it (a slice, a reshape,
+    another dtype): the allocation is found by address.  ValueError for an array that is not in frame memory of the library's."""
+    addr = a.ctypes.data
+    p = next((b for b, n in _HOST_ARRAYS.items() if b <= addr < b + max(n, 1)), None)
+    if p is None:
+        raise ValueError("host_array_free: the array at 0x%x does not lie in memory that host_array() handed out (or it was freed already)" % addr)
+    del _HOST_ARRAYS[p]
     f = lib().mi355_host_free
     f.restype = None
     f.argtypes = [C.c_void_p]

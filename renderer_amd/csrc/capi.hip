@@ -160,7 +160,8 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.exact_box = (flags & 1) ? 1 : 0;
     if (!c->boxes_tame) P.exact_box = 1;     // box coordinates outside the filtered test's validated range
     P.wave_prof = nullptr;
-    if (o->collect_stats) {
+    static const bool wavelog = getenv("MI355_WAVELOG") != nullptr;      // (measuring builds of k_raytrace: RT_WAVELOG)
+    if (o->collect_stats || wavelog) {
         if (c->wave_prof.ensure((size_t)8 * c->n_cus * 4 * 16 * 8) == hipSuccess) P.wave_prof = (unsigned long long *)c->wave_prof.p;
     }
     P.tile_order = nullptr;
@@ -171,8 +172,11 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
 }
 
 
+// host_cams (with P.lean_prep): the cameras of a batched launch as the caller's table on the host -- the launch is prepared by ONE small
+// kernel (k_tile_select_lean: camera table from its arguments, control block cleared by it) instead of a copy, a memset and a selection
+// kernel that each wait for free wave slots behind the previous launch; where the frame cannot be culled it falls back to those.
 int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hipStream_t st, void *ctrl = nullptr, RasterScratch *rs = nullptr,
-                  DevBuf *mlaa_scratch = nullptr, uint32_t *const *frame_outs = nullptr, DevBuf *sel = nullptr)
+                  DevBuf *mlaa_scratch = nullptr, uint32_t *const *frame_outs = nullptr, DevBuf *sel = nullptr, const FrameCam *host_cams = nullptr)
 {
     FrameParams P = P_in;
     const bool own_ctrl = ctrl != nullptr;
@@ -247,7 +251,16 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
     }
     // (a raster frame that does not count zeroes its control block in its first kernel: one launch less per frame, ~4.7 us)
     const bool raster_self_clear = mode >= MI355_MODE_AMBIENT && mode <= MI355_MODE_PHONG_SOFTSHADOWMAPS && !stats && !P.cams;
-    if (!raster_self_clear) HIP_TRY(hipMemsetAsync(ctrl, 0, rt ? MI_CTRL_BYTES : 16 + sizeof(unsigned long long) * CS_COUNT, st), -40);
+    // (a batched raytrace launch prepared by k_tile_select_lean: that kernel clears the control block and carries the cameras)
+    const long long n_tiles_all = (((long long)P.W + 7) / 8) * (((long long)P.n_rows + 7) / 8);
+    const bool lean = rt && P.lean_prep && host_cams && P.cams && P.n_frames >= 1 && P.n_frames <= MI_LEAN_FRAMES && !stats && !P.outf && c->has_bvh && c->dev.ordered_ok &&
+                      !P.ref_order && !P.exact_box && !P.use_refr && !P.ao && (P.band_count <= 1 || (P.band_rows > 0 && P.band_rows % 8 == 0)) && c->n_cull_boxes > 0 && !P.no_cull &&
+                      n_tiles_all <= MI_CULL_MAX_TILES && P.fill_first <= 0;
+    if (P.lean_prep && !lean) {
+        if (host_cams && P.cams) HIP_TRY(hipMemcpyAsync((void *)P.cams, host_cams, sizeof(FrameCam) * (size_t)P.n_frames, hipMemcpyHostToDevice, st), -31);
+        P.lean_prep = 0;
+    }
+    if (!raster_self_clear && !lean) HIP_TRY(hipMemsetAsync(ctrl, 0, rt ? MI_CTRL_BYTES : 16 + sizeof(unsigned long long) * CS_COUNT, st), -40);
     if (stats)   // the two "min" time stamps start at all-ones
         HIP_TRY(hipMemsetAsync((char *)ctrl + 16 + sizeof(unsigned long long) * CS_TIME0, 0xff, 2 * sizeof(unsigned long long), st), -40);
     c->last_stats = stats != 0;
@@ -272,7 +285,13 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
             FrameParams Q = P;
             Q.out = fl.fb;
             e = mi355i_launch_raster_overlapped(&c->dev, &Q, mode, c->rs_pipe[fl.k], fl.ps, c->ev_tile[fl.k]);
-            if (e != hipSuccess) break;
+            if (e != hipSuccess) {
+                // (the turn counters have advanced and part of the frame may be on the frame stream: the set's event is recorded behind
+                //  whatever got there, so that the next lease of this set waits for it like for any other frame)
+                (void)hipGetLastError();
+                (void)lease_done(c, fl, st, false);
+                break;
+            }
             if (int r = lease_done(c, fl, st, true)) return r;       // (ev_tile is the tile kernel's own completion signal)
             mi355i_prof_lap(5);
             e = mi355i_launch_frame_copy(P.out, Q.out, P.W, P.out_rows, P.pitch_words, st, c->ev_copy[fl.b]);
@@ -290,6 +309,7 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
     }
     case MI355_MODE_RAYTRACE: case MI355_MODE_RAYTRACE_ANTIALIAS: {
         if (!c->has_bvh) return fail(-41, "raytrace modes need mi355_scene_set_bvh first");
+        uint32_t *lean_mask = nullptr;
         int ordered = ((!stats || P.prof_ordered) && !P.ref_order && c->dev.ordered_ok) ? 1 : 0;
         // More waves per SIMD pay when the launch is long enough to be throughput bound (batches, 4K, 4 spp: three waves
         // +10-18 %, four another +6 %); a single 1080p frame is bound by its slowest tiles and runs fastest with two
@@ -340,8 +360,15 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
             P.tile_sel = (const uint32_t *)((char *)buf->p + 512);
             // (the background of the tiles that are not traced: written by the selection kernel before anything is traced -- or, P.fill_first
             //  set: a frame that crosses PCIe as it is written, by waves of the tracing kernel while the others trace)
-            uint32_t *gmask = P.fill_first > 0 ? (uint32_t *)((char *)buf->p + 512 + list_bytes) : nullptr;
-            P.tile_mask = gmask;
+            uint32_t *gmask = (P.fill_first > 0 || lean) ? (uint32_t *)((char *)buf->p + 512 + list_bytes) : nullptr;
+            P.tile_mask = lean ? nullptr : gmask;
+            if (lean) {
+                // (no fallback from here: the control block is this kernel's to clear)
+                if ((e = mi355i_launch_tile_select_lean(&P, (const float4 *)c->cull_boxes.p, c->n_cull_boxes, P.tile_order, (uint32_t *)((char *)buf->p + 512),
+                                                        (uint32_t *)buf->p, gmask, host_cams, (FrameCam *)P.cams, st)) != hipSuccess)
+                    return fail(-43, "kernel launch failed: %s", hipGetErrorString(e));
+                lean_mask = gmask;
+            } else
             if ((e = mi355i_launch_tile_select(&P, (const float4 *)c->cull_boxes.p, c->n_cull_boxes, P.tile_order, (uint32_t *)((char *)buf->p + 512),
                                                (uint32_t *)buf->p, gmask, st)) != hipSuccess) {
                 // (the selection could not be launched: the frame is traced without it -- every tile handed out, same pixels)
@@ -349,7 +376,10 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
                 P.tile_cnt = nullptr; P.tile_sel = nullptr; P.tile_mask = nullptr;
             }
         }
+        if (lean && !lean_mask) return fail(-43, "internal: a launch prepared for k_tile_select_lean cannot be culled");
         e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, waves, batch, ext, stack_rows, n_blocks, st);
+        // (the background of the tiles that were not traced, behind the tracing kernel: other pixels, any order)
+        if (e == hipSuccess && lean_mask) e = mi355i_launch_tile_background(&P, lean_mask, st);
         break;
     }
     case MI355_MODE_LINES:
@@ -434,6 +464,7 @@ mi355_ctx *mi355_scene_create(const mi355_scene_desc *d, int device)
     mi355_ctx *c = new mi355_ctx;
     c->device = device;
     device_use(device, +1);
+    { std::lock_guard<std::mutex> lk(g_dev_mu); g_ctx_list.push_back(c); }
     auto bail = [&](const char *what, hipError_t e) { fail(-4, "%s: %s", what, hipGetErrorString(e)); mi355_scene_destroy(c); return (mi355_ctx *)nullptr; };
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return bail("hipSetDevice", e);
@@ -480,7 +511,8 @@ mi355_ctx *mi355_scene_create(const mi355_scene_desc *d, int device)
     // kernel (if any of this fails the frames simply are not overlapped)
     c->rs_pipe[0] = c->rscratch;
     for (int k = 1; k < mi355_ctx::PIPE_SETS; k++) c->rs_pipe[k] = mi355i_raster_scratch_create();
-    c->pre = c->rs_pipe[1] && c->rs_pipe[2] && c->rs_pipe[3];
+    c->pre = true;
+    for (int k = 1; k < mi355_ctx::PIPE_SETS; k++) c->pre = c->pre && c->rs_pipe[k] != nullptr;      // (pipe_streams_for may pick any of the sets)
     for (int k = 0; c->pre && k < mi355_ctx::PIPE_SETS; k++) c->pre = hipEventCreateWithFlags(&c->ev_tile[k], hipEventDisableTiming) == hipSuccess;
     if (c->pre) {
         // the frames' own streams have a priority of their own: the runtime hands out hardware queues per priority, and a
@@ -504,6 +536,7 @@ void mi355_scene_destroy(mi355_ctx *c)
 {
     if (!c) return;
     device_use(c->device, -1);
+    { std::lock_guard<std::mutex> lk(g_dev_mu); for (size_t i = 0; i < g_ctx_list.size(); i++) if (g_ctx_list[i] == c) { g_ctx_list.erase(g_ctx_list.begin() + (long)i); break; } }
     (void)hipSetDevice(c->device);
     // (nothing of this context may be in flight on any stream -- its own, the internal frame streams, a caller's -- while its
     //  buffers go away)
@@ -723,15 +756,18 @@ int mi355_render_batch_device(mi355_ctx *c, int mode, int n_frames, const mi355_
             HIP_TRY(c->pipe_ctrl[k].ensure(MI_CTRL_BYTES), -31);
             HIP_TRY(c->pipe_cam[k].ensure(sizeof tab), -31);
             for (int f = 0; f < n_frames; f++) tab[f].out = fl.fb + (size_t)f * frame_words;
-            HIP_TRY(hipMemcpyAsync(c->pipe_cam[k].p, tab, sizeof(FrameCam) * (size_t)n_frames, hipMemcpyHostToDevice, fl.ps), -31);
+            static const bool no_lean = getenv("MI355_NO_LEAN_PREP") != nullptr;          // (measurement: round 5's copy + memset + selection kernel)
+            const bool lean = n_frames <= MI_LEAN_FRAMES && !no_lean;
+            if (!lean) HIP_TRY(hipMemcpyAsync(c->pipe_cam[k].p, tab, sizeof(FrameCam) * (size_t)n_frames, hipMemcpyHostToDevice, fl.ps), -31);
             FrameParams Q = P;
+            Q.lean_prep = lean ? 1 : 0;
             Q.cams = (const FrameCam *)c->pipe_cam[k].p;
             Q.n_frames = n_frames;
             Q.out = fl.fb;
             Q.work_counter = (uint32_t *)((char *)c->pipe_ctrl[k].p + MI_CTRL_DISPENSER_OFF);
             Q.fill_counter = (uint32_t *)((char *)c->pipe_ctrl[k].p + MI_CTRL_FILL_OFF);
             Q.counters = (unsigned long long *)((char *)c->pipe_ctrl[k].p + 16);
-            if (int r = enqueue_frame(c, mode, Q, 0, fl.ps, c->pipe_ctrl[k].p, nullptr, nullptr, nullptr, &c->pipe_sel[k])) return r;
+            if (int r = enqueue_frame(c, mode, Q, 0, fl.ps, c->pipe_ctrl[k].p, nullptr, nullptr, nullptr, &c->pipe_sel[k], lean ? tab : nullptr)) return r;
             if (int r = lease_done(c, fl, st, false)) return r;
             hipError_t ce = mi355i_launch_frames_copy(d_out, n_frames, fl.fb, P.W, P.out_rows, P.pitch_words, st, c->ev_copy[fl.b]);
             if (ce != hipSuccess) return fail(-43, "kernel launch failed: %s", hipGetErrorString(ce));
@@ -794,20 +830,36 @@ void *mi355_host_alloc(size_t bytes)
 void mi355_host_free(void *p)
 {
     if (!p) return;
+    size_t bytes = 0;
     {
         std::lock_guard<std::mutex> lk(g_host_alloc_mu);
         for (size_t i = 0; i < g_host_alloc.size(); i++)
-            if (g_host_alloc[i].first == (char *)p) { g_host_alloc.erase(g_host_alloc.begin() + (long)i); break; }
+            if (g_host_alloc[i].first == (char *)p) { bytes = g_host_alloc[i].second; g_host_alloc.erase(g_host_alloc.begin() + (long)i); break; }
     }
-    {   // (no copy or kernel may still target it: the current device's and those of the devices that hold contexts)
+    // No copy or kernel may still target the buffer.  What can be on its way into caller's host memory when a call has returned: the
+    // frames of mi355_render_async that have not been waited for (mi355_render itself returns when its frame is there).  So: the
+    // streams of exactly those slots, in whatever context they are -- not every queue of every device that holds a context (round 5:
+    // a hipDeviceSynchronize per device, from every Screen destructor).  A pointer this library did not hand out is released the
+    // careful way.
+    {
         int cur = 0;
-        if (hipGetDevice(&cur) == hipSuccess) {
-            (void)hipDeviceSynchronize();
+        const bool have_dev = hipGetDevice(&cur) == hipSuccess;
+        std::vector<std::pair<int, hipStream_t>> waits;
+        bool known = bytes != 0;
+        {
+            std::lock_guard<std::mutex> lk(g_dev_mu);
+            for (mi355_ctx *c : g_ctx_list)
+                for (auto &a : c->slot)
+                    if (a.busy && a.st && !a.staged && (!known || ((const char *)a.user >= (const char *)p && (const char *)a.user < (const char *)p + bytes)))
+                        waits.emplace_back(c->device, a.st);
+        }
+        for (auto &w : waits) if (hipSetDevice(w.first) == hipSuccess) (void)hipStreamSynchronize(w.second);
+        if (!known && have_dev) {
             bool used[64];
             { std::lock_guard<std::mutex> lk(g_dev_mu); for (int d = 0; d < 64; d++) used[d] = g_dev_use[d] > 0; }
-            for (int d = 0; d < 64; d++) if (used[d] && d != cur && hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
-            (void)hipSetDevice(cur);
+            for (int d = 0; d < 64; d++) if (used[d] && hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
         }
+        if (have_dev) (void)hipSetDevice(cur);
         (void)hipGetLastError();
     }
     host_trace("host_free %p", p);

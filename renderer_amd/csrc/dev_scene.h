@@ -36,6 +36,7 @@
 
 #define MI_MAX_LIGHTS 4
 #define MI_MAX_DEPTH 4
+#define MI_LEAN_FRAMES 16           // frames per launch whose camera table rides in k_tile_select_lean's arguments
 #define MI_CULL_BOXES 128           // boxes of the tree's top the tiles of a frame are culled against
 #define MI_CULL_MAX_TILES (1 << 18) // frames with more 8x8 tiles are not culled (the tile mask lives in LDS: 32 KB here, beside 2 KB of static LDS -- inside the 64 KB a block gets without asking)
 
@@ -147,13 +148,16 @@ struct FrameParams {
     int32_t ao, ao_samples;    // AMBIENT_OCCLUSION, AMBIENT_SAMPLES
     float ao_range;            // AMBIENT_RANGE
     int32_t mlaa;              // MLAA post filter on the finished frame
+    int32_t lean_prep;         // the launch was prepared by k_tile_select_lean (the tracing kernel adds the culled tiles' camera rays to the counters)
 };
 
 enum CounterSlot {
     CS_NORMAL_RAYS = 0, CS_SHADOW_RAYS, CS_NODE_POPS, CS_INNER_HITS, CS_TRI_TESTS, CS_PLANE_PASS,
     CS_SHADED_HITS, CS_TRIS_DRAWN, CS_SPANS, CS_ZTESTS, CS_PLOTS, CS_OVERFLOW,
     CS_PROF0, CS_TIME0 = CS_PROF0 + 16,   // phase profile + time stamps (counting builds only)
-    CS_CULLED_RAYS = CS_TIME0 + 4,       // camera rays of the tiles k_tile_select set to black without tracing them (they are part of CS_NORMAL_RAYS too)
+    CS_CULLED_RAYS = CS_TIME0 + 4,       // rays counted as the reference casts them but not traced, because their result cannot change a pixel: the camera rays of
+                                         // the tiles k_tile_select set to black (part of CS_NORMAL_RAYS too) and the shadow rays towards lights a hit faces away from
+                                         // (part of CS_SHADOW_RAYS too)
     CS_COUNT
 };
 

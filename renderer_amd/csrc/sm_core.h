@@ -139,36 +139,46 @@ MI_HD int sm_lists(int n_bands) { return n_bands + 1 + (n_bands + SMT_CB - 1) / 
 // ---- what k_sm_prep computes for one triangle, apart from entering it in lists --------------------------------------------------
 // false = the triangle plots nothing (rejected, or beside the map).  bb = (first row | last row << 16, first column | last column
 // << 16), rows = ~0 when it plots nothing; P = its record for the tiles (only when drawn).
-// Columns: every plotted x is a value of a serial chain between two of the corners' x (edges, then spans), so it lies in their range
-// widened by the chains' drift (<= one ulp of the largest |x| per addition, <= size additions per chain, two chains) and the pixel
-// it is truncated into.  Anything unordered or out of the integers' range: every column.
-MI_HD bool sm_prep_triangle(const DevScene &S, const ShadowParams &Q, uint32_t t, SmPrep &P, uint2 &bb)
+// Columns: every plotted x is a value of a serial float chain between two of the corners' x -- an edge walker (Light.cc:270-272: at most
+// `size` additions, the rows are cut to the map) and then the span's own `start += dLR` (Light.cc:286-292: |x2 - x1| additions, which
+// for corners anywhere in (-4 size, 4 size) is up to 8 size) --, so it lies in the corners' range widened by the chains' drift (<= one
+// ulp of the largest |x| per addition, <= 9 size + 8 additions in a row) and by the pixel it is truncated into.  Anything unordered
+// or beyond 4 size (chains too long for this bound): every column.
+MI_HD bool sm_prep_projected(const float (&f)[3][3], const int (&iy)[3], int size, SmPrep &P, uint2 &bb)
 {
     bb = make_uint2(0xffffffffu, 0u);
-    float f[3][3]; int iy[3], miny = 0, maxy = 0;
-    if (!(t < S.n_tris && sm_project(S, Q, t, f, iy) && rs_tri_rows(iy, Q.size, miny, maxy))) return false;
+    int miny = 0, maxy = 0;
+    if (!rs_tri_rows(iy, size, miny, maxy)) return false;
     const float xa = f[0][0], xb = f[1][0], xc = f[2][0];
     float lo = xa < xb ? xa : xb; lo = lo < xc ? lo : xc;
     float hi = xa > xb ? xa : xb; hi = hi > xc ? hi : xc;
     const float amax = __builtin_fmaxf(__builtin_fabsf(lo), __builtin_fabsf(hi));
-    const float drift = (float)(2 * Q.size + 8) * amax * 1.1920929e-07f + 2.0f;       // 2^-23 per addition
+    const float drift = (float)(9 * size + 8) * amax * 1.1920929e-07f + 2.0f;       // 2^-23 per addition
     lo -= drift; hi += drift;
-    int c0 = 0, c1 = Q.size - 1;
-    if (lo == lo && hi == hi && amax < 4.f * (float)Q.size) {       // (a triangle that reaches far beyond the map: chains too long for the bound)
-        if (hi < 0.f || lo > (float)(Q.size - 1)) c1 = -1;                             // beside the map
-        else { c0 = lo > 0.f ? (int)lo : 0; c1 = hi < (float)(Q.size - 1) ? (int)hi : Q.size - 1; }
+    int c0 = 0, c1 = size - 1;
+    if (lo == lo && hi == hi && amax < 4.f * (float)size) {
+        if (hi < 0.f || lo > (float)(size - 1)) c1 = -1;                               // beside the map
+        else { c0 = lo > 0.f ? (int)lo : 0; c1 = hi < (float)(size - 1) ? (int)hi : size - 1; }
     }
     if (c1 < c0) return false;
     bb = make_uint2((uint32_t)miny | ((uint32_t)maxy << 16), (uint32_t)c0 | ((uint32_t)c1 << 16));
 #pragma unroll
     for (int k = 0; k < 3; k++) { P.f[3 * k] = f[k][0]; P.f[3 * k + 1] = f[k][1]; P.f[3 * k + 2] = f[k][2]; P.iy[k] = iy[k]; }
     RsEdge<3> e0, e1, e2;                      // Light.cc:270-272: v1v2, v2v3, v1v3
-    rs_edge_init<3>(e0, iy[0], f[0], iy[1], f[1], Q.size);
-    rs_edge_init<3>(e1, iy[1], f[1], iy[2], f[2], Q.size);
-    rs_edge_init<3>(e2, iy[0], f[0], iy[2], f[2], Q.size);
+    rs_edge_init<3>(e0, iy[0], f[0], iy[1], f[1], size);
+    rs_edge_init<3>(e1, iy[1], f[1], iy[2], f[2], size);
+    rs_edge_init<3>(e2, iy[0], f[0], iy[2], f[2], size);
 #pragma unroll
     for (int i = 0; i < 3; i++) { P.d[i] = e0.d[i]; P.d[3 + i] = e1.d[i]; P.d[6 + i] = e2.d[i]; }
     return true;
+}
+
+MI_HD bool sm_prep_triangle(const DevScene &S, const ShadowParams &Q, uint32_t t, SmPrep &P, uint2 &bb)
+{
+    bb = make_uint2(0xffffffffu, 0u);
+    float f[3][3]; int iy[3];
+    if (!(t < S.n_tris && sm_project(S, Q, t, f, iy))) return false;
+    return sm_prep_projected(f, iy, Q.size, P, bb);
 }
 
 // the lists a drawn triangle with rows bb.x is entered in: b0 .. b1 (bands, or coarse bands when it crosses more than SMT_WIDE)

@@ -62,7 +62,10 @@ def main():
         size = lambda h: sum(len(b["ins"]) for b in members[h])
         for h, bl in members.items():
             ins_h = [x for b in bl for x in b["ins"]]
-            if sum("global_load_dwordx4" in x for x in ins_h) >= 4 and any("ds_write" in x for x in ins_h):
+            # (the walk loop: it requests wide records AND holds the work sharing's hand-over -- the ray through ~20 ds_bpermute; the loop
+            #  that tests the queued leaves also loads records and shuffles a ray, nine values of it)
+            walkish = sum("ds_bpermute" in x for x in ins_h) >= 15 or not any("ds_bpermute" in x for b2 in blocks for x in b2["ins"])
+            if sum("global_load_dwordx4" in x for x in ins_h) >= 4 and any("ds_write" in x for x in ins_h) and walkish:
                 if best is None or size(h) < size(best): best = h
         if not best: continue
         # blocks the compiler laid out behind the loop's back edge are its cold paths (the exact box tests)

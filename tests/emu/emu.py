@@ -91,3 +91,18 @@ def shadowmap(hs, light, size=1024, streams=None, items_per_tile=None):
     if rc != 0:
         raise RuntimeError("emu_shadowmap failed (%d)" % rc)
     return out, dict(drawn=st[0], list_entries=st[1], tile_entries=st[2], items=st[3], max_entries_per_tile=st[4], pixels=st[5])
+
+
+def shadow_column_bound(size, xspan, seed, n):
+    """tests/emu/libemu_shadow.so: random light-space triangles against the prep kernel's column range (emu_shadow_column_bound)."""
+    global _slib
+    if _slib is None:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        _slib = C.CDLL(os.path.join(_HERE, "libemu_shadow.so"))
+        _slib.emu_shadowmap.restype = C.c_int
+    out = (C.c_ulonglong * 5)()
+    _slib.emu_shadow_column_bound.restype = C.c_int
+    rc = _slib.emu_shadow_column_bound(C.c_int(size), C.c_float(xspan), C.c_uint32(seed), C.c_int(n), out)
+    if rc != 0:
+        raise RuntimeError("emu_shadow_column_bound failed (%d)" % rc)
+    return dict(drawn=out[0], narrowed=out[1], pixels=out[2], outside=out[3], longest_span=out[4])

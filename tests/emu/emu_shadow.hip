@@ -78,3 +78,42 @@ extern "C" int emu_shadowmap(uint32_t n_tris, uint32_t n_verts, const uint32_t *
     if (stats) memcpy(stats, st, sizeof st);
     return 0;
 }
+
+// ---- the column pre-filter's bound, by itself (sm_prep_projected) -------------------------------------------------------------------
+// n random triangles given in LIGHT SPACE (projected corners), their x anywhere in (-xspan * size, xspan * size) -- spans of up to
+// 2 * xspan * size serial additions --, rows inside and around the map.  For each: the column range c0 .. c1 the prep kernel would
+// store, and every pixel the (triangle, row) items plot over the WHOLE row (sm_tile_row from column 0 to size - 1: the exact values of
+// Light.cc's chains).  out[0] = triangles drawn, out[1] = of them with a range narrower than the map, out[2] = pixels plotted,
+// out[3] = pixels outside their triangle's range (must be 0), out[4] = longest span in pixels.
+extern "C" int emu_shadow_column_bound(int size, float xspan, uint32_t seed, int n, unsigned long long *out)
+{
+    if (size <= 0 || size > SMT_BANDS * SMT_H) return -1;
+    uint64_t s = seed * 0x9e3779b97f4a7c15ull + 0x632be59bd9b4e019ull;
+    const auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (double)(s >> 11) / 9007199254740992.0; };
+    unsigned long long st[5] = {0, 0, 0, 0, 0};
+    for (int t = 0; t < n; t++) {
+        float f[3][3]; int iy[3];
+        const double cy = rnd() * size, hy = 1.0 + rnd() * rnd() * size * 0.5;     // mostly a few rows, sometimes half the map
+        for (int k = 0; k < 3; k++) {
+            f[k][0] = (float)((2.0 * rnd() - 1.0) * xspan * size);
+            f[k][1] = (float)(cy + (2.0 * rnd() - 1.0) * hy);
+            f[k][2] = (float)(0.05 + rnd());
+            iy[k] = cvtt_i32(f[k][1]);
+        }
+        if (t % 7 == 0) f[1][0] = f[0][0];                                        // vertical edges, equal corners
+        if (t % 11 == 0) { f[2][1] = f[1][1]; iy[2] = iy[1]; }                    // a horizontal edge
+        SmPrep P; uint2 bb;
+        memset(&P, 0xcd, sizeof P);
+        if (!sm_prep_projected(f, iy, size, P, bb)) continue;
+        st[0]++;
+        const int c0 = (int)(bb.y & 0xffffu), c1 = (int)(bb.y >> 16);
+        if (c0 > 0 || c1 < size - 1) st[1]++;
+        for (int y = (int)(bb.x & 0xffffu); y <= (int)(bb.x >> 16); y++) {
+            int lo = size, hi = -1;
+            sm_tile_row(P, size, y, 0, size - 1, [&](int x, float) { st[2]++; if (x < c0 || x > c1) st[3]++; lo = x < lo ? x : lo; hi = x > hi ? x : hi; });
+            if (hi >= lo && (unsigned long long)(hi - lo + 1) > st[4]) st[4] = (unsigned long long)(hi - lo + 1);
+        }
+    }
+    memcpy(out, st, sizeof st);
+    return 0;
+}

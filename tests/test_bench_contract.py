@@ -44,13 +44,14 @@ def _line(name):
     return rows[-1]
 
 
-@pytest.mark.parametrize("name,n", [("r05_bench_dryrun_n2.jsonl", 2), ("r05_bench_dryrun_n8.jsonl", 8)])
+@pytest.mark.parametrize("name,n", [("r05_bench_dryrun_n2.jsonl", 2), ("r05_bench_dryrun_n8.jsonl", 8), ("r06_bench_dryrun_n2.jsonl", 2), ("r06_bench_dryrun_n8.jsonl", 8)])
 def test_the_dry_run_line_of_the_multi_gpu_path(name, n):
     """For every N the headline is the N = 1 workload -- dragon 1920x1080, 8 frames per GPU and step, bands over the GPUs, one exchange
     per step -- so that the driver's curve over N = 1, 2, 4, 8 compares like with like; BASELINE config 5
     (3840x2160) is a region of its own."""
     r = _line(name)
-    n1 = _line("r05_bench_n1.jsonl") if os.path.exists(os.path.join(ROOT, "profiles", "r05_bench_n1.jsonl")) else None
+    n1_name = name[:3] + "_bench_n1.jsonl"
+    n1 = _line(n1_name) if os.path.exists(os.path.join(ROOT, "profiles", n1_name)) else None
     assert r["n_gpus"] == n and r["dry_run"] is True and r["scaling"] == "weak"
     assert r["metric"] == "Mrays/sec" and r["unit"] == "Mrays/s" and r["value"] > 0 and r["higher_is_better"] is True
     assert "1920x1080" in r["config"]["workload"] and "dragon_vis.ply" in r["config"]["workload"]
@@ -75,6 +76,22 @@ def test_the_dry_run_line_of_the_multi_gpu_path(name, n):
     c5 = mg["config5"]
     assert "3840x2160" in c5["workload"] and c5["Mrays_per_s"] > 0 and c5["assembly"] in ("rank0", "spread")
     assert mg["whole_frames_no_exchange"]["frames_per_sec"] > 0
+    if name.startswith("r06"):
+        # round 6: the N > 1 line checks its own pictures -- every assembly that was timed hashes orbit frames f0 / f37 / f100 / f150 of the
+        # assembled 1080p frames (and f37 / f100 of config 5's 3840x2160) against the reference's pins where they end up, the rasterizer
+        # has a region of its own (chessboard, Phong and soft shadows, bands over the ranks, hashed against BASELINE config 2's pins),
+        # and `value` is only printed because all of them agree
+        sha = mg["assembled_sha"]
+        assert mg["assembled_sha_ok"] is True and sha["pinned_frames"] == [0, 37, 100, 150]
+        for kind in ("rank0", "spread"):
+            assert sha[kind] == {"checked": 4, "differ": 0}
+        assert sha["config5"]["checked"] == 2 and sha["config5"]["differ"] == 0 and sha["config5"]["pinned_frames"] == [37, 100]
+        ras = mg["raster_1080p"]
+        assert ras["assembly"] in ("rank0", "spread") and "%d frames of 1920x1080" % min(64, 8 * n) in ras["step"]
+        for name_r, mode in (("phong", 6), ("softshadow", 8)):
+            rr = ras[name_r]
+            assert rr["mode"] == mode and rr["frames_per_sec"] > 0 and rr["assembled_sha"] == {"checked": 1, "differ": 0, "pinned_frames": [0]}
+        assert mg["assembled_sha_checked"] == 4 + 4 + 2 + 1 + 1 and "invalid" not in r
 
 
 def test_the_committed_single_gpu_line_keeps_the_measurement_contract():

@@ -154,3 +154,41 @@ def test_frames_written_in_place_at_odd_sizes_pitches_and_cameras(seed):
             assert (canvas == 0x00abcdef).all(), "seed %d trial %d: pixels outside the window were written" % (seed, trial)
     finally:
         R.host_array_free(canvas)
+
+
+def test_host_array_free_takes_views_and_waits_only_for_frames_into_that_buffer():
+    """host_array_free finds the allocation by address: a slice, a reshape or another dtype of the array releases it; an array that
+    is not frame memory (or one that was released already) is a ValueError.  Releasing one buffer while a pipelined frame is on its
+    way into ANOTHER one waits for nothing that is not its own (mi355_host_free looks at the frames in flight, not at whole devices):
+    the other frame is complete and correct afterwards."""
+    W, H = 320, 200
+    a = R.host_array((H, W))
+    view = a[7:, 5:].view(np.int32)
+    R.host_array_free(view)
+    with pytest.raises(ValueError):
+        R.host_array_free(a)                       # released already
+    with pytest.raises(ValueError):
+        R.host_array_free(np.zeros((4, 4), np.uint32))
+    s = R.Scene(R.assets.mesh_path("dragon_vis.ply"))
+    s.bvh_create()
+    cam, lights, n = R.benchmark_frame(11)
+    o = R.default_opts(W, H)
+    want = s.render(9, cam, lights, n, o)[0]
+    keep, spare = R.host_array((H, W)), R.host_array((H, W))
+    try:
+        for _ in range(5):
+            t = s.render_async(9, cam, lights, n, o, keep)
+            R.host_array_free(spare)               # (a frame is in flight -- into `keep`)
+            spare = R.host_array((H, W))
+            s.render_wait(t)
+            assert np.array_equal(keep, want)
+            keep[:] = 0
+        # ... and releasing the target itself while its frame is in flight waits for that frame (no write after free)
+        t = s.render_async(9, cam, lights, n, o, keep)
+        R.host_array_free(keep)
+        keep = None
+        s.render_wait(t)
+    finally:
+        if keep is not None:
+            R.host_array_free(keep)
+        R.host_array_free(spare)

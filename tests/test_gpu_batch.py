@@ -106,6 +106,28 @@ def test_batch_with_band_sharding(dragon):
         assert np.array_equal(got, full[j].cpu().numpy())
 
 
+@pytest.mark.parametrize("mode", [6, 8])
+def test_raster_batch_with_band_sharding(mode):
+    """What bench.py --gpus N times for the rasterizer (multi_gpu.raster_1080p): every rank rasterizes its interleaved bands of all
+    frames of a step in one batched launch into compact buffers; assembled, they are the frames a single device draws."""
+    from renderer_amd import multigpu
+    s = R.Scene(R.assets.mesh_path("chessboard.tri"))
+    s.shadowmap_render(0, R.benchmark_frame(0)[1][0])
+    W, H = 642, 363                                    # 46 bands: the ranks own different numbers of rows, the last band is short
+    frames = [0, 37, 100, 150, 199]
+    full, _, _ = render_batch(s, mode, frames, R.default_opts(W, H), W, H)
+    for world in (2, 3):
+        parts = []
+        for rank in range(world):
+            o = R.default_opts(W, H, band_rows=multigpu.BAND_ROWS, band_index=rank, band_count=world, compact_rows=1)
+            b, _, _ = render_batch(s, mode, frames, o, W, H)
+            rows = multigpu.rows_of_rank(H, multigpu.BAND_ROWS, world, rank)
+            parts.append([x.cpu().numpy()[:rows] for x in b])
+        for j in range(len(frames)):
+            got = multigpu.assemble_numpy([parts[r][j] for r in range(world)], H, multigpu.BAND_ROWS)
+            assert np.array_equal(got, full[j].cpu().numpy()), "mode %d, %d ranks, frame %d" % (mode, world, frames[j])
+
+
 def test_batch_argument_errors(dragon):
     W, H = 64, 48
     dev = torch.device("cuda", 0)

@@ -119,3 +119,18 @@ def test_a_triangle_is_entered_in_bands_or_in_coarse_bands(oracle, scenes):
     m, om, st = both(oracle, hs, osc, streams, (3.394, 3.394, 4.8), 1024)
     assert st["list_entries"] < 4 * st["drawn"]
     assert st["max_entries_per_tile"] < st["drawn"] // 8
+
+
+@pytest.mark.parametrize("size,xspan,n", [(8192, 3.99, 300), (1024, 3.99, 2000), (8192, 1.5, 200), (37, 3.9, 6000)])
+def test_every_plotted_column_lies_in_the_prep_kernels_range(size, xspan, n):
+    """The column pre-filter (sm_prep_projected): triangles given in light space with corners anywhere in (-4 size, 4 size) -- spans
+    of up to 8 size serial additions, Light.cc:286-292 -- plot no pixel outside the range c0 .. c1 the prep kernel stores for them,
+    and the test is not vacuous: many ranges are narrower than the map, and the spans are as long as the map is wide."""
+    tot = dict(drawn=0, narrowed=0, pixels=0, outside=0, longest_span=0)
+    for seed in (1, 2):
+        r = emu.shadow_column_bound(size, xspan, seed, n)
+        for k in tot:
+            tot[k] = max(tot[k], r[k]) if k == "longest_span" else tot[k] + r[k]
+    assert tot["outside"] == 0, tot
+    assert tot["drawn"] > n and tot["narrowed"] > tot["drawn"] // 8 and tot["pixels"] > 100 * n, tot
+    assert tot["longest_span"] >= size - 1, tot
