@@ -805,9 +805,10 @@ def main():
                        "rays_per_frame": round(total_rays / (K * B), 1),
                        "traced_rays_per_frame": round((total_rays - total_culled) / (K * B), 1),
                        "rays_note": "rays_per_frame counts BVH_IntersectTriangles calls as the reference makes them (SURVEY 8d: a camera ray that misses "
-                                    "everything counts, and the CPU baseline counts the same rays); traced_rays_per_frame leaves out the camera rays of "
-                                    "8x8 tiles whose rays cannot reach any box of the tree's top -- the launch sets those pixels to black without "
-                                    "generating a ray (k_tile_select)",
+                                    "everything counts, and the CPU baseline counts the same rays); traced_rays_per_frame leaves out the rays whose result "
+                                    "cannot change a pixel and which the launch therefore does not walk: the camera rays of 8x8 tiles whose rays cannot reach "
+                                    "any box of the tree's top (k_tile_select sets those pixels to black) and, since round 6, the shadow rays towards a light "
+                                    "the hit faces away from (Raytracer.cc:472-475: `intensity < 0` adds nothing whether or not the ray is blocked)",
                        "tune": json.loads(args.tune)},
             "frames_per_sec": round(K * B / dt, 3),
             "traced_Mrays_per_s": round((total_rays - total_culled) / dt / 1e6, 3),

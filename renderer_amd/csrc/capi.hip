@@ -172,11 +172,8 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
 }
 
 
-// host_cams (with P.lean_prep): the cameras of a batched launch as the caller's table on the host -- the launch is prepared by ONE small
-// kernel (k_tile_select_lean: camera table from its arguments, control block cleared by it) instead of a copy, a memset and a selection
-// kernel that each wait for free wave slots behind the previous launch; where the frame cannot be culled it falls back to those.
 int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hipStream_t st, void *ctrl = nullptr, RasterScratch *rs = nullptr,
-                  DevBuf *mlaa_scratch = nullptr, uint32_t *const *frame_outs = nullptr, DevBuf *sel = nullptr, const FrameCam *host_cams = nullptr)
+                  DevBuf *mlaa_scratch = nullptr, uint32_t *const *frame_outs = nullptr, DevBuf *sel = nullptr)
 {
     FrameParams P = P_in;
     const bool own_ctrl = ctrl != nullptr;
@@ -251,16 +248,7 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
     }
     // (a raster frame that does not count zeroes its control block in its first kernel: one launch less per frame, ~4.7 us)
     const bool raster_self_clear = mode >= MI355_MODE_AMBIENT && mode <= MI355_MODE_PHONG_SOFTSHADOWMAPS && !stats && !P.cams;
-    // (a batched raytrace launch prepared by k_tile_select_lean: that kernel clears the control block and carries the cameras)
-    const long long n_tiles_all = (((long long)P.W + 7) / 8) * (((long long)P.n_rows + 7) / 8);
-    const bool lean = rt && P.lean_prep && host_cams && P.cams && P.n_frames >= 1 && P.n_frames <= MI_LEAN_FRAMES && !stats && !P.outf && c->has_bvh && c->dev.ordered_ok &&
-                      !P.ref_order && !P.exact_box && !P.use_refr && !P.ao && (P.band_count <= 1 || (P.band_rows > 0 && P.band_rows % 8 == 0)) && c->n_cull_boxes > 0 && !P.no_cull &&
-                      n_tiles_all <= MI_CULL_MAX_TILES && P.fill_first <= 0;
-    if (P.lean_prep && !lean) {
-        if (host_cams && P.cams) HIP_TRY(hipMemcpyAsync((void *)P.cams, host_cams, sizeof(FrameCam) * (size_t)P.n_frames, hipMemcpyHostToDevice, st), -31);
-        P.lean_prep = 0;
-    }
-    if (!raster_self_clear && !lean) HIP_TRY(hipMemsetAsync(ctrl, 0, rt ? MI_CTRL_BYTES : 16 + sizeof(unsigned long long) * CS_COUNT, st), -40);
+    if (!raster_self_clear) HIP_TRY(hipMemsetAsync(ctrl, 0, rt ? MI_CTRL_BYTES : 16 + sizeof(unsigned long long) * CS_COUNT, st), -40);
     if (stats)   // the two "min" time stamps start at all-ones
         HIP_TRY(hipMemsetAsync((char *)ctrl + 16 + sizeof(unsigned long long) * CS_TIME0, 0xff, 2 * sizeof(unsigned long long), st), -40);
     c->last_stats = stats != 0;
@@ -309,7 +297,6 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
     }
     case MI355_MODE_RAYTRACE: case MI355_MODE_RAYTRACE_ANTIALIAS: {
         if (!c->has_bvh) return fail(-41, "raytrace modes need mi355_scene_set_bvh first");
-        uint32_t *lean_mask = nullptr;
         int ordered = ((!stats || P.prof_ordered) && !P.ref_order && c->dev.ordered_ok) ? 1 : 0;
         // More waves per SIMD pay when the launch is long enough to be throughput bound (batches, 4K, 4 spp: three waves
         // +10-18 %, four another +6 %); a single 1080p frame is bound by its slowest tiles and runs fastest with two
@@ -360,15 +347,8 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
             P.tile_sel = (const uint32_t *)((char *)buf->p + 512);
             // (the background of the tiles that are not traced: written by the selection kernel before anything is traced -- or, P.fill_first
             //  set: a frame that crosses PCIe as it is written, by waves of the tracing kernel while the others trace)
-            uint32_t *gmask = (P.fill_first > 0 || lean) ? (uint32_t *)((char *)buf->p + 512 + list_bytes) : nullptr;
-            P.tile_mask = lean ? nullptr : gmask;
-            if (lean) {
-                // (no fallback from here: the control block is this kernel's to clear)
-                if ((e = mi355i_launch_tile_select_lean(&P, (const float4 *)c->cull_boxes.p, c->n_cull_boxes, P.tile_order, (uint32_t *)((char *)buf->p + 512),
-                                                        (uint32_t *)buf->p, gmask, host_cams, (FrameCam *)P.cams, st)) != hipSuccess)
-                    return fail(-43, "kernel launch failed: %s", hipGetErrorString(e));
-                lean_mask = gmask;
-            } else
+            uint32_t *gmask = P.fill_first > 0 ? (uint32_t *)((char *)buf->p + 512 + list_bytes) : nullptr;
+            P.tile_mask = gmask;
             if ((e = mi355i_launch_tile_select(&P, (const float4 *)c->cull_boxes.p, c->n_cull_boxes, P.tile_order, (uint32_t *)((char *)buf->p + 512),
                                                (uint32_t *)buf->p, gmask, st)) != hipSuccess) {
                 // (the selection could not be launched: the frame is traced without it -- every tile handed out, same pixels)
@@ -376,10 +356,7 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
                 P.tile_cnt = nullptr; P.tile_sel = nullptr; P.tile_mask = nullptr;
             }
         }
-        if (lean && !lean_mask) return fail(-43, "internal: a launch prepared for k_tile_select_lean cannot be culled");
         e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, waves, batch, ext, stack_rows, n_blocks, st);
-        // (the background of the tiles that were not traced, behind the tracing kernel: other pixels, any order)
-        if (e == hipSuccess && lean_mask) e = mi355i_launch_tile_background(&P, lean_mask, st);
         break;
     }
     case MI355_MODE_LINES:
@@ -756,18 +733,15 @@ int mi355_render_batch_device(mi355_ctx *c, int mode, int n_frames, const mi355_
             HIP_TRY(c->pipe_ctrl[k].ensure(MI_CTRL_BYTES), -31);
             HIP_TRY(c->pipe_cam[k].ensure(sizeof tab), -31);
             for (int f = 0; f < n_frames; f++) tab[f].out = fl.fb + (size_t)f * frame_words;
-            static const bool no_lean = getenv("MI355_NO_LEAN_PREP") != nullptr;          // (measurement: round 5's copy + memset + selection kernel)
-            const bool lean = n_frames <= MI_LEAN_FRAMES && !no_lean;
-            if (!lean) HIP_TRY(hipMemcpyAsync(c->pipe_cam[k].p, tab, sizeof(FrameCam) * (size_t)n_frames, hipMemcpyHostToDevice, fl.ps), -31);
+            HIP_TRY(hipMemcpyAsync(c->pipe_cam[k].p, tab, sizeof(FrameCam) * (size_t)n_frames, hipMemcpyHostToDevice, fl.ps), -31);
             FrameParams Q = P;
-            Q.lean_prep = lean ? 1 : 0;
             Q.cams = (const FrameCam *)c->pipe_cam[k].p;
             Q.n_frames = n_frames;
             Q.out = fl.fb;
             Q.work_counter = (uint32_t *)((char *)c->pipe_ctrl[k].p + MI_CTRL_DISPENSER_OFF);
             Q.fill_counter = (uint32_t *)((char *)c->pipe_ctrl[k].p + MI_CTRL_FILL_OFF);
             Q.counters = (unsigned long long *)((char *)c->pipe_ctrl[k].p + 16);
-            if (int r = enqueue_frame(c, mode, Q, 0, fl.ps, c->pipe_ctrl[k].p, nullptr, nullptr, nullptr, &c->pipe_sel[k], lean ? tab : nullptr)) return r;
+            if (int r = enqueue_frame(c, mode, Q, 0, fl.ps, c->pipe_ctrl[k].p, nullptr, nullptr, nullptr, &c->pipe_sel[k])) return r;
             if (int r = lease_done(c, fl, st, false)) return r;
             hipError_t ce = mi355i_launch_frames_copy(d_out, n_frames, fl.fb, P.W, P.out_rows, P.pitch_words, st, c->ev_copy[fl.b]);
             if (ce != hipSuccess) return fail(-43, "kernel launch failed: %s", hipGetErrorString(ce));

@@ -30,9 +30,6 @@ extern "C" hipError_t mi355i_launch_tile_select(const FrameParams *P, const floa
                                                 uint32_t *gmask, hipStream_t st);
 extern "C" int mi355i_raytrace_waves_per_cu(int stats, int exact, int ordered, int waves, int batch, int stack_depth, int ext);
 extern "C" void mi355i_raytrace_variant(int stats, int *exact, int *ordered, int *waves, int ext, int batch);
-extern "C" hipError_t mi355i_launch_tile_select_lean(const FrameParams *P, const float4 *boxes, int n_boxes, const uint32_t *order, uint32_t *sel, uint32_t *cnt,
-                                                     uint32_t *gmask, const FrameCam *host_cams, FrameCam *cams_dst, hipStream_t st);
-extern "C" hipError_t mi355i_launch_tile_background(const FrameParams *P, const uint32_t *gmask, hipStream_t st);
 extern "C" hipError_t mi355i_launch_raytrace(const DevScene *, const FrameParams *, int stats, int exact, int ordered, int waves, int batch, int ext,
                                              int stack_depth, int n_blocks, hipStream_t);
 extern "C" hipError_t mi355i_launch_points(const DevScene *, const FrameParams *, int as_triangles, hipStream_t);

@@ -36,7 +36,6 @@
 
 #define MI_MAX_LIGHTS 4
 #define MI_MAX_DEPTH 4
-#define MI_LEAN_FRAMES 16           // frames per launch whose camera table rides in k_tile_select_lean's arguments
 #define MI_CULL_BOXES 128           // boxes of the tree's top the tiles of a frame are culled against
 #define MI_CULL_MAX_TILES (1 << 18) // frames with more 8x8 tiles are not culled (the tile mask lives in LDS: 32 KB here, beside 2 KB of static LDS -- inside the 64 KB a block gets without asking)
 
@@ -148,7 +147,6 @@ struct FrameParams {
     int32_t ao, ao_samples;    // AMBIENT_OCCLUSION, AMBIENT_SAMPLES
     float ao_range;            // AMBIENT_RANGE
     int32_t mlaa;              // MLAA post filter on the finished frame
-    int32_t lean_prep;         // the launch was prepared by k_tile_select_lean (the tracing kernel adds the culled tiles' camera rays to the counters)
 };
 
 enum CounterSlot {

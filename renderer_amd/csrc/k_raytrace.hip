@@ -946,13 +946,13 @@ k_raytrace(const DevScene S, const FrameParams P)
                         f3 ptl = sub3(L.lp, L.hit);
                         float distSq = lensq3(ptl);
                         L.d = div3(ptl, __builtin_sqrtf(distSq));
-                        if constexpr (SKIP_DARK) {
-                            // A light the surface faces away from adds nothing whether or not something lies in between (Raytracer.cc:472-475:
-                            // `intensity < 0.` leaves dColor black), so its shadow ray decides nothing: it is COUNTED as the reference casts it
-                            // and not traced.  The test is the reference's own: pointToLight.normalize() is the shadow ray's direction, operation
-                            // for operation (norm3 = div3 by the root of lensq3), so dot3(L.pn, L.d) is the `intensity` add_light would compute.
-                            if (dot3(L.pn, L.d) < 0.f) { n_shadow++; n_skip++; L.li++; continue; }
-                        }
+                        // A light the surface faces away from adds nothing whether or not something lies in between (Raytracer.cc:472-475:
+                        // `intensity < 0.` leaves dColor black), so its shadow ray decides nothing: it is COUNTED as the reference casts it and
+                        // not traced -- the lane gets a ray that has ended already and counts as blocked, and helps with the other lanes' rays
+                        // until the tile's next transition (the generations of a tile stay in step).  The test is the reference's own:
+                        // pointToLight.normalize() is the shadow ray's direction operation for operation (norm3 = div3 by the root of lensq3),
+                        // so dot3(L.pn, L.d) is the `intensity` add_light would compute.
+                        const bool dark = SKIP_DARK && dot3(L.pn, L.d) < 0.f;
                         L.o = L.hit;
                         set_ray_aux(L, S.scene_mag);
                         L.best = distsq3(L.o, L.lp);            // Raytracer.cc:209
@@ -960,12 +960,14 @@ k_raytrace(const DevScene S, const FrameParams P)
                         // parameter below twice the light's distance
                         L.cull = cull_from(2.f * __builtin_sqrtf(L.best) * 1.001f + ray_delta(L.o, S.scene_mag), L.dmax2);
                         L.mode = MODE_SHADOW;
-                        L.shadow_hit = false;
+                        L.shadow_hit = dark;
                         if constexpr (STEAL) {
-                            result[threadIdx.x] = result_key(FLT_MAX, L.btri); L.owner = (int)threadIdx.x;
+                            // (upper half 0 = blocked; the lower half keeps the triangle the ray starts on)
+                            result[threadIdx.x] = dark ? (unsigned long long)(uint32_t)L.btri : result_key(FLT_MAX, L.btri); L.owner = (int)threadIdx.x;
                             lds_lp[threadIdx.x] = L.lp.x; lds_lp[RT_BLK + threadIdx.x] = L.lp.y; lds_lp[2 * RT_BLK + threadIdx.x] = L.lp.z;
                         }
                         begin_walk<ORDERED>(S, L, R, R2, !BATCH && !STATS);
+                        if (dark) { L.cur = MI_END_LINK; n_skip++; }
                         L.avoid = L.btri;                       // avoidSelf = the triangle just hit (Raytracer.cc:335)
                         n_shadow++;
                         launched = true;
@@ -1144,7 +1146,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         L.cur = vgive;
                         const float4 *p = S.walk + (size_t)(vgive & MI_INDEX_MASK);
                         R.a = p[0]; R.b = p[1]; R2.a = p[2]; R2.b = p[3];
-                        n_steal++;
+                        if (RT_COUNT) n_steal++;
                         took = true;
                     }
                     if (robbed) {
@@ -1281,7 +1283,7 @@ k_raytrace(const DevScene S, const FrameParams P)
                         const float4 *p = S.walk + (size_t)(vgive & MI_INDEX_MASK);
                         R.a = p[0]; R.b = p[1];
                         if ((vgive & MI_LEAF_BIT) == 0) { R2.a = p[2]; R2.b = p[3]; }
-                        n_steal++;
+                        if (RT_COUNT) n_steal++;
                         took = true;
                         seen = MI_RESULT_NONE;           // (the word read above was the one of the ray this lane walked before)
                     }
@@ -1681,17 +1683,10 @@ k_raytrace(const DevScene S, const FrameParams P)
         };
         const unsigned long long a = wsum(n_normal), b = wsum(n_shadow);
         const bool lead = (threadIdx.x & 63u) == 0;
-        if (P.lean_prep && P.tile_cnt && blockIdx.x == 0 && lead) {
-            // (k_tile_select_lean left the camera rays of the tiles it culled in cnt[64 + f]: it must not touch the counters itself)
-            unsigned long long px = 0;
-            for (int f = 0; f < (BATCH ? P.n_frames : 1); f++) px += P.tile_cnt[64 + f];
-            px *= P.aa ? 4ull : 1ull;
-            if (px) { atomicAdd(&P.counters[CS_NORMAL_RAYS], px); atomicAdd(&P.counters[CS_CULLED_RAYS], px); }
-        }
         if (lead) { atomicAdd(&P.counters[CS_NORMAL_RAYS], a); atomicAdd(&P.counters[CS_SHADOW_RAYS], b); }
         if constexpr (SKIP_DARK) { const unsigned long long sk = wsum(n_skip); if (lead && sk) atomicAdd(&P.counters[CS_CULLED_RAYS], sk); }
         if (RT_COUNT && lead) for (int i = 0; i < 20; i++) if (i < 11 || i == 13 || i == 14 || i == 15 || i >= 18) atomicAdd(&P.counters[CS_PROF0 + i], cq[i]);
-        if constexpr (STEAL) {      // (debug: subtrees handed from lane to lane, in a word the counting builds use for their profile)
+        if constexpr (STEAL && RT_COUNT) {      // (measuring variant: subtrees handed from lane to lane, in words the counting builds use for their profile)
             const unsigned long long ns = wsum(n_steal);
             if (lead && ns) { atomicAdd(&P.counters[CS_PROF0 + 12], ns); atomicAdd(&P.counters[CS_PROF0 + 11], (unsigned long long)n_event); }
         }
@@ -1860,160 +1855,6 @@ k_tile_select(const FrameParams P, const float4 *boxes, int n_boxes, const uint3
         }
     }
 }
-// ---- the same selection for launches that overlap on the frame streams (round 6) ------------------------------------------------
-// A launch of k_raytrace holds every wave slot of the chip until its waves run dry, so whatever has to run BEFORE the next launch
-// can start only when slots come free -- and k_tile_select's blocks of 1024 threads need sixteen free slots on ONE compute unit,
-// which a draining launch offers when half of its waves are gone (rocprofv3 time line, profiles/r06_analysis.md: copy of the camera
-// table 5 us + clear of the control block 5 us + selection 30-100 us, each waiting for the one before, began ~110 us before the next
-// launch's first wave -- with most of the chip idle).  Here everything the next launch needs is ONE kernel of one-wave blocks, a
-// block per frame: it fits into the first slot that comes free -- in practice while the launch before the previous one drains, a
-// whole launch ahead of time --, takes the camera table from its own arguments (no copy), clears the control block (no memset),
-// and leaves the background to k_tile_background, which runs BEHIND the tracing kernel (different pixels: order does not matter).
-// The camera rays of the culled tiles are added to the counters by the tracing kernel's first wave (cnt[64 + f]: a block of this
-// kernel must not touch counters that block 0 may not have cleared yet).
-struct CamTab { FrameCam f[MI_LEAN_FRAMES]; };
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))      // (a wave of it fits the registers one wave of the tracing kernel leaves)
-k_tile_select_lean(const FrameParams P, const float4 *boxes, int n_boxes, const uint32_t *order, uint32_t *sel, uint32_t *cnt, uint32_t *gmask,
-                   const CamTab tab, FrameCam *cams_dst)
-{
-    extern __shared__ uint32_t mask[];               // one bit per tile
-    __shared__ int s_rect[MI_CULL_BOXES][4];
-    const int f = (int)blockIdx.x, lane = (int)threadIdx.x;
-    const int tiles_x = (P.W + 7) >> 3, tiles_y = (P.n_rows + 7) >> 3;
-    const uint32_t n_tiles = (uint32_t)tiles_x * (uint32_t)tiles_y, n_words = (n_tiles + 31u) >> 5;
-    // this frame's row of the camera table, for the tracing kernel's lanes
-    if (lane < (int)(sizeof(FrameCam) / 16)) ((float4 *)(cams_dst + f))[lane] = ((const float4 *)&tab.f[f])[lane];
-    if (f == 0) {
-        // the control block of the launch: counters, the pixel dispensers, the background's row counter
-        for (int i = lane; i < (int)CS_COUNT; i += 64) P.counters[i] = 0ull;
-        if (lane < MI_DISPENSERS) P.work_counter[(size_t)lane * MI_DISPENSER_STRIDE] = 0u;
-        if (lane == 0) P.fill_counter[0] = 0u;
-    }
-    for (uint32_t i = (uint32_t)lane; i < n_words; i += 64u) mask[i] = 0u;
-    const FrameCam &C = tab.f[f];
-    const f3 eye = mk3(C.eye[0], C.eye[1], C.eye[2]);
-    const f3 r1 = mk3(C.mv[0][0], C.mv[0][1], C.mv[0][2]), r2 = mk3(C.mv[1][0], C.mv[1][1], C.mv[1][2]), r3 = mk3(C.mv[2][0], C.mv[2][1], C.mv[2][2]);
-    for (int b = lane; b < n_boxes; b += 64) {
-        const float4 lo = boxes[2 * b], hi = boxes[2 * b + 1];
-        float x0 = FLT_MAX, x1 = -FLT_MAX, y0 = FLT_MAX, y1 = -FLT_MAX;
-        bool whole = false;
-        for (int k = 0; k < 8; k++) {
-            const f3 p = sub3(mk3((k & 1) ? hi.x : lo.x, (k & 2) ? hi.y : lo.y, (k & 4) ? hi.z : lo.z), eye);
-            const float cx = dot3(r1, p), cy = dot3(r2, p), cz = dot3(r3, p);
-            if (!(cz > 1e-3f * len3(p))) { whole = true; continue; }
-            const float sx = (float)(P.W / 2) + (float)P.SD * cy / cz, sy = (float)(P.H / 2) - (float)P.SD * cx / cz;
-            if (!(__builtin_fabsf(sx) < 1e9f) || !(__builtin_fabsf(sy) < 1e9f)) { whole = true; continue; }
-            x0 = sx < x0 ? sx : x0; x1 = sx > x1 ? sx : x1; y0 = sy < y0 ? sy : y0; y1 = sy > y1 ? sy : y1;
-        }
-        int tx0 = 0, ty0 = 0, tx1 = tiles_x - 1, ty1 = (P.H - 1) >> 3;
-        if (!whole) {
-            const float fx0 = __builtin_floorf(x0) - 2.f, fx1 = __builtin_ceilf(x1) + 2.f, fy0 = __builtin_floorf(y0) - 2.f, fy1 = __builtin_ceilf(y1) + 2.f;
-            if (fx1 < 0.f || fy1 < 0.f || fx0 > (float)(P.W - 1) || fy0 > (float)(P.H - 1)) { tx0 = 1; tx1 = 0; }
-            else {
-                tx0 = (int)(fx0 < 0.f ? 0.f : fx0) >> 3; ty0 = (int)(fy0 < 0.f ? 0.f : fy0) >> 3;
-                tx1 = (int)(fx1 > (float)(P.W - 1) ? (float)(P.W - 1) : fx1) >> 3; ty1 = (int)(fy1 > (float)(P.H - 1) ? (float)(P.H - 1) : fy1) >> 3;
-            }
-        }
-        s_rect[b][0] = tx0; s_rect[b][1] = ty0; s_rect[b][2] = tx1; s_rect[b][3] = ty1;
-    }
-    __syncthreads();
-    // mark: eight lanes per box (a tile row of its rectangle each), eight boxes at a time
-    for (int b0 = 0; b0 < n_boxes; b0 += 8) {
-        const int b = b0 + (lane >> 3);
-        int tx0 = 1, ty0 = 0, tx1 = 0, ty1 = -1;
-        if (b < n_boxes) { tx0 = s_rect[b][0]; ty0 = s_rect[b][1]; tx1 = s_rect[b][2]; ty1 = s_rect[b][3]; }
-        if (tx0 > tx1) ty1 = ty0 - 1;
-        for (int sty = ty0 + (lane & 7); sty <= ty1; sty += 8) {
-            int ty = sty;
-            if (P.band_count > 1) {           // (band_rows is a multiple of 8 here: a tile row lies in one band)
-                const int band = (sty * 8) / P.band_rows;
-                if (band % P.band_count != P.band_index) continue;
-                ty = ((band / P.band_count) * P.band_rows + (sty * 8 - band * P.band_rows)) >> 3;
-            }
-            if (ty >= tiles_y) continue;
-            const uint32_t a = (uint32_t)ty * (uint32_t)tiles_x + (uint32_t)tx0, e = (uint32_t)ty * (uint32_t)tiles_x + (uint32_t)tx1;
-            for (uint32_t w = a >> 5; w <= e >> 5; w++) {
-                const uint32_t lo_bit = w == (a >> 5) ? (a & 31u) : 0u, hi_bit = w == (e >> 5) ? (e & 31u) : 31u;
-                atomicOr(&mask[w], (0xffffffffu >> (31u - hi_bit)) & (0xffffffffu << lo_bit));
-            }
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = (uint32_t)lane; i < n_words; i += 64u) gmask[(size_t)f * n_words + i] = mask[i];
-    // the tile order restricted to marked tiles, order kept: 2048 entries at a time (32 independent loads per lane)
-    uint32_t at = 0;
-    for (uint32_t p0 = 0; p0 < n_tiles; p0 += 2048u) {
-        uint32_t tl[32];
-#pragma unroll
-        for (int j = 0; j < 32; j++) {
-            const uint32_t i = p0 + (uint32_t)j * 64u + (uint32_t)lane;
-            tl[j] = i < n_tiles ? (order ? order[i] : i) : 0xffffffffu;
-        }
-#pragma unroll
-        for (int j = 0; j < 32; j++) {
-            const uint32_t t = tl[j];
-            const unsigned long long m = __ballot(t != 0xffffffffu && ((mask[t >> 5] >> (t & 31u)) & 1u));
-            if ((m >> lane) & 1ull) sel[(size_t)f * n_tiles + at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = t;
-            at += (uint32_t)__popcll(m);
-        }
-    }
-    // the camera rays of the other tiles: counted here, added to the counters by the tracing kernel (Raytracer.cc:570-597: one per pixel sample)
-    unsigned long long px = 0;
-    for (uint32_t t = (uint32_t)lane; t < n_tiles; t += 64u) {
-        if ((mask[t >> 5] >> (t & 31u)) & 1u) continue;
-        const int w = P.W - (int)(t % (uint32_t)tiles_x) * 8, h = P.n_rows - (int)(t / (uint32_t)tiles_x) * 8;
-        px += (unsigned long long)((w < 8 ? w : 8) * (h < 8 ? h : 8));
-    }
-    for (int off = 32; off > 0; off >>= 1) px += __shfl_xor(px, off);
-    if (lane == 0) { cnt[f] = at; cnt[64 + f] = (uint32_t)px; }
-}
-
-// the background of the tiles a launch did not trace (black, Raytracer.cc:327-331), from the selection's masks: a wave per pixel row,
-// four pixels per lane and step.  Runs behind the tracing kernel on the frame's stream.
-__global__ void __launch_bounds__(256)
-k_tile_background(const FrameParams P, const uint32_t *gmask)
-{
-    const int f = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int tiles_x = (P.W + 7) >> 3, tiles_y = (P.n_rows + 7) >> 3;
-    const uint32_t n_tiles = (uint32_t)tiles_x * (uint32_t)tiles_y, n_words = (n_tiles + 31u) >> 5;
-    const uint32_t *mask = gmask + (size_t)f * n_words;
-    const bool batch = P.cams != nullptr;
-    uint32_t *const out = batch ? P.cams[f].out : P.out;
-    float *const outf = batch ? P.cams[f].outf : P.outf;
-    const bool vec = (P.pitch_words & 3) == 0 && (((size_t)out) & 15u) == 0;
-    for (int r = (int)(blockIdx.y * 4u) + wid; r < P.n_rows; r += (int)(gridDim.y * 4u)) {
-        const uint32_t trow = (uint32_t)(r >> 3) * (uint32_t)tiles_x;
-        const int out_r = P.compact ? r : band_row_to_y(r, P.band_rows, P.band_index, P.band_count);
-        uint32_t *const orow = out + (size_t)out_r * P.pitch_words;
-        for (int x = lane * 4; x < P.W; x += 256) {
-            const uint32_t t = trow + (uint32_t)(x >> 3);             // (four pixels from a multiple of four: one tile)
-            if ((mask[t >> 5] >> (t & 31u)) & 1u) continue;
-            if (vec && x + 3 < P.W) *(uint4 *)(orow + x) = make_uint4(0u, 0u, 0u, 0u);
-            else for (int k = 0; k < 4 && x + k < P.W; k++) orow[x + k] = 0u;
-            if (outf) {
-                float *q = outf + ((size_t)out_r * P.W + x) * 3;
-                for (int k = 0; k < 12 && x + k / 3 < P.W; k++) q[k] = 0.f;
-            }
-        }
-    }
-}
-} // namespace
-extern "C" hipError_t mi355i_launch_tile_select_lean(const FrameParams *P, const float4 *boxes, int n_boxes, const uint32_t *order, uint32_t *sel, uint32_t *cnt,
-                                                     uint32_t *gmask, const FrameCam *host_cams, FrameCam *cams_dst, hipStream_t st)
-{
-    if (P->n_frames < 1 || P->n_frames > MI_LEAN_FRAMES) return hipErrorInvalidValue;
-    const uint32_t n_tiles = (uint32_t)((P->W + 7) >> 3) * (uint32_t)((P->n_rows + 7) >> 3);
-    CamTab tab = {};
-    for (int f = 0; f < P->n_frames; f++) tab.f[f] = host_cams[f];
-    hipLaunchKernelGGL(k_tile_select_lean, dim3((unsigned)P->n_frames), dim3(64), ((n_tiles + 31u) >> 5) * 4u, st, *P, boxes, n_boxes, order, sel, cnt, gmask, tab, cams_dst);
-    return hipGetLastError();
-}
-extern "C" hipError_t mi355i_launch_tile_background(const FrameParams *P, const uint32_t *gmask, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_tile_background, dim3((unsigned)P->n_frames, 64), dim3(256), 0, st, *P, gmask);
-    return hipGetLastError();
-}
-namespace {
 } // namespace
 // gmask != NULL: the selection only -- one block per frame; the mask goes to gmask for k_raytrace, which writes the background itself
 extern "C" hipError_t mi355i_launch_tile_select(const FrameParams *P, const float4 *boxes, int n_boxes, const uint32_t *order, uint32_t *sel, uint32_t *cnt,
