@@ -590,9 +590,10 @@ k_raytrace(const DevScene S, const FrameParams P)
     L.nocull = 0u; L.path = 1u; L.pendmask = 0u; L.ao_i = -1; L.ao_draw = 0u; L.ao_total = L.ao_max = L.ao_cos = 0.f;
 
     unsigned n_normal = 0, n_shadow = 0, n_steal = 0, n_event = 0, n_skip = 0;
-    // (shadow rays towards lights a hit faces away from are counted, not traced: not in the counting builds, which reproduce the
-    //  reference's traversal counters, nor in the EXT builds)
-    constexpr bool SKIP_DARK = RT_SKIP_DARK && !STATS && !EXT;
+    // (shadow rays towards lights a hit faces away from are counted, not traced: not in the counting builds of the reference-order walk,
+    //  which reproduce the reference's traversal counters, nor in the EXT builds; the counting build of the ORDERED walk describes the
+    //  production walk -- the floor-of-work and own-bytes figures of the bench line come from it -- and leaves them out like it)
+    constexpr bool SKIP_DARK = RT_SKIP_DARK && !EXT && (!STATS || ORDERED);
     unsigned long long cq[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // RT_COUNT
     unsigned n_pops = 0, n_ihits = 0, n_tris = 0, n_plane = 0, n_shaded = 0;
     // phase profile (STATS builds only; wave-uniform): cycles and lane occupancy per phase

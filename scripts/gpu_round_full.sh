@@ -1,17 +1,24 @@
-# The evidence run behind profiles/<tag>_*  (one gpurun call:  gpurun --timeout 1500 -- 'bash scripts/gpu_round_full.sh r05'):
+# The evidence run behind profiles/<tag>_*  (one gpurun call:  gpurun --timeout 2400 -- 'bash scripts/gpu_round_full.sh r06'):
 # GPU tests, the bench line (counters collected in the run), kernel stats of launches one after the other and of the default
 # overlapped run, the rasterizer's and the shadow map's kernels, side measurements (variants, frame by frame, the seam, render_cli -b),
 # counter passes of the bench kernel; scripts/make_profiles.py <tag> then copies what is tracked into profiles/.
-TAG=${1:-r05}
+TAG=${1:-r06}
 mkdir -p gpurun_out
 R=$(pwd)
 (timeout 900 python -m pytest tests -m gpu -q -rs --capture=sys 2>&1 | tail -12) > gpurun_out/pytest_full.log
 tail -3 gpurun_out/pytest_full.log
 (timeout 600 python bench.py 2>gpurun_out/bench_full.err | tail -1) > gpurun_out/bench_full.log
 tail -1 gpurun_out/bench_full.log | cut -c1-300
+# the N > 1 script path on this one GPU (every rank on cuda:0, exchange staged over gloo): the lines check their own assembled frames
+# against the reference pins (multi_gpu.assembled_sha_ok) and carry the rasterizer's region; their timings mean nothing
+for n in 2 8; do
+  (timeout 900 python bench.py --gpus $n --dry-run --steps 10 --warmup 2 2>gpurun_out/bench_dryrun_n$n.err | tail -1) > gpurun_out/bench_dryrun_n$n.log
+  python -c "import json,sys; d=json.loads(open('gpurun_out/bench_dryrun_n$n.log').read()); mg=d['multi_gpu']; print('dry run N=$n: value', d['value'], 'assembled_sha_ok', mg['assembled_sha_ok'], 'frames checked', mg['assembled_sha_checked'], 'raster', {k: v.get('frames_per_sec') for k, v in mg['raster_1080p'].items() if isinstance(v, dict)})" 2>&1 | tail -1
+done
 {
-  echo "== scripts/rt_variants.py (dragon 1080p depth 3 and statue depth 1: batches of 8, single frames, frame hashes; work sharing off / register builds / 16 frames per launch as knobs)"
-  timeout 300 python scripts/rt_variants.py default 'default:RT_TUNE={"noshare":1}' 'default:RT_TUNE={"bpc":3}' 'default:RT_B=16' 2>&1 | grep variant
+  echo "== scripts/rt_variants.py (dragon 1080p depth 3 and statue depth 1: batches of 8, single frames, frame hashes; default / dark shadow rays walked / round 5 loop (leaves in the step for batches, tests inside the walk loop) / work sharing off / three waves / 16 frames per launch)"
+  for v in "noskip -DRT_SKIP_DARK=0" "r05loop -DRT_SKIP_DARK=0 -DRT_DEFER_BATCH=0 -DRT_FLUSH_OUT=0"; do set -- $v; n=$1; shift; bash scripts/build_rt_variant.sh $n "$@" > /dev/null 2>&1; done
+  timeout 400 python scripts/rt_variants.py default noskip r05loop 'default:RT_TUNE={"noshare":1}' 'default:RT_TUNE={"bpc":3}' 'default:RT_B=16' 2>&1 | grep variant
   echo "== scripts/shadowmap_time.py (LDS tiles from a dispenser)"; timeout 100 python scripts/shadowmap_time.py 2>&1 | grep "us per"
   echo "== scripts/raster_phases.py (the tile kernel's phases on counting frames; frames/s by threads per tile)"; timeout 100 python scripts/raster_phases.py 2>&1 | tail -14
   echo "== scripts/raytrace_frame_by_frame.py"; timeout 100 python scripts/raytrace_frame_by_frame.py 2>&1 | tail -8

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Distil the rocprofv3 output of scripts/gpu_round_full.sh (under gpurun_out/) into the tracked files in profiles/.
 
-    python scripts/make_profiles.py [round-tag, default r05]
+    python scripts/make_profiles.py [round-tag, default r06]
 """
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r06"
 KERNELS = {"default": "k_raytrace<false, false, true, 4, true", "noshare": "k_raytrace<false, false, true, 4, true", "bpc3": "k_raytrace<false, false, true, 3, true"}
 
 
@@ -60,7 +60,8 @@ def main():
             "by_variant": variants,
             "raster_kernels": old.get("raster_kernels"), "raster_kernels_round": old.get("round") if old.get("raster_kernels") else None,
         }, open(tf, "w"), indent=1)
-    for src, dst in (("gpurun_out/bench_full.log", "%s_bench_n1.jsonl" % TAG), ("gpurun_out/pytest_full.log", "%s_pytest_gpu.log" % TAG),
+    for src, dst in (("gpurun_out/bench_full.log", "%s_bench_n1.jsonl" % TAG), ("gpurun_out/bench_dryrun_n2.log", "%s_bench_dryrun_n2.jsonl" % TAG),
+                     ("gpurun_out/bench_dryrun_n8.log", "%s_bench_dryrun_n8.jsonl" % TAG), ("gpurun_out/pytest_full.log", "%s_pytest_gpu.log" % TAG),
                      ("gpurun_out/misc_full.log", "%s_side_measurements.log" % TAG), ("gpurun_out/rt_pmc.json", "%s_pmc_bench_kernel.json" % TAG)):
         p = os.path.join(ROOT, src)
         if os.path.exists(p):
