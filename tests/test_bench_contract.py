@@ -94,6 +94,29 @@ def test_the_dry_run_line_of_the_multi_gpu_path(name, n):
         assert mg["assembled_sha_checked"] == 4 + 4 + 2 + 1 + 1 and "invalid" not in r
 
 
+def test_the_round_6_line_says_what_the_host_grants_and_which_rays_were_walked():
+    """profiles/r06_bench_n1.jsonl: `cpu_baseline.cores` is what the box grants the process (its CFS quota, else its affinity mask), `threads`
+    what was launched, with the CPU seconds per wall second the sample actually got, the share of periods it was throttled in and the
+    burst figure of the probe beside the sustained value; `traced_Mrays_per_s` beside `value`; both fractions of the
+    roofline block."""
+    d = _line("r06_bench_n1.jsonl")
+    c = d["cpu_baseline"]
+    assert c["kind"] == "reference" and c["threads"] >= 1 and 1 <= c["cores"] <= c["host_threads"] and c["value"] > 0
+    assert c["effective_cores_used"] > 0 and c["effective_cores_used"] <= c["threads"] + 0.5
+    if c["cpu_quota_cores"] is not None:
+        assert c["cores"] == min(c["cpu_quota_cores"], c["affinity_threads"]) and c["throttled_fraction"] is not None
+        if c["throttled_fraction"] > 0.10:
+            assert "throttled" in c["sample"]
+    assert c["burst_Mrays_per_s"] is None or c["burst_Mrays_per_s"] > 0
+    assert d["cpu_baseline_author"]["cores"] == c["cores"] and d["cpu_baseline_author"]["threads"] == c["threads"]
+    assert 0 < d["traced_Mrays_per_s"] < d["value"] and d["config"]["traced_rays_per_frame"] < d["config"]["rays_per_frame"]
+    assert "faces away" in d["config"]["rays_note"]
+    r = d["roofline"]
+    assert 0.0 < r["useful"]["frac"] < r["frac"] <= 1.0 and r["kernel_ms"] > 0 and r["traffic"] > 0
+    recomputed = d["config"]["rays_per_frame"] * d["config"]["frames"] / (d["ms_per_step"] * 1e-3 * d["steps"]) / 1e6
+    assert abs(recomputed - d["value"]) / d["value"] < 0.01
+
+
 def test_the_committed_single_gpu_line_keeps_the_measurement_contract():
     """profiles/r05_bench_n1.jsonl (the round's evidence run) has what the contract asks of the N = 1 line: BASELINE.json's metric and
     unit on the configuration it is quoted on, a whole-job value that recomputes from the frames and the time, the roofline object with
