@@ -211,7 +211,9 @@ int mi355_host_unregister(mi355_ctx *, void *p);
  * a registered piece of the heap shares pages and an address range with unrelated allocations, and ROCm 7.2 faulted in later
  * hipMemcpy calls into pageable heap memory at addresses that had been registered and unregistered before (the runtime pins such
  * destinations in place).  The C++ host layer's Screen::_pixels lives here.  NULL when no HIP device is usable or
- * the allocation fails (mi355_last_error); mi355_host_free(NULL) is a no-op.  Zero-filled. */
+ * the allocation fails (mi355_last_error); mi355_host_free(NULL) is a no-op.  Zero-filled.
+ * mi355_host_free waits for the frames of mi355_render_async that are still on their way INTO the buffer (of any context), and for
+ * nothing else: the caller must not have device work of its OWN in flight that still reads or writes it. */
 void *mi355_host_alloc(size_t bytes);
 void mi355_host_free(void *p);
 
