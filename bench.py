@@ -81,17 +81,21 @@ def _read(path):
         return None
 
 
+CGROUP_FS = "/sys/fs/cgroup"            # (tests point these two at a fake tree)
+PROC_CGROUP = "/proc/self/cgroup"
+
+
 def _cgroup_dirs():
     """Directories whose CPU controller files bound this process, innermost first: cgroup v2 (unified) and v1 (cpu / cpuacct)."""
     v2, v1 = [], []
-    txt = _read("/proc/self/cgroup") or ""
+    txt = _read(PROC_CGROUP) or ""
     for line in txt.splitlines():
         parts = line.split(":", 2)
         if len(parts) != 3:
             continue
         hid, ctrl, path = parts
         if hid == "0" and ctrl == "":
-            base = "/sys/fs/cgroup" if os.path.exists("/sys/fs/cgroup/cgroup.controllers") else "/sys/fs/cgroup/unified"
+            base = CGROUP_FS if os.path.exists(CGROUP_FS + "/cgroup.controllers") else CGROUP_FS + "/unified"
             p = path
             while True:
                 v2.append(os.path.normpath(base + "/" + p))
@@ -101,7 +105,7 @@ def _cgroup_dirs():
         elif "cpu" in ctrl.split(","):
             p = path
             while True:
-                v1.append(os.path.normpath("/sys/fs/cgroup/cpu/" + p))
+                v1.append(os.path.normpath(CGROUP_FS + "/cpu/" + p))
                 if p in ("", "/"):
                     break
                 p = os.path.dirname(p)

@@ -161,3 +161,48 @@ def test_the_committed_single_gpu_line_keeps_the_measurement_contract():
     rows = d["other_workloads"]["render_cli_bench"]["rows"]
     assert len(rows) == 5 and all(x["fps_3_in_flight"] and x["fps_reference_loop"] for x in rows)
     assert set(d["other_workloads"]["shadowmap_1024_us"]) == {"chessboard.tri", "dragon_vis.ply"}
+
+
+def _fake_cgroup(tmp_path, monkeypatch, proc_text, files):
+    import bench
+    root = tmp_path / "cg"
+    for rel, text in files.items():
+        f = root / rel
+        f.parent.mkdir(parents=True, exist_ok=True)
+        f.write_text(text)
+    proc = tmp_path / "proc_cgroup"
+    proc.write_text(proc_text)
+    monkeypatch.setattr(bench, "CGROUP_FS", str(root))
+    monkeypatch.setattr(bench, "PROC_CGROUP", str(proc))
+    return bench
+
+
+def test_cpu_grant_reads_the_quota_of_the_tightest_cgroup(tmp_path, monkeypatch):
+    """bench.py's cpu_baseline.cores: cgroup v2 (cpu.max of the process's group or any group above it), cgroup v1 (cfs_quota / period),
+    no quota (the affinity mask), and the throttling counters between two snapshots."""
+    import os
+    aff = len(os.sched_getaffinity(0))
+    # v2, nested: the parent's 16-core quota is tighter than the leaf's "max"
+    b = _fake_cgroup(tmp_path / "a", monkeypatch, "0::/pod/box\n",
+                     {"cgroup.controllers": "cpu", "pod/box/cpu.max": "max 100000\n", "pod/cpu.max": "1600000 100000\n",
+                      "pod/cpu.stat": "usage_usec 1\nnr_periods 100\nnr_throttled 40\nthrottled_usec 2000000\n"})
+    g = b.cpu_grant()
+    assert g["cpu_quota_cores"] == 16.0 and g["granted_cores"] == min(16.0, aff) and g["cpu_quota_from"].endswith("pod/cpu.max")
+    s0 = b.cpu_stat()
+    (tmp_path / "a" / "cg" / "pod" / "cpu.stat").write_text("usage_usec 1\nnr_periods 200\nnr_throttled 90\nthrottled_usec 5000000\n")
+    s1 = b.cpu_stat(); s1["wall"] = s0["wall"] + 10.0
+    d = b.cpu_stat_delta(s0, s1, 64)
+    assert d["throttled_fraction"] == 0.5 and d["throttled_seconds_per_wall_second"] == 0.3 and d["threads"] == 64
+    # v1: quota / period in the cpu controller's hierarchy
+    b = _fake_cgroup(tmp_path / "b", monkeypatch, "3:cpu,cpuacct:/jobs/x\n2:memory:/y\n",
+                     {"cpu/jobs/x/cpu.cfs_quota_us": "250000\n", "cpu/jobs/x/cpu.cfs_period_us": "100000\n",
+                      "cpu/jobs/x/cpu.stat": "nr_periods 10\nnr_throttled 1\nthrottled_time 1000000\n"})
+    g = b.cpu_grant()
+    assert g["cpu_quota_cores"] == 2.5 and g["granted_cores"] == min(2.5, aff)
+    assert b.cpu_stat()["throttled_usec"] == 1000.0            # (v1 counts nanoseconds)
+    # no quota anywhere: the affinity mask is what the host grants; no throttling counters -> None, not 0
+    b = _fake_cgroup(tmp_path / "c", monkeypatch, "0::/\n", {"cgroup.controllers": "cpu", "cpu.max": "max 100000\n"})
+    g = b.cpu_grant()
+    assert g["cpu_quota_cores"] is None and g["granted_cores"] == aff
+    s0 = b.cpu_stat(); s1 = dict(s0, wall=s0["wall"] + 1.0)
+    assert b.cpu_stat_delta(s0, s1, 8)["throttled_fraction"] is None
