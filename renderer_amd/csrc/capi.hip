@@ -316,7 +316,8 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
         if (ordered && !stats && !ext && !P.exact_box) {
             // (round 5: single frames queue their leaves' triangles -- k_raytrace.hip, DEFER -- and are never faster on the four-wave build:
             //  4K 0.912 ms on three waves against 0.935, 4 spp 1080p 1.85 against 2.25; batches keep it)
-            for (int w = batch ? 4 : 3; w >= 3; w--) {
+            // (a single frame takes the four-wave build only when it is asked for: frames that share the GPU -- the overlapped device path)
+            for (int w = (batch || P.blocks_per_cu >= 4) ? 4 : 3; w >= 3; w--) {
                 // (round 3, with work shared inside the waves: a single 1080p frame is 3 % faster on the three-wave build than on
                 //  the two-wave one -- 0.649 against 0.668 ms -- so the bar for three waves is half of what it is for four)
                 const bool wanted = P.blocks_per_cu == 0 ? work_tiles >= (w == 3 ? 10ll : 20ll) * w * c->n_cus * 4 : P.blocks_per_cu >= w;

@@ -59,9 +59,6 @@ namespace {
 #ifndef RT_FLUSH_AT
 #define RT_FLUSH_AT 48
 #endif
-#ifndef RT_SLOAD
-#define RT_SLOAD 0          // experiment: a wide record every lane of the wave goes to next is read through the scalar cache
-#endif
 #ifndef RT_SKIP_DARK
 #define RT_SKIP_DARK 1      // shadow rays that cannot change a pixel (the hit faces away from the light) are counted, not traced
 #endif
@@ -548,7 +545,7 @@ k_raytrace(const DevScene S, const FrameParams P)
     // behind the stack's: the verdict words, and a per-wave table (rank among the givers -> lane).
     constexpr bool STEAL = ORDERED && !STATS && !EXT;
     const bool steal_on = STEAL && P.steal_min > 0;
-    constexpr bool DEFER = STEAL && RT_DEFER && (BATCH ? RT_DEFER_BATCH != 0 : WAVES <= 3);
+    constexpr bool DEFER = STEAL && RT_DEFER && (BATCH ? RT_DEFER_BATCH != 0 : true);
     // Rows behind the stack's.  Two rows of 64-bit RESULT words, one per thread of the block: the state of the ray that thread
     // owns, as everybody who walks a part of it sees it -- a closest-hit ray: distance^2 bits << 32 | triangle of the best hit so
     // far (atomic min: the nearest hit, the lowest triangle among equals -- the rule of the walk itself), a shadow ray: 0 once a
@@ -564,9 +561,9 @@ k_raytrace(const DevScene S, const FrameParams P)
     float *const lds_lp = (float *)(lds_q + (DEFER ? 3 * RT_BLK : 0));
     // (ordered builds: a hit's reflected direction waits in three rows while the hit's shadow rays are walked; a 4 spp frame
     //  keeps its pixel sums in three more, which only such a launch allocates)
-    //  (a batch build that queues its leaves keeps the direction in the lane instead -- the compiler parks it in scratch with the rest of
-    //   the transition state --: the queue's three rows take the place of these, and sixteen waves of the dragon's tree still fit a CU)
-    constexpr bool REFL_LDS = ORDERED && !(DEFER && BATCH);
+    //  (the four-wave builds that queue their leaves keep the direction in the lane instead -- the compiler parks it in scratch with the
+    //   rest of the transition state --: the queue's three rows take the place of these, and sixteen waves of the dragon's tree still fit a CU)
+    constexpr bool REFL_LDS = ORDERED && !(DEFER && (BATCH || WAVES >= 4));
     float *const lds_refl = lds_lp + 3 * RT_BLK + threadIdx.x;
     float *const lds_sum = lds_refl + (REFL_LDS ? 3 * RT_BLK : 0);
     Lane L;
@@ -1410,32 +1407,6 @@ k_raytrace(const DevScene S, const FrameParams P)
                 L.sp--;
                 if (L.sp > sbase) L.top = stk[(L.sp - 1) * RT_BLK];
             }
-#if RT_SLOAD
-            // Lanes that all go to the SAME wide record next (every ray starts at the root, and the rays of a tile stay together for
-            // the first levels) take it through the scalar cache: one s_load of 64 bytes for the wave instead of 64 lanes x 4 x 16 bytes
-            // through the texture path, which is the busiest unit of this kernel (TD_BUSY 0.85).  The scalar load is issued here and
-            // its registers are copied at the end of the step, behind the triangle phase.
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            v4f s0, s1, s2, s3;
-            unsigned long long mS = 0ull;
-            if (walking) L.cur = next;
-            {
-                const unsigned long long mNi = mWalk & __ballot((int)next >= 0 && next != MI_END_LINK);
-                uint32_t n0 = 0u;
-                if (mNi) {
-                    n0 = (uint32_t)__builtin_amdgcn_readlane((int)next, __ffsll((long long)mNi) - 1);
-                    if ((mNi & __ballot(next != n0)) == 0ull) mS = mNi; else n0 = 0u;
-                }
-                typedef const v4f __attribute__((address_space(4))) *cptr;
-                cptr p = (cptr)(S.walk + (size_t)(n0 & MI_INDEX_MASK));
-                s0 = p[0]; s1 = p[1]; s2 = p[2]; s3 = p[3];
-                if (walking && next != MI_END_LINK && !__builtin_amdgcn_inverse_ballot_w64(mS)) {
-                    const float4 *p = S.walk + (size_t)(next & MI_INDEX_MASK);
-                    R.a = p[0]; R.b = p[1];
-                    if ((next & MI_LEAF_BIT) == 0) { R2.a = p[2]; R2.b = p[3]; }
-                }
-            }
-#else
             if (walking) {
                 L.cur = next;
                 if (next != MI_END_LINK) {
@@ -1444,7 +1415,6 @@ k_raytrace(const DevScene S, const FrameParams P)
                     if ((next & MI_LEAF_BIT) == 0) { R2.a = p[2]; R2.b = p[3]; }
                 }
             }
-#endif
             if constexpr (WAVES >= 3) {
             // 4. while that request is in flight: this step's triangle -- plane half, and for the lanes that pass it the
             //    edge half at once (Raytracer.cc:245-297 as straight-line predicates: the same float operations in the
@@ -1562,14 +1532,6 @@ k_raytrace(const DevScene S, const FrameParams P)
                     }
                 }
             }
-#if RT_SLOAD
-            if (mS) {
-                if (__builtin_amdgcn_inverse_ballot_w64(mS)) {
-                    R.a = make_float4(s0.x, s0.y, s0.z, s0.w); R.b = make_float4(s1.x, s1.y, s1.z, s1.w);
-                    R2.a = make_float4(s2.x, s2.y, s2.z, s2.w); R2.b = make_float4(s3.x, s3.y, s3.z, s3.w);
-                }
-            }
-#endif
             const unsigned long long mBusy = __ballot(L.cur != MI_END_LINK || L.pend);
             if (!mBusy) break;
             if (xmin_now < 64 && __popcll(__ballot(alive && L.cur == MI_END_LINK && !L.pend)) >= xmin_now) break;
@@ -1898,7 +1860,7 @@ extern "C" hipError_t mi355i_launch_cull_probe(const float *rays6, const uint32_
 // ---- launch helper (called from capi.hip) ------------------------------------------------
 namespace {
 typedef void (*rt_kernel)(const DevScene, const FrameParams);
-// The builds that exist (15).  Production = the ordered walk with the filtered box test: three register builds (waves = wavefronts
+// The builds that exist (16).  Production = the ordered walk with the filtered box test: three register builds (waves = wavefronts
 // per SIMD: 2, 3 or 4) x single frame / batch.  Everything else is a fallback or a measuring tool and comes in ONE register build
 // (two waves per SIMD): the exact-only box test (scenes whose box coordinates are outside the filtered test's range, tune flag 1),
 // the walk in the reference's order (unchecked trees, tune flag 4; its counting builds reproduce the reference's counters), the
@@ -1914,6 +1876,7 @@ rt_kernel pick_kernel(int stats, int exact, int ordered, int waves, int batch, i
     if (ordered && exact) return batch ? k_raytrace<false, true, true, 2, true> : k_raytrace<false, true, true, 2, false>;
     if (ordered) {
         if (waves >= 4 && batch) return k_raytrace<false, false, true, 4, true>;
+        if (waves >= 4) return k_raytrace<false, false, true, 4, false>;      // (single frames that share the GPU: asked for explicitly, capi.hip)
         if (waves >= 3) return batch ? k_raytrace<false, false, true, 3, true> : k_raytrace<false, false, true, 3, false>;
         return batch ? k_raytrace<false, false, true, 2, true> : k_raytrace<false, false, true, 2, false>;
     }
@@ -1931,7 +1894,8 @@ size_t stack_bytes(int ordered, int rows, int defer) { return (size_t)(rows + (o
 int uses_defer(int stats, int ordered, int waves, int batch, int ext)
 {
     if (!(RT_DEFER && ordered && !stats && !ext)) return 0;
-    return batch ? (RT_DEFER_BATCH != 0 ? 2 : 0) : 1;
+    if (batch) return RT_DEFER_BATCH != 0 ? 2 : 0;
+    return waves >= 4 ? 2 : 1;          // (2: the queue's rows take the place of the reflected directions' -- k_raytrace: REFL_LDS)
 }
 } // namespace
 
@@ -1947,7 +1911,6 @@ extern "C" void mi355i_raytrace_variant(int stats, int *exact, int *ordered, int
     if (ext && !*ordered) *exact = 1;
     if (ext || stats || !*ordered || *exact) *waves = 2;
     if (*waves > 4) *waves = 4;
-    if (*waves == 4 && !batch_) *waves = 3;      // (single frames queue their leaves: never faster on the four-wave build)
     if (*waves < 2) *waves = 2;
 }
 
