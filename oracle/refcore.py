@@ -16,6 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 BINARY = os.path.join(_HERE, "_ref", "refcore")
 RASTER_BINARY = os.path.join(_HERE, "_ref", "refraster")
+RASTER_BINARY_1080 = os.path.join(_HERE, "_ref", "refraster_1080")      # the same sources with Defines.h:26-27 patched to 1920 x 1080 (refcore/Makefile)
 REFERENCE_SRC = "/root/reference/src"
 
 
@@ -165,9 +166,9 @@ def raster_available() -> bool:
     return os.path.exists(RASTER_BINARY)
 
 
-def raster_winners(osc, mode, eye, lookat, light_positions, timeout=1800):
+def raster_winners(osc, mode, eye, lookat, light_positions, timeout=1800, binary=None):
     """The reference's OWN rasterizer (oracle/refcore/refraster.cc: RasterizeScene<T>::DrawTriangles, Filler<>, ScanConverter,
-    Screen::RasterizeTriangle, the Z-buffer) with recording plotters, at its compile-time 800 x 600: returns
+    Screen::RasterizeTriangle, the Z-buffer) with recording plotters, at its compile-time 800 x 600 (binary=RASTER_BINARY_1080: 1920 x 1080): returns
     (W, H, camera matrix[9], winning triangle per pixel or -1 [H, W], Z-passes per pixel [H, W], fat point of the last pass [H, W, 8])."""
     lp = np.asarray(light_positions, np.float32).reshape(-1)
     blobs = scene_blobs(osc) + [_u32(len(lp) // 3), lp, np.array(list(eye) + list(lookat), np.float32)]
@@ -176,7 +177,7 @@ def raster_winners(osc, mode, eye, lookat, light_positions, timeout=1800):
         with open(fin, "wb") as f:
             for b in blobs:
                 f.write(b if isinstance(b, (bytes, bytearray)) else np.ascontiguousarray(b).tobytes())
-        subprocess.run([RASTER_BINARY, str(mode), fin, fout], check=True, timeout=timeout, stdout=subprocess.DEVNULL)
+        subprocess.run([binary or RASTER_BINARY, str(mode), fin, fout], check=True, timeout=timeout, stdout=subprocess.DEVNULL)
         raw = np.fromfile(fout, dtype=np.uint32)
     W, H = int(raw[0]), int(raw[1])
     mv = raw[2:11].view(np.float32).copy()

@@ -76,12 +76,24 @@ def main():
             rout.append({"id": "cfg2_f%d" % k, "mesh": "chessboard.tri", "mode": 6, "w": W, "h": H, "frame": k, "covered": int((tri >= 0).sum()),
                          "overdrawn": int((passes > 1).sum()), "sha256_winners": winners_hash(tri, passes, fat)})
             print(rout[-1], flush=True)
+        # ... and at BASELINE config 2's own 1920 x 1080 (oracle/_ref/refraster_1080: the same sources compiled from a temporary copy whose
+        # Defines.h:26-27 says 1920 x 1080, SURVEY 8(c)'s recipe)
+        if os.path.exists(RC.RASTER_BINARY_1080):
+            for k in (0, 37, 100, 150):
+                cam, lights, n = O.benchmark_frame(k)
+                W, H, mv, tri, passes, fat = RC.raster_winners(osc, 6, list(cam.eye), [0.0, 0.0, 0.0], [list(lights[0].pos)], binary=RC.RASTER_BINARY_1080)
+                assert (W, H) == (1920, 1080)
+                assert np.array_equal(mv.view(np.uint32), np.array(list(cam.mv), np.float32).view(np.uint32)), "frame %d: not the orbit's camera" % k
+                rout.append({"id": "cfg2_1080p_f%d" % k, "mesh": "chessboard.tri", "mode": 6, "w": W, "h": H, "frame": k, "covered": int((tri >= 0).sum()),
+                             "overdrawn": int((passes > 1).sum()), "sha256_winners": winners_hash(tri, passes, fat)})
+                print(rout[-1], flush=True)
     doc = {"_comment": "Full-size orbit frames beyond f0 from the reference's own Raytracer.cc compiled here (scripts/make_refcore_frame_pins.py: "
                        "oracle/_ref/refcore `raytrace`, strict flags, camera rays of benchmark frame k; f0 made the same way reproduces the survey's "
                        "pins of tests/golden/reference_pins.json).  sha256 over raw R,G,B bytes, row-major, top row first; sha256_f32 over the r,g,b "
                        "float32 values clamped at 255 (what mi355_render hands out as out_rgb_f32).",
            "frames": out,
-           "_comment_raster": "oracle/_ref/refraster (the reference's Rasterizers.cc with recording plotters, 800 x 600 = its compile-time size) on "
+           "_comment_raster": "oracle/_ref/refraster (the reference's Rasterizers.cc with recording plotters, 800 x 600 = its compile-time size; the cfg2_1080p "
+                              "rows: refraster_1080 = the same sources compiled from a temporary copy with Defines.h:26-27 patched to 1920 x 1080) on "
                               "orbit cameras: sha256 over the winning triangle per pixel (int32, -1 = none), the Z-pass count per pixel (int32) and, for "
                               "covered pixels, the bits of the eight floats of the fat point the plotter received (NaN -> 0x7fc00000).",
            "raster_winners": rout}

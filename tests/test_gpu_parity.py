@@ -174,8 +174,9 @@ def winners_hash(tri, passes, fat):
 
 @pytest.mark.parametrize("pin", ORBIT_PINS["raster_winners"], ids=[p["id"] for p in ORBIT_PINS["raster_winners"]])
 def test_raster_frames_on_the_pinned_winner_maps(oracle, oracle_scene, gpu_scene, pin):
-    """The rasterizer along the orbit at the reference's compile-time 800 x 600: the oracle's winner maps are the ones the reference's
-    own Rasterizers.cc produced in the build container (hash pin), and the HIP frame is the frame the oracle plots from them."""
+    """The rasterizer along the orbit at the reference's compile-time 800 x 600 and (round 6) at BASELINE config 2's own 1920 x 1080: the
+    oracle's winner maps are the ones the reference's own Rasterizers.cc produced in the build container (hash pin), and the HIP frame is
+    the frame the oracle plots from them."""
     osc, hs = oracle_scene(pin["mesh"]), gpu_scene(pin["mesh"])
     ocam, olights, on = oracle.benchmark_frame(pin["frame"])
     oimg, tri, passes, fat = oracle.raster_winners(osc, pin["mode"], ocam, olights, on, oracle.default_opts(pin["w"], pin["h"]))

@@ -48,7 +48,8 @@ def winners_hash(tri, passes, fat):
 
 @pytest.mark.parametrize("pin", ORBIT_PINS["raster_winners"], ids=[p["id"] for p in ORBIT_PINS["raster_winners"]])
 def test_oracle_reproduces_the_rasterizer_winner_pins(oracle, oracle_scene, pin):
-    """BASELINE configs[1] (chessboard.tri, per-pixel Phong) along the orbit at the reference's own compile-time frame size: the winning
+    """BASELINE configs[1] (chessboard.tri, per-pixel Phong) along the orbit at the reference's own compile-time frame size and at the
+    configuration's 1920 x 1080 (refraster_1080: the same sources from a temporary copy with Defines.h:26-27 patched): the winning
     triangle, the Z-pass count and the fat point of every pixel as the reference's Rasterizers.cc hands them to its plotter
     (oracle/_ref/refraster in the build container) -- hashed there, reproduced here by the oracle."""
     s = oracle_scene(pin["mesh"])
