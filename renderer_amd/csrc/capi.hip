@@ -272,6 +272,7 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
             mi355i_prof_lap(1);
             FrameParams Q = P;
             Q.out = fl.fb;
+            if (Q.wave_prof) { static unsigned log_seq = 0; Q.wave_prof += (size_t)(log_seq++ & 3u) * 2048u * 16u; c->last_blocks = 8192; }      // (RS_TILELOG builds: the last four frames side by side)
             e = mi355i_launch_raster_overlapped(&c->dev, &Q, mode, c->rs_pipe[fl.k], fl.ps, c->ev_tile[fl.k]);
             if (e != hipSuccess) {
                 // (the turn counters have advanced and part of the frame may be on the frame stream: the set's event is recorded behind

@@ -170,13 +170,25 @@ MI_DEV uint32_t rs_setup_chunk(const DevScene &S, const FrameParams &P, const Fr
     return n_bands;          // (the block's band records: band_base .. band_base + n_bands)
 }
 
+// Measuring variant (-DRS_TILELOG=1, run with MI355_WAVELOG=1; scripts/rs_tilelog.py): the blocks of the three kernels write when they
+// started, passed their phases and ended (100 MHz clock) into P.wave_prof, 16 words per block index: words 0-11 the tile kernel's, 12-13
+// the setup kernel's, 14-15 the fill kernel's.
+#ifndef RS_TILELOG
+#define RS_TILELOG 0
+#endif
+#define RS_LOG_NOW() (RS_TILELOG ? __builtin_amdgcn_s_memrealtime() : 0ull)
+
 template <int MODE>
 __global__ void __launch_bounds__(256) k_rs_setup(const DevScene S, const FrameParams P, const FrameParams *batch, const RsGrid g,
                                                   const RsBuffers B)
 {
     __shared__ BlockPairs bp;
     __shared__ uint32_t band_base;
+    const unsigned long long t_log = RS_LOG_NOW();
     (void)rs_setup_chunk<MODE>(S, P, batch, g, B, bp, band_base, blockIdx.x, blockIdx.y, gridDim.y);
+    if (RS_TILELOG && P.wave_prof && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 2048u) {
+        P.wave_prof[(size_t)blockIdx.x * 16u + 12u] = t_log; P.wave_prof[(size_t)blockIdx.x * 16u + 13u] = RS_LOG_NOW();
+    }
 }
 
 // exclusive scan of one frame's bin counts (block f = frame f); offset[n] = the frame's total.  Only for frames with more
@@ -296,6 +308,15 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
 {
     const FrameParams &F = batch ? batch[blockIdx.y] : P;
     const int height = F.H;
+    const unsigned long long t_log = RS_LOG_NOW();
+    struct LogEnd {        // (the kernel has several ways out)
+        const FrameParams &P; unsigned long long t0;
+        __device__ ~LogEnd() {
+            if (RS_TILELOG && P.wave_prof && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 2048u) {
+                P.wave_prof[(size_t)blockIdx.x * 16u + 14u] = t0; P.wave_prof[(size_t)blockIdx.x * 16u + 15u] = RS_LOG_NOW();
+            }
+        }
+    } log_end{P, t_log};
     __shared__ BlockPairs bp;
     __shared__ uint32_t soff[LDS_SCAN ? RS_SCAN_LDS + 1 : 1];
     __shared__ uint32_t stot[4];
@@ -351,6 +372,12 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
     __shared__ RsTileLds lds;
     const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
     const bool prof = P.counters && P.raster_stats;
+    unsigned long long tl[12];           // RS_TILELOG: start, first tile: taken, cleared, filtered, staged, depth done, runs, attributes, shaded; block's end; bin entries | kept << 32, tile
+#pragma unroll
+    for (int i = 0; i < 12; i++) tl[i] = 0ull;
+    tl[0] = RS_LOG_NOW();
+    bool tl_first = true;
+#define RS_TL(i) do { if (RS_TILELOG && tl_first) tl[i] = RS_LOG_NOW(); } while (0)
     unsigned long long acc[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0ull;
@@ -383,30 +410,37 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
         const FrameParams &F = batch ? batch[f] : P;
         unsigned long long t_mark = prof ? __builtin_readcyclecounter() : 0ull;
         const unsigned long long t_begin = t_mark;
+        RS_TL(1);
         const RsTileBins L = rs_tile_bins(g, B, f, tx, ty);
         const uint32_t total = L.total();
         rs_tile_clear(lds, tid, nt);
         __syncthreads();
         RS_PROF_MARK(0);
+        RS_TL(2);
+        if (RS_TILELOG && tl_first) { tl[10] = total; tl[11] = tile; }
         bool any = false;
         int parity = 0;
         for (uint32_t first = 0; first < total; first += RS_LIST_CAP) {
             rs_tile_filter(B, f, tx, ty, L, first, lds, tid, nt);
             __syncthreads();
             RS_PROF_MARK(1);
+            RS_TL(3);
             const uint32_t nl = lds.n_list;
+            if (RS_TILELOG && tl_first) tl[10] += (unsigned long long)nl << 32;
             any = any || nl != 0u;
             if (prof && tid == 0) acc[10] += nl;
             for (uint32_t chunk = 0; chunk < nl; chunk += RS_CHUNK) {
                 rs_tile_stage(ty, chunk, nl, parity, lds, tid, nt);
                 __syncthreads();
                 RS_PROF_MARK(2);
+                RS_TL(4);
                 if (prof && tid == 0) acc[11] += lds.n_items[parity];
                 rs_tile_depth<MODE>(F, B, S.n_tris, f, tx, ty, chunk, parity, lds, tid, nt, ztests);
                 if (tid == 0) { lds.n_items[parity ^ 1] = 0u; if (chunk + RS_CHUNK >= nl) lds.n_list = 0u; }
                 parity ^= 1;
                 __syncthreads();
                 RS_PROF_MARK(3);
+                RS_TL(5);
             }
         }
         if (prof && tid == 0) acc[13] += total;
@@ -414,15 +448,19 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
             rs_tile_runs(lds, tid, nt);
             __syncthreads();
             RS_PROF_MARK(4);
+            RS_TL(6);
             if (prof && tid == 0) acc[12] += lds.n_runs;
             rs_tile_attr<MODE>(F, B, S.n_tris, f, tx, ty, lds, tid, nt);
             __syncthreads();
             RS_PROF_MARK(5);
+            RS_TL(7);
             rs_tile_shade<MODE>(S, F, tx, ty, lds, tid, nt, plots);
+            RS_TL(8);
         } else if (clear_rows) rs_tile_blank(F, tx, ty, tid, nt);     // (nobody else clears a tile whose bin holds entries)
         const uint32_t nw = next_w;                           // (written by thread 0 at the top of this tile, barriers ago)
         __syncthreads();                                      // (the next tile clears the keys and draws the next item)
         w = nw;
+        tl_first = false;
         RS_PROF_MARK(6);
         if (prof && tid == 0) {
             const unsigned long long dt = __builtin_readcyclecounter() - t_begin;
@@ -455,6 +493,11 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
                 }
             }
         }
+    }
+    if (RS_TILELOG && P.wave_prof && tid == 0 && blockIdx.x < 2048u) {
+        tl[9] = RS_LOG_NOW();
+#pragma unroll
+        for (int i = 0; i < 12; i++) P.wave_prof[(size_t)blockIdx.x * 16u + (uint32_t)i] = tl[i];
     }
     if (prof) {
         if (ztests) atomicAdd(&P.counters[CS_ZTESTS], ztests);

@@ -99,6 +99,7 @@ def test_ff_add_equals_the_serial_chain(tmp_path):
     """x after k additions of d: ff_add's binade walk against the loop, on random and adversarial operands."""
     src = tmp_path / "ff.cc"
     src.write_text(r'''
+#include <math.h>
 #define MI_HD static inline
 #include "%s/renderer_amd/csrc/ff_add.h"
 extern "C" void ff_many(const float *x, const float *d, const int *k, float *fast, float *slow, int n)
@@ -113,7 +114,12 @@ extern "C" void ff_many(const float *x, const float *d, const int *k, float *fas
 ''' % os.path.dirname(HERE))
     so = str(tmp_path / "ff.so")
     subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC", "-o", so, str(src)])
-    lib = C.CDLL(so)
+    # ... and with the device's way to the step count (a reciprocal instead of a division), the reciprocal one ulp too large / too small
+    libs = [C.CDLL(so)]
+    for tag, rcp in (("up", "nextafterf(1.0f / (x), INFINITY)"), ("down", "nextafterf(1.0f / (x), 0.0f)")):
+        so2 = str(tmp_path / ("ff_%s.so" % tag))
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC", "-DFF_ADD_TEST_RCP(x)=" + rcp, "-o", so2, str(src)])
+        libs.append(C.CDLL(so2))
     rng = np.random.default_rng(2024)
     f = np.float32
     xs, ds, ks = [], [], []
@@ -138,11 +144,12 @@ extern "C" void ff_many(const float *x, const float *d, const int *k, float *fas
     g = np.array(np.meshgrid(sp, sp, [0, 1, 2, 3, 6, 7, 8, 50, 5000])).reshape(3, -1)
     xs.append(g[0].astype(f)); ds.append(g[1].astype(f)); ks.append(g[2].astype(np.int32))
     x, d, k = np.concatenate(xs), np.concatenate(ds), np.concatenate(ks)
-    fast, slow = np.empty_like(x), np.empty_like(x)
-    lib.ff_many(C.c_void_p(x.ctypes.data), C.c_void_p(d.ctypes.data), C.c_void_p(k.ctypes.data), C.c_void_p(fast.ctypes.data),
-                C.c_void_p(slow.ctypes.data), C.c_int(len(x)))
-    same = (fast.view(np.uint32) == slow.view(np.uint32)) | (np.isnan(fast) & np.isnan(slow))
-    assert same.all(), "%d of %d chains differ, e.g. x=%r d=%r k=%d" % (int((~same).sum()), len(x), x[~same][0], d[~same][0], k[~same][0])
+    for lib in libs:
+        fast, slow = np.empty_like(x), np.empty_like(x)
+        lib.ff_many(C.c_void_p(x.ctypes.data), C.c_void_p(d.ctypes.data), C.c_void_p(k.ctypes.data), C.c_void_p(fast.ctypes.data),
+                    C.c_void_p(slow.ctypes.data), C.c_int(len(x)))
+        same = (fast.view(np.uint32) == slow.view(np.uint32)) | (np.isnan(fast) & np.isnan(slow))
+        assert same.all(), "%d of %d chains differ, e.g. x=%r d=%r k=%d" % (int((~same).sum()), len(x), x[~same][0], d[~same][0], k[~same][0])
 
 
 @pytest.mark.parametrize("nt", [64, 128, 512])
