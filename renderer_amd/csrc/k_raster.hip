@@ -31,7 +31,7 @@ struct RasterScratch {
     size_t bin_words = 0;          // capacity of B.count (B.offset has frames more)
     size_t bins_words = 0;         // capacity of B.bins in entries
     int count_bins = 0, count_frames = 0;   // geometry B.count was last cleared for
-    size_t order_words = 0;        // capacity of B.order
+    size_t order_words = 0;        // capacity of B.order in entries
     size_t band_words = 0;         // capacity of B.band in records
     int band_frames = 0;
     FrameParams *d_frames = nullptr, *h_frames = nullptr; int frames_cap = 0;   // batched launches: per-frame parameters
@@ -221,7 +221,8 @@ __global__ void __launch_bounds__(1024) k_rs_scan(const RsGrid g, const RsBuffer
 #define RS_SCAN_LDS 2048          // frames with at most this many bins (1080p: 511, 4K: 2041): every block of k_rs_fill scans the counts itself
 
 // The work items of the tile kernel: the tiles of a frame whose bins hold entries (the others are background: nobody reads
-// anything for them): order[0] = their number, order[1 ..] = the tiles.  One block; off = the frame's bin offsets; tot = 4 words of LDS.
+// anything for them): order[0] = their number and the global bin, order[1 ..] = the tiles with their coarse bins (RsBuffers::order).
+// One block; off = the frame's bin offsets; tot = 4 words of LDS.
 // (Rounds 4 and 5 measured heavy tiles drawn as strips of rows by several blocks -- of 256, 128 and 64 threads --: never faster than
 //  whole tiles, 12-17 k frames/s against 26 k; a tile's time is its chain of dependent steps, and a strip walks the same chain.)
 MI_DEV void tile_order(const RsGrid &g, const RsBuffers &B, uint32_t f, const uint32_t *off, uint32_t *tot)
@@ -230,10 +231,13 @@ MI_DEV void tile_order(const RsGrid &g, const RsBuffers &B, uint32_t f, const ui
     const uint32_t n = (uint32_t)g.n_tiles, per = (n + 255u) / 256u;
     const uint32_t b = (uint32_t)tid * per < n ? (uint32_t)tid * per : n, e = b + per < n ? b + per : n;
     const uint32_t n_global = off[g.n_coarse + 1] - off[g.n_coarse];
-    uint32_t *order = B.order + (size_t)f * (n + 1);
-    auto active = [&](uint32_t tile) -> uint32_t {
+    uint4 *order = B.order + (size_t)f * (n + 1);
+    auto bin_of = [&](uint32_t tile) -> int {
         const int tx = (int)(tile % (uint32_t)g.tiles_x), ty = (int)(tile / (uint32_t)g.tiles_x);
-        const int cb = (ty / RS_CB) * g.cx + tx / RS_CB;
+        return (ty / RS_CB) * g.cx + tx / RS_CB;
+    };
+    auto active = [&](uint32_t tile) -> uint32_t {
+        const int cb = bin_of(tile);
         return (off[cb + 1] - off[cb] + n_global) ? 1u : 0u;
     };
     uint32_t mine = 0;
@@ -246,8 +250,9 @@ MI_DEV void tile_order(const RsGrid &g, const RsBuffers &B, uint32_t f, const ui
     uint32_t before = 0, n_items = 0;
     for (int w = 0; w < 4; w++) { const uint32_t v = tot[w]; if (w < wid) before += v; n_items += v; }
     uint32_t at = before + incl - mine;
-    for (uint32_t i = b; i < e; i++) if (active(i)) order[1 + at++] = i;
-    if (tid == 0) order[0] = n_items;
+    for (uint32_t i = b; i < e; i++)
+        if (active(i)) { const int cb = bin_of(i); order[1 + at++] = make_uint4(i, off[cb], off[cb + 1] - off[cb], 0u); }
+    if (tid == 0) order[0] = make_uint4(n_items, off[g.n_coarse], n_global, 0u);
 }
 
 // exclusive scan of frame f's bin counts into LDS (soff[n_bins + 1]) by a 256-thread block; tot: 4 words of LDS
@@ -387,7 +392,12 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
     // such tiles than the grid).  Everything else is background, cleared by rs_setup.
     __shared__ uint32_t next_w;
     uint32_t max_active = 0;
-    for (int ff = 0; ff < n_frames; ff++) { const uint32_t a = B.order[(size_t)ff * ((size_t)g.n_tiles + 1)]; max_active = a > max_active ? a : max_active; }
+    // (the block's first item is its index: its entry of the work list is asked for together with the list's head -- one memory round
+    //  trip before the bin entries instead of three: head, entry, bin offsets)
+    const uint32_t w0 = blockIdx.x, f0 = w0 % (uint32_t)n_frames, slot0 = w0 / (uint32_t)n_frames;
+    uint4 ahead = make_uint4(0u, 0u, 0u, 0u);
+    if (slot0 < (uint32_t)g.n_tiles) ahead = B.order[(size_t)f0 * ((size_t)g.n_tiles + 1) + 1u + slot0];     // (stale beyond the list's length: not used then)
+    for (int ff = 0; ff < n_frames; ff++) { const uint32_t a = B.order[(size_t)ff * ((size_t)g.n_tiles + 1)].x; max_active = a > max_active ? a : max_active; }
     const uint32_t total_items = max_active * (uint32_t)n_frames;
     if (blockIdx.x == 0)                                      // the next frame's rs_setup counts from zero
         for (int ff = 0; ff < n_frames; ff++) {
@@ -396,7 +406,8 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
         }
     for (uint32_t w = blockIdx.x; w < total_items;) {
         const uint32_t f = w % (uint32_t)n_frames, slot = w / (uint32_t)n_frames;
-        const uint32_t *order = B.order + (size_t)f * ((size_t)g.n_tiles + 1);
+        const uint4 *order = B.order + (size_t)f * ((size_t)g.n_tiles + 1);
+        const uint4 head = order[0];
         // The next item: none when every item is some block's first one (a single frame).  Else from one of RS_DISPENSERS
         // counters (counter c hands out items grid + c, grid + c + RS_DISPENSERS, ...): atomics on ONE address come back
         // ~10 ns apart, and a wave's later loads queue behind its atomic -- a single counter cost 10 us of a 1080p frame.
@@ -404,14 +415,15 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
             const uint32_t nd = gridDim.x < RS_DISPENSERS ? 1u : (uint32_t)RS_DISPENSERS, c = blockIdx.x % nd;
             next_w = total_items <= gridDim.x ? total_items : gridDim.x + c + nd * atomicAdd(&B.band_top[n_frames + c], 1u);
         }
-        if (slot >= order[0]) { __syncthreads(); const uint32_t nw = next_w; __syncthreads(); w = nw; continue; }
-        const uint32_t tile = order[1 + slot];
+        if (slot >= head.x) { __syncthreads(); const uint32_t nw = next_w; __syncthreads(); w = nw; continue; }
+        const uint4 mine = w == w0 ? ahead : order[1 + slot];
+        const uint32_t tile = mine.x;
         const int tx = (int)(tile % (uint32_t)g.tiles_x), ty = (int)(tile / (uint32_t)g.tiles_x);
         const FrameParams &F = batch ? batch[f] : P;
         unsigned long long t_mark = prof ? __builtin_readcyclecounter() : 0ull;
         const unsigned long long t_begin = t_mark;
         RS_TL(1);
-        const RsTileBins L = rs_tile_bins(g, B, f, tx, ty);
+        const RsTileBins L = rs_tile_bins_of(B, mine.y, mine.z, head.y, head.z);
         const uint32_t total = L.total();
         rs_tile_clear(lds, tid, nt);
         __syncthreads();
@@ -897,7 +909,7 @@ static hipError_t tiled_ensure(RasterScratch *s, const RsGrid &g, uint32_t n_tri
     if (order_words > s->order_words || !s->B.order) {
         if (s->B.order) (void)hipFree(s->B.order);
         s->B.order = nullptr; s->order_words = 0;
-        if ((e = hipMalloc((void **)&s->B.order, order_words * 4)) != hipSuccess) return e;
+        if ((e = hipMalloc((void **)&s->B.order, order_words * sizeof(uint4))) != hipSuccess) return e;
         s->order_words = order_words;
     }
     // k_rs_tile leaves every count at zero for the next frame of the same geometry; a new geometry (or a frame that was
@@ -1211,6 +1223,6 @@ extern "C" uint32_t mi355i_raster_overflow(RasterScratch *s)
 extern "C" size_t mi355i_raster_scratch_bytes(const RasterScratch *s)
 {
     if (!s) return 0;
-    return s->rec_slots * (RS_REC4 * sizeof(float4) + sizeof(uint4)) + s->bin_words * 12 + s->order_words * 4 + s->bins_words * 16 + s->band_words * (RS_BAND4 * sizeof(float4) + sizeof(uint2)) +
+    return s->rec_slots * (RS_REC4 * sizeof(float4) + sizeof(uint4)) + s->bin_words * 12 + s->order_words * sizeof(uint4) + s->bins_words * 16 + s->band_words * (RS_BAND4 * sizeof(float4) + sizeof(uint2)) +
            (size_t)s->rows_cap * sizeof(RowRec) + s->sm_words * 4;
 }

@@ -44,6 +44,18 @@
 #define RS_LIST_CAP 1024      // bin entries filtered per pass of a tile (LDS list of accepted triangles)
 #define RS_CHUNK 256          // list entries whose scanlines are one round of depth items
 #define RS_BH 8               // scanlines per band record
+// Loops whose trip counts differ from lane to lane cost a wave its longest lane's trips, each with the scalar bookkeeping of a
+// divergent loop; round 6 replaced the short ones of the tile kernel's items by straight code (measured one by one, scripts/rs_variants.py):
+#ifndef RS_WALK_BITS
+#define RS_WALK_BITS 1        // an edge's walk from its band record to the scanline (< RS_BH additions) by the bits of the step count instead of a loop
+#endif
+#ifndef RS_ATTR_ONE_LOOP
+#define RS_ATTR_ONE_LOOP 1    // a run's interpolants are stored by one loop over its pixels instead of a loop per interpolant
+#endif
+#ifndef RS_DEPTH_FLAT
+#define RS_DEPTH_FLAT 1       // a depth item's <= RS_TW pixels as straight predicated code instead of a loop
+#endif
+// (the loop that writes a list entry's <= RS_TH work items as straight predicated code: slower, 28.67 -> 28.47 k frames/s; not kept)
 #define RS_BAND4 12           // float4 per band record: 3 edges x 8 interpolants x (value, step), interpolants 2j, 2j+1 in one float4
 
 enum { M_AMBIENT = 4, M_GOURAUD = 5, M_PHONG = 6, M_PHONG_SH = 7, M_PHONG_SOFT = 8, M_SHADOWMAP = 100 };
@@ -99,7 +111,10 @@ struct RsBuffers {
     uint32_t *band_top;            // [frames + RS_DISPENSERS]           band records handed out (rs_setup; zeroed again by rs_tile); the last
                                    //                        word: k_rs_tile's tile dispenser (zeroed by rs_setup)
     uint2 *band_owner;             // [frames][band_cap]     (triangle, band = scanline / RS_BH) of each band record
-    uint32_t *order;               // [frames][n_tiles + 1]  [0] = number of tiles with bin entries, then those tiles, then the others (rs_fill)
+    uint4 *order;                  // [frames][n_tiles + 1]  [0] = (number of tiles with bin entries, the global bin's first entry, its length, -),
+                                   //                        then (tile, its coarse bin's first entry, its length, -) of those tiles (rs_fill): a
+                                   //                        tile's block reads its entry and the head at once and then its bin entries -- no
+                                   //                        offsets in between
 };
 
 // y -> output row, or -1 when the row belongs to another GPU's band
@@ -241,14 +256,14 @@ MI_HD void scan_add_n(float (&l)[NC + 1], float (&r)[NC + 1], uint32_t &cnt, con
     scan_add<NC + 1>(l, r, cnt, v);
 }
 
-// Scanline y of a triangle, interpolants {0 (projx), k0 .. k0 + nc - 1} (nc <= NC): left / right end points and
-// ScanConverter's lines[y], from the band record of the band y lies in: each feeding edge's value is (y - rb) additions away
-// from the record's.  `pts` = the triangle's fat points as floats (used by horizontal edges only).
-template <int NC>
-MI_HD uint32_t rs_row_from_band(const int (&iy)[3], const float4 *band4, const float *pts, int k0, int nc, int height, int y,
+// Scanline y of a triangle, interpolants {0 (projx), K0 .. K0 + NC - 1}: left / right end points and ScanConverter's
+// lines[y], from the band record of the band y lies in: each feeding edge's value is (y - rb) additions away from the
+// record's.  `pts` = the triangle's fat points as floats (used by horizontal edges only).  The interpolants are known at
+// compile time: an edge's part of the record is read as whole float4 (interpolants 2j, 2j + 1 with their steps), not word by word.
+template <int K0, int NC>
+MI_HD uint32_t rs_row_from_band(const int (&iy)[3], const float4 *band4, const float *pts, int height, int y,
                                 float (&l)[NC + 1], float (&r)[NC + 1])
 {
-    const float *band = (const float *)band4;
     const int Y0 = (y / RS_BH) * RS_BH;
     uint32_t cnt = 0;
 #pragma unroll
@@ -262,20 +277,43 @@ MI_HD uint32_t rs_row_from_band(const int (&iy)[3], const float4 *band4, const f
             float pa[NC + 1], pb[NC + 1];
             pa[0] = pts[8 * ia]; pb[0] = pts[8 * ib];
 #pragma unroll
-            for (int c = 0; c < NC; c++) { pa[1 + c] = c < nc ? pts[8 * ia + k0 + c] : 0.f; pb[1 + c] = c < nc ? pts[8 * ib + k0 + c] : 0.f; }
+            for (int c = 0; c < NC; c++) { pa[1 + c] = pts[8 * ia + K0 + c]; pb[1 + c] = pts[8 * ib + K0 + c]; }
             scan_add_n<NC>(l, r, cnt, pa); scan_add_n<NC>(l, r, cnt, pb);
             continue;
         }
         const int rb = R.first > Y0 ? R.first : Y0;
-        const float *be = band + e * 16;
-        float v[NC + 1], d[NC + 1];
-        v[0] = be[0]; d[0] = be[1];
+        float4 q[4];
 #pragma unroll
-        for (int c = 0; c < NC; c++) { v[1 + c] = c < nc ? be[2 * (k0 + c)] : 0.f; d[1 + c] = c < nc ? be[2 * (k0 + c) + 1] : 0.f; }
+        for (int j4 = 0; j4 < 4; j4++) {
+            const bool need = j4 == 0 || (j4 >= K0 / 2 && j4 <= (K0 + NC - 1) / 2);
+            q[j4] = need ? band4[e * 4 + j4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float v[NC + 1], d[NC + 1];
+        v[0] = q[0].x; d[0] = q[0].y;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const float4 qq = q[(K0 + c) / 2];
+            v[1 + c] = ((K0 + c) & 1) ? qq.z : qq.x; d[1 + c] = ((K0 + c) & 1) ? qq.w : qq.y;
+        }
+#if RS_WALK_BITS
+        {   // (y - rb < RS_BH additions, by the bits of their number)
+            const int steps = y - rb;
+#pragma unroll
+            for (int bit = RS_BH / 2; bit >= 1; bit >>= 1)
+                if (steps & bit) {
+#pragma unroll
+                    for (int t = 0; t < bit; t++) {
+#pragma unroll
+                        for (int c = 0; c <= NC; c++) v[c] += d[c];
+                    }
+                }
+        }
+#else
         for (int j = y - rb; j > 0; j--) {
 #pragma unroll
             for (int c = 0; c <= NC; c++) v[c] += d[c];
         }
+#endif
         scan_add_n<NC>(l, r, cnt, v);
     }
     return cnt;
@@ -568,19 +606,23 @@ struct RsTileBins {
     MI_HD uint32_t pos(uint32_t e) const { return e < n0 ? o0 + e : o1 + (e - n0); }
 };
 
-MI_HD RsTileBins rs_tile_bins(const RsGrid &g, const RsBuffers &B, uint32_t frame, int tx, int ty)
+MI_HD RsTileBins rs_tile_bins_of(const RsBuffers &B, uint32_t o0, uint32_t n0, uint32_t o1, uint32_t n1)
 {
-    const uint32_t *off = B.offset + (size_t)frame * (g.n_bins + 1);
-    const int b0 = (ty / RS_CB) * g.cx + tx / RS_CB, b1 = g.n_coarse;
     RsTileBins L;
-    L.o0 = off[b0]; L.n0 = off[b0 + 1] - L.o0;
-    L.o1 = off[b1]; L.n1 = off[b1 + 1] - L.o1;
+    L.o0 = o0; L.n0 = n0; L.o1 = o1; L.n1 = n1;
     // (a bin cut short by bins_cap: the frame reports the overflow; never read beyond the buffer)
     if (L.o0 > B.bins_cap) L.o0 = B.bins_cap;
     if (L.o1 > B.bins_cap) L.o1 = B.bins_cap;
     if (L.n0 > B.bins_cap - L.o0) L.n0 = B.bins_cap - L.o0;
     if (L.n1 > B.bins_cap - L.o1) L.n1 = B.bins_cap - L.o1;
     return L;
+}
+
+MI_HD RsTileBins rs_tile_bins(const RsGrid &g, const RsBuffers &B, uint32_t frame, int tx, int ty)
+{
+    const uint32_t *off = B.offset + (size_t)frame * (g.n_bins + 1);
+    const int b0 = (ty / RS_CB) * g.cx + tx / RS_CB, b1 = g.n_coarse;
+    return rs_tile_bins_of(B, off[b0], off[b0 + 1] - off[b0], off[b1], off[b1 + 1] - off[b1]);
 }
 
 // phase 0 (thread = pixel): clear the tile's keys
@@ -670,7 +712,19 @@ MI_HD uint32_t rs_row_from_item(const RsDepthItem &it, int zi, int height, int y
         const int rb = R.first > Y0 ? R.first : Y0;
         float v[2] = {it.bw[e][0], it.bw[e][2]};
         const float d[2] = {it.bw[e][1], it.bw[e][3]};
+#if RS_WALK_BITS
+        {
+            const int steps = y - rb;
+#pragma unroll
+            for (int bit = RS_BH / 2; bit >= 1; bit >>= 1)
+                if (steps & bit) {
+#pragma unroll
+                    for (int t = 0; t < bit; t++) { v[0] += d[0]; v[1] += d[1]; }
+                }
+        }
+#else
         for (int j = y - rb; j > 0; j--) { v[0] += d[0]; v[1] += d[1]; }
+#endif
         scan_add_n<1>(l, r, cnt, v);
     }
     return cnt;
@@ -693,11 +747,13 @@ MI_HD void rs_tile_depth(const FrameParams &P, const RsBuffers &B, uint32_t n_tr
         q.tri = li[0];
         q.rec = (const float *)(B.rec + ((size_t)frame * n_tris + q.tri) * RS_REC4);
         const float *band = (const float *)rs_band_of(B, frame, (int)(li[1] & 0xffffu), li[2], y);
-        q.iy[0] = (int)ff_f2u(q.rec[24]); q.iy[1] = (int)ff_f2u(q.rec[25]); q.iy[2] = (int)ff_f2u(q.rec[26]);
+        const float4 r6 = ((const float4 *)q.rec)[6];
+        q.iy[0] = (int)ff_f2u(r6.x); q.iy[1] = (int)ff_f2u(r6.y); q.iy[2] = (int)ff_f2u(r6.z);
 #pragma unroll
         for (int e = 0; e < 3; e++) {
-            const float *be = band + e * 16;
-            q.bw[e][0] = be[0]; q.bw[e][1] = be[1]; q.bw[e][2] = be[2 * ZI]; q.bw[e][3] = be[2 * ZI + 1];
+            const float2 *be = (const float2 *)(band + e * 16);           // (value, step) pairs
+            const float2 bx = be[0], bz = be[ZI];
+            q.bw[e][0] = bx.x; q.bw[e][1] = bx.y; q.bw[e][2] = bz.x; q.bw[e][3] = bz.y;
         }
     };
     RsDepthItem cur, nxt;
@@ -720,6 +776,15 @@ MI_HD void rs_tile_depth(const FrameParams &P, const RsBuffers &B, uint32_t n_tr
             unsigned long long *krow = lds.keys + row * RS_TW - X0;
             float d = 0.f, z = l[1];
             if (!s.single) z = rs_span_value(s, l[1], r[1], xa - s.x1, d);
+#if RS_DEPTH_FLAT
+            ztests += (unsigned long long)(xb - xa + 1);
+#pragma unroll
+            for (int k = 0; k < RS_TW; k++) {
+                if (xa + k <= xb && z > 0.f)                 // only 1/z > 0 can beat the cleared Z-buffer (Screen.h:209)
+                    RS_ATOMIC_MAX_U64(&krow[xa + k], ((unsigned long long)ff_f2u(z) << 32) | trikey);
+                z += d;                                      // (beyond the span's end: not used)
+            }
+#else
             for (int x = xa;; x++) {
                 ztests++;
                 if (z > 0.f)                                 // only 1/z > 0 can beat the cleared Z-buffer (Screen.h:209)
@@ -727,6 +792,7 @@ MI_HD void rs_tile_depth(const FrameParams &P, const RsBuffers &B, uint32_t n_tr
                 if (x == xb) break;
                 z += d;
             }
+#endif
         } while (0);
         if (more) cur = nxt;
     }
@@ -750,38 +816,68 @@ MI_HD void rs_tile_runs(RsTileLds &lds, int tid, int nt)
 // phase 3b: one work item = one group of interpolants of one run: the scanline's end points for projx (it orders the
 // edges) and the group, the span's values at the run's first pixel, then the run -- the same evaluation as the depth pass.
 // Groups: {1,2,3} {4,5,6,7} of the Phong fat point, {1,2} {3,4} of the colour one.
+template <int MODE, int K0, int NC>
+MI_HD void rs_attr_item(const FrameParams &P, const RsBuffers &B, uint32_t n_tris, uint32_t frame, int tx, int ty, RsTileLds &lds, uint32_t run)
+{
+    const int i = (int)(run & ((1u << RS_PIX_BITS) - 1u)), len = (int)(run >> RS_PIX_BITS) + 1;
+    const int px = i % RS_TW, row = i / RS_TW;
+    const uint32_t tri = 0xffffffffu - (uint32_t)(lds.keys[i] & 0xffffffffull);
+    const float4 *rec4 = B.rec + ((size_t)frame * n_tris + tri) * RS_REC4;
+    const float4 r6 = rec4[6];                                              // the scanlines of the corners, the first band record
+    const int iy[3] = {(int)ff_f2u(r6.x), (int)ff_f2u(r6.y), (int)ff_f2u(r6.z)};
+    const int y = ty * RS_TH + row, x = tx * RS_TW + px;
+    float l[NC + 1], r[NC + 1];
+    int miny = iy[0] < iy[1] ? iy[0] : iy[1]; miny = miny < iy[2] ? miny : iy[2];
+    const uint32_t cnt = rs_row_from_band<K0, NC>(iy, rs_band_of(B, frame, miny < 0 ? 0 : miny, ff_f2u(r6.w), y), (const float *)rec4, P.H, y, l, r);
+    RsSpan s;
+    if (!cnt || !rs_span(l[0], r[0], cnt, P.W, s)) return;                  // (cannot happen: the key came from this scanline)
+#if RS_ATTR_ONE_LOOP
+    float v[NC], d[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        d[c] = 0.f; v[c] = l[1 + c];
+        if (!s.single) v[c] = rs_span_value(s, l[1 + c], r[1 + c], x - s.x1, d[c]);
+    }
+    for (int j = 0;; j++) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) lds.gbuf[K0 + c][i + j] = v[c];
+        if (j == len - 1) break;
+#pragma unroll
+        for (int c = 0; c < NC; c++) v[c] += d[c];
+    }
+#else
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        float d = 0.f, v = l[1 + c];
+        if (!s.single) v = rs_span_value(s, l[1 + c], r[1 + c], x - s.x1, d);
+        float *g = lds.gbuf[K0 + c] + i;
+        for (int j = 0;; j++) {
+            g[j] = v;
+            if (j == len - 1) break;
+            v += d;
+        }
+    }
+#endif
+}
+
+// The items over the block: wave-sized pieces of ONE group each (piece v: runs 64 (v / 2) .., group v & 1), so that a wave never
+// runs both groups' code -- the interpolants of a group are compile-time constants of its code (whole float4 of the band record
+// instead of words picked by a run-time index, no per-interpolant bounds checks): round 6, 1 673 -> ~1 100 instructions per pass.
 template <int MODE>
 MI_HD void rs_tile_attr(const FrameParams &P, const RsBuffers &B, uint32_t n_tris, uint32_t frame, int tx, int ty, RsTileLds &lds, int tid, int nt)
 {
     constexpr int N = FatN<MODE>::N;
-    constexpr int NC = N == 8 ? 4 : 2;
-    const uint32_t n = lds.n_runs * 2u;
-    for (uint32_t it = (uint32_t)tid; it < n; it += (uint32_t)nt) {
-        const uint32_t run = lds.items[it >> 1];
-        const int grp = (int)(it & 1u);
-        const int k0 = N == 8 ? (grp ? 4 : 1) : (grp ? 3 : 1), nc = N == 8 ? (grp ? 4 : 3) : 2;
-        const int i = (int)(run & ((1u << RS_PIX_BITS) - 1u)), len = (int)(run >> RS_PIX_BITS) + 1;
-        const int px = i % RS_TW, row = i / RS_TW;
-        const uint32_t tri = 0xffffffffu - (uint32_t)(lds.keys[i] & 0xffffffffull);
-        const float *rec = (const float *)(B.rec + ((size_t)frame * n_tris + tri) * RS_REC4);
-        const int iy[3] = {(int)ff_f2u(rec[24]), (int)ff_f2u(rec[25]), (int)ff_f2u(rec[26])};
-        const int y = ty * RS_TH + row, x = tx * RS_TW + px;
-        float l[NC + 1], r[NC + 1];
-        int miny = iy[0] < iy[1] ? iy[0] : iy[1]; miny = miny < iy[2] ? miny : iy[2];
-        const uint32_t cnt = rs_row_from_band<NC>(iy, rs_band_of(B, frame, miny < 0 ? 0 : miny, ff_f2u(rec[27]), y), rec, k0, nc, P.H, y, l, r);
-        RsSpan s;
-        if (!cnt || !rs_span(l[0], r[0], cnt, P.W, s)) continue;            // (cannot happen: the key came from this scanline)
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
-            if (c >= nc) break;
-            float d = 0.f, v = l[1 + c];
-            if (!s.single) v = rs_span_value(s, l[1 + c], r[1 + c], x - s.x1, d);
-            float *g = lds.gbuf[k0 + c] + i;
-            for (int j = 0;; j++) {
-                g[j] = v;
-                if (j == len - 1) break;
-                v += d;
-            }
+    const uint32_t n_runs = lds.n_runs, pieces = 2u * ((n_runs + 63u) / 64u);
+    for (uint32_t v = (uint32_t)tid >> 6; v < pieces; v += (uint32_t)nt >> 6) {
+        const uint32_t ri = (v >> 1) * 64u + ((uint32_t)tid & 63u);
+        if (ri >= n_runs) continue;
+        const uint32_t run = lds.items[ri];
+        if (N == 8) {
+            if (v & 1u) rs_attr_item<MODE, 4, 4>(P, B, n_tris, frame, tx, ty, lds, run);
+            else rs_attr_item<MODE, 1, 3>(P, B, n_tris, frame, tx, ty, lds, run);
+        } else {
+            if (v & 1u) rs_attr_item<MODE, 3, 2>(P, B, n_tris, frame, tx, ty, lds, run);
+            else rs_attr_item<MODE, 1, 2>(P, B, n_tris, frame, tx, ty, lds, run);
         }
     }
 }
