@@ -377,12 +377,12 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
     __shared__ RsTileLds lds;
     const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
     const bool prof = P.counters && P.raster_stats;
-    unsigned long long tl[12];           // RS_TILELOG: start, first tile: taken, cleared, filtered, staged, depth done, runs, attributes, shaded; block's end; bin entries | kept << 32, tile
+    unsigned long long tl[12], tl_last;  // RS_TILELOG: start; the first tile's time in taking it, clearing, filtering, staging, depth, runs, attributes, shading (summed over passes); the block's end; bin entries | kept << 32, tile
 #pragma unroll
     for (int i = 0; i < 12; i++) tl[i] = 0ull;
-    tl[0] = RS_LOG_NOW();
+    tl[0] = tl_last = RS_LOG_NOW();
     bool tl_first = true;
-#define RS_TL(i) do { if (RS_TILELOG && tl_first) tl[i] = RS_LOG_NOW(); } while (0)
+#define RS_TL(i) do { if (RS_TILELOG && tl_first) { const unsigned long long now_ = RS_LOG_NOW(); tl[i] += now_ - tl_last; tl_last = now_; } } while (0)
     unsigned long long acc[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0ull;
@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
         bool any = false;
         int parity = 0;
         for (uint32_t first = 0; first < total; first += RS_LIST_CAP) {
-            rs_tile_filter(B, f, tx, ty, L, first, lds, tid, nt);
+            rs_tile_filter(B, f, tx, ty, L, first, parity, lds, tid, nt);
             __syncthreads();
             RS_PROF_MARK(1);
             RS_TL(3);
@@ -442,8 +442,10 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
             any = any || nl != 0u;
             if (prof && tid == 0) acc[10] += nl;
             for (uint32_t chunk = 0; chunk < nl; chunk += RS_CHUNK) {
-                rs_tile_stage(ty, chunk, nl, parity, lds, tid, nt);
-                __syncthreads();
+                if (chunk) {                                  // (the first chunk was staged by the filter)
+                    rs_tile_stage(ty, chunk, nl, parity, lds, tid, nt);
+                    __syncthreads();
+                }
                 RS_PROF_MARK(2);
                 RS_TL(4);
                 if (prof && tid == 0) acc[11] += lds.n_items[parity];
@@ -985,7 +987,10 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     if (blocks > 2048) blocks = 2048;
     // threads per tile: mi355_opts::tune[3] (64..512, whole waves), default 256
     const int nt = P->rs_threads >= 64 && P->rs_threads <= RS_MAX_THREADS && (P->rs_threads & 63) == 0 ? P->rs_threads : 256;
-    if (whole) hipExtLaunchKernelGGL((k_rs_tile<MODE, 4>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, nullptr, tile_done, 0, *S, *P, d_batch, n_frames, g, s->B, 1);
+#ifndef RS_SINGLE_OCC
+#define RS_SINGLE_OCC 4
+#endif
+    if (whole) hipExtLaunchKernelGGL((k_rs_tile<MODE, RS_SINGLE_OCC>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, nullptr, tile_done, 0, *S, *P, d_batch, n_frames, g, s->B, 1);
     else if (n_frames > 1) hipLaunchKernelGGL((k_rs_tile<MODE, 5>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B, 0);
     else hipLaunchKernelGGL((k_rs_tile<MODE, 4>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B, 0);
     mi355i_prof_lap(4);

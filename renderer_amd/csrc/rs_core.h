@@ -52,6 +52,9 @@
 #ifndef RS_ATTR_ONE_LOOP
 #define RS_ATTR_ONE_LOOP 1    // a run's interpolants are stored by one loop over its pixels instead of a loop per interpolant
 #endif
+#ifndef RS_RUNS_BALLOT
+#define RS_RUNS_BALLOT 1      // the runs of a tile's scanlines from wave-wide bit masks instead of a loop per pixel (device only: the host emulation
+#endif                        // of tests/emu runs a block thread by thread and keeps the loop)
 #ifndef RS_DEPTH_FLAT
 #define RS_DEPTH_FLAT 1       // a depth item's <= RS_TW pixels as straight predicated code instead of a loop
 #endif
@@ -633,7 +636,10 @@ MI_HD void rs_tile_clear(RsTileLds &lds, int tid, int nt)
 }
 
 // phase 1: bin entries [first, first + RS_LIST_CAP) of the tile's bins -> LDS list of the triangles whose box touches the tile
-MI_HD void rs_tile_filter(const RsBuffers &B, uint32_t frame, int tx, int ty, const RsTileBins &L, uint32_t first, RsTileLds &lds, int tid, int nt)
+// The first RS_CHUNK triangles of the list are staged on the spot (phase 2a: their work items, one per scanline of the tile): the
+// thread that accepts a triangle has its scanlines in registers, and most tiles keep fewer than RS_CHUNK triangles -- their
+// staging phase and its barrier are gone (round 6: 1.5 us of a tile's ~15).
+MI_HD void rs_tile_filter(const RsBuffers &B, uint32_t frame, int tx, int ty, const RsTileBins &L, uint32_t first, int parity, RsTileLds &lds, int tid, int nt)
 {
     const int ya = ty * RS_TH, yb = ty * RS_TH + RS_TH - 1;
     const uint32_t n = L.total();
@@ -650,14 +656,21 @@ MI_HD void rs_tile_filter(const RsBuffers &B, uint32_t frame, int tx, int ty, co
             if (e0 + (uint32_t)u * (uint32_t)nt >= end) break;
             const int tx0 = (int)(b[u].y & 0xffffu), tx1 = (int)(b[u].y >> 16), y0 = (int)(b[u].z & 0xffffu), y1 = (int)(b[u].z >> 16);
             if (tx >= tx0 && tx <= tx1 && yb >= y0 && ya <= y1) {
-                uint32_t *li = lds.list[RS_ATOMIC_ADD_U32(&lds.n_list, 1u)];
+                const uint32_t slot = RS_ATOMIC_ADD_U32(&lds.n_list, 1u);
+                uint32_t *li = lds.list[slot];
                 li[0] = b[u].x; li[1] = b[u].z; li[2] = b[u].w;
+                if (slot < RS_CHUNK) {
+                    const int ys = y0 > ya ? y0 : ya, ye = y1 < yb ? y1 : yb;
+                    const uint32_t base = RS_ATOMIC_ADD_U32(&lds.n_items[parity], (uint32_t)(ye - ys + 1));
+                    for (int y = ys; y <= ye; y++) lds.items[base + (uint32_t)(y - ys)] = (uint16_t)((slot << 4) | (uint32_t)(y - ya));
+                }
             }
         }
     }
 }
 
-// phase 2a (thread = slot of the chunk): list entry `chunk + tid` -> one work item per scanline of the tile it touches
+// phase 2a (thread = slot of the chunk): list entry `chunk + tid` -> one work item per scanline of the tile it touches (chunks
+// behind the first: rs_tile_filter stages the first one itself)
 MI_HD void rs_tile_stage(int ty, uint32_t chunk, uint32_t n_list, int parity, RsTileLds &lds, int tid, int nt)
 {
     // (a block of fewer than RS_CHUNK threads takes several slots per thread: round 4 staged only the first `nt` entries of a
@@ -801,6 +814,31 @@ MI_HD void rs_tile_depth(const FrameParams &P, const RsBuffers &B, uint32_t n_tr
 // phase 3a (thread = pixel): list the runs of pixels one triangle owns on a scanline (pixel of the first | length - 1 << 8)
 MI_HD void rs_tile_runs(RsTileLds &lds, int tid, int nt)
 {
+#if defined(__HIP_DEVICE_COMPILE__) && RS_RUNS_BALLOT
+    // A wave holds 64 consecutive pixels = four whole scanlines of the tile (nt is a multiple of 64): where a run starts is one bit
+    // per lane (the pixel is the tile's first column, or its neighbour on the left belongs to another triangle), a run's length the
+    // distance to the next such bit -- no loop over the pixels, one list append per wave.  (The low word of a key is ~triangle: never
+    // zero for a triangle, zero for the background.)
+    static_assert(RS_TW == 16 && (64 % RS_TW) == 0, "a wave holds whole scanlines");
+    for (int i = tid; i < RS_TPIX; i += nt) {
+        const int lane = i & 63;
+        const uint32_t low = (uint32_t)(lds.keys[i] & 0xffffffffull);
+        const uint32_t left = (uint32_t)__shfl_up((int)low, 1);
+        const bool edge = (i % RS_TW) == 0 || left != low;
+        const unsigned long long edges = __ballot(edge);
+        const bool start = edge && low != 0u;
+        const unsigned long long starts = __ballot(start);
+        if (!starts) continue;
+        const unsigned long long behind = lane == 63 ? 0ull : edges >> (lane + 1);
+        const int len = behind ? __ffsll((long long)behind) : 64 - lane;          // (the next scanline's first column is an edge)
+        uint32_t base = 0;
+        const int leader = __ffsll((long long)starts) - 1;
+        if (lane == leader) base = atomicAdd(&lds.n_runs, (uint32_t)__popcll(starts));
+        base = (uint32_t)__shfl((int)base, leader);
+        if (start) lds.items[base + (uint32_t)__popcll(starts & ((1ull << lane) - 1ull))] = (uint16_t)((uint32_t)i | ((uint32_t)(len - 1) << RS_PIX_BITS));
+    }
+    return;
+#endif
     for (int i = tid; i < RS_TPIX; i += nt) {
         const unsigned long long key = lds.keys[i];
         if (!key) continue;

@@ -31,33 +31,25 @@ def fetch():
 
 
 def report(tag, a, t_ref=None):
-    """a: the 2 048 records of one frame"""
+    """a: the 2 048 records of one frame: [0] start, [1..8] time of the first tile's phases, [9] end, [10] entries | kept << 32, [11] tile"""
     tile = a[a[:, 9] > 0]
     busy = tile[tile[:, 2] > 0]                                   # blocks that drew a tile
     setup = a[a[:, 13] > 0][:, 12:14]; fill = a[a[:, 15] > 0][:, 14:16]
     t0 = setup[:, 0].min() if len(setup) else tile[:, 0].min()
     us = lambda v: (v - t0) / 100.0
     names = ["taken", "cleared", "filtered", "staged", "depth", "runs", "attr", "shaded"]
+    life = busy[:, 1:9].sum(axis=1) / 100.0
     d = {"frame": tag, "frame_start_us_abs": round(float((t0 - (t_ref or t0)) / 100.0), 1),
-         "setup_blocks": int(len(setup)), "setup_start_us": q(us(setup[:, 0])), "setup_end_us": q(us(setup[:, 1])),
-         "fill_blocks": int(len(fill)), "fill_start_us": q(us(fill[:, 0])), "fill_end_us": q(us(fill[:, 1])),
-         "tile_blocks": int(len(tile)), "busy_tiles": int(len(busy)), "tile_start_us": q(us(tile[:, 0])), "busy_tile_end_us": q(us(busy[:, 8])),
-         "kernel_end_us": round(float(us(tile[:, 9]).max()), 1)}
-    life = (busy[:, 8] - busy[:, 0]) / 100.0
-    d["busy_tile_life_us"] = q(life)
-    prev = busy[:, 0]
+         "setup_end_us": q(us(setup[:, 1])), "fill_start_us": q(us(fill[:, 0])), "fill_end_us": q(us(fill[:, 1])),
+         "busy_tiles": int(len(busy)), "tile_start_us": q(us(tile[:, 0])), "busy_tile_end_us": q(us(busy[:, 0]) + life),
+         "kernel_end_us": round(float(us(tile[:, 9]).max()), 1), "busy_tile_life_us": q(life), "sum_busy_life_us": round(float(life.sum()))}
     for i, nm in enumerate(names):
-        cur = busy[:, 1 + i]
-        ok = cur > 0
-        d["phase_" + nm + "_us"] = q(((cur - prev) / 100.0)[ok])
-        prev = np.where(ok, cur, prev)
-    # slot-time: the sum of the blocks' lives over the chip's slots x the frame's span
-    d["sum_tile_life_us"] = round(float(((tile[:, 9] - tile[:, 0]) / 100.0).sum()), 0)
+        d["phase_" + nm + "_us"] = q(busy[:, 1 + i] / 100.0)
+    d["phase_means_us"] = {nm: round(float(busy[:, 1 + i].mean() / 100.0), 2) for i, nm in enumerate(names)}
     d["entries_read_mean_max"] = [round(float((busy[:, 10] % 2 ** 32).mean()), 1), float((busy[:, 10] % 2 ** 32).max())]
-    # the longest tiles
     order = np.argsort(-life)[:3]
     d["longest"] = [{"life_us": round(float(life[i]), 1), "entries": int(busy[i, 10] % 2 ** 32), "kept": int(busy[i, 10] // 2 ** 32),
-                     "phases_us": [round(float((busy[i, 1 + k] - busy[i, k]) / 100.0), 1) for k in range(8)]} for i in order]
+                     "phases_us": [round(float(busy[i, 1 + k] / 100.0), 1) for k in range(8)]} for i in order]
     print(json.dumps(d), flush=True)
     return t0
 

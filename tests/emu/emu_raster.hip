@@ -10,6 +10,9 @@
 #include <cstring>
 #include <vector>
 
+// tiles of the last call that read their bins in more than one pass / staged their list in more than one chunk (tests look at them)
+extern "C" { unsigned emu_multi_pass_tiles = 0, emu_multi_chunk_tiles = 0; }
+
 namespace {
 
 int count_rows(const mi355_opts &o)
@@ -103,16 +106,18 @@ void run(const DevScene &S, const std::vector<FrameParams> &F, const RsGrid &g, 
 #define ALL_THREADS(stmt) for (int tid = 0; tid < nt; tid++) { stmt; }
 #define ALL_THREADS_REVERSED(stmt) for (int tid = nt - 1; tid >= 0; tid--) { stmt; }
                 if (!total) continue;                          // background: cleared by rs_setup
+                if (total > RS_LIST_CAP) emu_multi_pass_tiles++;
                 memset(&lds, 0xcd, sizeof lds);                // LDS is not initialised on the device either
                 ALL_THREADS(rs_tile_clear(lds, tid, nt));
                 bool any = false;
                 int parity = 0;
                 for (uint32_t first = 0; first < total; first += RS_LIST_CAP) {
-                    ALL_THREADS_REVERSED(rs_tile_filter(B, (uint32_t)f, tx, ty, L, first, lds, tid, nt));      // (any thread order)
+                    ALL_THREADS_REVERSED(rs_tile_filter(B, (uint32_t)f, tx, ty, L, first, parity, lds, tid, nt));      // (any thread order)
                     const uint32_t nl = lds.n_list;
                     any = any || nl != 0u;
+                    if (nl > RS_CHUNK) emu_multi_chunk_tiles++;
                     for (uint32_t chunk = 0; chunk < nl; chunk += RS_CHUNK) {
-                        ALL_THREADS_REVERSED(rs_tile_stage(ty, chunk, nl, parity, lds, tid, nt));
+                        if (chunk) ALL_THREADS_REVERSED(rs_tile_stage(ty, chunk, nl, parity, lds, tid, nt));
                         ALL_THREADS(rs_tile_depth<MODE>(F[f], B, S.n_tris, (uint32_t)f, tx, ty, chunk, parity, lds, tid, nt, zt));
                         lds.n_items[parity ^ 1] = 0u;
                         if (chunk + RS_CHUNK >= nl) lds.n_list = 0u;
@@ -137,6 +142,7 @@ extern "C" int emu_raster(uint32_t n_tris, uint32_t n_verts, const float *rs_tri
                           unsigned long long *stats4, uint32_t bins_cap, unsigned long long *overflow, uint32_t band_cap_arg)
 {
     DevScene S;
+    emu_multi_pass_tiles = emu_multi_chunk_tiles = 0;
     memset(&S, 0, sizeof S);
     S.n_tris = n_tris; S.n_verts = n_verts;
     S.rs_tri = (const float4 *)rs_tri; S.rs_col = (const float4 *)rs_col; S.rs_idx = (const uint4 *)rs_idx; S.rs_vert = (const float4 *)rs_vert;
