@@ -636,6 +636,8 @@ int mi355_light_update(mi355_ctx *c, int slot, const float pos[3], int size, mi3
     // behind every frame enqueued so far, wherever it runs (the frames' own streams carry ev_tile; the caller's stream orders itself)
     for (int k = 0; k < mi355_ctx::PIPE_SETS; k++) if (c->ev_tile_set[k]) HIP_TRY(hipStreamWaitEvent(st, c->ev_tile[k], 0), -40);
     for (auto &a : c->slot) if (a.busy && a.ev1) HIP_TRY(hipStreamWaitEvent(st, a.ev1, 0), -40);      // (frames of mi355_render_async still in flight)
+    static const bool wavelog = getenv("MI355_WAVELOG") != nullptr;       // (measuring builds: RS_TILELOG)
+    if (wavelog && c->wave_prof.ensure((size_t)8 * c->n_cus * 4 * 16 * 8) == hipSuccess) { mi355i_raster_set_log(c->rs_light, (unsigned long long *)c->wave_prof.p); c->last_blocks = 8192; }
     const hipError_t e = mi355i_launch_shadowmap(&c->dev, l.pos, l.world_to_light, size, (float *)c->smap[slot].p, c->rs_light, st);
     if (e != hipSuccess) return fail(-43, "shadow map launch failed: %s", hipGetErrorString(e));
     HIP_TRY(hipEventRecord(c->ev_light, st), -40);

@@ -53,6 +53,7 @@ extern "C" hipError_t mi355i_launch_raster_overlapped(const DevScene *S, const F
 extern "C" hipError_t mi355i_launch_frame_copy(uint32_t *dst, const uint32_t *src, int W, int rows, int pitch_words, hipStream_t st, hipEvent_t done);
 extern "C" hipError_t mi355i_launch_frames_copy(void *const *dst, int n_frames, const uint32_t *src, int W, int rows, int pitch_words, hipStream_t st, hipEvent_t done);
 extern "C" int mi355i_raster_grow(RasterScratch *);
+extern "C" void mi355i_raster_set_log(RasterScratch *, unsigned long long *);
 
 namespace mi355i {
 

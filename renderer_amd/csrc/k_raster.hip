@@ -43,6 +43,7 @@ struct RasterScratch {
     uint32_t *ctl = nullptr;       // [0] rows used, [1] rows dropped because the row buffer was full; the tile kernels: a pair per parity (below)
     int ctl_pair = 0;              // the pair of control words the last launch of the tile kernels used (the launch clears the other one for the next)
     uint32_t *smkeys = nullptr; size_t sm_words = 0;
+    unsigned long long *sm_log = nullptr;   // RS_TILELOG builds: where k_sm_tiles' blocks write their clocks (mi355i_raster_set_log), else NULL
 };
 
 namespace {
@@ -537,6 +538,12 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
 // edge walkers to the item's row with ff_add -- the exact result of the reference's repeated `vtc += d12` (ScanConverter.h:
 // 112-116) without taking the steps -- and walks the row's span; spans of more than SM_LONG pixels are cut into 64 pieces by
 // the whole wave, each piece starting from ff_add of the span's first pixel.  Same plots, same values, same maximum.
+#ifndef SMT_LONG
+#define SMT_LONG 48     // k_sm_tiles: a span with more pixels ahead in its tile than this may be walked by the whole wave ...
+#endif
+#ifndef SMT_COOP
+#define SMT_COOP 8      // ... if that is more than this many per long span the wave holds
+#endif
 #define SM_LONG 48
 #ifndef SM_COOP
 #define SM_COOP 64      // a span is taken by the whole wave only if it is longer than this many pixels per long span the wave holds
@@ -757,34 +764,90 @@ __global__ void __launch_bounds__(256) k_sm_prep(const DevScene S, const ShadowP
 }
 
 __global__ void __launch_bounds__(SMT_T) k_sm_tiles(const ShadowParams Q, const SmPrep *prep, const uint2 *bbox, const uint32_t *table, uint32_t n_blocks, const uint4 *ids,
-                                                  uint32_t ids_cap, float *map, uint32_t *ctl_next)
+                                                  uint32_t ids_cap, float *map, uint32_t *ctl_next, unsigned long long *log)
 {
+    // (RS_TILELOG builds, scripts/sm_tilelog.py: thread 0's clock at the block's start and the time it spent up to the cleared keys, in the
+    //  lists' scan, in collecting the tile's triangles, in drawing them, in storing the tile; entries seen, triangles kept)
+    unsigned long long tl[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, tl_last = RS_LOG_NOW();
+    tl[0] = tl_last;
+#define SM_TL(i) do { if (RS_TILELOG && log) { const unsigned long long now_ = RS_LOG_NOW(); tl[i] += now_ - tl_last; tl_last = now_; } } while (0)
     __shared__ uint32_t keys[SMT_H][SMT_W];
     __shared__ uint32_t list[SMT_LIST], list_rows[SMT_LIST];
-    __shared__ uint32_t n_list;
+    __shared__ uint32_t n_list, n_tall;      // short triangles of the round (from the list's back), tall ones (from its front)
     __shared__ uint32_t seg_start[SMT_T], seg_pre[SMT_T + 1], seg_tot[SMT_T / 64];
     const int tid = (int)threadIdx.x, SM = Q.size;
     const int tiles_x = (SM + SMT_W - 1) / SMT_W, n_bands = (SM + SMT_H - 1) / SMT_H;
-    const int tx = (int)(blockIdx.x % (uint32_t)tiles_x), ty = (int)(blockIdx.x / (uint32_t)tiles_x);
+    // (Round 6, measured: the tiles dealt out in steps coprime to their number, so that no CU holds four neighbours of a mesh's heavy
+    //  region -- 83 -> 102 us for the chessboard: the blocks that do not fit the chip at once start 20-40 us late and were then heavy ones;
+    //  a heavy tile's time is its own longest spans, not its neighbours'.)
+    const uint32_t tile_i = blockIdx.x;
+    const int tx = (int)(tile_i % (uint32_t)tiles_x), ty = (int)(tile_i / (uint32_t)tiles_x);
     const int X0 = tx * SMT_W, Y0 = ty * SMT_H;
     const int X1 = (X0 + SMT_W < SM ? X0 + SMT_W : SM) - 1, Y1 = (Y0 + SMT_H < SM ? Y0 + SMT_H : SM) - 1;
     for (int i = tid; i < SMT_H * SMT_W; i += SMT_T) keys[0][i] = ~0xFEFEFEFEu;             // Light::ClearShadowBuffer: bytes 0xFE (Light.h:48-52)
-    if (tid == 0) n_list = 0u;
+    if (tid == 0) { n_list = 0u; n_tall = 0u; }
     if (blockIdx.x == 0 && tid < 2) ctl_next[tid] = 0u;       // (the next launch's counters: k_sm_prep of THIS launch has finished with its own pair)
     __syncthreads();
+    SM_TL(1);
     const auto drain = [&]() {       // the triangles of the list over the threads
-        const uint32_t n = n_list < SMT_LIST ? n_list : SMT_LIST;
+        // Tall triangles (more than FF_ADD_LOOP_MAX rows: their walkers may take ff_add's binade jumps, and their spans are the long ones)
+        // sit at the list's front, the others at its back, and the two kinds are dealt to different waves: a wave of short triangles'
+        // items never enters the jump loops (six of them per item), and the long spans start first.  (Round 6.)
+        const uint32_t n_t = n_tall < SMT_LIST ? n_tall : SMT_LIST, n_s = n_list < SMT_LIST - n_t ? n_list : SMT_LIST - n_t;
+        const uint32_t first_short = (n_t * SMT_H + 63u) & ~63u;             // (items; a wave's 64 items are of one kind)
         // (a thread per (triangle, row of the tile): a thread that took a triangle's rows one after the other made the chessboard's
         //  large triangles twice as slow, 142 -> 284 us)
-        for (uint32_t it = (uint32_t)tid; it < n * SMT_H; it += SMT_T) {
+        // Long spans are walked by the whole wave (round 6: a lane that walks 500 pixels alone -- the chessboard's squares -- keeps its
+        // wave for ~10 000 instructions; a heavy tile of that map spent 68 of its 74 us on two such rounds): the lanes bring their items
+        // to the span (sm_tile_span), walk the short ones themselves, and the long ones one after the other in 64 pieces, each piece
+        // from ff_add's jump to its first pixel -- a span's x never decreases, so every pixel of it inside the tile's columns is offered
+        // whoever walks it.  All 64 lanes stay in the loop (the pieces need them): no lane leaves early.
+        const int lane = tid & 63;
+        const uint32_t n_items = first_short + n_s * SMT_H;
+        for (uint32_t it0 = (uint32_t)(tid & ~63); it0 < n_items; it0 += SMT_T) {
+            const uint32_t it = it0 + (uint32_t)lane;
             const int y = Y0 + (int)(it % SMT_H);
-            const uint32_t rows = list_rows[it / SMT_H];
-            if (y > Y1 || y < (int)(rows & 0xffffu) || y > (int)(rows >> 16)) continue;
+            bool have = it < n_items;
+            uint32_t en = 0;
+            if (it < first_short) { en = it / SMT_H; have = have && en < n_t; }
+            else en = SMT_LIST - 1u - (it - first_short) / SMT_H;
+            if (have) { const uint32_t rows = list_rows[en]; have = !(y > Y1 || y < (int)(rows & 0xffffu) || y > (int)(rows >> 16)); }
             // (sm_core.h: the three edge walkers brought to row y, Light.cc's edge order and truncations, the span entered at the tile's
             //  first column; the keys of the tile's row take the maximum)
-            uint32_t *row = keys[y - Y0];
-            const SmPrep P = prep[list[it / SMT_H]];                         // (loaded whole, up front: six 16-byte loads)
-            sm_tile_row(P, SM, y, X0, X1, [&](int x, float z) { atomicMax(&row[x - X0], f2key(z)); });
+            SmSpan S; S.sx = S.sz = S.dx = S.dz = 0.f; S.j = 0; S.steps = -1;
+            bool walk = false;
+            if (have) {
+                uint32_t *row = keys[y - Y0];
+                const SmPrep P = prep[list[en]];                             // (loaded whole, up front: six 16-byte loads)
+                walk = sm_tile_span(P, SM, y, X0, X1, [&](int x, float z) { atomicMax(&row[x - X0], f2key(z)); }, S);
+            }
+            // pixels of the span still ahead inside the tile (an estimate that errs on the long side: the last piece stops by itself)
+            int ahead = 0;
+            if (walk) {
+                ahead = S.steps - S.j + 1;
+                if (ahead > SMT_LONG && S.dx > 0.f) { const float e = ((float)(X1 + 1) - S.sx) / S.dx + 4.f; if (e < (float)ahead) ahead = e > 1.f ? (int)e : 1; }
+            }
+            bool is_long = walk && ahead > SMT_LONG && S.steps < (1 << 22);      // (ff_add's jumps are exact for chains below 2^22)
+            { const int n_long = __popcll(__ballot(is_long)); is_long = is_long && ahead > n_long * SMT_COOP; }
+            if (walk && !is_long) { uint32_t *row = keys[y - Y0]; sm_span_walk(S, X0, X1, [&](int x, float z) { atomicMax(&row[x - X0], f2key(z)); }); }
+            unsigned long long todo = __ballot(is_long);
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                SmSpan B;
+                B.sx = __shfl(S.sx, src); B.sz = __shfl(S.sz, src); B.dx = __shfl(S.dx, src); B.dz = __shfl(S.dz, src);
+                B.j = __shfl(S.j, src); B.steps = __shfl(S.steps, src);
+                const int n = __shfl(ahead, src), by = __shfl(y, src);
+                uint32_t *brow = keys[by - Y0];
+                const int per = (n + 63) >> 6, k0 = lane * per;              // this lane: pixels B.j + k0 .. of the span
+                if (k0 < n) {
+                    SmSpan Q = B;
+                    Q.sx = ff_add(B.sx, B.dx, k0); Q.sz = ff_add(B.sz, B.dz, k0); Q.j = B.j + k0;
+                    // (the last piece runs to the span's end, or until it has left the tile's columns: sm_span_walk's own stop)
+                    if (k0 + per < n && Q.j + per - 1 < B.steps) Q.steps = Q.j + per - 1;
+                    sm_span_walk(Q, X0, X1, [&](int x, float z) { atomicMax(&brow[x - X0], f2key(z)); });
+                }
+            }
         }
         // (a thread per 128 or 64 columns of a span as well -- the chessboard's spans cross the whole tile -- gave the chessboard nothing
         //  and doubled and tripled the dragon: the lanes that skip their item wait for the ones that do not)
@@ -824,7 +887,9 @@ __global__ void __launch_bounds__(SMT_T) k_sm_tiles(const ShadowParams Q, const 
             if (tid == 0) seg_pre[SMT_T] = total;
             __syncthreads();
         }
+        SM_TL(2);
         const uint32_t total = seg_pre[SMT_T];
+        if (RS_TILELOG && log) tl[6] += total;
         for (uint32_t e0 = 0; e0 < total; e0 += SMT_LIST) {
             for (uint32_t e = e0 + (uint32_t)tid; e < total && e < e0 + SMT_LIST; e += SMT_T) {
                 int lo = 0, hi = SMT_T - 1;                          // the list entry e belongs to: the last one that starts at or before it
@@ -832,12 +897,19 @@ __global__ void __launch_bounds__(SMT_T) k_sm_tiles(const ShadowParams Q, const 
                 const uint4 en = ids[seg_start[lo] + (e - seg_pre[lo])];
                 const uint32_t t = en.x;
                 const uint2 bb = make_uint2(en.y, en.z);
-                if ((int)(bb.y & 0xffffu) <= X1 && (int)(bb.y >> 16) >= X0 && (int)(bb.x & 0xffffu) <= Y1 && (int)(bb.x >> 16) >= Y0) { const uint32_t at = atomicAdd(&n_list, 1u); list[at] = t; list_rows[at] = bb.x; }
+                if ((int)(bb.y & 0xffffu) <= X1 && (int)(bb.y >> 16) >= X0 && (int)(bb.x & 0xffffu) <= Y1 && (int)(bb.x >> 16) >= Y0) {
+                    const bool tall = (int)(bb.x >> 16) - (int)(bb.x & 0xffffu) > FF_ADD_LOOP_MAX;
+                    const uint32_t at = tall ? atomicAdd(&n_tall, 1u) : SMT_LIST - 1u - atomicAdd(&n_list, 1u);       // (a round holds SMT_LIST entries at most: they do not meet)
+                    list[at] = t; list_rows[at] = bb.x;
+                }
             }
             __syncthreads();
+            SM_TL(3);
+            if (RS_TILELOG && log) tl[7] += n_list + n_tall;
             drain();
             __syncthreads();
-            if (tid == 0) n_list = 0u;
+            SM_TL(4);
+            if (tid == 0) { n_list = 0u; n_tall = 0u; }
             __syncthreads();
         }
     }
@@ -845,6 +917,11 @@ __global__ void __launch_bounds__(SMT_T) k_sm_tiles(const ShadowParams Q, const 
     for (int i = tid; i < SMT_H * SMT_W; i += SMT_T) {
         const int y = Y0 + i / SMT_W, x = X0 + i % SMT_W;
         if (y <= Y1 && x <= X1) map[(size_t)y * SM + x] = key2f(keys[0][i]);
+    }
+    if (RS_TILELOG && log && tid == 0 && blockIdx.x < 8192u) {
+        SM_TL(5);
+#pragma unroll
+        for (int i = 0; i < 8; i++) log[(size_t)blockIdx.x * 16u + (uint32_t)i] = tl[i];
     }
 }
 
@@ -987,10 +1064,8 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     if (blocks > 2048) blocks = 2048;
     // threads per tile: mi355_opts::tune[3] (64..512, whole waves), default 256
     const int nt = P->rs_threads >= 64 && P->rs_threads <= RS_MAX_THREADS && (P->rs_threads & 63) == 0 ? P->rs_threads : 256;
-#ifndef RS_SINGLE_OCC
-#define RS_SINGLE_OCC 4
-#endif
-    if (whole) hipExtLaunchKernelGGL((k_rs_tile<MODE, RS_SINGLE_OCC>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, nullptr, tile_done, 0, *S, *P, d_batch, n_frames, g, s->B, 1);
+    // (the five-wave build for single overlapped frames, measured again in round 6 with the shorter items: 27.2 k frames/s against 29.1 k)
+    if (whole) hipExtLaunchKernelGGL((k_rs_tile<MODE, 4>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, nullptr, tile_done, 0, *S, *P, d_batch, n_frames, g, s->B, 1);
     else if (n_frames > 1) hipLaunchKernelGGL((k_rs_tile<MODE, 5>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B, 0);
     else hipLaunchKernelGGL((k_rs_tile<MODE, 4>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B, 0);
     mi355i_prof_lap(4);
@@ -1190,7 +1265,7 @@ extern "C" hipError_t mi355i_launch_shadowmap(const DevScene *S, const float *li
         hipLaunchKernelGGL(k_sm_prep, dim3(nbT), dim3(256), 0, st, *S, Q, prep, bbox, table, ids, ids_cap, ctl);
         const unsigned tiles = (unsigned)(((size + SMT_W - 1) / SMT_W) * n_bands);
         hipLaunchKernelGGL(k_sm_tiles, dim3(tiles), dim3(SMT_T), 0, st, Q, (const SmPrep *)prep, (const uint2 *)bbox, (const uint32_t *)table, (uint32_t)nbT, (const uint4 *)ids, ids_cap,
-                           d_map, ctl_next);
+                           d_map, ctl_next, s->sm_log);
         return hipGetLastError();
     }
     if ((e = hipMemsetAsync(s->ctl, 0, 64, st)) != hipSuccess) return e;
@@ -1207,6 +1282,8 @@ extern "C" hipError_t mi355i_launch_shadowmap(const DevScene *S, const float *li
     hipLaunchKernelGGL(k_sm_resolve, dim3(1024), dim3(256), 0, st, s->smkeys, d_map, n);
     return hipGetLastError();
 }
+
+extern "C" void mi355i_raster_set_log(RasterScratch *s, unsigned long long *log) { if (s) s->sm_log = log; }
 
 // after an overflow: the next frame's bins / span rows are twice as large (up to 2^8 times the default)
 extern "C" int mi355i_raster_grow(RasterScratch *s)

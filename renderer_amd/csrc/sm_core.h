@@ -105,34 +105,19 @@ MI_HD void sm_edge_at(const RsEdge<3> &E, int y, float (&v)[3])
 #define SMT_WIDE 4            // a triangle of more bands than this goes to the coarse bands' lists
 #define SMT_CB 16             // bands per coarse band
 
-struct SmPrep { float f[9]; int iy[3]; float d[9]; float pad[3]; };      // projected corners (x, y, 1/z), their truncated rows, the three edges' steps per row: 96 bytes
-
-// rs_edge_init with the edge's per-row steps already known (k_sm_prep made them with rs_edge_init itself: the same divisions, once
-// per triangle instead of once per row and tile)
-MI_HD void sm_edge_init(RsEdge<3> &E, int ya, const float (&va)[3], int yb, const float (&vb)[3], const float *d, int height)
-{
-    E.horiz = false; E.y0 = 1; E.y1 = 0;
-#pragma unroll
-    for (int i = 0; i < 3; i++) { E.v[i] = 0.f; E.d[i] = 0.f; }
-    if (ya == yb) {
-        if (ya >= 0 && ya < height) { E.horiz = true; E.y0 = E.y1 = ya; }
-        return;
-    }
-    const bool sw = ya > yb;
-    int y1 = sw ? yb : ya, y2 = sw ? ya : yb;
-    if (y1 < 0 && y2 < 0) return;
-    if (y1 >= height && y2 >= height) return;
-#pragma unroll
-    for (int i = 0; i < 3; i++) { E.v[i] = sw ? vb[i] : va[i]; E.d[i] = d[i]; }
-    if (y1 < 0) {
-        const float k = (float)-y1;
-#pragma unroll
-        for (int i = 0; i < 3; i++) E.v[i] += E.d[i] * k;
-        y1 = 0;
-    }
-    if (height - 1 < y2) y2 = height - 1;
-    E.y0 = y1; E.y1 = y2;
-}
+// A triangle's record for the tiles (96 bytes): per edge (Light.cc:270-272: v1v2, v2v3, v1v3) the walker as ScanConverter starts it --
+// x and 1/z on the first row it feeds (after the clip against the map's top) and their steps per row --, the rows it feeds, and the
+// corners' x and 1/z (a horizontal edge feeds its two end points).  Round 6: rounds 4-5 stored the corners and the steps and every
+// (triangle, row) item set the three walkers up again (rs_edge_init's compares, selects and the clip's multiply-adds: ~150 of an
+// item's ~700 instructions); the y coordinate is not walked at all (nothing reads it behind the row number).
+struct SmPrep {
+    float v[3][2], d[3][2];    // per edge: x, 1/z on row y0; their steps per row
+    uint32_t rows[3];          // per edge: y0 | y1 << 16, the rows it feeds (y0 > y1: none)
+    uint32_t horiz;            // bit e: edge e is horizontal
+    float c[3][2];             // the corners' x, 1/z
+    float pad[2];
+};
+static_assert(sizeof(SmPrep) == 96, "six 16-byte loads");
 
 MI_HD int sm_lists(int n_bands) { return n_bands + 1 + (n_bands + SMT_CB - 1) / SMT_CB + 1; }
 
@@ -162,14 +147,19 @@ MI_HD bool sm_prep_projected(const float (&f)[3][3], const int (&iy)[3], int siz
     }
     if (c1 < c0) return false;
     bb = make_uint2((uint32_t)miny | ((uint32_t)maxy << 16), (uint32_t)c0 | ((uint32_t)c1 << 16));
+    RsEdge<3> e[3];                            // Light.cc:270-272: v1v2, v2v3, v1v3
+    rs_edge_init<3>(e[0], iy[0], f[0], iy[1], f[1], size);
+    rs_edge_init<3>(e[1], iy[1], f[1], iy[2], f[2], size);
+    rs_edge_init<3>(e[2], iy[0], f[0], iy[2], f[2], size);
+    P.horiz = 0u;
 #pragma unroll
-    for (int k = 0; k < 3; k++) { P.f[3 * k] = f[k][0]; P.f[3 * k + 1] = f[k][1]; P.f[3 * k + 2] = f[k][2]; P.iy[k] = iy[k]; }
-    RsEdge<3> e0, e1, e2;                      // Light.cc:270-272: v1v2, v2v3, v1v3
-    rs_edge_init<3>(e0, iy[0], f[0], iy[1], f[1], size);
-    rs_edge_init<3>(e1, iy[1], f[1], iy[2], f[2], size);
-    rs_edge_init<3>(e2, iy[0], f[0], iy[2], f[2], size);
-#pragma unroll
-    for (int i = 0; i < 3; i++) { P.d[i] = e0.d[i]; P.d[3 + i] = e1.d[i]; P.d[6 + i] = e2.d[i]; }
+    for (int k = 0; k < 3; k++) {
+        P.v[k][0] = e[k].v[0]; P.v[k][1] = e[k].v[2]; P.d[k][0] = e[k].d[0]; P.d[k][1] = e[k].d[2];
+        P.rows[k] = (uint32_t)e[k].y0 | ((uint32_t)e[k].y1 << 16);             // (0 .. size - 1 <= 8191, or 1 | 0 << 16: none)
+        if (e[k].horiz) P.horiz |= 1u << k;
+        P.c[k][0] = f[k][0]; P.c[k][1] = f[k][2];
+    }
+    P.pad[0] = P.pad[1] = 0.f;
     return true;
 }
 
@@ -191,40 +181,58 @@ MI_HD void sm_lists_of(uint32_t rows, int n_bands, int &b0, int &b1)
 // ---- what a thread of k_sm_tiles does for (triangle, row y): k_sm_rows' body, the span cut to the columns xs .. xe ------------------
 // put(x, z) is called for every pixel of the row the triangle plots whose column lies in xs .. xe (PlotShadowPixel, Light.cc:253-259:
 // this range's share of it), in the reference's order along the span.
+// The part of a row's span that is still to be offered: pixels j .. steps of it (pixel k = k additions from the span's first; x, 1/z
+// of pixel j = sx, sz).  With dx > 0 -- the only way a span has more than two pixels -- x never decreases along the span.
+struct SmSpan { float sx, sz, dx, dz; int j, steps; };
+
+// The serial walk (Light.cc:286-292): stops behind the last column.
 template <class Put>
-MI_HD void sm_tile_row(const SmPrep &P, int SM, int y, int xs, int xe, Put put)
+MI_HD void sm_span_walk(SmSpan S, int xs, int xe, Put put)
 {
-    const float f[3][3] = {{P.f[0], P.f[1], P.f[2]}, {P.f[3], P.f[4], P.f[5]}, {P.f[6], P.f[7], P.f[8]}};
-    RsEdge<3> e0, e1, e2;                      // Light.cc:270-272: v1v2, v2v3, v1v3
-    sm_edge_init(e0, P.iy[0], f[0], P.iy[1], f[1], P.d, SM);
-    sm_edge_init(e1, P.iy[1], f[1], P.iy[2], f[2], P.d + 3, SM);
-    sm_edge_init(e2, P.iy[0], f[0], P.iy[2], f[2], P.d + 6, SM);
-    float l[3] = {0.f, 0.f, 0.f}, r[3] = {0.f, 0.f, 0.f};
+    for (;; S.j++) {
+        const int idx = cvtt_i32(S.sx);
+        if (idx >= xs && idx <= xe && S.sz == S.sz) put(idx, S.sz);
+        if (S.j >= S.steps || (S.dx > 0.f && idx > xe && idx != (int)0x80000000)) break;
+        S.sx += S.dx; S.sz += S.dz;
+    }
+}
+
+// Everything of (triangle, row y) up to the span's walk: true = S is to be walked (sm_span_walk, or in pieces: k_sm_tiles); the rows of
+// one or two pixels are plotted here.
+template <class Put>
+MI_HD bool sm_tile_span(const SmPrep &P, int SM, int y, int xs, int xe, Put put, SmSpan &S)
+{
+    float l[2] = {0.f, 0.f}, r[2] = {0.f, 0.f};          // x, 1/z of the row's end points
     uint32_t cnt = 0;
-    const auto feed = [&](const RsEdge<3> &E, const float (&a)[3], const float (&b)[3]) {
-        if (y < E.y0 || y > E.y1) return;
-        if (E.horiz) { scan_add<3>(l, r, cnt, a); scan_add<3>(l, r, cnt, b); return; }
-        float v[3];
-        sm_edge_at(E, y, v);
-        scan_add<3>(l, r, cnt, v);
-    };
-    feed(e0, f[0], f[1]); feed(e1, f[1], f[2]); feed(e2, f[0], f[2]);
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        const int y0 = (int)(P.rows[e] & 0xffffu), y1 = (int)(P.rows[e] >> 16);
+        if (y < y0 || y > y1) continue;
+        if (P.horiz & (1u << e)) {
+            const int a = e == 1 ? 1 : 0, b = e == 0 ? 1 : 2;
+            const float pa[2] = {P.c[a][0], P.c[a][1]}, pb[2] = {P.c[b][0], P.c[b][1]};
+            scan_add<2>(l, r, cnt, pa); scan_add<2>(l, r, cnt, pb);
+            continue;
+        }
+        const float v[2] = {ff_add(P.v[e][0], P.d[e][0], y - y0), ff_add(P.v[e][1], P.d[e][1], y - y0)};      // (y - y0 additions, taken at once)
+        scan_add<2>(l, r, cnt, v);
+    }
     const auto plot = [&](float x, float z) {
         const int idx = cvtt_i32(x);
         if (idx >= xs && idx <= xe && z == z) put(idx, z);
         return idx;
     };
-    if (cnt == 1) { plot(l[0], l[2]); return; }
-    if (cnt != 2) return;
+    if (cnt == 1) { plot(l[0], l[1]); return false; }
+    if (cnt != 2) return false;
     const int x1 = cvtt_i32(l[0]), x2 = cvtt_i32(r[0]);
     long long st = (long long)x2 - (long long)x1;
     if (st < 0) st = -st;
-    if (!st) { plot(l[0], l[2]); plot(r[0], r[2]); return; }
-    if (st > (1ll << 24)) return;                                      // a degenerate projection (geometry at the light's plane)
+    if (!st) { plot(l[0], l[1]); plot(r[0], r[1]); return false; }
+    if (st > (1ll << 24)) return false;                                // a degenerate projection (geometry at the light's plane)
     const int steps = (int)st;
     const float fsteps = (float)steps;
-    const float dx = (r[0] - l[0]) / fsteps, dz = (r[2] - l[2]) / fsteps;
-    float sx = l[0], sz = l[2];
+    const float dx = (r[0] - l[0]) / fsteps, dz = (r[1] - l[1]) / fsteps;
+    float sx = l[0], sz = l[1];
     // the pixels 0 .. steps of the span whose x falls into xs .. xe: start a few pixels before the estimate (the chain drifts from the
     // straight line by far less), stop beyond the last column; chains ff_add cannot jump into are walked whole
     int j = 0;
@@ -234,18 +242,27 @@ MI_HD void sm_tile_row(const SmPrep &P, int SM, int y, int xs, int xe, Put put)
         const auto x_at = [&](int k) { float v = l[0]; for (int done = 0; done < k;) { const int n = k - done < (1 << 21) ? k - done : (1 << 21); v = ff_add(v, dx, n); done += n; } return v; };
         const float est = ((float)xs - sx) / dx - 4.f;
         if (est >= (float)steps) j = steps; else if (est > 0.f) j = (int)est;
-        if (j > 0 && cvtt_i32(x_at(j)) >= xs) {
-            // the estimate is not left of the range (a span of millions of pixels drifts from the straight line): the last pixel that
-            // is, by bisection
-            int lo_j = 0, hi_j = j;                                     // x(lo_j) < xs <= x(hi_j)
-            while (hi_j - lo_j > 1) { const int mid = lo_j + (hi_j - lo_j) / 2; if (cvtt_i32(x_at(mid)) < xs) lo_j = mid; else hi_j = mid; }
-            j = lo_j;
+        float xj = sx;
+        if (j > 0) {
+            xj = x_at(j);
+            if (cvtt_i32(xj) >= xs) {
+                // the estimate is not left of the range (a span of millions of pixels drifts from the straight line): the last pixel that
+                // is, by bisection
+                int lo_j = 0, hi_j = j;                                 // x(lo_j) < xs <= x(hi_j)
+                while (hi_j - lo_j > 1) { const int mid = lo_j + (hi_j - lo_j) / 2; if (cvtt_i32(x_at(mid)) < xs) lo_j = mid; else hi_j = mid; }
+                j = lo_j;
+                xj = j > 0 ? x_at(j) : sx;
+            }
         }
-        if (j > 0) { sx = x_at(j); for (int done = 0; done < j;) { const int n = j - done < (1 << 21) ? j - done : (1 << 21); sz = ff_add(sz, dz, n); done += n; } }
+        if (j > 0) { sx = xj; for (int done = 0; done < j;) { const int n = j - done < (1 << 21) ? j - done : (1 << 21); sz = ff_add(sz, dz, n); done += n; } }
     }
-    for (;; j++) {
-        const int idx = plot(sx, sz);
-        if (j >= steps || (dx > 0.f && idx > xe && idx != (int)0x80000000)) break;
-        sx += dx; sz += dz;
-    }
+    S.sx = sx; S.sz = sz; S.dx = dx; S.dz = dz; S.j = j; S.steps = steps;
+    return true;
+}
+
+template <class Put>
+MI_HD void sm_tile_row(const SmPrep &P, int SM, int y, int xs, int xe, Put put)
+{
+    SmSpan S;
+    if (sm_tile_span(P, SM, y, xs, xe, put, S)) sm_span_walk(S, xs, xe, put);
 }
