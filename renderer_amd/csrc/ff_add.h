@@ -93,3 +93,15 @@ MI_HD float ff_add(float x, const float d, int k)
         }
     return x;
 }
+
+// Two chains of the same length (an edge walker's x and 1/z): short ones share the tests of the step count's bits
+MI_HD void ff_add2(float &x, const float dx, float &z, const float dz, int k)
+{
+    if (k > FF_ADD_LOOP_MAX) { x = ff_add(x, dx, k); z = ff_add(z, dz, k); return; }
+#pragma unroll
+    for (int bit = FF_ADD_TAIL; bit >= 1; bit >>= 1)
+        if (k & bit) {
+#pragma unroll
+            for (int j = 0; j < bit; j++) { x = x + dx; z = z + dz; }
+        }
+}

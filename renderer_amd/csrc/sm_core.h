@@ -214,7 +214,8 @@ MI_HD bool sm_tile_span(const SmPrep &P, int SM, int y, int xs, int xe, Put put,
             scan_add<2>(l, r, cnt, pa); scan_add<2>(l, r, cnt, pb);
             continue;
         }
-        const float v[2] = {ff_add(P.v[e][0], P.d[e][0], y - y0), ff_add(P.v[e][1], P.d[e][1], y - y0)};      // (y - y0 additions, taken at once)
+        float v[2] = {P.v[e][0], P.v[e][1]};
+        ff_add2(v[0], P.d[e][0], v[1], P.d[e][1], y - y0);                   // (y - y0 additions, taken at once)
         scan_add<2>(l, r, cnt, v);
     }
     const auto plot = [&](float x, float z) {

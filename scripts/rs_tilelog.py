@@ -43,6 +43,14 @@ def report(tag, a, t_ref=None):
          "setup_end_us": q(us(setup[:, 1])), "fill_start_us": q(us(fill[:, 0])), "fill_end_us": q(us(fill[:, 1])),
          "busy_tiles": int(len(busy)), "tile_start_us": q(us(tile[:, 0])), "busy_tile_end_us": q(us(busy[:, 0]) + life),
          "kernel_end_us": round(float(us(tile[:, 9]).max()), 1), "busy_tile_life_us": q(life), "sum_busy_life_us": round(float(life.sum()))}
+    fa = a[:, 14:16]; ok = fa[:, 1] > 0
+    if ok.any():
+        fe = np.where(ok, (fa[:, 1] - t0) / 100.0, 0.0)
+        slow = np.argsort(-fe)[:6]
+        d["slowest_fill_blocks"] = [[int(i), round(float((fa[i, 0] - t0) / 100.0), 1), round(float(fe[i]), 1)] for i in slow]     # index, start, end
+        sa = a[:, 12:14]; oks = sa[:, 1] > 0
+        se = np.where(oks, (sa[:, 1] - t0) / 100.0, 0.0)
+        d["slowest_setup_blocks"] = [[int(i), round(float((sa[i, 0] - t0) / 100.0), 1), round(float(se[i]), 1)] for i in np.argsort(-se)[:4]]
     for i, nm in enumerate(names):
         d["phase_" + nm + "_us"] = q(busy[:, 1 + i] / 100.0)
     d["phase_means_us"] = {nm: round(float(busy[:, 1 + i].mean() / 100.0), 2) for i, nm in enumerate(names)}
