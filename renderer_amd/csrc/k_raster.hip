@@ -386,6 +386,9 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
 // tile's chain of phases is what a frame waits for --, 5 (96 registers, 64-76 bytes of scratch) for a batch of frames, where one
 // more tile per CU in flight is worth more (measured both ways, profiles/r03_analysis.md).
 template <int MODE, int OCC>
+// (Round 6: fewer registers for the four-wave build, so that a wave of the next frame's setup or fill kernel fits a SIMD beside four
+//  tile waves -- 4 x 120 of 512 leave 32, the fill kernel needs 40 --: the compiler has no handle for it; amdgpu_num_vgpr is ignored
+//  beside amdgpu_waves_per_eu and without it.)
 __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) k_rs_tile(const DevScene S, const FrameParams P, const FrameParams *batch, int n_frames,
                                                         const RsGrid g, const RsBuffers B, const int clear_rows)
 {
@@ -552,6 +555,9 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
 // edge walkers to the item's row with ff_add -- the exact result of the reference's repeated `vtc += d12` (ScanConverter.h:
 // 112-116) without taking the steps -- and walks the row's span; spans of more than SM_LONG pixels are cut into 64 pieces by
 // the whole wave, each piece starting from ff_add of the span's first pixel.  Same plots, same values, same maximum.
+#ifndef SMT_WAVES
+#define SMT_WAVES 7     // k_sm_tiles: waves per SIMD its registers are allotted for (72 registers, three tiles per CU; 8 = 64 registers + 24 B of scratch, four tiles per CU: chessboard 54.5 -> 53.2 us, dragon 56.2 -> 58.3, statue 53.1 -> 56.6)
+#endif
 #ifndef SMT_LONG
 #define SMT_LONG 48     // k_sm_tiles: a span with more pixels ahead in its tile than this may be walked by the whole wave ...
 #endif
@@ -777,7 +783,7 @@ __global__ void __launch_bounds__(256) k_sm_prep(const DevScene S, const ShadowP
     }
 }
 
-__global__ void __launch_bounds__(SMT_T) k_sm_tiles(const ShadowParams Q, const SmPrep *prep, const uint2 *bbox, const uint32_t *table, uint32_t n_blocks, const uint4 *ids,
+__global__ void __launch_bounds__(SMT_T) __attribute__((amdgpu_waves_per_eu(SMT_WAVES, SMT_WAVES))) k_sm_tiles(const ShadowParams Q, const SmPrep *prep, const uint2 *bbox, const uint32_t *table, uint32_t n_blocks, const uint4 *ids,
                                                   uint32_t ids_cap, float *map, uint32_t *ctl_next, unsigned long long *log)
 {
     // (RS_TILELOG builds, scripts/sm_tilelog.py: thread 0's clock at the block's start and the time it spent up to the cleared keys, in the

@@ -19,7 +19,12 @@ done
   echo "== scripts/rt_variants.py (dragon 1080p depth 3 and statue depth 1: batches of 8, single frames, frame hashes; default / dark shadow rays walked / round 5 loop (leaves in the step for batches, tests inside the walk loop) / work sharing off / three waves / 16 frames per launch)"
   for v in "noskip -DRT_SKIP_DARK=0" "r05loop -DRT_SKIP_DARK=0 -DRT_DEFER_BATCH=0 -DRT_FLUSH_OUT=0"; do set -- $v; n=$1; shift; bash scripts/build_rt_variant.sh $n "$@" > /dev/null 2>&1; done
   timeout 400 python scripts/rt_variants.py default noskip r05loop 'default:RT_TUNE={"noshare":1}' 'default:RT_TUNE={"bpc":3}' 'default:RT_B=16' 2>&1 | grep variant
-  echo "== scripts/shadowmap_time.py (LDS tiles from a dispenser)"; timeout 100 python scripts/shadowmap_time.py 2>&1 | grep "us per"
+  echo "== scripts/rs_variants.py default (chessboard 1080p frame by frame / batches of 8 / single frames, shadow maps; frame hashes)"; timeout 200 python scripts/rs_variants.py default 2>&1 | grep variant
+  echo "== scripts/rs_tilelog.py, scripts/sm_tilelog.py (RS_TILELOG build: when the blocks of a raster frame's kernels and of the shadow map's tile kernel start, pass their phases and end)"
+  bash scripts/build_rs_variant.sh tilelog -DRS_TILELOG=1 > /dev/null 2>&1
+  (export MI355_WAVELOG=1 MI355_RENDER_SO=$R/renderer_amd/lib/variant_tilelog.so; timeout 100 python scripts/rs_tilelog.py 6 2>&1 | grep "^{" | cut -c1-1800; timeout 100 python scripts/sm_tilelog.py 2>&1 | grep "^{" | cut -c1-900)
+  echo "== scripts/rs_pmc.sh 6 (counters of the raster frame's kernels)"; timeout 400 bash scripts/rs_pmc.sh 6 2>&1 | tail -80; rm -rf gpurun_out/rspmc_*
+  echo "== scripts/shadowmap_time.py"; timeout 100 python scripts/shadowmap_time.py 2>&1 | grep "us per"
   echo "== scripts/raster_phases.py (the tile kernel's phases on counting frames; frames/s by threads per tile)"; timeout 100 python scripts/raster_phases.py 2>&1 | tail -14
   echo "== scripts/raytrace_frame_by_frame.py"; timeout 100 python scripts/raytrace_frame_by_frame.py 2>&1 | tail -8
   echo "== scripts/render_cli_configs.sh (render_cli -b, BASELINE.json's five configurations)"; timeout 200 bash scripts/render_cli_configs.sh 2>&1

@@ -100,12 +100,20 @@ def test_ff_add_equals_the_serial_chain(tmp_path):
     src = tmp_path / "ff.cc"
     src.write_text(r'''
 #include <math.h>
+#include <string.h>
 #define MI_HD static inline
 #include "%s/renderer_amd/csrc/ff_add.h"
 extern "C" void ff_many(const float *x, const float *d, const int *k, float *fast, float *slow, int n)
 {
     for (int i = 0; i < n; i++) {
         fast[i] = ff_add(x[i], d[i], k[i]);
+        // (ff_add2: two chains of one length; here this chain and its neighbour's operands)
+        const int i1 = i + 1 < n ? i + 1 : 0;
+        float a = x[i], b = x[i1];
+        ff_add2(a, d[i], b, d[i1], k[i]);
+        if (memcmp(&a, &fast[i], 4) != 0 && !(a != a && fast[i] != fast[i])) fast[i] = __builtin_nanf("");      // (reported as a difference below)
+        const float b1 = ff_add(x[i1], d[i1], k[i]);
+        if (memcmp(&b, &b1, 4) != 0 && !(b != b && b1 != b1)) fast[i] = __builtin_nanf("");
         volatile float v = x[i];
         for (int j = 0; j < k[i]; j++) v = v + d[i];
         slow[i] = v;
