@@ -57,7 +57,7 @@ class Opts(C.Structure):
                 ("band_count", C.c_int32), ("compact_rows", C.c_int32), ("collect_stats", C.c_int32),
                 ("tune", C.c_int32 * 8), ("mlaa", C.c_int32),
                 ("use_refractions", C.c_int32), ("refract_rate", C.c_float), ("ambient_occlusion", C.c_int32),
-                ("ao_samples", C.c_int32), ("ao_range", C.c_float), ("reserved", C.c_int32 * 2)]
+                ("ao_samples", C.c_int32), ("ao_range", C.c_float), ("keep_canvas", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Stats(C.Structure):

@@ -543,6 +543,7 @@ void mi355_scene_destroy(mi355_ctx *c)
     }
     for (auto &h : c->host_reg) if (h.p) { const hipError_t ue = hipHostUnregister(h.p); host_trace("destroy ctx %p: unregister %p + %zu -> %d", (void *)c, (void *)h.p, h.bytes, (int)ue); }
     c->direct_ctrl.release(); c->direct_sel.release();
+    c->canvas.mask[0].release(); c->canvas.mask[1].release();
     if (c->ev_direct) (void)hipEventDestroy(c->ev_direct);
     if (c->rs_light) mi355i_raster_scratch_destroy(c->rs_light);
     if (c->ev_light) (void)hipEventDestroy(c->ev_light);
@@ -792,6 +793,9 @@ static bool host_range_registered(const mi355_ctx *c, const void *p, size_t byte
     return false;
 }
 
+// (mgpu.hip: a frame assembled in host memory by something other than mi355_render)
+void mi355i_canvases_written(const void *p, size_t bytes) { canvases_written(nullptr, true, p, bytes); }
+
 void *mi355_host_alloc(size_t bytes)
 {
     if (!bytes) { (void)fail(-3, "mi355_host_alloc: zero bytes"); return nullptr; }
@@ -826,10 +830,13 @@ void mi355_host_free(void *p)
         bool known = bytes != 0;
         {
             std::lock_guard<std::mutex> lk(g_dev_mu);
-            for (mi355_ctx *c : g_ctx_list)
+            for (mi355_ctx *c : g_ctx_list) {
+                // (a canvas whose last frame was known lives in this buffer: whatever comes to lie at the address later is not that frame)
+                if (c->canvas.host && (!known || ((const char *)c->canvas.host >= (const char *)p && (const char *)c->canvas.host < (const char *)p + bytes))) c->canvas.valid = false;
                 for (auto &a : c->slot)
                     if (a.busy && a.st && !a.staged && (!known || ((const char *)a.user >= (const char *)p && (const char *)a.user < (const char *)p + bytes)))
                         waits.emplace_back(c->device, a.st);
+            }
         }
         for (auto &w : waits) if (hipSetDevice(w.first) == hipSuccess) (void)hipStreamSynchronize(w.second);
         if (!known && have_dev) {
@@ -871,6 +878,7 @@ int mi355_host_unregister(mi355_ctx *c, void *p)
             host_trace("unregister ctx %p: %p + %zu -> %d", (void *)c, p, h.bytes, (int)ue);
             HIP_TRY(ue, -46);
             h.p = nullptr; h.bytes = 0;
+            c->canvas.valid = false;
             return 0;
         }
     return fail(-46, "mi355_host_unregister: %p was not registered", p);
@@ -903,11 +911,38 @@ int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_li
                            host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4) &&
                            hipHostGetDevicePointer(&host_alias, out_xrgb, 0) == hipSuccess && host_alias;
     if (!zero_copy) (void)hipGetLastError();
+    // A raster frame into a canvas whose last frame is known (mi355_opts::keep_canvas): written THERE too, but only where it can differ
+    // from the frame before -- the 64x64-pixel bins that hold triangles now (by their tiles' blocks) and black into those that held
+    // some before and hold none now (k_rs_tile): a 1080p chessboard frame sends ~1.5 of its 8.3 MB across PCIe, and the 166 us of the
+    // copy behind the kernels are gone.  The first such frame of a canvas (or after anything else was drawn into host memory by this
+    // context) is written in full: every bin counts as held.
+    const bool raster_mode = mode >= MI355_MODE_AMBIENT && mode <= MI355_MODE_PHONG_SOFTSHADOWMAPS;
+    void *canvas_alias = nullptr;
+    const bool keep = o->keep_canvas && raster_mode && !o->mlaa && o->band_count <= 1 && !o->collect_stats && pitch_bytes >= W * 4 && !(pitch_bytes & 3) &&
+                      host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4) &&
+                      hipHostGetDevicePointer(&canvas_alias, out_xrgb, 0) == hipSuccess && canvas_alias;
+    if (o->keep_canvas && raster_mode && !keep) (void)hipGetLastError();
+    mi355_ctx::Canvas &cv = c->canvas;
+    if (keep) {
+        const size_t mask_bytes = (size_t)mi355i_raster_coarse_bins(W, o->height) * 4;
+        const bool known = o->keep_canvas == 1 && cv.valid && cv.host == out_xrgb && cv.W == W && cv.H == o->height && cv.pitch == pitch_bytes &&
+                           cv.mask[0].bytes >= mask_bytes && cv.mask[1].bytes >= mask_bytes;
+        cv.valid = false;                    // (until this frame is known to be there)
+        if (!known) {
+            HIP_TRY(cv.mask[0].ensure(mask_bytes), -31);
+            HIP_TRY(cv.mask[1].ensure(mask_bytes), -31);
+            cv.cur = 0;
+            HIP_TRY(hipMemsetAsync(cv.mask[0].p, 0xff, mask_bytes, c->stream), -40);
+        }
+    }
+    // (a frame into host memory: whoever keeps a canvas there knows nothing of it -- this context too, unless it is the kept frame)
+    canvases_written(c, !keep, out_xrgb, (size_t)pitch_bytes * (size_t)(rows > 0 ? rows - 1 : 0) + (size_t)W * 4);
     host_trace("render ctx %p mode %d %dx%d: out %p + %zu zero_copy %d (alias %p) registered %d f32 %p + %zu", (void *)c, mode, W, o->height, (void *)out_xrgb,
                (size_t)pitch_bytes * (size_t)(rows > 0 ? rows - 1 : 0) + (size_t)W * 4, (int)zero_copy, host_alias,
                (int)host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows > 0 ? rows - 1 : 0) + (size_t)W * 4), (void *)(wantf ? out_rgb_f32 : nullptr), wantf ? (size_t)W * rows * 12 : (size_t)0);
     FrameParams P;
-    if (int r = fill_params(c, mode, cam, lights, n_lights, o, zero_copy ? host_alias : c->fb.p, zero_copy ? pitch_bytes : W * 4, wantf ? c->fbf.p : nullptr, P)) return r;
+    if (int r = fill_params(c, mode, cam, lights, n_lights, o, zero_copy ? host_alias : keep ? canvas_alias : c->fb.p, zero_copy || keep ? pitch_bytes : W * 4, wantf ? c->fbf.p : nullptr, P)) return r;
+    if (keep) { P.canvas_keep = 1; P.canvas_prev = (const uint32_t *)cv.mask[cv.cur].p; P.canvas_next = (uint32_t *)cv.mask[cv.cur ^ 1].p; }
     mi355_stats tmp;
     mi355_stats *st = stats ? stats : &tmp;
     P.no_pipe = 1;          // (a synchronous frame has nothing to overlap with: its kernels follow each other on the context's stream)
@@ -931,6 +966,10 @@ int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_li
     }
     if (zero_copy) {
         // (the frame is where it belongs; the stream has been synchronised)
+    } else if (keep) {
+        // (... and so is this one; the tile kernel has noted the bins it holds)
+        std::lock_guard<std::mutex> lk(g_dev_mu);            // (canvases_written of another thread's frame reads these)
+        cv.host = out_xrgb; cv.W = W; cv.H = o->height; cv.pitch = pitch_bytes; cv.cur ^= 1; cv.valid = true;
     } else if (pitch_bytes > 0 && host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4)) {
         // page-locked by the caller (mi355_host_register): one DMA transfer, no staging by the runtime
         HIP_TRY(hipMemcpy2DAsync(out_xrgb, (size_t)pitch_bytes, c->fb.p, (size_t)W * 4, (size_t)W * 4, (size_t)rows, hipMemcpyDeviceToHost, c->stream), -31);
@@ -958,6 +997,8 @@ int mi355_render_async(mi355_ctx *c, int mode, const mi355_camera *cam, const mi
     if (int r = validate_opts(*o, mode)) return r;
     if (n_lights < 0 || n_lights > MI355_MAX_LIGHTS) return fail(-21, "n_lights %d outside 0..%d", n_lights, MI355_MAX_LIGHTS);
     if (o->collect_stats) return fail(-21, "pipelined frames cannot collect the counters");
+    // (a frame on its way into host memory: a kept canvas it touches is no longer what its masks say)
+    canvases_written(c, true, out_xrgb, (size_t)pitch_bytes * (size_t)(o->height > 0 ? o->height - 1 : 0) + (size_t)o->width * 4);
     // (the staged path copies row by row with the caller's pitch: checked here, fill_params below only sees the internal one)
     if (pitch_bytes < o->width * 4 || (pitch_bytes & 3)) return fail(-21, "bad pitch %d for width %d", pitch_bytes, o->width);
     if (int r = select_device(c)) return r;
@@ -1012,6 +1053,7 @@ int mi355_render_wait(mi355_ctx *c, int ticket, mi355_stats *stats)
     if (!a) return fail(-45, "mi355_render_wait: no frame with ticket %d is in flight", ticket);
     HIP_TRY(hipStreamSynchronize(a->st), -40);
     a->busy = false;
+    canvases_written(c, true, a->user, (size_t)a->pitch_bytes * (size_t)(a->opts.height > 0 ? a->opts.height - 1 : 0) + (size_t)a->opts.width * 4);   // (see mi355_render_async)
     unsigned long long h[CS_COUNT];
     HIP_TRY(hipMemcpy(h, (char *)a->ctrl.p + 16, sizeof h, hipMemcpyDeviceToHost), -31);
     if (h[CS_OVERFLOW]) {

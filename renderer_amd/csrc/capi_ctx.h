@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -53,6 +54,7 @@ extern "C" hipError_t mi355i_launch_raster_overlapped(const DevScene *S, const F
 extern "C" hipError_t mi355i_launch_frame_copy(uint32_t *dst, const uint32_t *src, int W, int rows, int pitch_words, hipStream_t st, hipEvent_t done);
 extern "C" hipError_t mi355i_launch_frames_copy(void *const *dst, int n_frames, const uint32_t *src, int W, int rows, int pitch_words, hipStream_t st, hipEvent_t done);
 extern "C" int mi355i_raster_grow(RasterScratch *);
+extern "C" int mi355i_raster_coarse_bins(int W, int H);
 extern "C" void mi355i_raster_set_log(RasterScratch *, unsigned long long *);
 
 namespace mi355i {
@@ -271,6 +273,20 @@ struct mi355_ctx {
         mi355_opts opts{};
     } slot[MI355_MAX_IN_FLIGHT];
     int next_ticket = 1;
+    // A canvas whose last frame is known (mi355_opts::keep_canvas, mi355_render): the raster kernels write the frame straight into
+    // the caller's page-locked memory and only into the 64x64-pixel bins that hold pixels of this frame or held pixels of the one
+    // before (mask[cur]: a word per bin, written by the tile kernel of that frame; the next frame writes mask[cur ^ 1]).  Any other
+    // frame of this context into host memory, and any buffer released, makes the canvas unknown again.
+    struct Canvas {
+        uint32_t *host = nullptr; int W = 0, H = 0, pitch = 0, cur = 0; std::atomic<bool> valid{false}; DevBuf mask[2];
+        // something else is written into [p, p + bytes) of host memory: the canvas is unknown if that touches it
+        void written(const void *p, size_t bytes)
+        {
+            if (!valid || !host) return;
+            const char *a = (const char *)host, *b = a + (size_t)pitch * (size_t)(H > 0 ? H - 1 : 0) + (size_t)W * 4;
+            if ((const char *)p < b && (const char *)p + bytes > a) valid = false;
+        }
+    } canvas;
     // caller's page-locked output buffers (mi355_host_register): frames are copied straight into them
     struct HostRange { char *p = nullptr; size_t bytes = 0; } host_reg[8];
     // dispenser orders of the last few frame geometries (a buffer in use by an enqueued frame is never rewritten)
@@ -284,6 +300,13 @@ struct mi355_ctx {
 
 // the contexts that exist (mi355_host_free looks for frames still on their way into the buffer it is about to release); under g_dev_mu
 inline std::vector<mi355_ctx *> g_ctx_list;
+// [p, p + bytes) of host memory is written by a frame: every context's kept canvas that it touches -- `self`'s own only if asked --
+// is unknown from here on (a canvas may be shared by several Scenes)
+inline void canvases_written(const mi355_ctx *self, bool self_too, const void *p, size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    for (mi355_ctx *c : g_ctx_list) if (c != self || self_too) c->canvas.written(p, bytes);
+}
 
 namespace mi355i {
 inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }

@@ -136,9 +136,13 @@ struct FrameParams {
     // traced ((n_tiles + 31) / 32 words per frame): waves of k_raytrace write the background of the others -- fill_first of them to
     // begin with, the others when the dispenser has nothing left for them (fill_counter hands out the tile rows) --, else NULL (the
     // selection kernel writes the background before anything is traced)
-    const uint32_t *tile_mask;
-    uint32_t *fill_counter;
-    int32_t fill_first;        // that many waves of the launch START with the background (a frame that crosses PCIe as it is written)
+    // (the rasterizer reads the three words under other names -- a raster frame drawn straight into a canvas in the caller's host
+    //  memory whose last frame is known, mi355_opts::keep_canvas: canvas_keep != 0, canvas_prev[b] != 0 = coarse bin b of the canvas
+    //  holds pixels of the frame before, canvas_next[b] = whether it holds pixels of this one; k_rs_tile)
+    union { const uint32_t *tile_mask; const uint32_t *canvas_prev; };
+    union { uint32_t *fill_counter; uint32_t *canvas_next; };
+    union { int32_t fill_first;        // that many waves of the launch START with the background (a frame that crosses PCIe as it is written)
+            int32_t canvas_keep; };
     int32_t blocks_per_cu;     // 0 = occupancy query
     int32_t rs_threads;        // rasterizer: threads per tile block (0 = default)
     // the raytracer's compile-time extras (Raytracer.cc:70-80)

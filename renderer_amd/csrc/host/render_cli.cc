@@ -38,10 +38,11 @@ using namespace mi355;
 static void usage()
 {
     fprintf(stderr,
-            "Usage: render_cli [-b] [-r] [--bench] [-n frames] [-m mode] [-w] [-W width] [-H height] [-d device] [-g gpus] [-p in_flight] [-o ppm_prefix] FILE\n"
+            "Usage: render_cli [-b] [-r] [--bench] [-n frames] [-m mode] [-w] [-W width] [-H height] [-d device] [-g gpus] [-p in_flight] [--keep-canvas] [-o ppm_prefix] FILE\n"
             "  -m <mode>  1 points, 2 points from triangles, 3 wireframe, 4 ambient, 5 Gouraud, 6 Phong,\n"
             "             7 Phong+shadow maps, 8 Phong+soft shadow maps, 9 raytracing, 0 raytracing+AA\n"
-            "  -w         use two lights        -n N  frames (default 100)\n");
+            "  -w         use two lights        -n N  frames (default 100)\n"
+            "  --keep-canvas  (-p 1, modes 4-8) nothing but Scene::render* writes into the canvas: frames cross PCIe only where they differ from the last\n");
     exit(1);
 }
 
@@ -58,6 +59,7 @@ static void write_ppm(const char *prefix, int frame, const Screen &canvas)
 
 // one `renderer -b -n frames` run; returns frames per second (time inside Scene::render* only, renderer.cc:584-585, 631-633)
 static int g_depth = 0;            // --depth (0: the reference's 3)
+static bool g_keepCanvas = false;  // --keep-canvas (Screen::_keepCanvas)
 
 static double run(const char *fname, int mode, int frames, int W, int H, const std::vector<int> &devices, bool twoLights, bool periodic, const char *dump,
                   int inFlight = 1)
@@ -67,6 +69,7 @@ static double run(const char *fname, int mode, int frames, int W, int H, const s
     if (devices.size() > 1) scene._devices = devices;
     else if (!devices.empty()) scene._device = devices[0];
     Screen canvas(scene, W, H);
+    canvas._keepCanvas = g_keepCanvas;
     scene.load(fname);
     printf("Vertexes: %zu Triangles: %zu\n", scene.numVertices(), scene.numTriangles());
     if (mode >= 9) scene.UpdateBoundingVolumeHierarchy(fname);          // renderer.cc:254-258 (untimed)
@@ -215,6 +218,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--keys")) keysFile = next();
         else if (!strcmp(a, "--frame-ms")) frameMS = atol(next());
         else if (!strcmp(a, "--no-brakes")) brakes = false;
+        else if (!strcmp(a, "--keep-canvas")) g_keepCanvas = true;
         else if (!strcmp(a, "--depth")) { g_depth = atoi(next()); if (g_depth < 1 || g_depth > 4) usage(); }
         else if (a[0] == '-') usage();
         else fname = a;

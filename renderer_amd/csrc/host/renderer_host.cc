@@ -149,7 +149,7 @@ PixelBuffer::~PixelBuffer()
 Screen::Screen(const Scene &scene, int width, int height)
     : _width(width), _height(height), _pitch(width * 4), _pixels((size_t)width * height), _scene(scene) {}
 Screen::~Screen() = default;
-void Screen::ClearScreen() { std::fill(_pixels.begin(), _pixels.end(), 0u); }
+void Screen::ClearScreen() { std::fill(_pixels.begin(), _pixels.end(), 0u); _canvasKnown = false; }
 void Screen::ShowScreen(bool, bool) { if (_present) _present(*this, _presentArg); }
 
 // ---------------------------------------------------------------- scene: loading -----------------------
@@ -822,8 +822,11 @@ void Scene::renderMode(int mode, const Camera &eye, Screen &canvas)
         return;
     }
     mi355_ctx *ctx = context();
+    o.keep_canvas = canvas._keepCanvas ? (canvas._canvasKnown ? 1 : 2) : 0;       // (the library ignores it where it does not apply)
+    canvas._canvasKnown = false;
     if (mi355_render(ctx, mode, &cam, lights, n, &o, canvas._pixels.data(), canvas._pitch, nullptr, &_lastStats) != 0)
         raise(std::string("mi355_render: ") + mi355_last_error());
+    canvas._canvasKnown = canvas._keepCanvas;
 }
 
 int Scene::renderAsync(int mode, const Camera &eye, Screen &canvas)

@@ -108,6 +108,13 @@ struct Screen {                                        // Screen.h:49-171 (canva
     const Scene &_scene;
     void (*_present)(const Screen &, void *) = nullptr; // front-end hook called by ShowScreen (SDL_Flip)
     void *_presentArg = nullptr;
+    // Opt-in for front-ends shaped like the reference's loop (renderer.cc:522-583: Scene::render* clears and draws the canvas,
+    // ShowScreen only reads it): with _keepCanvas set the rasterizer modes send a frame across PCIe only where it can differ from the
+    // frame before (mi355_opts::keep_canvas; same pixels).  ClearScreen() is accounted for; a front-end that writes into _pixels
+    // itself calls touched() afterwards.
+    bool _keepCanvas = false;
+    bool _canvasKnown = false;                         // (what _pixels holds is the last frame drawn with _keepCanvas)
+    void touched() { _canvasKnown = false; }
     Screen(const Scene &scene, int width, int height);
     ~Screen();
     Screen(const Screen &) = delete;

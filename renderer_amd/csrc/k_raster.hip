@@ -508,6 +508,13 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
         const uint32_t *off = B.offset;
         const bool global_any = off[g.n_coarse + 1] != off[g.n_coarse];
         const uint32_t first = total_items + 64u <= gridDim.x ? total_items : 0u, nb = gridDim.x - first;
+        // A canvas whose last frame is known (mi355_opts::keep_canvas: the frame goes straight into the caller's host memory): outside
+        // the coarse bins that held pixels of the frame before the canvas is black already -- only those that hold none of this frame
+        // are written here, and the last block notes which bins hold pixels now.  (canvas_prev is read, canvas_next written: the
+        // caller swaps them between frames.)
+        const uint32_t *const kept = P.canvas_keep ? P.canvas_prev : nullptr;
+        if (kept && blockIdx.x == gridDim.x - 1u)
+            for (int cb = tid; cb < g.n_coarse; cb += nt) P.canvas_next[cb] = (global_any || off[cb + 1] != off[cb]) ? 1u : 0u;
         if (!global_any && blockIdx.x >= first) {
             const uint32_t wpb = (uint32_t)nt >> 6, n_waves = nb * wpb;
             const int lane = tid & 63;
@@ -517,9 +524,11 @@ __global__ void __launch_bounds__(RS_MAX_THREADS) __attribute__((amdgpu_waves_pe
                 const bool owned = rs_out_row(P, y) >= 0;
                 const uint32_t *crow = off + (y / (RS_TH * RS_CB)) * g.cx;
                 uint32_t *orow = P.out + (size_t)o * P.pitch_words;
+                const uint32_t *krow = kept ? kept + (y / (RS_TH * RS_CB)) * g.cx : nullptr;
                 for (int x = lane * 4; x < P.W; x += 256) {
                     const int cb = x / (RS_TW * RS_CB);
                     if (owned && crow[cb + 1] != crow[cb]) continue;           // a tile with triangles: its block writes it
+                    if (krow && !krow[cb]) continue;                           // black since the frame before last
                     if (vec && x + 3 < P.W) *(uint4 *)(orow + x) = make_uint4(0u, 0u, 0u, 0u);
                     else for (int k = 0; k < 4 && x + k < P.W; k++) orow[x + k] = 0u;
                 }
@@ -1076,6 +1085,8 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
                                 hipStream_t st, hipEvent_t tile_done = nullptr)
 {
     const bool whole = tile_done != nullptr && n_frames == 1;
+    // (a frame into a canvas whose last frame is known: the tile kernel writes what has to be written of the background, see there)
+    const bool kept = !whole && n_frames == 1 && P->canvas_keep && P->canvas_prev && P->canvas_next;
     const RsGrid g = rs_grid(P->W, P->H);
     hipError_t e = tiled_ensure(s, g, S->n_tris, n_frames, st);
     if (e != hipSuccess) return e;
@@ -1085,10 +1096,10 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     mi355i_prof_lap(2);
     // (the fill kernel's grid also has to carry the band items: at least four blocks per CU)
     const dim3 fill_grid(per_tri.x > 1024u ? per_tri.x : 1024u, n_frames);
-    if (g.n_bins <= RS_SCAN_LDS) hipLaunchKernelGGL(k_rs_fill<true>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters, whole ? 0 : 1);
+    if (g.n_bins <= RS_SCAN_LDS) hipLaunchKernelGGL(k_rs_fill<true>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters, whole || kept ? 0 : 1);
     else {
         hipLaunchKernelGGL(k_rs_scan, dim3(n_frames), dim3(1024), 0, st, g, s->B, P->counters);
-        hipLaunchKernelGGL(k_rs_fill<false>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters, whole ? 0 : 1);
+        hipLaunchKernelGGL(k_rs_fill<false>, fill_grid, dim3(256), 0, st, g, s->B, S->n_tris, *P, d_batch, P->counters, whole || kept ? 0 : 1);
     }
     mi355i_prof_lap(3);
     // Tiles that hold triangles are handed out by a dispenser (a fixed assignment to resident blocks balances unequal
@@ -1100,10 +1111,13 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     // (the five-wave build for single overlapped frames, measured again in round 6 with the shorter items: 27.2 k frames/s against 29.1 k)
     if (whole) hipExtLaunchKernelGGL((k_rs_tile<MODE, 4>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, nullptr, tile_done, 0, *S, *P, d_batch, n_frames, g, s->B, 1);
     else if (n_frames > 1) hipLaunchKernelGGL((k_rs_tile<MODE, 5>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B, 0);
-    else hipLaunchKernelGGL((k_rs_tile<MODE, 4>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B, 0);
+    else hipLaunchKernelGGL((k_rs_tile<MODE, 4>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B, kept ? 1 : 0);
     mi355i_prof_lap(4);
     return hipGetLastError();
 }
+
+// words of a canvas mask (FrameParams::canvas_prev / canvas_next): one per coarse bin
+extern "C" int mi355i_raster_coarse_bins(int W, int H) { return rs_grid(W, H).n_coarse; }
 
 static hipError_t raster_dispatch(const DevScene *S, const FrameParams *P, const FrameParams *d_batch, int n_frames, int mode,
                                   RasterScratch *s, hipStream_t st, hipEvent_t tile_done = nullptr)

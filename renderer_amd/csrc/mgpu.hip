@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+extern "C" void mi355i_canvases_written(const void *p, size_t bytes);     // capi.hip
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -421,7 +423,10 @@ int mi355_mgpu_render(mi355_mgpu *m, int mode, const mi355_camera *cam, const mi
     int ticket = 0;
     if (int e = mi355_mgpu_render_batch(m, mode, 1, cam, lights, n_lights, o, &dst, d_out ? pitch_bytes : W * 4, &ticket)) return e;
     if (int e = mi355_mgpu_wait(m, ticket, stats)) return e;
-    if (!d_out) MG_HIP(hipMemcpy2D(out_xrgb, (size_t)pitch_bytes, m->frame, (size_t)W * 4, (size_t)W * 4, (size_t)H, hipMemcpyDeviceToHost), -31);
+    if (!d_out) {
+        mi355i_canvases_written(out_xrgb, (size_t)pitch_bytes * (size_t)(H - 1) + (size_t)W * 4);      // (a kept canvas there, mi355_opts::keep_canvas, is no longer what its context remembers)
+        MG_HIP(hipMemcpy2D(out_xrgb, (size_t)pitch_bytes, m->frame, (size_t)W * 4, (size_t)W * 4, (size_t)H, hipMemcpyDeviceToHost), -31);
+    }
     return 0;
 }
 
