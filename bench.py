@@ -1162,7 +1162,10 @@ def main():
                                  ("4: dragon_vis.ply -m 9 1920x1080", ["-n", "500", "-m", "9", "-W", "1920", "-H", "1080", "dragon_vis.ply"]),
                                  ("5: dragon_vis.ply -m 9 3840x2160 (one GPU)", ["-n", "200", "-m", "9", "-W", "3840", "-H", "2160", "dragon_vis.ply"])):
                     row = {"config": label}
-                    for key, pre in (("fps_3_in_flight", []), ("fps_reference_loop", ["-p", "1"])):
+                    # (--keep-canvas: Screen::_keepCanvas, the front-end's promise that only Scene::render* writes into its canvases -- as
+                    #  renderer.cc's loop does --: raster frames then cross PCIe only where they differ from the canvas's last frame)
+                    kept = (("fps_3_in_flight_keep_canvas", ["--keep-canvas"]), ("fps_reference_loop_keep_canvas", ["-p", "1", "--keep-canvas"])) if "-m 6" in label else ()
+                    for key, pre in (("fps_3_in_flight", []), ("fps_reference_loop", ["-p", "1"])) + kept:
                         try:
                             out = subprocess.run([cli, "-b"] + pre + a[:-1] + [os.path.join(md, a[-1])], capture_output=True, text=True, timeout=60,
                                                  env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local_rank))))
@@ -1174,7 +1177,9 @@ def main():
                     rows.append(row)
                 extra["render_cli_bench"] = {"rows": rows, "note": "render_cli -b: fps_3_in_flight = its default for -b (the cameras are known: three "
                                              "frames in flight through Scene::renderAsync); fps_reference_loop = -p 1, one synchronous Scene::render* per "
-                                             "pass like renderer.cc:481-520, rate = frames / time inside the calls"}
+                                             "pass like renderer.cc:481-520, rate = frames / time inside the calls; *_keep_canvas (rasterizer rows): the "
+                                             "same runs with --keep-canvas (mi355_opts::keep_canvas: the kernels write a frame straight into the page-locked "
+                                             "canvas and only into the 64x64-pixel bins that hold triangles now or held some in the canvas's last frame)"}
             # BVH build of the benchmark mesh: GPU level kernels + download + flatten, host builder beside it
             import ctypes as C
             bs = R.Scene(R.assets.mesh_path(args.mesh), device=local_rank)

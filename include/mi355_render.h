@@ -117,16 +117,18 @@ typedef struct {
                               * reproducible and independent of scheduling */
     int32_t ao_samples;      /* AMBIENT_SAMPLES 32 */
     float ao_range;          /* AMBIENT_RANGE 0.15f */
-    int32_t keep_canvas;     /* mi355_render, modes 4-8, whole frames into page-locked memory (mi355_host_alloc / _register): the
-                              * caller promises that NOTHING but mi355_render has written into out_xrgb since the frame before
+    int32_t keep_canvas;     /* mi355_render / mi355_render_async, modes 4-8, whole frames into page-locked memory (mi355_host_alloc /
+                              * _register): the caller promises that NOTHING but these calls has written into out_xrgb since the frame before
                               * (the reference's loop: Scene::render* clears and draws the canvas, ShowScreen only reads it --
                               * renderer.cc:522-583).  The kernels then write the frame straight into that memory and only where it
                               * can differ from the frame before: the 64x64-pixel bins that hold triangles now, and black into those
                               * that held some before -- ~1.5 MB of a 1080p chessboard frame's 8.3 MB cross PCIe.  1 = the canvas holds
                               * the last frame this context drew there with keep_canvas; 2 = its content is unknown (the frame is
                               * written in full and remembered); 0 (default) = every frame is written in full, whatever the canvas
-                              * holds.  The pixels are the same in all three.  Ignored (= 0) for other modes, bands, mlaa, counting
-                              * frames and pageable memory. */
+                              * holds.  The pixels are the same in all three.  A context remembers its four most recent canvases (a
+                              * ring of frames in flight: one per slot); what the library itself writes into that memory by any other
+                              * call or context makes a canvas unknown again, and so does releasing it.  Ignored (= 0) for other modes,
+                              * bands, mlaa, counting frames and pageable memory. */
     int32_t reserved;        /* 0 */
 } mi355_opts;
 

@@ -543,7 +543,7 @@ void mi355_scene_destroy(mi355_ctx *c)
     }
     for (auto &h : c->host_reg) if (h.p) { const hipError_t ue = hipHostUnregister(h.p); host_trace("destroy ctx %p: unregister %p + %zu -> %d", (void *)c, (void *)h.p, h.bytes, (int)ue); }
     c->direct_ctrl.release(); c->direct_sel.release();
-    c->canvas.mask[0].release(); c->canvas.mask[1].release();
+    for (auto &cv : c->canvas) { cv.mask[0].release(); cv.mask[1].release(); if (cv.ev) (void)hipEventDestroy(cv.ev); }
     if (c->ev_direct) (void)hipEventDestroy(c->ev_direct);
     if (c->rs_light) mi355i_raster_scratch_destroy(c->rs_light);
     if (c->ev_light) (void)hipEventDestroy(c->ev_light);
@@ -794,7 +794,7 @@ static bool host_range_registered(const mi355_ctx *c, const void *p, size_t byte
 }
 
 // (mgpu.hip: a frame assembled in host memory by something other than mi355_render)
-void mi355i_canvases_written(const void *p, size_t bytes) { canvases_written(nullptr, true, p, bytes); }
+void mi355i_canvases_written(const void *p, size_t bytes) { canvases_written(nullptr, p, bytes); }
 
 void *mi355_host_alloc(size_t bytes)
 {
@@ -832,7 +832,8 @@ void mi355_host_free(void *p)
             std::lock_guard<std::mutex> lk(g_dev_mu);
             for (mi355_ctx *c : g_ctx_list) {
                 // (a canvas whose last frame was known lives in this buffer: whatever comes to lie at the address later is not that frame)
-                if (c->canvas.host && (!known || ((const char *)c->canvas.host >= (const char *)p && (const char *)c->canvas.host < (const char *)p + bytes))) c->canvas.valid = false;
+                for (auto &cv : c->canvas)
+                    if (cv.host && (!known || ((const char *)cv.host >= (const char *)p && (const char *)cv.host < (const char *)p + bytes))) cv.valid = false;
                 for (auto &a : c->slot)
                     if (a.busy && a.st && !a.staged && (!known || ((const char *)a.user >= (const char *)p && (const char *)a.user < (const char *)p + bytes)))
                         waits.emplace_back(c->device, a.st);
@@ -878,11 +879,69 @@ int mi355_host_unregister(mi355_ctx *c, void *p)
             host_trace("unregister ctx %p: %p + %zu -> %d", (void *)c, p, h.bytes, (int)ue);
             HIP_TRY(ue, -46);
             h.p = nullptr; h.bytes = 0;
-            c->canvas.valid = false;
+            for (auto &cv : c->canvas) cv.valid = false;
             return 0;
         }
     return fail(-46, "mi355_host_unregister: %p was not registered", p);
 }
+
+// ---- mi355_opts::keep_canvas (capi_ctx.h: mi355_ctx::Canvas) ----
+} // extern "C"
+
+// is this frame one that keeps its canvas?  (alias = the device's address of the caller's memory)
+static bool canvas_wanted(mi355_ctx *c, int mode, const mi355_opts *o, uint32_t *out_xrgb, int pitch_bytes, int rows, void **alias)
+{
+    const bool raster_mode = mode >= MI355_MODE_AMBIENT && mode <= MI355_MODE_PHONG_SOFTSHADOWMAPS;
+    if (!o->keep_canvas || !raster_mode) return false;
+    const bool ok = !o->mlaa && o->band_count <= 1 && !o->collect_stats && pitch_bytes >= o->width * 4 && !(pitch_bytes & 3) && rows > 0 &&
+                    host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)o->width * 4) &&
+                    hipHostGetDevicePointer(alias, out_xrgb, 0) == hipSuccess && *alias;
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}
+
+// The context's record of the canvas at out_xrgb, ready for a frame on stream `st`: masks that describe what the canvas holds -- every
+// bin, if that is not known (keep_canvas = 2, a canvas not seen before, anything else written there since) --, ordered behind the
+// kernels of the canvas's last frame.  The canvas counts as unknown until canvas_done.
+static int canvas_begin(mi355_ctx *c, const mi355_opts *o, uint32_t *out_xrgb, int pitch_bytes, hipStream_t st, mi355_ctx::Canvas **out)
+{
+    const int W = o->width, H = o->height;
+    const size_t mask_bytes = (size_t)mi355i_raster_coarse_bins(W, H) * 4;
+    mi355_ctx::Canvas *cv = nullptr;
+    for (auto &e : c->canvas) if (e.host == out_xrgb) { cv = &e; break; }
+    if (!cv) { cv = &c->canvas[0]; for (auto &e : c->canvas) if (e.used < cv->used) cv = &e; }       // (the least recently used record goes)
+    const bool known = o->keep_canvas == 1 && cv->valid && cv->host == out_xrgb && cv->W == W && cv->H == H && cv->pitch == pitch_bytes &&
+                       cv->mask[0].bytes >= mask_bytes && cv->mask[1].bytes >= mask_bytes;
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mu);            // (canvases_written of another thread's frame reads these)
+        cv->valid = false;
+        cv->host = out_xrgb; cv->W = W; cv->H = H; cv->pitch = pitch_bytes;
+    }
+    cv->used = ++c->canvas_clock;
+    // (the frame this record last saw -- of this canvas or of the one it has just forgotten -- may still be reading and writing the masks)
+    if (cv->ev_set) HIP_TRY(wait_unless_done(st, cv->ev), -40);
+    if (!known) {
+        HIP_TRY(cv->mask[0].ensure(mask_bytes), -31);
+        HIP_TRY(cv->mask[1].ensure(mask_bytes), -31);
+        cv->cur = 0;
+        HIP_TRY(hipMemsetAsync(cv->mask[0].p, 0xff, mask_bytes, st), -40);
+    }
+    *out = cv;
+    return 0;
+}
+
+// the frame's kernels are on `st`: the canvas holds it (in stream order), its masks have changed places
+static int canvas_done(mi355_ctx *c, mi355_ctx::Canvas *cv, const mi355_opts *o, uint32_t *out_xrgb, int pitch_bytes, hipStream_t st)
+{
+    if (!cv->ev) HIP_TRY(hipEventCreateWithFlags(&cv->ev, hipEventDisableTiming), -11);
+    HIP_TRY(hipEventRecord(cv->ev, st), -40);
+    cv->ev_set = true;
+    cv->cur ^= 1;
+    cv->valid = true;
+    return 0;
+}
+
+extern "C" {
 
 int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_light *lights, int n_lights,
                  const mi355_opts *o, uint32_t *out_xrgb, int pitch_bytes, float *out_rgb_f32, mi355_stats *stats)
@@ -914,35 +973,21 @@ int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_li
     // A raster frame into a canvas whose last frame is known (mi355_opts::keep_canvas): written THERE too, but only where it can differ
     // from the frame before -- the 64x64-pixel bins that hold triangles now (by their tiles' blocks) and black into those that held
     // some before and hold none now (k_rs_tile): a 1080p chessboard frame sends ~1.5 of its 8.3 MB across PCIe, and the 166 us of the
-    // copy behind the kernels are gone.  The first such frame of a canvas (or after anything else was drawn into host memory by this
-    // context) is written in full: every bin counts as held.
-    const bool raster_mode = mode >= MI355_MODE_AMBIENT && mode <= MI355_MODE_PHONG_SOFTSHADOWMAPS;
+    // copy behind the kernels are gone.  The first such frame of a canvas (or after anything else was drawn into that memory) is
+    // written in full: every bin counts as held.
     void *canvas_alias = nullptr;
-    const bool keep = o->keep_canvas && raster_mode && !o->mlaa && o->band_count <= 1 && !o->collect_stats && pitch_bytes >= W * 4 && !(pitch_bytes & 3) &&
-                      host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4) &&
-                      hipHostGetDevicePointer(&canvas_alias, out_xrgb, 0) == hipSuccess && canvas_alias;
-    if (o->keep_canvas && raster_mode && !keep) (void)hipGetLastError();
-    mi355_ctx::Canvas &cv = c->canvas;
-    if (keep) {
-        const size_t mask_bytes = (size_t)mi355i_raster_coarse_bins(W, o->height) * 4;
-        const bool known = o->keep_canvas == 1 && cv.valid && cv.host == out_xrgb && cv.W == W && cv.H == o->height && cv.pitch == pitch_bytes &&
-                           cv.mask[0].bytes >= mask_bytes && cv.mask[1].bytes >= mask_bytes;
-        cv.valid = false;                    // (until this frame is known to be there)
-        if (!known) {
-            HIP_TRY(cv.mask[0].ensure(mask_bytes), -31);
-            HIP_TRY(cv.mask[1].ensure(mask_bytes), -31);
-            cv.cur = 0;
-            HIP_TRY(hipMemsetAsync(cv.mask[0].p, 0xff, mask_bytes, c->stream), -40);
-        }
-    }
-    // (a frame into host memory: whoever keeps a canvas there knows nothing of it -- this context too, unless it is the kept frame)
-    canvases_written(c, !keep, out_xrgb, (size_t)pitch_bytes * (size_t)(rows > 0 ? rows - 1 : 0) + (size_t)W * 4);
+    mi355_ctx::Canvas *cv = nullptr;
+    if (canvas_wanted(c, mode, o, out_xrgb, pitch_bytes, rows, &canvas_alias))
+        if (int r = canvas_begin(c, o, out_xrgb, pitch_bytes, c->stream, &cv)) return r;
+    const bool keep = cv != nullptr;
+    // (a frame into host memory: whoever keeps a canvas there knows nothing of it -- but the canvas this frame keeps)
+    canvases_written(cv, out_xrgb, (size_t)pitch_bytes * (size_t)(rows > 0 ? rows - 1 : 0) + (size_t)W * 4);
     host_trace("render ctx %p mode %d %dx%d: out %p + %zu zero_copy %d (alias %p) registered %d f32 %p + %zu", (void *)c, mode, W, o->height, (void *)out_xrgb,
                (size_t)pitch_bytes * (size_t)(rows > 0 ? rows - 1 : 0) + (size_t)W * 4, (int)zero_copy, host_alias,
                (int)host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows > 0 ? rows - 1 : 0) + (size_t)W * 4), (void *)(wantf ? out_rgb_f32 : nullptr), wantf ? (size_t)W * rows * 12 : (size_t)0);
     FrameParams P;
     if (int r = fill_params(c, mode, cam, lights, n_lights, o, zero_copy ? host_alias : keep ? canvas_alias : c->fb.p, zero_copy || keep ? pitch_bytes : W * 4, wantf ? c->fbf.p : nullptr, P)) return r;
-    if (keep) { P.canvas_keep = 1; P.canvas_prev = (const uint32_t *)cv.mask[cv.cur].p; P.canvas_next = (uint32_t *)cv.mask[cv.cur ^ 1].p; }
+    if (keep) { P.canvas_keep = 1; P.canvas_prev = (const uint32_t *)cv->mask[cv->cur].p; P.canvas_next = (uint32_t *)cv->mask[cv->cur ^ 1].p; }
     mi355_stats tmp;
     mi355_stats *st = stats ? stats : &tmp;
     P.no_pipe = 1;          // (a synchronous frame has nothing to overlap with: its kernels follow each other on the context's stream)
@@ -968,8 +1013,7 @@ int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_li
         // (the frame is where it belongs; the stream has been synchronised)
     } else if (keep) {
         // (... and so is this one; the tile kernel has noted the bins it holds)
-        std::lock_guard<std::mutex> lk(g_dev_mu);            // (canvases_written of another thread's frame reads these)
-        cv.host = out_xrgb; cv.W = W; cv.H = o->height; cv.pitch = pitch_bytes; cv.cur ^= 1; cv.valid = true;
+        if (int r = canvas_done(c, cv, o, out_xrgb, pitch_bytes, c->stream)) return r;
     } else if (pitch_bytes > 0 && host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4)) {
         // page-locked by the caller (mi355_host_register): one DMA transfer, no staging by the runtime
         HIP_TRY(hipMemcpy2DAsync(out_xrgb, (size_t)pitch_bytes, c->fb.p, (size_t)W * 4, (size_t)W * 4, (size_t)rows, hipMemcpyDeviceToHost, c->stream), -31);
@@ -997,8 +1041,6 @@ int mi355_render_async(mi355_ctx *c, int mode, const mi355_camera *cam, const mi
     if (int r = validate_opts(*o, mode)) return r;
     if (n_lights < 0 || n_lights > MI355_MAX_LIGHTS) return fail(-21, "n_lights %d outside 0..%d", n_lights, MI355_MAX_LIGHTS);
     if (o->collect_stats) return fail(-21, "pipelined frames cannot collect the counters");
-    // (a frame on its way into host memory: a kept canvas it touches is no longer what its masks say)
-    canvases_written(c, true, out_xrgb, (size_t)pitch_bytes * (size_t)(o->height > 0 ? o->height - 1 : 0) + (size_t)o->width * 4);
     // (the staged path copies row by row with the caller's pitch: checked here, fill_params below only sees the internal one)
     if (pitch_bytes < o->width * 4 || (pitch_bytes & 3)) return fail(-21, "bad pitch %d for width %d", pitch_bytes, o->width);
     if (int r = select_device(c)) return r;
@@ -1025,14 +1067,26 @@ int mi355_render_async(mi355_ctx *c, int mode, const mi355_camera *cam, const mi
     }
     HIP_TRY(a->fb.ensure((size_t)W * o->height * 4), -31);
     if (o->band_count > 1) HIP_TRY(hipMemsetAsync(a->fb.p, 0, (size_t)W * o->height * 4, a->st), -40);
+    // (a raster frame into a canvas whose last frame is known, mi355_opts::keep_canvas: written there by the kernels, where it can differ)
+    void *canvas_alias = nullptr;
+    mi355_ctx::Canvas *cv = nullptr;
+    if (canvas_wanted(c, mode, o, out_xrgb, pitch_bytes, rows, &canvas_alias))
+        if (int r = canvas_begin(c, o, out_xrgb, pitch_bytes, a->st, &cv)) return r;
+    // (a frame on its way into host memory: any other kept canvas it touches is no longer what its masks say)
+    canvases_written(cv, out_xrgb, (size_t)pitch_bytes * (size_t)(rows > 0 ? rows - 1 : 0) + (size_t)W * 4);
     FrameParams P;
-    if (int r = fill_params(c, mode, cam, lights, n_lights, o, a->fb.p, W * 4, nullptr, P, a->ctrl.p)) return r;
+    if (int r = fill_params(c, mode, cam, lights, n_lights, o, cv ? canvas_alias : a->fb.p, cv ? pitch_bytes : W * 4, nullptr, P, a->ctrl.p)) return r;
+    if (cv) { P.canvas_keep = 1; P.canvas_prev = (const uint32_t *)cv->mask[cv->cur].p; P.canvas_next = (uint32_t *)cv->mask[cv->cur ^ 1].p; }
     HIP_TRY(hipEventRecord(a->ev0, a->st), -40);
     if (int r = enqueue_frame(c, mode, P, 0, a->st, a->ctrl.p, a->rs, &a->mlaa, nullptr, &a->sel)) return r;
     HIP_TRY(hipEventRecord(a->ev1, a->st), -40);
-    a->staged = !host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4);
+    a->kept = cv;
+    if (cv) { if (int r = canvas_done(c, cv, o, out_xrgb, pitch_bytes, a->st)) return r; }
+    a->staged = !cv && !host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4);
     host_trace("render_async ctx %p mode %d %dx%d: out %p + %zu staged %d", (void *)c, mode, W, o->height, (void *)out_xrgb, (size_t)pitch_bytes * (size_t)(rows > 0 ? rows - 1 : 0) + (size_t)W * 4, (int)a->staged);
-    if (a->staged) {
+    if (cv) {
+        // (nothing to copy: the frame is in the canvas when the stream gets there)
+    } else if (a->staged) {
         HIP_TRY(a->pin.ensure((size_t)W * rows * 4), -31);
         HIP_TRY(hipMemcpyAsync(a->pin.p, a->fb.p, (size_t)W * rows * 4, hipMemcpyDeviceToHost, a->st), -31);
     } else
@@ -1053,9 +1107,12 @@ int mi355_render_wait(mi355_ctx *c, int ticket, mi355_stats *stats)
     if (!a) return fail(-45, "mi355_render_wait: no frame with ticket %d is in flight", ticket);
     HIP_TRY(hipStreamSynchronize(a->st), -40);
     a->busy = false;
-    canvases_written(c, true, a->user, (size_t)a->pitch_bytes * (size_t)(a->opts.height > 0 ? a->opts.height - 1 : 0) + (size_t)a->opts.width * 4);   // (see mi355_render_async)
     unsigned long long h[CS_COUNT];
     HIP_TRY(hipMemcpy(h, (char *)a->ctrl.p + 16, sizeof h, hipMemcpyDeviceToHost), -31);
+    // (the frame has landed in host memory: see mi355_render_async.  A kept frame whose bins overflowed is drawn again below like any
+    //  other -- into the slot's buffer, copied to the canvas in full --, and the canvas is no longer what its masks say)
+    canvases_written(h[CS_OVERFLOW] ? nullptr : a->kept, a->user, (size_t)a->pitch_bytes * (size_t)(a->opts.height > 0 ? a->opts.height - 1 : 0) + (size_t)a->opts.width * 4);
+    a->kept = nullptr;
     if (h[CS_OVERFLOW]) {
         // the rasterizer's bins were too small for this frame: this slot's grow, and the frame is drawn again (synchronously)
         for (int attempt = 0; attempt < 8; attempt++) {

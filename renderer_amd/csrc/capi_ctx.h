@@ -257,6 +257,7 @@ struct mi355_ctx {
     WireScratch *wscratch = nullptr;     // mode 3 (created with its first frame)
     // pipelined frames (mi355_render_async / _wait): each slot is a stream with its own control block (counters, pixel
     // dispenser), framebuffer, page-locked staging and rasterizer scratch
+    struct Canvas;
     struct AsyncSlot {
         hipStream_t st = nullptr;     // one of cand_st (slot i: a stream of queue class i, so that no two slots share a hardware queue), or its own
         bool st_owned = false;
@@ -268,17 +269,21 @@ struct mi355_ctx {
         int ticket = 0, mode = 0, n_lights = 0, pitch_bytes = 0;
         uint32_t *user = nullptr;
         bool staged = false;          // the frame lands in `pin` and is copied to `user` by mi355_render_wait
+        Canvas *kept = nullptr;       // the frame is written straight into `user`, a canvas whose last frame is known (mi355_opts::keep_canvas)
         mi355_camera cam{};
         mi355_light lights[MI355_MAX_LIGHTS]{};
         mi355_opts opts{};
     } slot[MI355_MAX_IN_FLIGHT];
     int next_ticket = 1;
-    // A canvas whose last frame is known (mi355_opts::keep_canvas, mi355_render): the raster kernels write the frame straight into
-    // the caller's page-locked memory and only into the 64x64-pixel bins that hold pixels of this frame or held pixels of the one
-    // before (mask[cur]: a word per bin, written by the tile kernel of that frame; the next frame writes mask[cur ^ 1]).  Any other
-    // frame of this context into host memory, and any buffer released, makes the canvas unknown again.
+    // Canvases whose last frame is known (mi355_opts::keep_canvas; mi355_render, mi355_render_async): the raster kernels write a
+    // frame straight into the caller's page-locked memory and only into the 64x64-pixel bins that hold pixels of this frame or held
+    // pixels of the one before (mask[cur]: a word per bin, written by the tile kernel of that frame; the next frame writes
+    // mask[cur ^ 1]).  ev = the last kept frame's kernels (frames of one canvas may run on different streams: each follows the one
+    // before).  Any other frame into that memory -- whatever context or entry point it comes from -- and any buffer released make
+    // the canvas unknown again.  N_CANVAS of them (the least recently used one goes): a ring of frames in flight has one per slot.
     struct Canvas {
         uint32_t *host = nullptr; int W = 0, H = 0, pitch = 0, cur = 0; std::atomic<bool> valid{false}; DevBuf mask[2];
+        hipEvent_t ev = nullptr; bool ev_set = false; unsigned long long used = 0;
         // something else is written into [p, p + bytes) of host memory: the canvas is unknown if that touches it
         void written(const void *p, size_t bytes)
         {
@@ -286,7 +291,10 @@ struct mi355_ctx {
             const char *a = (const char *)host, *b = a + (size_t)pitch * (size_t)(H > 0 ? H - 1 : 0) + (size_t)W * 4;
             if ((const char *)p < b && (const char *)p + bytes > a) valid = false;
         }
-    } canvas;
+    };
+    enum { N_CANVAS = 4 };
+    Canvas canvas[N_CANVAS];
+    unsigned long long canvas_clock = 0;
     // caller's page-locked output buffers (mi355_host_register): frames are copied straight into them
     struct HostRange { char *p = nullptr; size_t bytes = 0; } host_reg[8];
     // dispenser orders of the last few frame geometries (a buffer in use by an enqueued frame is never rewritten)
@@ -300,12 +308,12 @@ struct mi355_ctx {
 
 // the contexts that exist (mi355_host_free looks for frames still on their way into the buffer it is about to release); under g_dev_mu
 inline std::vector<mi355_ctx *> g_ctx_list;
-// [p, p + bytes) of host memory is written by a frame: every context's kept canvas that it touches -- `self`'s own only if asked --
-// is unknown from here on (a canvas may be shared by several Scenes)
-inline void canvases_written(const mi355_ctx *self, bool self_too, const void *p, size_t bytes)
+// [p, p + bytes) of host memory is written by a frame: every kept canvas of every context that it touches -- but `keep`, the canvas the
+// frame itself keeps -- is unknown from here on (a canvas may be shared by several Scenes)
+inline void canvases_written(const mi355_ctx::Canvas *keep, const void *p, size_t bytes)
 {
     std::lock_guard<std::mutex> lk(g_dev_mu);
-    for (mi355_ctx *c : g_ctx_list) if (c != self || self_too) c->canvas.written(p, bytes);
+    for (mi355_ctx *c : g_ctx_list) for (auto &cv : c->canvas) if (&cv != keep) cv.written(p, bytes);
 }
 
 namespace mi355i {

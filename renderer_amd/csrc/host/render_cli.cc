@@ -42,7 +42,7 @@ static void usage()
             "  -m <mode>  1 points, 2 points from triangles, 3 wireframe, 4 ambient, 5 Gouraud, 6 Phong,\n"
             "             7 Phong+shadow maps, 8 Phong+soft shadow maps, 9 raytracing, 0 raytracing+AA\n"
             "  -w         use two lights        -n N  frames (default 100)\n"
-            "  --keep-canvas  (-p 1, modes 4-8) nothing but Scene::render* writes into the canvas: frames cross PCIe only where they differ from the last\n");
+            "  --keep-canvas  (modes 4-8) nothing but Scene::render* writes into the canvases: frames cross PCIe only where they differ from the last\n");
     exit(1);
 }
 
@@ -89,6 +89,7 @@ static double run(const char *fname, int mode, int frames, int W, int H, const s
         std::vector<std::unique_ptr<Screen>> ring;
         for (int i = 0; i < inFlight; i++) {
             ring.emplace_back(new Screen(scene, W, H));                    // (page-locked by its first frame: direct DMA into the canvas)
+            ring.back()->_keepCanvas = g_keepCanvas;
         }
         std::vector<int> ticket((size_t)inFlight, -1), frameOf((size_t)inFlight, 0);
         const int m = mode == 2 ? MI355_MODE_POINTS_FROM_TRIANGLES : mode;

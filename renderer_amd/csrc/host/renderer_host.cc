@@ -841,8 +841,11 @@ int Scene::renderAsync(int mode, const Camera &eye, Screen &canvas)
     const int n = (int)std::min<size_t>(_lights.size(), MI355_MAX_LIGHTS);
     for (int i = 0; i < n; i++) lights[i] = _lights[i]->abi();
     int ticket = -1;
+    o.keep_canvas = canvas._keepCanvas ? (canvas._canvasKnown ? 1 : 2) : 0;       // (as in renderMode)
+    canvas._canvasKnown = false;
     if (mi355_render_async(context(), mode, &cam, lights, n, &o, canvas._pixels.data(), canvas._pitch, &ticket) != 0)
         raise(std::string("mi355_render_async: ") + mi355_last_error());
+    canvas._canvasKnown = canvas._keepCanvas;
     return ticket;
 }
 

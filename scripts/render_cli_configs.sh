@@ -8,7 +8,13 @@ run() { # label, args...
   label=$1; shift
   a=$($CLI -b "$@" 2>&1 | grep Rendering | sed 's/.*(\(.*\) fps.*/\1/')
   b=$($CLI -b -p 1 "$@" 2>&1 | grep Rendering | sed 's/.*(\(.*\) fps.*/\1/')
-  echo "{\"config\": \"$label\", \"fps_3_in_flight\": $a, \"fps_reference_loop\": $b}"
+  k=""
+  case "$*" in *"-m 6"*|*"-m 8"*)   # the rasterizer's rows also with --keep-canvas (Screen::_keepCanvas: frames cross PCIe only where they differ from the canvas's last)
+    c=$($CLI -b --keep-canvas "$@" 2>&1 | grep Rendering | sed 's/.*(\(.*\) fps.*/\1/')
+    d=$($CLI -b -p 1 --keep-canvas "$@" 2>&1 | grep Rendering | sed 's/.*(\(.*\) fps.*/\1/')
+    k=", \"fps_3_in_flight_keep_canvas\": $c, \"fps_reference_loop_keep_canvas\": $d";;
+  esac
+  echo "{\"config\": \"$label\", \"fps_3_in_flight\": $a, \"fps_reference_loop\": $b$k}"
 }
 run "1: chessboard.tri -m 2 (points from triangles) 640x480" -n 2000 -m 2 -W 640 -H 480 $D/chessboard.tri
 run "2: chessboard.tri -m 6 (Phong) 1920x1080" -n 2000 -m 6 -W 1920 -H 1080 $D/chessboard.tri

@@ -110,8 +110,8 @@ def test_other_frames_in_between_make_the_canvas_unknown(scene):
 
 
 def test_canvases_sizes_and_pitches_take_turns(scene):
-    """Two canvases of one size, one of another, one with padding words (which are never touched): the context remembers one
-    canvas -- a frame into any other is written in full."""
+    """Two canvases of one size, one of another, one with padding words (which are never touched), each with the frames it
+    held before."""
     a, b = R.host_array((360, 640)), R.host_array((360, 640))
     c, d = R.host_array((217, 333)), R.host_array((360, 640 + 16))
     try:
@@ -216,6 +216,56 @@ def test_bins_that_overflow_are_drawn_again_into_the_canvas(tmp_path):
         R.host_array_free(canvas)
 
 
+def test_frames_in_flight_keep_their_canvases(scene):
+    """mi355_render_async: a ring of three canvases, three frames in flight, every frame written where it differs from the frame
+    that canvas held three frames ago; then the ring shrinks to ONE canvas used by every slot in turn (its frames follow each
+    other across the slots' streams), a synchronous kept frame and a plain one in between."""
+    W, H = 1280, 720
+    ring = [R.host_array((H, W)) for _ in range(3)]
+    try:
+        for c in ring:
+            c[:] = GARBAGE
+        o = R.default_opts(W, H, keep_canvas=1)
+        tickets = [None, None, None]
+        frame_of = [0, 0, 0]
+        checked = 0
+        for f in range(30):
+            slot = f % 3
+            if tickets[slot] is not None:
+                scene.render_wait(tickets[slot])
+                assert np.array_equal(ring[slot], plain(scene, frame_of[slot][0], frame_of[slot][1], W, H)), "frame %d" % f
+                checked += 1
+            mode, k = (6, 8, 4)[(f // 3) % 3], 5 * f
+            cam, lights, n = R.benchmark_frame(k)
+            tickets[slot] = scene.render_async(mode, cam, lights, n, o, ring[slot])
+            frame_of[slot] = (mode, k)
+        for slot in range(3):
+            scene.render_wait(tickets[slot])
+            assert np.array_equal(ring[slot], plain(scene, frame_of[slot][0], frame_of[slot][1], W, H))
+        assert checked == 27
+        one = ring[0]
+        for f in range(12):
+            cam, lights, n = R.benchmark_frame(7 * f)
+            if f % 4 == 2:
+                scene.render_into(6, cam, lights, n, o, one)                           # the synchronous call, kept
+            elif f % 4 == 3:
+                scene.render_into(6, cam, lights, n, R.default_opts(W, H), one)        # ... and plain
+            else:
+                scene.render_wait(scene.render_async(6, cam, lights, n, o, one))
+            assert np.array_equal(one, plain(scene, 6, 7 * f, W, H)), "one canvas, frame %d" % f
+        # five canvases take turns: one more than the context remembers
+        more = ring + [R.host_array((H, W)), R.host_array((H, W))]
+        ring = more
+        for f in range(15):
+            cam, lights, n = R.benchmark_frame(3 * f)
+            c = more[f % 5]
+            scene.render_wait(scene.render_async(8, cam, lights, n, o, c))
+            assert np.array_equal(c, plain(scene, 8, 3 * f, W, H)), "five canvases, frame %d" % f
+    finally:
+        for c in ring:
+            R.host_array_free(c)
+
+
 def test_cxx_screen_keeps_its_canvas():
     """The host layer: Screen::_keepCanvas through Scene::renderPhong, ClearScreen() and touched() in between (render_cli
     --keep-canvas dumps the frames it presents)."""
@@ -224,8 +274,9 @@ def test_cxx_screen_keeps_its_canvas():
     mesh = R.assets.mesh_path("chessboard.tri")
     with tempfile.TemporaryDirectory() as d:
         outs = []
-        for flag in ([], ["--keep-canvas"]):
-            prefix = os.path.join(d, "k" if flag else "p")
-            subprocess.run([cli, "-b", "-n", "6", "-m", "6", "-W", "640", "-H", "360", "-p", "1", "-o", prefix] + flag + [mesh], check=True, capture_output=True)
-            outs.append([hashlib.sha256(open("%s_%04d.ppm" % (prefix, f), "rb").read()).hexdigest() for f in range(1, 7)])
-        assert outs[0] == outs[1]
+        for i, flag in enumerate(([], ["--keep-canvas"], ["--keep-canvas", "-p", "3"])):
+            prefix = os.path.join(d, "run%d" % i)
+            subprocess.run([cli, "-b", "-n", "8", "-m", "6", "-W", "640", "-H", "360", "-o", prefix] + (flag if "-p" in flag else flag + ["-p", "1"]) + [mesh],
+                           check=True, capture_output=True)
+            outs.append([hashlib.sha256(open("%s_%04d.ppm" % (prefix, f), "rb").read()).hexdigest() for f in range(1, 9)])
+        assert outs[0] == outs[1] == outs[2]
