@@ -117,7 +117,7 @@ typedef struct {
                               * reproducible and independent of scheduling */
     int32_t ao_samples;      /* AMBIENT_SAMPLES 32 */
     float ao_range;          /* AMBIENT_RANGE 0.15f */
-    int32_t keep_canvas;     /* mi355_render / mi355_render_async, modes 4-8, whole frames into page-locked memory (mi355_host_alloc /
+    int32_t keep_canvas;     /* mi355_render / mi355_render_async, modes 4-10, whole frames into page-locked memory (mi355_host_alloc /
                               * _register): the caller promises that NOTHING but these calls has written into out_xrgb since the frame before
                               * (the reference's loop: Scene::render* clears and draws the canvas, ShowScreen only reads it --
                               * renderer.cc:522-583).  The kernels then write the frame straight into that memory and only where it
@@ -127,8 +127,10 @@ typedef struct {
                               * written in full and remembered); 0 (default) = every frame is written in full, whatever the canvas
                               * holds.  The pixels are the same in all three.  A context remembers its four most recent canvases (a
                               * ring of frames in flight: one per slot); what the library itself writes into that memory by any other
-                              * call or context makes a canvas unknown again, and so does releasing it.  Ignored (= 0) for other modes,
-                              * bands, mlaa, counting frames and pageable memory. */
+                              * call or context makes a canvas unknown again, and so does releasing it.  Raytraced frames (modes 9, 10)
+                              * likewise by 8x8-pixel tile: the tiles whose camera rays can reach the tree's top boxes now, black into
+                              * those of the canvas's last frame.  Ignored (= 0) for modes 1-3, bands, mlaa, counting frames, float
+                              * output, trees that failed the checks of mi355_scene_set_bvh and pageable memory. */
     int32_t reserved;        /* 0 */
 } mi355_opts;
 

@@ -151,6 +151,7 @@ int fill_params(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_lig
     P.blocks_per_cu = t[4] > 0 ? t[4] : 0;
     P.rs_threads = t[3];
     P.mlaa = o->mlaa ? 1 : 0;
+    P.rt_keep_prev = nullptr; P.rt_keep_next = nullptr;
     if (P.mlaa) {
         if (o->band_count > 1) return fail(-20, "mlaa works on whole frames: no band sharding (mi355_mgpu_render filters the assembled frame)");
         if ((P.pitch_words & 3) || (o->height & 7) || P.pitch_words < 8 || o->height < 8)
@@ -356,8 +357,10 @@ int enqueue_frame(mi355_ctx *c, int mode, const FrameParams &P_in, int stats, hi
                 // (the selection could not be launched: the frame is traced without it -- every tile handed out, same pixels)
                 (void)hipGetLastError();
                 P.tile_cnt = nullptr; P.tile_sel = nullptr; P.tile_mask = nullptr;
+                if (P.rt_keep_prev) return fail(-43, "kernel launch failed: %s (tile selection of a frame that keeps its canvas)", hipGetErrorString(e));
             }
-        }
+        } else if (P.rt_keep_prev)
+            return fail(-41, "keep_canvas: this raytraced frame cannot be culled tile by tile (checked before the call: a bug)");
         e = mi355i_launch_raytrace(&c->dev, &P, stats, P.exact_box, ordered, waves, batch, ext, stack_rows, n_blocks, st);
         break;
     }
@@ -892,7 +895,11 @@ int mi355_host_unregister(mi355_ctx *c, void *p)
 static bool canvas_wanted(mi355_ctx *c, int mode, const mi355_opts *o, uint32_t *out_xrgb, int pitch_bytes, int rows, void **alias)
 {
     const bool raster_mode = mode >= MI355_MODE_AMBIENT && mode <= MI355_MODE_PHONG_SOFTSHADOWMAPS;
-    if (!o->keep_canvas || !raster_mode) return false;
+    // (a raytraced frame: where its tiles are culled against the boxes at the tree's top -- enqueue_frame's conditions; the mask of
+    //  the tiles it traces is what the canvas remembers)
+    const bool rt_mode = mode >= MI355_MODE_RAYTRACE && c->has_bvh && c->dev.ordered_ok && c->n_cull_boxes > 0 && !(o->tune[5] & (4 | 8 | 16)) &&
+                         ((long long)((o->width + 7) / 8) * ((o->height + 7) / 8)) <= (long long)MI_CULL_MAX_TILES;
+    if (!o->keep_canvas || !(raster_mode || rt_mode)) return false;
     const bool ok = !o->mlaa && o->band_count <= 1 && !o->collect_stats && pitch_bytes >= o->width * 4 && !(pitch_bytes & 3) && rows > 0 &&
                     host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)o->width * 4) &&
                     hipHostGetDevicePointer(alias, out_xrgb, 0) == hipSuccess && *alias;
@@ -903,19 +910,21 @@ static bool canvas_wanted(mi355_ctx *c, int mode, const mi355_opts *o, uint32_t 
 // The context's record of the canvas at out_xrgb, ready for a frame on stream `st`: masks that describe what the canvas holds -- every
 // bin, if that is not known (keep_canvas = 2, a canvas not seen before, anything else written there since) --, ordered behind the
 // kernels of the canvas's last frame.  The canvas counts as unknown until canvas_done.
-static int canvas_begin(mi355_ctx *c, const mi355_opts *o, uint32_t *out_xrgb, int pitch_bytes, hipStream_t st, mi355_ctx::Canvas **out)
+static int canvas_begin(mi355_ctx *c, int mode, const mi355_opts *o, uint32_t *out_xrgb, int pitch_bytes, hipStream_t st, mi355_ctx::Canvas **out)
 {
     const int W = o->width, H = o->height;
-    const size_t mask_bytes = (size_t)mi355i_raster_coarse_bins(W, H) * 4;
+    // (what a mask is: the rasterizer's -- a word per 64x64-pixel bin -- or the raytracer's -- a bit per 8x8-pixel tile)
+    const int kind = mode >= MI355_MODE_RAYTRACE ? 1 : 0;
+    const size_t mask_bytes = kind ? (size_t)(((long long)((W + 7) / 8) * ((H + 7) / 8) + 31) / 32) * 4 : (size_t)mi355i_raster_coarse_bins(W, H) * 4;
     mi355_ctx::Canvas *cv = nullptr;
     for (auto &e : c->canvas) if (e.host == out_xrgb) { cv = &e; break; }
     if (!cv) { cv = &c->canvas[0]; for (auto &e : c->canvas) if (e.used < cv->used) cv = &e; }       // (the least recently used record goes)
-    const bool known = o->keep_canvas == 1 && cv->valid && cv->host == out_xrgb && cv->W == W && cv->H == H && cv->pitch == pitch_bytes &&
+    const bool known = o->keep_canvas == 1 && cv->valid && cv->host == out_xrgb && cv->W == W && cv->H == H && cv->pitch == pitch_bytes && cv->kind == kind &&
                        cv->mask[0].bytes >= mask_bytes && cv->mask[1].bytes >= mask_bytes;
     {
         std::lock_guard<std::mutex> lk(g_dev_mu);            // (canvases_written of another thread's frame reads these)
         cv->valid = false;
-        cv->host = out_xrgb; cv->W = W; cv->H = H; cv->pitch = pitch_bytes;
+        cv->host = out_xrgb; cv->W = W; cv->H = H; cv->pitch = pitch_bytes; cv->kind = kind;
     }
     cv->used = ++c->canvas_clock;
     // (the frame this record last saw -- of this canvas or of the one it has just forgotten -- may still be reading and writing the masks)
@@ -966,7 +975,7 @@ int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_li
     void *host_alias = nullptr;
     // (... and only where the tiles are culled: a frame traced tile by tile would cross PCIe 32 bytes at a time)
     const bool culled = c->n_cull_boxes > 0 && !(o->tune[5] & (4 | 8 | 16)) && ((long long)((W + 7) / 8) * ((o->height + 7) / 8)) <= (long long)MI_CULL_MAX_TILES;
-    const bool zero_copy = culled && mode >= MI355_MODE_RAYTRACE && !o->mlaa && o->band_count <= 1 && !o->collect_stats && pitch_bytes >= W * 4 && !(pitch_bytes & 3) &&
+    bool zero_copy = culled && mode >= MI355_MODE_RAYTRACE && !o->mlaa && o->band_count <= 1 && !o->collect_stats && pitch_bytes >= W * 4 && !(pitch_bytes & 3) &&
                            host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4) &&
                            hipHostGetDevicePointer(&host_alias, out_xrgb, 0) == hipSuccess && host_alias;
     if (!zero_copy) (void)hipGetLastError();
@@ -977,8 +986,8 @@ int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_li
     // written in full: every bin counts as held.
     void *canvas_alias = nullptr;
     mi355_ctx::Canvas *cv = nullptr;
-    if (canvas_wanted(c, mode, o, out_xrgb, pitch_bytes, rows, &canvas_alias))
-        if (int r = canvas_begin(c, o, out_xrgb, pitch_bytes, c->stream, &cv)) return r;
+    if (!wantf && canvas_wanted(c, mode, o, out_xrgb, pitch_bytes, rows, &canvas_alias))      // (the float buffer is not a canvas: its background is written in full)
+        if (int r = canvas_begin(c, mode, o, out_xrgb, pitch_bytes, c->stream, &cv)) return r;
     const bool keep = cv != nullptr;
     // (a frame into host memory: whoever keeps a canvas there knows nothing of it -- but the canvas this frame keeps)
     canvases_written(cv, out_xrgb, (size_t)pitch_bytes * (size_t)(rows > 0 ? rows - 1 : 0) + (size_t)W * 4);
@@ -986,8 +995,10 @@ int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_li
                (size_t)pitch_bytes * (size_t)(rows > 0 ? rows - 1 : 0) + (size_t)W * 4, (int)zero_copy, host_alias,
                (int)host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows > 0 ? rows - 1 : 0) + (size_t)W * 4), (void *)(wantf ? out_rgb_f32 : nullptr), wantf ? (size_t)W * rows * 12 : (size_t)0);
     FrameParams P;
+    if (keep) zero_copy = false;             // (the kept frame is written there too, but not all of it)
     if (int r = fill_params(c, mode, cam, lights, n_lights, o, zero_copy ? host_alias : keep ? canvas_alias : c->fb.p, zero_copy || keep ? pitch_bytes : W * 4, wantf ? c->fbf.p : nullptr, P)) return r;
-    if (keep) { P.canvas_keep = 1; P.canvas_prev = (const uint32_t *)cv->mask[cv->cur].p; P.canvas_next = (uint32_t *)cv->mask[cv->cur ^ 1].p; }
+    if (keep && mode >= MI355_MODE_RAYTRACE) { P.rt_keep_prev = (const uint32_t *)cv->mask[cv->cur].p; P.rt_keep_next = (uint32_t *)cv->mask[cv->cur ^ 1].p; }
+    else if (keep) { P.canvas_keep = 1; P.canvas_prev = (const uint32_t *)cv->mask[cv->cur].p; P.canvas_next = (uint32_t *)cv->mask[cv->cur ^ 1].p; }
     mi355_stats tmp;
     mi355_stats *st = stats ? stats : &tmp;
     P.no_pipe = 1;          // (a synchronous frame has nothing to overlap with: its kernels follow each other on the context's stream)
@@ -1071,12 +1082,13 @@ int mi355_render_async(mi355_ctx *c, int mode, const mi355_camera *cam, const mi
     void *canvas_alias = nullptr;
     mi355_ctx::Canvas *cv = nullptr;
     if (canvas_wanted(c, mode, o, out_xrgb, pitch_bytes, rows, &canvas_alias))
-        if (int r = canvas_begin(c, o, out_xrgb, pitch_bytes, a->st, &cv)) return r;
+        if (int r = canvas_begin(c, mode, o, out_xrgb, pitch_bytes, a->st, &cv)) return r;
     // (a frame on its way into host memory: any other kept canvas it touches is no longer what its masks say)
     canvases_written(cv, out_xrgb, (size_t)pitch_bytes * (size_t)(rows > 0 ? rows - 1 : 0) + (size_t)W * 4);
     FrameParams P;
     if (int r = fill_params(c, mode, cam, lights, n_lights, o, cv ? canvas_alias : a->fb.p, cv ? pitch_bytes : W * 4, nullptr, P, a->ctrl.p)) return r;
-    if (cv) { P.canvas_keep = 1; P.canvas_prev = (const uint32_t *)cv->mask[cv->cur].p; P.canvas_next = (uint32_t *)cv->mask[cv->cur ^ 1].p; }
+    if (cv && mode >= MI355_MODE_RAYTRACE) { P.rt_keep_prev = (const uint32_t *)cv->mask[cv->cur].p; P.rt_keep_next = (uint32_t *)cv->mask[cv->cur ^ 1].p; }
+    else if (cv) { P.canvas_keep = 1; P.canvas_prev = (const uint32_t *)cv->mask[cv->cur].p; P.canvas_next = (uint32_t *)cv->mask[cv->cur ^ 1].p; }
     HIP_TRY(hipEventRecord(a->ev0, a->st), -40);
     if (int r = enqueue_frame(c, mode, P, 0, a->st, a->ctrl.p, a->rs, &a->mlaa, nullptr, &a->sel)) return r;
     HIP_TRY(hipEventRecord(a->ev1, a->st), -40);

@@ -282,7 +282,7 @@ struct mi355_ctx {
     // before).  Any other frame into that memory -- whatever context or entry point it comes from -- and any buffer released make
     // the canvas unknown again.  N_CANVAS of them (the least recently used one goes): a ring of frames in flight has one per slot.
     struct Canvas {
-        uint32_t *host = nullptr; int W = 0, H = 0, pitch = 0, cur = 0; std::atomic<bool> valid{false}; DevBuf mask[2];
+        uint32_t *host = nullptr; int W = 0, H = 0, pitch = 0, cur = 0, kind = 0; std::atomic<bool> valid{false}; DevBuf mask[2];
         hipEvent_t ev = nullptr; bool ev_set = false; unsigned long long used = 0;
         // something else is written into [p, p + bytes) of host memory: the canvas is unknown if that touches it
         void written(const void *p, size_t bytes)

@@ -151,6 +151,11 @@ struct FrameParams {
     int32_t ao, ao_samples;    // AMBIENT_OCCLUSION, AMBIENT_SAMPLES
     float ao_range;            // AMBIENT_RANGE
     int32_t mlaa;              // MLAA post filter on the finished frame
+    // A raytraced frame into a canvas whose last frame is known (mi355_opts::keep_canvas; read by k_tile_select only): rt_keep_prev = the
+    // bit mask of the 8x8 tiles that frame traced -- black is written into those of them that are not traced now, nowhere else --,
+    // rt_keep_next = where this frame's mask goes; else NULL
+    const uint32_t *rt_keep_prev;
+    uint32_t *rt_keep_next;
 };
 
 enum CounterSlot {

@@ -1753,6 +1753,8 @@ k_tile_select(const FrameParams P, const float4 *boxes, int n_boxes, const uint3
     __syncthreads();
     // (the mask itself, for the waves of k_raytrace that write the background)
     if (blockIdx.y == 0 && gmask) for (uint32_t i = (uint32_t)tid; i < n_words; i += 1024u) gmask[(size_t)f * n_words + i] = mask[i];
+    // (... and for the next frame of a canvas that is kept, P.rt_keep_next: single frames)
+    if (blockIdx.y == 0 && P.rt_keep_next) for (uint32_t i = (uint32_t)tid; i < n_words; i += 1024u) P.rt_keep_next[i] = mask[i];
     if (blockIdx.y == 0) {
         // the tile order restricted to marked tiles, order kept.  In pieces of 32768 entries: a wave owns 2048 contiguous
         // entries of the piece, loads them at once (32 independent loads per lane: one memory latency, not 32), counts its
@@ -1799,8 +1801,10 @@ k_tile_select(const FrameParams P, const float4 *boxes, int n_boxes, const uint3
     }
     if (gmask) return;                              // (k_raytrace writes the background: its waves without pixels do)
     // the other tiles are black: a wave per pixel row, four pixels per lane and step (whole cache lines per wave)
+    // (a canvas whose last frame is known, P.rt_keep_prev: black already but for the tiles that frame traced)
     uint32_t *const out = batch ? P.cams[f].out : P.out;
     float *const outf = batch ? P.cams[f].outf : P.outf;
+    const uint32_t *const kept = P.rt_keep_prev;
     const bool vec = (P.pitch_words & 3) == 0 && (((size_t)out) & 15u) == 0;
     for (int r = (int)(blockIdx.y * 16u) + wid; r < P.n_rows; r += (int)(gridDim.y * 16u)) {
         const uint32_t trow = (uint32_t)(r >> 3) * (uint32_t)tiles_x;
@@ -1809,6 +1813,7 @@ k_tile_select(const FrameParams P, const float4 *boxes, int n_boxes, const uint3
         for (int x = lane * 4; x < P.W; x += 256) {
             const uint32_t t = trow + (uint32_t)(x >> 3);             // (four pixels from a multiple of four: one tile)
             if ((mask[t >> 5] >> (t & 31u)) & 1u) continue;
+            if (kept && !((kept[t >> 5] >> (t & 31u)) & 1u)) continue;
             if (vec && x + 3 < P.W) *(uint4 *)(orow + x) = make_uint4(0u, 0u, 0u, 0u);
             else for (int k = 0; k < 4 && x + k < P.W; k++) orow[x + k] = 0u;
             if (outf) {

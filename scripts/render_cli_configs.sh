@@ -9,7 +9,7 @@ run() { # label, args...
   a=$($CLI -b "$@" 2>&1 | grep Rendering | sed 's/.*(\(.*\) fps.*/\1/')
   b=$($CLI -b -p 1 "$@" 2>&1 | grep Rendering | sed 's/.*(\(.*\) fps.*/\1/')
   k=""
-  case "$*" in *"-m 6"*|*"-m 8"*)   # the rasterizer's rows also with --keep-canvas (Screen::_keepCanvas: frames cross PCIe only where they differ from the canvas's last)
+  case "$*" in *"-m 6"*|*"-m 8"*|*"-m 9"*)   # ... and with --keep-canvas (Screen::_keepCanvas: frames cross PCIe only where they differ from the canvas's last)
     c=$($CLI -b --keep-canvas "$@" 2>&1 | grep Rendering | sed 's/.*(\(.*\) fps.*/\1/')
     d=$($CLI -b -p 1 --keep-canvas "$@" 2>&1 | grep Rendering | sed 's/.*(\(.*\) fps.*/\1/')
     k=", \"fps_3_in_flight_keep_canvas\": $c, \"fps_reference_loop_keep_canvas\": $d";;

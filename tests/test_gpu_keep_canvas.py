@@ -266,6 +266,80 @@ def test_frames_in_flight_keep_their_canvases(scene):
             R.host_array_free(c)
 
 
+@pytest.fixture(scope="module")
+def ray_scene():
+    s = R.Scene(R.assets.mesh_path("dragon_vis.ply"))
+    s.bvh_create()
+    cam, lights, n = R.benchmark_frame(0)
+    s.shadowmap_render(0, lights[0])
+    return s
+
+
+@pytest.mark.parametrize("W,H", [(1920, 1080), (333, 217), (8, 8)])
+def test_raytraced_frames_keep_their_canvas(ray_scene, W, H):
+    """Modes 9 and 10 by 8x8 tile: the tiles a frame traces are written by their waves, black goes into those the canvas's last
+    frame traced; a rasterized frame in between changes what the masks mean (the frame behind it is written in full)."""
+    s = ray_scene
+    canvas = R.host_array((H, W))
+    try:
+        canvas[:] = GARBAGE
+        for i, k in enumerate((0, 1, 2, 60, 61, 150, 0, 3, 4, 5)):
+            mode = (9, 9, 9, 9, 10, 9, 6, 9, 9, 8)[i] if W < 1000 else (9, 9, 9, 9, 9, 9, 6, 9, 9, 9)[i]
+            kept(s, mode, k, canvas, W, H)
+            assert np.array_equal(canvas, plain(s, mode, k, W, H)), "frame %d mode %d" % (k, mode)
+        if W == 1920:
+            # (the promise: a corner tile neither frame traces is not written)
+            canvas[2, 3] = GARBAGE
+            kept(s, 9, 6, canvas, W, H)
+            assert canvas[2, 3] == GARBAGE
+            kept(s, 9, 7, canvas, W, H, keep=2)
+            assert np.array_equal(canvas, plain(s, 9, 7, W, H))
+            # (the exact box test only, tune flag 1: the tiles are culled all the same, the canvas is kept)
+            cam, lights, n = R.benchmark_frame(8)
+            s.render_into(9, cam, lights, n, R.default_opts(W, H, keep_canvas=1, tune=R.tune(exact=1)), canvas)
+            assert np.array_equal(canvas, plain(s, 9, 8, W, H))
+            # three in flight, a canvas each
+            ring = [canvas, R.host_array((H, W)), R.host_array((H, W))]
+            try:
+                o = R.default_opts(W, H, keep_canvas=1)
+                tickets, frame_of = [None] * 3, [0] * 3
+                for f in range(12):
+                    slot = f % 3
+                    if tickets[slot] is not None:
+                        s.render_wait(tickets[slot])
+                        assert np.array_equal(ring[slot], plain(s, 9, frame_of[slot], W, H)), "in flight, frame %d" % f
+                    cam, lights, n = R.benchmark_frame(11 * f)
+                    tickets[slot] = s.render_async(9, cam, lights, n, o, ring[slot])
+                    frame_of[slot] = 11 * f
+                for slot in range(3):
+                    s.render_wait(tickets[slot])
+                    assert np.array_equal(ring[slot], plain(s, 9, frame_of[slot], W, H))
+            finally:
+                for c in ring[1:]:
+                    R.host_array_free(c)
+    finally:
+        R.host_array_free(canvas)
+
+
+def test_raytraced_keep_is_ignored_where_tiles_are_not_culled(ray_scene):
+    """Counting frames, float output, the reference-order walk and every-tile frames (tune flags 4, 16): no tile mask, no kept
+    canvas -- complete frames all the same."""
+    s = ray_scene
+    W, H = 320, 240
+    canvas = R.host_array((H, W))
+    try:
+        kept(s, 9, 0, canvas, W, H)
+        for i, kw in enumerate((dict(tune=R.tune(reforder=1)), dict(tune=R.tune(nocull=1)), dict(collect_stats=1))):
+            cam, lights, n = R.benchmark_frame(10 + i)
+            canvas[1, 1] = GARBAGE
+            s.render_into(9, cam, lights, n, R.default_opts(W, H, keep_canvas=1, **kw), canvas)
+            assert np.array_equal(canvas, plain(s, 9, 10 + i, W, H)), str(kw)
+            kept(s, 9, 20 + i, canvas, W, H)
+            assert np.array_equal(canvas, plain(s, 9, 20 + i, W, H)), "behind " + str(kw)
+    finally:
+        R.host_array_free(canvas)
+
+
 def test_cxx_screen_keeps_its_canvas():
     """The host layer: Screen::_keepCanvas through Scene::renderPhong, ClearScreen() and touched() in between (render_cli
     --keep-canvas dumps the frames it presents)."""
@@ -274,9 +348,11 @@ def test_cxx_screen_keeps_its_canvas():
     mesh = R.assets.mesh_path("chessboard.tri")
     with tempfile.TemporaryDirectory() as d:
         outs = []
-        for i, flag in enumerate(([], ["--keep-canvas"], ["--keep-canvas", "-p", "3"])):
-            prefix = os.path.join(d, "run%d" % i)
-            subprocess.run([cli, "-b", "-n", "8", "-m", "6", "-W", "640", "-H", "360", "-o", prefix] + (flag if "-p" in flag else flag + ["-p", "1"]) + [mesh],
-                           check=True, capture_output=True)
-            outs.append([hashlib.sha256(open("%s_%04d.ppm" % (prefix, f), "rb").read()).hexdigest() for f in range(1, 9)])
-        assert outs[0] == outs[1] == outs[2]
+        for m in ("6", "9"):
+            outs = []
+            for i, flag in enumerate(([], ["--keep-canvas"], ["--keep-canvas", "-p", "3"])):
+                prefix = os.path.join(d, "run%s%d" % (m, i))
+                subprocess.run([cli, "-b", "-n", "8", "-m", m, "-W", "640", "-H", "360", "-o", prefix] + (flag if "-p" in flag else flag + ["-p", "1"]) + [mesh],
+                               check=True, capture_output=True)
+                outs.append([hashlib.sha256(open("%s_%04d.ppm" % (prefix, f), "rb").read()).hexdigest() for f in range(1, 9)])
+            assert outs[0] == outs[1] == outs[2], "mode " + m
