@@ -538,7 +538,7 @@ void mi355_scene_destroy(mi355_ctx *c)
     for (auto &o : c->orders) o.buf.release();
     for (auto &a : c->slot) {
         if (a.st) (void)hipStreamSynchronize(a.st);
-        a.ctrl.release(); a.fb.release(); a.mlaa.release(); a.sel.release(); a.pin.release();
+        a.ctrl.release(); a.fb.release(); a.mlaa.release(); a.sel.release(); a.pin.release(); a.pin_counters.release();
         if (a.rs) mi355i_raster_scratch_destroy(a.rs);
         if (a.ev0) (void)hipEventDestroy(a.ev0);
         if (a.ev1) (void)hipEventDestroy(a.ev1);
@@ -1092,6 +1092,10 @@ int mi355_render_async(mi355_ctx *c, int mode, const mi355_camera *cam, const mi
     HIP_TRY(hipEventRecord(a->ev0, a->st), -40);
     if (int r = enqueue_frame(c, mode, P, 0, a->st, a->ctrl.p, a->rs, &a->mlaa, nullptr, &a->sel)) return r;
     HIP_TRY(hipEventRecord(a->ev1, a->st), -40);
+    // (the counters travel behind the kernels, as for a synchronous frame: mi355_render_wait finds them in page-locked memory -- a
+    //  blocking hipMemcpy of its own was 20 us of every frame's wait)
+    HIP_TRY(a->pin_counters.ensure(sizeof(unsigned long long) * CS_COUNT), -31);
+    HIP_TRY(hipMemcpyAsync(a->pin_counters.p, (char *)a->ctrl.p + 16, sizeof(unsigned long long) * CS_COUNT, hipMemcpyDeviceToHost, a->st), -31);
     a->kept = cv;
     if (cv) { if (int r = canvas_done(c, cv, o, out_xrgb, pitch_bytes, a->st)) return r; }
     a->staged = !cv && !host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4);
@@ -1120,7 +1124,8 @@ int mi355_render_wait(mi355_ctx *c, int ticket, mi355_stats *stats)
     HIP_TRY(hipStreamSynchronize(a->st), -40);
     a->busy = false;
     unsigned long long h[CS_COUNT];
-    HIP_TRY(hipMemcpy(h, (char *)a->ctrl.p + 16, sizeof h, hipMemcpyDeviceToHost), -31);
+    if (a->pin_counters.p) memcpy(h, a->pin_counters.p, sizeof h);                         // (copied behind the frame's kernels)
+    else HIP_TRY(hipMemcpy(h, (char *)a->ctrl.p + 16, sizeof h, hipMemcpyDeviceToHost), -31);
     // (the frame has landed in host memory: see mi355_render_async.  A kept frame whose bins overflowed is drawn again below like any
     //  other -- into the slot's buffer, copied to the canvas in full --, and the canvas is no longer what its masks say)
     canvases_written(h[CS_OVERFLOW] ? nullptr : a->kept, a->user, (size_t)a->pitch_bytes * (size_t)(a->opts.height > 0 ? a->opts.height - 1 : 0) + (size_t)a->opts.width * 4);

@@ -264,6 +264,7 @@ struct mi355_ctx {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         DevBuf ctrl, fb, mlaa, sel;
         PinBuf pin;
+        PinBuf pin_counters;          // the frame's counters, copied behind its kernels (mi355_render_wait reads them without a transfer of its own)
         RasterScratch *rs = nullptr;
         bool busy = false, ready = false;   // ready: stream, events, control block and scratch all exist
         int ticket = 0, mode = 0, n_lights = 0, pitch_bytes = 0;
