@@ -1038,6 +1038,25 @@ def main():
                     for t in q:
                         scene.render_wait(t)
                     seam["host_path_fps"] = round(200 / (time.perf_counter() - t1), 1)
+                    # ... and the same two loops with mi355_opts::keep_canvas (the front-end's promise that only the render calls write into
+                    # its canvases, Screen::_keepCanvas): a frame crosses PCIe only in the 8x8 tiles that are traced now or were in the
+                    # canvas's last frame
+                    ok = R.default_opts(W, H, max_ray_depth=o1.max_ray_depth, keep_canvas=1)
+                    ok.tune[:] = list(o1.tune)
+                    for k in range(5):
+                        scene.render_into(args.mode, cams[k][0], cams[k][1], cams[k][2], ok, pinned[1])
+                    t1 = time.perf_counter()
+                    for k in range(200):
+                        scene.render_into(args.mode, cams[k][0], cams[k][1], cams[k][2], ok, pinned[1])
+                    seam["sync_host_keep_canvas_fps"] = round(200 / (time.perf_counter() - t1), 1)
+                    t1 = time.perf_counter(); q = []
+                    for k in range(200):
+                        if len(q) == depth:
+                            scene.render_wait(q.pop(0))
+                        q.append(scene.render_async(args.mode, cams[k][0], cams[k][1], cams[k][2], ok, hb[k % depth]))
+                    for t in q:
+                        scene.render_wait(t)
+                    seam["host_path_keep_canvas_fps"] = round(200 / (time.perf_counter() - t1), 1)
                 finally:
                     for b in pinned:
                         R.host_array_free(b)
@@ -1045,7 +1064,9 @@ def main():
                                 "the kernels themselves over PCIe, the background by the waves that have run out of pixels; sync_host_pageable_fps: the same "
                                 "call into pageable memory (kernel + 8.3 MB D2H); "
                                 "host_path_fps: the same frames through mi355_render_async / _wait, %d in flight on their own streams, into "
-                                "frame memory of the library's (mi355_host_alloc); single_frame_kernel_ms: hipEvent time of one frame's launch"
+                                "frame memory of the library's (mi355_host_alloc); *_keep_canvas_fps: the two loops with mi355_opts::keep_canvas = 1 "
+                                "(a canvas per frame in flight; written only where a frame can differ from the canvas's last); "
+                                "single_frame_kernel_ms: hipEvent time of one frame's launch"
                                 % depth)
                 result["seam"] = seam
                 extra["frame_by_frame_Mrays_per_s"] = round(float(sum(rays_f[k] for k in range(200) if rays_f[k] > 0)) / max(1, sum(1 for k in range(200) if rays_f[k] > 0)) * 200 / dt1 / 1e6, 1)

@@ -28,6 +28,7 @@ done
   echo "== scripts/raster_phases.py (the tile kernel's phases on counting frames; frames/s by threads per tile)"; timeout 100 python scripts/raster_phases.py 2>&1 | tail -14
   echo "== scripts/raytrace_frame_by_frame.py"; timeout 100 python scripts/raytrace_frame_by_frame.py 2>&1 | tail -8
   echo "== scripts/render_cli_configs.sh (render_cli -b, BASELINE.json's five configurations)"; timeout 200 bash scripts/render_cli_configs.sh 2>&1
+  echo "== scripts/keep_canvas_rate.py (mi355_opts::keep_canvas: the synchronous seam and three frames in flight with and without, render_cli -b [--keep-canvas])"; timeout 280 python scripts/keep_canvas_rate.py 1000 2>&1 | grep -v amdgpu.ids
   echo "== scripts/ubench/apicost (host cost of the HIP calls a frame makes)"; (hipcc -O2 --offload-arch=gfx950 -o /tmp/apicost scripts/ubench/apicost.hip && timeout 60 /tmp/apicost) 2>&1 | tail -14
 } > gpurun_out/misc_full.log 2>&1
 cat gpurun_out/misc_full.log
