@@ -546,7 +546,7 @@ void mi355_scene_destroy(mi355_ctx *c)
     }
     for (auto &h : c->host_reg) if (h.p) { const hipError_t ue = hipHostUnregister(h.p); host_trace("destroy ctx %p: unregister %p + %zu -> %d", (void *)c, (void *)h.p, h.bytes, (int)ue); }
     c->direct_ctrl.release(); c->direct_sel.release();
-    for (auto &cv : c->canvas) { cv.mask[0].release(); cv.mask[1].release(); if (cv.ev) (void)hipEventDestroy(cv.ev); }
+    for (auto &cv : c->canvas) { cv.mask[0].release(); cv.mask[1].release(); }     // (cv.ev is borrowed)
     if (c->ev_direct) (void)hipEventDestroy(c->ev_direct);
     if (c->rs_light) mi355i_raster_scratch_destroy(c->rs_light);
     if (c->ev_light) (void)hipEventDestroy(c->ev_light);
@@ -940,11 +940,13 @@ static int canvas_begin(mi355_ctx *c, int mode, const mi355_opts *o, uint32_t *o
 }
 
 // the frame's kernels are on `st`: the canvas holds it (in stream order), its masks have changed places
-static int canvas_done(mi355_ctx *c, mi355_ctx::Canvas *cv, const mi355_opts *o, uint32_t *out_xrgb, int pitch_bytes, hipStream_t st)
+// (`behind` = an event of the context's or of a slot's that has just been recorded behind those kernels -- an event record costs the
+//  host 5 us, a tenth of a kept raster frame in flight, so the canvas borrows it: if its owner records it again for a later frame, the
+//  canvas's next frame waits a little longer than it has to)
+static int canvas_done(mi355_ctx *c, mi355_ctx::Canvas *cv, hipEvent_t behind)
 {
-    if (!cv->ev) HIP_TRY(hipEventCreateWithFlags(&cv->ev, hipEventDisableTiming), -11);
-    HIP_TRY(hipEventRecord(cv->ev, st), -40);
-    cv->ev_set = true;
+    cv->ev = behind;
+    cv->ev_set = behind != nullptr;
     cv->cur ^= 1;
     cv->valid = true;
     return 0;
@@ -1024,7 +1026,7 @@ int mi355_render(mi355_ctx *c, int mode, const mi355_camera *cam, const mi355_li
         // (the frame is where it belongs; the stream has been synchronised)
     } else if (keep) {
         // (... and so is this one; the tile kernel has noted the bins it holds)
-        if (int r = canvas_done(c, cv, o, out_xrgb, pitch_bytes, c->stream)) return r;
+        if (int r = canvas_done(c, cv, c->ev1)) return r;
     } else if (pitch_bytes > 0 && host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4)) {
         // page-locked by the caller (mi355_host_register): one DMA transfer, no staging by the runtime
         HIP_TRY(hipMemcpy2DAsync(out_xrgb, (size_t)pitch_bytes, c->fb.p, (size_t)W * 4, (size_t)W * 4, (size_t)rows, hipMemcpyDeviceToHost, c->stream), -31);
@@ -1097,7 +1099,7 @@ int mi355_render_async(mi355_ctx *c, int mode, const mi355_camera *cam, const mi
     HIP_TRY(a->pin_counters.ensure(sizeof(unsigned long long) * CS_COUNT), -31);
     HIP_TRY(hipMemcpyAsync(a->pin_counters.p, (char *)a->ctrl.p + 16, sizeof(unsigned long long) * CS_COUNT, hipMemcpyDeviceToHost, a->st), -31);
     a->kept = cv;
-    if (cv) { if (int r = canvas_done(c, cv, o, out_xrgb, pitch_bytes, a->st)) return r; }
+    if (cv) { if (int r = canvas_done(c, cv, a->ev1)) return r; }
     a->staged = !cv && !host_range_registered(c, out_xrgb, (size_t)pitch_bytes * (size_t)(rows - 1) + (size_t)W * 4);
     host_trace("render_async ctx %p mode %d %dx%d: out %p + %zu staged %d", (void *)c, mode, W, o->height, (void *)out_xrgb, (size_t)pitch_bytes * (size_t)(rows > 0 ? rows - 1 : 0) + (size_t)W * 4, (int)a->staged);
     if (cv) {

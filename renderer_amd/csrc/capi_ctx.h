@@ -279,8 +279,8 @@ struct mi355_ctx {
     // Canvases whose last frame is known (mi355_opts::keep_canvas; mi355_render, mi355_render_async): the raster kernels write a
     // frame straight into the caller's page-locked memory and only into the 64x64-pixel bins that hold pixels of this frame or held
     // pixels of the one before (mask[cur]: a word per bin, written by the tile kernel of that frame; the next frame writes
-    // mask[cur ^ 1]).  ev = the last kept frame's kernels (frames of one canvas may run on different streams: each follows the one
-    // before).  Any other frame into that memory -- whatever context or entry point it comes from -- and any buffer released make
+    // mask[cur ^ 1]).  ev = an event behind the last kept frame's kernels, borrowed from the context or the slot that ran it (frames of
+    // one canvas may run on different streams: each follows the one before).  Any other frame into that memory -- whatever context or entry point it comes from -- and any buffer released make
     // the canvas unknown again.  N_CANVAS of them (the least recently used one goes): a ring of frames in flight has one per slot.
     struct Canvas {
         uint32_t *host = nullptr; int W = 0, H = 0, pitch = 0, cur = 0, kind = 0; std::atomic<bool> valid{false}; DevBuf mask[2];
