@@ -1185,7 +1185,7 @@ def main():
                     row = {"config": label}
                     # (--keep-canvas: Screen::_keepCanvas, the front-end's promise that only Scene::render* writes into its canvases -- as
                     #  renderer.cc's loop does --: raster frames then cross PCIe only where they differ from the canvas's last frame)
-                    kept = (("fps_3_in_flight_keep_canvas", ["--keep-canvas"]), ("fps_reference_loop_keep_canvas", ["-p", "1", "--keep-canvas"])) if "-m 2" not in label else ()
+                    kept = (("fps_in_flight_keep_canvas", ["--keep-canvas"]), ("fps_reference_loop_keep_canvas", ["-p", "1", "--keep-canvas"])) if "-m 2" not in label else ()
                     for key, pre in (("fps_3_in_flight", []), ("fps_reference_loop", ["-p", "1"])) + kept:
                         try:
                             out = subprocess.run([cli, "-b"] + pre + a[:-1] + [os.path.join(md, a[-1])], capture_output=True, text=True, timeout=60,
@@ -1198,7 +1198,7 @@ def main():
                     rows.append(row)
                 extra["render_cli_bench"] = {"rows": rows, "note": "render_cli -b: fps_3_in_flight = its default for -b (the cameras are known: three "
                                              "frames in flight through Scene::renderAsync); fps_reference_loop = -p 1, one synchronous Scene::render* per "
-                                             "pass like renderer.cc:481-520, rate = frames / time inside the calls; *_keep_canvas (every row but the points): the "
+                                             "pass like renderer.cc:481-520, rate = frames / time inside the calls; *_keep_canvas (every row but the points; in flight: render_cli's default with --keep-canvas, four frames for the rasterizer, three for the raytracer): the "
                                              "same runs with --keep-canvas (mi355_opts::keep_canvas: the kernels write a frame straight into the page-locked "
                                              "canvas and only where it can differ from the canvas's last frame -- the rasterizer's 64x64-pixel bins that hold triangles now or held some then, the raytracer's 8x8-pixel tiles that are traced now or were then)"}
             # BVH build of the benchmark mesh: GPU level kernels + download + flatten, host builder beside it

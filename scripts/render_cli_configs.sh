@@ -12,7 +12,7 @@ run() { # label, args...
   case "$*" in *"-m 6"*|*"-m 8"*|*"-m 9"*)   # ... and with --keep-canvas (Screen::_keepCanvas: frames cross PCIe only where they differ from the canvas's last)
     c=$($CLI -b --keep-canvas "$@" 2>&1 | grep Rendering | sed 's/.*(\(.*\) fps.*/\1/')
     d=$($CLI -b -p 1 --keep-canvas "$@" 2>&1 | grep Rendering | sed 's/.*(\(.*\) fps.*/\1/')
-    k=", \"fps_3_in_flight_keep_canvas\": $c, \"fps_reference_loop_keep_canvas\": $d";;
+    k=", \"fps_in_flight_keep_canvas\": $c, \"fps_reference_loop_keep_canvas\": $d";;
   esac
   echo "{\"config\": \"$label\", \"fps_3_in_flight\": $a, \"fps_reference_loop\": $b$k}"
 }
