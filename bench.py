@@ -739,8 +739,12 @@ def main():
                 kind_r = mg["value_from"] if (mg["value_from"] != "spread" or r_B % world == 0) else "rank0"
                 g_r = (multigpu.SpreadAssembler(r_W, r_H, dev, frames=r_B, staged=dry) if kind_r == "spread" else
                        multigpu.FrameGatherer(r_W, r_H, dev, frames=r_B, staged=dry))
+                trace = (lambda *a: print("[trace rank %d]" % rank, *a, file=sys.stderr, flush=True)) if os.environ.get("MI355_BENCH_TRACE") else (lambda *a: None)
+                trace("raster region: scene")
                 rsc = R.Scene(R.assets.mesh_path("chessboard.tri"), device=local_rank)
                 rsc.shadowmap_render(0, cams[0][1][0])
+                torch.cuda.synchronize(dev)
+                trace("raster region: scene + shadow map done")
                 ras = {"step": "%d frames of %dx%d (8 per GPU), bands x%d, one exchange per step" % (r_B, r_W, r_H, world), "assembly": kind_r}
                 for r_mode, r_name in ((6, "phong"), (8, "softshadow")):
                     o_r = R.default_opts(r_W, r_H, tune=json.loads(args.tune))
@@ -749,9 +753,13 @@ def main():
                     def rstep(k, slot, r_mode=r_mode, o_r=o_r):
                         fs = [(k * r_B + j) % N_CAMS for j in range(r_B)]
                         buf = g_r.send_buffer(slot)
+                        trace("mode", r_mode, "step", k, "render")
                         rsc.render_batch_device(r_mode, [cams[f][0] for f in fs], [cams[f][1] for f in fs], cams[fs[0]][2], o_r,
                                                 [buf[g_r.slot_of_frame(j) if kind_r == "spread" else j].data_ptr() for j in range(r_B)], r_W * 4, None,
                                                 stream.cuda_stream)
+                        if os.environ.get("MI355_BENCH_TRACE"):
+                            torch.cuda.synchronize(dev)
+                            trace("mode", r_mode, "step", k, "rendered; exchange")
                         g_r.gather(slot)
                     for k in range(3):
                         rstep(k, k & 1)
@@ -765,12 +773,16 @@ def main():
                     torch.cuda.synchronize(dev); barrier(); torch.cuda.synchronize(dev)
                     t_r = all_reduce([time.perf_counter() - t1], "max")[0]
                     pins_r = frame_pins("chessboard.tri", r_mode, r_W, r_H, 3)
+                    trace("mode", r_mode, "timed steps done; verify")
                     rc, rb = verify_assembled(g_r, kind_r, rstep, r_B, pins_r) if pins_r else (0, 0)
+                    trace("mode", r_mode, "verified")
                     ras[r_name] = {"mode": r_mode, "steps": n_r, "ms_per_step": round(t_r * 1e3 / n_r, 4), "frames_per_sec": round(n_r * r_B / t_r, 1),
                                    "assembled_sha": {"checked": rc, "differ": rb, "pinned_frames": sorted(pins_r)}}
                     mg["assembled_sha"]["raster_" + r_name] = {"checked": rc, "differ": rb}
                 mg["raster_1080p"] = ras
+                trace("raster region: releasing")
                 del g_r, rsc
+                trace("raster region: released")
             except Exception as e:      # (a secondary region must not take the headline with it -- but its hashes, if it got that far, still count)
                 mg["raster_1080p"] = {"error": str(e)}
         # one verdict over every assembly that was checked: a frame that differs anywhere voids the line's `value`

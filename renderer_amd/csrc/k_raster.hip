@@ -385,6 +385,16 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
 // OCC = waves per SIMD the registers are allotted for: 4 (125 registers, no scratch) is the faster build for a single frame -- a
 // tile's chain of phases is what a frame waits for --, 5 (96 registers, 64-76 bytes of scratch) for a batch of frames, where one
 // more tile per CU in flight is worth more (measured both ways, profiles/r03_analysis.md).
+// The tile kernel's build for batches of frames: 4 = the single frames' build (125 registers, no scratch).  Rounds 3-6 used 5 (96 registers
+// + 52-64 B of scratch per lane: one more tile per CU in flight, +x % for batches) -- until round 6's last evidence runs: with EIGHT processes
+// on one GPU (bench.py --gpus 8 --dry-run) a rank died of a GPU memory fault ("Memory access fault ... Reason: Unknown", once
+// HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION) in 6 of 74 runs, always inside the rasterizer's region of 64-frame batches, with this
+// round's library and with round 5's alike; with the scratch-free build 0 of 36 (profiles/r06_analysis.md 10).  Nothing in the kernel's
+// own addressing was found wrong (single-process fuzzers and 85 full-suite runs never faulted); a build that needs no scratch memory
+// does not depend on how the runtime hands it out.  (-DRS_BATCH_OCC=5 builds the old one.)
+#ifndef RS_BATCH_OCC
+#define RS_BATCH_OCC 4
+#endif
 template <int MODE, int OCC>
 // (Round 6: fewer registers for the four-wave build, so that a wave of the next frame's setup or fill kernel fits a SIMD beside four
 //  tile waves -- 4 x 120 of 512 leave 32, the fill kernel needs 40 --: the compiler has no handle for it; amdgpu_num_vgpr is ignored
@@ -1110,7 +1120,7 @@ static hipError_t raster_frames(const DevScene *S, const FrameParams *P, const F
     const int nt = P->rs_threads >= 64 && P->rs_threads <= RS_MAX_THREADS && (P->rs_threads & 63) == 0 ? P->rs_threads : 256;
     // (the five-wave build for single overlapped frames, measured again in round 6 with the shorter items: 27.2 k frames/s against 29.1 k)
     if (whole) hipExtLaunchKernelGGL((k_rs_tile<MODE, 4>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, nullptr, tile_done, 0, *S, *P, d_batch, n_frames, g, s->B, 1);
-    else if (n_frames > 1) hipLaunchKernelGGL((k_rs_tile<MODE, 5>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B, 0);
+    else if (n_frames > 1) hipLaunchKernelGGL((k_rs_tile<MODE, RS_BATCH_OCC>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B, 0);
     else hipLaunchKernelGGL((k_rs_tile<MODE, 4>), dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3((unsigned)nt), 0, st, *S, *P, d_batch, n_frames, g, s->B, kept ? 1 : 0);
     mi355i_prof_lap(4);
     return hipGetLastError();

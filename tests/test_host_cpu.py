@@ -52,6 +52,31 @@ def test_struct_sizes_match_header():
     assert C.sizeof(R.SceneDesc) == 8 + 11 * 8
 
 
+def test_struct_field_offsets_match_header(tmp_path):
+    """Every field of the ctypes mirrors lies where the C compiler puts the header's field of the same name (a field added to
+    mi355_opts -- keep_canvas took a reserved word in round 6 -- must not shift its neighbours in one of the two)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no C compiler")
+    structs = (("mi355_opts", R.Opts), ("mi355_camera", R.Camera), ("mi355_light", R.Light), ("mi355_stats", R.Stats))
+    src = ['#include <stddef.h>', '#include <stdio.h>', '#include "mi355_render.h"', 'int main(void) {']
+    for cname, T in structs:
+        src.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f in T._fields_:
+            src.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f[0], cname, f[0]))
+    src += ['return 0;', '}']
+    c = tmp_path / "offsets.c"
+    c.write_text("\n".join(src))
+    exe = str(tmp_path / "offsets")
+    subprocess.run(["gcc", "-I", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include"), str(c), "-o", exe], check=True)
+    got = dict(l.split() for l in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, T in structs:
+        assert int(got[cname]) == C.sizeof(T), cname
+        for f in T._fields_:
+            assert int(got["%s.%s" % (cname, f[0])]) == getattr(T, f[0]).offset, "%s.%s" % (cname, f[0])
+
+
 def test_no_gpu_means_loud_failure():
     """Without a GPU the library must refuse to render: there is no CPU fallback."""
     if R.device_count() > 0:
