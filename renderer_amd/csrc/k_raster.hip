@@ -389,9 +389,9 @@ __global__ void __launch_bounds__(256) k_rs_fill(const RsGrid g, const RsBuffers
 // + 52-64 B of scratch per lane: one more tile per CU in flight, +x % for batches) -- until round 6's last evidence runs: with EIGHT processes
 // on one GPU (bench.py --gpus 8 --dry-run) a rank died of a GPU memory fault ("Memory access fault ... Reason: Unknown", once
 // HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION) in 6 of 74 runs, always inside the rasterizer's region of 64-frame batches, with this
-// round's library and with round 5's alike; with the scratch-free build 0 of 36 (profiles/r06_analysis.md 10).  Nothing in the kernel's
-// own addressing was found wrong (single-process fuzzers and 85 full-suite runs never faulted); a build that needs no scratch memory
-// does not depend on how the runtime hands it out.  (-DRS_BATCH_OCC=5 builds the old one.)
+// round's library and with round 5's alike; with the scratch-free build 1 of 77 (profiles/r06_analysis.md 10): rarer, not gone, cause
+// not found.  Nothing in the kernel's own addressing was found wrong (single-process fuzzers, 85 full-suite runs and the same batches
+// from 1 / 2 / 4 / 8 processes by themselves never faulted).  (-DRS_BATCH_OCC=5 builds the old one.)
 #ifndef RS_BATCH_OCC
 #define RS_BATCH_OCC 4
 #endif
