@@ -312,6 +312,14 @@ def main():
     dry = bool(args.dry_run and world > 1)
     if dry:
         local_rank = 0                       # every rank plays its part on the one GPU there is
+        # N processes on one GPU oversubscribe its queues, and on this stack a kernel that needs scratch memory then now and again dies
+        # of a memory fault (profiles/r06_analysis.md 10: 6 of 74 N = 8 dry runs while the rasterizer's batches took a build with scratch).
+        # The dry run is a check of the script path, not of the schedule: its raytraced launches take the three-wave build (no scratch,
+        # same pixels -- the line hashes them) unless --tune says otherwise.
+        t_dry = dict(json.loads(args.tune))
+        if "bpc" not in t_dry:
+            t_dry["bpc"] = 3
+            args.tune = json.dumps(t_dry)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -575,7 +583,7 @@ def main():
     mg = None
     if world > 1:
         mg = {"transport": "dryrun: %d ranks on ONE GPU (cuda:0), exchange staged through host memory over gloo -- exercises the N > 1 "
-                           "script path, measures nothing about scaling" % world if dry else "rccl (torch.distributed backend nccl = RCCL over xGMI)",
+                           "script path, measures nothing about scaling; raytraced launches on the three-wave build (no scratch memory: N processes oversubscribe the one GPU's queues)" % world if dry else "rccl (torch.distributed backend nccl = RCCL over xGMI)",
               "sharding": ("whole frames: rank r renders every %d-th frame of a step" % world if by_frames else
                            "interleaved %d-scanline bands: band b -> rank b %% %d, compact [frames][rows][W] buffers" % (multigpu.BAND_ROWS, world)),
               "step": "%d frames of %dx%d" % (B, W, H)}
